@@ -1,0 +1,126 @@
+"""Generates tests/golden/*.npz from the CPU oracle (TEST INFRASTRUCTURE ONLY).
+
+Run from the repo root:  python oracle/make_golden.py
+The reference (Wolfram Language) cannot run here, so these vectors come from the oracle after it
+has been pinned by closed forms, the MVN second formulation and mpmath (tests/test_oracle.py).
+Fixtures: F1 cfg-1 (N=512,d=1,SE); F2 N=256,d=8 SE-ARD + Matern-5/2-ARD;
+F3 scalars only for N=2048/4096/8192 (data regenerated from the seeded generator, checksummed);
+F4 sentinel cases; HP mpmath 50-digit values for N=24/48.
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from bayesianinference_amd import synthetic as syn  # noqa: E402
+from oracle import gp_oracle as orc  # noqa: E402
+from oracle import hp_oracle as hp  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def _evaluate(kernel, thetas, X, y, Xs, mean="zero", npred=4):
+    ll, ld, qd, info = [], [], [], []
+    for th in thetas:
+        a, b, c, i = orc.log_likelihood(kernel, th, X, y, mean, parts=True)
+        ll.append(a), ld.append(b), qd.append(c), info.append(i)
+    mu, sd = [], []
+    for th in thetas[:npred]:
+        m, s = orc.predict_internal(kernel, th, X, y, Xs, mean)
+        mu.append(m), sd.append(s)
+    return dict(loglik=np.array(ll), logdet=np.array(ld), quad=np.array(qd), info=np.array(info),
+                pred_mu=np.array(mu), pred_sd=np.array(sd))
+
+
+def f1():
+    X, y = syn.make_dataset(512, 1)
+    Xs = np.linspace(-1.2, 1.2, 64)[:, None]
+    thetas = syn.theta_batch(16, "se", 1)
+    thetas[0] = syn.default_theta("se", 1)
+    thetas[:, 2] = np.maximum(thetas[:, 2], 0.05)       # keep cond(K) <= ~1e8 for the parity bar
+    res = _evaluate("se", thetas, X, y, Xs)
+    np.savez_compressed(os.path.join(OUT, "f1_se_n512_d1.npz"), X=X, y=y, Xs=Xs, thetas=thetas,
+                        kernel="se", mean="zero", **res)
+
+
+def f2():
+    X, y = syn.make_dataset(256, 8)
+    Xs = syn.make_test_points(64, 8)
+    for kernel in ("se_ard", "matern52_ard"):
+        thetas = syn.theta_batch(16, kernel, 8)
+        thetas[0] = syn.default_theta(kernel, 8)
+        thetas[:, -1] = np.maximum(thetas[:, -1], 0.05)
+        res = _evaluate(kernel, thetas, X, y, Xs)
+        np.savez_compressed(os.path.join(OUT, f"f2_{kernel}_n256_d8.npz"), X=X, y=y, Xs=Xs,
+                            thetas=thetas, kernel=kernel, mean="zero", **res)
+    # constant-mean variant + isotropic matern, ragged N (not a multiple of the 128 tile)
+    X, y = syn.make_dataset(333, 3)
+    Xs = syn.make_test_points(17, 3)
+    thetas = np.column_stack([syn.theta_batch(8, "matern52", 3), np.linspace(-0.5, 0.5, 8)])
+    thetas[:, 2] = np.maximum(thetas[:, 2], 0.05)
+    res = _evaluate("matern52", thetas, X, y, Xs, mean="const")
+    np.savez_compressed(os.path.join(OUT, "f2_matern52_const_n333_d3.npz"), X=X, y=y, Xs=Xs,
+                        thetas=thetas, kernel="matern52", mean="const", **res)
+
+
+def f3():
+    rows = []
+    for n, kernel in ((2048, "se_ard"), (4096, "se_ard"), (8192, "se_ard"), (2048, "matern52_ard")):
+        X, y = syn.make_dataset(n, 8)
+        th = syn.default_theta(kernel, 8)
+        ll, ld, qd, info = orc.log_likelihood(kernel, th, X, y, parts=True)
+        rows.append((n, 8, kernel, float(X.sum()), float(y.sum()), ll, ld, qd, info))
+        print("F3", rows[-1])
+    np.savez_compressed(
+        os.path.join(OUT, "f3_scalars.npz"),
+        n=np.array([r[0] for r in rows]), d=np.array([r[1] for r in rows]),
+        kernel=np.array([r[2] for r in rows]),
+        xsum=np.array([r[3] for r in rows]), ysum=np.array([r[4] for r in rows]),
+        loglik=np.array([r[5] for r in rows]), logdet=np.array([r[6] for r in rows]),
+        quad=np.array([r[7] for r in rows]), info=np.array([r[8] for r in rows]))
+
+
+def f4():
+    # duplicate rows + zero nugget -> singular; sigma_n = 1e-12 -> hopelessly ill-conditioned
+    X, y = syn.make_dataset(64, 2)
+    Xd = X.copy()
+    Xd[17] = Xd[3]
+    cases = dict(
+        dup_X=Xd, dup_y=y, dup_theta=np.array([1.0, 1.0, 1.0, 0.0]),
+        ill_X=X, ill_y=y, ill_theta=np.array([5.0, 5.0, 1.0, 1e-12]),
+        ok_X=X, ok_y=y, ok_theta=np.array([0.5, 0.7, 1.3, 0.2]))
+    out = {}
+    for name in ("dup", "ill", "ok"):
+        ll, ld, qd, info = orc.log_likelihood("se_ard", cases[f"{name}_theta"], cases[f"{name}_X"],
+                                              cases[f"{name}_y"], parts=True)
+        out[f"{name}_loglik"], out[f"{name}_info"] = ll, info
+        print("F4", name, ll, info)
+    np.savez_compressed(os.path.join(OUT, "f4_sentinel.npz"), kernel="se_ard", **cases, **out)
+
+
+def fhp():
+    out = {}
+    for n, d, kernel in ((24, 2, "se_ard"), (48, 3, "matern52_ard"), (32, 1, "se")):
+        X, y = syn.make_dataset(n, d)
+        Xs = syn.make_test_points(5, d)
+        th = syn.default_theta(kernel, d)
+        th[-1] = 0.2
+        ll, ld, qd = hp.log_likelihood(kernel, th, X.tolist(), y.tolist())
+        mu, sd = hp.predict(kernel, th, X.tolist(), y.tolist(), Xs.tolist())
+        key = f"{kernel}_n{n}"
+        out.update({f"{key}_X": X, f"{key}_y": y, f"{key}_Xs": Xs, f"{key}_theta": th,
+                    f"{key}_loglik": ll, f"{key}_logdet": ld, f"{key}_quad": qd,
+                    f"{key}_mu": np.array(mu), f"{key}_sd": np.array(sd)})
+        print("HP", key, ll)
+    np.savez_compressed(os.path.join(OUT, "hp_mpmath.npz"), **out)
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    f1(), f2(), f4(), fhp(), f3()
+    print("golden fixtures written to", OUT)
