@@ -1,0 +1,214 @@
+"""ctypes binding of the C ABI in include/gphip.h (the drop-in boundary).
+
+The library is the product: there is no CPU fallback.  If `libgphip.so` is missing or no gfx950
+device is visible, every compute entry point raises `GphipError` loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+
+import numpy as np
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG, "lib", "libgphip.so")
+HEADER = os.path.join(os.path.dirname(PKG), "include", "gphip.h")
+
+OK = 0
+INFO_OK, INFO_NOT_SPD, INFO_NAN = 0, 1, 2
+KERNEL_IDS = {"se": 0, "se_ard": 1, "matern52": 2, "matern52_ard": 3, "null": 4}
+MEAN_IDS = {"zero": 0, "const": 1}
+PROFILE_CLASSES = ("kbuild", "potrf", "trsm", "gemm_panel", "syrk_trailing", "eval_total")
+
+_STATUS = {1: "bad argument", 2: "dimension mismatch", 3: "HIP runtime failure",
+           4: "handle not fitted", 5: "no gfx950 device", 6: "unsupported"}
+
+
+class GphipError(RuntimeError):
+    def __init__(self, status: int, msg: str = ""):
+        self.status = status
+        super().__init__(f"gphip status {status} ({_STATUS.get(status, '?')}): {msg}")
+
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+_h = C.c_void_p
+
+_SIGNATURES = {
+    "gphip_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int,
+                               _ip, C.c_int, C.POINTER(_h)]),
+    "gphip_destroy": (C.c_int, [_h]),
+    "gphip_num_params": (C.c_int, [_h, _ip]),
+    "gphip_loglik": (C.c_int, [_h, _dp, C.c_int, _dp, _ip]),
+    "gphip_loglik_batch": (C.c_int, [_h, _dp, C.c_int, C.c_int, _dp, _ip]),
+    "gphip_loglik_parts": (C.c_int, [_h, _dp, C.c_int, _dp, _dp, _ip]),
+    "gphip_fit": (C.c_int, [_h, _dp, C.c_int, _ip]),
+    "gphip_predict": (C.c_int, [_h, C.c_void_p, C.c_int64, _dp, _dp]),
+    "gphip_covariance": (C.c_int, [_h, _dp, C.c_int, _dp]),
+    "gphip_solve": (C.c_int, [_h, _dp, C.c_int64, _dp]),
+    "gphip_logdet": (C.c_int, [_h, _dp]),
+    "gphip_set_option": (C.c_int, [_h, C.c_char_p, C.c_double]),
+    "gphip_get_profile": (C.c_int, [_h, C.c_int, _dp, _dp, _dp, _dp]),
+    "gphip_reset_profile": (C.c_int, [_h]),
+    "gphip_sync": (C.c_int, [_h]),
+    "gphip_last_error": (C.c_char_p, [_h]),
+    "gphip_version": (C.c_char_p, []),
+    "gphip_device_count": (C.c_int, [_ip]),
+}
+
+_lib = None
+
+
+def declared_symbols() -> list[str]:
+    """Every function name include/gphip.h declares (used by the symbol-export test)."""
+    with open(HEADER) as f:
+        text = f.read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(gphip_[a-z_]+)\s*\(", text)))
+
+
+def load():
+    """dlopen the in-tree library (built by `python -m bayesianinference_amd.build`)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GphipError(3, f"{LIB_PATH} is missing -- run `python -m bayesianinference_amd.build` "
+                            "(hipcc, gfx950).  There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    load().gphip_device_count(C.byref(n))
+    return n.value
+
+
+def _d(a: np.ndarray):
+    return a.ctypes.data_as(_dp)
+
+
+class Handle:
+    """Owns one gphip_handle: training data resident on the device (gphip_create .. gphip_destroy)."""
+
+    def __init__(self, X, y, kernel: str = "se_ard", mean: str = "zero", dtype: int = 64, device=None):
+        lib = load()
+        X = np.ascontiguousarray(np.atleast_2d(np.asarray(X, dtype=np.float64)))
+        y = np.ascontiguousarray(np.asarray(y, dtype=np.float64).ravel())
+        if X.shape[0] != y.shape[0]:
+            raise GphipError(2, "Input and output data are not of same length")     # BGP:251-253
+        if kernel not in KERNEL_IDS or mean not in MEAN_IDS:
+            raise GphipError(1, f"unknown kernel/mean {kernel!r}/{mean!r}")
+        self.N, self.d = X.shape
+        self.kernel, self.mean = kernel, mean
+        self._lib = lib
+        self._h = _h()
+        devs, nd = (None, 0)
+        if device is not None:
+            arr = (C.c_int * 1)(int(device))
+            devs, nd = arr, 1
+        rc = lib.gphip_create(X.ctypes.data, y.ctypes.data, self.N, self.d, KERNEL_IDS[kernel],
+                              MEAN_IDS[mean], dtype, devs, nd, C.byref(self._h))
+        if rc != OK:
+            self._h = None
+            raise GphipError(rc, "gphip_create failed (is a gfx950 GPU visible?)")
+        p = C.c_int(0)
+        lib.gphip_num_params(self._h, C.byref(p))
+        self.p = p.value
+
+    # -- helpers -------------------------------------------------------------------------
+    def _check(self, rc: int):
+        if rc != OK:
+            raise GphipError(rc, (self._lib.gphip_last_error(self._h) or b"").decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.gphip_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_option(self, name: str, value: float):
+        self._check(self._lib.gphip_set_option(self._h, name.encode(), float(value)))
+
+    # -- hot path ------------------------------------------------------------------------
+    def loglik(self, theta):
+        th = np.ascontiguousarray(np.asarray(theta, dtype=np.float64).ravel())
+        out, info = C.c_double(0.0), C.c_int(0)
+        self._check(self._lib.gphip_loglik(self._h, _d(th), th.size, C.byref(out), C.byref(info)))
+        return out.value, info.value
+
+    def loglik_parts(self, theta):
+        th = np.ascontiguousarray(np.asarray(theta, dtype=np.float64).ravel())
+        out, info = C.c_double(0.0), C.c_int(0)
+        parts = np.zeros(2)
+        self._check(self._lib.gphip_loglik_parts(self._h, _d(th), th.size, C.byref(out), _d(parts),
+                                                 C.byref(info)))
+        return out.value, parts[0], parts[1], info.value
+
+    def loglik_batch(self, Theta):
+        Th = np.ascontiguousarray(np.atleast_2d(np.asarray(Theta, dtype=np.float64)))
+        B, p = Th.shape
+        out = np.zeros(B)
+        info = np.zeros(B, dtype=np.int32)
+        self._check(self._lib.gphip_loglik_batch(self._h, _d(Th), B, p, _d(out), info.ctypes.data_as(_ip)))
+        return out, info
+
+    def fit(self, theta) -> int:
+        th = np.ascontiguousarray(np.asarray(theta, dtype=np.float64).ravel())
+        info = C.c_int(0)
+        self._check(self._lib.gphip_fit(self._h, _d(th), th.size, C.byref(info)))
+        return info.value
+
+    def predict(self, Xs):
+        Xs = np.ascontiguousarray(np.atleast_2d(np.asarray(Xs, dtype=np.float64)))
+        if Xs.shape[1] != self.d:
+            raise GphipError(2, "test points have the wrong dimension")
+        M = Xs.shape[0]
+        mean, var = np.zeros(M), np.zeros(M)
+        self._check(self._lib.gphip_predict(self._h, Xs.ctypes.data, M, _d(mean), _d(var)))
+        return mean, var
+
+    def covariance(self, theta):
+        th = np.ascontiguousarray(np.asarray(theta, dtype=np.float64).ravel())
+        K = np.zeros((self.N, self.N))
+        self._check(self._lib.gphip_covariance(self._h, _d(th), th.size, _d(K)))
+        return K
+
+    def solve(self, rhs):
+        rhs = np.asarray(rhs, dtype=np.float64)
+        vec = rhs.ndim == 1
+        B = np.ascontiguousarray(rhs.reshape(self.N, -1).T)      # each rhs contiguous
+        out = np.zeros_like(B)
+        self._check(self._lib.gphip_solve(self._h, _d(B), B.shape[0], _d(out)))
+        return out[0] if vec else out.T.copy()
+
+    def logdet(self) -> float:
+        out = C.c_double(0.0)
+        self._check(self._lib.gphip_logdet(self._h, C.byref(out)))
+        return out.value
+
+    # -- measurement ---------------------------------------------------------------------
+    def reset_profile(self):
+        self._check(self._lib.gphip_reset_profile(self._h))
+
+    def profile(self) -> dict:
+        res = {}
+        for i, name in enumerate(PROFILE_CLASSES):
+            v = [C.c_double(0.0) for _ in range(4)]
+            self._check(self._lib.gphip_get_profile(self._h, i, *[C.byref(x) for x in v]))
+            res[name] = dict(ms=v[0].value, launches=v[1].value, flops=v[2].value, bytes=v[3].value)
+        return res
+
+    def sync(self):
+        self._check(self._lib.gphip_sync(self._h))

@@ -1,0 +1,49 @@
+"""Builds the in-tree HIP shared library (gfx950 only) with hipcc.
+
+    python -m bayesianinference_amd.build          # -> bayesianinference_amd/lib/libgphip.so
+hipcc cross-compiles without a GPU; the built .so travels to the GPU box with the snapshot.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(PKG, "csrc", "gphip.hip")
+DEPS = [SRC, os.path.join(PKG, "csrc", "gp_kernels.h"),
+        os.path.join(os.path.dirname(PKG), "include", "gphip.h")]
+LIB = os.path.join(PKG, "lib", "libgphip.so")
+
+
+def hipcc_path() -> str:
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: cannot build libgphip.so (ROCm >= 7.0 required)")
+
+
+def needs_build() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(p) > t for p in DEPS if os.path.exists(p))
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    if not force and not needs_build():
+        return LIB
+    os.makedirs(os.path.dirname(LIB), exist_ok=True)
+    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+           "-Wall", "-Wno-unused-function", "-o", LIB, SRC]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

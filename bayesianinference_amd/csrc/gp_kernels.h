@@ -1,0 +1,452 @@
+// gp_kernels.h -- hand-written gfx950 (CDNA4, wave64) kernels of the GP likelihood path.
+//
+//   k_scale        xs = x / l                       (prologue of K1)
+//   kbuild_kernel  K1/K7: pairwise kernel matrix tiles, lower triangle, straight into the
+//                  Cholesky workspace (BGP:29-43 covarianceMatrix; BGP:100-109 cross form)
+//   potrf128       K2a + K3: 128x128 diagonal-block Cholesky in LDS, log-det partial, SPD test
+//   trsm128        K2b: X L^T = A panel solve (also carries r -> z = L^-1 r, K4)
+//   gemm_nt        K2c: C -= A B^T on fp64 MFMA (v_mfma_f64_16x16x4_f64), SYRK/GEMM trailing update
+//   finalize       log det = 2 sum log L_ii, quad = |z|^2, info
+//   predict_reduce K9/K10 epilogue: mu* and var* from V = k*^T L^-T and z
+//
+// Storage: one column-major workspace matrix per batch slot, leading dimension ld = Npad + 128
+// (Npad = N rounded up to the 128 tile).  Rows [Npad, Npad+128) carry right-hand sides as extra
+// ROWS (row Npad = r^T): the panel solve and the trailing update then produce z^T = (L^-1 r)^T in
+// that row and -|z|^2 in element (Npad, Npad) with no extra kernels ("bordered" Cholesky).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace gphip {
+
+constexpr int TB = 128;         // tile edge
+constexpr int SLOTP = 8;        // doubles of per-slot scalars: sf2, sn2, mu, pivot_tol, bad_theta
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------------------------------------
+// exp(x) for x <= 0, fp64, no hardware transcendental on gfx950: Cody-Waite reduction by ln2,
+// degree-13 Taylor/Horner on |r| <= ln2/2 (truncation 4e-18), v_ldexp_f64 scaling. ~20 VALU ops.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double exp_nonpos(double x) {
+    x = fmax(x, -800.0);
+    const double k = __builtin_rint(x * 1.4426950408889634074);
+    double r = __builtin_fma(-k, 6.93147180369123816490e-01, x);
+    r = __builtin_fma(-k, 1.90821492927058770002e-10, r);
+    double p = 1.6059043836821613e-10;              // 1/13!
+    p = __builtin_fma(p, r, 2.0876756987868099e-09);   // 1/12!
+    p = __builtin_fma(p, r, 2.5052108385441719e-08);   // 1/11!
+    p = __builtin_fma(p, r, 2.7557319223985891e-07);   // 1/10!
+    p = __builtin_fma(p, r, 2.7557319223985893e-06);   // 1/9!
+    p = __builtin_fma(p, r, 2.4801587301587302e-05);   // 1/8!
+    p = __builtin_fma(p, r, 1.9841269841269841e-04);   // 1/7!
+    p = __builtin_fma(p, r, 1.3888888888888889e-03);   // 1/6!
+    p = __builtin_fma(p, r, 8.3333333333333332e-03);   // 1/5!
+    p = __builtin_fma(p, r, 4.1666666666666664e-02);   // 1/4!
+    p = __builtin_fma(p, r, 1.6666666666666666e-01);   // 1/3!
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    p = __builtin_fma(p, r, 1.0);
+    return __builtin_ldexp(p, (int)k);
+}
+
+// KT = 0: squared exponential  sf2 * exp(-r2/2)
+// KT = 1: Matern-5/2           sf2 * (1 + s5 + 5 r2/3) exp(-s5),  s5 = sqrt(5 r2)
+template <int KT>
+__device__ __forceinline__ double kfun(double r2, double sf2) {
+    if (KT == 0) {
+        return sf2 * exp_nonpos(-0.5 * r2);
+    } else {
+        const double s5 = __builtin_sqrt(5.0 * r2);
+        return sf2 * (1.0 + s5 + (5.0 / 3.0) * r2) * exp_nonpos(-s5);
+    }
+}
+
+// xs[slot][dd][i] = X[dd][i] * inv_ell[slot][dd]      (Xt is the transposed copy [d][npad])
+__global__ void k_scale(const double* __restrict__ Xt, double* __restrict__ xs,
+                        const double* __restrict__ inv_ell, int d, int npad) {
+    const int slot = blockIdx.y;
+    const long total = (long)d * npad;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long)gridDim.x * blockDim.x) {
+        const int dd = (int)(idx / npad);
+        xs[(long)slot * total + idx] = Xt[idx] * inv_ell[slot * d + dd];
+    }
+}
+
+// Decode linear index t of the lower triangle (incl. diagonal) of an n x n tile grid, enumerated
+// column by column: column c holds rows c..n-1.
+__device__ __forceinline__ void tri_decode(int t, int n, int& ti, int& tj) {
+    const double b = 2.0 * n + 1.0;
+    int c = (int)((b - __builtin_sqrt(b * b - 8.0 * (double)t)) * 0.5);
+    if (c < 0) c = 0;
+    if (c > n - 1) c = n - 1;
+    // offset(c) = c*n - c(c-1)/2
+    while (c > 0 && (long)c * n - (long)c * (c - 1) / 2 > t) --c;
+    while ((long)(c + 1) * n - (long)(c + 1) * c / 2 <= t) ++c;
+    tj = c;
+    ti = c + (t - (int)((long)c * n - (long)c * (c - 1) / 2));
+}
+
+struct KBuildArgs {
+    double* out;            // workspace base (slot 0)
+    long ld;                // leading dimension (doubles)
+    long bstride;           // doubles between slots
+    const double* xi;       // scaled I-operand points [slot][D][npad_i]  (rows of the output)
+    const double* xj;       // scaled J-operand points [slot][D][npad_j]  (columns of the output)
+    long xi_bstride, xj_bstride;
+    int npad_i, npad_j;     // padded point counts (multiples of 128)
+    int n_i, n_j;           // true point counts
+    const double* y;        // [npad_j] outputs (mode 0 only)
+    const double* slotp;    // [slot][SLOTP]
+    int d;                  // runtime dimension (used when D == 0)
+    int mode;               // 0: train x train (lower-tri tiles, nugget, identity padding, rhs rows)
+                            // 1: cross  (rectangular tiles, zero padding)
+    int nt_i, nt_j;         // tile counts; mode 0: nt_i = nt_j + 1 (extra rhs block-row)
+};
+
+// One 128x128 tile per workgroup (4 waves).  Wave w owns 32 output columns; lane owns 2 adjacent
+// rows, so every store is a 16-byte dwordx4 and a wave writes one full 1 KiB column segment.
+// The J-side points come from LDS as wave-uniform broadcasts; the I-side points live in registers.
+template <int D, int KT>
+__global__ __launch_bounds__(256) void kbuild_kernel(KBuildArgs a) {
+    extern __shared__ double lds[];           // xj tile [d][128] (+ xi tile [d][128] when D == 0)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int slot = blockIdx.y;
+    int ti, tj;
+    if (a.mode == 0) {
+        tri_decode(blockIdx.x, a.nt_i, ti, tj);
+    } else {
+        ti = blockIdx.x % a.nt_i;
+        tj = blockIdx.x / a.nt_i;
+    }
+    const double* sp = a.slotp + (long)slot * SLOTP;
+    const double sf2 = sp[0], sn2 = sp[1], mu = sp[2];
+    double* out = a.out + (long)slot * a.bstride + (long)tj * TB * a.ld + (long)ti * TB;
+    const int r0 = 2 * lane;
+
+    if (a.mode == 0 && ti == a.nt_i - 1) {      // right-hand-side block-row: row 0 = r^T, rest 0
+        for (int jj = wave * 32; jj < wave * 32 + 32; ++jj) {
+            const int gj = tj * TB + jj;
+            double2 v = make_double2(0.0, 0.0);
+            if (lane == 0 && tj < a.nt_j && gj < a.n_j) v.x = a.y[gj] - mu;
+            *reinterpret_cast<double2*>(out + (long)jj * a.ld + r0) = v;
+        }
+        return;
+    }
+
+    const int d = (D > 0) ? D : a.d;
+    const double* xjg = a.xj + (long)slot * a.xj_bstride + (long)tj * TB;
+    const double* xig = a.xi + (long)slot * a.xi_bstride + (long)ti * TB;
+    double* xjs = lds;
+    double* xis = lds + d * TB;
+    for (int idx = tid; idx < d * TB; idx += 256) {
+        const int dd = idx >> 7, c = idx & 127;
+        xjs[idx] = xjg[(long)dd * a.npad_j + c];
+        if (D == 0) xis[idx] = xig[(long)dd * a.npad_i + c];
+    }
+    double xa[D > 0 ? D : 1], xb[D > 0 ? D : 1];
+    if (D > 0) {
+#pragma unroll
+        for (int dd = 0; dd < D; ++dd) {
+            const double2 v = *reinterpret_cast<const double2*>(xig + (long)dd * a.npad_i + r0);
+            xa[dd] = v.x;
+            xb[dd] = v.y;
+        }
+    }
+    __syncthreads();
+
+    const int gi = ti * TB + r0;
+    const bool edge = (a.mode == 0) ? (ti == tj || (ti + 1) * TB > a.n_i)
+                                    : ((ti + 1) * TB > a.n_i || (tj + 1) * TB > a.n_j);
+    for (int jj = wave * 32; jj < wave * 32 + 32; ++jj) {
+        double ra = 0.0, rb = 0.0;
+        if (D > 0) {
+#pragma unroll
+            for (int dd = 0; dd < D; ++dd) {
+                const double xjv = xjs[dd * TB + jj];
+                const double da = xa[dd] - xjv, db = xb[dd] - xjv;
+                ra = __builtin_fma(da, da, ra);
+                rb = __builtin_fma(db, db, rb);
+            }
+        } else {
+            for (int dd = 0; dd < d; ++dd) {
+                const double xjv = xjs[dd * TB + jj];
+                const double da = xis[dd * TB + r0] - xjv, db = xis[dd * TB + r0 + 1] - xjv;
+                ra = __builtin_fma(da, da, ra);
+                rb = __builtin_fma(db, db, rb);
+            }
+        }
+        double va = kfun<KT>(ra, sf2), vb = kfun<KT>(rb, sf2);
+        if (edge) {
+            const int gj = tj * TB + jj;
+            if (a.mode == 0) {
+                if (gi == gj) va += sn2;
+                if (gi + 1 == gj) vb += sn2;
+                if (gj >= a.n_j || gi >= a.n_i) va = (gi == gj) ? 1.0 : 0.0;       // identity pad
+                if (gj >= a.n_j || gi + 1 >= a.n_i) vb = (gi + 1 == gj) ? 1.0 : 0.0;
+            } else {
+                if (gj >= a.n_j || gi >= a.n_i) va = 0.0;
+                if (gj >= a.n_j || gi + 1 >= a.n_i) vb = 0.0;
+            }
+        }
+        *reinterpret_cast<double2*>(out + (long)jj * a.ld + r0) = make_double2(va, vb);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// potrf128: Cholesky of one 128x128 diagonal block, entirely in LDS (128 KiB, column-major).
+// Right-looking, column by column.  Writes L back in place, a row-major packed copy Lr (rows of
+// L contiguous, for the scalar-load panel solve), the block's sum(log L_ii) and the SPD verdict:
+// pivot <= tol (tol = 64 eps (sf2+sn2)) or NaN -> info = NOT_SPD (stands for LinearSolve::sing1/
+// ::luc -> Throw "MatInv", BGP:131-135).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void potrf128_kernel(double* __restrict__ Abase, long ld,
+                                                       long bstride, int b,
+                                                       double* __restrict__ Lr, double* __restrict__ partial,
+                                                       int nt, int* __restrict__ info,
+                                                       const double* __restrict__ slotp) {
+    extern __shared__ double Ls[];            // Ls[c*128 + r]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int slot = blockIdx.x;
+    double* Ad = Abase + (long)slot * bstride + (long)b * TB * (ld + 1);
+    for (int c = wave; c < TB; c += 4)
+        *reinterpret_cast<double2*>(&Ls[c * TB + 2 * lane]) =
+            *reinterpret_cast<const double2*>(Ad + (long)c * ld + 2 * lane);
+    const double tol = slotp[(long)slot * SLOTP + 3];
+    bool bad = false;
+    const int r = tid & 127, half = tid >> 7;
+    // One barrier per column: the scaled column j is kept in registers (ljr) and written to LDS
+    // at the top of step j+1, when no thread reads column j any more; during step j every thread
+    // reads the still-unscaled column j and applies 1/l itself.
+    double pljr = 0.0, pl = 0.0;
+    for (int j = 0; j < TB; ++j) {
+        __syncthreads();
+        if (j > 0 && half == 0) {
+            if (r > j - 1) Ls[(j - 1) * TB + r] = pljr;
+            if (r == j - 1) Ls[(j - 1) * TB + r] = pl;
+        }
+        double dj = Ls[j * TB + j];
+        if (!(dj > tol)) { bad = true; dj = 1.0; }
+        const double l = __builtin_sqrt(dj);
+        const double inv = 1.0 / l;
+        const double ljr = (r > j) ? Ls[j * TB + r] * inv : 0.0;
+        for (int c = j + 1 + half; c <= r; c += 2)
+            Ls[c * TB + r] = __builtin_fma(-ljr, Ls[j * TB + c] * inv, Ls[c * TB + r]);
+        pljr = ljr;
+        pl = l;
+    }
+    __syncthreads();
+    if (tid == TB - 1) Ls[(TB - 1) * TB + (TB - 1)] = pl;
+    __syncthreads();
+    // write back: lower triangle incl. diagonal (upper part of the block is never read again)
+    for (int c = wave; c < TB; c += 4) {
+        double2 v = *reinterpret_cast<const double2*>(&Ls[c * TB + 2 * lane]);
+        *reinterpret_cast<double2*>(Ad + (long)c * ld + 2 * lane) = v;
+    }
+    double* Lrs = Lr + ((long)slot * nt + b) * TB * TB;       // Lrs[row*128 + k]
+    for (int idx = tid; idx < TB * TB; idx += 256) {
+        const int row = idx >> 7, k = idx & 127;
+        Lrs[idx] = (k <= row) ? Ls[k * TB + row] : 0.0;
+    }
+    // sum of log diag: wave 0 + wave 1 reduce 128 values
+    double lg = 0.0;
+    if (tid < TB) lg = log(Ls[tid * TB + tid]);
+    for (int off = 32; off > 0; off >>= 1) lg += __shfl_down(lg, off);
+    double* red = Ls + TB * TB;             // 2 spare doubles behind the block (dynamic LDS)
+    if (tid < TB && lane == 0) red[wave] = lg;
+    __syncthreads();
+    if (tid == 0) {
+        partial[(long)slot * nt + b] = red[0] + red[1];
+        if (bad) info[slot] = 1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// trsm128: X <- X L^-T for a 128-wide panel, 64 rows per single-wave workgroup.  Row-per-lane
+// forward substitution; L rows come from the packed row-major copy through wave-uniform
+// (scalar-cache) loads, X lives in LDS as [c][row].
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void trsm128_kernel(double* __restrict__ Xbase, long ldx,
+                                                     long xbstride, const double* __restrict__ Lr,
+                                                     long lbstride) {
+    extern __shared__ double Xs[];            // Xs[c*64 + lane]
+    const int lane = threadIdx.x;
+    const int slot = blockIdx.y;
+    double* X = Xbase + (long)slot * xbstride + (long)blockIdx.x * 64;
+    const double* L = Lr + (long)slot * lbstride;
+    for (int c = 0; c < TB; ++c) Xs[c * 64 + lane] = X[(long)c * ldx + lane];
+    for (int c = 0; c < TB; ++c) {
+        const double* Lc = L + c * TB;
+        double a0 = Xs[c * 64 + lane], a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        int k = 0;
+        for (; k + 4 <= c; k += 4) {
+            a0 = __builtin_fma(-Xs[(k + 0) * 64 + lane], Lc[k + 0], a0);
+            a1 = __builtin_fma(-Xs[(k + 1) * 64 + lane], Lc[k + 1], a1);
+            a2 = __builtin_fma(-Xs[(k + 2) * 64 + lane], Lc[k + 2], a2);
+            a3 = __builtin_fma(-Xs[(k + 3) * 64 + lane], Lc[k + 3], a3);
+        }
+        for (; k < c; ++k) a0 = __builtin_fma(-Xs[k * 64 + lane], Lc[k], a0);
+        Xs[c * 64 + lane] = ((a0 + a1) + (a2 + a3)) / Lc[c];
+    }
+    for (int c = 0; c < TB; ++c) X[(long)c * ldx + lane] = Xs[c * 64 + lane];
+}
+
+// ---------------------------------------------------------------------------------------------
+// gemm_nt: C(i,j) -= sum_k A(i,k) B(j,k) for 128x128 tiles on v_mfma_f64_16x16x4_f64.
+//
+// 256 threads = 4 waves in a 2(i) x 2(j) arrangement, 64x64 per wave = 4x4 MFMA tiles, 64 fp64
+// accumulators (128 VGPRs) per lane.  K is consumed in stages of 16 through double-buffered LDS
+// (register-staged global loads issued a stage ahead).  Both operand tiles are stored [k][row]
+// with a padded leading dimension of 144 doubles so the MFMA fragment read
+// (lane -> row = lane&15, k = lane>>4) is ds_read_b64 bank-conflict free.
+//
+// MFMA operand roles: the C-row (memory-contiguous) index i feeds the MFMA *B* operand so that
+// D's column index (= lane&15) runs along contiguous memory of column-major C; the C-column index
+// j feeds the *A* operand (D row = (lane>>4) + 4*reg; f64 layout, cdna_hip_programming.md §3).
+// ---------------------------------------------------------------------------------------------
+constexpr int GK = 16;          // K per LDS stage
+constexpr int LDT = 144;        // padded LDS leading dimension (doubles)
+
+struct GemmArgs {
+    double* C; long ldc; long c_bstride;
+    const double* A; long lda; long a_bstride;   // I operand: A(i,k) at A[i + k*lda]
+    const double* B; long ldb; long b_bstride;   // J operand: B(j,k) at B[j + k*ldb]
+    int K;                                       // multiple of 16
+    int r0, r1, c0, c1;                          // tile ranges: rows [r0,r1), cols [c0,c1)
+    int tri;                                     // 1: keep only tiles with ti >= tj (needs r0 >= c0)
+    int nrect;                                   // tiles in the full-height rectangle part
+    int ntiles;
+    int swizzle;                                 // XCD-aware block remap
+};
+
+__device__ __forceinline__ void gemm_tile_decode(const GemmArgs& g, int t, int& ti, int& tj) {
+    const int H = g.r1 - g.r0;
+    if (!g.tri || t < g.nrect) {
+        tj = g.c0 + t / H;
+        ti = g.r0 + t % H;
+    } else {
+        int u, v;
+        tri_decode(t - g.nrect, H, u, v);      // u >= v in an H x H triangle anchored at (r0, r0)
+        ti = g.r0 + u;
+        tj = g.r0 + v;
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
+    extern __shared__ double smem[];           // [2 stages][I: GK*LDT | J: GK*LDT]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wi = wave & 1, wj = wave >> 1;
+    const int slot = blockIdx.y;
+    int bid = blockIdx.x;
+    if (g.swizzle) {                           // blocks b, b+8, b+16.. share an XCD (b % 8): give
+        const int nx = 8, n = g.ntiles;        // each XCD a contiguous chunk of the tile list
+        const int q = n / nx, rem = n % nx, x = bid % nx, o = bid / nx;
+        bid = (x < rem ? x * (q + 1) : rem * (q + 1) + (x - rem) * q) + o;
+    }
+    int ti, tj;
+    gemm_tile_decode(g, bid, ti, tj);
+
+    const double* Ag = g.A + (long)slot * g.a_bstride + (long)ti * TB;
+    const double* Bg = g.B + (long)slot * g.b_bstride + (long)tj * TB;
+    // staging: thread loads rows (2*lane, 2*lane+1) of k-columns wave, wave+4, wave+8, wave+12
+    double2 ra[4], rb[4];
+    const int srow = 2 * lane;
+    auto gload = [&](int kb) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const long kcol = (long)kb * GK + wave + 4 * s;
+            ra[s] = *reinterpret_cast<const double2*>(Ag + kcol * g.lda + srow);
+            rb[s] = *reinterpret_cast<const double2*>(Bg + kcol * g.ldb + srow);
+        }
+    };
+    auto lstore = [&](int st) {
+        double* Is = smem + st * (2 * GK * LDT);
+        double* Js = Is + GK * LDT;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int kk = wave + 4 * s;
+            *reinterpret_cast<double2*>(Is + kk * LDT + srow) = ra[s];
+            *reinterpret_cast<double2*>(Js + kk * LDT + srow) = rb[s];
+        }
+    };
+
+    d4 acc[4][4];
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y) acc[x][y] = (d4){0.0, 0.0, 0.0, 0.0};
+
+    const int nk = g.K / GK;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    const int foff = (lane >> 4) * LDT + (lane & 15);
+    for (int kb = 0; kb < nk; ++kb) {
+        const int cur = kb & 1;
+        if (kb + 1 < nk) gload(kb + 1);
+        const double* Is = smem + cur * (2 * GK * LDT) + wi * 64 + foff;
+        const double* Js = smem + cur * (2 * GK * LDT) + GK * LDT + wj * 64 + foff;
+#pragma unroll
+        for (int kk = 0; kk < GK / 4; ++kk) {
+            double fi[4], fj[4];
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                fi[f] = Is[kk * 4 * LDT + f * 16];
+                fj[f] = Js[kk * 4 * LDT + f * 16];
+            }
+#pragma unroll
+            for (int x = 0; x < 4; ++x)
+#pragma unroll
+                for (int y = 0; y < 4; ++y)
+                    acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(fj[x], fi[y], acc[x][y], 0, 0, 0);
+        }
+        if (kb + 1 < nk) lstore(cur ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: C(i,j) -= acc.  lane holds i = i0 + y*16 + (lane&15), j = j0 + x*16 + (lane>>4) + 4r
+    double* Cg = g.C + (long)slot * g.c_bstride + ((long)tj * TB + wj * 64 + (lane >> 4)) * g.ldc +
+                 (long)ti * TB + wi * 64 + (lane & 15);
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            double* cp = Cg + (long)(x * 16 + 4 * r) * g.ldc;
+#pragma unroll
+            for (int y = 0; y < 4; ++y) cp[y * 16] -= acc[x][y][r];
+        }
+}
+
+// log det = 2 sum partial ; quad = -E(0,0) ; res[slot] = {logdet, quad}
+__global__ void finalize_kernel(const double* __restrict__ Abase, long ld, long bstride, int npad,
+                                const double* __restrict__ partial, int nt, double* __restrict__ res) {
+    const int slot = blockIdx.x;
+    double s = 0.0;
+    for (int b = threadIdx.x; b < nt; b += 64) s += partial[(long)slot * nt + b];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+    if (threadIdx.x == 0) {
+        res[slot * 2 + 0] = 2.0 * s;
+        res[slot * 2 + 1] = -Abase[(long)slot * bstride + (long)npad * ld + npad];
+    }
+}
+
+// V: column-major [mpad x npad] (ld = mpad), V(t, j) = (L^-1 k*_t)_j.  z: row npad of the factor.
+// mean[t] = mu + sum_j V(t,j) z_j ; var[t] = kappa - sum_j V(t,j)^2
+__global__ void predict_reduce_kernel(const double* __restrict__ V, long ldv, int n,
+                                      const double* __restrict__ zrow, long ldz, double mu,
+                                      double kappa, int m, double* __restrict__ mean,
+                                      double* __restrict__ var) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= m) return;
+    double dot = 0.0, nrm = 0.0;
+    for (int j = 0; j < n; ++j) {
+        const double v = V[(long)j * ldv + t];
+        dot = __builtin_fma(v, zrow[(long)j * ldz], dot);
+        nrm = __builtin_fma(v, v, nrm);
+    }
+    mean[t] = mu + dot;
+    var[t] = kappa - nrm;
+}
+
+}  // namespace gphip

@@ -1,0 +1,632 @@
+// gphip.hip -- C ABI (include/gphip.h) and host orchestration of the GP likelihood path.
+//
+// Per evaluation (BGP:297-305 closure = K1 -> K2 -> K3 -> K4 -> K6):
+//   k_scale + kbuild      lower-triangle tiles of K(theta) + nugget, plus r^T as an extra row
+//   two-level right-looking Cholesky:
+//       for each outer panel of `panel` 128-tiles:
+//           for each 128-tile column b in the panel:  potrf128(b); trsm128(rows below b);
+//                                                     gemm_nt(K=128) on the rest of the panel
+//           gemm_nt(K=panel*128) trailing SYRK on everything to the right (fp64 MFMA, dominant)
+//   finalize              log det, quadratic form (bordered row), info
+//   host epilogue         -1/2 (N log 2pi + logdet + quad)   (BGP:190-196)
+// All work is queued on one handle-owned HIP stream; X, y stay device resident.
+#include "gp_kernels.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/gphip.h"
+
+using namespace gphip;
+
+namespace {
+
+constexpr double LOG_TWO_PI = 1.8378770664093454835606594728112;
+constexpr double PIVOT_TOL_REL = 64.0 * 2.220446049250313e-16;
+
+struct ProfRec {
+    int cls;
+    hipEvent_t e0, e1;
+    double flops, bytes;
+};
+
+}  // namespace
+
+struct gphip_ctx {
+    std::mutex mu;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int64_t N = 0, d = 0, Npad = 0, Nt = 0, ld = 0;
+    int kernel_id = 0, mean_id = 0, nl = 0, p = 0, kt = 0;
+    double sum_y = 0, sum_y2 = 0;
+    double *dXt = nullptr, *dY = nullptr;
+    // batch workspace
+    int slots = 0;
+    double *dA = nullptr, *dXs = nullptr, *dInvEll = nullptr, *dSlotp = nullptr, *dLr = nullptr,
+           *dPartial = nullptr, *dRes = nullptr;
+    int* dInfo = nullptr;
+    double *hInvEll = nullptr, *hSlotp = nullptr, *hRes = nullptr;
+    int* hInfo = nullptr;
+    // options
+    int panel = 4, profile = 0, swizzle = 1, max_slots = 256;
+    // fitted state (slot 0)
+    bool fitted = false;
+    std::vector<double> theta_fit;
+    double logdet_fit = 0, mu_fit = 0, kappa_fit = 0;
+    // prediction scratch
+    double *dV = nullptr, *dXsT = nullptr, *dXsS = nullptr, *dMean = nullptr, *dVar = nullptr;
+    int64_t vcap = 0;
+    // profiling
+    std::vector<ProfRec> recs;
+    std::vector<hipEvent_t> pool;
+    double acc_ms[GPHIP_NCLASS] = {0}, acc_n[GPHIP_NCLASS] = {0}, acc_flops[GPHIP_NCLASS] = {0},
+           acc_bytes[GPHIP_NCLASS] = {0};
+    std::string err;
+};
+
+namespace {
+
+#define HIPCHK(call)                                                                       \
+    do {                                                                                   \
+        hipError_t e_ = (call);                                                            \
+        if (e_ != hipSuccess) {                                                            \
+            char buf_[512];                                                                \
+            snprintf(buf_, sizeof buf_, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
+                     __FILE__, __LINE__);                                                  \
+            h->err = buf_;                                                                 \
+            return GPHIP_ERR_HIP;                                                          \
+        }                                                                                  \
+    } while (0)
+
+int fail(gphip_ctx* h, int code, const char* msg) {
+    if (h) h->err = msg;
+    return code;
+}
+
+hipEvent_t get_event(gphip_ctx* h) {
+    if (!h->pool.empty()) {
+        hipEvent_t e = h->pool.back();
+        h->pool.pop_back();
+        return e;
+    }
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+// profile levels: 1 = trailing SYRK + whole eval, 2 = every class
+struct ProfScope {
+    gphip_ctx* h;
+    bool on;
+    ProfRec r;
+    ProfScope(gphip_ctx* h_, int cls, double flops, double bytes) : h(h_) {
+        on = h->profile >= 2 || (h->profile == 1 && cls >= 4);
+        if (on) {
+            r.cls = cls;
+            r.flops = flops;
+            r.bytes = bytes;
+            r.e0 = get_event(h);
+            r.e1 = get_event(h);
+            (void)hipEventRecord(r.e0, h->stream);
+        }
+    }
+    ~ProfScope() {
+        if (on) {
+            (void)hipEventRecord(r.e1, h->stream);
+            h->recs.push_back(r);
+        }
+    }
+};
+
+void harvest(gphip_ctx* h) {   // call after stream sync
+    for (auto& r : h->recs) {
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, r.e0, r.e1);
+        h->acc_ms[r.cls] += ms;
+        h->acc_n[r.cls] += 1;
+        h->acc_flops[r.cls] += r.flops;
+        h->acc_bytes[r.cls] += r.bytes;
+        h->pool.push_back(r.e0);
+        h->pool.push_back(r.e1);
+    }
+    h->recs.clear();
+}
+
+void free_slots(gphip_ctx* h) {
+    (void)hipFree(h->dA); (void)hipFree(h->dXs); (void)hipFree(h->dInvEll); (void)hipFree(h->dSlotp);
+    (void)hipFree(h->dLr); (void)hipFree(h->dPartial); (void)hipFree(h->dRes); (void)hipFree(h->dInfo);
+    (void)hipHostFree(h->hInvEll); (void)hipHostFree(h->hSlotp); (void)hipHostFree(h->hRes);
+    (void)hipHostFree(h->hInfo);
+    h->dA = h->dXs = h->dInvEll = h->dSlotp = h->dLr = h->dPartial = h->dRes = nullptr;
+    h->dInfo = nullptr;
+    h->hInvEll = h->hSlotp = h->hRes = nullptr;
+    h->hInfo = nullptr;
+    h->slots = 0;
+    h->fitted = false;
+}
+
+size_t slot_bytes(const gphip_ctx* h) {
+    return (size_t)h->ld * h->ld * 8 + (size_t)h->d * h->Npad * 8 + (size_t)h->Nt * TB * TB * 8 +
+           (size_t)h->Nt * 8 + 4096;
+}
+
+int ensure_slots(gphip_ctx* h, int want) {
+    if (want <= h->slots) return GPHIP_OK;
+    size_t fr = 0, tot = 0;
+    HIPCHK(hipMemGetInfo(&fr, &tot));
+    fr += (size_t)h->slots * slot_bytes(h);               // what we are about to give back
+    int fit = (int)((double)fr * 0.85 / (double)slot_bytes(h));
+    if (fit < 1) return fail(h, GPHIP_ERR_HIP, "not enough device memory for one workspace matrix");
+    if (want > fit) want = fit;
+    if (want > h->max_slots) want = h->max_slots;
+    if (want <= h->slots) return GPHIP_OK;
+    free_slots(h);
+    const size_t S = (size_t)want;
+    HIPCHK(hipMalloc(&h->dA, S * h->ld * h->ld * 8));
+    HIPCHK(hipMalloc(&h->dXs, S * h->d * h->Npad * 8));
+    HIPCHK(hipMalloc(&h->dInvEll, S * h->d * 8));
+    HIPCHK(hipMalloc(&h->dSlotp, S * SLOTP * 8));
+    HIPCHK(hipMalloc(&h->dLr, S * h->Nt * TB * TB * 8));
+    HIPCHK(hipMalloc(&h->dPartial, S * h->Nt * 8));
+    HIPCHK(hipMalloc(&h->dRes, S * 2 * 8));
+    HIPCHK(hipMalloc(&h->dInfo, S * 4));
+    HIPCHK(hipHostMalloc(&h->hInvEll, S * h->d * 8));
+    HIPCHK(hipHostMalloc(&h->hSlotp, S * SLOTP * 8));
+    HIPCHK(hipHostMalloc(&h->hRes, S * 2 * 8));
+    HIPCHK(hipHostMalloc(&h->hInfo, S * 4));
+    h->slots = want;
+    return GPHIP_OK;
+}
+
+template <int KT>
+void launch_kbuild_kt(gphip_ctx* h, const KBuildArgs& a, dim3 grid) {
+    const int d = a.d;
+#define KB_CASE(DD)                                                                            \
+    case DD:                                                                                   \
+        hipLaunchKernelGGL((kbuild_kernel<DD, KT>), grid, dim3(256), (size_t)DD * TB * 8, h->stream, a); \
+        break;
+    switch (d) {
+        KB_CASE(1) KB_CASE(2) KB_CASE(3) KB_CASE(4) KB_CASE(5) KB_CASE(6) KB_CASE(7) KB_CASE(8)
+        KB_CASE(16)
+        default:
+            hipLaunchKernelGGL((kbuild_kernel<0, KT>), grid, dim3(256), (size_t)2 * d * TB * 8,
+                               h->stream, a);
+    }
+#undef KB_CASE
+}
+
+void launch_kbuild(gphip_ctx* h, const KBuildArgs& a, dim3 grid) {
+    if (h->kt == 0) launch_kbuild_kt<0>(h, a, grid);
+    else launch_kbuild_kt<1>(h, a, grid);
+}
+
+// queue k_scale + kbuild for nslots slots (theta already staged in dInvEll / dSlotp)
+void queue_build(gphip_ctx* h, int nslots) {
+    const long tot = (long)h->d * h->Npad;
+    int gx = (int)((tot + 255) / 256);
+    if (gx > 1024) gx = 1024;
+    hipLaunchKernelGGL(k_scale, dim3(gx, nslots), dim3(256), 0, h->stream, h->dXt, h->dXs, h->dInvEll,
+                       (int)h->d, (int)h->Npad);
+    KBuildArgs a{};
+    a.out = h->dA; a.ld = h->ld; a.bstride = h->ld * h->ld;
+    a.xi = h->dXs; a.xj = h->dXs; a.xi_bstride = a.xj_bstride = tot;
+    a.npad_i = a.npad_j = (int)h->Npad; a.n_i = a.n_j = (int)h->N;
+    a.y = h->dY; a.slotp = h->dSlotp; a.d = (int)h->d; a.mode = 0;
+    a.nt_i = (int)h->Nt + 1; a.nt_j = (int)h->Nt;
+    const long ntiles = (long)(h->Nt + 1) * (h->Nt + 2) / 2;
+    ProfScope ps(h, 0, 0.0, 8.0 * nslots * ((double)h->N * (h->N + 1) / 2 + (double)h->N * h->d));
+    launch_kbuild(h, a, dim3((unsigned)ntiles, nslots));
+}
+
+void launch_gemm(gphip_ctx* h, int cls, double* C, long ldc, long cbs, const double* A, long lda,
+                 long abs_, const double* B, long ldb, long bbs, int K, int r0, int r1, int c0, int c1,
+                 int tri, int nslots) {
+    GemmArgs g{};
+    g.C = C; g.ldc = ldc; g.c_bstride = cbs;
+    g.A = A; g.lda = lda; g.a_bstride = abs_;
+    g.B = B; g.ldb = ldb; g.b_bstride = bbs;
+    g.K = K; g.r0 = r0; g.r1 = r1; g.c0 = c0; g.c1 = c1; g.tri = tri;
+    const int H = r1 - r0, W = c1 - c0;
+    if (H <= 0 || W <= 0) return;
+    if (!tri) {
+        g.nrect = H * W;
+        g.ntiles = H * W;
+    } else {
+        int nrc = r0 - c0;                      // columns left of the triangle: full height
+        if (nrc > W) nrc = W;
+        const int ntc = W - nrc;                // triangle columns (heights H, H-1, ..)
+        g.nrect = nrc * H;
+        g.ntiles = g.nrect + ntc * H - ntc * (ntc - 1) / 2;
+    }
+    g.swizzle = h->swizzle && g.ntiles >= 64;
+    const double flops = 2.0 * TB * TB * (double)K * g.ntiles * nslots;
+    const double bytes = 8.0 * TB * ((double)2 * TB + 2.0 * K) * g.ntiles * nslots;
+    ProfScope ps(h, cls, flops, bytes);
+    hipLaunchKernelGGL(gemm_nt_kernel, dim3(g.ntiles, nslots), dim3(256), (size_t)2 * 2 * GK * LDT * 8,
+                       h->stream, g);
+}
+
+// two-level right-looking Cholesky of slots [0, nslots) (workspace already built)
+void queue_factor(gphip_ctx* h, int nslots) {
+    const int Nt = (int)h->Nt, R = Nt + 1;     // R = tile rows incl. the rhs block-row
+    const long ld = h->ld, bs = ld * ld;
+    const long lrs = (long)Nt * TB * TB;
+    for (int K0 = 0; K0 < Nt; K0 += h->panel) {
+        const int nin = (Nt - K0 < h->panel) ? (Nt - K0) : h->panel;
+        for (int s = 0; s < nin; ++s) {
+            const int b = K0 + s;
+            {
+                ProfScope ps(h, 1, (double)TB * TB * TB / 3.0 * nslots, 0.0);
+                hipLaunchKernelGGL(potrf128_kernel, dim3(nslots), dim3(256), (size_t)(TB * TB + 2) * 8,
+                                   h->stream, h->dA, ld, bs, b, h->dLr, h->dPartial, Nt, h->dInfo,
+                                   h->dSlotp);
+            }
+            const int rows = (R - (b + 1)) * TB;
+            {
+                ProfScope ps(h, 2, (double)rows * TB * TB * nslots, 0.0);
+                hipLaunchKernelGGL(trsm128_kernel, dim3(rows / 64, nslots), dim3(64), (size_t)TB * 64 * 8,
+                                   h->stream, h->dA + (long)b * TB * ld + (long)(b + 1) * TB, ld, bs,
+                                   h->dLr + (long)b * TB * TB, lrs);
+            }
+            if (s + 1 < nin) {
+                const double* P = h->dA + (long)b * TB * ld;
+                launch_gemm(h, 3, h->dA, ld, bs, P, ld, bs, P, ld, bs, TB, b + 1, R, b + 1, K0 + nin, 1,
+                            nslots);
+            }
+        }
+        const double* P = h->dA + (long)K0 * TB * ld;
+        launch_gemm(h, 4, h->dA, ld, bs, P, ld, bs, P, ld, bs, nin * TB, K0 + nin, R, K0 + nin, R, 1,
+                    nslots);
+    }
+    hipLaunchKernelGGL(finalize_kernel, dim3(nslots), dim3(64), 0, h->stream, h->dA, ld, bs,
+                       (int)h->Npad, h->dPartial, Nt, h->dRes);
+}
+
+// stage theta of one slot into the pinned host buffers; returns false if theta is unusable
+bool stage_theta(gphip_ctx* h, int slot, const double* th) {
+    double* ie = h->hInvEll + (size_t)slot * h->d;
+    double* sp = h->hSlotp + (size_t)slot * SLOTP;
+    bool ok = true;
+    for (int i = 0; i < h->p; ++i)
+        if (!std::isfinite(th[i])) ok = false;
+    for (int j = 0; j < h->d; ++j) {
+        const double l = th[h->nl == 1 ? 0 : j];
+        if (!(std::fabs(l) > 0.0) || !std::isfinite(1.0 / l)) ok = false;
+        ie[j] = ok ? 1.0 / std::fabs(l) : 1.0;
+    }
+    double sf = th[h->nl], sn = th[h->nl + 1];
+    double mu = (h->mean_id == GPHIP_MEAN_CONST) ? th[h->nl + 2] : 0.0;
+    if (!ok) { sf = 1.0; sn = 1.0; mu = 0.0; }
+    sp[0] = sf * sf; sp[1] = sn * sn; sp[2] = mu;
+    sp[3] = PIVOT_TOL_REL * (sf * sf + sn * sn);
+    if (!std::isfinite(sp[0]) || !std::isfinite(sp[1])) { ok = false; sp[0] = sp[1] = 1.0; sp[3] = 1e-14; }
+    sp[4] = ok ? 0.0 : 1.0;
+    return ok;
+}
+
+// null kernel (BGP:25-27, 156-159): K = diag(sn^2); O(1) from the cached sums of y
+void null_kernel_eval(const gphip_ctx* h, const double* th, double* out, double* parts, int* info) {
+    const double sn = th[0];
+    const double mu = (h->mean_id == GPHIP_MEAN_CONST) ? th[1] : 0.0;
+    const double v = sn * sn;
+    const double logdet = (double)h->N * std::log(std::fabs(v));
+    const double quad = (h->sum_y2 - 2.0 * mu * h->sum_y + (double)h->N * mu * mu) / v;
+    const double ll = -0.5 * ((double)h->N * LOG_TWO_PI + logdet + quad);
+    *info = std::isfinite(ll) ? (v > 0.0 ? GPHIP_INFO_OK : GPHIP_INFO_NOT_SPD) : GPHIP_INFO_NAN;
+    *out = ll;
+    if (parts) { parts[0] = logdet; parts[1] = quad; }
+}
+
+int eval_chunk(gphip_ctx* h, const double* Theta, int nb, double* out, double* parts, int* info) {
+    std::vector<char> okv(nb);
+    for (int s = 0; s < nb; ++s) okv[s] = stage_theta(h, s, Theta + (size_t)s * h->p);
+    HIPCHK(hipMemcpyAsync(h->dInvEll, h->hInvEll, (size_t)nb * h->d * 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->dSlotp, h->hSlotp, (size_t)nb * SLOTP * 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemsetAsync(h->dInfo, 0, (size_t)nb * 4, h->stream));
+    {
+        ProfScope ps(h, 5, 0.0, 0.0);
+        queue_build(h, nb);
+        queue_factor(h, nb);
+    }
+    HIPCHK(hipMemcpyAsync(h->hRes, h->dRes, (size_t)nb * 16, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(h->hInfo, h->dInfo, (size_t)nb * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipGetLastError());
+    harvest(h);
+    for (int s = 0; s < nb; ++s) {
+        const double logdet = h->hRes[2 * s], quad = h->hRes[2 * s + 1];
+        const double ll = -0.5 * ((double)h->N * LOG_TWO_PI + logdet + quad);
+        int inf = h->hInfo[s];
+        if (!okv[s]) inf = GPHIP_INFO_NAN;
+        else if (inf == 0 && !std::isfinite(ll)) inf = GPHIP_INFO_NAN;
+        info[s] = inf;
+        out[s] = ll;
+        if (parts) { parts[2 * s] = logdet; parts[2 * s + 1] = quad; }
+    }
+    return GPHIP_OK;
+}
+
+int eval_batch(gphip_ctx* h, const double* Theta, int B, int p, double* out, double* parts, int* info) {
+    if (!h || !Theta || !out || !info) return fail(h, GPHIP_ERR_ARG, "null argument");
+    if (p != h->p) return fail(h, GPHIP_ERR_DIM, "theta has the wrong length for this kernel/mean");
+    if (B <= 0) return GPHIP_OK;
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIPCHK(hipSetDevice(h->device));
+    if (h->kernel_id == GPHIP_KERNEL_NULL) {
+        for (int s = 0; s < B; ++s)
+            null_kernel_eval(h, Theta + (size_t)s * p, out + s, parts ? parts + 2 * s : nullptr, info + s);
+        return GPHIP_OK;
+    }
+    int rc = ensure_slots(h, B);
+    if (rc) return rc;
+    h->fitted = false;
+    for (int s0 = 0; s0 < B; s0 += h->slots) {
+        const int nb = (B - s0 < h->slots) ? (B - s0) : h->slots;
+        rc = eval_chunk(h, Theta + (size_t)s0 * p, nb, out + s0, parts ? parts + 2 * s0 : nullptr, info + s0);
+        if (rc) return rc;
+    }
+    return GPHIP_OK;
+}
+
+int set_func_attrs(gphip_ctx* h) {
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(potrf128_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (TB * TB + 2) * 8));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trsm128_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, TB * 64 * 8));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * GK * LDT * 8));
+    return GPHIP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* gphip_version(void) { return "gphip 0.1.0 (gfx950)"; }
+
+int gphip_device_count(int* n) {
+    if (!n) return GPHIP_ERR_ARG;
+    int c = 0;
+    if (hipGetDeviceCount(&c) != hipSuccess) c = 0;
+    *n = c;
+    return GPHIP_OK;
+}
+
+const char* gphip_last_error(gphip_handle h) { return h ? h->err.c_str() : "null handle"; }
+
+int gphip_create(const void* X, const void* y, int64_t N, int64_t d, int kernel_id, int mean_id,
+                 int dtype, const int* devices, int ndev, gphip_handle* out) {
+    if (!out) return GPHIP_ERR_ARG;
+    *out = nullptr;
+    if (!X || !y) return GPHIP_ERR_ARG;
+    if (N < 1 || d < 1) return GPHIP_ERR_DIM;
+    if (d > 32) return GPHIP_ERR_UNSUPPORTED;   // LDS-resident point tiles: 2*d*1 KiB <= 64 KiB
+    if (kernel_id < 0 || kernel_id > GPHIP_KERNEL_NULL) return GPHIP_ERR_ARG;
+    if (mean_id != GPHIP_MEAN_ZERO && mean_id != GPHIP_MEAN_CONST) return GPHIP_ERR_ARG;
+    if (dtype != 64) return GPHIP_ERR_UNSUPPORTED;
+    int ndevs = 0;
+    if (hipGetDeviceCount(&ndevs) != hipSuccess || ndevs < 1) return GPHIP_ERR_NODEVICE;
+    gphip_ctx* h = new gphip_ctx;
+    if (devices && ndev > 0) h->device = devices[0];
+    else (void)hipGetDevice(&h->device);
+    if (h->device < 0 || h->device >= ndevs) { delete h; return GPHIP_ERR_NODEVICE; }
+    h->N = N; h->d = d;
+    h->Npad = (N + TB - 1) / TB * TB;
+    h->Nt = h->Npad / TB;
+    h->ld = h->Npad + TB;
+    h->kernel_id = kernel_id; h->mean_id = mean_id;
+    h->kt = (kernel_id == GPHIP_KERNEL_MATERN52 || kernel_id == GPHIP_KERNEL_MATERN52_ARD) ? 1 : 0;
+    h->nl = (kernel_id == GPHIP_KERNEL_SE || kernel_id == GPHIP_KERNEL_MATERN52) ? 1
+            : (kernel_id == GPHIP_KERNEL_NULL ? 0 : (int)d);
+    h->p = (kernel_id == GPHIP_KERNEL_NULL ? 1 : h->nl + 2) + (mean_id == GPHIP_MEAN_CONST ? 1 : 0);
+    const double* Xd = static_cast<const double*>(X);
+    const double* yd = static_cast<const double*>(y);
+    for (int64_t i = 0; i < N; ++i) { h->sum_y += yd[i]; h->sum_y2 += yd[i] * yd[i]; }
+    auto bail = [&](int code) { gphip_destroy(h); return code; };
+    if (hipSetDevice(h->device) != hipSuccess) return bail(GPHIP_ERR_HIP);
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return bail(GPHIP_ERR_HIP);
+    std::vector<double> xt((size_t)d * h->Npad, 0.0), yp((size_t)h->Npad, 0.0);
+    for (int64_t i = 0; i < N; ++i) {
+        for (int64_t j = 0; j < d; ++j) xt[(size_t)j * h->Npad + i] = Xd[i * d + j];
+        yp[i] = yd[i];
+    }
+    if (hipMalloc(&h->dXt, xt.size() * 8) != hipSuccess) return bail(GPHIP_ERR_HIP);
+    if (hipMalloc(&h->dY, yp.size() * 8) != hipSuccess) return bail(GPHIP_ERR_HIP);
+    if (hipMemcpy(h->dXt, xt.data(), xt.size() * 8, hipMemcpyHostToDevice) != hipSuccess) return bail(GPHIP_ERR_HIP);
+    if (hipMemcpy(h->dY, yp.data(), yp.size() * 8, hipMemcpyHostToDevice) != hipSuccess) return bail(GPHIP_ERR_HIP);
+    if (set_func_attrs(h) != GPHIP_OK) return bail(GPHIP_ERR_HIP);
+    *out = h;
+    return GPHIP_OK;
+}
+
+int gphip_destroy(gphip_handle h) {
+    if (!h) return GPHIP_OK;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    free_slots(h);
+    (void)hipFree(h->dXt); (void)hipFree(h->dY);
+    (void)hipFree(h->dV); (void)hipFree(h->dXsT); (void)hipFree(h->dXsS); (void)hipFree(h->dMean);
+    (void)hipFree(h->dVar);
+    for (auto e : h->pool) (void)hipEventDestroy(e);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return GPHIP_OK;
+}
+
+int gphip_num_params(gphip_handle h, int* p) {
+    if (!h || !p) return GPHIP_ERR_ARG;
+    *p = h->p;
+    return GPHIP_OK;
+}
+
+int gphip_loglik(gphip_handle h, const double* theta, int p, double* out, int* info) {
+    return eval_batch(h, theta, 1, p, out, nullptr, info);
+}
+
+int gphip_loglik_parts(gphip_handle h, const double* theta, int p, double* out, double* parts, int* info) {
+    return eval_batch(h, theta, 1, p, out, parts, info);
+}
+
+int gphip_loglik_batch(gphip_handle h, const double* Theta, int B, int p, double* out, int* info) {
+    return eval_batch(h, Theta, B, p, out, nullptr, info);
+}
+
+int gphip_fit(gphip_handle h, const double* theta, int p, int* info) {
+    if (!h || !theta || !info) return fail(h, GPHIP_ERR_ARG, "null argument");
+    if (h->kernel_id == GPHIP_KERNEL_NULL) return fail(h, GPHIP_ERR_UNSUPPORTED, "fit: null kernel has no factor");
+    double out, parts[2];
+    int rc = eval_batch(h, theta, 1, p, &out, parts, info);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(h->mu);
+    h->fitted = (*info == 0);
+    h->theta_fit.assign(theta, theta + p);
+    h->logdet_fit = parts[0];
+    h->mu_fit = h->hSlotp[2];
+    h->kappa_fit = h->hSlotp[0] + h->hSlotp[1];
+    return GPHIP_OK;
+}
+
+int gphip_logdet(gphip_handle h, double* out) {
+    if (!h || !out) return fail(h, GPHIP_ERR_ARG, "null argument");
+    if (!h->fitted) return fail(h, GPHIP_ERR_STATE, "gphip_logdet before a successful gphip_fit");
+    *out = h->logdet_fit;
+    return GPHIP_OK;
+}
+
+int gphip_covariance(gphip_handle h, const double* theta, int p, double* K) {
+    if (!h || !theta || !K) return fail(h, GPHIP_ERR_ARG, "null argument");
+    if (p != h->p) return fail(h, GPHIP_ERR_DIM, "theta has the wrong length");
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIPCHK(hipSetDevice(h->device));
+    const int64_t N = h->N;
+    if (h->kernel_id == GPHIP_KERNEL_NULL) {
+        for (int64_t i = 0; i < N * N; ++i) K[i] = 0.0;
+        for (int64_t i = 0; i < N; ++i) K[i * N + i] = theta[0] * theta[0];
+        return GPHIP_OK;
+    }
+    int rc = ensure_slots(h, 1);
+    if (rc) return rc;
+    h->fitted = false;
+    if (!stage_theta(h, 0, theta)) return fail(h, GPHIP_ERR_ARG, "non-finite or zero hyper-parameter");
+    HIPCHK(hipMemcpyAsync(h->dInvEll, h->hInvEll, (size_t)h->d * 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->dSlotp, h->hSlotp, SLOTP * 8, hipMemcpyHostToDevice, h->stream));
+    queue_build(h, 1);
+    std::vector<double> tmp((size_t)N * N);
+    HIPCHK(hipMemcpy2DAsync(tmp.data(), (size_t)N * 8, h->dA, (size_t)h->ld * 8, (size_t)N * 8, (size_t)N,
+                            hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    harvest(h);
+    // tmp is column-major with only the lower triangle valid: tmp[j*N + i], i >= j
+    for (int64_t j = 0; j < N; ++j)
+        for (int64_t i = j; i < N; ++i) K[i * N + j] = K[j * N + i] = tmp[j * N + i];
+    return GPHIP_OK;
+}
+
+int gphip_predict(gphip_handle h, const void* Xs, int64_t M, double* mean, double* var) {
+    if (!h || !Xs || !mean || !var) return fail(h, GPHIP_ERR_ARG, "null argument");
+    if (M < 1) return fail(h, GPHIP_ERR_DIM, "M < 1");
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (!h->fitted) return fail(h, GPHIP_ERR_STATE, "gphip_predict before a successful gphip_fit");
+    HIPCHK(hipSetDevice(h->device));
+    const double* X = static_cast<const double*>(Xs);
+    const int64_t d = h->d, Npad = h->Npad, ld = h->ld;
+    const int Nt = (int)h->Nt;
+    const int64_t MC = 2048;                                   // test points per chunk
+    const int64_t cap = (M < MC ? (M + TB - 1) / TB * TB : MC);
+    if (cap > h->vcap) {
+        (void)hipFree(h->dV); (void)hipFree(h->dXsT); (void)hipFree(h->dXsS); (void)hipFree(h->dMean); (void)hipFree(h->dVar);
+        h->dV = h->dXsT = h->dXsS = h->dMean = h->dVar = nullptr;
+        h->vcap = 0;
+        HIPCHK(hipMalloc(&h->dV, (size_t)cap * Npad * 8));
+        HIPCHK(hipMalloc(&h->dXsT, (size_t)cap * d * 8));
+        HIPCHK(hipMalloc(&h->dXsS, (size_t)cap * d * 8));
+        HIPCHK(hipMalloc(&h->dMean, (size_t)cap * 8));
+        HIPCHK(hipMalloc(&h->dVar, (size_t)cap * 8));
+        h->vcap = cap;
+    }
+    std::vector<double> xt;
+    for (int64_t m0 = 0; m0 < M; m0 += MC) {
+        const int64_t mc = (M - m0 < MC) ? (M - m0) : MC;
+        const int64_t mpad = (mc + TB - 1) / TB * TB;
+        const int Mt = (int)(mpad / TB);
+        xt.assign((size_t)d * mpad, 0.0);
+        for (int64_t i = 0; i < mc; ++i)
+            for (int64_t j = 0; j < d; ++j) xt[(size_t)j * mpad + i] = X[(m0 + i) * d + j];
+        HIPCHK(hipMemcpyAsync(h->dXsT, xt.data(), xt.size() * 8, hipMemcpyHostToDevice, h->stream));
+        const long tot = (long)d * mpad;
+        hipLaunchKernelGGL(k_scale, dim3((unsigned)((tot + 255) / 256), 1), dim3(256), 0, h->stream,
+                           h->dXsT, h->dXsS, h->dInvEll, (int)d, (int)mpad);
+        KBuildArgs a{};
+        a.out = h->dV; a.ld = mpad; a.bstride = 0;
+        a.xi = h->dXsS; a.xj = h->dXs; a.xi_bstride = a.xj_bstride = 0;
+        a.npad_i = (int)mpad; a.npad_j = (int)Npad; a.n_i = (int)mc; a.n_j = (int)h->N;
+        a.y = nullptr; a.slotp = h->dSlotp; a.d = (int)d; a.mode = 1; a.nt_i = Mt; a.nt_j = Nt;
+        launch_kbuild(h, a, dim3((unsigned)(Mt * Nt), 1));
+        // V <- V L^-T, right-looking over the 128-tile columns of L
+        for (int b = 0; b < Nt; ++b) {
+            hipLaunchKernelGGL(trsm128_kernel, dim3((unsigned)(mpad / 64), 1), dim3(64), (size_t)TB * 64 * 8,
+                               h->stream, h->dV + (long)b * TB * mpad, (long)mpad, 0L,
+                               h->dLr + (long)b * TB * TB, 0L);
+            if (b + 1 < Nt)
+                launch_gemm(h, 3, h->dV, mpad, 0, h->dV + (long)b * TB * mpad, mpad, 0,
+                            h->dA + (long)b * TB * ld, ld, 0, TB, 0, Mt, b + 1, Nt, 0, 1);
+        }
+        hipLaunchKernelGGL(predict_reduce_kernel, dim3((unsigned)((mc + 63) / 64)), dim3(64), 0, h->stream,
+                           h->dV, (long)mpad, (int)h->N, h->dA + Npad, ld, h->mu_fit, h->kappa_fit, (int)mc,
+                           h->dMean, h->dVar);
+        HIPCHK(hipMemcpyAsync(mean + m0, h->dMean, (size_t)mc * 8, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(var + m0, h->dVar, (size_t)mc * 8, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        HIPCHK(hipGetLastError());
+        harvest(h);
+    }
+    return GPHIP_OK;
+}
+
+int gphip_solve(gphip_handle h, const double* rhs, int64_t nrhs, double* out) {
+    (void)rhs; (void)nrhs; (void)out;
+    return fail(h, GPHIP_ERR_UNSUPPORTED, "gphip_solve: not implemented in this version");
+}
+
+int gphip_set_option(gphip_handle h, const char* name, double value) {
+    if (!h || !name) return GPHIP_ERR_ARG;
+    std::lock_guard<std::mutex> lk(h->mu);
+    const int v = (int)value;
+    if (!strcmp(name, "panel")) { if (v < 1 || v > 64) return fail(h, GPHIP_ERR_ARG, "panel out of range"); h->panel = v; }
+    else if (!strcmp(name, "profile")) h->profile = v;
+    else if (!strcmp(name, "xcd_swizzle")) h->swizzle = v;
+    else if (!strcmp(name, "max_slots")) { if (v < 1) return fail(h, GPHIP_ERR_ARG, "max_slots < 1"); h->max_slots = v; }
+    else return fail(h, GPHIP_ERR_ARG, "unknown option");
+    return GPHIP_OK;
+}
+
+int gphip_get_profile(gphip_handle h, int cls, double* ms, double* launches, double* flops, double* bytes) {
+    if (!h || cls < 0 || cls >= GPHIP_NCLASS) return GPHIP_ERR_ARG;
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (ms) *ms = h->acc_ms[cls];
+    if (launches) *launches = h->acc_n[cls];
+    if (flops) *flops = h->acc_flops[cls];
+    if (bytes) *bytes = h->acc_bytes[cls];
+    return GPHIP_OK;
+}
+
+int gphip_reset_profile(gphip_handle h) {
+    if (!h) return GPHIP_ERR_ARG;
+    std::lock_guard<std::mutex> lk(h->mu);
+    for (int c = 0; c < GPHIP_NCLASS; ++c) h->acc_ms[c] = h->acc_n[c] = h->acc_flops[c] = h->acc_bytes[c] = 0;
+    return GPHIP_OK;
+}
+
+int gphip_sync(gphip_handle h) {
+    if (!h) return GPHIP_ERR_ARG;
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return GPHIP_OK;
+}
+
+}  // extern "C"

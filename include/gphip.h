@@ -1,0 +1,108 @@
+/* gphip.h -- plain C ABI of the MI355X-native Gaussian-process likelihood / prediction path.
+ *
+ * Drop-in boundary for the GP hot path of ssmit1986/BayesianInference.  Every
+ * entry point replaces a Wolfram-Language call site of the reference
+ * (BayesianInference/Kernel/BayesianGaussianProcess.wl, cited as BGP:line):
+ *
+ *   gphip_create        data capture of defineGaussianProcess              BGP:228-238
+ *   gphip_loglik        the "LogLikelihoodFunction" closure theta -> R     BGP:295-306 (+181-199)
+ *   gphip_loglik_batch  the same closure mapped over a theta matrix        BS:276-298, BS:902-916
+ *   gphip_fit           matrixInverseAndDet[covarianceFunction[theta]]     BGP:308 (invCovFun)
+ *   gphip_predict       predictFromGaussianProcessInternal                 BGP:396-422
+ *   gphip_covariance    "CovarianceFunction" = compiledCovarianceMatrix    BGP:45-61
+ *   gphip_solve         "InverseCovarianceFunction"[theta]["Inverse"][b]   BGP:130-141
+ *   gphip_logdet        "InverseCovarianceFunction"[theta]["LogDet"]       BGP:126-128,139
+ *
+ * Conventions: every function returns an int status (0 = GPHIP_OK).  "K is not positive
+ * definite / hopelessly ill-conditioned" is NOT an error status: it is reported through *info
+ * (the WL shim / Python host then substitutes $MachineLogZero exactly like Catch["MatInv"],
+ * BGP:298-304).  theta and results are fp64 at the ABI.  Host buffers stay owned by the caller;
+ * X and y are copied to the device once and stay resident.  One in-flight call per handle
+ * (internally serialised); different handles may be used concurrently.
+ */
+#ifndef GPHIP_H
+#define GPHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gphip_ctx* gphip_handle;
+
+/* status codes */
+#define GPHIP_OK 0
+#define GPHIP_ERR_ARG 1        /* bad argument value / unknown id            (LIBRARY_TYPE_ERROR)      */
+#define GPHIP_ERR_DIM 2        /* shape mismatch (p, N, d, M)                (LIBRARY_DIMENSION_ERROR) */
+#define GPHIP_ERR_HIP 3        /* HIP runtime failure, see gphip_last_error  (LIBRARY_FUNCTION_ERROR)  */
+#define GPHIP_ERR_STATE 4      /* predict/solve/logdet before a successful gphip_fit                    */
+#define GPHIP_ERR_NODEVICE 5   /* no gfx950 device visible                                              */
+#define GPHIP_ERR_UNSUPPORTED 6
+
+/* *info values */
+#define GPHIP_INFO_OK 0
+#define GPHIP_INFO_NOT_SPD 1   /* pivot <= tol: singular or ill-conditioned K (LinearSolve::sing1/luc) */
+#define GPHIP_INFO_NAN 2       /* non-finite theta or result                                           */
+
+/* kernel_id: named covariance functions (exact forms in SURVEY.md §8d / DESIGN.md).
+ * theta layout: (l_1..l_nl, sigma_f, sigma_n [, mu]);  nl = 1 (isotropic) or d (ARD). */
+#define GPHIP_KERNEL_SE 0            /* sf^2 exp(-|p-q|^2 / (2 l^2))                                  */
+#define GPHIP_KERNEL_SE_ARD 1        /* sf^2 exp(-1/2 sum ((p_j-q_j)/l_j)^2)                          */
+#define GPHIP_KERNEL_MATERN52 2      /* sf^2 (1+sqrt5 s+5 s^2/3) exp(-sqrt5 s), s=|p-q|/l             */
+#define GPHIP_KERNEL_MATERN52_ARD 3  /* same with s = sqrt(sum ((p_j-q_j)/l_j)^2)                     */
+#define GPHIP_KERNEL_NULL 4          /* Function[0]: K = diag(sn^2) (BGP:25-27,156-159); theta=(sn[,mu]) */
+#define GPHIP_MEAN_ZERO 0            /* Function[0]  (BGP:168,255)                                    */
+#define GPHIP_MEAN_CONST 1           /* Function[mu], mu = last entry of theta                        */
+
+/* X: row-major N x d, y: length N, both fp64 (dtype must be 64 in this version).
+ * devices/ndev: HIP device ordinals this handle may use (NULL/0 = current device). */
+int gphip_create(const void* X, const void* y, int64_t N, int64_t d, int kernel_id, int mean_id,
+                 int dtype, const int* devices, int ndev, gphip_handle* out);
+int gphip_destroy(gphip_handle h);
+
+/* number of hyper-parameters p expected for this handle */
+int gphip_num_params(gphip_handle h, int* p);
+
+/* log p(y | X, theta) = -1/2 (N log 2pi + log det K + r^T K^-1 r).  *out undefined if *info != 0. */
+int gphip_loglik(gphip_handle h, const double* theta, int p, double* out, int* info);
+/* Theta: row-major B x p; out, info: length B. */
+int gphip_loglik_batch(gphip_handle h, const double* Theta, int B, int p, double* out, int* info);
+/* loglik plus its parts: parts[0]=log det K, parts[1]=r^T K^-1 r (for parity tests). */
+int gphip_loglik_parts(gphip_handle h, const double* theta, int p, double* out, double* parts,
+                       int* info);
+
+/* Factor K(theta) and keep L and L^-1 r resident for predict / solve / logdet. */
+int gphip_fit(gphip_handle h, const double* theta, int p, int* info);
+/* Xs: row-major M x d fp64.  mean[j] = m(x*_j) + k*_j^T K^-1 r ; var[j] = k(x*,x*) + sn^2 -
+ * k*_j^T K^-1 k*_j  (variance of a noisy observation, BGP:113,414-417; sd = sqrt(var)). */
+int gphip_predict(gphip_handle h, const void* Xs, int64_t M, double* mean, double* var);
+/* K: row-major N x N fp64 (full, both triangles), for parity tests at small N. */
+int gphip_covariance(gphip_handle h, const double* theta, int p, double* K);
+/* rhs, out: column-major N x nrhs (each right-hand side contiguous); out = K^-1 rhs. */
+int gphip_solve(gphip_handle h, const double* rhs, int64_t nrhs, double* out);
+int gphip_logdet(gphip_handle h, double* out);
+
+/* Options: "panel" (outer panel width in 128-tiles, default 4), "profile" (0/1),
+ * "xcd_swizzle" (0/1), "max_slots" (cap on concurrently resident batch matrices). */
+int gphip_set_option(gphip_handle h, const char* name, double value);
+
+/* Per-kernel-class timing, measured with HIP events on the handle's stream while "profile"=1.
+ * class: 0 kbuild, 1 potrf, 2 trsm, 3 gemm (in-panel), 4 gemm/syrk (trailing), 5 total eval.
+ * Returns accumulated milliseconds, launches, algorithmic flops and bytes since the last reset. */
+#define GPHIP_NCLASS 6
+int gphip_get_profile(gphip_handle h, int cls, double* ms, double* launches, double* flops,
+                      double* bytes);
+int gphip_reset_profile(gphip_handle h);
+
+/* Block until all work queued on the handle's stream is complete. */
+int gphip_sync(gphip_handle h);
+
+const char* gphip_last_error(gphip_handle h);   /* owned by the library */
+const char* gphip_version(void);
+int gphip_device_count(int* n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPHIP_H */

@@ -1,0 +1,161 @@
+"""GPU parity tests proper: the HIP path, called through the C ABI (ctypes), against the CPU
+oracle and the committed golden vectors.  Tolerance: fp64 log-likelihood, log-det,
+quadratic form, predictive mean and sd to 1e-8 relative (abs floor 1e-8 * N near zero)."""
+import os
+
+import numpy as np
+import pytest
+
+from bayesianinference_amd import _lib, synthetic as syn
+from oracle import gp_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-8
+
+
+def close(a, b, n=1, rtol=RTOL):
+    return abs(a - b) <= rtol * max(abs(b), float(n))
+
+
+GOLD = ["f1_se_n512_d1", "f2_se_ard_n256_d8", "f2_matern52_ard_n256_d8", "f2_matern52_const_n333_d3"]
+
+
+@pytest.mark.parametrize("name", GOLD)
+def test_loglik_matches_golden(golden_dir, name):
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    h = _lib.Handle(g["X"], g["y"], str(g["kernel"]), str(g["mean"]))
+    n = h.N
+    for i, th in enumerate(g["thetas"]):
+        ll, ld, qd, info = h.loglik_parts(th)
+        assert info == 0
+        assert close(ld, float(g["logdet"][i]), n), (i, ld, g["logdet"][i])
+        assert close(qd, float(g["quad"][i]), n), (i, qd, g["quad"][i])
+        assert close(ll, float(g["loglik"][i]), n), (i, ll, g["loglik"][i])
+    out, info = h.loglik_batch(g["thetas"])
+    assert np.all(info == 0)
+    np.testing.assert_allclose(out, g["loglik"], rtol=RTOL, atol=RTOL * n)
+    h.close()
+
+
+@pytest.mark.parametrize("name", GOLD)
+def test_predict_matches_golden(golden_dir, name):
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    h = _lib.Handle(g["X"], g["y"], str(g["kernel"]), str(g["mean"]))
+    for i in range(g["pred_mu"].shape[0]):
+        assert h.fit(g["thetas"][i]) == 0
+        mu, var = h.predict(g["Xs"])
+        np.testing.assert_allclose(mu, g["pred_mu"][i], rtol=1e-7, atol=1e-8)
+        np.testing.assert_allclose(np.sqrt(var), g["pred_sd"][i], rtol=1e-7, atol=1e-9)
+    h.close()
+
+
+@pytest.mark.parametrize("kernel,d,n", [("se", 1, 200), ("se_ard", 8, 300), ("matern52_ard", 5, 129),
+                                        ("matern52", 2, 128), ("se_ard", 11, 77)])
+def test_covariance_matches_oracle(kernel, d, n):
+    X, y = syn.make_dataset(n, d)
+    h = _lib.Handle(X, y, kernel)
+    for th in syn.theta_batch(3, kernel, d):
+        K = h.covariance(th)
+        Ko = orc.covariance_matrix(kernel, th, X)
+        np.testing.assert_allclose(K, Ko, rtol=5e-15 * 200, atol=1e-300)
+    h.close()
+
+
+def test_hp_mpmath_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, "hp_mpmath.npz"))
+    for key, kernel in (("se_ard_n24", "se_ard"), ("matern52_ard_n48", "matern52_ard"), ("se_n32", "se")):
+        h = _lib.Handle(g[f"{key}_X"], g[f"{key}_y"], kernel)
+        ll, ld, qd, info = h.loglik_parts(g[f"{key}_theta"])
+        assert info == 0
+        assert close(ll, float(g[f"{key}_loglik"]), h.N, 1e-10)
+        assert close(ld, float(g[f"{key}_logdet"]), h.N, 1e-10)
+        assert h.fit(g[f"{key}_theta"]) == 0
+        mu, var = h.predict(g[f"{key}_Xs"])
+        np.testing.assert_allclose(mu, g[f"{key}_mu"], rtol=1e-9, atol=1e-11)
+        np.testing.assert_allclose(np.sqrt(var), g[f"{key}_sd"], rtol=1e-9)
+        h.close()
+
+
+def test_f3_scalars_medium_sizes(golden_dir):
+    g = np.load(os.path.join(golden_dir, "f3_scalars.npz"))
+    for i in range(len(g["n"])):
+        n, d, kernel = int(g["n"][i]), int(g["d"][i]), str(g["kernel"][i])
+        X, y = syn.make_dataset(n, d)
+        assert float(X.sum()) == float(g["xsum"][i])
+        h = _lib.Handle(X, y, kernel)
+        ll, ld, qd, info = h.loglik_parts(syn.default_theta(kernel, d))
+        assert info == 0
+        assert close(ld, float(g["logdet"][i]), n) and close(qd, float(g["quad"][i]), n)
+        assert close(ll, float(g["loglik"][i]), n)
+        h.close()
+
+
+def test_closed_forms_and_edge_sizes():
+    # N = 1 (BGP:181-199 closed form), N = 2, N = 127/128/129 around the tile edge
+    h = _lib.Handle([[0.3]], [1.7], "se", "const")
+    ll, info = h.loglik([0.8, 1.3, 0.4, 0.25])
+    v = 1.3 ** 2 + 0.4 ** 2
+    assert info == 0 and close(ll, -0.5 * (np.log(2 * np.pi) + np.log(v) + (1.7 - 0.25) ** 2 / v))
+    h.close()
+    for n in (2, 127, 128, 129, 257):
+        X, y = syn.make_dataset(n, 3)
+        th = np.array([0.7, 1.1, 0.9, 1.3, 0.2])
+        h = _lib.Handle(X, y, "se_ard")
+        ll, info = h.loglik(th)
+        assert info == 0 and close(ll, orc.log_likelihood("se_ard", th, X, y), n)
+        h.close()
+
+
+def test_null_kernel_diagonal_path():
+    X, y = syn.make_dataset(40, 2)
+    h = _lib.Handle(X, y, "null", "const")
+    ll, info = h.loglik([0.7, 0.1])
+    assert info == 0 and close(ll, orc.log_likelihood("null", [0.7, 0.1], X, y, "const"), 40)
+    h.close()
+
+
+def test_sentinel_cases(golden_dir):
+    g = np.load(os.path.join(golden_dir, "f4_sentinel.npz"))
+    for name, want in (("dup", 1), ("ill", 1), ("ok", 0)):
+        h = _lib.Handle(g[f"{name}_X"], g[f"{name}_y"], "se_ard")
+        ll, info = h.loglik(g[f"{name}_theta"])
+        assert (info != 0) == (want != 0), name
+        if want == 0:
+            assert close(ll, float(g["ok_loglik"]), h.N)
+        h.close()
+    # non-finite / zero hyper-parameters never raise: info = NaN (closure must be total, BS:276-298)
+    X, y = syn.make_dataset(64, 2)
+    h = _lib.Handle(X, y, "se_ard")
+    for th in ([np.nan, 1, 1, 1], [0.0, 1, 1, 1], [1, 1, np.inf, 1]):
+        _, info = h.loglik(th)
+        assert info == _lib.INFO_NAN
+    h.close()
+
+
+def test_panel_width_and_swizzle_invariance():
+    X, y = syn.make_dataset(1100, 4)
+    th = syn.default_theta("se_ard", 4)
+    want = orc.log_likelihood("se_ard", th, X, y)
+    h = _lib.Handle(X, y, "se_ard")
+    for panel in (1, 2, 3, 4, 8):
+        for swz in (0, 1):
+            h.set_option("panel", panel)
+            h.set_option("xcd_swizzle", swz)
+            ll, info = h.loglik(th)
+            assert info == 0 and close(ll, want, 1100), (panel, swz, ll, want)
+    h.close()
+
+
+def test_argument_errors():
+    X, y = syn.make_dataset(10, 2)
+    h = _lib.Handle(X, y, "se_ard")
+    with pytest.raises(_lib.GphipError) as e:
+        h.loglik([1.0, 1.0])
+    assert e.value.status == 2
+    with pytest.raises(_lib.GphipError) as e:
+        h.predict(X)                       # not fitted
+    assert e.value.status == 4
+    h.close()
+    with pytest.raises(_lib.GphipError):
+        _lib.Handle(X, y[:5], "se_ard")
