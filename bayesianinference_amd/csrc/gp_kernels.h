@@ -23,6 +23,8 @@ constexpr int TB = 128;         // tile edge
 constexpr int SLOTP = 8;        // doubles of per-slot scalars: sf2, sn2, mu, pivot_tol, bad_theta
 
 typedef double d4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_void;
 
 // ---------------------------------------------------------------------------------------------
 // exp(x) for x <= 0, fp64, no hardware transcendental on gfx950: Cody-Waite reduction by ln2,
@@ -297,7 +299,7 @@ __global__ __launch_bounds__(64) void trsm128_kernel(double* __restrict__ Xbase,
 //
 // 256 threads = 4 waves in a 2(i) x 2(j) arrangement, 64x64 per wave = 4x4 MFMA tiles, 64 fp64
 // accumulators (128 VGPRs) per lane.  K is consumed in stages of 16 through double-buffered LDS
-// (register-staged global loads issued a stage ahead).  Both operand tiles are stored [k][row]
+// (LDS-DMA global_load_lds_dwordx4 issued a stage ahead).  Both operand tiles are stored [k][row]
 // with a padded leading dimension of 144 doubles so the MFMA fragment read
 // (lane -> row = lane&15, k = lane>>4) is ds_read_b64 bank-conflict free.
 //
@@ -349,25 +351,23 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
 
     const double* Ag = g.A + (long)slot * g.a_bstride + (long)ti * TB;
     const double* Bg = g.B + (long)slot * g.b_bstride + (long)tj * TB;
-    // staging: thread loads rows (2*lane, 2*lane+1) of k-columns wave, wave+4, wave+8, wave+12
-    double2 ra[4], rb[4];
+    // Staging: LDS-DMA (global_load_lds_dwordx4), no staging registers and no ds_write pass.
+    // One wave-instruction moves one k-column of a tile: 64 lanes x 16 B = 128 rows = 1 KiB,
+    // landing lane-linear at a wave-uniform LDS base (column kk at kk*LDT doubles, so the
+    // padding sits between instructions).  Wave w moves columns w, w+4, w+8, w+12 of both tiles.
+    const int uw = __builtin_amdgcn_readfirstlane(wave);
     const int srow = 2 * lane;
-    auto gload = [&](int kb) {
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const long kcol = (long)kb * GK + wave + 4 * s;
-            ra[s] = *reinterpret_cast<const double2*>(Ag + kcol * g.lda + srow);
-            rb[s] = *reinterpret_cast<const double2*>(Bg + kcol * g.ldb + srow);
-        }
-    };
-    auto lstore = [&](int st) {
+    auto stage = [&](int kb, int st) {
         double* Is = smem + st * (2 * GK * LDT);
         double* Js = Is + GK * LDT;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            const int kk = wave + 4 * s;
-            *reinterpret_cast<double2*>(Is + kk * LDT + srow) = ra[s];
-            *reinterpret_cast<double2*>(Js + kk * LDT + srow) = rb[s];
+            const int kk = uw + 4 * s;
+            const long kcol = (long)kb * GK + kk;
+            __builtin_amdgcn_global_load_lds((glb_void*)(Ag + kcol * g.lda + srow),
+                                             (lds_void*)(Is + kk * LDT), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_void*)(Bg + kcol * g.ldb + srow),
+                                             (lds_void*)(Js + kk * LDT), 16, 0, 0);
         }
     };
 
@@ -378,13 +378,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
         for (int y = 0; y < 4; ++y) acc[x][y] = (d4){0.0, 0.0, 0.0, 0.0};
 
     const int nk = g.K / GK;
-    gload(0);
-    lstore(0);
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     const int foff = (lane >> 4) * LDT + (lane & 15);
     for (int kb = 0; kb < nk; ++kb) {
         const int cur = kb & 1;
-        if (kb + 1 < nk) gload(kb + 1);
+        if (kb + 1 < nk) stage(kb + 1, cur ^ 1);       // DMA of the next stage flies under the MFMAs
         const double* Is = smem + cur * (2 * GK * LDT) + wi * 64 + foff;
         const double* Js = smem + cur * (2 * GK * LDT) + GK * LDT + wj * 64 + foff;
 #pragma unroll
@@ -401,7 +401,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
                 for (int y = 0; y < 4; ++y)
                     acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(fj[x], fi[y], acc[x][y], 0, 0, 0);
         }
-        if (kb + 1 < nk) lstore(cur ^ 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
 

@@ -1,0 +1,157 @@
+"""bench.py -- GP log-marginal-likelihood evaluations per second (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--n 32768] [--d 8]
+
+A "step" is one pass of the hot path over one batch of synthetic input: one evaluation of
+theta -> log p(y | X, theta) (kernel-matrix build + Cholesky + log|K| + quadratic form) at
+N=32768, d=8, SE-ARD, fp64, with X and y already resident in HBM (`gphip_create` ran before the
+timed region).  Every step uses a different theta (nested sampling never repeats a point).
+
+Multi-GPU (N>1, launched by torch.distributed.run, one rank per GPU): the path shards over theta
+-- independent likelihood evaluations, exactly how the reference's callers consume the closure
+(BS:902-916 sweep, BS:1349 replicas) -- so ranks evaluate disjoint theta with NO data-path
+collective ("weak" scaling); torch.distributed (RCCL) is used only for the timing barrier and the
+max-over-ranks reduction.
+
+One JSON line on rank 0, with `roofline` (dominant kernel = trailing SYRK on fp64 MFMA, timed
+with HIP events on the library's own stream, inside the timed region) and `cpu_baseline`
+(the CPU oracle = LU restatement of the reference algorithm, bounded sample, rank 0 at N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FP64_MFMA_PEAK_TFLOPS = 78.6      # 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz (v_mfma_f64_16x16x4_f64)
+
+
+def cpu_baseline(n_full: int, d: int, sample_n: int = 4096, reps: int = 2) -> dict:
+    """Times the CPU oracle (scipy LAPACK LU, the algorithm LinearSolve uses) on a bounded sample
+    and scales it to the metric's unit (evals/s at n_full) with the cubic cost of the factorisation."""
+    from oracle import gp_oracle as orc
+    from bayesianinference_amd import synthetic as syn
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    X, y = syn.make_dataset(sample_n, d)
+    th = syn.default_theta("se_ard", d)
+    orc.log_likelihood("se_ard", th, X[:512], y[:512])
+    t0 = time.perf_counter()
+    for i in range(reps):
+        orc.log_likelihood("se_ard", th * (1.0 + 0.01 * i), X, y)
+    dt = (time.perf_counter() - t0) / reps
+    scale = (n_full / sample_n) ** 3
+    return {"value": 1.0 / (dt * scale), "unit": "evals/s", "cores": int(threads), "kind": "port",
+            "sample": f"CPU oracle (scipy dgetrf/dgetrs LU restatement of BGP:29-43,130-141,181-199; not "
+                      f"Mathematica) timed at N={sample_n} d={d}: {dt:.3f} s/eval x{reps}, scaled by "
+                      f"(N/{sample_n})^3={scale:.0f} to N={n_full}"}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n", type=int, default=32768)
+    ap.add_argument("--d", type=int, default=8)
+    ap.add_argument("--panel", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        args.gpus = world
+
+    import torch
+    from bayesianinference_amd import _lib, synthetic as syn
+
+    if not torch.cuda.is_available() or _lib.device_count() < 1:
+        raise SystemExit("bench.py needs an MI355X (gfx950): the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_
+        dist = dist_
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    n, d = args.n, args.d
+    X, y = syn.make_dataset(n, d)                      # every rank regenerates the same data
+    h = _lib.Handle(X, y, "se_ard", device=local_rank)
+    if args.panel:
+        h.set_option("panel", args.panel)
+    base = syn.default_theta("se_ard", d)
+    total_steps = args.warmup + args.steps
+    # disjoint theta per rank and step: jitter the length-scales by < 5 %
+    jit = syn.uniform(syn.STREAM_THETA, 1000 + rank * total_steps * (d + 2), total_steps * (d + 2))
+    thetas = base[None, :] * (1.0 + 0.05 * (jit.reshape(total_steps, d + 2) - 0.5))
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        h.loglik(thetas[i])
+    h.set_option("profile", 1)                         # events around the trailing SYRK launches only
+    h.reset_profile()
+    barrier()
+    t0 = time.perf_counter()
+    vals = []
+    for i in range(args.warmup, total_steps):
+        ll, info = h.loglik(thetas[i])
+        vals.append((ll, info))
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    prof = h.profile()
+    bad = [v for v in vals if v[1] != 0 or not np.isfinite(v[0])]
+    if bad:
+        raise SystemExit(f"bench: evaluation failed: {bad[:3]}")
+
+    if rank == 0:
+        syrk = prof["syrk_trailing"]
+        achieved = syrk["flops"] / (syrk["ms"] * 1e-3) / 1e12 if syrk["ms"] > 0 else 0.0
+        evals = args.steps * world
+        chol_flops = n ** 3 / 3.0
+        out = {
+            "metric": "GP log-marg-lik evals/sec at N=32768, d=8; Cholesky TFLOP/s vs fp64 peak",
+            "value": evals / dt, "unit": "evals/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"SE-ARD GP log marginal likelihood, N={n} d={d} fp64, one theta per "
+                                   f"step per GPU (kernel build + Cholesky + log|K| + quad form)",
+                       "N": n, "d": d, "kernel": "se_ard", "parallelism": f"theta-sharded x{world}"},
+            "cholesky_tflops_per_gpu": chol_flops * args.steps / dt / 1e12,
+            "roofline": {"bound": "mfma", "kernel": "gemm_nt_kernel (trailing SYRK, v_mfma_f64_16x16x4_f64)",
+                         "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
+                         "launches": int(syrk["launches"]), "avg_launch_ms": syrk["ms"] / max(syrk["launches"], 1),
+                         "traffic": None},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(n, d)
+        print(json.dumps(out), flush=True)
+    h.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
