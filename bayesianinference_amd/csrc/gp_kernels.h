@@ -3,9 +3,10 @@
 //   k_scale        xs = x / l                       (prologue of K1)
 //   kbuild_kernel  K1/K7: pairwise kernel matrix tiles, lower triangle, straight into the
 //                  Cholesky workspace (BGP:29-43 covarianceMatrix; BGP:100-109 cross form)
-//   potrf128       K2a + K3: 128x128 diagonal-block Cholesky in LDS, log-det partial, SPD test
-//   trsm128        K2b: X L^T = A panel solve (also carries r -> z = L^-1 r, K4)
-//   gemm_nt        K2c: C -= A B^T on fp64 MFMA (v_mfma_f64_16x16x4_f64), SYRK/GEMM trailing update
+//   potrf128       K2a + K3: 128x128 diagonal-block Cholesky + triangular inverse in LDS (MFMA),
+//                  log-det partial, SPD test
+//   gemm_nt        K2b/K2c on fp64 MFMA (v_mfma_f64_16x16x4_f64): mode 1 = panel solve X <- X W^T
+//                  (also carries r -> z = L^-1 r, K4), mode 0 = C -= A B^T SYRK/GEMM trailing update
 //   finalize       log det = 2 sum log L_ii, quad = |z|^2, info
 //   predict_reduce K9/K10 epilogue: mu* and var* from V = k*^T L^-T and z
 //
@@ -197,101 +198,221 @@ __global__ __launch_bounds__(256) void kbuild_kernel(KBuildArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// potrf128: Cholesky of one 128x128 diagonal block, entirely in LDS (128 KiB, column-major).
-// Right-looking, column by column.  Writes L back in place, a row-major packed copy Lr (rows of
-// L contiguous, for the scalar-load panel solve), the block's sum(log L_ii) and the SPD verdict:
-// pivot <= tol (tol = 64 eps (sf2+sn2)) or NaN -> info = NOT_SPD (stands for LinearSolve::sing1/
-// ::luc -> Throw "MatInv", BGP:131-135).
+// potrf128: Cholesky of one 128x128 diagonal block AND its triangular inverse, in LDS.
+//
+// LDS image Ls[c*PLD + r] (column-major, PLD = 144 so MFMA fragment reads are conflict free).
+// Factor phase, 8 panels of 16 columns:
+//   (a) wave 0 factors the 16x16 diagonal block in registers (lane = row, v_readlane broadcasts),
+//   (b) one thread per row below solves its 16 panel entries against L_pp,
+//   (c) all 4 waves apply the rank-16 trailing update on v_mfma_f64_16x16x4_f64.
+// Then L goes back to HBM, and W = L^-1 is formed in place (LAPACK dtrtri order, 16x16 blocks,
+// MFMA products) and stored to the Winv workspace: the panel solve below the block is then a
+// plain MFMA GEMM  X <- A W^T  (gemm_nt mode 1).
+// SPD verdict: pivot <= tol (tol = 64 eps (sf2+sn2)) or NaN -> info = NOT_SPD (stands for
+// LinearSolve::sing1/::luc -> Throw "MatInv", BGP:131-135).
 // ---------------------------------------------------------------------------------------------
+constexpr int PLD = 144;
+
+__device__ __forceinline__ double readlane_d(double v, int src) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, src);
+    hi = __builtin_amdgcn_readlane(hi, src);
+    return __hiloint2double(hi, lo);
+}
+
 __global__ __launch_bounds__(256) void potrf128_kernel(double* __restrict__ Abase, long ld,
                                                        long bstride, int b,
-                                                       double* __restrict__ Lr, double* __restrict__ partial,
+                                                       double* __restrict__ Winv, double* __restrict__ partial,
                                                        int nt, int* __restrict__ info,
                                                        const double* __restrict__ slotp) {
-    extern __shared__ double Ls[];            // Ls[c*128 + r]
+    extern __shared__ double Ls[];            // [128][PLD] + dinv[128] + red[2]
+    double* dinv = Ls + TB * PLD;
+    double* red = dinv + TB;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
     const int slot = blockIdx.x;
     double* Ad = Abase + (long)slot * bstride + (long)b * TB * (ld + 1);
     for (int c = wave; c < TB; c += 4)
-        *reinterpret_cast<double2*>(&Ls[c * TB + 2 * lane]) =
+        *reinterpret_cast<double2*>(&Ls[c * PLD + 2 * lane]) =
             *reinterpret_cast<const double2*>(Ad + (long)c * ld + 2 * lane);
     const double tol = slotp[(long)slot * SLOTP + 3];
     bool bad = false;
-    const int r = tid & 127, half = tid >> 7;
-    // One barrier per column: the scaled column j is kept in registers (ljr) and written to LDS
-    // at the top of step j+1, when no thread reads column j any more; during step j every thread
-    // reads the still-unscaled column j and applies 1/l itself.
-    double pljr = 0.0, pl = 0.0;
-    for (int j = 0; j < TB; ++j) {
-        __syncthreads();
-        if (j > 0 && half == 0) {
-            if (r > j - 1) Ls[(j - 1) * TB + r] = pljr;
-            if (r == j - 1) Ls[(j - 1) * TB + r] = pl;
+    __syncthreads();
+
+    // ------------------------------ factor phase ------------------------------
+    for (int p = 0; p < 8; ++p) {
+        const int j0 = 16 * p;
+        if (wave == 0) {                      // (a) 16x16 diagonal block, lane l15 owns row j0+l15
+            double a[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) a[c] = Ls[(j0 + c) * PLD + j0 + l15];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                double dj = readlane_d(a[j], j);
+                if (!(dj > tol)) { bad = true; dj = 1.0; }
+                const double l = __builtin_sqrt(dj);
+                const double rs = 1.0 / l;
+                a[j] = (l15 == j) ? l : a[j] * rs;
+#pragma unroll
+                for (int c = j + 1; c < 16; ++c) {
+                    const double sc = readlane_d(a[j], c);
+                    a[c] = __builtin_fma(-a[j], sc, a[c]);
+                }
+                if (lane == 0) dinv[j0 + j] = rs;
+            }
+            if (lane < 16) {
+#pragma unroll
+                for (int c = 0; c < 16; ++c)
+                    if (c <= l15) Ls[(j0 + c) * PLD + j0 + l15] = a[c];
+            }
         }
-        double dj = Ls[j * TB + j];
-        if (!(dj > tol)) { bad = true; dj = 1.0; }
-        const double l = __builtin_sqrt(dj);
-        const double inv = 1.0 / l;
-        const double ljr = (r > j) ? Ls[j * TB + r] * inv : 0.0;
-        for (int c = j + 1 + half; c <= r; c += 2)
-            Ls[c * TB + r] = __builtin_fma(-ljr, Ls[j * TB + c] * inv, Ls[c * TB + r]);
-        pljr = ljr;
-        pl = l;
+        __syncthreads();
+        if (p == 7) break;
+        if (tid < TB - j0 - 16) {             // (b) rows below: x L_pp^T = a, one row per thread
+            const int r = j0 + 16 + tid;
+            double x[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) x[c] = Ls[(j0 + c) * PLD + r];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                double sacc = x[c];
+#pragma unroll
+                for (int k = 0; k < c; ++k) sacc = __builtin_fma(-x[k], Ls[(j0 + k) * PLD + j0 + c], sacc);
+                x[c] = sacc * dinv[j0 + c];
+            }
+#pragma unroll
+            for (int c = 0; c < 16; ++c) Ls[(j0 + c) * PLD + r] = x[c];
+        }
+        __syncthreads();
+        {                                      // (c) trailing update C -= X X^T on MFMA
+            const int t = 7 - p, ntile = t * (t + 1) / 2;
+            for (int tt = wave; tt < ntile; tt += 4) {
+                int u = 0;
+                while ((u + 1) * (u + 2) / 2 <= tt) ++u;
+                const int v = tt - u * (u + 1) / 2;
+                const int ri = (p + 1 + u) * 16, ci = (p + 1 + v) * 16;
+                d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const double fa = Ls[(j0 + 4 * kk + l4) * PLD + ci + l15];
+                    const double fb = Ls[(j0 + 4 * kk + l4) * PLD + ri + l15];
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fa, fb, acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Ls[(ci + l4 + 4 * r) * PLD + ri + l15] -= acc[r];
+            }
+        }
+        __syncthreads();
     }
-    __syncthreads();
-    if (tid == TB - 1) Ls[(TB - 1) * TB + (TB - 1)] = pl;
-    __syncthreads();
-    // write back: lower triangle incl. diagonal (upper part of the block is never read again)
+
+    // L back to HBM (lower triangle incl. diagonal; the block's upper part is never read)
     for (int c = wave; c < TB; c += 4) {
-        double2 v = *reinterpret_cast<const double2*>(&Ls[c * TB + 2 * lane]);
+        const double2 v = *reinterpret_cast<const double2*>(&Ls[c * PLD + 2 * lane]);
         *reinterpret_cast<double2*>(Ad + (long)c * ld + 2 * lane) = v;
     }
-    double* Lrs = Lr + ((long)slot * nt + b) * TB * TB;       // Lrs[row*128 + k]
-    for (int idx = tid; idx < TB * TB; idx += 256) {
-        const int row = idx >> 7, k = idx & 127;
-        Lrs[idx] = (k <= row) ? Ls[k * TB + row] : 0.0;
+    {   // sum log L_jj = -sum log dinv_j
+        double lg = 0.0;
+        if (tid < TB) lg = -log(dinv[tid]);
+        for (int off = 32; off > 0; off >>= 1) lg += __shfl_down(lg, off);
+        if (tid < TB && lane == 0) red[wave] = lg;
     }
-    // sum of log diag: wave 0 + wave 1 reduce 128 values
-    double lg = 0.0;
-    if (tid < TB) lg = log(Ls[tid * TB + tid]);
-    for (int off = 32; off > 0; off >>= 1) lg += __shfl_down(lg, off);
-    double* red = Ls + TB * TB;             // 2 spare doubles behind the block (dynamic LDS)
-    if (tid < TB && lane == 0) red[wave] = lg;
-    __syncthreads();
+
+    // ------------------------------ inverse phase ------------------------------
+    {   // (i) the eight 16x16 diagonal inverses: thread = (block, column)
+        double w[16];
+        const int blk = tid >> 4, c = tid & 15, j0 = blk * 16;
+        if (tid < TB) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                double sacc = 0.0;
+#pragma unroll
+                for (int k = 0; k < i; ++k) sacc = __builtin_fma(Ls[(j0 + k) * PLD + j0 + i], w[k], sacc);
+                w[i] = (i < c) ? 0.0 : ((i == c) ? dinv[j0 + i] : -sacc * dinv[j0 + i]);
+            }
+        }
+        __syncthreads();
+        if (tid < TB) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                if (i >= c) Ls[(j0 + c) * PLD + j0 + i] = w[i];
+        }
+        __syncthreads();
+    }
+    for (int pb = 6; pb >= 0; --pb) {          // (ii) block column pb, rows q = pb+1..7
+        const int c0 = pb * 16, t = 7 - pb;
+        // step 1: T'_r = T_r W_pp  (W_pp lower triangular: mask k < j)
+        d4 t1[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            t1[s] = (d4){0.0, 0.0, 0.0, 0.0};
+            const int rr = wave + 4 * s;
+            if (rr < t) {
+                const int r0 = (pb + 1 + rr) * 16;
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const int k = 4 * kk + l4;
+                    const double fa = Ls[(c0 + k) * PLD + r0 + l15];                    // T_r(i=l15, k)
+                    const double fb = (k >= l15) ? Ls[(c0 + l15) * PLD + c0 + k] : 0.0;   // W_pp(k, j=l15)
+                    t1[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa, fb, t1[s], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int rr = wave + 4 * s;
+            if (rr < t) {
+                const int r0 = (pb + 1 + rr) * 16;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Ls[(c0 + l15) * PLD + r0 + l4 + 4 * r] = t1[s][r];
+            }
+        }
+        __syncthreads();
+        // step 2: W_q,pb = - sum_{r=pb+1..q} W_qr T'_r   (W_qq lower triangular: mask k > i)
+        d4 t2[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            t2[s] = (d4){0.0, 0.0, 0.0, 0.0};
+            const int qq = wave + 4 * s;
+            if (qq < t) {
+                const int q = pb + 1 + qq, q0 = q * 16;
+                for (int r = pb + 1; r <= q; ++r) {
+                    const int r0 = r * 16;
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) {
+                        const int k = 4 * kk + l4;
+                        double fa = Ls[(r0 + k) * PLD + q0 + l15];                       // W_qr(i=l15, k)
+                        if (r == q && k > l15) fa = 0.0;
+                        const double fb = Ls[(c0 + l15) * PLD + r0 + k];                  // T'_r(k, j=l15)
+                        t2[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa, fb, t2[s], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int qq = wave + 4 * s;
+            if (qq < t) {
+                const int q0 = (pb + 1 + qq) * 16;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Ls[(c0 + l15) * PLD + q0 + l4 + 4 * r] = -t2[s][r];
+            }
+        }
+        __syncthreads();
+    }
+    // W to the workspace, dense column-major 128x128 with an explicit zero upper triangle
+    double* Wg = Winv + ((long)slot * nt + b) * TB * TB;
+    for (int c = wave; c < TB; c += 4) {
+        double2 v = *reinterpret_cast<const double2*>(&Ls[c * PLD + 2 * lane]);
+        if (2 * lane < c) v.x = 0.0;
+        if (2 * lane + 1 < c) v.y = 0.0;
+        *reinterpret_cast<double2*>(Wg + c * TB + 2 * lane) = v;
+    }
     if (tid == 0) {
         partial[(long)slot * nt + b] = red[0] + red[1];
         if (bad) info[slot] = 1;
     }
-}
-
-// ---------------------------------------------------------------------------------------------
-// trsm128: X <- X L^-T for a 128-wide panel, 64 rows per single-wave workgroup.  Row-per-lane
-// forward substitution; L rows come from the packed row-major copy through wave-uniform
-// (scalar-cache) loads, X lives in LDS as [c][row].
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void trsm128_kernel(double* __restrict__ Xbase, long ldx,
-                                                     long xbstride, const double* __restrict__ Lr,
-                                                     long lbstride) {
-    extern __shared__ double Xs[];            // Xs[c*64 + lane]
-    const int lane = threadIdx.x;
-    const int slot = blockIdx.y;
-    double* X = Xbase + (long)slot * xbstride + (long)blockIdx.x * 64;
-    const double* L = Lr + (long)slot * lbstride;
-    for (int c = 0; c < TB; ++c) Xs[c * 64 + lane] = X[(long)c * ldx + lane];
-    for (int c = 0; c < TB; ++c) {
-        const double* Lc = L + c * TB;
-        double a0 = Xs[c * 64 + lane], a1 = 0.0, a2 = 0.0, a3 = 0.0;
-        int k = 0;
-        for (; k + 4 <= c; k += 4) {
-            a0 = __builtin_fma(-Xs[(k + 0) * 64 + lane], Lc[k + 0], a0);
-            a1 = __builtin_fma(-Xs[(k + 1) * 64 + lane], Lc[k + 1], a1);
-            a2 = __builtin_fma(-Xs[(k + 2) * 64 + lane], Lc[k + 2], a2);
-            a3 = __builtin_fma(-Xs[(k + 3) * 64 + lane], Lc[k + 3], a3);
-        }
-        for (; k < c; ++k) a0 = __builtin_fma(-Xs[k * 64 + lane], Lc[k], a0);
-        Xs[c * 64 + lane] = ((a0 + a1) + (a2 + a3)) / Lc[c];
-    }
-    for (int c = 0; c < TB; ++c) X[(long)c * ldx + lane] = Xs[c * 64 + lane];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -320,6 +441,8 @@ struct GemmArgs {
     int nrect;                                   // tiles in the full-height rectangle part
     int ntiles;
     int swizzle;                                 // XCD-aware block remap
+    int mode;                                    // 0: C -= A B^T ; 1: C = A B^T (in-place panel solve
+                                                 //    X <- X W^T: A aliases C, one column tile)
 };
 
 __device__ __forceinline__ void gemm_tile_decode(const GemmArgs& g, int t, int& ti, int& tj) {
@@ -414,7 +537,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
         for (int r = 0; r < 4; ++r) {
             double* cp = Cg + (long)(x * 16 + 4 * r) * g.ldc;
 #pragma unroll
-            for (int y = 0; y < 4; ++y) cp[y * 16] -= acc[x][y][r];
+            for (int y = 0; y < 4; ++y) {
+                if (g.mode == 0) cp[y * 16] -= acc[x][y][r];
+                else cp[y * 16] = acc[x][y][r];
+            }
         }
 }
 

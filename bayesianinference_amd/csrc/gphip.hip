@@ -4,7 +4,8 @@
 //   k_scale + kbuild      lower-triangle tiles of K(theta) + nugget, plus r^T as an extra row
 //   two-level right-looking Cholesky:
 //       for each outer panel of `panel` 128-tiles:
-//           for each 128-tile column b in the panel:  potrf128(b); trsm128(rows below b);
+//           for each 128-tile column b in the panel:  potrf128(b) [L_bb and W_b = L_bb^-1];
+//                                                     gemm_nt mode 1: X <- X W_b^T below b;
 //                                                     gemm_nt(K=128) on the rest of the panel
 //           gemm_nt(K=panel*128) trailing SYRK on everything to the right (fp64 MFMA, dominant)
 //   finalize              log det, quadratic form (bordered row), info
@@ -27,6 +28,7 @@ namespace {
 
 constexpr double LOG_TWO_PI = 1.8378770664093454835606594728112;
 constexpr double PIVOT_TOL_REL = 64.0 * 2.220446049250313e-16;
+constexpr size_t POTRF_LDS = (size_t)(TB * PLD + TB + 2) * 8;
 
 struct ProfRec {
     int cls;
@@ -46,7 +48,7 @@ struct gphip_ctx {
     double *dXt = nullptr, *dY = nullptr;
     // batch workspace
     int slots = 0;
-    double *dA = nullptr, *dXs = nullptr, *dInvEll = nullptr, *dSlotp = nullptr, *dLr = nullptr,
+    double *dA = nullptr, *dXs = nullptr, *dInvEll = nullptr, *dSlotp = nullptr, *dW = nullptr,
            *dPartial = nullptr, *dRes = nullptr;
     int* dInfo = nullptr;
     double *hInvEll = nullptr, *hSlotp = nullptr, *hRes = nullptr;
@@ -138,10 +140,10 @@ void harvest(gphip_ctx* h) {   // call after stream sync
 
 void free_slots(gphip_ctx* h) {
     (void)hipFree(h->dA); (void)hipFree(h->dXs); (void)hipFree(h->dInvEll); (void)hipFree(h->dSlotp);
-    (void)hipFree(h->dLr); (void)hipFree(h->dPartial); (void)hipFree(h->dRes); (void)hipFree(h->dInfo);
+    (void)hipFree(h->dW); (void)hipFree(h->dPartial); (void)hipFree(h->dRes); (void)hipFree(h->dInfo);
     (void)hipHostFree(h->hInvEll); (void)hipHostFree(h->hSlotp); (void)hipHostFree(h->hRes);
     (void)hipHostFree(h->hInfo);
-    h->dA = h->dXs = h->dInvEll = h->dSlotp = h->dLr = h->dPartial = h->dRes = nullptr;
+    h->dA = h->dXs = h->dInvEll = h->dSlotp = h->dW = h->dPartial = h->dRes = nullptr;
     h->dInfo = nullptr;
     h->hInvEll = h->hSlotp = h->hRes = nullptr;
     h->hInfo = nullptr;
@@ -170,7 +172,7 @@ int ensure_slots(gphip_ctx* h, int want) {
     HIPCHK(hipMalloc(&h->dXs, S * h->d * h->Npad * 8));
     HIPCHK(hipMalloc(&h->dInvEll, S * h->d * 8));
     HIPCHK(hipMalloc(&h->dSlotp, S * SLOTP * 8));
-    HIPCHK(hipMalloc(&h->dLr, S * h->Nt * TB * TB * 8));
+    HIPCHK(hipMalloc(&h->dW, S * h->Nt * TB * TB * 8));
     HIPCHK(hipMalloc(&h->dPartial, S * h->Nt * 8));
     HIPCHK(hipMalloc(&h->dRes, S * 2 * 8));
     HIPCHK(hipMalloc(&h->dInfo, S * 4));
@@ -224,8 +226,9 @@ void queue_build(gphip_ctx* h, int nslots) {
 
 void launch_gemm(gphip_ctx* h, int cls, double* C, long ldc, long cbs, const double* A, long lda,
                  long abs_, const double* B, long ldb, long bbs, int K, int r0, int r1, int c0, int c1,
-                 int tri, int nslots) {
+                 int tri, int nslots, int mode = 0) {
     GemmArgs g{};
+    g.mode = mode;
     g.C = C; g.ldc = ldc; g.c_bstride = cbs;
     g.A = A; g.lda = lda; g.a_bstride = abs_;
     g.B = B; g.ldb = ldb; g.b_bstride = bbs;
@@ -261,17 +264,12 @@ void queue_factor(gphip_ctx* h, int nslots) {
             const int b = K0 + s;
             {
                 ProfScope ps(h, 1, (double)TB * TB * TB / 3.0 * nslots, 0.0);
-                hipLaunchKernelGGL(potrf128_kernel, dim3(nslots), dim3(256), (size_t)(TB * TB + 2) * 8,
-                                   h->stream, h->dA, ld, bs, b, h->dLr, h->dPartial, Nt, h->dInfo,
-                                   h->dSlotp);
+                hipLaunchKernelGGL(potrf128_kernel, dim3(nslots), dim3(256), POTRF_LDS, h->stream, h->dA,
+                                   ld, bs, b, h->dW, h->dPartial, Nt, h->dInfo, h->dSlotp);
             }
-            const int rows = (R - (b + 1)) * TB;
-            {
-                ProfScope ps(h, 2, (double)rows * TB * TB * nslots, 0.0);
-                hipLaunchKernelGGL(trsm128_kernel, dim3(rows / 64, nslots), dim3(64), (size_t)TB * 64 * 8,
-                                   h->stream, h->dA + (long)b * TB * ld + (long)(b + 1) * TB, ld, bs,
-                                   h->dLr + (long)b * TB * TB, lrs);
-            }
+            // panel solve X <- X W_b^T for every row tile below the diagonal block (incl. rhs rows)
+            launch_gemm(h, 2, h->dA, ld, bs, h->dA + (long)b * TB * ld, ld, bs,
+                        h->dW + (long)b * TB * TB - (long)b * TB, TB, lrs, TB, b + 1, R, b, b + 1, 0, nslots, 1);
             if (s + 1 < nin) {
                 const double* P = h->dA + (long)b * TB * ld;
                 launch_gemm(h, 3, h->dA, ld, bs, P, ld, bs, P, ld, bs, TB, b + 1, R, b + 1, K0 + nin, 1,
@@ -374,9 +372,7 @@ int eval_batch(gphip_ctx* h, const double* Theta, int B, int p, double* out, dou
 
 int set_func_attrs(gphip_ctx* h) {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(potrf128_kernel),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (TB * TB + 2) * 8));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trsm128_kernel),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, TB * 64 * 8));
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)POTRF_LDS));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * GK * LDT * 8));
     return GPHIP_OK;
@@ -568,9 +564,8 @@ int gphip_predict(gphip_handle h, const void* Xs, int64_t M, double* mean, doubl
         launch_kbuild(h, a, dim3((unsigned)(Mt * Nt), 1));
         // V <- V L^-T, right-looking over the 128-tile columns of L
         for (int b = 0; b < Nt; ++b) {
-            hipLaunchKernelGGL(trsm128_kernel, dim3((unsigned)(mpad / 64), 1), dim3(64), (size_t)TB * 64 * 8,
-                               h->stream, h->dV + (long)b * TB * mpad, (long)mpad, 0L,
-                               h->dLr + (long)b * TB * TB, 0L);
+            launch_gemm(h, 2, h->dV, mpad, 0, h->dV + (long)b * TB * mpad, mpad, 0,
+                        h->dW + (long)b * TB * TB - (long)b * TB, TB, 0, TB, 0, Mt, b, b + 1, 0, 1, 1);
             if (b + 1 < Nt)
                 launch_gemm(h, 3, h->dV, mpad, 0, h->dV + (long)b * TB * mpad, mpad, 0,
                             h->dA + (long)b * TB * ld, ld, 0, TB, 0, Mt, b + 1, Nt, 0, 1);
