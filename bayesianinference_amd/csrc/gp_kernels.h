@@ -458,6 +458,10 @@ __device__ __forceinline__ void gemm_tile_decode(const GemmArgs& g, int t, int& 
     }
 }
 
+// ROLE only gives each use its own kernel symbol (separate rows in rocprof summaries):
+// 0 = trailing SYRK (K = panel*128, the dominant kernel), 1 = in-panel GEMM (K = 128),
+// 2 = panel solve X <- X W^T (mode 1).
+template <int ROLE>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
     extern __shared__ double smem[];           // [2 stages][I: GK*LDT | J: GK*LDT]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;

@@ -249,8 +249,11 @@ void launch_gemm(gphip_ctx* h, int cls, double* C, long ldc, long cbs, const dou
     const double flops = 2.0 * TB * TB * (double)K * g.ntiles * nslots;
     const double bytes = 8.0 * TB * ((double)2 * TB + 2.0 * K) * g.ntiles * nslots;
     ProfScope ps(h, cls, flops, bytes);
-    hipLaunchKernelGGL(gemm_nt_kernel, dim3(g.ntiles, nslots), dim3(256), (size_t)2 * 2 * GK * LDT * 8,
-                       h->stream, g);
+    const dim3 grid(g.ntiles, nslots);
+    const size_t lds = (size_t)2 * 2 * GK * LDT * 8;
+    if (mode == 1) hipLaunchKernelGGL(gemm_nt_kernel<2>, grid, dim3(256), lds, h->stream, g);
+    else if (cls == 4) hipLaunchKernelGGL(gemm_nt_kernel<0>, grid, dim3(256), lds, h->stream, g);
+    else hipLaunchKernelGGL(gemm_nt_kernel<1>, grid, dim3(256), lds, h->stream, g);
 }
 
 // two-level right-looking Cholesky of slots [0, nslots) (workspace already built)
@@ -373,7 +376,11 @@ int eval_batch(gphip_ctx* h, const double* Theta, int B, int p, double* out, dou
 int set_func_attrs(gphip_ctx* h) {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(potrf128_kernel),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)POTRF_LDS));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel),
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<0>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * GK * LDT * 8));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<1>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * GK * LDT * 8));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<2>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * GK * LDT * 8));
     return GPHIP_OK;
 }
