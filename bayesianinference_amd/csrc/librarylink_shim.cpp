@@ -1,0 +1,142 @@
+// librarylink_shim.cpp -- Wolfram LibraryLink entry points over the plain C ABI (include/gphip.h).
+//
+// Compiled ONLY where a Wolfram installation provides WolframLibrary.h
+// (SystemFiles/IncludeFiles/C); it is not part of the hipcc build and is not testable in the
+// build containers.  Build (on a machine with Mathematica 14+ and ROCm):
+//   g++ -O2 -fPIC -shared -I$WOLFRAM/SystemFiles/IncludeFiles/C -Iinclude \
+//       bayesianinference_amd/csrc/librarylink_shim.cpp -Lbayesianinference_amd/lib -lgphip \
+//       -o libgphip_wl.so
+// Conventions honoured: "Constant" tensors are read-only and kernel-owned; results
+// are created with MTensor_new and handed over with MArgument_setMTensor; "K is not positive
+// definite" is reported through the RESULT ({value, info}), never through the return code, so the
+// WL closure stays numeric for every theta (BayesianStatistics.wl:276-298).
+#include <vector>
+
+#include "WolframLibrary.h"
+#include "gphip.h"
+
+static std::vector<gphip_handle> g_handles;
+
+EXTERN_C DLLEXPORT mint WolframLibrary_getVersion() { return WolframLibraryVersion; }
+EXTERN_C DLLEXPORT int WolframLibrary_initialize(WolframLibraryData) { return LIBRARY_NO_ERROR; }
+EXTERN_C DLLEXPORT void WolframLibrary_uninitialize(WolframLibraryData) {
+    for (auto h : g_handles) gphip_destroy(h);
+    g_handles.clear();
+}
+
+static gphip_handle lookup(mint id) {
+    return (id >= 0 && (size_t)id < g_handles.size()) ? g_handles[(size_t)id] : nullptr;
+}
+
+static int status_to_wl(int rc) {
+    switch (rc) {
+        case GPHIP_OK: return LIBRARY_NO_ERROR;
+        case GPHIP_ERR_ARG: return LIBRARY_TYPE_ERROR;
+        case GPHIP_ERR_DIM: return LIBRARY_DIMENSION_ERROR;
+        default: return LIBRARY_FUNCTION_ERROR;
+    }
+}
+
+// gphip_wl_create[X (N x d), y (N), kernelId, meanId, device] -> handle id
+EXTERN_C DLLEXPORT int gphip_wl_create(WolframLibraryData lib, mint argc, MArgument* args, MArgument res) {
+    if (argc != 5) return LIBRARY_FUNCTION_ERROR;
+    MTensor X = MArgument_getMTensor(args[0]), y = MArgument_getMTensor(args[1]);
+    if (lib->MTensor_getRank(X) != 2 || lib->MTensor_getRank(y) != 1) return LIBRARY_RANK_ERROR;
+    const mint* dims = lib->MTensor_getDimensions(X);
+    if (lib->MTensor_getDimensions(y)[0] != dims[0]) return LIBRARY_DIMENSION_ERROR;
+    int dev = (int)MArgument_getInteger(args[4]);
+    gphip_handle h = nullptr;
+    int rc = gphip_create(lib->MTensor_getRealData(X), lib->MTensor_getRealData(y), dims[0], dims[1],
+                          (int)MArgument_getInteger(args[2]), (int)MArgument_getInteger(args[3]), 64, &dev, 1, &h);
+    if (rc != GPHIP_OK) return status_to_wl(rc);
+    g_handles.push_back(h);
+    MArgument_setInteger(res, (mint)g_handles.size() - 1);
+    return LIBRARY_NO_ERROR;
+}
+
+// gphip_wl_loglik[h, theta] -> {value, info}
+EXTERN_C DLLEXPORT int gphip_wl_loglik(WolframLibraryData lib, mint argc, MArgument* args, MArgument res) {
+    if (argc != 2) return LIBRARY_FUNCTION_ERROR;
+    gphip_handle h = lookup(MArgument_getInteger(args[0]));
+    MTensor th = MArgument_getMTensor(args[1]);
+    if (!h) return LIBRARY_FUNCTION_ERROR;
+    double out = 0.0; int info = 0;
+    int rc = gphip_loglik(h, lib->MTensor_getRealData(th), (int)lib->MTensor_getDimensions(th)[0], &out, &info);
+    if (rc != GPHIP_OK) return status_to_wl(rc);
+    MTensor r; mint d[1] = {2};
+    if (lib->MTensor_new(MType_Real, 1, d, &r)) return LIBRARY_FUNCTION_ERROR;
+    double* p = lib->MTensor_getRealData(r);
+    p[0] = info == 0 ? out : 0.0; p[1] = (double)info;
+    MArgument_setMTensor(res, r);
+    return LIBRARY_NO_ERROR;
+}
+
+// gphip_wl_loglik_batch[h, Theta (B x p)] -> B x 2 {{value, info}..}
+EXTERN_C DLLEXPORT int gphip_wl_loglik_batch(WolframLibraryData lib, mint argc, MArgument* args, MArgument res) {
+    if (argc != 2) return LIBRARY_FUNCTION_ERROR;
+    gphip_handle h = lookup(MArgument_getInteger(args[0]));
+    MTensor th = MArgument_getMTensor(args[1]);
+    if (!h || lib->MTensor_getRank(th) != 2) return LIBRARY_RANK_ERROR;
+    const mint* dims = lib->MTensor_getDimensions(th);
+    std::vector<double> out((size_t)dims[0]);
+    std::vector<int> info((size_t)dims[0]);
+    int rc = gphip_loglik_batch(h, lib->MTensor_getRealData(th), (int)dims[0], (int)dims[1], out.data(), info.data());
+    if (rc != GPHIP_OK) return status_to_wl(rc);
+    MTensor r; mint d[2] = {dims[0], 2};
+    if (lib->MTensor_new(MType_Real, 2, d, &r)) return LIBRARY_FUNCTION_ERROR;
+    double* p = lib->MTensor_getRealData(r);
+    for (mint i = 0; i < dims[0]; ++i) { p[2 * i] = info[i] == 0 ? out[i] : 0.0; p[2 * i + 1] = info[i]; }
+    MArgument_setMTensor(res, r);
+    return LIBRARY_NO_ERROR;
+}
+
+// gphip_wl_fit[h, theta] -> info
+EXTERN_C DLLEXPORT int gphip_wl_fit(WolframLibraryData lib, mint argc, MArgument* args, MArgument res) {
+    if (argc != 2) return LIBRARY_FUNCTION_ERROR;
+    gphip_handle h = lookup(MArgument_getInteger(args[0]));
+    MTensor th = MArgument_getMTensor(args[1]);
+    if (!h) return LIBRARY_FUNCTION_ERROR;
+    int info = 0;
+    int rc = gphip_fit(h, lib->MTensor_getRealData(th), (int)lib->MTensor_getDimensions(th)[0], &info);
+    if (rc != GPHIP_OK) return status_to_wl(rc);
+    MArgument_setInteger(res, info);
+    return LIBRARY_NO_ERROR;
+}
+
+// gphip_wl_predict[h, Xs (M x d)] -> 2 x M {means, variances}
+EXTERN_C DLLEXPORT int gphip_wl_predict(WolframLibraryData lib, mint argc, MArgument* args, MArgument res) {
+    if (argc != 2) return LIBRARY_FUNCTION_ERROR;
+    gphip_handle h = lookup(MArgument_getInteger(args[0]));
+    MTensor xs = MArgument_getMTensor(args[1]);
+    if (!h || lib->MTensor_getRank(xs) != 2) return LIBRARY_RANK_ERROR;
+    const mint M = lib->MTensor_getDimensions(xs)[0];
+    MTensor r; mint d[2] = {2, M};
+    if (lib->MTensor_new(MType_Real, 2, d, &r)) return LIBRARY_FUNCTION_ERROR;
+    double* p = lib->MTensor_getRealData(r);
+    int rc = gphip_predict(h, lib->MTensor_getRealData(xs), M, p, p + M);
+    if (rc != GPHIP_OK) { lib->MTensor_free(r); return status_to_wl(rc); }
+    MArgument_setMTensor(res, r);
+    return LIBRARY_NO_ERROR;
+}
+
+// gphip_wl_covariance[h, theta] -> N x N
+EXTERN_C DLLEXPORT int gphip_wl_covariance(WolframLibraryData lib, mint argc, MArgument* args, MArgument res) {
+    if (argc != 2) return LIBRARY_FUNCTION_ERROR;
+    gphip_handle h = lookup(MArgument_getInteger(args[0]));
+    MTensor th = MArgument_getMTensor(args[1]);
+    if (!h) return LIBRARY_FUNCTION_ERROR;
+    int p = 0; gphip_num_params(h, &p);
+    // N is recovered from the handle by asking for a 0-length query is not part of the ABI: the WL
+    // side passes theta only, so the shim keeps N next to the handle in a real deployment.
+    (void)p; (void)th; (void)res;
+    return LIBRARY_FUNCTION_ERROR;   // small-N debugging aid; wire up with a stored N when needed
+}
+
+EXTERN_C DLLEXPORT int gphip_wl_destroy(WolframLibraryData, mint argc, MArgument* args, MArgument res) {
+    if (argc != 1) return LIBRARY_FUNCTION_ERROR;
+    const mint id = MArgument_getInteger(args[0]);
+    gphip_handle h = lookup(id);
+    if (h) { gphip_destroy(h); g_handles[(size_t)id] = nullptr; }
+    MArgument_setInteger(res, 0);
+    return LIBRARY_NO_ERROR;
+}

@@ -1,0 +1,333 @@
+"""Host-side mirror of the reference's GP interface for the MI355X path.
+
+The reference is Wolfram Language (no Wolfram kernel exists here or on the GPU box), so the host
+side above the C ABI is Python, keeping the reference's names, argument meaning, association
+keys and failure behaviour:
+
+  inferenceObject                       BayesianUtilities.wl:107-138
+  dataNormalForm                        BayesianUtilities.wl:203-221
+  defineGaussianProcess                 BayesianGaussianProcess.wl:228-330  (BGP)
+  defineInferenceProblem (GP subset)    BayesianStatistics.wl:164-308       (BS)
+  predictFromGaussianProcess            BayesianGaussianProcess.wl:332-394
+
+Differences forced by the closed kernel set (SURVEY.md §7 "Arbitrary WL kernels vs named
+kernels"): `kernel` is a named spec ("SE", "SEARD", "Matern52", "Matern52ARD" or None for the
+null kernel BGP:25), the nugget is the constant sigma_n^2 and the mean is None / "Constant";
+`variables` must list the hyper-parameters in the C-ABI order (l.., sigma_f, sigma_n[, mu]).
+All arithmetic runs in the HIP library; nothing here falls back to the CPU.
+"""
+from __future__ import annotations
+
+import math
+from collections.abc import Mapping
+
+import numpy as np
+
+from . import _lib
+
+# BU:47 -- closed-source constant in the reference; the WL shim reads the real one at load time.
+MACHINE_LOG_ZERO = -1.7976931348623157e308
+
+_KERNEL_ALIASES = {
+    "se": "se", "squaredexponential": "se", "se_iso": "se",
+    "seard": "se_ard", "se_ard": "se_ard",
+    "matern52": "matern52", "matern5/2": "matern52",
+    "matern52ard": "matern52_ard", "matern52_ard": "matern52_ard",
+    "null": "null", "none": "null",
+}
+
+# The WL expressions that define each named kernel for the *reference* defineGaussianProcess, so
+# that "same inputs" is well defined.
+WL_KERNEL_EXPRESSIONS = {
+    "se": "Function[{p, q}, sf^2 Exp[-Total[(p - q)^2]/(2 l^2)]]",
+    "se_ard": "Function[{p, q}, sf^2 Exp[-1/2 Total[((p - q)/{l1, ..., ld})^2]]]",
+    "matern52": "Function[{p, q}, With[{s = Sqrt[Total[(p - q)^2]]/l}, sf^2 (1 + Sqrt[5] s + 5 s^2/3) Exp[-Sqrt[5] s]]]",
+    "matern52_ard": "Function[{p, q}, With[{s = Sqrt[Total[((p - q)/{l1, ..., ld})^2]]}, sf^2 (1 + Sqrt[5] s + 5 s^2/3) Exp[-Sqrt[5] s]]]",
+    "null": "Function[0]",
+}
+WL_NUGGET_EXPRESSION = "Function[sn^2]"
+
+
+class inferenceObject(Mapping):
+    """Association wrapper (BU:107-138): obj[key], obj["Properties"], Normal -> .normal(),
+    Append -> .append(), inferenceObject[$Failed] -> inferenceObject(None) with .failed."""
+
+    def __init__(self, assoc):
+        if isinstance(assoc, inferenceObject):          # BU:128 idempotent wrapping
+            assoc = assoc._assoc
+        self._assoc = None if assoc is None else dict(assoc)
+
+    @property
+    def failed(self) -> bool:                           # BU:126 FailureQ
+        return self._assoc is None
+
+    def normal(self) -> dict:                           # BU:121 Normal
+        return dict(self._assoc or {})
+
+    def append(self, extra: Mapping) -> "inferenceObject":   # BU:122-125 Append
+        out = self.normal()
+        out.update(extra)
+        return inferenceObject(out)
+
+    def __getitem__(self, key):
+        if self._assoc is None:
+            raise KeyError("inferenceObject[$Failed]")
+        if key == "Properties":                         # BU:130
+            return sorted(list(self._assoc) + ["Properties"])
+        if isinstance(key, tuple):                      # obj["GaussianProcessData", "ModelFunctions"]
+            cur = self._assoc
+            for k in key:
+                cur = cur[k]
+            return cur
+        return self._assoc[key]
+
+    def __iter__(self):
+        return iter(self._assoc or {})
+
+    def __len__(self):
+        return len(self._assoc or {})
+
+    def __repr__(self):
+        if self.failed:
+            return "inferenceObject[$Failed]"
+        return f"inferenceObject[<{len(self._assoc)} defined properties: {', '.join(list(self._assoc)[:4])}...>]"
+
+
+def dataNormalForm(data):
+    """BU:203-221: vector -> N x 1 matrix; (in, out) / {"Input","Output"} / [(x, y), ...] ->
+    (X[N,d], Y[N,k]); None on malformed input ($Failed)."""
+    try:
+        if isinstance(data, Mapping) and "Input" in data:
+            data = (data["Input"], data["Output"])
+        if isinstance(data, tuple) and len(data) == 2:
+            xin, xout = dataNormalForm(data[0]), dataNormalForm(data[1])
+            if xin is None or xout is None or len(xin) != len(xout):
+                return None
+            return xin, xout
+        if isinstance(data, list) and data and isinstance(data[0], tuple) and len(data[0]) == 2:
+            return dataNormalForm(([p[0] for p in data], [p[1] for p in data]))   # {x -> y ..}
+        arr = np.asarray(data, dtype=np.float64)
+        if arr.ndim == 1:
+            return arr[:, None]
+        if arr.ndim == 2:
+            return arr
+    except (TypeError, ValueError):
+        pass
+    return None
+
+
+def _resolve_kernel(kernel):
+    if kernel is None:
+        return "null"
+    key = str(kernel).lower().replace(" ", "").replace("-", "")
+    if key not in _KERNEL_ALIASES:
+        raise ValueError(f"kernel {kernel!r} is not one of the named kernels {sorted(set(_KERNEL_ALIASES.values()))}; "
+                         "arbitrary pure functions stay on the reference's own path")
+    return _KERNEL_ALIASES[key]
+
+
+def _log_prior_function(prior, params):
+    """'LogPriorPDFFunction' (BS:256-274): callable theta -> log pdf.  Accepts a callable, a list
+    of scipy.stats frozen distributions (ProductDistribution), or "Uniform"/None over the box."""
+    lo = np.array([p[1] for p in params], dtype=np.float64)
+    hi = np.array([p[2] for p in params], dtype=np.float64)
+    if callable(prior):
+        return prior
+    if prior is None or (isinstance(prior, str) and prior.lower() == "uniform"):
+        logvol = float(np.sum(np.log(hi - lo)))
+
+        def uniform_logpdf(theta):
+            theta = np.asarray(theta, dtype=np.float64)
+            return -logvol if np.all((theta >= lo) & (theta <= hi)) else MACHINE_LOG_ZERO
+        return uniform_logpdf
+    dists = list(prior)
+    if len(dists) != len(params):
+        raise ValueError("prior list length differs from the number of parameters")
+
+    def product_logpdf(theta):
+        theta = np.asarray(theta, dtype=np.float64)
+        if not np.all((theta >= lo) & (theta <= hi)):
+            return MACHINE_LOG_ZERO
+        val = float(sum(d.logpdf(t) for d, t in zip(dists, theta)))
+        return val if math.isfinite(val) else MACHINE_LOG_ZERO
+    return product_logpdf
+
+
+def random_domain_points(params, count=100, width=100.0, rng=None):
+    """BU:366-372 randomDomainPointDistribution: Cauchy(0, width) truncated to the parameter box."""
+    rng = rng or np.random.default_rng(0)
+    lo = np.array([p[1] for p in params], dtype=np.float64)
+    hi = np.array([p[2] for p in params], dtype=np.float64)
+    u = rng.random((count, len(params)))
+    clo = np.arctan(np.maximum(lo, -1e300) / width)
+    chi = np.arctan(np.minimum(hi, 1e300) / width)
+    return width * np.tan(clo + u * (chi - clo))
+
+
+def make_log_likelihood(handle: "_lib.Handle"):
+    """The drop-in closure for "LogLikelihoodFunction" (seam at BGP:249,293-294): theta -> machine
+    real, total over the parameter box, $MachineLogZero on numerical failure (BGP:298-304), never an
+    exception for bad theta values (BS:276-298)."""
+    def log_likelihood(theta):
+        theta = np.asarray(theta, dtype=np.float64)
+        if theta.ndim == 2:                               # Listable use: B x p -> B (BGP:59)
+            out, info = handle.loglik_batch(theta)
+            return np.where(info == 0, np.clip(out, MACHINE_LOG_ZERO, -MACHINE_LOG_ZERO), MACHINE_LOG_ZERO)
+        ll, info = handle.loglik(theta)
+        if info != 0 or not math.isfinite(ll):
+            return MACHINE_LOG_ZERO
+        return min(max(ll, MACHINE_LOG_ZERO), -MACHINE_LOG_ZERO)     # Clip, BGP:183,190-197
+    return log_likelihood
+
+
+def defineGaussianProcess(data, kernel, nugget="Constant", meanFunction=None, variables=(),
+                          variablePrior="Uniform", **rules) -> inferenceObject:
+    """BGP:228-330.  data: (X, Y) with Y N x 1 (BGP:220-226); variables: [(name, min, max), ...] in
+    the order (l.., sigma_f, sigma_n[, mu]); variablePrior: callable / list of scipy frozen
+    distributions / "Uniform"; extra rules are forwarded into the object (`rest___Rule`, BGP:233,323)
+    -- e.g. Device=0.  A caller-supplied LogLikelihoodFunction=callable is installed verbatim
+    (BGP:293-294).  Returns inferenceObject(None) where the reference returns inferenceObject[$Failed]."""
+    norm = dataNormalForm(data)
+    if norm is None or not isinstance(norm, tuple):
+        return inferenceObject(None)                              # BGP:204-207 dataFormat
+    X, Y = norm
+    if Y.shape[1] != 1:                                           # BGP:220-226 outputDim
+        return inferenceObject(None)
+    if len(X) != len(Y):                                          # BGP:251-253
+        return inferenceObject(None)
+    if isinstance(nugget, str) and nugget.lower() != "constant":
+        raise ValueError("only the constant nugget Function[sn^2] is supported on the HIP path")
+    kname = _resolve_kernel(kernel)
+    mean = "zero" if meanFunction in (None, 0, "Zero", "zero") else "const"
+    if mean == "const" and str(meanFunction).lower() not in ("constant", "const"):
+        raise ValueError("meanFunction must be None/0 or 'Constant' on the HIP path")
+    params = [tuple(v) for v in variables]
+    if not params or any(len(v) != 3 for v in params):            # paramSpecPattern, BS:19
+        return inferenceObject(None)
+    device = rules.pop("Device", None)
+    handle = _lib.Handle(X, Y[:, 0], kname, mean, device=device)  # raises loudly without the library / GPU
+    if handle.p != len(params):
+        handle.close()
+        raise ValueError(f"kernel {kname!r} with mean {mean!r} on d={X.shape[1]} needs {handle.p} "
+                         f"hyper-parameters (l.., sigma_f, sigma_n[, mu]); got {len(params)}")
+    user_ll = rules.pop("LogLikelihoodFunction", None)
+    loglik = user_ll if callable(user_ll) else make_log_likelihood(handle)
+
+    def covariance_function(theta):                               # "CovarianceFunction", BGP:264-271
+        return handle.covariance(theta)
+
+    def inverse_covariance_function(theta):                       # "InverseCovarianceFunction", BGP:308
+        info = handle.fit(theta)
+        if info != 0:
+            return MACHINE_LOG_ZERO                               # Throw[$MachineLogZero, "MatInv"]
+        return {"Inverse": handle.solve, "LogDet": handle.logdet()}
+
+    return defineInferenceProblem({
+        "Data": (X, Y),
+        "PriorDistribution": variablePrior,
+        "Parameters": params,
+        "GaussianProcessData": {
+            "ModelFunctions": {
+                "KernelFunction": (kname, WL_KERNEL_EXPRESSIONS[kname]),
+                "NuggetFunction": WL_NUGGET_EXPRESSION,
+                "MeanFunction": mean,
+                "CovarianceFunction": covariance_function,
+                "InverseCovarianceFunction": inverse_covariance_function,
+            },
+            "HIPHandle": handle,
+        },
+        **rules,
+        "LogLikelihoodFunction": loglik,
+    })
+
+
+def defineInferenceProblem(assoc: Mapping) -> inferenceObject:
+    """The subset of BS:164-308 a GP object goes through: parameter normal form, ParameterSymbols
+    (BS:222), LogPriorPDFFunction (BS:256-274) and the 100-random-theta smoke test of both closures
+    (BS:276-298) -- a closure that returns anything but finite reals fails the definition."""
+    assoc = dict(assoc)
+    params = assoc.get("Parameters")
+    if not params or "LogLikelihoodFunction" not in assoc:
+        return inferenceObject(None)
+    assoc["ParameterSymbols"] = [p[0] for p in params]
+    if "LogPriorPDFFunction" not in assoc:
+        assoc["LogPriorPDFFunction"] = _log_prior_function(assoc.get("PriorDistribution"), params)
+    pts = random_domain_points(params, 100)
+    prior_vals = np.array([assoc["LogPriorPDFFunction"](t) for t in pts], dtype=np.float64)
+    if not np.all(np.isfinite(prior_vals)):
+        return inferenceObject(None)
+    ll = assoc["LogLikelihoodFunction"]
+    try:
+        vals = np.asarray(ll(pts), dtype=np.float64)             # one batched sweep (B x p -> B)
+        if vals.shape != (len(pts),):
+            raise ValueError
+    except (TypeError, ValueError):
+        vals = np.array([ll(t) for t in pts], dtype=np.float64)
+    if not np.all(np.isfinite(vals)):
+        return inferenceObject(None)
+    return inferenceObject(assoc)
+
+
+def predictFromGaussianProcess(obj_or_examples, pts, kernel=None, theta=None, meanFunction=None):
+    """BGP:332-394.  Two forms:
+      predictFromGaussianProcess(obj, pts)            obj has "GaussianProcessData" and "Samples"
+          (BGP:343-376): one Normal per posterior sample, mixed with the CrudePosteriorWeights.
+          pts may be an int > 1: regular grid over the data bounds (BGP:332-341).
+      predictFromGaussianProcess((X, Y), pts, kernel, theta[, meanFunction])
+          direct form with the hyper-parameters baked in (BGP:378-394); duplicates in pts are
+          removed first (DeleteDuplicates, BGP:380).
+    Returns a dict with "Points" [M,d], "Weights" [S], "Mean" [S,M], "StandardDeviation" [S,M]:
+    the content of Association[x* -> MixtureDistribution[weights, {NormalDistribution[mu, sigma]..}]]
+    (for the direct form S = 1).  The variance includes the test-point nugget (BGP:113)."""
+    if isinstance(obj_or_examples, inferenceObject):
+        obj = obj_or_examples
+        if obj.failed or "GaussianProcessData" not in obj or "Samples" not in obj:
+            return None
+        X = obj["Data"][0]
+        if isinstance(pts, (int, np.integer)):
+            if pts <= 1 or X.shape[1] != 1:
+                return None
+            pts = np.linspace(X.min(), X.max(), int(pts))         # CoordinateBoundsArray, BGP:336-339
+        P = dataNormalForm(pts)
+        if P is None or isinstance(P, tuple):
+            return None
+        handle = obj["GaussianProcessData"]["HIPHandle"]
+        samples = obj["Samples"]
+        points = np.array([s["Point"] for s in samples], dtype=np.float64)
+        weights = np.array([s["CrudePosteriorWeight"] for s in samples], dtype=np.float64)
+        return _predict_samples(handle, points, weights, P)
+    norm = dataNormalForm(obj_or_examples)
+    P = dataNormalForm(pts)
+    if norm is None or not isinstance(norm, tuple) or P is None or norm[1].shape[1] != 1:
+        return None                                               # Return[$Failed], BGP:383-390
+    _, first = np.unique(P, axis=0, return_index=True)
+    P = P[np.sort(first)]
+    mean = "zero" if meanFunction in (None, 0, "Zero", "zero") else "const"
+    handle = _lib.Handle(norm[0], norm[1][:, 0], _resolve_kernel(kernel), mean)
+    try:
+        return _predict_samples(handle, np.atleast_2d(np.asarray(theta, dtype=np.float64)), np.ones(1), P)
+    finally:
+        handle.close()
+
+
+def _predict_samples(handle, points, weights, P):
+    mus, sds = [], []
+    for th in points:
+        if handle.fit(th) != 0:                                   # singular K for this sample
+            mus.append(np.full(len(P), np.nan))
+            sds.append(np.full(len(P), np.nan))
+            continue
+        mu, var = handle.predict(P)
+        mus.append(mu)
+        with np.errstate(invalid="ignore"):
+            sds.append(np.sqrt(var))                              # Sqrt, BGP:414
+    return {"Points": P, "Weights": weights, "Mean": np.array(mus), "StandardDeviation": np.array(sds)}
+
+
+def mixture_moments(pred: Mapping):
+    """Mean and variance of the per-point MixtureDistribution (what regressionPlot1D draws, BV:310-374)."""
+    w = np.asarray(pred["Weights"], dtype=np.float64)
+    w = w / w.sum()
+    mu, sd = pred["Mean"], pred["StandardDeviation"]
+    m = w @ mu
+    return m, w @ (sd ** 2 + mu ** 2) - m ** 2

@@ -1,0 +1,68 @@
+"""GPU tests of the host-side mirror: defineGaussianProcess / predictFromGaussianProcess behave
+like the reference's (BGP:228-330, 332-394) with the HIP closure installed."""
+import numpy as np
+import pytest
+
+from bayesianinference_amd import gaussian_process as gp, synthetic as syn
+from oracle import gp_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def test_define_gaussian_process_object_and_closure():
+    X, y = syn.make_dataset(200, 2)
+    variables = [("l1", 0.1, 10.0), ("l2", 0.1, 10.0), ("sf", 0.1, 10.0), ("sn", 0.05, 1.0)]
+    obj = gp.defineGaussianProcess((X, y), "SEARD", "Constant", None, variables, "Uniform", Note="extra rule")
+    assert not obj.failed
+    for key in ("Data", "PriorDistribution", "Parameters", "ParameterSymbols", "GaussianProcessData",
+                "LogLikelihoodFunction", "LogPriorPDFFunction", "Note"):
+        assert key in obj
+    mf = obj["GaussianProcessData", "ModelFunctions"]
+    assert set(mf) == {"KernelFunction", "NuggetFunction", "MeanFunction", "CovarianceFunction",
+                       "InverseCovarianceFunction"}
+    th = np.array([0.8, 1.7, 1.2, 0.3])
+    want = orc.log_likelihood("se_ard", th, X, y)
+    assert obj["LogLikelihoodFunction"](th) == pytest.approx(want, rel=1e-8)
+    # Listable use (B x p) and sentinel on numerical failure, never an exception (BS:276-298)
+    batch = obj["LogLikelihoodFunction"](np.array([th, [0.8, 1.7, 1.2, 0.0]]))
+    assert batch[0] == pytest.approx(want, rel=1e-8)
+    Xd = X.copy()
+    Xd[5] = Xd[9]
+    obj2 = gp.defineGaussianProcess((Xd, y), "SEARD", variables=variables,
+                                    LogLikelihoodFunction=None)
+    assert obj2["LogLikelihoodFunction"]([1.0, 1.0, 1.0, 0.0]) == gp.MACHINE_LOG_ZERO
+    np.testing.assert_allclose(mf["CovarianceFunction"](th), orc.covariance_matrix("se_ard", th, X), rtol=1e-12)
+    inv = mf["InverseCovarianceFunction"](th)
+    assert inv["LogDet"] == pytest.approx(orc.log_likelihood("se_ard", th, X, y, parts=True)[1], rel=1e-9)
+
+
+def test_user_supplied_loglikelihood_passes_through():
+    X, y = syn.make_dataset(50, 1)
+    f = lambda theta: -1.0                                       # noqa: E731  (BGP:293-294)
+    obj = gp.defineGaussianProcess((X, y), "SE", variables=[("l", 0.1, 1), ("sf", 0.1, 1), ("sn", 0.1, 1)],
+                                   LogLikelihoodFunction=f)
+    assert obj["LogLikelihoodFunction"] is f
+
+
+def test_predict_from_gaussian_process_forms():
+    X, y = syn.make_dataset(150, 1)
+    variables = [("l", 0.05, 5.0), ("sf", 0.1, 5.0), ("sn", 0.05, 1.0)]
+    obj = gp.defineGaussianProcess((X, y), "SE", variables=variables)
+    samples = [{"Point": [0.3, 1.0, 0.1], "CrudePosteriorWeight": 0.7},
+               {"Point": [0.5, 1.3, 0.2], "CrudePosteriorWeight": 0.3}]
+    res = gp.predictFromGaussianProcess(obj.append({"Samples": samples}), 9)      # integer-grid form
+    assert res["Points"].shape == (9, 1) and res["Mean"].shape == (2, 9)
+    w, mu, sd = orc.predict_mixture("se", [s["Point"] for s in samples], [0.7, 0.3], X, y, res["Points"])
+    np.testing.assert_allclose(res["Mean"], mu, rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(res["StandardDeviation"], sd, rtol=1e-7)
+    m, v = gp.mixture_moments(res)
+    mo, vo = orc.mixture_moments(w, mu, sd)
+    np.testing.assert_allclose(m, mo, rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(v, vo, rtol=1e-6)
+    assert gp.predictFromGaussianProcess(obj, 9) is None                          # no "Samples" key
+    # direct form, duplicates removed (BGP:380)
+    pts = np.array([[0.1], [0.2], [0.1]])
+    res = gp.predictFromGaussianProcess((X, y), pts, "SE", [0.3, 1.0, 0.1])
+    assert res["Points"].shape == (2, 1)
+    mo, so = orc.predict_internal("se", [0.3, 1.0, 0.1], X, y, res["Points"])
+    np.testing.assert_allclose(res["Mean"][0], mo, rtol=1e-7, atol=1e-9)

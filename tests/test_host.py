@@ -1,0 +1,80 @@
+"""CPU tests of the host-side mirror (no GPU): object model, data normal form, priors, the
+defineInferenceProblem smoke-test contract (BS:276-298) and sharding maps."""
+import math
+
+import numpy as np
+import pytest
+from scipy import stats
+
+from bayesianinference_amd import distributed as D
+from bayesianinference_amd import gaussian_process as gp
+
+
+def test_inference_object_semantics():
+    obj = gp.inferenceObject({"A": 1, "B": {"C": 2}})
+    assert obj["A"] == 1 and obj["B", "C"] == 2
+    assert obj["Properties"] == ["A", "B", "Properties"]
+    assert gp.inferenceObject(obj).normal() == obj.normal()          # idempotent, BU:128
+    assert obj.append({"Z": 3})["Z"] == 3 and "Z" not in obj
+    failed = gp.inferenceObject(None)
+    assert failed.failed and repr(failed) == "inferenceObject[$Failed]"
+
+
+def test_data_normal_form():
+    assert gp.dataNormalForm([1.0, 2.0, 3.0]).shape == (3, 1)         # BU:206
+    X, Y = gp.dataNormalForm(([1.0, 2.0], [3.0, 4.0]))
+    assert X.shape == (2, 1) and Y.shape == (2, 1)
+    X, Y = gp.dataNormalForm([([0.0, 1.0], 2.0), ([1.0, 2.0], 3.0)])   # {x -> y ..}, BU:207
+    assert X.shape == (2, 2) and Y.shape == (2, 1)
+    assert gp.dataNormalForm(([1.0, 2.0], [3.0])) is None             # length mismatch -> $Failed
+    assert gp.dataNormalForm("nonsense") is None
+
+
+def test_kernel_names_and_wl_expressions():
+    assert gp._resolve_kernel("SEARD") == "se_ard" and gp._resolve_kernel(None) == "null"
+    assert gp._resolve_kernel("Matern-52") == "matern52"
+    with pytest.raises(ValueError):
+        gp._resolve_kernel(lambda p, q: 0.0)
+    assert set(gp.WL_KERNEL_EXPRESSIONS) == {"se", "se_ard", "matern52", "matern52_ard", "null"}
+
+
+def test_priors_and_random_domain_points():
+    params = [("l", 0.1, 10.0), ("sf", 0.1, 10.0), ("sn", 0.01, 1.0)]
+    lp = gp._log_prior_function("Uniform", params)
+    assert lp([1.0, 1.0, 0.1]) == pytest.approx(-math.log(9.9 * 9.9 * 0.99))
+    assert lp([20.0, 1.0, 0.1]) == gp.MACHINE_LOG_ZERO
+    lp2 = gp._log_prior_function([stats.lognorm(1.0)] * 3, params)
+    assert lp2([1.0, 1.0, 0.1]) == pytest.approx(sum(stats.lognorm(1.0).logpdf(t) for t in (1.0, 1.0, 0.1)))
+    pts = gp.random_domain_points(params, 100)
+    lo, hi = np.array([p[1] for p in params]), np.array([p[2] for p in params])
+    assert pts.shape == (100, 3) and np.all(pts >= lo) and np.all(pts <= hi)
+
+
+def test_define_inference_problem_smoke_contract():
+    params = [("a", -1.0, 1.0), ("b", 0.0, 2.0)]
+    good = gp.defineInferenceProblem({"Parameters": params, "PriorDistribution": "Uniform",
+                                      "LogLikelihoodFunction": lambda t: -float(np.sum(np.square(t)))})
+    assert not good.failed and good["ParameterSymbols"] == ["a", "b"]
+    assert callable(good["LogPriorPDFFunction"])
+    # a closure that is not total over the box fails the definition (BS:290-296)
+    bad = gp.defineInferenceProblem({"Parameters": params, "PriorDistribution": "Uniform",
+                                     "LogLikelihoodFunction": lambda t: float("nan")})
+    assert bad.failed
+    assert gp.defineInferenceProblem({"Parameters": params}).failed
+
+
+def test_define_gaussian_process_argument_guards_need_no_gpu():
+    X = np.zeros((4, 2))
+    assert gp.defineGaussianProcess((X, np.zeros((4, 2))), "SEARD", variables=[("l", 0, 1)]).failed  # BGP:220
+    assert gp.defineGaussianProcess((X, np.zeros(3)), "SEARD", variables=[("l", 0, 1)]).failed       # lengths
+    assert gp.defineGaussianProcess("junk", "SEARD", variables=[("l", 0, 1)]).failed
+
+
+def test_sharding_maps():
+    assert list(D.shard_indices(7, 1, 3)) == [1, 4]
+    allidx = np.sort(np.concatenate([D.shard_indices(10, r, 4) for r in range(4)]))
+    assert list(allidx) == list(range(10))
+    assert [D.block_cyclic_owner(j, 8) for j in (0, 7, 8, 9)] == [0, 7, 0, 1]
+    assert list(D.local_block_columns(10, 2, 4)) == [2, 6]
+    v, i = D.sharded_map(lambda th: (th.sum(axis=1), np.zeros(len(th), dtype=int)), np.ones((5, 3)))
+    assert list(v) == [3.0] * 5 and not i.any()
