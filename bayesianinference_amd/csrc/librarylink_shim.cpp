@@ -16,6 +16,7 @@
 #include "gphip.h"
 
 static std::vector<gphip_handle> g_handles;
+static std::vector<mint> g_n;              // training-set size per handle (for gphip_wl_covariance)
 
 EXTERN_C DLLEXPORT mint WolframLibrary_getVersion() { return WolframLibraryVersion; }
 EXTERN_C DLLEXPORT int WolframLibrary_initialize(WolframLibraryData) { return LIBRARY_NO_ERROR; }
@@ -50,6 +51,7 @@ EXTERN_C DLLEXPORT int gphip_wl_create(WolframLibraryData lib, mint argc, MArgum
                           (int)MArgument_getInteger(args[2]), (int)MArgument_getInteger(args[3]), 64, &dev, 1, &h);
     if (rc != GPHIP_OK) return status_to_wl(rc);
     g_handles.push_back(h);
+    g_n.push_back(dims[0]);
     MArgument_setInteger(res, (mint)g_handles.size() - 1);
     return LIBRARY_NO_ERROR;
 }
@@ -125,11 +127,14 @@ EXTERN_C DLLEXPORT int gphip_wl_covariance(WolframLibraryData lib, mint argc, MA
     gphip_handle h = lookup(MArgument_getInteger(args[0]));
     MTensor th = MArgument_getMTensor(args[1]);
     if (!h) return LIBRARY_FUNCTION_ERROR;
-    int p = 0; gphip_num_params(h, &p);
-    // N is recovered from the handle by asking for a 0-length query is not part of the ABI: the WL
-    // side passes theta only, so the shim keeps N next to the handle in a real deployment.
-    (void)p; (void)th; (void)res;
-    return LIBRARY_FUNCTION_ERROR;   // small-N debugging aid; wire up with a stored N when needed
+    const mint N = g_n[(size_t)MArgument_getInteger(args[0])];
+    MTensor r; mint d[2] = {N, N};
+    if (lib->MTensor_new(MType_Real, 2, d, &r)) return LIBRARY_FUNCTION_ERROR;
+    int rc = gphip_covariance(h, lib->MTensor_getRealData(th), (int)lib->MTensor_getDimensions(th)[0],
+                              lib->MTensor_getRealData(r));
+    if (rc != GPHIP_OK) { lib->MTensor_free(r); return status_to_wl(rc); }
+    MArgument_setMTensor(res, r);
+    return LIBRARY_NO_ERROR;
 }
 
 EXTERN_C DLLEXPORT int gphip_wl_destroy(WolframLibraryData, mint argc, MArgument* args, MArgument res) {
