@@ -200,7 +200,6 @@ __global__ __launch_bounds__(256) void kbuild_kernel(KBuildArgs a) {
 // ---------------------------------------------------------------------------------------------
 // potrf128: Cholesky of one 128x128 diagonal block AND its triangular inverse, in LDS.
 //
-// LDS image Ls[c*PLD + r] (column-major, PLD = 144 so MFMA fragment reads are conflict free).
 // Factor phase, 8 panels of 16 columns:
 //   (a) wave 0 factors the 16x16 diagonal block in registers (lane = row, v_readlane broadcasts),
 //   (b) one thread per row below solves its 16 panel entries against L_pp,
@@ -211,7 +210,13 @@ __global__ __launch_bounds__(256) void kbuild_kernel(KBuildArgs a) {
 // SPD verdict: pivot <= tol (tol = 64 eps (sf2+sn2)) or NaN -> info = NOT_SPD (stands for
 // LinearSolve::sing1/::luc -> Throw "MatInv", BGP:131-135).
 // ---------------------------------------------------------------------------------------------
-constexpr int PLD = 144;
+// LDS image: the 36 lower-triangle 16x16 tiles, tile (bi,bj) at ((bi(bi+1)/2 + bj) * 256) doubles,
+// column-major inside the tile.  72 KiB: the kernel fits on a CU next to one gemm_nt workgroup
+// (look-ahead runs it concurrently with the trailing SYRK), and MFMA fragment reads
+// (lane -> row l&15, k = l>>4) touch 64 distinct banks.
+constexpr int PT_LDS_DOUBLES = 36 * 256 + TB + 2;
+
+__device__ __forceinline__ int ptile(int bi, int bj) { return ((bi * (bi + 1) / 2) + bj) << 8; }
 
 __device__ __forceinline__ double readlane_d(double v, int src) {
     int lo = __double2loint(v), hi = __double2hiint(v);
@@ -225,27 +230,28 @@ __global__ __launch_bounds__(256) void potrf128_kernel(double* __restrict__ Abas
                                                        double* __restrict__ Winv, double* __restrict__ partial,
                                                        int nt, int* __restrict__ info,
                                                        const double* __restrict__ slotp) {
-    extern __shared__ double Ls[];            // [128][PLD] + dinv[128] + red[2]
-    double* dinv = Ls + TB * PLD;
+    extern __shared__ double Ls[];            // 36 tiles + dinv[128] + red[2]
+    double* dinv = Ls + 36 * 256;
     double* red = dinv + TB;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
+    const int er = tid & 15, ec = tid >> 4;   // element (row, col) of a 16x16 tile owned in copies
     const int slot = blockIdx.x;
     double* Ad = Abase + (long)slot * bstride + (long)b * TB * (ld + 1);
-    for (int c = wave; c < TB; c += 4)
-        *reinterpret_cast<double2*>(&Ls[c * PLD + 2 * lane]) =
-            *reinterpret_cast<const double2*>(Ad + (long)c * ld + 2 * lane);
+    for (int bi = 0; bi < 8; ++bi)
+        for (int bj = 0; bj <= bi; ++bj)
+            Ls[ptile(bi, bj) + tid] = Ad[(long)(bj * 16 + ec) * ld + bi * 16 + er];
     const double tol = slotp[(long)slot * SLOTP + 3];
     bool bad = false;
     __syncthreads();
 
     // ------------------------------ factor phase ------------------------------
     for (int p = 0; p < 8; ++p) {
-        const int j0 = 16 * p;
-        if (wave == 0) {                      // (a) 16x16 diagonal block, lane l15 owns row j0+l15
+        double* Dpp = Ls + ptile(p, p);
+        if (wave == 0) {                      // (a) 16x16 diagonal block, lane l15 owns row l15
             double a[16];
 #pragma unroll
-            for (int c = 0; c < 16; ++c) a[c] = Ls[(j0 + c) * PLD + j0 + l15];
+            for (int c = 0; c < 16; ++c) a[c] = Dpp[c * 16 + l15];
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 double dj = readlane_d(a[j], j);
@@ -258,30 +264,30 @@ __global__ __launch_bounds__(256) void potrf128_kernel(double* __restrict__ Abas
                     const double sc = readlane_d(a[j], c);
                     a[c] = __builtin_fma(-a[j], sc, a[c]);
                 }
-                if (lane == 0) dinv[j0 + j] = rs;
+                if (lane == 0) dinv[16 * p + j] = rs;
             }
             if (lane < 16) {
 #pragma unroll
                 for (int c = 0; c < 16; ++c)
-                    if (c <= l15) Ls[(j0 + c) * PLD + j0 + l15] = a[c];
+                    if (c <= l15) Dpp[c * 16 + l15] = a[c];
             }
         }
         __syncthreads();
         if (p == 7) break;
-        if (tid < TB - j0 - 16) {             // (b) rows below: x L_pp^T = a, one row per thread
-            const int r = j0 + 16 + tid;
+        if (tid < TB - 16 * p - 16) {         // (b) rows below: x L_pp^T = a, one row per thread
+            double* Xr = Ls + ptile(p + 1 + (tid >> 4), p) + (tid & 15);
             double x[16];
 #pragma unroll
-            for (int c = 0; c < 16; ++c) x[c] = Ls[(j0 + c) * PLD + r];
+            for (int c = 0; c < 16; ++c) x[c] = Xr[c * 16];
 #pragma unroll
             for (int c = 0; c < 16; ++c) {
                 double sacc = x[c];
 #pragma unroll
-                for (int k = 0; k < c; ++k) sacc = __builtin_fma(-x[k], Ls[(j0 + k) * PLD + j0 + c], sacc);
-                x[c] = sacc * dinv[j0 + c];
+                for (int k = 0; k < c; ++k) sacc = __builtin_fma(-x[k], Dpp[k * 16 + c], sacc);
+                x[c] = sacc * dinv[16 * p + c];
             }
 #pragma unroll
-            for (int c = 0; c < 16; ++c) Ls[(j0 + c) * PLD + r] = x[c];
+            for (int c = 0; c < 16; ++c) Xr[c * 16] = x[c];
         }
         __syncthreads();
         {                                      // (c) trailing update C -= X X^T on MFMA
@@ -290,26 +296,24 @@ __global__ __launch_bounds__(256) void potrf128_kernel(double* __restrict__ Abas
                 int u = 0;
                 while ((u + 1) * (u + 2) / 2 <= tt) ++u;
                 const int v = tt - u * (u + 1) / 2;
-                const int ri = (p + 1 + u) * 16, ci = (p + 1 + v) * 16;
+                const double* Xc = Ls + ptile(p + 1 + v, p) + l4 * 16 + l15;
+                const double* Xrw = Ls + ptile(p + 1 + u, p) + l4 * 16 + l15;
                 d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-                    const double fa = Ls[(j0 + 4 * kk + l4) * PLD + ci + l15];
-                    const double fb = Ls[(j0 + 4 * kk + l4) * PLD + ri + l15];
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fa, fb, acc, 0, 0, 0);
-                }
+                for (int kk = 0; kk < 4; ++kk)
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Xc[kk * 64], Xrw[kk * 64], acc, 0, 0, 0);
+                double* Ct = Ls + ptile(p + 1 + u, p + 1 + v) + l4 * 16 + l15;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) Ls[(ci + l4 + 4 * r) * PLD + ri + l15] -= acc[r];
+                for (int r = 0; r < 4; ++r) Ct[r * 64] -= acc[r];
             }
         }
         __syncthreads();
     }
 
-    // L back to HBM (lower triangle incl. diagonal; the block's upper part is never read)
-    for (int c = wave; c < TB; c += 4) {
-        const double2 v = *reinterpret_cast<const double2*>(&Ls[c * PLD + 2 * lane]);
-        *reinterpret_cast<double2*>(Ad + (long)c * ld + 2 * lane) = v;
-    }
+    // L back to HBM (lower-triangle tiles; diagonal tiles whole, their upper part is never read)
+    for (int bi = 0; bi < 8; ++bi)
+        for (int bj = 0; bj <= bi; ++bj)
+            Ad[(long)(bj * 16 + ec) * ld + bi * 16 + er] = Ls[ptile(bi, bj) + tid];
     {   // sum log L_jj = -sum log dinv_j
         double lg = 0.0;
         if (tid < TB) lg = -log(dinv[tid]);
@@ -320,26 +324,29 @@ __global__ __launch_bounds__(256) void potrf128_kernel(double* __restrict__ Abas
     // ------------------------------ inverse phase ------------------------------
     {   // (i) the eight 16x16 diagonal inverses: thread = (block, column)
         double w[16];
-        const int blk = tid >> 4, c = tid & 15, j0 = blk * 16;
+        const int blk = tid >> 4, c = tid & 15;
+        double* Dbb = Ls + ptile(blk & 7, blk & 7);
         if (tid < TB) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 double sacc = 0.0;
 #pragma unroll
-                for (int k = 0; k < i; ++k) sacc = __builtin_fma(Ls[(j0 + k) * PLD + j0 + i], w[k], sacc);
-                w[i] = (i < c) ? 0.0 : ((i == c) ? dinv[j0 + i] : -sacc * dinv[j0 + i]);
+                for (int k = 0; k < i; ++k) sacc = __builtin_fma(Dbb[k * 16 + i], w[k], sacc);
+                const double di = dinv[16 * blk + i];
+                w[i] = (i < c) ? 0.0 : ((i == c) ? di : -sacc * di);
             }
         }
         __syncthreads();
         if (tid < TB) {
 #pragma unroll
             for (int i = 0; i < 16; ++i)
-                if (i >= c) Ls[(j0 + c) * PLD + j0 + i] = w[i];
+                if (i >= c) Dbb[c * 16 + i] = w[i];
         }
         __syncthreads();
     }
     for (int pb = 6; pb >= 0; --pb) {          // (ii) block column pb, rows q = pb+1..7
-        const int c0 = pb * 16, t = 7 - pb;
+        const int t = 7 - pb;
+        const double* Wpp = Ls + ptile(pb, pb);
         // step 1: T'_r = T_r W_pp  (W_pp lower triangular: mask k < j)
         d4 t1[2];
 #pragma unroll
@@ -347,12 +354,12 @@ __global__ __launch_bounds__(256) void potrf128_kernel(double* __restrict__ Abas
             t1[s] = (d4){0.0, 0.0, 0.0, 0.0};
             const int rr = wave + 4 * s;
             if (rr < t) {
-                const int r0 = (pb + 1 + rr) * 16;
+                const double* Tr = Ls + ptile(pb + 1 + rr, pb);
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
                     const int k = 4 * kk + l4;
-                    const double fa = Ls[(c0 + k) * PLD + r0 + l15];                    // T_r(i=l15, k)
-                    const double fb = (k >= l15) ? Ls[(c0 + l15) * PLD + c0 + k] : 0.0;   // W_pp(k, j=l15)
+                    const double fa = Tr[k * 16 + l15];                               // T_r(i=l15, k)
+                    const double fb = (k >= l15) ? Wpp[l15 * 16 + k] : 0.0;           // W_pp(k, j=l15)
                     t1[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa, fb, t1[s], 0, 0, 0);
                 }
             }
@@ -362,9 +369,9 @@ __global__ __launch_bounds__(256) void potrf128_kernel(double* __restrict__ Abas
         for (int s = 0; s < 2; ++s) {
             const int rr = wave + 4 * s;
             if (rr < t) {
-                const int r0 = (pb + 1 + rr) * 16;
+                double* Tr = Ls + ptile(pb + 1 + rr, pb);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) Ls[(c0 + l15) * PLD + r0 + l4 + 4 * r] = t1[s][r];
+                for (int r = 0; r < 4; ++r) Tr[l15 * 16 + l4 + 4 * r] = t1[s][r];
             }
         }
         __syncthreads();
@@ -375,15 +382,16 @@ __global__ __launch_bounds__(256) void potrf128_kernel(double* __restrict__ Abas
             t2[s] = (d4){0.0, 0.0, 0.0, 0.0};
             const int qq = wave + 4 * s;
             if (qq < t) {
-                const int q = pb + 1 + qq, q0 = q * 16;
+                const int q = pb + 1 + qq;
                 for (int r = pb + 1; r <= q; ++r) {
-                    const int r0 = r * 16;
+                    const double* Wqr = Ls + ptile(q, r);
+                    const double* Tr = Ls + ptile(r, pb);
 #pragma unroll
                     for (int kk = 0; kk < 4; ++kk) {
                         const int k = 4 * kk + l4;
-                        double fa = Ls[(r0 + k) * PLD + q0 + l15];                       // W_qr(i=l15, k)
+                        double fa = Wqr[k * 16 + l15];                                // W_qr(i=l15, k)
                         if (r == q && k > l15) fa = 0.0;
-                        const double fb = Ls[(c0 + l15) * PLD + r0 + k];                  // T'_r(k, j=l15)
+                        const double fb = Tr[l15 * 16 + k];                           // T'_r(k, j=l15)
                         t2[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa, fb, t2[s], 0, 0, 0);
                     }
                 }
@@ -394,21 +402,21 @@ __global__ __launch_bounds__(256) void potrf128_kernel(double* __restrict__ Abas
         for (int s = 0; s < 2; ++s) {
             const int qq = wave + 4 * s;
             if (qq < t) {
-                const int q0 = (pb + 1 + qq) * 16;
+                double* Wq = Ls + ptile(pb + 1 + qq, pb);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) Ls[(c0 + l15) * PLD + q0 + l4 + 4 * r] = -t2[s][r];
+                for (int r = 0; r < 4; ++r) Wq[l15 * 16 + l4 + 4 * r] = -t2[s][r];
             }
         }
         __syncthreads();
     }
     // W to the workspace, dense column-major 128x128 with an explicit zero upper triangle
     double* Wg = Winv + ((long)slot * nt + b) * TB * TB;
-    for (int c = wave; c < TB; c += 4) {
-        double2 v = *reinterpret_cast<const double2*>(&Ls[c * PLD + 2 * lane]);
-        if (2 * lane < c) v.x = 0.0;
-        if (2 * lane + 1 < c) v.y = 0.0;
-        *reinterpret_cast<double2*>(Wg + c * TB + 2 * lane) = v;
-    }
+    for (int bi = 0; bi < 8; ++bi)
+        for (int bj = 0; bj < 8; ++bj) {
+            double v = 0.0;
+            if (bi > bj || (bi == bj && er >= ec)) v = Ls[ptile(bi, bj) + tid];
+            Wg[(bj * 16 + ec) * TB + bi * 16 + er] = v;
+        }
     if (tid == 0) {
         partial[(long)slot * nt + b] = red[0] + red[1];
         if (bad) info[slot] = 1;

@@ -28,7 +28,7 @@ namespace {
 
 constexpr double LOG_TWO_PI = 1.8378770664093454835606594728112;
 constexpr double PIVOT_TOL_REL = 64.0 * 2.220446049250313e-16;
-constexpr size_t POTRF_LDS = (size_t)(TB * PLD + TB + 2) * 8;
+constexpr size_t POTRF_LDS = (size_t)PT_LDS_DOUBLES * 8;
 
 struct ProfRec {
     int cls;
@@ -41,7 +41,11 @@ struct ProfRec {
 struct gphip_ctx {
     std::mutex mu;
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;      // main stream: build, trailing updates, copies
+    hipStream_t pstream = nullptr;     // panel stream (high priority): look-ahead panel factorisation
+    hipStream_t cs = nullptr;          // stream the launch helpers currently target
+    std::vector<hipEvent_t> sync_events;
+    size_t sync_used = 0;
     int64_t N = 0, d = 0, Npad = 0, Nt = 0, ld = 0;
     int kernel_id = 0, mean_id = 0, nl = 0, p = 0, kt = 0;
     double sum_y = 0, sum_y2 = 0;
@@ -54,7 +58,7 @@ struct gphip_ctx {
     double *hInvEll = nullptr, *hSlotp = nullptr, *hRes = nullptr;
     int* hInfo = nullptr;
     // options
-    int panel = 4, profile = 0, swizzle = 1, max_slots = 256;
+    int panel = 4, profile = 0, swizzle = 1, max_slots = 256, lookahead = 1;
     // fitted state (slot 0)
     bool fitted = false;
     std::vector<double> theta_fit;
@@ -113,12 +117,12 @@ struct ProfScope {
             r.bytes = bytes;
             r.e0 = get_event(h);
             r.e1 = get_event(h);
-            (void)hipEventRecord(r.e0, h->stream);
+            (void)hipEventRecord(r.e0, h->cs);
         }
     }
     ~ProfScope() {
         if (on) {
-            (void)hipEventRecord(r.e1, h->stream);
+            (void)hipEventRecord(r.e1, h->cs);
             h->recs.push_back(r);
         }
     }
@@ -251,37 +255,91 @@ void launch_gemm(gphip_ctx* h, int cls, double* C, long ldc, long cbs, const dou
     ProfScope ps(h, cls, flops, bytes);
     const dim3 grid(g.ntiles, nslots);
     const size_t lds = (size_t)2 * 2 * GK * LDT * 8;
-    if (mode == 1) hipLaunchKernelGGL(gemm_nt_kernel<2>, grid, dim3(256), lds, h->stream, g);
-    else if (cls == 4) hipLaunchKernelGGL(gemm_nt_kernel<0>, grid, dim3(256), lds, h->stream, g);
-    else hipLaunchKernelGGL(gemm_nt_kernel<1>, grid, dim3(256), lds, h->stream, g);
+    if (mode == 1) hipLaunchKernelGGL(gemm_nt_kernel<2>, grid, dim3(256), lds, h->cs, g);
+    else if (cls == 4) hipLaunchKernelGGL(gemm_nt_kernel<0>, grid, dim3(256), lds, h->cs, g);
+    else hipLaunchKernelGGL(gemm_nt_kernel<1>, grid, dim3(256), lds, h->cs, g);
 }
 
-// two-level right-looking Cholesky of slots [0, nslots) (workspace already built)
+hipEvent_t sync_event(gphip_ctx* h) {       // untimed events for cross-stream ordering
+    if (h->sync_used == h->sync_events.size()) {
+        hipEvent_t e;
+        (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
+        h->sync_events.push_back(e);
+    }
+    return h->sync_events[h->sync_used++];
+}
+
+// factor the tile columns [K0, K0+nin) of all slots (diagonal blocks, panel solves, in-panel updates)
+void queue_panel(gphip_ctx* h, int K0, int nin, int nslots) {
+    const int Nt = (int)h->Nt, R = Nt + 1;
+    const long ld = h->ld, bs = ld * ld, lrs = (long)Nt * TB * TB;
+    for (int s = 0; s < nin; ++s) {
+        const int b = K0 + s;
+        {
+            ProfScope ps(h, 1, 2.0 * TB * TB * TB / 3.0 * nslots, 0.0);
+            hipLaunchKernelGGL(potrf128_kernel, dim3(nslots), dim3(256), POTRF_LDS, h->cs, h->dA, ld, bs, b,
+                               h->dW, h->dPartial, Nt, h->dInfo, h->dSlotp);
+        }
+        // panel solve X <- X W_b^T for every row tile below the diagonal block (incl. rhs rows)
+        launch_gemm(h, 2, h->dA, ld, bs, h->dA + (long)b * TB * ld, ld, bs,
+                    h->dW + (long)b * TB * TB - (long)b * TB, TB, lrs, TB, b + 1, R, b, b + 1, 0, nslots, 1);
+        if (s + 1 < nin) {
+            const double* P = h->dA + (long)b * TB * ld;
+            launch_gemm(h, 3, h->dA, ld, bs, P, ld, bs, P, ld, bs, TB, b + 1, R, b + 1, K0 + nin, 1, nslots);
+        }
+    }
+}
+
+// Two-level right-looking Cholesky of slots [0, nslots) (workspace already built on h->stream).
+// With look-ahead (default) the panel stream factors panel k+1 while the main stream is still
+// applying panel k to everything right of panel k+1:
+//   panel stream:  [wait REST(k-1)]  LA(k) = update of panel k+1's columns by panel k;  factor panel k+1
+//   main  stream:  [wait panel k]    REST(k) = update of the columns right of panel k+1 by panel k
 void queue_factor(gphip_ctx* h, int nslots) {
     const int Nt = (int)h->Nt, R = Nt + 1;     // R = tile rows incl. the rhs block-row
     const long ld = h->ld, bs = ld * ld;
-    const long lrs = (long)Nt * TB * TB;
-    for (int K0 = 0; K0 < Nt; K0 += h->panel) {
-        const int nin = (Nt - K0 < h->panel) ? (Nt - K0) : h->panel;
-        for (int s = 0; s < nin; ++s) {
-            const int b = K0 + s;
-            {
-                ProfScope ps(h, 1, (double)TB * TB * TB / 3.0 * nslots, 0.0);
-                hipLaunchKernelGGL(potrf128_kernel, dim3(nslots), dim3(256), POTRF_LDS, h->stream, h->dA,
-                                   ld, bs, b, h->dW, h->dPartial, Nt, h->dInfo, h->dSlotp);
-            }
-            // panel solve X <- X W_b^T for every row tile below the diagonal block (incl. rhs rows)
-            launch_gemm(h, 2, h->dA, ld, bs, h->dA + (long)b * TB * ld, ld, bs,
-                        h->dW + (long)b * TB * TB - (long)b * TB, TB, lrs, TB, b + 1, R, b, b + 1, 0, nslots, 1);
-            if (s + 1 < nin) {
-                const double* P = h->dA + (long)b * TB * ld;
-                launch_gemm(h, 3, h->dA, ld, bs, P, ld, bs, P, ld, bs, TB, b + 1, R, b + 1, K0 + nin, 1,
-                            nslots);
-            }
+    const int P = h->panel;
+    const int nouter = (Nt + P - 1) / P;
+    auto k0 = [&](int k) { return k * P < Nt ? k * P : Nt; };
+    auto trailing = [&](int k, int c_lo, int c_hi, int cls) {      // apply panel k to tile columns [c_lo,c_hi)
+        const double* Pk = h->dA + (long)k0(k) * TB * ld;
+        launch_gemm(h, cls, h->dA, ld, bs, Pk, ld, bs, Pk, ld, bs, (k0(k + 1) - k0(k)) * TB, c_lo, R, c_lo, c_hi,
+                    1, nslots);
+    };
+    if (!h->lookahead || nouter < 2) {
+        h->cs = h->stream;
+        for (int k = 0; k < nouter; ++k) {
+            queue_panel(h, k0(k), k0(k + 1) - k0(k), nslots);
+            trailing(k, k0(k + 1), R, 4);
         }
-        const double* P = h->dA + (long)K0 * TB * ld;
-        launch_gemm(h, 4, h->dA, ld, bs, P, ld, bs, P, ld, bs, nin * TB, K0 + nin, R, K0 + nin, R, 1,
-                    nslots);
+    } else {
+        h->sync_used = 0;
+        hipEvent_t built = sync_event(h);
+        (void)hipEventRecord(built, h->stream);
+        (void)hipStreamWaitEvent(h->pstream, built, 0);
+        h->cs = h->pstream;
+        queue_panel(h, 0, k0(1), nslots);
+        hipEvent_t ev_panel = sync_event(h);
+        (void)hipEventRecord(ev_panel, h->pstream);
+        hipEvent_t ev_rest = nullptr;
+        for (int k = 0; k < nouter; ++k) {
+            hipEvent_t ev_next = nullptr;
+            if (k + 1 < nouter) {
+                h->cs = h->pstream;
+                if (ev_rest) (void)hipStreamWaitEvent(h->pstream, ev_rest, 0);
+                trailing(k, k0(k + 1), k0(k + 2), 3);                       // LA(k)
+                queue_panel(h, k0(k + 1), k0(k + 2) - k0(k + 1), nslots);    // factor panel k+1
+                ev_next = sync_event(h);
+                (void)hipEventRecord(ev_next, h->pstream);
+            }
+            h->cs = h->stream;
+            (void)hipStreamWaitEvent(h->stream, ev_panel, 0);
+            trailing(k, k0(k + 2), R, 4);                                   // REST(k)
+            ev_rest = sync_event(h);
+            (void)hipEventRecord(ev_rest, h->stream);
+            ev_panel = ev_next;
+        }
+        h->cs = h->stream;
     }
     hipLaunchKernelGGL(finalize_kernel, dim3(nslots), dim3(64), 0, h->stream, h->dA, ld, bs,
                        (int)h->Npad, h->dPartial, Nt, h->dRes);
@@ -431,7 +489,13 @@ int gphip_create(const void* X, const void* y, int64_t N, int64_t d, int kernel_
     for (int64_t i = 0; i < N; ++i) { h->sum_y += yd[i]; h->sum_y2 += yd[i] * yd[i]; }
     auto bail = [&](int code) { gphip_destroy(h); return code; };
     if (hipSetDevice(h->device) != hipSuccess) return bail(GPHIP_ERR_HIP);
-    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return bail(GPHIP_ERR_HIP);
+    {
+        int lo = 0, hi = 0;                         // numerically lower = higher priority
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        if (hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, lo) != hipSuccess) return bail(GPHIP_ERR_HIP);
+        if (hipStreamCreateWithPriority(&h->pstream, hipStreamNonBlocking, hi) != hipSuccess) return bail(GPHIP_ERR_HIP);
+        h->cs = h->stream;
+    }
     std::vector<double> xt((size_t)d * h->Npad, 0.0), yp((size_t)h->Npad, 0.0);
     for (int64_t i = 0; i < N; ++i) {
         for (int64_t j = 0; j < d; ++j) xt[(size_t)j * h->Npad + i] = Xd[i * d + j];
@@ -449,12 +513,15 @@ int gphip_create(const void* X, const void* y, int64_t N, int64_t d, int kernel_
 int gphip_destroy(gphip_handle h) {
     if (!h) return GPHIP_OK;
     (void)hipSetDevice(h->device);
+    if (h->pstream) (void)hipStreamSynchronize(h->pstream);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     free_slots(h);
     (void)hipFree(h->dXt); (void)hipFree(h->dY);
     (void)hipFree(h->dV); (void)hipFree(h->dXsT); (void)hipFree(h->dXsS); (void)hipFree(h->dMean);
     (void)hipFree(h->dVar);
     for (auto e : h->pool) (void)hipEventDestroy(e);
+    for (auto e : h->sync_events) (void)hipEventDestroy(e);
+    if (h->pstream) (void)hipStreamDestroy(h->pstream);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return GPHIP_OK;
@@ -601,6 +668,7 @@ int gphip_set_option(gphip_handle h, const char* name, double value) {
     if (!strcmp(name, "panel")) { if (v < 1 || v > 64) return fail(h, GPHIP_ERR_ARG, "panel out of range"); h->panel = v; }
     else if (!strcmp(name, "profile")) h->profile = v;
     else if (!strcmp(name, "xcd_swizzle")) h->swizzle = v;
+    else if (!strcmp(name, "lookahead")) h->lookahead = v;
     else if (!strcmp(name, "max_slots")) { if (v < 1) return fail(h, GPHIP_ERR_ARG, "max_slots < 1"); h->max_slots = v; }
     else return fail(h, GPHIP_ERR_ARG, "unknown option");
     return GPHIP_OK;
