@@ -449,6 +449,8 @@ struct GemmArgs {
     int nrect;                                   // tiles in the full-height rectangle part
     int ntiles;
     int swizzle;                                 // XCD-aware block remap
+    int super;                                   // 1: pure-triangle launch enumerated in 8x8 super-tiles,
+                                                 //    one super-tile per XCD at a time (L2 reuse)
     int mode;                                    // 0: C -= A B^T ; 1: C = A B^T (in-place panel solve
                                                  //    X <- X W^T: A aliases C, one column tile)
 };
@@ -476,13 +478,29 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
     const int wi = wave & 1, wj = wave >> 1;
     const int slot = blockIdx.y;
     int bid = blockIdx.x;
-    if (g.swizzle) {                           // blocks b, b+8, b+16.. share an XCD (b % 8): give
-        const int nx = 8, n = g.ntiles;        // each XCD a contiguous chunk of the tile list
-        const int q = n / nx, rem = n % nx, x = bid % nx, o = bid / nx;
-        bid = (x < rem ? x * (q + 1) : rem * (q + 1) + (x - rem) * q) + o;
-    }
     int ti, tj;
-    gemm_tile_decode(g, bid, ti, tj);
+    if (g.super) {
+        // Blocks b, b+8, b+16, .. run on XCD b % 8 (observed dispatch rule; speed only).  Give each
+        // XCD whole 8x8 super-tiles: its 64 resident workgroups then share 8 row panels and 8
+        // column panels through that XCD's private 4 MiB L2 instead of streaming 65 panels.
+        const int H = g.r1 - g.r0, S = (H + 7) >> 3;
+        const int x = bid & 7, q = bid >> 3;
+        const int sidx = (q >> 6) * 8 + x, within = q & 63;
+        if (sidx >= S * (S + 1) / 2) return;
+        int I, J;
+        tri_decode(sidx, S, I, J);
+        const int u = 8 * I + (within & 7), v = 8 * J + (within >> 3);
+        if (u >= H || v > u) return;
+        ti = g.r0 + u;
+        tj = g.r0 + v;
+    } else {
+        if (g.swizzle) {                       // give each XCD a contiguous chunk of the tile list
+            const int nx = 8, n = g.ntiles;
+            const int q = n / nx, rem = n % nx, x = bid % nx, o = bid / nx;
+            bid = (x < rem ? x * (q + 1) : rem * (q + 1) + (x - rem) * q) + o;
+        }
+        gemm_tile_decode(g, bid, ti, tj);
+    }
 
     const double* Ag = g.A + (long)slot * g.a_bstride + (long)ti * TB;
     const double* Bg = g.B + (long)slot * g.b_bstride + (long)tj * TB;
@@ -506,14 +524,25 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
         }
     };
 
+    // C tile: lane holds i = i0 + y*16 + (lane&15), j = j0 + x*16 + (lane>>4) + 4r (f64 MFMA D layout)
+    double* Cg = g.C + (long)slot * g.c_bstride + ((long)tj * TB + wj * 64 + (lane >> 4)) * g.ldc +
+                 (long)ti * TB + wi * 64 + (lane & 15);
+    const int nk = g.K / GK;
+    stage(0, 0);
+    // Update roles start the accumulators AT C (loads fly with the first DMA stage) and feed the
+    // MFMA the negated J fragment, so acc ends as C - A B^T and the epilogue is stores only.
     d4 acc[4][4];
 #pragma unroll
     for (int x = 0; x < 4; ++x)
 #pragma unroll
-        for (int y = 0; y < 4; ++y) acc[x][y] = (d4){0.0, 0.0, 0.0, 0.0};
-
-    const int nk = g.K / GK;
-    stage(0, 0);
+        for (int y = 0; y < 4; ++y) {
+            if (ROLE == 2) {
+                acc[x][y] = (d4){0.0, 0.0, 0.0, 0.0};
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[x][y][r] = Cg[(long)(x * 16 + 4 * r) * g.ldc + y * 16];
+            }
+        }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     const int foff = (lane >> 4) * LDT + (lane & 15);
@@ -528,7 +557,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
 #pragma unroll
             for (int f = 0; f < 4; ++f) {
                 fi[f] = Is[kk * 4 * LDT + f * 16];
-                fj[f] = Js[kk * 4 * LDT + f * 16];
+                fj[f] = (ROLE == 2) ? Js[kk * 4 * LDT + f * 16] : -Js[kk * 4 * LDT + f * 16];
             }
 #pragma unroll
             for (int x = 0; x < 4; ++x)
@@ -540,19 +569,14 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
         __syncthreads();
     }
 
-    // epilogue: C(i,j) -= acc.  lane holds i = i0 + y*16 + (lane&15), j = j0 + x*16 + (lane>>4) + 4r
-    double* Cg = g.C + (long)slot * g.c_bstride + ((long)tj * TB + wj * 64 + (lane >> 4)) * g.ldc +
-                 (long)ti * TB + wi * 64 + (lane & 15);
+    // epilogue: stores only
 #pragma unroll
     for (int x = 0; x < 4; ++x)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             double* cp = Cg + (long)(x * 16 + 4 * r) * g.ldc;
 #pragma unroll
-            for (int y = 0; y < 4; ++y) {
-                if (g.mode == 0) cp[y * 16] -= acc[x][y][r];
-                else cp[y * 16] = acc[x][y][r];
-            }
+            for (int y = 0; y < 4; ++y) cp[y * 16] = acc[x][y][r];
         }
 }
 

@@ -58,7 +58,7 @@ struct gphip_ctx {
     double *hInvEll = nullptr, *hSlotp = nullptr, *hRes = nullptr;
     int* hInfo = nullptr;
     // options
-    int panel = 4, profile = 0, swizzle = 1, max_slots = 256, lookahead = 1;
+    int panel = 4, profile = 0, swizzle = 1, max_slots = 256, lookahead = 1, supertile = 0;
     // fitted state (slot 0)
     bool fitted = false;
     std::vector<double> theta_fit;
@@ -250,10 +250,17 @@ void launch_gemm(gphip_ctx* h, int cls, double* C, long ldc, long cbs, const dou
         g.ntiles = g.nrect + ntc * H - ntc * (ntc - 1) / 2;
     }
     g.swizzle = h->swizzle && g.ntiles >= 64;
+    int grid_x = g.ntiles;
+    if (tri && r0 == c0 && W == H && h->supertile && H >= 16 && mode == 0) {   // pure triangle: 8x8 super-tiles
+        const int S = (H + 7) / 8;
+        const int nsuper = (S * (S + 1) / 2 + 7) / 8 * 8;
+        g.super = 1;
+        grid_x = nsuper * 64;
+    }
     const double flops = 2.0 * TB * TB * (double)K * g.ntiles * nslots;
     const double bytes = 8.0 * TB * ((double)2 * TB + 2.0 * K) * g.ntiles * nslots;
     ProfScope ps(h, cls, flops, bytes);
-    const dim3 grid(g.ntiles, nslots);
+    const dim3 grid(grid_x, nslots);
     const size_t lds = (size_t)2 * 2 * GK * LDT * 8;
     if (mode == 1) hipLaunchKernelGGL(gemm_nt_kernel<2>, grid, dim3(256), lds, h->cs, g);
     else if (cls == 4) hipLaunchKernelGGL(gemm_nt_kernel<0>, grid, dim3(256), lds, h->cs, g);
@@ -669,6 +676,7 @@ int gphip_set_option(gphip_handle h, const char* name, double value) {
     else if (!strcmp(name, "profile")) h->profile = v;
     else if (!strcmp(name, "xcd_swizzle")) h->swizzle = v;
     else if (!strcmp(name, "lookahead")) h->lookahead = v;
+    else if (!strcmp(name, "supertile")) h->supertile = v;
     else if (!strcmp(name, "max_slots")) { if (v < 1) return fail(h, GPHIP_ERR_ARG, "max_slots < 1"); h->max_slots = v; }
     else return fail(h, GPHIP_ERR_ARG, "unknown option");
     return GPHIP_OK;
