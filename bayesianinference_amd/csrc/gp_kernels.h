@@ -470,7 +470,10 @@ __device__ __forceinline__ void gemm_tile_decode(const GemmArgs& g, int t, int& 
 
 // ROLE only gives each use its own kernel symbol (separate rows in rocprof summaries):
 // 0 = trailing SYRK (K = panel*128, the dominant kernel), 1 = in-panel GEMM (K = 128),
-// 2 = panel solve X <- X W^T (mode 1).
+// 2 = panel solve X <- X W^T (mode 1),
+// 3 = "NN" form for the backward solve: the J operand is read transposed, B(j,k) at
+//     B[k + j*ldb] (k contiguous), through an XOR-swizzled [j][16] LDS image; g.mode picks
+//     C -= A B (0) or C = A B (1).
 template <int ROLE>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
     extern __shared__ double smem[];           // [2 stages][I: GK*LDT | J: GK*LDT]
@@ -503,7 +506,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
     }
 
     const double* Ag = g.A + (long)slot * g.a_bstride + (long)ti * TB;
-    const double* Bg = g.B + (long)slot * g.b_bstride + (long)tj * TB;
+    const double* Bg = g.B + (long)slot * g.b_bstride + (ROLE == 3 ? (long)tj * TB * g.ldb : (long)tj * TB);
     // Staging: LDS-DMA (global_load_lds_dwordx4), no staging registers and no ds_write pass.
     // One wave-instruction moves one k-column of a tile: 64 lanes x 16 B = 128 rows = 1 KiB,
     // landing lane-linear at a wave-uniform LDS base (column kk at kk*LDT doubles, so the
@@ -519,8 +522,16 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
             const long kcol = (long)kb * GK + kk;
             __builtin_amdgcn_global_load_lds((glb_void*)(Ag + kcol * g.lda + srow),
                                              (lds_void*)(Is + kk * LDT), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((glb_void*)(Bg + kcol * g.ldb + srow),
-                                             (lds_void*)(Js + kk * LDT), 16, 0, 0);
+            if (ROLE != 3) {
+                __builtin_amdgcn_global_load_lds((glb_void*)(Bg + kcol * g.ldb + srow),
+                                                 (lds_void*)(Js + kk * LDT), 16, 0, 0);
+            } else {
+                // transposed source: instruction kk covers j = 8kk..8kk+7, lane -> (j, k-pair);
+                // image Js[j*16 + 2*((k>>1) ^ (j&7)) + (k&1)] (swizzle applied on the source side)
+                const int j = 8 * kk + (lane >> 3), kp = (lane & 7) ^ (j & 7);
+                __builtin_amdgcn_global_load_lds((glb_void*)(Bg + (long)kb * GK + 2 * kp + (long)j * g.ldb),
+                                                 (lds_void*)(Js + kk * 128), 16, 0, 0);
+            }
         }
     };
 
@@ -536,7 +547,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
     for (int x = 0; x < 4; ++x)
 #pragma unroll
         for (int y = 0; y < 4; ++y) {
-            if (ROLE == 2) {
+            if (ROLE == 2 || (ROLE == 3 && g.mode == 1)) {
                 acc[x][y] = (d4){0.0, 0.0, 0.0, 0.0};
             } else {
 #pragma unroll
@@ -557,7 +568,14 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
 #pragma unroll
             for (int f = 0; f < 4; ++f) {
                 fi[f] = Is[kk * 4 * LDT + f * 16];
-                fj[f] = (ROLE == 2) ? Js[kk * 4 * LDT + f * 16] : -Js[kk * 4 * LDT + f * 16];
+                if (ROLE == 3) {
+                    const int jrow = wj * 64 + f * 16 + (lane & 15), k = 4 * kk + (lane >> 4);
+                    const double v = smem[cur * (2 * GK * LDT) + GK * LDT + jrow * 16 +
+                                          2 * ((k >> 1) ^ (jrow & 7)) + (k & 1)];
+                    fj[f] = (g.mode == 1) ? v : -v;
+                } else {
+                    fj[f] = (ROLE == 2) ? Js[kk * 4 * LDT + f * 16] : -Js[kk * 4 * LDT + f * 16];
+                }
             }
 #pragma unroll
             for (int x = 0; x < 4; ++x)

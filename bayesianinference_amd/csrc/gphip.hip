@@ -259,10 +259,11 @@ void launch_gemm(gphip_ctx* h, int cls, double* C, long ldc, long cbs, const dou
     }
     const double flops = 2.0 * TB * TB * (double)K * g.ntiles * nslots;
     const double bytes = 8.0 * TB * ((double)2 * TB + 2.0 * K) * g.ntiles * nslots;
-    ProfScope ps(h, cls, flops, bytes);
+    ProfScope ps(h, cls == 6 ? 3 : cls, flops, bytes);
     const dim3 grid(grid_x, nslots);
     const size_t lds = (size_t)2 * 2 * GK * LDT * 8;
-    if (mode == 1) hipLaunchKernelGGL(gemm_nt_kernel<2>, grid, dim3(256), lds, h->cs, g);
+    if (cls == 6) hipLaunchKernelGGL(gemm_nt_kernel<3>, grid, dim3(256), lds, h->cs, g);
+    else if (mode == 1) hipLaunchKernelGGL(gemm_nt_kernel<2>, grid, dim3(256), lds, h->cs, g);
     else if (cls == 4) hipLaunchKernelGGL(gemm_nt_kernel<0>, grid, dim3(256), lds, h->cs, g);
     else hipLaunchKernelGGL(gemm_nt_kernel<1>, grid, dim3(256), lds, h->cs, g);
 }
@@ -447,6 +448,8 @@ int set_func_attrs(gphip_ctx* h) {
                                hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * GK * LDT * 8));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<2>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * GK * LDT * 8));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<3>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * GK * LDT * 8));
     return GPHIP_OK;
 }
 
@@ -603,6 +606,48 @@ int gphip_covariance(gphip_handle h, const double* theta, int p, double* K) {
     return GPHIP_OK;
 }
 
+static int ensure_vbuf(gphip_ctx* h, int64_t cap) {
+    if (cap <= h->vcap) return GPHIP_OK;
+    (void)hipFree(h->dV); (void)hipFree(h->dXsT); (void)hipFree(h->dXsS); (void)hipFree(h->dMean); (void)hipFree(h->dVar);
+    h->dV = h->dXsT = h->dXsS = h->dMean = h->dVar = nullptr;
+    h->vcap = 0;
+    HIPCHK(hipMalloc(&h->dV, (size_t)cap * h->Npad * 8));
+    HIPCHK(hipMalloc(&h->dXsT, (size_t)cap * h->d * 8));
+    HIPCHK(hipMalloc(&h->dXsS, (size_t)cap * h->d * 8));
+    HIPCHK(hipMalloc(&h->dMean, (size_t)cap * 8));
+    HIPCHK(hipMalloc(&h->dVar, (size_t)cap * 8));
+    h->vcap = cap;
+    return GPHIP_OK;
+}
+
+// V <- V L^-T for the mpad x Npad row block in dV (right-looking over the 128-tile columns of L):
+// every row of V becomes (L^-1 v)^T.  Panel solves and updates are the same MFMA GEMM kernel.
+static void queue_forward_rows(gphip_ctx* h, int64_t mpad) {
+    const int Nt = (int)h->Nt, Mt = (int)(mpad / TB);
+    const long ld = h->ld;
+    for (int b = 0; b < Nt; ++b) {
+        launch_gemm(h, 2, h->dV, mpad, 0, h->dV + (long)b * TB * mpad, mpad, 0,
+                    h->dW + (long)b * TB * TB - (long)b * TB, TB, 0, TB, 0, Mt, b, b + 1, 0, 1, 1);
+        if (b + 1 < Nt)
+            launch_gemm(h, 3, h->dV, mpad, 0, h->dV + (long)b * TB * mpad, mpad, 0,
+                        h->dA + (long)b * TB * ld, ld, 0, TB, 0, Mt, b + 1, Nt, 0, 1);
+    }
+}
+
+// V <- V L^-1 (backward substitution, block columns from last to first), "NN" GEMM role:
+//   X_b = Y_b W_b ;  Y_c -= X_b L(b,c) for c < b.
+static void queue_backward_rows(gphip_ctx* h, int64_t mpad) {
+    const int Nt = (int)h->Nt, Mt = (int)(mpad / TB);
+    const long ld = h->ld;
+    for (int b = Nt - 1; b >= 0; --b) {
+        launch_gemm(h, 6, h->dV, mpad, 0, h->dV + (long)b * TB * mpad, mpad, 0,
+                    h->dW, TB, 0, TB, 0, Mt, b, b + 1, 0, 1, 1);
+        if (b > 0)
+            launch_gemm(h, 6, h->dV, mpad, 0, h->dV + (long)b * TB * mpad, mpad, 0,
+                        h->dA + (long)b * TB, ld, 0, TB, 0, Mt, 0, b, 0, 1, 0);
+    }
+}
+
 int gphip_predict(gphip_handle h, const void* Xs, int64_t M, double* mean, double* var) {
     if (!h || !Xs || !mean || !var) return fail(h, GPHIP_ERR_ARG, "null argument");
     if (M < 1) return fail(h, GPHIP_ERR_DIM, "M < 1");
@@ -613,18 +658,9 @@ int gphip_predict(gphip_handle h, const void* Xs, int64_t M, double* mean, doubl
     const int64_t d = h->d, Npad = h->Npad, ld = h->ld;
     const int Nt = (int)h->Nt;
     const int64_t MC = 2048;                                   // test points per chunk
-    const int64_t cap = (M < MC ? (M + TB - 1) / TB * TB : MC);
-    if (cap > h->vcap) {
-        (void)hipFree(h->dV); (void)hipFree(h->dXsT); (void)hipFree(h->dXsS); (void)hipFree(h->dMean); (void)hipFree(h->dVar);
-        h->dV = h->dXsT = h->dXsS = h->dMean = h->dVar = nullptr;
-        h->vcap = 0;
-        HIPCHK(hipMalloc(&h->dV, (size_t)cap * Npad * 8));
-        HIPCHK(hipMalloc(&h->dXsT, (size_t)cap * d * 8));
-        HIPCHK(hipMalloc(&h->dXsS, (size_t)cap * d * 8));
-        HIPCHK(hipMalloc(&h->dMean, (size_t)cap * 8));
-        HIPCHK(hipMalloc(&h->dVar, (size_t)cap * 8));
-        h->vcap = cap;
-    }
+    int rc = ensure_vbuf(h, M < MC ? (M + TB - 1) / TB * TB : MC);
+    if (rc) return rc;
+    h->cs = h->stream;
     std::vector<double> xt;
     for (int64_t m0 = 0; m0 < M; m0 += MC) {
         const int64_t mc = (M - m0 < MC) ? (M - m0) : MC;
@@ -643,14 +679,7 @@ int gphip_predict(gphip_handle h, const void* Xs, int64_t M, double* mean, doubl
         a.npad_i = (int)mpad; a.npad_j = (int)Npad; a.n_i = (int)mc; a.n_j = (int)h->N;
         a.y = nullptr; a.slotp = h->dSlotp; a.d = (int)d; a.mode = 1; a.nt_i = Mt; a.nt_j = Nt;
         launch_kbuild(h, a, dim3((unsigned)(Mt * Nt), 1));
-        // V <- V L^-T, right-looking over the 128-tile columns of L
-        for (int b = 0; b < Nt; ++b) {
-            launch_gemm(h, 2, h->dV, mpad, 0, h->dV + (long)b * TB * mpad, mpad, 0,
-                        h->dW + (long)b * TB * TB - (long)b * TB, TB, 0, TB, 0, Mt, b, b + 1, 0, 1, 1);
-            if (b + 1 < Nt)
-                launch_gemm(h, 3, h->dV, mpad, 0, h->dV + (long)b * TB * mpad, mpad, 0,
-                            h->dA + (long)b * TB * ld, ld, 0, TB, 0, Mt, b + 1, Nt, 0, 1);
-        }
+        queue_forward_rows(h, mpad);
         hipLaunchKernelGGL(predict_reduce_kernel, dim3((unsigned)((mc + 63) / 64)), dim3(64), 0, h->stream,
                            h->dV, (long)mpad, (int)h->N, h->dA + Npad, ld, h->mu_fit, h->kappa_fit, (int)mc,
                            h->dMean, h->dVar);
@@ -663,9 +692,36 @@ int gphip_predict(gphip_handle h, const void* Xs, int64_t M, double* mean, doubl
     return GPHIP_OK;
 }
 
+// out = K^-1 rhs = L^-T (L^-1 rhs): right-hand sides ride as ROWS of the scratch block V
+// (V(t, j) = rhs_t[j]), forward pass V <- V L^-T, backward pass V <- V L^-1.
 int gphip_solve(gphip_handle h, const double* rhs, int64_t nrhs, double* out) {
-    (void)rhs; (void)nrhs; (void)out;
-    return fail(h, GPHIP_ERR_UNSUPPORTED, "gphip_solve: not implemented in this version");
+    if (!h || !rhs || !out) return fail(h, GPHIP_ERR_ARG, "null argument");
+    if (nrhs < 1) return fail(h, GPHIP_ERR_DIM, "nrhs < 1");
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (!h->fitted) return fail(h, GPHIP_ERR_STATE, "gphip_solve before a successful gphip_fit");
+    HIPCHK(hipSetDevice(h->device));
+    const int64_t N = h->N, Npad = h->Npad, MC = 2048;
+    int rc = ensure_vbuf(h, nrhs < MC ? (nrhs + TB - 1) / TB * TB : MC);
+    if (rc) return rc;
+    h->cs = h->stream;
+    std::vector<double> v;
+    for (int64_t m0 = 0; m0 < nrhs; m0 += MC) {
+        const int64_t mc = (nrhs - m0 < MC) ? (nrhs - m0) : MC;
+        const int64_t mpad = (mc + TB - 1) / TB * TB;
+        v.assign((size_t)mpad * Npad, 0.0);
+        for (int64_t t = 0; t < mc; ++t)
+            for (int64_t j = 0; j < N; ++j) v[(size_t)j * mpad + t] = rhs[(m0 + t) * N + j];
+        HIPCHK(hipMemcpyAsync(h->dV, v.data(), v.size() * 8, hipMemcpyHostToDevice, h->stream));
+        queue_forward_rows(h, mpad);
+        queue_backward_rows(h, mpad);
+        HIPCHK(hipMemcpyAsync(v.data(), h->dV, v.size() * 8, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        HIPCHK(hipGetLastError());
+        harvest(h);
+        for (int64_t t = 0; t < mc; ++t)
+            for (int64_t j = 0; j < N; ++j) out[(m0 + t) * N + j] = v[(size_t)j * mpad + t];
+    }
+    return GPHIP_OK;
 }
 
 int gphip_set_option(gphip_handle h, const char* name, double value) {

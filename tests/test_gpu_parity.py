@@ -159,3 +159,21 @@ def test_argument_errors():
     h.close()
     with pytest.raises(_lib.GphipError):
         _lib.Handle(X, y[:5], "se_ard")
+
+
+@pytest.mark.parametrize("kernel,d,n,nrhs", [("se_ard", 3, 300, 1), ("matern52", 2, 129, 5), ("se", 1, 640, 130)])
+def test_solve_and_logdet_match_numpy(kernel, d, n, nrhs):
+    """"InverseCovarianceFunction"[theta]: ["Inverse"][b] = K^-1 b, ["LogDet"] (BGP:130-141)."""
+    X, y = syn.make_dataset(n, d)
+    th = syn.default_theta(kernel, d)
+    th[-1] = 0.3
+    K = orc.covariance_matrix(kernel, th, X)
+    h = _lib.Handle(X, y, kernel)
+    assert h.fit(th) == 0
+    rng = np.random.default_rng(3)
+    B = rng.standard_normal((n, nrhs))
+    got = h.solve(B if nrhs > 1 else B[:, 0])
+    want = np.linalg.solve(K, B)
+    np.testing.assert_allclose(got.reshape(n, -1), want, rtol=1e-8, atol=1e-9 * np.abs(want).max())
+    assert close(h.logdet(), np.linalg.slogdet(K)[1], n)
+    h.close()
