@@ -52,6 +52,13 @@ _SIGNATURES = {
     "gphip_get_profile": (C.c_int, [_h, C.c_int, _dp, _dp, _dp, _dp]),
     "gphip_reset_profile": (C.c_int, [_h]),
     "gphip_sync": (C.c_int, [_h]),
+    "gphip_set_streams": (C.c_int, [_h, C.c_void_p, C.c_void_p]),
+    "gphip_dist_num_panels": (C.c_int, [_h, _ip]),
+    "gphip_dist_panel_shape": (C.c_int, [_h, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "gphip_dist_begin": (C.c_int, [_h, _dp, C.c_int, C.c_int, C.c_int]),
+    "gphip_dist_factor_panel": (C.c_int, [_h, C.c_int, C.c_void_p]),
+    "gphip_dist_update": (C.c_int, [_h, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "gphip_dist_end": (C.c_int, [_h, _dp, _dp, _ip]),
     "gphip_last_error": (C.c_char_p, [_h]),
     "gphip_version": (C.c_char_p, []),
     "gphip_device_count": (C.c_int, [_ip]),
@@ -76,6 +83,15 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise GphipError(3, f"{LIB_PATH} is missing -- run `python -m bayesianinference_amd.build` "
                             "(hipcc, gfx950).  There is no CPU fallback.")
+    # PyTorch-ROCm wheels bundle their own libamdhip64/libhsa-runtime64.  A process must end up with
+    # ONE HIP runtime, or torch later reports "No HIP GPUs are available" and torch streams cannot be
+    # handed to this library (dist_cholesky.py).  Importing torch first makes the dynamic loader
+    # resolve libgphip's libamdhip64.so.7 dependency to the copy torch already mapped.
+    if os.environ.get("GPHIP_NO_TORCH", "0") != "1":
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in _SIGNATURES.items():
         fn = getattr(lib, name)
@@ -212,3 +228,33 @@ class Handle:
 
     def sync(self):
         self._check(self._lib.gphip_sync(self._h))
+
+    # -- multi-GPU block-cyclic Cholesky steps (driven by dist_cholesky.py) ---------------
+    def set_streams(self, main_stream: int, panel_stream: int):
+        self._check(self._lib.gphip_set_streams(self._h, C.c_void_p(main_stream), C.c_void_p(panel_stream)))
+
+    def dist_num_panels(self) -> int:
+        n = C.c_int(0)
+        self._check(self._lib.gphip_dist_num_panels(self._h, C.byref(n)))
+        return n.value
+
+    def dist_panel_shape(self, k: int):
+        r, c = C.c_int64(0), C.c_int64(0)
+        self._check(self._lib.gphip_dist_panel_shape(self._h, k, C.byref(r), C.byref(c)))
+        return r.value, c.value
+
+    def dist_begin(self, theta, rank: int, world: int):
+        th = np.ascontiguousarray(np.asarray(theta, dtype=np.float64).ravel())
+        self._check(self._lib.gphip_dist_begin(self._h, _d(th), th.size, rank, world))
+
+    def dist_factor_panel(self, k: int, packed_ptr: int):
+        self._check(self._lib.gphip_dist_factor_panel(self._h, k, C.c_void_p(packed_ptr)))
+
+    def dist_update(self, k: int, packed_ptr: int, j_first: int, j_last: int, on_panel_stream: bool):
+        self._check(self._lib.gphip_dist_update(self._h, k, C.c_void_p(packed_ptr), j_first, j_last,
+                                                int(on_panel_stream)))
+
+    def dist_end(self):
+        ld, qd, info = C.c_double(0.0), C.c_double(0.0), C.c_int(0)
+        self._check(self._lib.gphip_dist_end(self._h, C.byref(ld), C.byref(qd), C.byref(info)))
+        return ld.value, qd.value, info.value

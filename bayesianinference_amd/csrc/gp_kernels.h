@@ -106,6 +106,9 @@ struct KBuildArgs {
     int mode;               // 0: train x train (lower-tri tiles, nugget, identity padding, rhs rows)
                             // 1: cross  (rectangular tiles, zero padding)
     int nt_i, nt_j;         // tile counts; mode 0: nt_i = nt_j + 1 (extra rhs block-row)
+    int own_panel, own_world, own_rank;   // own_world > 0 (multi-GPU 1-D block-cyclic layout): build
+                            // only tile columns whose outer panel (tj / own_panel) belongs to own_rank;
+                            // the rhs x rhs corner tile belongs to rank 0
 };
 
 // One 128x128 tile per workgroup (4 waves).  Wave w owns 32 output columns; lane owns 2 adjacent
@@ -122,6 +125,10 @@ __global__ __launch_bounds__(256) void kbuild_kernel(KBuildArgs a) {
     } else {
         ti = blockIdx.x % a.nt_i;
         tj = blockIdx.x / a.nt_i;
+    }
+    if (a.own_world > 0) {
+        const int owner = (tj == a.nt_j) ? 0 : (tj / a.own_panel) % a.own_world;
+        if (owner != a.own_rank) return;
     }
     const double* sp = a.slotp + (long)slot * SLOTP;
     const double sf2 = sp[0], sn2 = sp[1], mu = sp[2];

@@ -46,6 +46,9 @@ struct gphip_ctx {
     hipStream_t cs = nullptr;          // stream the launch helpers currently target
     std::vector<hipEvent_t> sync_events;
     size_t sync_used = 0;
+    bool own_streams = true;
+    int dist_rank = 0, dist_world = 0;  // > 0 between gphip_dist_begin and gphip_dist_end
+    bool dist_theta_ok = true;
     int64_t N = 0, d = 0, Npad = 0, Nt = 0, ld = 0;
     int kernel_id = 0, mean_id = 0, nl = 0, p = 0, kt = 0;
     double sum_y = 0, sum_y2 = 0;
@@ -223,6 +226,7 @@ void queue_build(gphip_ctx* h, int nslots) {
     a.npad_i = a.npad_j = (int)h->Npad; a.n_i = a.n_j = (int)h->N;
     a.y = h->dY; a.slotp = h->dSlotp; a.d = (int)h->d; a.mode = 0;
     a.nt_i = (int)h->Nt + 1; a.nt_j = (int)h->Nt;
+    a.own_panel = h->panel; a.own_world = h->dist_world; a.own_rank = h->dist_rank;
     const long ntiles = (long)(h->Nt + 1) * (h->Nt + 2) / 2;
     ProfScope ps(h, 0, 0.0, 8.0 * nslots * ((double)h->N * (h->N + 1) / 2 + (double)h->N * h->d));
     launch_kbuild(h, a, dim3((unsigned)ntiles, nslots));
@@ -258,7 +262,8 @@ void launch_gemm(gphip_ctx* h, int cls, double* C, long ldc, long cbs, const dou
         grid_x = nsuper * 64;
     }
     const double flops = 2.0 * TB * TB * (double)K * g.ntiles * nslots;
-    const double bytes = 8.0 * TB * ((double)2 * TB + 2.0 * K) * g.ntiles * nslots;
+    // algorithmic bytes: C tiles read + written once, each operand panel streamed once
+    const double bytes = 8.0 * nslots * (2.0 * TB * TB * g.ntiles + (double)(tri ? H : H + W) * TB * K);
     ProfScope ps(h, cls == 6 ? 3 : cls, flops, bytes);
     const dim3 grid(grid_x, nslots);
     const size_t lds = (size_t)2 * 2 * GK * LDT * 8;
@@ -531,8 +536,10 @@ int gphip_destroy(gphip_handle h) {
     (void)hipFree(h->dVar);
     for (auto e : h->pool) (void)hipEventDestroy(e);
     for (auto e : h->sync_events) (void)hipEventDestroy(e);
-    if (h->pstream) (void)hipStreamDestroy(h->pstream);
-    if (h->stream) (void)hipStreamDestroy(h->stream);
+    if (h->own_streams) {
+        if (h->pstream) (void)hipStreamDestroy(h->pstream);
+        if (h->stream) (void)hipStreamDestroy(h->stream);
+    }
     delete h;
     return GPHIP_OK;
 }
@@ -721,6 +728,139 @@ int gphip_solve(gphip_handle h, const double* rhs, int64_t nrhs, double* out) {
         for (int64_t t = 0; t < mc; ++t)
             for (int64_t j = 0; j < N; ++j) out[(m0 + t) * N + j] = v[(size_t)j * mpad + t];
     }
+    return GPHIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Multi-GPU 1-D block-cyclic Cholesky: per-rank compute steps.  The host
+// (bayesianinference_amd/dist_cholesky.py) owns the schedule and moves factored panels between
+// ranks with torch.distributed broadcast (RCCL over xGMI); outer panel j (h->panel tile columns)
+// belongs to rank j % world, the rhs x rhs corner tile to rank 0.
+// ------------------------------------------------------------------------------------------
+int gphip_set_streams(gphip_handle h, void* main_stream, void* panel_stream) {
+    if (!h || !main_stream || !panel_stream) return fail(h, GPHIP_ERR_ARG, "null stream");
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIPCHK(hipSetDevice(h->device));
+    if (h->own_streams) {
+        HIPCHK(hipStreamSynchronize(h->pstream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        (void)hipStreamDestroy(h->pstream);
+        (void)hipStreamDestroy(h->stream);
+        h->own_streams = false;
+    }
+    h->stream = static_cast<hipStream_t>(main_stream);
+    h->pstream = static_cast<hipStream_t>(panel_stream);
+    h->cs = h->stream;
+    return GPHIP_OK;
+}
+
+int gphip_dist_num_panels(gphip_handle h, int* nouter) {
+    if (!h || !nouter) return GPHIP_ERR_ARG;
+    *nouter = (int)((h->Nt + h->panel - 1) / h->panel);
+    return GPHIP_OK;
+}
+
+// shape of packed panel k: rows = all tile rows from the panel's first diagonal block down to
+// and including the rhs block-row, cols = the panel's width
+int gphip_dist_panel_shape(gphip_handle h, int k, int64_t* rows, int64_t* cols) {
+    if (!h || !rows || !cols) return GPHIP_ERR_ARG;
+    const int64_t K0 = (int64_t)k * h->panel, K1 = (K0 + h->panel < h->Nt) ? K0 + h->panel : h->Nt;
+    if (k < 0 || K0 >= h->Nt) return fail(h, GPHIP_ERR_DIM, "panel index out of range");
+    *rows = (h->Nt + 1 - K0) * TB;
+    *cols = (K1 - K0) * TB;
+    return GPHIP_OK;
+}
+
+int gphip_dist_begin(gphip_handle h, const double* theta, int p, int rank, int world) {
+    if (!h || !theta) return fail(h, GPHIP_ERR_ARG, "null argument");
+    if (p != h->p) return fail(h, GPHIP_ERR_DIM, "theta has the wrong length");
+    if (world < 1 || rank < 0 || rank >= world) return fail(h, GPHIP_ERR_ARG, "bad rank/world");
+    if (h->kernel_id == GPHIP_KERNEL_NULL) return fail(h, GPHIP_ERR_UNSUPPORTED, "null kernel needs no factorisation");
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIPCHK(hipSetDevice(h->device));
+    int rc = ensure_slots(h, 1);
+    if (rc) return rc;
+    h->fitted = false;
+    h->dist_rank = rank; h->dist_world = world;
+    h->dist_theta_ok = stage_theta(h, 0, theta);
+    HIPCHK(hipMemcpyAsync(h->dInvEll, h->hInvEll, (size_t)h->d * 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->dSlotp, h->hSlotp, SLOTP * 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemsetAsync(h->dInfo, 0, 4, h->stream));
+    HIPCHK(hipMemsetAsync(h->dPartial, 0, (size_t)h->Nt * 8, h->stream));
+    h->cs = h->stream;
+    queue_build(h, 1);
+    return GPHIP_OK;
+}
+
+// owner of panel k: factor it in place (panel stream) and pack it into `packed`
+// (rows x cols doubles, column-major, contiguous) for the broadcast
+int gphip_dist_factor_panel(gphip_handle h, int k, double* packed) {
+    if (!h || !packed) return fail(h, GPHIP_ERR_ARG, "null argument");
+    int64_t rows, cols;
+    int rc = gphip_dist_panel_shape(h, k, &rows, &cols);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (h->dist_world < 1) return fail(h, GPHIP_ERR_STATE, "gphip_dist_factor_panel outside dist_begin/dist_end");
+    HIPCHK(hipSetDevice(h->device));
+    const int64_t K0 = (int64_t)k * h->panel;
+    h->cs = h->pstream;
+    queue_panel(h, (int)K0, (int)(cols / TB), 1);
+    HIPCHK(hipMemcpy2DAsync(packed, (size_t)rows * 8, h->dA + K0 * TB * h->ld + K0 * TB, (size_t)h->ld * 8,
+                            (size_t)rows * 8, (size_t)cols, hipMemcpyDeviceToDevice, h->pstream));
+    h->cs = h->stream;
+    return GPHIP_OK;
+}
+
+// apply panel k (read from `packed`) to the outer panels j in [j_first, j_last) this rank owns;
+// j == num_panels addresses the rhs x rhs corner tile (rank 0).  on_panel_stream selects the stream.
+int gphip_dist_update(gphip_handle h, int k, const double* packed, int j_first, int j_last, int on_panel_stream) {
+    if (!h || !packed) return fail(h, GPHIP_ERR_ARG, "null argument");
+    int64_t rows, cols;
+    int rc = gphip_dist_panel_shape(h, k, &rows, &cols);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (h->dist_world < 1) return fail(h, GPHIP_ERR_STATE, "gphip_dist_update outside dist_begin/dist_end");
+    HIPCHK(hipSetDevice(h->device));
+    const int Nt = (int)h->Nt, R = Nt + 1, P = h->panel;
+    const int nouter = (Nt + P - 1) / P;
+    const long K0 = (long)k * P;
+    const double* base = packed - K0 * TB;          // so that absolute tile row t sits at base + t*128
+    h->cs = on_panel_stream ? h->pstream : h->stream;
+    for (int j = (j_first > k + 1 ? j_first : k + 1); j < j_last && j <= nouter; ++j) {
+        int c_lo, c_hi;
+        if (j == nouter) {
+            if (h->dist_rank != 0) continue;
+            c_lo = Nt; c_hi = R;
+        } else {
+            if (j % h->dist_world != h->dist_rank) continue;
+            c_lo = j * P; c_hi = (c_lo + P < Nt) ? c_lo + P : Nt;
+        }
+        launch_gemm(h, on_panel_stream ? 3 : 4, h->dA, h->ld, 0, base, rows, 0, base, rows, 0, (int)cols, c_lo, R,
+                    c_lo, c_hi, 1, 1);
+    }
+    h->cs = h->stream;
+    return GPHIP_OK;
+}
+
+// local results: logdet_partial = 2 * sum over owned diagonal blocks of sum(log L_ii); quad is
+// meaningful on rank 0 only (0 elsewhere); the host all-reduces (sum, sum, max).
+int gphip_dist_end(gphip_handle h, double* logdet_partial, double* quad, int* info) {
+    if (!h || !logdet_partial || !quad || !info) return fail(h, GPHIP_ERR_ARG, "null argument");
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (h->dist_world < 1) return fail(h, GPHIP_ERR_STATE, "gphip_dist_end without gphip_dist_begin");
+    HIPCHK(hipSetDevice(h->device));
+    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(64), 0, h->stream, h->dA, h->ld, h->ld * h->ld,
+                       (int)h->Npad, h->dPartial, (int)h->Nt, h->dRes);
+    HIPCHK(hipMemcpyAsync(h->hRes, h->dRes, 16, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(h->hInfo, h->dInfo, 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->pstream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipGetLastError());
+    harvest(h);
+    *logdet_partial = h->hRes[0];
+    *quad = (h->dist_rank == 0) ? h->hRes[1] : 0.0;
+    *info = h->dist_theta_ok ? h->hInfo[0] : GPHIP_INFO_NAN;
+    h->dist_world = 0; h->dist_rank = 0;
     return GPHIP_OK;
 }
 

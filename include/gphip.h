@@ -95,6 +95,19 @@ int gphip_get_profile(gphip_handle h, int cls, double* ms, double* launches, dou
                       double* bytes);
 int gphip_reset_profile(gphip_handle h);
 
+/* ---- multi-GPU 1-D block-cyclic Cholesky; no reference equivalent (the
+ * reference never shards one factorisation).  One handle per rank/GPU; the host schedules the
+ * steps and broadcasts packed panels between ranks (torch.distributed / RCCL over xGMI).  Outer
+ * panel j ("panel" option tile columns) belongs to rank j % world; see dist_cholesky.py. ---- */
+int gphip_set_streams(gphip_handle h, void* main_stream, void* panel_stream); /* adopt hipStream_t's */
+int gphip_dist_num_panels(gphip_handle h, int* nouter);
+int gphip_dist_panel_shape(gphip_handle h, int k, int64_t* rows, int64_t* cols);
+int gphip_dist_begin(gphip_handle h, const double* theta, int p, int rank, int world);
+int gphip_dist_factor_panel(gphip_handle h, int k, double* packed_dev);
+int gphip_dist_update(gphip_handle h, int k, const double* packed_dev, int j_first, int j_last,
+                      int on_panel_stream);
+int gphip_dist_end(gphip_handle h, double* logdet_partial, double* quad, int* info);
+
 /* Block until all work queued on the handle's stream is complete. */
 int gphip_sync(gphip_handle h);
 

@@ -1,0 +1,82 @@
+"""GPU tests of the 1-D block-cyclic distributed Cholesky.  Only one GPU is
+available to the tests, so (a) several virtual ranks run in one process through LoopbackComm
+(device copies stand in for the RCCL broadcast; the schedule, ownership, packing and stream
+ordering are the real ones) and (b) the real torch.distributed / RCCL path runs with world_size 1."""
+import os
+
+import numpy as np
+import pytest
+
+from bayesianinference_amd import _lib, synthetic as syn
+from bayesianinference_amd.dist_cholesky import DistributedCholesky, LoopbackComm, TorchDistComm
+from oracle import gp_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _handles(X, y, kernel, world, panel):
+    hs = {}
+    for r in range(world):
+        hs[r] = _lib.Handle(X, y, kernel)
+        hs[r].set_option("panel", panel)
+    return hs
+
+
+@pytest.mark.parametrize("world,n,panel", [(2, 1500, 2), (3, 1100, 1), (8, 2500, 2), (4, 640, 4), (2, 100, 4)])
+def test_virtual_ranks_match_oracle(world, n, panel):
+    X, y = syn.make_dataset(n, 4)
+    th = syn.default_theta("se_ard", 4)
+    want = orc.log_likelihood("se_ard", th, X, y, parts=True)
+    hs = _handles(X, y, "se_ard", world, panel)
+    dc = DistributedCholesky(hs, LoopbackComm(world))
+    for rep in range(2):                               # second pass reuses buffers / streams
+        ll, ld, qd, info = dc.loglik(th)
+        assert info == 0
+        assert abs(ld - want[1]) <= 1e-9 * max(abs(want[1]), n)
+        assert abs(qd - want[2]) <= 1e-9 * max(abs(want[2]), n)
+        assert abs(ll - want[0]) <= 1e-9 * max(abs(want[0]), n)
+    # not-SPD verdict propagates from whichever rank owns the offending block
+    Xd = X.copy()
+    Xd[n - 3] = Xd[5]
+    hs2 = _handles(Xd, y, "se_ard", world, panel)
+    th0 = th.copy()
+    th0[-1] = 0.0
+    assert DistributedCholesky(hs2, LoopbackComm(world)).loglik(th0)[3] != 0
+    for h in list(hs.values()) + list(hs2.values()):
+        h.close()
+
+
+def test_virtual_ranks_full_panel_width_n8192():
+    n = 8192
+    X, y = syn.make_dataset(n, 8)
+    th = syn.default_theta("se_ard", 8)
+    ref = _lib.Handle(X, y, "se_ard")
+    want = ref.loglik_parts(th)
+    ref.close()
+    hs = _handles(X, y, "se_ard", 4, 4)
+    ll, ld, qd, info = DistributedCholesky(hs, LoopbackComm(4)).loglik(th)
+    assert info == 0 and abs(ll - want[0]) <= 1e-10 * abs(want[0]) and abs(ld - want[1]) <= 1e-10 * abs(want[1])
+    for h in hs.values():
+        h.close()
+
+
+def test_rccl_world_size_one():
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(29700 + os.getpid() % 200))
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        X, y = syn.make_dataset(1300, 3)
+        th = syn.default_theta("matern52_ard", 3)
+        want = orc.log_likelihood("matern52_ard", th, X, y)
+        h = _lib.Handle(X, y, "matern52_ard")
+        h.set_option("panel", 2)
+        dc = DistributedCholesky({0: h}, TorchDistComm(dist))
+        for _ in range(2):
+            ll, ld, qd, info = dc.loglik(th)
+            assert info == 0 and abs(ll - want) <= 1e-9 * max(abs(want), 1300)
+        h.close()
+    finally:
+        dist.destroy_process_group()

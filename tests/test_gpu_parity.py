@@ -177,3 +177,30 @@ def test_solve_and_logdet_match_numpy(kernel, d, n, nrhs):
     np.testing.assert_allclose(got.reshape(n, -1), want, rtol=1e-8, atol=1e-9 * np.abs(want).max())
     assert close(h.logdet(), np.linalg.slogdet(K)[1], n)
     h.close()
+
+
+def test_full_size_properties_n32768():
+    """BASELINE.json's full size (N=32768, d=8): no oracle run is affordable, so check
+    size-independent properties: schedule invariance (look-ahead / panel width), the bordered
+    quadratic form against an independent K^-1 y solve, and the K K^-1 residual."""
+    n, d = 32768, 8
+    X, y = syn.make_dataset(n, d)
+    th = syn.default_theta("se_ard", d)
+    h = _lib.Handle(X, y, "se_ard")
+    ll, ld, qd, info = h.loglik_parts(th)
+    assert info == 0 and np.isfinite(ll)
+    h.set_option("lookahead", 0)
+    h.set_option("panel", 2)
+    ll2, ld2, qd2, info2 = h.loglik_parts(th)
+    assert info2 == 0 and close(ld2, ld, n, 1e-10) and close(qd2, qd, n, 1e-9) and close(ll2, ll, n, 1e-10)
+    h.set_option("lookahead", 1)
+    h.set_option("panel", 4)
+    assert h.fit(th) == 0
+    alpha = h.solve(y)                                   # K^-1 y by forward + backward substitution
+    assert close(float(y @ alpha), qd, n, 1e-9)          # == r^T K^-1 r from the bordered row
+    idx = np.array([0, 1, 4097, 20000, 32767])           # residual of a few rows of K alpha = y
+    ell, sf, sn, _ = orc.split_theta("se_ard", d, th)
+    Krows = orc.kernel_matrix("se_ard", ell, sf, X[idx], X)
+    Krows[np.arange(len(idx)), idx] += sn * sn
+    np.testing.assert_allclose(Krows @ alpha, y[idx], rtol=1e-7, atol=1e-7)
+    h.close()
