@@ -1,0 +1,21 @@
+"""cfg 4 of BASELINE.json: nested sampling over GP hyper-parameters (l, sf, sn), 200 live points x
+N=4096 log marginal likelihoods on one MI355X."""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bayesianinference_amd import gaussian_process as gp, nested_sampling as ns, synthetic as syn
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 60
+X, y = syn.make_dataset(n, 1)
+variables = [("l", 0.1, 10.0), ("sf", 0.1, 10.0), ("sn", 0.01, 1.0)]
+t0 = time.perf_counter()
+obj = gp.defineGaussianProcess((X, y), "SE", variables=variables, variablePrior="Uniform")
+print(f"defineGaussianProcess (incl. 100-theta smoke sweep): {time.perf_counter()-t0:.2f} s", flush=True)
+t0 = time.perf_counter()
+res = ns.nestedSampling(obj, SamplePoolSize=200, MonteCarloSteps=20, Walkers=200, MaxIterations=iters,
+                        MinIterations=iters, Seed=1)
+dt = time.perf_counter() - t0
+ev = res["LikelihoodEvaluations"]
+print(f"N={n}: {iters} nested iterations, {ev} likelihood evaluations in {dt:.2f} s -> {ev/dt:.0f} evals/s; "
+      f"logZ(crude)={res['CrudeLogEvidence']:.3f}", flush=True)

@@ -1,0 +1,94 @@
+"""CPU tests of the nested-sampling driver (host logic, no GPU): the deterministic pieces are pinned
+by hand against the reference's formulas (BS:757-835); the sampler is checked on a likelihood with
+a known evidence (the chain kernel of the reference is closed source, so only log Z +- its own
+standard error is comparable -- SURVEY.md §8f)."""
+import math
+
+import numpy as np
+import pytest
+
+from bayesianinference_amd import gaussian_process as gp
+from bayesianinference_amd import nested_sampling as ns
+
+
+def test_x_values_match_reference_formula():
+    lx = ns.calculate_x_values_log(4, 3)                  # BS:790-802
+    want = [-1 / 4, -2 / 4, -3 / 4] + [math.log(i / 5) - 3 / 4 for i in (4, 3, 2, 1)]
+    np.testing.assert_allclose(lx, want, rtol=1e-15)
+    assert np.all(np.diff(lx) < 0)
+
+
+def test_trapezoid_weights_match_linear_form():
+    x = np.array([0.9, 0.7, 0.4, 0.15, 0.05])
+    # BS:747-755 linear form: 0.5 (Prepend[Most x, 2 - x1] - Append[Rest x, -x_last])
+    lin = 0.5 * (np.concatenate([[2 - x[0]], x[:-1]]) - np.concatenate([x[1:], [-x[-1]]]))
+    np.testing.assert_allclose(np.exp(ns.trapezoid_weights_log(np.log(x))), lin, rtol=1e-13)
+    assert lin.sum() == pytest.approx(1.0)                # the weights tile the prior mass exactly
+
+
+def test_weights_crude_sorting_and_evidence_of_constant_likelihood():
+    rng = np.random.default_rng(1)
+    pts = rng.random((12, 2))
+    ll = np.zeros(12)                                     # L = 1 everywhere -> Z = 1 exactly
+    ll[3] = ll[7]                                         # ties are broken by the point (BS:822)
+    order, logx, logw = ns.calculate_weights_crude(pts, ll, 5)
+    assert sorted(order) == list(range(12))
+    assert ns.log_sum_exp(logw) == pytest.approx(0.0, abs=1e-12)
+    assert ns.calculate_entropy(logw, ll[order], 0.0) == pytest.approx(0.0, abs=1e-12)
+
+
+def test_log_helpers():
+    assert ns.log_sum_exp([-np.inf, 0.0, math.log(3.0)]) == pytest.approx(math.log(4.0))
+    assert float(ns.log_add(math.log(2.0), math.log(3.0))) == pytest.approx(math.log(5.0))
+    assert float(ns.log_subtract(math.log(5.0), math.log(3.0))) == pytest.approx(math.log(2.0))
+
+
+def _gauss_problem(s=0.1):
+    params = [("a", -1.0, 1.0), ("b", -1.0, 1.0)]
+    calls = {"batches": 0, "evals": 0}
+
+    def loglik(theta):
+        theta = np.asarray(theta, dtype=np.float64)
+        if theta.ndim == 2:
+            calls["batches"] += 1
+            calls["evals"] += len(theta)
+            return -0.5 * np.sum(theta ** 2, axis=1) / s ** 2
+        calls["evals"] += 1
+        return -0.5 * float(np.sum(theta ** 2)) / s ** 2
+
+    obj = gp.defineInferenceProblem({"Parameters": params, "PriorDistribution": "Uniform",
+                                     "LogLikelihoodFunction": loglik})
+    return obj, calls, math.log(2 * math.pi * s * s / 4.0)
+
+
+def test_nested_sampling_recovers_known_evidence():
+    obj, calls, want = _gauss_problem()
+    res = ns.nestedSampling(obj, SamplePoolSize=100, MonteCarloSteps=25, Walkers=16, Seed=3)
+    assert not isinstance(res, str)
+    z, se = res["LogEvidence"]["Mean"], res["LogEvidence"]["StandardError"]
+    assert 0.03 < se < 0.5
+    assert abs(z - want) < 4 * se + 0.15, (z, se, want)
+    assert abs(res["CrudeLogEvidence"] - want) < 0.6
+    assert res["GeneratedNestedSamples"] >= 100 and res["TotalSamples"] == len(res["LogLikelihood"])
+    assert np.all(np.diff(res["LogLikelihood"]) >= 0) and np.all(np.diff(res["LogX"]) < 0)
+    w = np.array([s["CrudePosteriorWeight"] for s in res["Samples"]])
+    assert w.sum() == pytest.approx(1.0, rel=1e-9) and np.all(np.diff(w) <= 1e-15)   # sorted by weight, BS:1240
+    m = res["ParameterExpectedValues"]
+    assert abs(m["a"]["Mean"]) < 0.05 and abs(m["b"]["Mean"]) < 0.05
+    # the likelihood was driven in batches: W-wide calls, not one theta at a time
+    assert calls["evals"] / calls["batches"] > 8
+
+
+def test_bad_likelihood_is_reported_like_the_reference():
+    params = [("a", 0.0, 1.0)]
+    out = ns.nested_sampling_internal(lambda t: np.full(len(np.atleast_2d(t)), np.nan), lambda t: 0.0,
+                                      np.random.default_rng(0).random((10, 1)), params)
+    assert out == "Bad likelihood function"               # BS:917-921
+
+
+def test_parallel_runs_combine():
+    obj, _, want = _gauss_problem()
+    res = ns.parallelNestedSampling(obj, ParallelRuns=3, SamplePoolSize=40, MonteCarloSteps=20, Walkers=8,
+                                    MinIterations=50)
+    assert res["SamplePoolSize"] == 120                   # pool sizes add, BS:1306
+    assert abs(res["LogEvidence"]["Mean"] - want) < 4 * res["LogEvidence"]["StandardError"] + 0.2
