@@ -122,7 +122,7 @@ class Handle:
         if kernel not in KERNEL_IDS or mean not in MEAN_IDS:
             raise GphipError(1, f"unknown kernel/mean {kernel!r}/{mean!r}")
         self.N, self.d = X.shape
-        self.kernel, self.mean = kernel, mean
+        self.kernel, self.mean, self.dtype = kernel, mean, int(dtype)
         self._lib = lib
         self._h = _h()
         devs, nd = (None, 0)

@@ -5,10 +5,15 @@
 //                  Cholesky workspace (BGP:29-43 covarianceMatrix; BGP:100-109 cross form)
 //   potrf128       K2a + K3: 128x128 diagonal-block Cholesky + triangular inverse in LDS (MFMA),
 //                  log-det partial, SPD test
-//   gemm_nt        K2b/K2c on fp64 MFMA (v_mfma_f64_16x16x4_f64): mode 1 = panel solve X <- X W^T
-//                  (also carries r -> z = L^-1 r, K4), mode 0 = C -= A B^T SYRK/GEMM trailing update
+//   gemm_nt        K2b/K2c on MFMA: mode 1 = panel solve X <- X W^T (also carries r -> z = L^-1 r,
+//                  K4), mode 0 = C -= A B^T SYRK/GEMM trailing update
 //   finalize       log det = 2 sum log L_ii, quad = |z|^2, info
 //   predict_reduce K9/K10 epilogue: mu* and var* from V = k*^T L^-T and z
+//
+// Every kernel is templated on the arithmetic type T: double (v_mfma_f64_16x16x4_f64, the headline
+// path) or float (v_mfma_f32_16x16x4_f32, BASELINE.json config 5).  The two MFMA forms share the A/B
+// operand layout (lane -> row l&15, k = l>>4) but NOT the C/D layout -- f64: row = (l>>4) + 4 reg,
+// f32: row = 4 (l>>4) + reg -- which is what Num<T>::drow encodes.
 //
 // Storage: one column-major workspace matrix per batch slot, leading dimension ld = Npad + 128
 // (Npad = N rounded up to the 128 tile).  Rows [Npad, Npad+128) carry right-hand sides as extra
@@ -24,6 +29,7 @@ constexpr int TB = 128;         // tile edge
 constexpr int SLOTP = 8;        // doubles of per-slot scalars: sf2, sn2, mu, pivot_tol, bad_theta
 
 typedef double d4 __attribute__((ext_vector_type(4)));
+typedef float f4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
 
@@ -52,28 +58,63 @@ __device__ __forceinline__ double exp_nonpos(double x) {
     p = __builtin_fma(p, r, 1.0);
     return __builtin_ldexp(p, (int)k);
 }
+// fp32: v_exp_f32 (2^x) exists in hardware
+__device__ __forceinline__ float exp_nonpos(float x) { return __expf(fmaxf(x, -100.0f)); }
+
+// Per-type numerics and MFMA shape
+template <typename T> struct Num;
+template <> struct Num<double> {
+    typedef d4 acc_t;
+    typedef double2 pair_t;
+    static constexpr int GK = 16;            // K per LDS stage of gemm_nt (16 KiB per operand tile)
+    static __device__ __forceinline__ acc_t mfma(double a, double b, acc_t c) {
+        return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ int drow(int l4, int r) { return l4 + 4 * r; }
+    static __device__ __forceinline__ double readlane(double v, int src) {
+        int lo = __double2loint(v), hi = __double2hiint(v);
+        lo = __builtin_amdgcn_readlane(lo, src);
+        hi = __builtin_amdgcn_readlane(hi, src);
+        return __hiloint2double(hi, lo);
+    }
+    static __device__ __forceinline__ double sqrt_(double x) { return __builtin_sqrt(x); }
+};
+template <> struct Num<float> {
+    typedef f4 acc_t;
+    typedef float2 pair_t;
+    static constexpr int GK = 32;
+    static __device__ __forceinline__ acc_t mfma(float a, float b, acc_t c) {
+        return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ int drow(int l4, int r) { return 4 * l4 + r; }
+    static __device__ __forceinline__ float readlane(float v, int src) {
+        return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
+    }
+    static __device__ __forceinline__ float sqrt_(float x) { return __builtin_sqrtf(x); }
+};
 
 // KT = 0: squared exponential  sf2 * exp(-r2/2)
 // KT = 1: Matern-5/2           sf2 * (1 + s5 + 5 r2/3) exp(-s5),  s5 = sqrt(5 r2)
-template <int KT>
-__device__ __forceinline__ double kfun(double r2, double sf2) {
+template <int KT, typename T>
+__device__ __forceinline__ T kfun(T r2, T sf2) {
     if (KT == 0) {
-        return sf2 * exp_nonpos(-0.5 * r2);
+        return sf2 * exp_nonpos((T)-0.5 * r2);
     } else {
-        const double s5 = __builtin_sqrt(5.0 * r2);
-        return sf2 * (1.0 + s5 + (5.0 / 3.0) * r2) * exp_nonpos(-s5);
+        const T s5 = Num<T>::sqrt_((T)5.0 * r2);
+        return sf2 * ((T)1.0 + s5 + (T)(5.0 / 3.0) * r2) * exp_nonpos(-s5);
     }
 }
 
 // xs[slot][dd][i] = X[dd][i] * inv_ell[slot][dd]      (Xt is the transposed copy [d][npad])
-__global__ void k_scale(const double* __restrict__ Xt, double* __restrict__ xs,
-                        const double* __restrict__ inv_ell, int d, int npad) {
+template <typename T>
+__global__ void k_scale(const T* __restrict__ Xt, T* __restrict__ xs, const double* __restrict__ inv_ell,
+                        int d, int npad) {
     const int slot = blockIdx.y;
     const long total = (long)d * npad;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (long)gridDim.x * blockDim.x) {
         const int dd = (int)(idx / npad);
-        xs[(long)slot * total + idx] = Xt[idx] * inv_ell[slot * d + dd];
+        xs[(long)slot * total + idx] = (T)((double)Xt[idx] * inv_ell[slot * d + dd]);
     }
 }
 
@@ -91,16 +132,17 @@ __device__ __forceinline__ void tri_decode(int t, int n, int& ti, int& tj) {
     ti = c + (t - (int)((long)c * n - (long)c * (c - 1) / 2));
 }
 
+template <typename T>
 struct KBuildArgs {
-    double* out;            // workspace base (slot 0)
-    long ld;                // leading dimension (doubles)
-    long bstride;           // doubles between slots
-    const double* xi;       // scaled I-operand points [slot][D][npad_i]  (rows of the output)
-    const double* xj;       // scaled J-operand points [slot][D][npad_j]  (columns of the output)
+    T* out;                 // workspace base (slot 0)
+    long ld;                // leading dimension (elements)
+    long bstride;           // elements between slots
+    const T* xi;            // scaled I-operand points [slot][D][npad_i]  (rows of the output)
+    const T* xj;            // scaled J-operand points [slot][D][npad_j]  (columns of the output)
     long xi_bstride, xj_bstride;
     int npad_i, npad_j;     // padded point counts (multiples of 128)
     int n_i, n_j;           // true point counts
-    const double* y;        // [npad_j] outputs (mode 0 only)
+    const T* y;             // [npad_j] outputs (mode 0 only)
     const double* slotp;    // [slot][SLOTP]
     int d;                  // runtime dimension (used when D == 0)
     int mode;               // 0: train x train (lower-tri tiles, nugget, identity padding, rhs rows)
@@ -112,11 +154,13 @@ struct KBuildArgs {
 };
 
 // One 128x128 tile per workgroup (4 waves).  Wave w owns 32 output columns; lane owns 2 adjacent
-// rows, so every store is a 16-byte dwordx4 and a wave writes one full 1 KiB column segment.
+// rows (fp64: every store is a 16-byte dwordx4 and a wave writes one full 1 KiB column segment).
 // The J-side points come from LDS as wave-uniform broadcasts; the I-side points live in registers.
-template <int D, int KT>
-__global__ __launch_bounds__(256) void kbuild_kernel(KBuildArgs a) {
-    extern __shared__ double lds[];           // xj tile [d][128] (+ xi tile [d][128] when D == 0)
+template <typename T, int D, int KT>
+__global__ __launch_bounds__(256) void kbuild_kernel(KBuildArgs<T> a) {
+    extern __shared__ double lds_raw[];
+    T* lds = reinterpret_cast<T*>(lds_raw);   // xj tile [d][128] (+ xi tile [d][128] when D == 0)
+    typedef typename Num<T>::pair_t pair_t;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int slot = blockIdx.y;
     int ti, tj;
@@ -131,35 +175,37 @@ __global__ __launch_bounds__(256) void kbuild_kernel(KBuildArgs a) {
         if (owner != a.own_rank) return;
     }
     const double* sp = a.slotp + (long)slot * SLOTP;
-    const double sf2 = sp[0], sn2 = sp[1], mu = sp[2];
-    double* out = a.out + (long)slot * a.bstride + (long)tj * TB * a.ld + (long)ti * TB;
+    const T sf2 = (T)sp[0], sn2 = (T)sp[1], mu = (T)sp[2];
+    T* out = a.out + (long)slot * a.bstride + (long)tj * TB * a.ld + (long)ti * TB;
     const int r0 = 2 * lane;
 
     if (a.mode == 0 && ti == a.nt_i - 1) {      // right-hand-side block-row: row 0 = r^T, rest 0
         for (int jj = wave * 32; jj < wave * 32 + 32; ++jj) {
             const int gj = tj * TB + jj;
-            double2 v = make_double2(0.0, 0.0);
+            pair_t v;
+            v.x = (T)0;
+            v.y = (T)0;
             if (lane == 0 && tj < a.nt_j && gj < a.n_j) v.x = a.y[gj] - mu;
-            *reinterpret_cast<double2*>(out + (long)jj * a.ld + r0) = v;
+            *reinterpret_cast<pair_t*>(out + (long)jj * a.ld + r0) = v;
         }
         return;
     }
 
     const int d = (D > 0) ? D : a.d;
-    const double* xjg = a.xj + (long)slot * a.xj_bstride + (long)tj * TB;
-    const double* xig = a.xi + (long)slot * a.xi_bstride + (long)ti * TB;
-    double* xjs = lds;
-    double* xis = lds + d * TB;
+    const T* xjg = a.xj + (long)slot * a.xj_bstride + (long)tj * TB;
+    const T* xig = a.xi + (long)slot * a.xi_bstride + (long)ti * TB;
+    T* xjs = lds;
+    T* xis = lds + d * TB;
     for (int idx = tid; idx < d * TB; idx += 256) {
         const int dd = idx >> 7, c = idx & 127;
         xjs[idx] = xjg[(long)dd * a.npad_j + c];
         if (D == 0) xis[idx] = xig[(long)dd * a.npad_i + c];
     }
-    double xa[D > 0 ? D : 1], xb[D > 0 ? D : 1];
+    T xa[D > 0 ? D : 1], xb[D > 0 ? D : 1];
     if (D > 0) {
 #pragma unroll
         for (int dd = 0; dd < D; ++dd) {
-            const double2 v = *reinterpret_cast<const double2*>(xig + (long)dd * a.npad_i + r0);
+            const pair_t v = *reinterpret_cast<const pair_t*>(xig + (long)dd * a.npad_i + r0);
             xa[dd] = v.x;
             xb[dd] = v.y;
         }
@@ -170,37 +216,40 @@ __global__ __launch_bounds__(256) void kbuild_kernel(KBuildArgs a) {
     const bool edge = (a.mode == 0) ? (ti == tj || (ti + 1) * TB > a.n_i)
                                     : ((ti + 1) * TB > a.n_i || (tj + 1) * TB > a.n_j);
     for (int jj = wave * 32; jj < wave * 32 + 32; ++jj) {
-        double ra = 0.0, rb = 0.0;
+        T ra = (T)0, rb = (T)0;
         if (D > 0) {
 #pragma unroll
             for (int dd = 0; dd < D; ++dd) {
-                const double xjv = xjs[dd * TB + jj];
-                const double da = xa[dd] - xjv, db = xb[dd] - xjv;
+                const T xjv = xjs[dd * TB + jj];
+                const T da = xa[dd] - xjv, db = xb[dd] - xjv;
                 ra = __builtin_fma(da, da, ra);
                 rb = __builtin_fma(db, db, rb);
             }
         } else {
             for (int dd = 0; dd < d; ++dd) {
-                const double xjv = xjs[dd * TB + jj];
-                const double da = xis[dd * TB + r0] - xjv, db = xis[dd * TB + r0 + 1] - xjv;
+                const T xjv = xjs[dd * TB + jj];
+                const T da = xis[dd * TB + r0] - xjv, db = xis[dd * TB + r0 + 1] - xjv;
                 ra = __builtin_fma(da, da, ra);
                 rb = __builtin_fma(db, db, rb);
             }
         }
-        double va = kfun<KT>(ra, sf2), vb = kfun<KT>(rb, sf2);
+        T va = kfun<KT, T>(ra, sf2), vb = kfun<KT, T>(rb, sf2);
         if (edge) {
             const int gj = tj * TB + jj;
             if (a.mode == 0) {
                 if (gi == gj) va += sn2;
                 if (gi + 1 == gj) vb += sn2;
-                if (gj >= a.n_j || gi >= a.n_i) va = (gi == gj) ? 1.0 : 0.0;       // identity pad
-                if (gj >= a.n_j || gi + 1 >= a.n_i) vb = (gi + 1 == gj) ? 1.0 : 0.0;
+                if (gj >= a.n_j || gi >= a.n_i) va = (gi == gj) ? (T)1 : (T)0;       // identity pad
+                if (gj >= a.n_j || gi + 1 >= a.n_i) vb = (gi + 1 == gj) ? (T)1 : (T)0;
             } else {
-                if (gj >= a.n_j || gi >= a.n_i) va = 0.0;
-                if (gj >= a.n_j || gi + 1 >= a.n_i) vb = 0.0;
+                if (gj >= a.n_j || gi >= a.n_i) va = (T)0;
+                if (gj >= a.n_j || gi + 1 >= a.n_i) vb = (T)0;
             }
         }
-        *reinterpret_cast<double2*>(out + (long)jj * a.ld + r0) = make_double2(va, vb);
+        pair_t v;
+        v.x = va;
+        v.y = vb;
+        *reinterpret_cast<pair_t*>(out + (long)jj * a.ld + r0) = v;
     }
 }
 
@@ -210,65 +259,61 @@ __global__ __launch_bounds__(256) void kbuild_kernel(KBuildArgs a) {
 // Factor phase, 8 panels of 16 columns:
 //   (a) wave 0 factors the 16x16 diagonal block in registers (lane = row, v_readlane broadcasts),
 //   (b) one thread per row below solves its 16 panel entries against L_pp,
-//   (c) all 4 waves apply the rank-16 trailing update on v_mfma_f64_16x16x4_f64.
+//   (c) all 4 waves apply the rank-16 trailing update on the 16x16x4 MFMA.
 // Then L goes back to HBM, and W = L^-1 is formed in place (LAPACK dtrtri order, 16x16 blocks,
 // MFMA products) and stored to the Winv workspace: the panel solve below the block is then a
 // plain MFMA GEMM  X <- A W^T  (gemm_nt mode 1).
 // SPD verdict: pivot <= tol (tol = 64 eps (sf2+sn2)) or NaN -> info = NOT_SPD (stands for
 // LinearSolve::sing1/::luc -> Throw "MatInv", BGP:131-135).
+//
+// LDS image: the 36 lower-triangle 16x16 tiles, tile (bi,bj) at ((bi(bi+1)/2 + bj) * 256) elements,
+// column-major inside the tile.  72 KiB in fp64: the kernel fits on a CU next to one gemm_nt
+// workgroup (look-ahead runs it concurrently with the trailing SYRK), and MFMA fragment reads
+// (lane -> row l&15, k = l>>4) are bank-conflict free.
 // ---------------------------------------------------------------------------------------------
-// LDS image: the 36 lower-triangle 16x16 tiles, tile (bi,bj) at ((bi(bi+1)/2 + bj) * 256) doubles,
-// column-major inside the tile.  72 KiB: the kernel fits on a CU next to one gemm_nt workgroup
-// (look-ahead runs it concurrently with the trailing SYRK), and MFMA fragment reads
-// (lane -> row l&15, k = l>>4) touch 64 distinct banks.
-constexpr int PT_LDS_DOUBLES = 36 * 256 + TB + 2;
+constexpr int PT_LDS_ELEMS = 36 * 256 + TB;     // tiles + dinv[128]  (+ 2 doubles of reduction scratch)
 
 __device__ __forceinline__ int ptile(int bi, int bj) { return ((bi * (bi + 1) / 2) + bj) << 8; }
 
-__device__ __forceinline__ double readlane_d(double v, int src) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_readlane(lo, src);
-    hi = __builtin_amdgcn_readlane(hi, src);
-    return __hiloint2double(hi, lo);
-}
-
-__global__ __launch_bounds__(256) void potrf128_kernel(double* __restrict__ Abase, long ld,
-                                                       long bstride, int b,
-                                                       double* __restrict__ Winv, double* __restrict__ partial,
+template <typename T>
+__global__ __launch_bounds__(256) void potrf128_kernel(T* __restrict__ Abase, long ld, long bstride, int b,
+                                                       T* __restrict__ Winv, double* __restrict__ partial,
                                                        int nt, int* __restrict__ info,
                                                        const double* __restrict__ slotp) {
-    extern __shared__ double Ls[];            // 36 tiles + dinv[128] + red[2]
-    double* dinv = Ls + 36 * 256;
-    double* red = dinv + TB;
+    extern __shared__ double lds_raw[];
+    double* red = lds_raw;                      // 2 doubles
+    T* Ls = reinterpret_cast<T*>(lds_raw + 2);  // 36 tiles + dinv[128]
+    T* dinv = Ls + 36 * 256;
+    typedef typename Num<T>::acc_t acc_t;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
     const int er = tid & 15, ec = tid >> 4;   // element (row, col) of a 16x16 tile owned in copies
     const int slot = blockIdx.x;
-    double* Ad = Abase + (long)slot * bstride + (long)b * TB * (ld + 1);
+    T* Ad = Abase + (long)slot * bstride + (long)b * TB * (ld + 1);
     for (int bi = 0; bi < 8; ++bi)
         for (int bj = 0; bj <= bi; ++bj)
             Ls[ptile(bi, bj) + tid] = Ad[(long)(bj * 16 + ec) * ld + bi * 16 + er];
-    const double tol = slotp[(long)slot * SLOTP + 3];
+    const T tol = (T)slotp[(long)slot * SLOTP + 3];
     bool bad = false;
     __syncthreads();
 
     // ------------------------------ factor phase ------------------------------
     for (int p = 0; p < 8; ++p) {
-        double* Dpp = Ls + ptile(p, p);
+        T* Dpp = Ls + ptile(p, p);
         if (wave == 0) {                      // (a) 16x16 diagonal block, lane l15 owns row l15
-            double a[16];
+            T a[16];
 #pragma unroll
             for (int c = 0; c < 16; ++c) a[c] = Dpp[c * 16 + l15];
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
-                double dj = readlane_d(a[j], j);
-                if (!(dj > tol)) { bad = true; dj = 1.0; }
-                const double l = __builtin_sqrt(dj);
-                const double rs = 1.0 / l;
+                T dj = Num<T>::readlane(a[j], j);
+                if (!(dj > tol)) { bad = true; dj = (T)1; }
+                const T l = Num<T>::sqrt_(dj);
+                const T rs = (T)1 / l;
                 a[j] = (l15 == j) ? l : a[j] * rs;
 #pragma unroll
                 for (int c = j + 1; c < 16; ++c) {
-                    const double sc = readlane_d(a[j], c);
+                    const T sc = Num<T>::readlane(a[j], c);
                     a[c] = __builtin_fma(-a[j], sc, a[c]);
                 }
                 if (lane == 0) dinv[16 * p + j] = rs;
@@ -282,13 +327,13 @@ __global__ __launch_bounds__(256) void potrf128_kernel(double* __restrict__ Abas
         __syncthreads();
         if (p == 7) break;
         if (tid < TB - 16 * p - 16) {         // (b) rows below: x L_pp^T = a, one row per thread
-            double* Xr = Ls + ptile(p + 1 + (tid >> 4), p) + (tid & 15);
-            double x[16];
+            T* Xr = Ls + ptile(p + 1 + (tid >> 4), p) + (tid & 15);
+            T x[16];
 #pragma unroll
             for (int c = 0; c < 16; ++c) x[c] = Xr[c * 16];
 #pragma unroll
             for (int c = 0; c < 16; ++c) {
-                double sacc = x[c];
+                T sacc = x[c];
 #pragma unroll
                 for (int k = 0; k < c; ++k) sacc = __builtin_fma(-x[k], Dpp[k * 16 + c], sacc);
                 x[c] = sacc * dinv[16 * p + c];
@@ -303,15 +348,14 @@ __global__ __launch_bounds__(256) void potrf128_kernel(double* __restrict__ Abas
                 int u = 0;
                 while ((u + 1) * (u + 2) / 2 <= tt) ++u;
                 const int v = tt - u * (u + 1) / 2;
-                const double* Xc = Ls + ptile(p + 1 + v, p) + l4 * 16 + l15;
-                const double* Xrw = Ls + ptile(p + 1 + u, p) + l4 * 16 + l15;
-                d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
+                const T* Xc = Ls + ptile(p + 1 + v, p) + l4 * 16 + l15;
+                const T* Xrw = Ls + ptile(p + 1 + u, p) + l4 * 16 + l15;
+                acc_t acc = (acc_t){0, 0, 0, 0};
 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk)
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Xc[kk * 64], Xrw[kk * 64], acc, 0, 0, 0);
-                double* Ct = Ls + ptile(p + 1 + u, p + 1 + v) + l4 * 16 + l15;
+                for (int kk = 0; kk < 4; ++kk) acc = Num<T>::mfma(Xc[kk * 64], Xrw[kk * 64], acc);
+                T* Ct = Ls + ptile(p + 1 + u, p + 1 + v) + l15;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) Ct[r * 64] -= acc[r];
+                for (int r = 0; r < 4; ++r) Ct[Num<T>::drow(l4, r) * 16] -= acc[r];
             }
         }
         __syncthreads();
@@ -321,26 +365,26 @@ __global__ __launch_bounds__(256) void potrf128_kernel(double* __restrict__ Abas
     for (int bi = 0; bi < 8; ++bi)
         for (int bj = 0; bj <= bi; ++bj)
             Ad[(long)(bj * 16 + ec) * ld + bi * 16 + er] = Ls[ptile(bi, bj) + tid];
-    {   // sum log L_jj = -sum log dinv_j
+    {   // sum log L_jj = -sum log dinv_j  (always accumulated in fp64)
         double lg = 0.0;
-        if (tid < TB) lg = -log(dinv[tid]);
+        if (tid < TB) lg = -log((double)dinv[tid]);
         for (int off = 32; off > 0; off >>= 1) lg += __shfl_down(lg, off);
         if (tid < TB && lane == 0) red[wave] = lg;
     }
 
     // ------------------------------ inverse phase ------------------------------
     {   // (i) the eight 16x16 diagonal inverses: thread = (block, column)
-        double w[16];
+        T w[16];
         const int blk = tid >> 4, c = tid & 15;
-        double* Dbb = Ls + ptile(blk & 7, blk & 7);
+        T* Dbb = Ls + ptile(blk & 7, blk & 7);
         if (tid < TB) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                double sacc = 0.0;
+                T sacc = (T)0;
 #pragma unroll
                 for (int k = 0; k < i; ++k) sacc = __builtin_fma(Dbb[k * 16 + i], w[k], sacc);
-                const double di = dinv[16 * blk + i];
-                w[i] = (i < c) ? 0.0 : ((i == c) ? di : -sacc * di);
+                const T di = dinv[16 * blk + i];
+                w[i] = (i < c) ? (T)0 : ((i == c) ? di : -sacc * di);
             }
         }
         __syncthreads();
@@ -353,21 +397,21 @@ __global__ __launch_bounds__(256) void potrf128_kernel(double* __restrict__ Abas
     }
     for (int pb = 6; pb >= 0; --pb) {          // (ii) block column pb, rows q = pb+1..7
         const int t = 7 - pb;
-        const double* Wpp = Ls + ptile(pb, pb);
+        const T* Wpp = Ls + ptile(pb, pb);
         // step 1: T'_r = T_r W_pp  (W_pp lower triangular: mask k < j)
-        d4 t1[2];
+        acc_t t1[2];
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            t1[s] = (d4){0.0, 0.0, 0.0, 0.0};
+            t1[s] = (acc_t){0, 0, 0, 0};
             const int rr = wave + 4 * s;
             if (rr < t) {
-                const double* Tr = Ls + ptile(pb + 1 + rr, pb);
+                const T* Tr = Ls + ptile(pb + 1 + rr, pb);
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
                     const int k = 4 * kk + l4;
-                    const double fa = Tr[k * 16 + l15];                               // T_r(i=l15, k)
-                    const double fb = (k >= l15) ? Wpp[l15 * 16 + k] : 0.0;           // W_pp(k, j=l15)
-                    t1[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa, fb, t1[s], 0, 0, 0);
+                    const T fa = Tr[k * 16 + l15];                               // T_r(i=l15, k)
+                    const T fb = (k >= l15) ? Wpp[l15 * 16 + k] : (T)0;          // W_pp(k, j=l15)
+                    t1[s] = Num<T>::mfma(fa, fb, t1[s]);
                 }
             }
         }
@@ -376,30 +420,30 @@ __global__ __launch_bounds__(256) void potrf128_kernel(double* __restrict__ Abas
         for (int s = 0; s < 2; ++s) {
             const int rr = wave + 4 * s;
             if (rr < t) {
-                double* Tr = Ls + ptile(pb + 1 + rr, pb);
+                T* Tr = Ls + ptile(pb + 1 + rr, pb);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) Tr[l15 * 16 + l4 + 4 * r] = t1[s][r];
+                for (int r = 0; r < 4; ++r) Tr[l15 * 16 + Num<T>::drow(l4, r)] = t1[s][r];
             }
         }
         __syncthreads();
         // step 2: W_q,pb = - sum_{r=pb+1..q} W_qr T'_r   (W_qq lower triangular: mask k > i)
-        d4 t2[2];
+        acc_t t2[2];
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            t2[s] = (d4){0.0, 0.0, 0.0, 0.0};
+            t2[s] = (acc_t){0, 0, 0, 0};
             const int qq = wave + 4 * s;
             if (qq < t) {
                 const int q = pb + 1 + qq;
                 for (int r = pb + 1; r <= q; ++r) {
-                    const double* Wqr = Ls + ptile(q, r);
-                    const double* Tr = Ls + ptile(r, pb);
+                    const T* Wqr = Ls + ptile(q, r);
+                    const T* Tr = Ls + ptile(r, pb);
 #pragma unroll
                     for (int kk = 0; kk < 4; ++kk) {
                         const int k = 4 * kk + l4;
-                        double fa = Wqr[k * 16 + l15];                                // W_qr(i=l15, k)
-                        if (r == q && k > l15) fa = 0.0;
-                        const double fb = Tr[l15 * 16 + k];                           // T'_r(k, j=l15)
-                        t2[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa, fb, t2[s], 0, 0, 0);
+                        T fa = Wqr[k * 16 + l15];                                // W_qr(i=l15, k)
+                        if (r == q && k > l15) fa = (T)0;
+                        const T fb = Tr[l15 * 16 + k];                           // T'_r(k, j=l15)
+                        t2[s] = Num<T>::mfma(fa, fb, t2[s]);
                     }
                 }
             }
@@ -409,18 +453,18 @@ __global__ __launch_bounds__(256) void potrf128_kernel(double* __restrict__ Abas
         for (int s = 0; s < 2; ++s) {
             const int qq = wave + 4 * s;
             if (qq < t) {
-                double* Wq = Ls + ptile(pb + 1 + qq, pb);
+                T* Wq = Ls + ptile(pb + 1 + qq, pb);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) Wq[l15 * 16 + l4 + 4 * r] = -t2[s][r];
+                for (int r = 0; r < 4; ++r) Wq[l15 * 16 + Num<T>::drow(l4, r)] = -t2[s][r];
             }
         }
         __syncthreads();
     }
     // W to the workspace, dense column-major 128x128 with an explicit zero upper triangle
-    double* Wg = Winv + ((long)slot * nt + b) * TB * TB;
+    T* Wg = Winv + ((long)slot * nt + b) * TB * TB;
     for (int bi = 0; bi < 8; ++bi)
         for (int bj = 0; bj < 8; ++bj) {
-            double v = 0.0;
+            T v = (T)0;
             if (bi > bj || (bi == bj && er >= ec)) v = Ls[ptile(bi, bj) + tid];
             Wg[(bj * 16 + ec) * TB + bi * 16 + er] = v;
         }
@@ -431,26 +475,30 @@ __global__ __launch_bounds__(256) void potrf128_kernel(double* __restrict__ Abas
 }
 
 // ---------------------------------------------------------------------------------------------
-// gemm_nt: C(i,j) -= sum_k A(i,k) B(j,k) for 128x128 tiles on v_mfma_f64_16x16x4_f64.
+// gemm_nt: C(i,j) -= sum_k A(i,k) B(j,k) for 128x128 tiles on the 16x16x4 MFMA
+// (v_mfma_f64_16x16x4_f64 / v_mfma_f32_16x16x4_f32).
 //
-// 256 threads = 4 waves in a 2(i) x 2(j) arrangement, 64x64 per wave = 4x4 MFMA tiles, 64 fp64
-// accumulators (128 VGPRs) per lane.  K is consumed in stages of 16 through double-buffered LDS
-// (LDS-DMA global_load_lds_dwordx4 issued a stage ahead).  Both operand tiles are stored [k][row]
-// with a padded leading dimension of 144 doubles so the MFMA fragment read
-// (lane -> row = lane&15, k = lane>>4) is ds_read_b64 bank-conflict free.
+// 256 threads = 4 waves in a 2(i) x 2(j) arrangement, 64x64 per wave = 4x4 MFMA tiles, 64
+// accumulators per lane.  K is consumed in stages of GK (16 fp64 / 32 fp32 = 16 KiB per operand
+// tile) through double-buffered LDS filled by LDS-DMA (global_load_lds_dwordx4) a stage ahead.
+// fp64 image: [k][row] with a padded leading dimension of 144 doubles; fp32 image: k-columns
+// stored in pairs {4q, 4q+2} / {4q+1, 4q+3} with 16 floats of padding after each pair -- both make
+// the MFMA fragment read (lane -> row = lane&15, k = lane>>4) bank-conflict free.
 //
 // MFMA operand roles: the C-row (memory-contiguous) index i feeds the MFMA *B* operand so that
 // D's column index (= lane&15) runs along contiguous memory of column-major C; the C-column index
-// j feeds the *A* operand (D row = (lane>>4) + 4*reg; f64 layout, cdna_hip_programming.md §3).
+// j feeds the *A* operand (D row = Num<T>::drow(lane>>4, reg)).
 // ---------------------------------------------------------------------------------------------
-constexpr int GK = 16;          // K per LDS stage
-constexpr int LDT = 144;        // padded LDS leading dimension (doubles)
+constexpr int LDT = 144;          // fp64: padded LDS leading dimension (doubles)
+constexpr int LDP = 272;          // fp32: one pair of k-columns + 16 floats of padding
+constexpr int STAGE_BYTES = 2 * 16 * LDT * 8;      // one stage = I tile + J tile (36,864 B, both types)
 
+template <typename T>
 struct GemmArgs {
-    double* C; long ldc; long c_bstride;
-    const double* A; long lda; long a_bstride;   // I operand: A(i,k) at A[i + k*lda]
-    const double* B; long ldb; long b_bstride;   // J operand: B(j,k) at B[j + k*ldb]
-    int K;                                       // multiple of 16
+    T* C; long ldc; long c_bstride;
+    const T* A; long lda; long a_bstride;        // I operand: A(i,k) at A[i + k*lda]
+    const T* B; long ldb; long b_bstride;        // J operand: B(j,k) at B[j + k*ldb]
+    int K;                                       // multiple of GK
     int r0, r1, c0, c1;                          // tile ranges: rows [r0,r1), cols [c0,c1)
     int tri;                                     // 1: keep only tiles with ti >= tj (needs r0 >= c0)
     int nrect;                                   // tiles in the full-height rectangle part
@@ -458,11 +506,11 @@ struct GemmArgs {
     int swizzle;                                 // XCD-aware block remap
     int super;                                   // 1: pure-triangle launch enumerated in 8x8 super-tiles,
                                                  //    one super-tile per XCD at a time (L2 reuse)
-    int mode;                                    // 0: C -= A B^T ; 1: C = A B^T (in-place panel solve
-                                                 //    X <- X W^T: A aliases C, one column tile)
+    int mode;                                    // ROLE 3 only: 0: C -= A B ; 1: C = A B
 };
 
-__device__ __forceinline__ void gemm_tile_decode(const GemmArgs& g, int t, int& ti, int& tj) {
+template <typename T>
+__device__ __forceinline__ void gemm_tile_decode(const GemmArgs<T>& g, int t, int& ti, int& tj) {
     const int H = g.r1 - g.r0;
     if (!g.tri || t < g.nrect) {
         tj = g.c0 + t / H;
@@ -475,15 +523,28 @@ __device__ __forceinline__ void gemm_tile_decode(const GemmArgs& g, int t, int& 
     }
 }
 
+// element offset of (k, row) inside one staged operand tile
+template <typename T> __device__ __forceinline__ int lds_off(int k, int row);
+template <> __device__ __forceinline__ int lds_off<double>(int k, int row) { return k * LDT + row; }
+template <> __device__ __forceinline__ int lds_off<float>(int k, int row) {
+    return ((k >> 2) * 2 + (k & 1)) * LDP + ((k >> 1) & 1) * TB + row;
+}
+
 // ROLE only gives each use its own kernel symbol (separate rows in rocprof summaries):
 // 0 = trailing SYRK (K = panel*128, the dominant kernel), 1 = in-panel GEMM (K = 128),
-// 2 = panel solve X <- X W^T (mode 1),
+// 2 = panel solve X <- X W^T (C = A B^T, A aliases C, one column tile),
 // 3 = "NN" form for the backward solve: the J operand is read transposed, B(j,k) at
-//     B[k + j*ldb] (k contiguous), through an XOR-swizzled [j][16] LDS image; g.mode picks
+//     B[k + j*ldb] (k contiguous), through an XOR-swizzled [j][GK] LDS image; g.mode picks
 //     C -= A B (0) or C = A B (1).
-template <int ROLE>
-__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
-    extern __shared__ double smem[];           // [2 stages][I: GK*LDT | J: GK*LDT]
+template <typename T, int ROLE>
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs<T> g) {
+    extern __shared__ double smem_raw[];       // [2 stages][I tile | J tile]
+    T* smem = reinterpret_cast<T*>(smem_raw);
+    typedef typename Num<T>::acc_t acc_t;
+    constexpr int GK = Num<T>::GK;
+    constexpr int STAGE = STAGE_BYTES / (int)sizeof(T);     // elements per stage
+    constexpr int JOFF = STAGE / 2;
+    constexpr bool F64 = sizeof(T) == 8;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wi = wave & 1, wj = wave >> 1;
     const int slot = blockIdx.y;
@@ -512,83 +573,96 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
         gemm_tile_decode(g, bid, ti, tj);
     }
 
-    const double* Ag = g.A + (long)slot * g.a_bstride + (long)ti * TB;
-    const double* Bg = g.B + (long)slot * g.b_bstride + (ROLE == 3 ? (long)tj * TB * g.ldb : (long)tj * TB);
-    // Staging: LDS-DMA (global_load_lds_dwordx4), no staging registers and no ds_write pass.
-    // One wave-instruction moves one k-column of a tile: 64 lanes x 16 B = 128 rows = 1 KiB,
-    // landing lane-linear at a wave-uniform LDS base (column kk at kk*LDT doubles, so the
-    // padding sits between instructions).  Wave w moves columns w, w+4, w+8, w+12 of both tiles.
+    const T* Ag = g.A + (long)slot * g.a_bstride + (long)ti * TB;
+    const T* Bg = g.B + (long)slot * g.b_bstride + (ROLE == 3 ? (long)tj * TB * g.ldb : (long)tj * TB);
+    // Staging: LDS-DMA (global_load_lds_dwordx4), no staging registers and no ds_write pass.  One
+    // wave-instruction moves 1 KiB landing lane-linear at a wave-uniform LDS base: fp64 = one
+    // k-column of 128 rows; fp32 = the two k-columns of one pair (lanes 0-31 / 32-63).  Wave w
+    // issues instructions w, w+4, w+8, w+12 of both tiles.
     const int uw = __builtin_amdgcn_readfirstlane(wave);
-    const int srow = 2 * lane;
     auto stage = [&](int kb, int st) {
-        double* Is = smem + st * (2 * GK * LDT);
-        double* Js = Is + GK * LDT;
+        T* Is = smem + st * STAGE;
+        T* Js = Is + JOFF;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            const int kk = uw + 4 * s;
-            const long kcol = (long)kb * GK + kk;
-            __builtin_amdgcn_global_load_lds((glb_void*)(Ag + kcol * g.lda + srow),
-                                             (lds_void*)(Is + kk * LDT), 16, 0, 0);
-            if (ROLE != 3) {
-                __builtin_amdgcn_global_load_lds((glb_void*)(Bg + kcol * g.ldb + srow),
-                                                 (lds_void*)(Js + kk * LDT), 16, 0, 0);
+            const int q = uw + 4 * s;           // instruction index 0..15 within the stage
+            if (F64) {
+                const long kcol = (long)kb * GK + q;
+                __builtin_amdgcn_global_load_lds((glb_void*)(Ag + kcol * g.lda + 2 * lane),
+                                                 (lds_void*)(Is + q * LDT), 16, 0, 0);
+                if (ROLE != 3)
+                    __builtin_amdgcn_global_load_lds((glb_void*)(Bg + kcol * g.ldb + 2 * lane),
+                                                     (lds_void*)(Js + q * LDT), 16, 0, 0);
             } else {
-                // transposed source: instruction kk covers j = 8kk..8kk+7, lane -> (j, k-pair);
-                // image Js[j*16 + 2*((k>>1) ^ (j&7)) + (k&1)] (swizzle applied on the source side)
-                const int j = 8 * kk + (lane >> 3), kp = (lane & 7) ^ (j & 7);
-                __builtin_amdgcn_global_load_lds((glb_void*)(Bg + (long)kb * GK + 2 * kp + (long)j * g.ldb),
-                                                 (lds_void*)(Js + kk * 128), 16, 0, 0);
+                // pair q holds columns k0 = 4(q>>1) + (q&1) (lanes 0-31) and k0 + 2 (lanes 32-63)
+                const long kcol = (long)kb * GK + 4 * (q >> 1) + (q & 1) + 2 * (lane >> 5);
+                const int row = 4 * (lane & 31);
+                __builtin_amdgcn_global_load_lds((glb_void*)(Ag + kcol * g.lda + row),
+                                                 (lds_void*)(Is + q * LDP), 16, 0, 0);
+                if (ROLE != 3)
+                    __builtin_amdgcn_global_load_lds((glb_void*)(Bg + kcol * g.ldb + row),
+                                                     (lds_void*)(Js + q * LDP), 16, 0, 0);
+            }
+            if (ROLE == 3) {
+                // transposed source: instruction q covers j = 8q..8q+7; lane -> (j, 16-byte k-group);
+                // image Js[j*GK + G*((k/G) ^ (j&7)) + k%G], G = elements per 16 B (swizzle on the source)
+                constexpr int G = 16 / (int)sizeof(T);
+                const int j = 8 * q + (lane >> 3), kg = (lane & 7) ^ (j & 7);
+                __builtin_amdgcn_global_load_lds((glb_void*)(Bg + (long)kb * GK + G * kg + (long)j * g.ldb),
+                                                 (lds_void*)(Js + q * 8 * GK), 16, 0, 0);
             }
         }
     };
 
-    // C tile: lane holds i = i0 + y*16 + (lane&15), j = j0 + x*16 + (lane>>4) + 4r (f64 MFMA D layout)
-    double* Cg = g.C + (long)slot * g.c_bstride + ((long)tj * TB + wj * 64 + (lane >> 4)) * g.ldc +
-                 (long)ti * TB + wi * 64 + (lane & 15);
+    // C tile: lane holds i = i0 + y*16 + (lane&15), j = j0 + x*16 + drow(lane>>4, r)
+    T* Cg = g.C + (long)slot * g.c_bstride + ((long)tj * TB + wj * 64) * g.ldc + (long)ti * TB + wi * 64 + (lane & 15);
+    const int l4 = lane >> 4;
     const int nk = g.K / GK;
     stage(0, 0);
     // Update roles start the accumulators AT C (loads fly with the first DMA stage) and feed the
     // MFMA the negated J fragment, so acc ends as C - A B^T and the epilogue is stores only.
-    d4 acc[4][4];
+    const bool from_zero = (ROLE == 2) || (ROLE == 3 && g.mode == 1);
+    acc_t acc[4][4];
 #pragma unroll
     for (int x = 0; x < 4; ++x)
 #pragma unroll
         for (int y = 0; y < 4; ++y) {
-            if (ROLE == 2 || (ROLE == 3 && g.mode == 1)) {
-                acc[x][y] = (d4){0.0, 0.0, 0.0, 0.0};
+            if (from_zero) {
+                acc[x][y] = (acc_t){0, 0, 0, 0};
             } else {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc[x][y][r] = Cg[(long)(x * 16 + 4 * r) * g.ldc + y * 16];
+                for (int r = 0; r < 4; ++r)
+                    acc[x][y][r] = Cg[(long)(x * 16 + Num<T>::drow(l4, r)) * g.ldc + y * 16];
             }
         }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    const int foff = (lane >> 4) * LDT + (lane & 15);
     for (int kb = 0; kb < nk; ++kb) {
         const int cur = kb & 1;
         if (kb + 1 < nk) stage(kb + 1, cur ^ 1);       // DMA of the next stage flies under the MFMAs
-        const double* Is = smem + cur * (2 * GK * LDT) + wi * 64 + foff;
-        const double* Js = smem + cur * (2 * GK * LDT) + GK * LDT + wj * 64 + foff;
+        const T* Is = smem + cur * STAGE + wi * 64 + (lane & 15);
+        const T* Js = smem + cur * STAGE + JOFF;
 #pragma unroll
         for (int kk = 0; kk < GK / 4; ++kk) {
-            double fi[4], fj[4];
+            T fi[4], fj[4];
+            const int k = 4 * kk + l4;
 #pragma unroll
             for (int f = 0; f < 4; ++f) {
-                fi[f] = Is[kk * 4 * LDT + f * 16];
+                fi[f] = Is[lds_off<T>(k, f * 16)];
+                T v;
                 if (ROLE == 3) {
-                    const int jrow = wj * 64 + f * 16 + (lane & 15), k = 4 * kk + (lane >> 4);
-                    const double v = smem[cur * (2 * GK * LDT) + GK * LDT + jrow * 16 +
-                                          2 * ((k >> 1) ^ (jrow & 7)) + (k & 1)];
-                    fj[f] = (g.mode == 1) ? v : -v;
+                    constexpr int G = 16 / (int)sizeof(T);
+                    const int jrow = wj * 64 + f * 16 + (lane & 15);
+                    v = Js[jrow * GK + G * ((k / G) ^ (jrow & 7)) + (k % G)];
                 } else {
-                    fj[f] = (ROLE == 2) ? Js[kk * 4 * LDT + f * 16] : -Js[kk * 4 * LDT + f * 16];
+                    v = Js[lds_off<T>(k, wj * 64 + f * 16 + (lane & 15))];
                 }
+                fj[f] = from_zero ? v : -v;
             }
 #pragma unroll
             for (int x = 0; x < 4; ++x)
 #pragma unroll
-                for (int y = 0; y < 4; ++y)
-                    acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(fj[x], fi[y], acc[x][y], 0, 0, 0);
+                for (int y = 0; y < 4; ++y) acc[x][y] = Num<T>::mfma(fj[x], fi[y], acc[x][y]);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -599,14 +673,15 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
     for (int x = 0; x < 4; ++x)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            double* cp = Cg + (long)(x * 16 + 4 * r) * g.ldc;
+            T* cp = Cg + (long)(x * 16 + Num<T>::drow(l4, r)) * g.ldc;
 #pragma unroll
             for (int y = 0; y < 4; ++y) cp[y * 16] = acc[x][y][r];
         }
 }
 
 // log det = 2 sum partial ; quad = -E(0,0) ; res[slot] = {logdet, quad}
-__global__ void finalize_kernel(const double* __restrict__ Abase, long ld, long bstride, int npad,
+template <typename T>
+__global__ void finalize_kernel(const T* __restrict__ Abase, long ld, long bstride, int npad,
                                 const double* __restrict__ partial, int nt, double* __restrict__ res) {
     const int slot = blockIdx.x;
     double s = 0.0;
@@ -614,22 +689,22 @@ __global__ void finalize_kernel(const double* __restrict__ Abase, long ld, long 
     for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
     if (threadIdx.x == 0) {
         res[slot * 2 + 0] = 2.0 * s;
-        res[slot * 2 + 1] = -Abase[(long)slot * bstride + (long)npad * ld + npad];
+        res[slot * 2 + 1] = -(double)Abase[(long)slot * bstride + (long)npad * ld + npad];
     }
 }
 
 // V: column-major [mpad x npad] (ld = mpad), V(t, j) = (L^-1 k*_t)_j.  z: row npad of the factor.
-// mean[t] = mu + sum_j V(t,j) z_j ; var[t] = kappa - sum_j V(t,j)^2
-__global__ void predict_reduce_kernel(const double* __restrict__ V, long ldv, int n,
-                                      const double* __restrict__ zrow, long ldz, double mu,
-                                      double kappa, int m, double* __restrict__ mean,
+// mean[t] = mu + sum_j V(t,j) z_j ; var[t] = kappa - sum_j V(t,j)^2   (fp64 accumulation)
+template <typename T>
+__global__ void predict_reduce_kernel(const T* __restrict__ V, long ldv, int n, const T* __restrict__ zrow,
+                                      long ldz, double mu, double kappa, int m, double* __restrict__ mean,
                                       double* __restrict__ var) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= m) return;
     double dot = 0.0, nrm = 0.0;
     for (int j = 0; j < n; ++j) {
-        const double v = V[(long)j * ldv + t];
-        dot = __builtin_fma(v, zrow[(long)j * ldz], dot);
+        const double v = (double)V[(long)j * ldv + t];
+        dot = __builtin_fma(v, (double)zrow[(long)j * ldz], dot);
         nrm = __builtin_fma(v, v, nrm);
     }
     mean[t] = mu + dot;

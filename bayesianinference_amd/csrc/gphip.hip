@@ -2,15 +2,16 @@
 //
 // Per evaluation (BGP:297-305 closure = K1 -> K2 -> K3 -> K4 -> K6):
 //   k_scale + kbuild      lower-triangle tiles of K(theta) + nugget, plus r^T as an extra row
-//   two-level right-looking Cholesky:
+//   two-level right-looking Cholesky with look-ahead:
 //       for each outer panel of `panel` 128-tiles:
 //           for each 128-tile column b in the panel:  potrf128(b) [L_bb and W_b = L_bb^-1];
-//                                                     gemm_nt mode 1: X <- X W_b^T below b;
-//                                                     gemm_nt(K=128) on the rest of the panel
-//           gemm_nt(K=panel*128) trailing SYRK on everything to the right (fp64 MFMA, dominant)
+//                                                     gemm_nt<2>: X <- X W_b^T below b;
+//                                                     gemm_nt<1>(K=128) on the rest of the panel
+//           gemm_nt<0>(K=panel*128) trailing SYRK on everything to the right (MFMA, dominant)
 //   finalize              log det, quadratic form (bordered row), info
 //   host epilogue         -1/2 (N log 2pi + logdet + quad)   (BGP:190-196)
-// All work is queued on one handle-owned HIP stream; X, y stay device resident.
+// Work is queued on two handle-owned HIP streams (main + panel/look-ahead); X, y stay resident.
+// Device arithmetic is fp64 (dtype 64) or fp32 (dtype 32); the ABI is fp64 either way.
 #include "gp_kernels.h"
 
 #include <cmath>
@@ -27,8 +28,7 @@ using namespace gphip;
 namespace {
 
 constexpr double LOG_TWO_PI = 1.8378770664093454835606594728112;
-constexpr double PIVOT_TOL_REL = 64.0 * 2.220446049250313e-16;
-constexpr size_t POTRF_LDS = (size_t)PT_LDS_DOUBLES * 8;
+constexpr size_t GEMM_LDS = 2 * STAGE_BYTES;
 
 struct ProfRec {
     int cls;
@@ -41,6 +41,8 @@ struct ProfRec {
 struct gphip_ctx {
     std::mutex mu;
     int device = 0;
+    int dtype = 64;                    // 64: double, 32: float
+    size_t es = 8;                     // element size of the device arithmetic type
     hipStream_t stream = nullptr;      // main stream: build, trailing updates, copies
     hipStream_t pstream = nullptr;     // panel stream (high priority): look-ahead panel factorisation
     hipStream_t cs = nullptr;          // stream the launch helpers currently target
@@ -52,11 +54,11 @@ struct gphip_ctx {
     int64_t N = 0, d = 0, Npad = 0, Nt = 0, ld = 0;
     int kernel_id = 0, mean_id = 0, nl = 0, p = 0, kt = 0;
     double sum_y = 0, sum_y2 = 0;
-    double *dXt = nullptr, *dY = nullptr;
+    void *dXt = nullptr, *dY = nullptr;                     // typed: [d][Npad], [Npad]
     // batch workspace
     int slots = 0;
-    double *dA = nullptr, *dXs = nullptr, *dInvEll = nullptr, *dSlotp = nullptr, *dW = nullptr,
-           *dPartial = nullptr, *dRes = nullptr;
+    void *dA = nullptr, *dXs = nullptr, *dW = nullptr;      // typed
+    double *dInvEll = nullptr, *dSlotp = nullptr, *dPartial = nullptr, *dRes = nullptr;
     int* dInfo = nullptr;
     double *hInvEll = nullptr, *hSlotp = nullptr, *hRes = nullptr;
     int* hInfo = nullptr;
@@ -66,8 +68,9 @@ struct gphip_ctx {
     bool fitted = false;
     std::vector<double> theta_fit;
     double logdet_fit = 0, mu_fit = 0, kappa_fit = 0;
-    // prediction scratch
-    double *dV = nullptr, *dXsT = nullptr, *dXsS = nullptr, *dMean = nullptr, *dVar = nullptr;
+    // prediction / solve scratch
+    void *dV = nullptr, *dXsT = nullptr, *dXsS = nullptr;   // typed
+    double *dMean = nullptr, *dVar = nullptr;
     int64_t vcap = 0;
     // profiling
     std::vector<ProfRec> recs;
@@ -91,9 +94,16 @@ namespace {
         }                                                                                  \
     } while (0)
 
+// run f<double>(args) or f<float>(args) according to the handle's device type
+#define DISPATCH(h, f, ...) ((h)->dtype == 64 ? f<double>(__VA_ARGS__) : f<float>(__VA_ARGS__))
+
 int fail(gphip_ctx* h, int code, const char* msg) {
     if (h) h->err = msg;
     return code;
+}
+
+double pivot_tol_rel(const gphip_ctx* h) {
+    return 64.0 * (h->dtype == 64 ? 2.220446049250313e-16 : 1.1920929e-07);
 }
 
 hipEvent_t get_event(gphip_ctx* h) {
@@ -150,7 +160,8 @@ void free_slots(gphip_ctx* h) {
     (void)hipFree(h->dW); (void)hipFree(h->dPartial); (void)hipFree(h->dRes); (void)hipFree(h->dInfo);
     (void)hipHostFree(h->hInvEll); (void)hipHostFree(h->hSlotp); (void)hipHostFree(h->hRes);
     (void)hipHostFree(h->hInfo);
-    h->dA = h->dXs = h->dInvEll = h->dSlotp = h->dW = h->dPartial = h->dRes = nullptr;
+    h->dA = h->dXs = h->dW = nullptr;
+    h->dInvEll = h->dSlotp = h->dPartial = h->dRes = nullptr;
     h->dInfo = nullptr;
     h->hInvEll = h->hSlotp = h->hRes = nullptr;
     h->hInfo = nullptr;
@@ -159,7 +170,7 @@ void free_slots(gphip_ctx* h) {
 }
 
 size_t slot_bytes(const gphip_ctx* h) {
-    return (size_t)h->ld * h->ld * 8 + (size_t)h->d * h->Npad * 8 + (size_t)h->Nt * TB * TB * 8 +
+    return ((size_t)h->ld * h->ld + (size_t)h->d * h->Npad + (size_t)h->Nt * TB * TB) * h->es +
            (size_t)h->Nt * 8 + 4096;
 }
 
@@ -175,11 +186,11 @@ int ensure_slots(gphip_ctx* h, int want) {
     if (want <= h->slots) return GPHIP_OK;
     free_slots(h);
     const size_t S = (size_t)want;
-    HIPCHK(hipMalloc(&h->dA, S * h->ld * h->ld * 8));
-    HIPCHK(hipMalloc(&h->dXs, S * h->d * h->Npad * 8));
+    HIPCHK(hipMalloc(&h->dA, S * h->ld * h->ld * h->es));
+    HIPCHK(hipMalloc(&h->dXs, S * h->d * h->Npad * h->es));
+    HIPCHK(hipMalloc(&h->dW, S * h->Nt * TB * TB * h->es));
     HIPCHK(hipMalloc(&h->dInvEll, S * h->d * 8));
     HIPCHK(hipMalloc(&h->dSlotp, S * SLOTP * 8));
-    HIPCHK(hipMalloc(&h->dW, S * h->Nt * TB * TB * 8));
     HIPCHK(hipMalloc(&h->dPartial, S * h->Nt * 8));
     HIPCHK(hipMalloc(&h->dRes, S * 2 * 8));
     HIPCHK(hipMalloc(&h->dInfo, S * 4));
@@ -191,51 +202,57 @@ int ensure_slots(gphip_ctx* h, int want) {
     return GPHIP_OK;
 }
 
-template <int KT>
-void launch_kbuild_kt(gphip_ctx* h, const KBuildArgs& a, dim3 grid) {
+// ------------------------------------------------------------------------------------------
+// typed launch helpers
+// ------------------------------------------------------------------------------------------
+template <typename T, int KT>
+void launch_kbuild_kt(gphip_ctx* h, const KBuildArgs<T>& a, dim3 grid) {
     const int d = a.d;
-#define KB_CASE(DD)                                                                            \
-    case DD:                                                                                   \
-        hipLaunchKernelGGL((kbuild_kernel<DD, KT>), grid, dim3(256), (size_t)DD * TB * 8, h->stream, a); \
+#define KB_CASE(DD)                                                                                 \
+    case DD:                                                                                        \
+        hipLaunchKernelGGL((kbuild_kernel<T, DD, KT>), grid, dim3(256), (size_t)DD * TB * sizeof(T), h->cs, a); \
         break;
     switch (d) {
         KB_CASE(1) KB_CASE(2) KB_CASE(3) KB_CASE(4) KB_CASE(5) KB_CASE(6) KB_CASE(7) KB_CASE(8)
         KB_CASE(16)
         default:
-            hipLaunchKernelGGL((kbuild_kernel<0, KT>), grid, dim3(256), (size_t)2 * d * TB * 8,
-                               h->stream, a);
+            hipLaunchKernelGGL((kbuild_kernel<T, 0, KT>), grid, dim3(256), (size_t)2 * d * TB * sizeof(T), h->cs, a);
     }
 #undef KB_CASE
 }
 
-void launch_kbuild(gphip_ctx* h, const KBuildArgs& a, dim3 grid) {
-    if (h->kt == 0) launch_kbuild_kt<0>(h, a, grid);
-    else launch_kbuild_kt<1>(h, a, grid);
+template <typename T>
+void launch_kbuild(gphip_ctx* h, const KBuildArgs<T>& a, dim3 grid) {
+    if (h->kt == 0) launch_kbuild_kt<T, 0>(h, a, grid);
+    else launch_kbuild_kt<T, 1>(h, a, grid);
 }
 
 // queue k_scale + kbuild for nslots slots (theta already staged in dInvEll / dSlotp)
-void queue_build(gphip_ctx* h, int nslots) {
+template <typename T>
+int queue_build(gphip_ctx* h, int nslots) {
     const long tot = (long)h->d * h->Npad;
     int gx = (int)((tot + 255) / 256);
     if (gx > 1024) gx = 1024;
-    hipLaunchKernelGGL(k_scale, dim3(gx, nslots), dim3(256), 0, h->stream, h->dXt, h->dXs, h->dInvEll,
-                       (int)h->d, (int)h->Npad);
-    KBuildArgs a{};
-    a.out = h->dA; a.ld = h->ld; a.bstride = h->ld * h->ld;
-    a.xi = h->dXs; a.xj = h->dXs; a.xi_bstride = a.xj_bstride = tot;
+    hipLaunchKernelGGL(k_scale<T>, dim3(gx, nslots), dim3(256), 0, h->cs, (const T*)h->dXt, (T*)h->dXs,
+                       h->dInvEll, (int)h->d, (int)h->Npad);
+    KBuildArgs<T> a{};
+    a.out = (T*)h->dA; a.ld = h->ld; a.bstride = h->ld * h->ld;
+    a.xi = (const T*)h->dXs; a.xj = (const T*)h->dXs; a.xi_bstride = a.xj_bstride = tot;
     a.npad_i = a.npad_j = (int)h->Npad; a.n_i = a.n_j = (int)h->N;
-    a.y = h->dY; a.slotp = h->dSlotp; a.d = (int)h->d; a.mode = 0;
+    a.y = (const T*)h->dY; a.slotp = h->dSlotp; a.d = (int)h->d; a.mode = 0;
     a.nt_i = (int)h->Nt + 1; a.nt_j = (int)h->Nt;
     a.own_panel = h->panel; a.own_world = h->dist_world; a.own_rank = h->dist_rank;
     const long ntiles = (long)(h->Nt + 1) * (h->Nt + 2) / 2;
-    ProfScope ps(h, 0, 0.0, 8.0 * nslots * ((double)h->N * (h->N + 1) / 2 + (double)h->N * h->d));
-    launch_kbuild(h, a, dim3((unsigned)ntiles, nslots));
+    ProfScope ps(h, 0, 0.0, (double)sizeof(T) * nslots * ((double)h->N * (h->N + 1) / 2 + (double)h->N * h->d));
+    launch_kbuild<T>(h, a, dim3((unsigned)ntiles, nslots));
+    return 0;
 }
 
-void launch_gemm(gphip_ctx* h, int cls, double* C, long ldc, long cbs, const double* A, long lda,
-                 long abs_, const double* B, long ldb, long bbs, int K, int r0, int r1, int c0, int c1,
-                 int tri, int nslots, int mode = 0) {
-    GemmArgs g{};
+// cls: profile class (2 panel solve, 3 in-panel/look-ahead GEMM, 4 trailing SYRK, 6 = "NN" role)
+template <typename T>
+void launch_gemm(gphip_ctx* h, int cls, T* C, long ldc, long cbs, const T* A, long lda, long abs_, const T* B,
+                 long ldb, long bbs, int K, int r0, int r1, int c0, int c1, int tri, int nslots, int mode = 0) {
+    GemmArgs<T> g{};
     g.mode = mode;
     g.C = C; g.ldc = ldc; g.c_bstride = cbs;
     g.A = A; g.lda = lda; g.a_bstride = abs_;
@@ -263,14 +280,13 @@ void launch_gemm(gphip_ctx* h, int cls, double* C, long ldc, long cbs, const dou
     }
     const double flops = 2.0 * TB * TB * (double)K * g.ntiles * nslots;
     // algorithmic bytes: C tiles read + written once, each operand panel streamed once
-    const double bytes = 8.0 * nslots * (2.0 * TB * TB * g.ntiles + (double)(tri ? H : H + W) * TB * K);
+    const double bytes = (double)sizeof(T) * nslots * (2.0 * TB * TB * g.ntiles + (double)(tri ? H : H + W) * TB * K);
     ProfScope ps(h, cls == 6 ? 3 : cls, flops, bytes);
     const dim3 grid(grid_x, nslots);
-    const size_t lds = (size_t)2 * 2 * GK * LDT * 8;
-    if (cls == 6) hipLaunchKernelGGL(gemm_nt_kernel<3>, grid, dim3(256), lds, h->cs, g);
-    else if (mode == 1) hipLaunchKernelGGL(gemm_nt_kernel<2>, grid, dim3(256), lds, h->cs, g);
-    else if (cls == 4) hipLaunchKernelGGL(gemm_nt_kernel<0>, grid, dim3(256), lds, h->cs, g);
-    else hipLaunchKernelGGL(gemm_nt_kernel<1>, grid, dim3(256), lds, h->cs, g);
+    if (cls == 6) hipLaunchKernelGGL((gemm_nt_kernel<T, 3>), grid, dim3(256), GEMM_LDS, h->cs, g);
+    else if (mode == 1) hipLaunchKernelGGL((gemm_nt_kernel<T, 2>), grid, dim3(256), GEMM_LDS, h->cs, g);
+    else if (cls == 4) hipLaunchKernelGGL((gemm_nt_kernel<T, 0>), grid, dim3(256), GEMM_LDS, h->cs, g);
+    else hipLaunchKernelGGL((gemm_nt_kernel<T, 1>), grid, dim3(256), GEMM_LDS, h->cs, g);
 }
 
 hipEvent_t sync_event(gphip_ctx* h) {       // untimed events for cross-stream ordering
@@ -282,25 +298,32 @@ hipEvent_t sync_event(gphip_ctx* h) {       // untimed events for cross-stream o
     return h->sync_events[h->sync_used++];
 }
 
+template <typename T>
+size_t potrf_lds() { return 16 + (size_t)PT_LDS_ELEMS * sizeof(T); }
+
 // factor the tile columns [K0, K0+nin) of all slots (diagonal blocks, panel solves, in-panel updates)
-void queue_panel(gphip_ctx* h, int K0, int nin, int nslots) {
+template <typename T>
+int queue_panel(gphip_ctx* h, int K0, int nin, int nslots) {
     const int Nt = (int)h->Nt, R = Nt + 1;
     const long ld = h->ld, bs = ld * ld, lrs = (long)Nt * TB * TB;
+    T* A = (T*)h->dA;
+    T* W = (T*)h->dW;
     for (int s = 0; s < nin; ++s) {
         const int b = K0 + s;
         {
             ProfScope ps(h, 1, 2.0 * TB * TB * TB / 3.0 * nslots, 0.0);
-            hipLaunchKernelGGL(potrf128_kernel, dim3(nslots), dim3(256), POTRF_LDS, h->cs, h->dA, ld, bs, b,
-                               h->dW, h->dPartial, Nt, h->dInfo, h->dSlotp);
+            hipLaunchKernelGGL(potrf128_kernel<T>, dim3(nslots), dim3(256), potrf_lds<T>(), h->cs, A, ld, bs, b, W,
+                               h->dPartial, Nt, h->dInfo, h->dSlotp);
         }
         // panel solve X <- X W_b^T for every row tile below the diagonal block (incl. rhs rows)
-        launch_gemm(h, 2, h->dA, ld, bs, h->dA + (long)b * TB * ld, ld, bs,
-                    h->dW + (long)b * TB * TB - (long)b * TB, TB, lrs, TB, b + 1, R, b, b + 1, 0, nslots, 1);
+        launch_gemm<T>(h, 2, A, ld, bs, A + (long)b * TB * ld, ld, bs, W + (long)b * TB * TB - (long)b * TB, TB, lrs,
+                       TB, b + 1, R, b, b + 1, 0, nslots, 1);
         if (s + 1 < nin) {
-            const double* P = h->dA + (long)b * TB * ld;
-            launch_gemm(h, 3, h->dA, ld, bs, P, ld, bs, P, ld, bs, TB, b + 1, R, b + 1, K0 + nin, 1, nslots);
+            const T* P = A + (long)b * TB * ld;
+            launch_gemm<T>(h, 3, A, ld, bs, P, ld, bs, P, ld, bs, TB, b + 1, R, b + 1, K0 + nin, 1, nslots);
         }
     }
+    return 0;
 }
 
 // Two-level right-looking Cholesky of slots [0, nslots) (workspace already built on h->stream).
@@ -308,21 +331,23 @@ void queue_panel(gphip_ctx* h, int K0, int nin, int nslots) {
 // applying panel k to everything right of panel k+1:
 //   panel stream:  [wait REST(k-1)]  LA(k) = update of panel k+1's columns by panel k;  factor panel k+1
 //   main  stream:  [wait panel k]    REST(k) = update of the columns right of panel k+1 by panel k
-void queue_factor(gphip_ctx* h, int nslots) {
+template <typename T>
+int queue_factor(gphip_ctx* h, int nslots) {
     const int Nt = (int)h->Nt, R = Nt + 1;     // R = tile rows incl. the rhs block-row
     const long ld = h->ld, bs = ld * ld;
     const int P = h->panel;
     const int nouter = (Nt + P - 1) / P;
+    T* A = (T*)h->dA;
     auto k0 = [&](int k) { return k * P < Nt ? k * P : Nt; };
     auto trailing = [&](int k, int c_lo, int c_hi, int cls) {      // apply panel k to tile columns [c_lo,c_hi)
-        const double* Pk = h->dA + (long)k0(k) * TB * ld;
-        launch_gemm(h, cls, h->dA, ld, bs, Pk, ld, bs, Pk, ld, bs, (k0(k + 1) - k0(k)) * TB, c_lo, R, c_lo, c_hi,
-                    1, nslots);
+        const T* Pk = A + (long)k0(k) * TB * ld;
+        launch_gemm<T>(h, cls, A, ld, bs, Pk, ld, bs, Pk, ld, bs, (k0(k + 1) - k0(k)) * TB, c_lo, R, c_lo, c_hi, 1,
+                       nslots);
     };
     if (!h->lookahead || nouter < 2) {
         h->cs = h->stream;
         for (int k = 0; k < nouter; ++k) {
-            queue_panel(h, k0(k), k0(k + 1) - k0(k), nslots);
+            queue_panel<T>(h, k0(k), k0(k + 1) - k0(k), nslots);
             trailing(k, k0(k + 1), R, 4);
         }
     } else {
@@ -331,7 +356,7 @@ void queue_factor(gphip_ctx* h, int nslots) {
         (void)hipEventRecord(built, h->stream);
         (void)hipStreamWaitEvent(h->pstream, built, 0);
         h->cs = h->pstream;
-        queue_panel(h, 0, k0(1), nslots);
+        queue_panel<T>(h, 0, k0(1), nslots);
         hipEvent_t ev_panel = sync_event(h);
         (void)hipEventRecord(ev_panel, h->pstream);
         hipEvent_t ev_rest = nullptr;
@@ -340,22 +365,23 @@ void queue_factor(gphip_ctx* h, int nslots) {
             if (k + 1 < nouter) {
                 h->cs = h->pstream;
                 if (ev_rest) (void)hipStreamWaitEvent(h->pstream, ev_rest, 0);
-                trailing(k, k0(k + 1), k0(k + 2), 3);                       // LA(k)
-                queue_panel(h, k0(k + 1), k0(k + 2) - k0(k + 1), nslots);    // factor panel k+1
+                trailing(k, k0(k + 1), k0(k + 2), 3);                          // LA(k)
+                queue_panel<T>(h, k0(k + 1), k0(k + 2) - k0(k + 1), nslots);    // factor panel k+1
                 ev_next = sync_event(h);
                 (void)hipEventRecord(ev_next, h->pstream);
             }
             h->cs = h->stream;
             (void)hipStreamWaitEvent(h->stream, ev_panel, 0);
-            trailing(k, k0(k + 2), R, 4);                                   // REST(k)
+            trailing(k, k0(k + 2), R, 4);                                      // REST(k)
             ev_rest = sync_event(h);
             (void)hipEventRecord(ev_rest, h->stream);
             ev_panel = ev_next;
         }
         h->cs = h->stream;
     }
-    hipLaunchKernelGGL(finalize_kernel, dim3(nslots), dim3(64), 0, h->stream, h->dA, ld, bs,
-                       (int)h->Npad, h->dPartial, Nt, h->dRes);
+    hipLaunchKernelGGL(finalize_kernel<T>, dim3(nslots), dim3(64), 0, h->stream, (const T*)A, ld, bs, (int)h->Npad,
+                       h->dPartial, Nt, h->dRes);
+    return 0;
 }
 
 // stage theta of one slot into the pinned host buffers; returns false if theta is unusable
@@ -374,7 +400,7 @@ bool stage_theta(gphip_ctx* h, int slot, const double* th) {
     double mu = (h->mean_id == GPHIP_MEAN_CONST) ? th[h->nl + 2] : 0.0;
     if (!ok) { sf = 1.0; sn = 1.0; mu = 0.0; }
     sp[0] = sf * sf; sp[1] = sn * sn; sp[2] = mu;
-    sp[3] = PIVOT_TOL_REL * (sf * sf + sn * sn);
+    sp[3] = pivot_tol_rel(h) * (sf * sf + sn * sn);
     if (!std::isfinite(sp[0]) || !std::isfinite(sp[1])) { ok = false; sp[0] = sp[1] = 1.0; sp[3] = 1e-14; }
     sp[4] = ok ? 0.0 : 1.0;
     return ok;
@@ -399,10 +425,11 @@ int eval_chunk(gphip_ctx* h, const double* Theta, int nb, double* out, double* p
     HIPCHK(hipMemcpyAsync(h->dInvEll, h->hInvEll, (size_t)nb * h->d * 8, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->dSlotp, h->hSlotp, (size_t)nb * SLOTP * 8, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemsetAsync(h->dInfo, 0, (size_t)nb * 4, h->stream));
+    h->cs = h->stream;
     {
         ProfScope ps(h, 5, 0.0, 0.0);
-        queue_build(h, nb);
-        queue_factor(h, nb);
+        DISPATCH(h, queue_build, h, nb);
+        DISPATCH(h, queue_factor, h, nb);
     }
     HIPCHK(hipMemcpyAsync(h->hRes, h->dRes, (size_t)nb * 16, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipMemcpyAsync(h->hInfo, h->dInfo, (size_t)nb * 4, hipMemcpyDeviceToHost, h->stream));
@@ -444,25 +471,140 @@ int eval_batch(gphip_ctx* h, const double* Theta, int B, int p, double* out, dou
     return GPHIP_OK;
 }
 
+template <typename T>
 int set_func_attrs(gphip_ctx* h) {
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(potrf128_kernel),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)POTRF_LDS));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<0>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * GK * LDT * 8));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<1>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * GK * LDT * 8));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<2>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * GK * LDT * 8));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<3>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * GK * LDT * 8));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(potrf128_kernel<T>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)potrf_lds<T>()));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<T, 0>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<T, 1>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<T, 2>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<T, 3>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS));
     return GPHIP_OK;
+}
+
+// host fp64 -> device T upload / download helpers (synchronous on `st`)
+template <typename T>
+int upload(gphip_ctx* h, void* dst, const std::vector<double>& src, hipStream_t st) {
+    if (sizeof(T) == 8) {
+        HIPCHK(hipMemcpyAsync(dst, src.data(), src.size() * 8, hipMemcpyHostToDevice, st));
+        HIPCHK(hipStreamSynchronize(st));
+    } else {
+        std::vector<float> tmp(src.begin(), src.end());
+        HIPCHK(hipMemcpyAsync(dst, tmp.data(), tmp.size() * 4, hipMemcpyHostToDevice, st));
+        HIPCHK(hipStreamSynchronize(st));
+    }
+    return GPHIP_OK;
+}
+
+template <typename T>
+int download(gphip_ctx* h, std::vector<double>& dst, const void* src, size_t n, hipStream_t st) {
+    dst.resize(n);
+    if (sizeof(T) == 8) {
+        HIPCHK(hipMemcpyAsync(dst.data(), src, n * 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+    } else {
+        std::vector<float> tmp(n);
+        HIPCHK(hipMemcpyAsync(tmp.data(), src, n * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        for (size_t i = 0; i < n; ++i) dst[i] = tmp[i];
+    }
+    return GPHIP_OK;
+}
+
+int ensure_vbuf(gphip_ctx* h, int64_t cap) {
+    if (cap <= h->vcap) return GPHIP_OK;
+    (void)hipFree(h->dV); (void)hipFree(h->dXsT); (void)hipFree(h->dXsS); (void)hipFree(h->dMean); (void)hipFree(h->dVar);
+    h->dV = h->dXsT = h->dXsS = nullptr;
+    h->dMean = h->dVar = nullptr;
+    h->vcap = 0;
+    HIPCHK(hipMalloc(&h->dV, (size_t)cap * h->Npad * h->es));
+    HIPCHK(hipMalloc(&h->dXsT, (size_t)cap * h->d * h->es));
+    HIPCHK(hipMalloc(&h->dXsS, (size_t)cap * h->d * h->es));
+    HIPCHK(hipMalloc(&h->dMean, (size_t)cap * 8));
+    HIPCHK(hipMalloc(&h->dVar, (size_t)cap * 8));
+    h->vcap = cap;
+    return GPHIP_OK;
+}
+
+// V <- V L^-T for the mpad x Npad row block in dV (right-looking over the 128-tile columns of L):
+// every row of V becomes (L^-1 v)^T.  Panel solves and updates are the same MFMA GEMM kernel.
+template <typename T>
+int queue_forward_rows(gphip_ctx* h, int64_t mpad) {
+    const int Nt = (int)h->Nt, Mt = (int)(mpad / TB);
+    const long ld = h->ld;
+    T *V = (T*)h->dV, *A = (T*)h->dA, *W = (T*)h->dW;
+    for (int b = 0; b < Nt; ++b) {
+        launch_gemm<T>(h, 2, V, mpad, 0, V + (long)b * TB * mpad, mpad, 0, W + (long)b * TB * TB - (long)b * TB, TB, 0,
+                       TB, 0, Mt, b, b + 1, 0, 1, 1);
+        if (b + 1 < Nt)
+            launch_gemm<T>(h, 3, V, mpad, 0, V + (long)b * TB * mpad, mpad, 0, A + (long)b * TB * ld, ld, 0, TB, 0, Mt,
+                           b + 1, Nt, 0, 1);
+    }
+    return 0;
+}
+
+// V <- V L^-1 (backward substitution, block columns from last to first), "NN" GEMM role:
+//   X_b = Y_b W_b ;  Y_c -= X_b L(b,c) for c < b.
+template <typename T>
+int queue_backward_rows(gphip_ctx* h, int64_t mpad) {
+    const int Nt = (int)h->Nt, Mt = (int)(mpad / TB);
+    const long ld = h->ld;
+    T *V = (T*)h->dV, *A = (T*)h->dA, *W = (T*)h->dW;
+    for (int b = Nt - 1; b >= 0; --b) {
+        launch_gemm<T>(h, 6, V, mpad, 0, V + (long)b * TB * mpad, mpad, 0, W, TB, 0, TB, 0, Mt, b, b + 1, 0, 1, 1);
+        if (b > 0)
+            launch_gemm<T>(h, 6, V, mpad, 0, V + (long)b * TB * mpad, mpad, 0, A + (long)b * TB, ld, 0, TB, 0, Mt, 0, b,
+                           0, 1, 0);
+    }
+    return 0;
+}
+
+template <typename T>
+int queue_cross(gphip_ctx* h, int64_t mc, int64_t mpad) {      // V(t, j) = k(x*_t, x_j), scaled test points in dXsS
+    const long tot = (long)h->d * mpad;
+    hipLaunchKernelGGL(k_scale<T>, dim3((unsigned)((tot + 255) / 256), 1), dim3(256), 0, h->stream, (const T*)h->dXsT,
+                       (T*)h->dXsS, h->dInvEll, (int)h->d, (int)mpad);
+    KBuildArgs<T> a{};
+    a.out = (T*)h->dV; a.ld = mpad; a.bstride = 0;
+    a.xi = (const T*)h->dXsS; a.xj = (const T*)h->dXs; a.xi_bstride = a.xj_bstride = 0;
+    a.npad_i = (int)mpad; a.npad_j = (int)h->Npad; a.n_i = (int)mc; a.n_j = (int)h->N;
+    a.y = nullptr; a.slotp = h->dSlotp; a.d = (int)h->d; a.mode = 1; a.nt_i = (int)(mpad / TB); a.nt_j = (int)h->Nt;
+    launch_kbuild<T>(h, a, dim3((unsigned)((mpad / TB) * h->Nt), 1));
+    return 0;
+}
+
+template <typename T>
+int queue_predict_reduce(gphip_ctx* h, int64_t mc, int64_t mpad) {
+    hipLaunchKernelGGL(predict_reduce_kernel<T>, dim3((unsigned)((mc + 63) / 64)), dim3(64), 0, h->stream,
+                       (const T*)h->dV, (long)mpad, (int)h->N, (const T*)h->dA + h->Npad, (long)h->ld, h->mu_fit,
+                       h->kappa_fit, (int)mc, h->dMean, h->dVar);
+    return 0;
+}
+
+template <typename T>
+int queue_dist_update(gphip_ctx* h, const void* packed, long K0, long rows, long cols, int c_lo, int c_hi, int cls) {
+    const T* base = (const T*)packed - K0 * TB;     // so that absolute tile row t sits at base + t*128
+    launch_gemm<T>(h, cls, (T*)h->dA, h->ld, 0, base, rows, 0, base, rows, 0, (int)cols, c_lo, (int)h->Nt + 1, c_lo,
+                   c_hi, 1, 1);
+    return 0;
+}
+
+template <typename T>
+int queue_finalize(gphip_ctx* h) {
+    hipLaunchKernelGGL(finalize_kernel<T>, dim3(1), dim3(64), 0, h->stream, (const T*)h->dA, h->ld, h->ld * h->ld,
+                       (int)h->Npad, h->dPartial, (int)h->Nt, h->dRes);
+    return 0;
 }
 
 }  // namespace
 
 extern "C" {
 
-const char* gphip_version(void) { return "gphip 0.1.0 (gfx950)"; }
+const char* gphip_version(void) { return "gphip 0.2.0 (gfx950; fp64 + fp32)"; }
 
 int gphip_device_count(int* n) {
     if (!n) return GPHIP_ERR_ARG;
@@ -483,13 +625,15 @@ int gphip_create(const void* X, const void* y, int64_t N, int64_t d, int kernel_
     if (d > 32) return GPHIP_ERR_UNSUPPORTED;   // LDS-resident point tiles: 2*d*1 KiB <= 64 KiB
     if (kernel_id < 0 || kernel_id > GPHIP_KERNEL_NULL) return GPHIP_ERR_ARG;
     if (mean_id != GPHIP_MEAN_ZERO && mean_id != GPHIP_MEAN_CONST) return GPHIP_ERR_ARG;
-    if (dtype != 64) return GPHIP_ERR_UNSUPPORTED;
+    if (dtype != 64 && dtype != 32) return GPHIP_ERR_UNSUPPORTED;
     int ndevs = 0;
     if (hipGetDeviceCount(&ndevs) != hipSuccess || ndevs < 1) return GPHIP_ERR_NODEVICE;
     gphip_ctx* h = new gphip_ctx;
     if (devices && ndev > 0) h->device = devices[0];
     else (void)hipGetDevice(&h->device);
     if (h->device < 0 || h->device >= ndevs) { delete h; return GPHIP_ERR_NODEVICE; }
+    h->dtype = dtype;
+    h->es = dtype == 64 ? 8 : 4;
     h->N = N; h->d = d;
     h->Npad = (N + TB - 1) / TB * TB;
     h->Nt = h->Npad / TB;
@@ -505,10 +649,10 @@ int gphip_create(const void* X, const void* y, int64_t N, int64_t d, int kernel_
     auto bail = [&](int code) { gphip_destroy(h); return code; };
     if (hipSetDevice(h->device) != hipSuccess) return bail(GPHIP_ERR_HIP);
     {
-        int lo = 0, hi = 0;                         // numerically lower = higher priority
-        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-        if (hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, lo) != hipSuccess) return bail(GPHIP_ERR_HIP);
-        if (hipStreamCreateWithPriority(&h->pstream, hipStreamNonBlocking, hi) != hipSuccess) return bail(GPHIP_ERR_HIP);
+        int least = 0, greatest = 0;                // numerically lower = higher priority
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        if (hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, least) != hipSuccess) return bail(GPHIP_ERR_HIP);
+        if (hipStreamCreateWithPriority(&h->pstream, hipStreamNonBlocking, greatest) != hipSuccess) return bail(GPHIP_ERR_HIP);
         h->cs = h->stream;
     }
     std::vector<double> xt((size_t)d * h->Npad, 0.0), yp((size_t)h->Npad, 0.0);
@@ -516,11 +660,11 @@ int gphip_create(const void* X, const void* y, int64_t N, int64_t d, int kernel_
         for (int64_t j = 0; j < d; ++j) xt[(size_t)j * h->Npad + i] = Xd[i * d + j];
         yp[i] = yd[i];
     }
-    if (hipMalloc(&h->dXt, xt.size() * 8) != hipSuccess) return bail(GPHIP_ERR_HIP);
-    if (hipMalloc(&h->dY, yp.size() * 8) != hipSuccess) return bail(GPHIP_ERR_HIP);
-    if (hipMemcpy(h->dXt, xt.data(), xt.size() * 8, hipMemcpyHostToDevice) != hipSuccess) return bail(GPHIP_ERR_HIP);
-    if (hipMemcpy(h->dY, yp.data(), yp.size() * 8, hipMemcpyHostToDevice) != hipSuccess) return bail(GPHIP_ERR_HIP);
-    if (set_func_attrs(h) != GPHIP_OK) return bail(GPHIP_ERR_HIP);
+    if (hipMalloc(&h->dXt, xt.size() * h->es) != hipSuccess) return bail(GPHIP_ERR_HIP);
+    if (hipMalloc(&h->dY, yp.size() * h->es) != hipSuccess) return bail(GPHIP_ERR_HIP);
+    if (DISPATCH(h, upload, h, h->dXt, xt, h->stream) != GPHIP_OK) return bail(GPHIP_ERR_HIP);
+    if (DISPATCH(h, upload, h, h->dY, yp, h->stream) != GPHIP_OK) return bail(GPHIP_ERR_HIP);
+    if (DISPATCH(h, set_func_attrs, h) != GPHIP_OK) return bail(GPHIP_ERR_HIP);
     *out = h;
     return GPHIP_OK;
 }
@@ -601,58 +745,16 @@ int gphip_covariance(gphip_handle h, const double* theta, int p, double* K) {
     if (!stage_theta(h, 0, theta)) return fail(h, GPHIP_ERR_ARG, "non-finite or zero hyper-parameter");
     HIPCHK(hipMemcpyAsync(h->dInvEll, h->hInvEll, (size_t)h->d * 8, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->dSlotp, h->hSlotp, SLOTP * 8, hipMemcpyHostToDevice, h->stream));
-    queue_build(h, 1);
-    std::vector<double> tmp((size_t)N * N);
-    HIPCHK(hipMemcpy2DAsync(tmp.data(), (size_t)N * 8, h->dA, (size_t)h->ld * 8, (size_t)N * 8, (size_t)N,
-                            hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    h->cs = h->stream;
+    DISPATCH(h, queue_build, h, 1);
+    // the lower triangle of the leading N columns, column-major with leading dimension ld
+    std::vector<double> tmp;
+    rc = DISPATCH(h, download, h, tmp, h->dA, (size_t)h->ld * (size_t)N, h->stream);
+    if (rc) return rc;
     harvest(h);
-    // tmp is column-major with only the lower triangle valid: tmp[j*N + i], i >= j
     for (int64_t j = 0; j < N; ++j)
-        for (int64_t i = j; i < N; ++i) K[i * N + j] = K[j * N + i] = tmp[j * N + i];
+        for (int64_t i = j; i < N; ++i) K[i * N + j] = K[j * N + i] = tmp[(size_t)j * h->ld + i];
     return GPHIP_OK;
-}
-
-static int ensure_vbuf(gphip_ctx* h, int64_t cap) {
-    if (cap <= h->vcap) return GPHIP_OK;
-    (void)hipFree(h->dV); (void)hipFree(h->dXsT); (void)hipFree(h->dXsS); (void)hipFree(h->dMean); (void)hipFree(h->dVar);
-    h->dV = h->dXsT = h->dXsS = h->dMean = h->dVar = nullptr;
-    h->vcap = 0;
-    HIPCHK(hipMalloc(&h->dV, (size_t)cap * h->Npad * 8));
-    HIPCHK(hipMalloc(&h->dXsT, (size_t)cap * h->d * 8));
-    HIPCHK(hipMalloc(&h->dXsS, (size_t)cap * h->d * 8));
-    HIPCHK(hipMalloc(&h->dMean, (size_t)cap * 8));
-    HIPCHK(hipMalloc(&h->dVar, (size_t)cap * 8));
-    h->vcap = cap;
-    return GPHIP_OK;
-}
-
-// V <- V L^-T for the mpad x Npad row block in dV (right-looking over the 128-tile columns of L):
-// every row of V becomes (L^-1 v)^T.  Panel solves and updates are the same MFMA GEMM kernel.
-static void queue_forward_rows(gphip_ctx* h, int64_t mpad) {
-    const int Nt = (int)h->Nt, Mt = (int)(mpad / TB);
-    const long ld = h->ld;
-    for (int b = 0; b < Nt; ++b) {
-        launch_gemm(h, 2, h->dV, mpad, 0, h->dV + (long)b * TB * mpad, mpad, 0,
-                    h->dW + (long)b * TB * TB - (long)b * TB, TB, 0, TB, 0, Mt, b, b + 1, 0, 1, 1);
-        if (b + 1 < Nt)
-            launch_gemm(h, 3, h->dV, mpad, 0, h->dV + (long)b * TB * mpad, mpad, 0,
-                        h->dA + (long)b * TB * ld, ld, 0, TB, 0, Mt, b + 1, Nt, 0, 1);
-    }
-}
-
-// V <- V L^-1 (backward substitution, block columns from last to first), "NN" GEMM role:
-//   X_b = Y_b W_b ;  Y_c -= X_b L(b,c) for c < b.
-static void queue_backward_rows(gphip_ctx* h, int64_t mpad) {
-    const int Nt = (int)h->Nt, Mt = (int)(mpad / TB);
-    const long ld = h->ld;
-    for (int b = Nt - 1; b >= 0; --b) {
-        launch_gemm(h, 6, h->dV, mpad, 0, h->dV + (long)b * TB * mpad, mpad, 0,
-                    h->dW, TB, 0, TB, 0, Mt, b, b + 1, 0, 1, 1);
-        if (b > 0)
-            launch_gemm(h, 6, h->dV, mpad, 0, h->dV + (long)b * TB * mpad, mpad, 0,
-                        h->dA + (long)b * TB, ld, 0, TB, 0, Mt, 0, b, 0, 1, 0);
-    }
 }
 
 int gphip_predict(gphip_handle h, const void* Xs, int64_t M, double* mean, double* var) {
@@ -662,8 +764,7 @@ int gphip_predict(gphip_handle h, const void* Xs, int64_t M, double* mean, doubl
     if (!h->fitted) return fail(h, GPHIP_ERR_STATE, "gphip_predict before a successful gphip_fit");
     HIPCHK(hipSetDevice(h->device));
     const double* X = static_cast<const double*>(Xs);
-    const int64_t d = h->d, Npad = h->Npad, ld = h->ld;
-    const int Nt = (int)h->Nt;
+    const int64_t d = h->d;
     const int64_t MC = 2048;                                   // test points per chunk
     int rc = ensure_vbuf(h, M < MC ? (M + TB - 1) / TB * TB : MC);
     if (rc) return rc;
@@ -672,24 +773,14 @@ int gphip_predict(gphip_handle h, const void* Xs, int64_t M, double* mean, doubl
     for (int64_t m0 = 0; m0 < M; m0 += MC) {
         const int64_t mc = (M - m0 < MC) ? (M - m0) : MC;
         const int64_t mpad = (mc + TB - 1) / TB * TB;
-        const int Mt = (int)(mpad / TB);
         xt.assign((size_t)d * mpad, 0.0);
         for (int64_t i = 0; i < mc; ++i)
             for (int64_t j = 0; j < d; ++j) xt[(size_t)j * mpad + i] = X[(m0 + i) * d + j];
-        HIPCHK(hipMemcpyAsync(h->dXsT, xt.data(), xt.size() * 8, hipMemcpyHostToDevice, h->stream));
-        const long tot = (long)d * mpad;
-        hipLaunchKernelGGL(k_scale, dim3((unsigned)((tot + 255) / 256), 1), dim3(256), 0, h->stream,
-                           h->dXsT, h->dXsS, h->dInvEll, (int)d, (int)mpad);
-        KBuildArgs a{};
-        a.out = h->dV; a.ld = mpad; a.bstride = 0;
-        a.xi = h->dXsS; a.xj = h->dXs; a.xi_bstride = a.xj_bstride = 0;
-        a.npad_i = (int)mpad; a.npad_j = (int)Npad; a.n_i = (int)mc; a.n_j = (int)h->N;
-        a.y = nullptr; a.slotp = h->dSlotp; a.d = (int)d; a.mode = 1; a.nt_i = Mt; a.nt_j = Nt;
-        launch_kbuild(h, a, dim3((unsigned)(Mt * Nt), 1));
-        queue_forward_rows(h, mpad);
-        hipLaunchKernelGGL(predict_reduce_kernel, dim3((unsigned)((mc + 63) / 64)), dim3(64), 0, h->stream,
-                           h->dV, (long)mpad, (int)h->N, h->dA + Npad, ld, h->mu_fit, h->kappa_fit, (int)mc,
-                           h->dMean, h->dVar);
+        rc = DISPATCH(h, upload, h, h->dXsT, xt, h->stream);
+        if (rc) return rc;
+        DISPATCH(h, queue_cross, h, mc, mpad);
+        DISPATCH(h, queue_forward_rows, h, mpad);
+        DISPATCH(h, queue_predict_reduce, h, mc, mpad);
         HIPCHK(hipMemcpyAsync(mean + m0, h->dMean, (size_t)mc * 8, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipMemcpyAsync(var + m0, h->dVar, (size_t)mc * 8, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
@@ -718,11 +809,12 @@ int gphip_solve(gphip_handle h, const double* rhs, int64_t nrhs, double* out) {
         v.assign((size_t)mpad * Npad, 0.0);
         for (int64_t t = 0; t < mc; ++t)
             for (int64_t j = 0; j < N; ++j) v[(size_t)j * mpad + t] = rhs[(m0 + t) * N + j];
-        HIPCHK(hipMemcpyAsync(h->dV, v.data(), v.size() * 8, hipMemcpyHostToDevice, h->stream));
-        queue_forward_rows(h, mpad);
-        queue_backward_rows(h, mpad);
-        HIPCHK(hipMemcpyAsync(v.data(), h->dV, v.size() * 8, hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(hipStreamSynchronize(h->stream));
+        rc = DISPATCH(h, upload, h, h->dV, v, h->stream);
+        if (rc) return rc;
+        DISPATCH(h, queue_forward_rows, h, mpad);
+        DISPATCH(h, queue_backward_rows, h, mpad);
+        rc = DISPATCH(h, download, h, v, h->dV, (size_t)mpad * Npad, h->stream);
+        if (rc) return rc;
         HIPCHK(hipGetLastError());
         harvest(h);
         for (int64_t t = 0; t < mc; ++t)
@@ -760,8 +852,8 @@ int gphip_dist_num_panels(gphip_handle h, int* nouter) {
     return GPHIP_OK;
 }
 
-// shape of packed panel k: rows = all tile rows from the panel's first diagonal block down to
-// and including the rhs block-row, cols = the panel's width
+// shape (in elements of the handle's dtype) of packed panel k: rows = all tile rows from the
+// panel's first diagonal block down to and including the rhs block-row, cols = the panel's width
 int gphip_dist_panel_shape(gphip_handle h, int k, int64_t* rows, int64_t* cols) {
     if (!h || !rows || !cols) return GPHIP_ERR_ARG;
     const int64_t K0 = (int64_t)k * h->panel, K1 = (K0 + h->panel < h->Nt) ? K0 + h->panel : h->Nt;
@@ -788,13 +880,13 @@ int gphip_dist_begin(gphip_handle h, const double* theta, int p, int rank, int w
     HIPCHK(hipMemsetAsync(h->dInfo, 0, 4, h->stream));
     HIPCHK(hipMemsetAsync(h->dPartial, 0, (size_t)h->Nt * 8, h->stream));
     h->cs = h->stream;
-    queue_build(h, 1);
+    DISPATCH(h, queue_build, h, 1);
     return GPHIP_OK;
 }
 
 // owner of panel k: factor it in place (panel stream) and pack it into `packed`
-// (rows x cols doubles, column-major, contiguous) for the broadcast
-int gphip_dist_factor_panel(gphip_handle h, int k, double* packed) {
+// (rows x cols elements, column-major, contiguous) for the broadcast
+int gphip_dist_factor_panel(gphip_handle h, int k, void* packed) {
     if (!h || !packed) return fail(h, GPHIP_ERR_ARG, "null argument");
     int64_t rows, cols;
     int rc = gphip_dist_panel_shape(h, k, &rows, &cols);
@@ -804,16 +896,17 @@ int gphip_dist_factor_panel(gphip_handle h, int k, double* packed) {
     HIPCHK(hipSetDevice(h->device));
     const int64_t K0 = (int64_t)k * h->panel;
     h->cs = h->pstream;
-    queue_panel(h, (int)K0, (int)(cols / TB), 1);
-    HIPCHK(hipMemcpy2DAsync(packed, (size_t)rows * 8, h->dA + K0 * TB * h->ld + K0 * TB, (size_t)h->ld * 8,
-                            (size_t)rows * 8, (size_t)cols, hipMemcpyDeviceToDevice, h->pstream));
+    DISPATCH(h, queue_panel, h, (int)K0, (int)(cols / TB), 1);
+    const char* src = static_cast<const char*>(h->dA) + (size_t)(K0 * TB * h->ld + K0 * TB) * h->es;
+    HIPCHK(hipMemcpy2DAsync(packed, (size_t)rows * h->es, src, (size_t)h->ld * h->es, (size_t)rows * h->es,
+                            (size_t)cols, hipMemcpyDeviceToDevice, h->pstream));
     h->cs = h->stream;
     return GPHIP_OK;
 }
 
 // apply panel k (read from `packed`) to the outer panels j in [j_first, j_last) this rank owns;
 // j == num_panels addresses the rhs x rhs corner tile (rank 0).  on_panel_stream selects the stream.
-int gphip_dist_update(gphip_handle h, int k, const double* packed, int j_first, int j_last, int on_panel_stream) {
+int gphip_dist_update(gphip_handle h, int k, const void* packed, int j_first, int j_last, int on_panel_stream) {
     if (!h || !packed) return fail(h, GPHIP_ERR_ARG, "null argument");
     int64_t rows, cols;
     int rc = gphip_dist_panel_shape(h, k, &rows, &cols);
@@ -824,7 +917,6 @@ int gphip_dist_update(gphip_handle h, int k, const double* packed, int j_first, 
     const int Nt = (int)h->Nt, R = Nt + 1, P = h->panel;
     const int nouter = (Nt + P - 1) / P;
     const long K0 = (long)k * P;
-    const double* base = packed - K0 * TB;          // so that absolute tile row t sits at base + t*128
     h->cs = on_panel_stream ? h->pstream : h->stream;
     for (int j = (j_first > k + 1 ? j_first : k + 1); j < j_last && j <= nouter; ++j) {
         int c_lo, c_hi;
@@ -835,8 +927,7 @@ int gphip_dist_update(gphip_handle h, int k, const double* packed, int j_first, 
             if (j % h->dist_world != h->dist_rank) continue;
             c_lo = j * P; c_hi = (c_lo + P < Nt) ? c_lo + P : Nt;
         }
-        launch_gemm(h, on_panel_stream ? 3 : 4, h->dA, h->ld, 0, base, rows, 0, base, rows, 0, (int)cols, c_lo, R,
-                    c_lo, c_hi, 1, 1);
+        DISPATCH(h, queue_dist_update, h, packed, K0, (long)rows, (long)cols, c_lo, c_hi, on_panel_stream ? 3 : 4);
     }
     h->cs = h->stream;
     return GPHIP_OK;
@@ -849,8 +940,7 @@ int gphip_dist_end(gphip_handle h, double* logdet_partial, double* quad, int* in
     std::lock_guard<std::mutex> lk(h->mu);
     if (h->dist_world < 1) return fail(h, GPHIP_ERR_STATE, "gphip_dist_end without gphip_dist_begin");
     HIPCHK(hipSetDevice(h->device));
-    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(64), 0, h->stream, h->dA, h->ld, h->ld * h->ld,
-                       (int)h->Npad, h->dPartial, (int)h->Nt, h->dRes);
+    DISPATCH(h, queue_finalize, h);
     HIPCHK(hipMemcpyAsync(h->hRes, h->dRes, 16, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipMemcpyAsync(h->hInfo, h->dInfo, 4, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->pstream));
@@ -899,6 +989,7 @@ int gphip_sync(gphip_handle h) {
     if (!h) return GPHIP_ERR_ARG;
     std::lock_guard<std::mutex> lk(h->mu);
     HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->pstream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return GPHIP_OK;
 }

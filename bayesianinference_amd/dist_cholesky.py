@@ -88,7 +88,8 @@ class DistributedCholesky:
             h.set_streams(self.main[r].cuda_stream, self.panel[r].cuda_stream)
         nmax = max(r_ * c_ for r_, c_ in self.shapes)
         # three rotating packed-panel buffers per local rank: panel k+1 lands while panel k is read
-        self.bufs = {r: [torch.empty(nmax, dtype=torch.float64, device=self.device) for _ in range(3)]
+        tdtype = torch.float64 if any_h.dtype == 64 else torch.float32
+        self.bufs = {r: [torch.empty(nmax, dtype=tdtype, device=self.device) for _ in range(3)]
                      for r in handles}
 
     def owner(self, k: int) -> int:

@@ -55,7 +55,9 @@ typedef struct gphip_ctx* gphip_handle;
 #define GPHIP_MEAN_ZERO 0            /* Function[0]  (BGP:168,255)                                    */
 #define GPHIP_MEAN_CONST 1           /* Function[mu], mu = last entry of theta                        */
 
-/* X: row-major N x d, y: length N, both fp64 (dtype must be 64 in this version).
+/* X: row-major N x d, y: length N, always fp64 host arrays.  dtype selects the DEVICE arithmetic:
+ * 64 = fp64 (v_mfma_f64_16x16x4_f64, the 1e-8 parity path) or 32 = fp32 (v_mfma_f32_16x16x4_f32,
+ * BASELINE.json config 5; ~1e-3 relative vs the fp64 oracle).  theta and every result stay fp64.
  * devices/ndev: HIP device ordinals this handle may use (NULL/0 = current device). */
 int gphip_create(const void* X, const void* y, int64_t N, int64_t d, int kernel_id, int mean_id,
                  int dtype, const int* devices, int ndev, gphip_handle* out);
@@ -103,8 +105,9 @@ int gphip_set_streams(gphip_handle h, void* main_stream, void* panel_stream); /*
 int gphip_dist_num_panels(gphip_handle h, int* nouter);
 int gphip_dist_panel_shape(gphip_handle h, int k, int64_t* rows, int64_t* cols);
 int gphip_dist_begin(gphip_handle h, const double* theta, int p, int rank, int world);
-int gphip_dist_factor_panel(gphip_handle h, int k, double* packed_dev);
-int gphip_dist_update(gphip_handle h, int k, const double* packed_dev, int j_first, int j_last,
+/* packed_dev: device buffer of rows*cols elements of the handle's dtype (see gphip_dist_panel_shape) */
+int gphip_dist_factor_panel(gphip_handle h, int k, void* packed_dev);
+int gphip_dist_update(gphip_handle h, int k, const void* packed_dev, int j_first, int j_last,
                       int on_panel_stream);
 int gphip_dist_end(gphip_handle h, double* logdet_partial, double* quad, int* info);
 

@@ -80,3 +80,18 @@ def test_rccl_world_size_one():
         h.close()
     finally:
         dist.destroy_process_group()
+
+
+def test_virtual_ranks_fp32():
+    n = 1800
+    X, y = syn.make_dataset(n, 4)
+    th = syn.default_theta("matern52_ard", 4, dtype="f32")
+    want = orc.log_likelihood("matern52_ard", th, X, y)
+    hs = {}
+    for r in range(3):
+        hs[r] = _lib.Handle(X, y, "matern52_ard", dtype=32)
+        hs[r].set_option("panel", 2)
+    ll, ld, qd, info = DistributedCholesky(hs, LoopbackComm(3)).loglik(th)
+    assert info == 0 and abs(ll - want) <= 1e-3 * max(abs(want), n)
+    for h in hs.values():
+        h.close()

@@ -204,3 +204,34 @@ def test_full_size_properties_n32768():
     Krows[np.arange(len(idx)), idx] += sn * sn
     np.testing.assert_allclose(Krows @ alpha, y[idx], rtol=1e-7, atol=1e-7)
     h.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# fp32 device arithmetic (BASELINE.json config 5: Matern-5/2, fp32).  Tolerances are stated per test:
+# fp32 results are compared with the fp64 oracle at 1e-3 relative.
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("kernel,d,n", [("matern52_ard", 16, 1500), ("se_ard", 8, 1000), ("matern52", 2, 333)])
+def test_fp32_path_against_fp64_oracle(kernel, d, n):
+    X, y = syn.make_dataset(n, d)
+    th = syn.default_theta(kernel, d, dtype="f32")                 # sigma_n = 0.3
+    h = _lib.Handle(X, y, kernel, dtype=32)
+    K = h.covariance(th)
+    np.testing.assert_allclose(K, orc.covariance_matrix(kernel, th, X), rtol=2e-5, atol=1e-6)
+    ll, ld, qd, info = h.loglik_parts(th)
+    want = orc.log_likelihood(kernel, th, X, y, parts=True)
+    assert info == 0
+    assert abs(ld - want[1]) <= 1e-3 * max(abs(want[1]), n)
+    assert abs(qd - want[2]) <= 1e-3 * max(abs(want[2]), n)
+    assert abs(ll - want[0]) <= 1e-3 * max(abs(want[0]), n)
+    out, info = h.loglik_batch(np.stack([th, th * 1.1]))
+    assert info.tolist() == [0, 0] and abs(out[0] - ll) <= 1e-4 * max(abs(ll), n)
+    assert h.fit(th) == 0
+    Xs = syn.make_test_points(300, d)
+    mu, var = h.predict(Xs)
+    mo, so = orc.predict_internal(kernel, th, X, y, Xs)
+    np.testing.assert_allclose(mu, mo, rtol=1e-3, atol=2e-3)
+    np.testing.assert_allclose(np.sqrt(var), so, rtol=2e-3)
+    alpha = h.solve(y)
+    np.testing.assert_allclose(alpha, np.linalg.solve(orc.covariance_matrix(kernel, th, X), y), rtol=5e-3,
+                               atol=5e-3 * np.abs(alpha).max())
+    h.close()
