@@ -60,3 +60,39 @@ def sharded_map(evaluate, items: np.ndarray, dist=None):
         out_v[ridx] = g[:len(ridx), 0]
         out_i[ridx] = g[:len(ridx), 1].astype(np.int64)
     return out_v, out_i
+
+
+def shard_slice(n_items: int, rank: int, world: int) -> slice:
+    """Contiguous shard (for test points: keeps each rank's chunk coalesced)."""
+    per = (n_items + world - 1) // world
+    return slice(min(rank * per, n_items), min((rank + 1) * per, n_items))
+
+
+def sharded_predict(predict, Xs: np.ndarray, dist=None):
+    """Test-point sharding of the prediction: every rank holds the full factor
+    (each rank calls gphip_fit itself -- replicas; or received L once), predicts its contiguous
+    shard of the test points with `predict(Xs_shard) -> (mean, var)` and the shards are concatenated
+    on every rank with one all_gather.  No collective inside the solve."""
+    Xs = np.atleast_2d(np.asarray(Xs, dtype=np.float64))
+    m = len(Xs)
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return predict(Xs)
+    import torch
+    rank, world = dist.get_rank(), dist.get_world_size()
+    sl = shard_slice(m, rank, world)
+    mean, var = predict(Xs[sl]) if sl.stop > sl.start else (np.zeros(0), np.zeros(0))
+    per = (m + world - 1) // world
+    buf = torch.zeros(per, 2, dtype=torch.float64)
+    buf[:len(mean), 0] = torch.as_tensor(np.asarray(mean, dtype=np.float64))
+    buf[:len(mean), 1] = torch.as_tensor(np.asarray(var, dtype=np.float64))
+    if dist.get_backend() == "nccl":
+        buf = buf.cuda()
+    gathered = [torch.zeros_like(buf) for _ in range(world)]
+    dist.all_gather(gathered, buf)
+    out_m, out_v = np.zeros(m), np.zeros(m)
+    for r in range(world):
+        rs = shard_slice(m, r, world)
+        g = gathered[r].cpu().numpy()
+        out_m[rs] = g[:rs.stop - rs.start, 0]
+        out_v[rs] = g[:rs.stop - rs.start, 1]
+    return out_m, out_v

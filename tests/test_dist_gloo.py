@@ -29,7 +29,17 @@ def _worker(rank, world, port, q):
         return np.array([o[0] for o in out]), np.array([o[3] for o in out])
 
     vals, info = D.sharded_map(evaluate, thetas, dist)
-    q.put((rank, vals, info, sum(calls)))
+    # test-point sharding of the prediction: 11 points over 2 ranks
+    Xs = syn.make_test_points(11, 2)
+    npred = []
+
+    def predict(P):
+        npred.append(len(P))
+        mu, sd = orc.predict_internal("se_ard", thetas[0], X, y, P)
+        return mu, sd ** 2
+
+    pm, pv = D.sharded_predict(predict, Xs, dist)
+    q.put((rank, vals, info, sum(calls), pm, pv, sum(npred)))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -56,3 +66,8 @@ def test_theta_sharded_sweep_world2():
         np.testing.assert_array_equal(by_rank[r][1], want)          # identical merged result on every rank
         assert not by_rank[r][2].any()
     assert by_rank[0][3] == 4 and by_rank[1][3] == 3                 # 7 units dealt 4 + 3, no overlap
+    mu, sd = orc.predict_internal("se_ard", thetas[0], X, y, syn.make_test_points(11, 2))
+    for r in (0, 1):
+        np.testing.assert_allclose(by_rank[r][4], mu, rtol=1e-8, atol=1e-11)   # LAPACK rounding differs with nrhs
+        np.testing.assert_allclose(by_rank[r][5], sd ** 2, rtol=1e-8)
+    assert by_rank[0][6] == 6 and by_rank[1][6] == 5                 # 11 test points dealt 6 + 5
