@@ -73,7 +73,7 @@ def cpu_baseline(n_full: int, d: int, sample_n: int = 4096, reps: int = 2) -> di
                       f"(N/{sample_n})^3={scale:.0f} to N={n_full}"}
 
 
-def pmc_traffic(kernel_substr: str = "gemm_nt_kernel<0>"):
+def pmc_traffic(kernel_substr: str = "gemm_nt_kernel<double, 0>"):
     """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
     (profiles/*_pmc_summary.csv: separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same command,
     FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM).  None if no summary is present."""
@@ -84,11 +84,12 @@ def pmc_traffic(kernel_substr: str = "gemm_nt_kernel<0>"):
         with open(path) as f:
             for line in f:
                 parts = line.strip().split(",")
-                if len(parts) == 5 and kernel_substr in parts[0]:
-                    if parts[1] == "FETCH_SIZE":
-                        fetch = float(parts[3])
-                    elif parts[1] == "WRITE_SIZE":
-                        write = float(parts[3])
+                # kernel names contain a comma ("<double, 0>"): take the fields from the right
+                if len(parts) >= 5 and kernel_substr in ",".join(parts[:-4]):
+                    if parts[-4] == "FETCH_SIZE":
+                        fetch = float(parts[-2])
+                    elif parts[-4] == "WRITE_SIZE":
+                        write = float(parts[-2])
         if fetch is not None and write is not None:
             best = {"bytes_per_launch": (2.0 * fetch + write) * 1024.0, "source": os.path.basename(path)}
     return best
@@ -194,7 +195,7 @@ def main() -> None:
                        "N": n, "d": d, "kernel": "se_ard", "parallelism": (f"1-D block-cyclic Cholesky over {world} GPUs (RCCL panel broadcast)" if sharded
                                        else f"theta-sharded x{world}")},
             "cholesky_tflops_per_gpu": chol_flops * args.steps / dt / 1e12 / (world if sharded else 1),
-            "roofline": {"bound": "mfma", "kernel": "gemm_nt_kernel (trailing SYRK, v_mfma_f64_16x16x4_f64)",
+            "roofline": {"bound": "mfma", "kernel": "gemm_nt_kernel<double, 0> (trailing SYRK, v_mfma_f64_16x16x4_f64)",
                          "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
                          "launches": int(syrk["launches"]), "avg_launch_ms": syrk["ms"] / max(syrk["launches"], 1),
