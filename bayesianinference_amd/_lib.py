@@ -45,6 +45,7 @@ _SIGNATURES = {
     "gphip_loglik_parts": (C.c_int, [_h, _dp, C.c_int, _dp, _dp, _ip]),
     "gphip_fit": (C.c_int, [_h, _dp, C.c_int, _ip]),
     "gphip_predict": (C.c_int, [_h, C.c_void_p, C.c_int64, _dp, _dp]),
+    "gphip_predict_samples": (C.c_int, [_h, _dp, C.c_int, C.c_int, C.c_void_p, C.c_int64, _dp, _dp, _ip]),
     "gphip_covariance": (C.c_int, [_h, _dp, C.c_int, _dp]),
     "gphip_solve": (C.c_int, [_h, _dp, C.c_int64, _dp]),
     "gphip_logdet": (C.c_int, [_h, _dp]),
@@ -194,6 +195,19 @@ class Handle:
         mean, var = np.zeros(M), np.zeros(M)
         self._check(self._lib.gphip_predict(self._h, Xs.ctypes.data, M, _d(mean), _d(var)))
         return mean, var
+
+    def predict_samples(self, Thetas, Xs):
+        """All posterior samples in one batched pass: (mean[S,M], var[S,M], info[S])."""
+        Th = np.ascontiguousarray(np.atleast_2d(np.asarray(Thetas, dtype=np.float64)))
+        Xs = np.ascontiguousarray(np.atleast_2d(np.asarray(Xs, dtype=np.float64)))
+        if Xs.shape[1] != self.d:
+            raise GphipError(2, "test points have the wrong dimension")
+        S, M = Th.shape[0], Xs.shape[0]
+        mean, var = np.zeros((S, M)), np.zeros((S, M))
+        info = np.zeros(S, dtype=np.int32)
+        self._check(self._lib.gphip_predict_samples(self._h, _d(Th), S, Th.shape[1], Xs.ctypes.data, M,
+                                                    _d(mean), _d(var), info.ctypes.data_as(_ip)))
+        return mean, var, info
 
     def covariance(self, theta):
         th = np.ascontiguousarray(np.asarray(theta, dtype=np.float64).ravel())

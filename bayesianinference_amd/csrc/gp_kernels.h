@@ -693,22 +693,28 @@ __global__ void finalize_kernel(const T* __restrict__ Abase, long ld, long bstri
     }
 }
 
-// V: column-major [mpad x npad] (ld = mpad), V(t, j) = (L^-1 k*_t)_j.  z: row npad of the factor.
-// mean[t] = mu + sum_j V(t,j) z_j ; var[t] = kappa - sum_j V(t,j)^2   (fp64 accumulation)
+// V: column-major [mpad x npad] (ld = mpad) per slot, V(t, j) = (L^-1 k*_t)_j.  z: row npad of the
+// slot's factor.  mean[t] = mu + sum_j V(t,j) z_j ; var[t] = kappa - sum_j V(t,j)^2, with mu and
+// kappa = sf^2 + sn^2 of the slot's theta (fp64 accumulation).  grid.y = slot.
 template <typename T>
-__global__ void predict_reduce_kernel(const T* __restrict__ V, long ldv, int n, const T* __restrict__ zrow,
-                                      long ldz, double mu, double kappa, int m, double* __restrict__ mean,
-                                      double* __restrict__ var) {
+__global__ void predict_reduce_kernel(const T* __restrict__ V, long ldv, long v_bstride, int n,
+                                      const T* __restrict__ zrow, long ldz, long z_bstride,
+                                      const double* __restrict__ slotp, int m, long out_bstride,
+                                      double* __restrict__ mean, double* __restrict__ var) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int slot = blockIdx.y;
     if (t >= m) return;
+    V += (long)slot * v_bstride;
+    zrow += (long)slot * z_bstride;
+    const double* sp = slotp + (long)slot * SLOTP;
     double dot = 0.0, nrm = 0.0;
     for (int j = 0; j < n; ++j) {
         const double v = (double)V[(long)j * ldv + t];
         dot = __builtin_fma(v, (double)zrow[(long)j * ldz], dot);
         nrm = __builtin_fma(v, v, nrm);
     }
-    mean[t] = mu + dot;
-    var[t] = kappa - nrm;
+    mean[(long)slot * out_bstride + t] = sp[2] + dot;
+    var[(long)slot * out_bstride + t] = sp[0] + sp[1] - nrm;
 }
 
 }  // namespace gphip

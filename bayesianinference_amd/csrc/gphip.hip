@@ -533,16 +533,16 @@ int ensure_vbuf(gphip_ctx* h, int64_t cap) {
 // V <- V L^-T for the mpad x Npad row block in dV (right-looking over the 128-tile columns of L):
 // every row of V becomes (L^-1 v)^T.  Panel solves and updates are the same MFMA GEMM kernel.
 template <typename T>
-int queue_forward_rows(gphip_ctx* h, int64_t mpad) {
+int queue_forward_rows(gphip_ctx* h, int64_t mpad, int nslots) {
     const int Nt = (int)h->Nt, Mt = (int)(mpad / TB);
-    const long ld = h->ld;
+    const long ld = h->ld, vs = (long)mpad * h->Npad, bs = ld * ld, lrs = (long)Nt * TB * TB;
     T *V = (T*)h->dV, *A = (T*)h->dA, *W = (T*)h->dW;
     for (int b = 0; b < Nt; ++b) {
-        launch_gemm<T>(h, 2, V, mpad, 0, V + (long)b * TB * mpad, mpad, 0, W + (long)b * TB * TB - (long)b * TB, TB, 0,
-                       TB, 0, Mt, b, b + 1, 0, 1, 1);
+        launch_gemm<T>(h, 2, V, mpad, vs, V + (long)b * TB * mpad, mpad, vs, W + (long)b * TB * TB - (long)b * TB, TB,
+                       lrs, TB, 0, Mt, b, b + 1, 0, nslots, 1);
         if (b + 1 < Nt)
-            launch_gemm<T>(h, 3, V, mpad, 0, V + (long)b * TB * mpad, mpad, 0, A + (long)b * TB * ld, ld, 0, TB, 0, Mt,
-                           b + 1, Nt, 0, 1);
+            launch_gemm<T>(h, 3, V, mpad, vs, V + (long)b * TB * mpad, mpad, vs, A + (long)b * TB * ld, ld, bs, TB, 0,
+                           Mt, b + 1, Nt, 0, nslots);
     }
     return 0;
 }
@@ -563,25 +563,27 @@ int queue_backward_rows(gphip_ctx* h, int64_t mpad) {
     return 0;
 }
 
+// V(t, j) = k_theta_s(x*_t, x_j) for every slot s: the (unscaled) test points in dXsT are scaled by
+// each slot's 1/l into dXsS[slot]
 template <typename T>
-int queue_cross(gphip_ctx* h, int64_t mc, int64_t mpad) {      // V(t, j) = k(x*_t, x_j), scaled test points in dXsS
+int queue_cross(gphip_ctx* h, int64_t mc, int64_t mpad, int nslots) {
     const long tot = (long)h->d * mpad;
-    hipLaunchKernelGGL(k_scale<T>, dim3((unsigned)((tot + 255) / 256), 1), dim3(256), 0, h->stream, (const T*)h->dXsT,
-                       (T*)h->dXsS, h->dInvEll, (int)h->d, (int)mpad);
+    hipLaunchKernelGGL(k_scale<T>, dim3((unsigned)((tot + 255) / 256), nslots), dim3(256), 0, h->stream,
+                       (const T*)h->dXsT, (T*)h->dXsS, h->dInvEll, (int)h->d, (int)mpad);
     KBuildArgs<T> a{};
-    a.out = (T*)h->dV; a.ld = mpad; a.bstride = 0;
-    a.xi = (const T*)h->dXsS; a.xj = (const T*)h->dXs; a.xi_bstride = a.xj_bstride = 0;
+    a.out = (T*)h->dV; a.ld = mpad; a.bstride = (long)mpad * h->Npad;
+    a.xi = (const T*)h->dXsS; a.xj = (const T*)h->dXs; a.xi_bstride = tot; a.xj_bstride = (long)h->d * h->Npad;
     a.npad_i = (int)mpad; a.npad_j = (int)h->Npad; a.n_i = (int)mc; a.n_j = (int)h->N;
     a.y = nullptr; a.slotp = h->dSlotp; a.d = (int)h->d; a.mode = 1; a.nt_i = (int)(mpad / TB); a.nt_j = (int)h->Nt;
-    launch_kbuild<T>(h, a, dim3((unsigned)((mpad / TB) * h->Nt), 1));
+    launch_kbuild<T>(h, a, dim3((unsigned)((mpad / TB) * h->Nt), nslots));
     return 0;
 }
 
 template <typename T>
-int queue_predict_reduce(gphip_ctx* h, int64_t mc, int64_t mpad) {
-    hipLaunchKernelGGL(predict_reduce_kernel<T>, dim3((unsigned)((mc + 63) / 64)), dim3(64), 0, h->stream,
-                       (const T*)h->dV, (long)mpad, (int)h->N, (const T*)h->dA + h->Npad, (long)h->ld, h->mu_fit,
-                       h->kappa_fit, (int)mc, h->dMean, h->dVar);
+int queue_predict_reduce(gphip_ctx* h, int64_t mc, int64_t mpad, int nslots) {
+    hipLaunchKernelGGL(predict_reduce_kernel<T>, dim3((unsigned)((mc + 63) / 64), nslots), dim3(64), 0, h->stream,
+                       (const T*)h->dV, (long)mpad, (long)mpad * h->Npad, (int)h->N, (const T*)h->dA + h->Npad,
+                       (long)h->ld, (long)h->ld * h->ld, h->dSlotp, (int)mc, (long)mpad, h->dMean, h->dVar);
     return 0;
 }
 
@@ -778,14 +780,72 @@ int gphip_predict(gphip_handle h, const void* Xs, int64_t M, double* mean, doubl
             for (int64_t j = 0; j < d; ++j) xt[(size_t)j * mpad + i] = X[(m0 + i) * d + j];
         rc = DISPATCH(h, upload, h, h->dXsT, xt, h->stream);
         if (rc) return rc;
-        DISPATCH(h, queue_cross, h, mc, mpad);
-        DISPATCH(h, queue_forward_rows, h, mpad);
-        DISPATCH(h, queue_predict_reduce, h, mc, mpad);
+        DISPATCH(h, queue_cross, h, mc, mpad, 1);
+        DISPATCH(h, queue_forward_rows, h, mpad, 1);
+        DISPATCH(h, queue_predict_reduce, h, mc, mpad, 1);
         HIPCHK(hipMemcpyAsync(mean + m0, h->dMean, (size_t)mc * 8, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipMemcpyAsync(var + m0, h->dVar, (size_t)mc * 8, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
         HIPCHK(hipGetLastError());
         harvest(h);
+    }
+    return GPHIP_OK;
+}
+
+// Batched mixture prediction (BGP:343-376): every posterior sample theta_s gets
+// its own slot -- K(theta_s) built and factored for all samples of a chunk in ONE batched pass, then
+// k*, the forward solve and the reductions run for all slots at once.  mean/var: row-major S x M.
+int gphip_predict_samples(gphip_handle h, const double* Thetas, int S, int p, const void* Xs, int64_t M,
+                          double* mean, double* var, int* info) {
+    if (!h || !Thetas || !Xs || !mean || !var || !info) return fail(h, GPHIP_ERR_ARG, "null argument");
+    if (p != h->p) return fail(h, GPHIP_ERR_DIM, "theta has the wrong length");
+    if (S < 1 || M < 1) return fail(h, GPHIP_ERR_DIM, "S < 1 or M < 1");
+    if (h->kernel_id == GPHIP_KERNEL_NULL) return fail(h, GPHIP_ERR_UNSUPPORTED, "null kernel has no factor");
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIPCHK(hipSetDevice(h->device));
+    int rc = ensure_slots(h, S);
+    if (rc) return rc;
+    h->fitted = false;
+    const double* X = static_cast<const double*>(Xs);
+    const int64_t d = h->d;
+    std::vector<double> xt, hm, hv, scratch_out(1), scratch_parts;
+    for (int s0 = 0; s0 < S; s0 += h->slots) {
+        const int nb = (S - s0 < h->slots) ? (S - s0) : h->slots;
+        std::vector<double> ll(nb);
+        rc = eval_chunk(h, Thetas + (size_t)s0 * p, nb, ll.data(), nullptr, info + s0);   // build + factor, kept
+        if (rc) return rc;
+        // test-point chunk so that the nb V blocks stay within ~8 GiB
+        int64_t mcap = (int64_t)((8.0 * (1 << 30)) / ((double)nb * h->Npad * h->es)) / TB * TB;
+        if (mcap < TB) mcap = TB;
+        if (mcap > 2048) mcap = 2048;
+        const int64_t MC = (M < mcap) ? (M + TB - 1) / TB * TB : mcap;
+        rc = ensure_vbuf(h, (int64_t)nb * MC);
+        if (rc) return rc;
+        h->cs = h->stream;
+        for (int64_t m0 = 0; m0 < M; m0 += MC) {
+            const int64_t mc = (M - m0 < MC) ? (M - m0) : MC;
+            const int64_t mpad = (mc + TB - 1) / TB * TB;
+            xt.assign((size_t)d * mpad, 0.0);
+            for (int64_t i = 0; i < mc; ++i)
+                for (int64_t j = 0; j < d; ++j) xt[(size_t)j * mpad + i] = X[(m0 + i) * d + j];
+            rc = DISPATCH(h, upload, h, h->dXsT, xt, h->stream);
+            if (rc) return rc;
+            DISPATCH(h, queue_cross, h, mc, mpad, nb);
+            DISPATCH(h, queue_forward_rows, h, mpad, nb);
+            DISPATCH(h, queue_predict_reduce, h, mc, mpad, nb);
+            hm.resize((size_t)nb * mpad);
+            hv.resize((size_t)nb * mpad);
+            HIPCHK(hipMemcpyAsync(hm.data(), h->dMean, hm.size() * 8, hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(hipMemcpyAsync(hv.data(), h->dVar, hv.size() * 8, hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(hipStreamSynchronize(h->stream));
+            HIPCHK(hipGetLastError());
+            harvest(h);
+            for (int s = 0; s < nb; ++s)
+                for (int64_t t = 0; t < mc; ++t) {
+                    mean[(size_t)(s0 + s) * M + m0 + t] = hm[(size_t)s * mpad + t];
+                    var[(size_t)(s0 + s) * M + m0 + t] = hv[(size_t)s * mpad + t];
+                }
+        }
     }
     return GPHIP_OK;
 }
@@ -811,7 +871,7 @@ int gphip_solve(gphip_handle h, const double* rhs, int64_t nrhs, double* out) {
             for (int64_t j = 0; j < N; ++j) v[(size_t)j * mpad + t] = rhs[(m0 + t) * N + j];
         rc = DISPATCH(h, upload, h, h->dV, v, h->stream);
         if (rc) return rc;
-        DISPATCH(h, queue_forward_rows, h, mpad);
+        DISPATCH(h, queue_forward_rows, h, mpad, 1);
         DISPATCH(h, queue_backward_rows, h, mpad);
         rc = DISPATCH(h, download, h, v, h->dV, (size_t)mpad * Npad, h->stream);
         if (rc) return rc;

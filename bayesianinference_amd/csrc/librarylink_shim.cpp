@@ -10,6 +10,7 @@
 // are created with MTensor_new and handed over with MArgument_setMTensor; "K is not positive
 // definite" is reported through the RESULT ({value, info}), never through the return code, so the
 // WL closure stays numeric for every theta (BayesianStatistics.wl:276-298).
+#include <limits>
 #include <vector>
 
 #include "WolframLibrary.h"
@@ -117,6 +118,30 @@ EXTERN_C DLLEXPORT int gphip_wl_predict(WolframLibraryData lib, mint argc, MArgu
     double* p = lib->MTensor_getRealData(r);
     int rc = gphip_predict(h, lib->MTensor_getRealData(xs), M, p, p + M);
     if (rc != GPHIP_OK) { lib->MTensor_free(r); return status_to_wl(rc); }
+    MArgument_setMTensor(res, r);
+    return LIBRARY_NO_ERROR;
+}
+
+// gphip_wl_predict_samples[h, Thetas (S x p), Xs (M x d)] -> 2 x S x M {means, variances};
+// a sample whose K is not positive definite comes back as NaN rows (result value, not an error)
+EXTERN_C DLLEXPORT int gphip_wl_predict_samples(WolframLibraryData lib, mint argc, MArgument* args, MArgument res) {
+    if (argc != 3) return LIBRARY_FUNCTION_ERROR;
+    gphip_handle h = lookup(MArgument_getInteger(args[0]));
+    MTensor th = MArgument_getMTensor(args[1]), xs = MArgument_getMTensor(args[2]);
+    if (!h || lib->MTensor_getRank(th) != 2 || lib->MTensor_getRank(xs) != 2) return LIBRARY_RANK_ERROR;
+    const mint S = lib->MTensor_getDimensions(th)[0], p = lib->MTensor_getDimensions(th)[1];
+    const mint M = lib->MTensor_getDimensions(xs)[0];
+    MTensor r; mint d[3] = {2, S, M};
+    if (lib->MTensor_new(MType_Real, 3, d, &r)) return LIBRARY_FUNCTION_ERROR;
+    double* out = lib->MTensor_getRealData(r);
+    std::vector<int> info((size_t)S);
+    int rc = gphip_predict_samples(h, lib->MTensor_getRealData(th), (int)S, (int)p, lib->MTensor_getRealData(xs), M,
+                                   out, out + S * M, info.data());
+    if (rc != GPHIP_OK) { lib->MTensor_free(r); return status_to_wl(rc); }
+    const double nan = std::numeric_limits<double>::quiet_NaN();
+    for (mint s = 0; s < S; ++s)
+        if (info[(size_t)s] != 0)
+            for (mint t = 0; t < M; ++t) out[s * M + t] = out[S * M + s * M + t] = nan;
     MArgument_setMTensor(res, r);
     return LIBRARY_NO_ERROR;
 }

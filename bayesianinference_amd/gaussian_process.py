@@ -311,17 +311,13 @@ def predictFromGaussianProcess(obj_or_examples, pts, kernel=None, theta=None, me
 
 
 def _predict_samples(handle, points, weights, P):
-    mus, sds = [], []
-    for th in points:
-        if handle.fit(th) != 0:                                   # singular K for this sample
-            mus.append(np.full(len(P), np.nan))
-            sds.append(np.full(len(P), np.nan))
-            continue
-        mu, var = handle.predict(P)
-        mus.append(mu)
-        with np.errstate(invalid="ignore"):
-            sds.append(np.sqrt(var))                              # Sqrt, BGP:414
-    return {"Points": P, "Weights": weights, "Mean": np.array(mus), "StandardDeviation": np.array(sds)}
+    """One batched pass over all samples (gphip_predict_samples); singular samples -> NaN rows."""
+    mean, var, info = handle.predict_samples(points, P)
+    bad = info != 0
+    mean[bad], var[bad] = np.nan, np.nan
+    with np.errstate(invalid="ignore"):
+        sd = np.sqrt(var)                                          # Sqrt, BGP:414
+    return {"Points": P, "Weights": weights, "Mean": mean, "StandardDeviation": sd}
 
 
 def mixture_moments(pred: Mapping):

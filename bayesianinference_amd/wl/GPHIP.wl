@@ -29,6 +29,8 @@ gpFit     := gpFit     = LibraryFunctionLoad[$GPHIPLibrary, "gphip_wl_fit",
 	{Integer, {Real, 1, "Constant"}}, Integer];
 gpPredict := gpPredict = LibraryFunctionLoad[$GPHIPLibrary, "gphip_wl_predict",
 	{Integer, {Real, 2, "Constant"}}, {Real, 2}];        (* {means, variances} *)
+gpPredictS := gpPredictS = LibraryFunctionLoad[$GPHIPLibrary, "gphip_wl_predict_samples",
+	{Integer, {Real, 2, "Constant"}, {Real, 2, "Constant"}}, {Real, 3}];   (* {means, variances}, each S x M *)
 gpCov     := gpCov     = LibraryFunctionLoad[$GPHIPLibrary, "gphip_wl_covariance",
 	{Integer, {Real, 1, "Constant"}}, {Real, 2}];
 gpDestroy := gpDestroy = LibraryFunctionLoad[$GPHIPLibrary, "gphip_wl_destroy", {Integer}, Integer];
@@ -85,16 +87,12 @@ predictFromGaussianProcess[
 	weights = Values @ result[["Samples", All, "CrudePosteriorWeight"]],
 	perSample
 },
-	perSample = Map[
-		Function[theta,
-			If[ gpFit[h, N @ theta] === 0,
-				With[{mv = gpPredict[h, N @ points]},
-					MapThread[NormalDistribution, {mv[[1]], Sqrt[mv[[2]]]}]
-				],
-				ConstantArray[Missing["Singular"], Length[points]]
-			]
-		],
-		Values @ result[["Samples", All, "Point"]]
+	(* one batched call: every posterior sample is factored and solved in its own workspace slot *)
+	perSample = With[{mv = gpPredictS[h, N @ Values @ result[["Samples", All, "Point"]], N @ points]},
+		MapThread[
+			Function[{mus, vars}, MapThread[NormalDistribution, {mus, Sqrt[vars]}]],
+			{mv[[1]], mv[[2]]}
+		]
 	];
 	AssociationThread[points, MixtureDistribution[weights, #]& /@ Transpose[perSample]]
 ];

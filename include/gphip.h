@@ -9,6 +9,7 @@
  *   gphip_loglik_batch  the same closure mapped over a theta matrix        BS:276-298, BS:902-916
  *   gphip_fit           matrixInverseAndDet[covarianceFunction[theta]]     BGP:308 (invCovFun)
  *   gphip_predict       predictFromGaussianProcessInternal                 BGP:396-422
+ *   gphip_predict_samples  predictFromGaussianProcess over all samples     BGP:343-376
  *   gphip_covariance    "CovarianceFunction" = compiledCovarianceMatrix    BGP:45-61
  *   gphip_solve         "InverseCovarianceFunction"[theta]["Inverse"][b]   BGP:130-141
  *   gphip_logdet        "InverseCovarianceFunction"[theta]["LogDet"]       BGP:126-128,139
@@ -79,6 +80,11 @@ int gphip_fit(gphip_handle h, const double* theta, int p, int* info);
 /* Xs: row-major M x d fp64.  mean[j] = m(x*_j) + k*_j^T K^-1 r ; var[j] = k(x*,x*) + sn^2 -
  * k*_j^T K^-1 k*_j  (variance of a noisy observation, BGP:113,414-417; sd = sqrt(var)). */
 int gphip_predict(gphip_handle h, const void* Xs, int64_t M, double* mean, double* var);
+/* predictFromGaussianProcess over posterior samples (BGP:343-376): Thetas row-major S x p; mean, var
+ * row-major S x M; info[S] (a sample with info != 0 has undefined mean/var).  All samples of a chunk
+ * are factored and solved in one batched pass (one workspace slot per sample). */
+int gphip_predict_samples(gphip_handle h, const double* Thetas, int S, int p, const void* Xs, int64_t M,
+                          double* mean, double* var, int* info);
 /* K: row-major N x N fp64 (full, both triangles), for parity tests at small N. */
 int gphip_covariance(gphip_handle h, const double* theta, int p, double* K);
 /* rhs, out: column-major N x nrhs (each right-hand side contiguous); out = K^-1 rhs. */

@@ -235,3 +235,26 @@ def test_fp32_path_against_fp64_oracle(kernel, d, n):
     np.testing.assert_allclose(alpha, np.linalg.solve(orc.covariance_matrix(kernel, th, X), y), rtol=5e-3,
                                atol=5e-3 * np.abs(alpha).max())
     h.close()
+
+
+def test_predict_samples_batched_equals_per_sample():
+    X, y = syn.make_dataset(700, 3)
+    Xs = syn.make_test_points(150, 3)
+    thetas = syn.theta_batch(9, "matern52_ard", 3)
+    thetas[:, -1] = np.maximum(thetas[:, -1], 0.05)
+    thetas[4, 0] = 0.0                                   # unusable sample -> info != 0, others unaffected
+    h = _lib.Handle(X, y, "matern52_ard")
+    mean, var, info = h.predict_samples(thetas, Xs)
+    assert info[4] != 0 and np.all(np.delete(info, 4) == 0)
+    for s in (0, 3, 8):
+        mo, so = orc.predict_internal("matern52_ard", thetas[s], X, y, Xs)
+        np.testing.assert_allclose(mean[s], mo, rtol=1e-7, atol=1e-9)
+        np.testing.assert_allclose(np.sqrt(var[s]), so, rtol=1e-7)
+        assert h.fit(thetas[s]) == 0
+        m1, v1 = h.predict(Xs)
+        np.testing.assert_allclose(mean[s], m1, rtol=1e-12, atol=1e-13)
+    h.set_option("max_slots", 4)                         # force chunking over samples
+    mean2, var2, info2 = h.predict_samples(thetas, Xs)
+    keep = info == 0
+    np.testing.assert_allclose(mean2[keep], mean[keep], rtol=1e-12, atol=1e-13)
+    h.close()
