@@ -116,6 +116,52 @@ def dataNormalForm(data):
     return None
 
 
+def normalizeData(data_in, data_out=None):
+    """BU:232-265: per-column standardisation (FeatureExtraction[.., "StandardizedVector"]: subtract the
+    mean, divide by the sample standard deviation).  normalizeData(X) -> {"NormalizedData", "Function",
+    "InverseFunction"}; normalizeData(X, Y) -> {"Input": {..}, "Output": {..}} (BU:239-242)."""
+    if data_out is not None:
+        return {"Input": normalizeData(data_in), "Output": normalizeData(data_out)}
+    arr = dataNormalForm(data_in)
+    if arr is None or isinstance(arr, tuple):
+        return None
+    mean = arr.mean(axis=0)
+    sd = arr.std(axis=0, ddof=1) if len(arr) > 1 else np.ones(arr.shape[1])
+    sd = np.where(sd > 0, sd, 1.0)
+
+    def forward(x):
+        return (dataNormalForm(x) - mean) / sd
+
+    def inverse(z):
+        return dataNormalForm(z) * sd + mean
+
+    return {"NormalizedData": forward(arr), "Function": forward, "InverseFunction": inverse,
+            "Mean": mean, "StandardDeviation": sd}
+
+
+def normalizedDataQ(data) -> bool:
+    """BU:267-286."""
+    def test(a):
+        return isinstance(a, Mapping) and {"NormalizedData", "Function", "InverseFunction"} <= set(a)
+    return test(data) or (isinstance(data, Mapping) and set(data) == {"Input", "Output"}
+                          and all(test(v) for v in data.values()))
+
+
+def takePosteriorFraction(obj, frac: float):
+    """BU:288-316: keep the heaviest samples until their cumulative CrudePosteriorWeight exceeds `frac`
+    (frac = 1: all samples, sorted by decreasing weight)."""
+    samples = sorted(obj["Samples"], key=lambda smp: -smp["CrudeLogPosteriorWeight"])
+    if frac < 1:
+        kept, count = [], 0.0
+        for smp in samples:
+            if count > frac:
+                break
+            kept.append(smp)
+            count += smp["CrudePosteriorWeight"]
+        samples = kept
+    return inferenceObject(obj).append({"Samples": samples})
+
+
 def _resolve_kernel(kernel):
     if kernel is None:
         return "null"
@@ -187,6 +233,10 @@ def defineGaussianProcess(data, kernel, nugget="Constant", meanFunction=None, va
     distributions / "Uniform"; extra rules are forwarded into the object (`rest___Rule`, BGP:233,323)
     -- e.g. Device=0.  A caller-supplied LogLikelihoodFunction=callable is installed verbatim
     (BGP:293-294).  Returns inferenceObject(None) where the reference returns inferenceObject[$Failed]."""
+    if normalizedDataQ(data) and isinstance(data, Mapping) and "Input" in data:      # BGP:214-218
+        rules.setdefault("DataPreProcessors", {k: {"Function": v["Function"], "InverseFunction": v["InverseFunction"]}
+                                               for k, v in data.items()})
+        data = (data["Input"]["NormalizedData"], data["Output"]["NormalizedData"])
     norm = dataNormalForm(data)
     if norm is None or not isinstance(norm, tuple):
         return inferenceObject(None)                              # BGP:204-207 dataFormat
@@ -226,6 +276,7 @@ def defineGaussianProcess(data, kernel, nugget="Constant", meanFunction=None, va
         "Data": (X, Y),
         "PriorDistribution": variablePrior,
         "Parameters": params,
+        "KernelName": kname, "MeanName": mean,
         "GaussianProcessData": {
             "ModelFunctions": {
                 "KernelFunction": (kname, WL_KERNEL_EXPRESSIONS[kname]),
@@ -327,3 +378,43 @@ def mixture_moments(pred: Mapping):
     mu, sd = pred["Mean"], pred["StandardDeviation"]
     m = w @ mu
     return m, w @ (sd ** 2 + mu ** 2) - m ** 2
+
+
+# ---------------------------------------------------------------------------------------------
+# persistence: an inferenceObject is a plain Association the user may
+# Put/Export (BU:125); the device state (X, y resident; L, z after a fit) is rebuildable from it.
+# ---------------------------------------------------------------------------------------------
+def save_gaussian_process(obj, path: str, theta=None):
+    """Writes data, kernel/mean names, parameter specs, samples (if any) and an optional fitted theta."""
+    X, Y = obj["Data"]
+    payload = {"X": X, "Y": Y, "kernel": obj["KernelName"], "mean": obj["MeanName"],
+               "param_names": np.array([p[0] for p in obj["Parameters"]]),
+               "param_lo": np.array([p[1] for p in obj["Parameters"]], dtype=np.float64),
+               "param_hi": np.array([p[2] for p in obj["Parameters"]], dtype=np.float64)}
+    if "Samples" in obj:
+        payload["sample_points"] = np.array([smp["Point"] for smp in obj["Samples"]], dtype=np.float64)
+        payload["sample_logw"] = np.array([smp["CrudeLogPosteriorWeight"] for smp in obj["Samples"]])
+    if theta is not None:
+        payload["theta_fit"] = np.asarray(theta, dtype=np.float64)
+    np.savez_compressed(path, **payload)
+
+
+def load_gaussian_process(path: str, variablePrior="Uniform", **rules):
+    """Rebuilds the object (new device handle, data uploaded again); if a fitted theta was saved the
+    handle is re-fitted so predict/solve work immediately.  Returns (object, theta_fit or None)."""
+    z = np.load(path, allow_pickle=False)
+    params = [(str(n), float(a), float(b)) for n, a, b in zip(z["param_names"], z["param_lo"], z["param_hi"])]
+    kernel = None if str(z["kernel"]) == "null" else str(z["kernel"])
+    mean = "Constant" if str(z["mean"]) == "const" else None
+    obj = defineGaussianProcess((z["X"], z["Y"]), kernel, "Constant", mean, params, variablePrior, **rules)
+    if obj.failed:
+        return obj, None
+    extra = {}
+    if "sample_points" in z:
+        logw = z["sample_logw"]
+        extra["Samples"] = [{"Point": pt, "CrudeLogPosteriorWeight": float(lw), "CrudePosteriorWeight": float(np.exp(lw))}
+                            for pt, lw in zip(z["sample_points"], logw)]
+    theta = z["theta_fit"] if "theta_fit" in z else None
+    if theta is not None:
+        obj["GaussianProcessData"]["HIPHandle"].fit(theta)
+    return (obj.append(extra) if extra else obj), theta

@@ -66,3 +66,29 @@ def test_predict_from_gaussian_process_forms():
     assert res["Points"].shape == (2, 1)
     mo, so = orc.predict_internal("se", [0.3, 1.0, 0.1], X, y, res["Points"])
     np.testing.assert_allclose(res["Mean"][0], mo, rtol=1e-7, atol=1e-9)
+
+
+def test_normalized_data_and_persistence_roundtrip(tmp_path):
+    rng = np.random.default_rng(5)
+    X = rng.normal(10.0, 3.0, (120, 2))
+    y = np.sin(X[:, 0] / 3.0) + 0.05 * rng.standard_normal(120) + 4.0
+    nd = gp.normalizeData(X, y)
+    variables = [("l1", 0.1, 10.0), ("l2", 0.1, 10.0), ("sf", 0.1, 10.0), ("sn", 0.02, 1.0)]
+    obj = gp.defineGaussianProcess(nd, "SEARD", variables=variables)
+    assert not obj.failed and set(obj["DataPreProcessors"]) == {"Input", "Output"}       # BGP:214-218
+    th = np.array([1.0, 2.0, 1.0, 0.1])
+    want = orc.log_likelihood("se_ard", th, nd["Input"]["NormalizedData"], nd["Output"]["NormalizedData"][:, 0])
+    assert obj["LogLikelihoodFunction"](th) == pytest.approx(want, rel=1e-8)
+    samples = [{"Point": th, "CrudePosteriorWeight": 1.0, "CrudeLogPosteriorWeight": 0.0}]
+    path = str(tmp_path / "gp.npz")
+    gp.save_gaussian_process(obj.append({"Samples": samples}), path, theta=th)
+    obj2, th2 = gp.load_gaussian_process(path)
+    np.testing.assert_array_equal(th2, th)
+    pts = nd["Input"]["Function"](X[:7])
+    a = gp.predictFromGaussianProcess(obj.append({"Samples": samples}), pts)
+    b = gp.predictFromGaussianProcess(obj2, pts)
+    np.testing.assert_allclose(a["Mean"], b["Mean"], rtol=1e-12)
+    mu, var = obj2["GaussianProcessData"]["HIPHandle"].predict(pts)                      # re-fitted on load
+    np.testing.assert_allclose(mu, a["Mean"][0], rtol=1e-12)
+    back = nd["Output"]["InverseFunction"](mu)[:, 0]                                     # original units
+    assert np.sqrt(np.mean((back - y[:7]) ** 2)) < 0.3

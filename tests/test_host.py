@@ -78,3 +78,22 @@ def test_sharding_maps():
     assert list(D.local_block_columns(10, 2, 4)) == [2, 6]
     v, i = D.sharded_map(lambda th: (th.sum(axis=1), np.zeros(len(th), dtype=int)), np.ones((5, 3)))
     assert list(v) == [3.0] * 5 and not i.any()
+
+
+def test_normalize_data_and_posterior_fraction():
+    rng = np.random.default_rng(0)
+    X = rng.normal(3.0, 2.0, (50, 2))
+    Y = rng.normal(-1.0, 0.5, 50)
+    nd = gp.normalizeData(X, Y)
+    assert gp.normalizedDataQ(nd) and gp.normalizedDataQ(nd["Input"]) and not gp.normalizedDataQ({"a": 1})
+    Z = nd["Input"]["NormalizedData"]
+    np.testing.assert_allclose(Z.mean(axis=0), 0.0, atol=1e-12)
+    np.testing.assert_allclose(Z.std(axis=0, ddof=1), 1.0, rtol=1e-12)          # StandardizedVector
+    np.testing.assert_allclose(nd["Input"]["InverseFunction"](Z), X, rtol=1e-12)
+    np.testing.assert_allclose(nd["Output"]["Function"](Y)[:, 0], nd["Output"]["NormalizedData"][:, 0])
+    samples = [{"Point": [i], "CrudePosteriorWeight": w, "CrudeLogPosteriorWeight": math.log(w)}
+               for i, w in enumerate([0.1, 0.5, 0.15, 0.25])]
+    obj = gp.inferenceObject({"Samples": samples})
+    top = gp.takePosteriorFraction(obj, 0.7)["Samples"]                          # BU:298-316
+    assert [s["Point"][0] for s in top] == [1, 3]
+    assert [s["Point"][0] for s in gp.takePosteriorFraction(obj, 1)["Samples"]] == [1, 3, 2, 0]
