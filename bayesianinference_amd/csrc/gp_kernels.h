@@ -78,6 +78,7 @@ template <> struct Num<double> {
         return __hiloint2double(hi, lo);
     }
     static __device__ __forceinline__ double sqrt_(double x) { return __builtin_sqrt(x); }
+    static __device__ __forceinline__ double rsqrt_(double x) { return rsqrt(x); }
 };
 template <> struct Num<float> {
     typedef f4 acc_t;
@@ -91,6 +92,7 @@ template <> struct Num<float> {
         return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
     }
     static __device__ __forceinline__ float sqrt_(float x) { return __builtin_sqrtf(x); }
+    static __device__ __forceinline__ float rsqrt_(float x) { return rsqrtf(x); }
 };
 
 // KT = 0: squared exponential  sf2 * exp(-r2/2)
@@ -308,8 +310,8 @@ __global__ __launch_bounds__(256) void potrf128_kernel(T* __restrict__ Abase, lo
             for (int j = 0; j < 16; ++j) {
                 T dj = Num<T>::readlane(a[j], j);
                 if (!(dj > tol)) { bad = true; dj = (T)1; }
-                const T l = Num<T>::sqrt_(dj);
-                const T rs = (T)1 / l;
+                const T rs = Num<T>::rsqrt_(dj);       // one dependent transcendental per pivot, not sqrt + rcp
+                const T l = dj * rs;
                 a[j] = (l15 == j) ? l : a[j] * rs;
 #pragma unroll
                 for (int c = j + 1; c < 16; ++c) {

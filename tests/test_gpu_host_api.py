@@ -85,10 +85,10 @@ def test_normalized_data_and_persistence_roundtrip(tmp_path):
     obj2, th2 = gp.load_gaussian_process(path)
     np.testing.assert_array_equal(th2, th)
     pts = nd["Input"]["Function"](X[:7])
+    mu, var = obj2["GaussianProcessData"]["HIPHandle"].predict(pts)                      # re-fitted on load
     a = gp.predictFromGaussianProcess(obj.append({"Samples": samples}), pts)
     b = gp.predictFromGaussianProcess(obj2, pts)
     np.testing.assert_allclose(a["Mean"], b["Mean"], rtol=1e-12)
-    mu, var = obj2["GaussianProcessData"]["HIPHandle"].predict(pts)                      # re-fitted on load
     np.testing.assert_allclose(mu, a["Mean"][0], rtol=1e-12)
     back = nd["Output"]["InverseFunction"](mu)[:, 0]                                     # original units
     assert np.sqrt(np.mean((back - y[:7]) ** 2)) < 0.3

@@ -258,3 +258,83 @@ def test_predict_samples_batched_equals_per_sample():
     keep = info == 0
     np.testing.assert_allclose(mean2[keep], mean[keep], rtol=1e-12, atol=1e-13)
     h.close()
+
+
+def test_edge_shapes_and_chunking():
+    """Ragged / extreme shapes: M = 1 test point, more right-hand sides than one 2048-row chunk,
+    d = 32 (largest supported, generic-d kernel), batch larger than the slot cap, d > 32 rejected."""
+    X, y = syn.make_dataset(150, 32)
+    th = syn.default_theta("se_ard", 32)
+    th[:32] = 3.0
+    h = _lib.Handle(X, y, "se_ard")
+    ll, info = h.loglik(th)
+    assert info == 0 and close(ll, orc.log_likelihood("se_ard", th, X, y), 150)
+    assert h.fit(th) == 0
+    mu, var = h.predict(X[:1])
+    mo, so = orc.predict_internal("se_ard", th, X, y, X[:1])
+    assert mu.shape == (1,) and close(mu[0], mo[0], 1, 1e-7) and close(np.sqrt(var[0]), so[0], 1, 1e-7)
+    h.close()
+    with pytest.raises(_lib.GphipError) as e:
+        _lib.Handle(np.zeros((10, 33)), np.zeros(10), "se_ard")
+    assert e.value.status == 6
+    # nrhs = 2100 > 2048 -> two chunks through gphip_solve
+    X, y = syn.make_dataset(130, 2)
+    th = np.array([0.8, 1.2, 1.0, 0.3])
+    h = _lib.Handle(X, y, "se_ard")
+    assert h.fit(th) == 0
+    B = np.random.default_rng(0).standard_normal((130, 2100))
+    got = h.solve(B)
+    np.testing.assert_allclose(got, np.linalg.solve(orc.covariance_matrix("se_ard", th, X), B), rtol=1e-8, atol=1e-9)
+    # batch of 40 theta through a 16-slot cap: chunked, order preserved, per-theta info
+    h.set_option("max_slots", 16)
+    Th = syn.theta_batch(40, "se_ard", 2)
+    Th[:, -1] = np.maximum(Th[:, -1], 0.05)
+    Th[7, 1] = np.nan
+    out, info = h.loglik_batch(Th)
+    assert info[7] == _lib.INFO_NAN and np.all(np.delete(info, 7) == 0)
+    for i in (0, 15, 16, 39):
+        assert close(out[i], orc.log_likelihood("se_ard", Th[i], X, y), 130)
+    h.close()
+
+
+def test_handles_are_independent_across_threads():
+    """Different handles may be used concurrently (SURVEY.md §8b threading contract)."""
+    import threading
+    data = [syn.make_dataset(300 + 50 * i, 3, seed=100 + i) for i in range(3)]
+    th = syn.default_theta("matern52_ard", 3)
+    want = [orc.log_likelihood("matern52_ard", th, X, y) for X, y in data]
+    handles = [_lib.Handle(X, y, "matern52_ard") for X, y in data]
+    got = [None] * 3
+
+    def work(i):
+        vals = [handles[i].loglik(th)[0] for _ in range(20)]
+        got[i] = vals
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(3)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    for i in range(3):
+        assert all(close(v, want[i], 300) for v in got[i])
+        handles[i].close()
+
+
+def test_create_destroy_does_not_leak_device_memory():
+    import ctypes
+    lib = _lib.load()
+    X, y = syn.make_dataset(2000, 4)
+    th = syn.default_theta("se_ard", 4)
+
+    def used():
+        import torch
+        free, total = torch.cuda.mem_get_info()
+        return total - free
+
+    h = _lib.Handle(X, y, "se_ard"); h.loglik(th); h.close()
+    base = used()
+    for _ in range(5):
+        h = _lib.Handle(X, y, "se_ard")
+        h.loglik(th)
+        assert h.fit(th) == 0
+        h.predict(X[:10])
+        h.close()
+    assert used() - base < 64 * 2 ** 20
