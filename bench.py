@@ -107,6 +107,7 @@ def main() -> None:
                     help="N>1 only. theta (default): ranks evaluate disjoint theta, no data-path collective, "
                          "weak scaling.  cholesky: ONE evaluation per step sharded over all ranks with the 1-D "
                          "block-cyclic Cholesky (RCCL broadcast of factored panels), strong scaling.")
+    ap.add_argument("--supertile", type=int, default=0, help="experiment: XCD-private 8x8 super-tile order")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -134,6 +135,8 @@ def main() -> None:
     h = _lib.Handle(X, y, "se_ard", device=local_rank)
     if args.panel:
         h.set_option("panel", args.panel)
+    if args.supertile:
+        h.set_option("supertile", 1)
     base = syn.default_theta("se_ard", d)
     total_steps = args.warmup + args.steps
     # disjoint theta per rank and step: jitter the length-scales by < 5 %
