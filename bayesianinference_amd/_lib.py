@@ -43,6 +43,7 @@ _SIGNATURES = {
     "gphip_loglik": (C.c_int, [_h, _dp, C.c_int, _dp, _ip]),
     "gphip_loglik_batch": (C.c_int, [_h, _dp, C.c_int, C.c_int, _dp, _ip]),
     "gphip_loglik_parts": (C.c_int, [_h, _dp, C.c_int, _dp, _dp, _ip]),
+    "gphip_loglik_grad": (C.c_int, [_h, _dp, C.c_int, _dp, _dp, _ip]),
     "gphip_fit": (C.c_int, [_h, _dp, C.c_int, _ip]),
     "gphip_predict": (C.c_int, [_h, C.c_void_p, C.c_int64, _dp, _dp]),
     "gphip_predict_samples": (C.c_int, [_h, _dp, C.c_int, C.c_int, C.c_void_p, C.c_int64, _dp, _dp, _ip]),
@@ -180,6 +181,14 @@ class Handle:
         info = np.zeros(B, dtype=np.int32)
         self._check(self._lib.gphip_loglik_batch(self._h, _d(Th), B, p, _d(out), info.ctypes.data_as(_ip)))
         return out, info
+
+    def loglik_grad(self, theta):
+        """(loglik, grad[p], info)."""
+        th = np.ascontiguousarray(np.asarray(theta, dtype=np.float64).ravel())
+        out, info = C.c_double(0.0), C.c_int(0)
+        grad = np.zeros(th.size)
+        self._check(self._lib.gphip_loglik_grad(self._h, _d(th), th.size, C.byref(out), _d(grad), C.byref(info)))
+        return out.value, grad, info.value
 
     def fit(self, theta) -> int:
         th = np.ascontiguousarray(np.asarray(theta, dtype=np.float64).ravel())

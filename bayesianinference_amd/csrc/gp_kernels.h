@@ -719,4 +719,108 @@ __global__ void predict_reduce_kernel(const T* __restrict__ V, long ldv, long v_
     var[(long)slot * out_bstride + t] = sp[0] + sp[1] - nrm;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Hyper-parameter gradient (no reference counterpart):
+//   d loglik / d theta_p = 1/2 sum_{g,j} (alpha_g alpha_j - Kinv_gj) dK_gj/dtheta_p
+// identity_rows seeds a row block of V with rows of the identity (forward + backward substitution
+// then leave rows of K^-1 there); grad_reduce streams that row block once, rebuilds dK/dtheta on
+// the fly from the scaled inputs and accumulates   gacc[dd] += w fac u_dd^2  (length scales),
+// gacc[d] += w k  (sigma_f),  gacc[d+1] += w_gg  (sigma_n)   with fp64 atomics.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void identity_rows_kernel(T* __restrict__ V, long ldv, int npad, int c0, int mc) {
+    const long total = ldv * (long)npad;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int t = (int)(idx % ldv), j = (int)(idx / ldv);
+        V[idx] = (t < mc && j == c0 + t) ? (T)1 : (T)0;
+    }
+}
+
+template <typename T>
+struct GradArgs {
+    const T* Kinv; long ldv;        // row block: Kinv(t, j) at Kinv[j*ldv + t], t = row c0+t of K^-1
+    const T* alpha;                 // [npad]
+    const T* xs;                    // scaled inputs [d][npad]
+    int npad, n, c0, mc, d;
+    const double* slotp;
+    double* gacc;                   // [d + 2]
+};
+
+// One 128 (rows of the block) x 128 (columns) tile per workgroup; thread = one row, 64 columns.
+template <typename T, int D, int KT>
+__global__ __launch_bounds__(256) void grad_reduce_kernel(GradArgs<T> a) {
+    extern __shared__ double lds_raw[];
+    T* xjs = reinterpret_cast<T*>(lds_raw);      // [d][128] column points, then alpha_j [128]
+    const int d = (D > 0) ? D : a.d;
+    T* aj = xjs + d * TB;
+    const int tid = threadIdx.x, row = tid & 127, half = tid >> 7;
+    const int ti = blockIdx.x, tj = blockIdx.y;
+    const int t = ti * TB + row, g = a.c0 + t;
+    for (int idx = tid; idx < d * TB; idx += 256) xjs[idx] = a.xs[(long)(idx >> 7) * a.npad + tj * TB + (idx & 127)];
+    if (tid < TB) aj[tid] = a.alpha[tj * TB + tid];
+    constexpr int DM = (D > 0) ? D : 32;
+    T xg[DM];
+    double acc[DM];
+#pragma unroll
+    for (int dd = 0; dd < DM; ++dd) {
+        acc[dd] = 0.0;
+        xg[dd] = (dd < d && t < a.mc) ? a.xs[(long)dd * a.npad + g] : (T)0;
+    }
+    double acc_sf = 0.0, acc_dg = 0.0;
+    const T ag = (t < a.mc) ? a.alpha[g] : (T)0;
+    const T sf2 = (T)a.slotp[0];
+    __syncthreads();
+    if (t < a.mc && g < a.n) {
+        for (int jj = half * 64; jj < half * 64 + 64; ++jj) {
+            const int j = tj * TB + jj;
+            if (j >= a.n) break;
+            T u2[DM];
+            T r2 = (T)0;
+#pragma unroll
+            for (int dd = 0; dd < DM; ++dd) {
+                if (dd < d) {
+                    const T u = xg[dd] - xjs[dd * TB + jj];
+                    u2[dd] = u * u;
+                    r2 += u2[dd];
+                }
+            }
+            T kpart, fac;
+            if (KT == 0) {
+                kpart = sf2 * exp_nonpos((T)-0.5 * r2);
+                fac = kpart;
+            } else {
+                const T s5 = Num<T>::sqrt_((T)5.0 * r2);
+                const T e = exp_nonpos(-s5);
+                kpart = sf2 * ((T)1.0 + s5 + (T)(5.0 / 3.0) * r2) * e;
+                fac = sf2 * (T)(5.0 / 3.0) * ((T)1.0 + s5) * e;
+            }
+            const double w = (double)ag * (double)aj[jj] - (double)a.Kinv[(long)j * a.ldv + t];
+            const double wf = w * (double)fac;
+#pragma unroll
+            for (int dd = 0; dd < DM; ++dd)
+                if (dd < d) acc[dd] = __builtin_fma(wf, (double)u2[dd], acc[dd]);
+            acc_sf = __builtin_fma(w, (double)kpart, acc_sf);
+            if (j == g) acc_dg += w;
+        }
+    }
+    // wave reduction, one atomic per wave and parameter
+    const int lane = tid & 63;
+#pragma unroll
+    for (int dd = 0; dd < DM; ++dd) {
+        if (dd < d) {
+            double v = acc[dd];
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+            if (lane == 0) atomicAdd(a.gacc + dd, v);
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        acc_sf += __shfl_down(acc_sf, off);
+        acc_dg += __shfl_down(acc_dg, off);
+    }
+    if (lane == 0) {
+        atomicAdd(a.gacc + d, acc_sf);
+        atomicAdd(a.gacc + d + 1, acc_dg);
+    }
+}
+
 }  // namespace gphip

@@ -39,7 +39,7 @@ struct ProfRec {
 }  // namespace
 
 struct gphip_ctx {
-    std::mutex mu;
+    std::recursive_mutex mu;
     int device = 0;
     int dtype = 64;                    // 64: double, 32: float
     size_t es = 8;                     // element size of the device arithmetic type
@@ -72,6 +72,8 @@ struct gphip_ctx {
     void *dV = nullptr, *dXsT = nullptr, *dXsS = nullptr;   // typed
     double *dMean = nullptr, *dVar = nullptr;
     int64_t vcap = 0;
+    void* dAlpha = nullptr;                                  // typed [Npad] (gradient)
+    double* dGacc = nullptr;                                 // [d + 2] gradient accumulators
     // profiling
     std::vector<ProfRec> recs;
     std::vector<hipEvent_t> pool;
@@ -453,7 +455,7 @@ int eval_batch(gphip_ctx* h, const double* Theta, int B, int p, double* out, dou
     if (!h || !Theta || !out || !info) return fail(h, GPHIP_ERR_ARG, "null argument");
     if (p != h->p) return fail(h, GPHIP_ERR_DIM, "theta has the wrong length for this kernel/mean");
     if (B <= 0) return GPHIP_OK;
-    std::lock_guard<std::mutex> lk(h->mu);
+    std::lock_guard<std::recursive_mutex> lk(h->mu);
     HIPCHK(hipSetDevice(h->device));
     if (h->kernel_id == GPHIP_KERNEL_NULL) {
         for (int s = 0; s < B; ++s)
@@ -533,11 +535,11 @@ int ensure_vbuf(gphip_ctx* h, int64_t cap) {
 // V <- V L^-T for the mpad x Npad row block in dV (right-looking over the 128-tile columns of L):
 // every row of V becomes (L^-1 v)^T.  Panel solves and updates are the same MFMA GEMM kernel.
 template <typename T>
-int queue_forward_rows(gphip_ctx* h, int64_t mpad, int nslots) {
+int queue_forward_rows(gphip_ctx* h, int64_t mpad, int nslots, int b_start = 0) {
     const int Nt = (int)h->Nt, Mt = (int)(mpad / TB);
     const long ld = h->ld, vs = (long)mpad * h->Npad, bs = ld * ld, lrs = (long)Nt * TB * TB;
     T *V = (T*)h->dV, *A = (T*)h->dA, *W = (T*)h->dW;
-    for (int b = 0; b < Nt; ++b) {
+    for (int b = b_start; b < Nt; ++b) {     // b_start > 0: the rows are known to be zero left of tile column b_start
         launch_gemm<T>(h, 2, V, mpad, vs, V + (long)b * TB * mpad, mpad, vs, W + (long)b * TB * TB - (long)b * TB, TB,
                        lrs, TB, 0, Mt, b, b + 1, 0, nslots, 1);
         if (b + 1 < Nt)
@@ -600,6 +602,54 @@ int queue_finalize(gphip_ctx* h) {
     hipLaunchKernelGGL(finalize_kernel<T>, dim3(1), dim3(64), 0, h->stream, (const T*)h->dA, h->ld, h->ld * h->ld,
                        (int)h->Npad, h->dPartial, (int)h->Nt, h->dRes);
     return 0;
+}
+
+template <typename T, int KT>
+void launch_grad_kt(gphip_ctx* h, const GradArgs<T>& a, dim3 grid) {
+#define GR_CASE(DD)                                                                                   \
+    case DD:                                                                                          \
+        hipLaunchKernelGGL((grad_reduce_kernel<T, DD, KT>), grid, dim3(256), (size_t)(DD + 1) * TB * sizeof(T), h->cs, a); \
+        break;
+    switch (a.d) {
+        GR_CASE(1) GR_CASE(2) GR_CASE(3) GR_CASE(4) GR_CASE(5) GR_CASE(6) GR_CASE(7) GR_CASE(8) GR_CASE(16)
+        default:
+            hipLaunchKernelGGL((grad_reduce_kernel<T, 0, KT>), grid, dim3(256), (size_t)(a.d + 1) * TB * sizeof(T), h->cs, a);
+    }
+#undef GR_CASE
+}
+
+// alpha = K^-1 r from the fitted factor (z = L^-1 r sits in the rhs row): one backward pass on a
+// 128-row scratch block whose row 0 is z
+template <typename T>
+int queue_alpha(gphip_ctx* h) {
+    const int64_t mpad = TB, Npad = h->Npad;
+    HIPCHK(hipMemsetAsync(h->dV, 0, (size_t)mpad * Npad * sizeof(T), h->stream));
+    HIPCHK(hipMemcpy2DAsync(h->dV, (size_t)mpad * sizeof(T), (const T*)h->dA + Npad, (size_t)h->ld * sizeof(T), sizeof(T),
+                            (size_t)Npad, hipMemcpyDeviceToDevice, h->stream));
+    queue_backward_rows<T>(h, mpad);
+    HIPCHK(hipMemcpy2DAsync(h->dAlpha, sizeof(T), h->dV, (size_t)mpad * sizeof(T), sizeof(T), (size_t)Npad,
+                            hipMemcpyDeviceToDevice, h->stream));
+    return GPHIP_OK;
+}
+
+// rows [c0, c0+mc) of K^-1 into dV (identity rows -> forward -> backward), then the reduction
+template <typename T>
+int queue_grad_chunk(gphip_ctx* h, int64_t c0, int64_t mc, int64_t mpad) {
+    const long tot = (long)mpad * h->Npad;
+    int gx = (int)((tot + 255) / 256);
+    if (gx > 4096) gx = 4096;
+    hipLaunchKernelGGL(identity_rows_kernel<T>, dim3(gx), dim3(256), 0, h->stream, (T*)h->dV, (long)mpad, (int)h->Npad,
+                       (int)c0, (int)mc);
+    queue_forward_rows<T>(h, mpad, 1, (int)(c0 / TB));
+    queue_backward_rows<T>(h, mpad);
+    GradArgs<T> a{};
+    a.Kinv = (const T*)h->dV; a.ldv = mpad; a.alpha = (const T*)h->dAlpha; a.xs = (const T*)h->dXs;
+    a.npad = (int)h->Npad; a.n = (int)h->N; a.c0 = (int)c0; a.mc = (int)mc; a.d = (int)h->d;
+    a.slotp = h->dSlotp; a.gacc = h->dGacc;
+    const dim3 grid((unsigned)(mpad / TB), (unsigned)h->Nt);
+    if (h->kt == 0) launch_grad_kt<T, 0>(h, a, grid);
+    else launch_grad_kt<T, 1>(h, a, grid);
+    return GPHIP_OK;
 }
 
 }  // namespace
@@ -679,7 +729,7 @@ int gphip_destroy(gphip_handle h) {
     free_slots(h);
     (void)hipFree(h->dXt); (void)hipFree(h->dY);
     (void)hipFree(h->dV); (void)hipFree(h->dXsT); (void)hipFree(h->dXsS); (void)hipFree(h->dMean);
-    (void)hipFree(h->dVar);
+    (void)hipFree(h->dVar); (void)hipFree(h->dAlpha); (void)hipFree(h->dGacc);
     for (auto e : h->pool) (void)hipEventDestroy(e);
     for (auto e : h->sync_events) (void)hipEventDestroy(e);
     if (h->own_streams) {
@@ -708,13 +758,79 @@ int gphip_loglik_batch(gphip_handle h, const double* Theta, int B, int p, double
     return eval_batch(h, Theta, B, p, out, nullptr, info);
 }
 
+// log-likelihood and its gradient with respect to theta (same layout as theta).  One factorisation,
+// then K^-1 is streamed through the scratch block 2048 rows at a time (forward + backward
+// substitution of identity rows) and contracted against dK/dtheta on the fly.
+int gphip_loglik_grad(gphip_handle h, const double* theta, int p, double* out, double* grad, int* info) {
+    if (!h || !theta || !out || !grad || !info) return fail(h, GPHIP_ERR_ARG, "null argument");
+    if (h->kernel_id == GPHIP_KERNEL_NULL) {
+        // closed form for K = diag(sn^2): d/dsn = -N/sn + quad/sn, d/dmu = sum(y - mu)/sn^2
+        std::lock_guard<std::recursive_mutex> lk(h->mu);
+        if (p != h->p) return fail(h, GPHIP_ERR_DIM, "theta has the wrong length");
+        double parts[2];
+        null_kernel_eval(h, theta, out, parts, info);
+        const double sn = theta[0], mu = (h->mean_id == GPHIP_MEAN_CONST) ? theta[1] : 0.0;
+        grad[0] = (-(double)h->N + parts[1]) / sn;
+        if (h->mean_id == GPHIP_MEAN_CONST) grad[1] = (h->sum_y - (double)h->N * mu) / (sn * sn);
+        return GPHIP_OK;
+    }
+    std::lock_guard<std::recursive_mutex> lk(h->mu);
+    int rc = eval_batch(h, theta, 1, p, out, nullptr, info);
+    if (rc) return rc;
+    for (int i = 0; i < p; ++i) grad[i] = std::nan("");
+    if (*info != 0) return GPHIP_OK;
+    HIPCHK(hipSetDevice(h->device));
+    const int64_t N = h->N, Npad = h->Npad, d = h->d, MC = 2048;
+    rc = ensure_vbuf(h, N < MC ? Npad : MC);
+    if (rc) return rc;
+    if (!h->dAlpha) HIPCHK(hipMalloc(&h->dAlpha, (size_t)Npad * h->es));
+    if (!h->dGacc) HIPCHK(hipMalloc(&h->dGacc, (size_t)(d + 2) * 8));
+    h->cs = h->stream;
+    rc = DISPATCH(h, queue_alpha, h);
+    if (rc) return rc;
+    HIPCHK(hipMemsetAsync(h->dGacc, 0, (size_t)(d + 2) * 8, h->stream));
+    for (int64_t c0 = 0; c0 < N; c0 += MC) {
+        const int64_t mc = (N - c0 < MC) ? (N - c0) : MC;
+        const int64_t mpad = (mc + TB - 1) / TB * TB;
+        rc = DISPATCH(h, queue_grad_chunk, h, c0, mc, mpad);
+        if (rc) return rc;
+    }
+    std::vector<double> gacc((size_t)d + 2), alpha;
+    HIPCHK(hipMemcpyAsync(gacc.data(), h->dGacc, gacc.size() * 8, hipMemcpyDeviceToHost, h->stream));
+    rc = DISPATCH(h, download, h, alpha, h->dAlpha, (size_t)N, h->stream);
+    if (rc) return rc;
+    HIPCHK(hipGetLastError());
+    harvest(h);
+    const double sf = theta[h->nl], sn = theta[h->nl + 1];
+    if (h->nl == 1) {
+        double sum = 0.0;
+        for (int64_t j = 0; j < d; ++j) sum += gacc[(size_t)j];
+        grad[0] = 0.5 * sum / theta[0];                       // even in l: d/dl of f(l^2)
+    } else {
+        for (int64_t j = 0; j < d; ++j) grad[j] = 0.5 * gacc[(size_t)j] / theta[j];
+    }
+    grad[h->nl] = gacc[(size_t)d] / sf;                       // 1/2 * sum w k * 2/sf
+    grad[h->nl + 1] = gacc[(size_t)d + 1] * sn;               // 1/2 * tr(W) * 2 sn
+    if (h->mean_id == GPHIP_MEAN_CONST) {
+        double sum = 0.0;
+        for (double v : alpha) sum += v;
+        grad[h->nl + 2] = sum;
+    }
+    h->fitted = true;                                         // the factor of theta is still resident
+    h->theta_fit.assign(theta, theta + p);
+    h->logdet_fit = h->hRes[0];
+    h->mu_fit = h->hSlotp[2];
+    h->kappa_fit = h->hSlotp[0] + h->hSlotp[1];
+    return GPHIP_OK;
+}
+
 int gphip_fit(gphip_handle h, const double* theta, int p, int* info) {
     if (!h || !theta || !info) return fail(h, GPHIP_ERR_ARG, "null argument");
     if (h->kernel_id == GPHIP_KERNEL_NULL) return fail(h, GPHIP_ERR_UNSUPPORTED, "fit: null kernel has no factor");
     double out, parts[2];
     int rc = eval_batch(h, theta, 1, p, &out, parts, info);
     if (rc) return rc;
-    std::lock_guard<std::mutex> lk(h->mu);
+    std::lock_guard<std::recursive_mutex> lk(h->mu);
     h->fitted = (*info == 0);
     h->theta_fit.assign(theta, theta + p);
     h->logdet_fit = parts[0];
@@ -733,7 +849,7 @@ int gphip_logdet(gphip_handle h, double* out) {
 int gphip_covariance(gphip_handle h, const double* theta, int p, double* K) {
     if (!h || !theta || !K) return fail(h, GPHIP_ERR_ARG, "null argument");
     if (p != h->p) return fail(h, GPHIP_ERR_DIM, "theta has the wrong length");
-    std::lock_guard<std::mutex> lk(h->mu);
+    std::lock_guard<std::recursive_mutex> lk(h->mu);
     HIPCHK(hipSetDevice(h->device));
     const int64_t N = h->N;
     if (h->kernel_id == GPHIP_KERNEL_NULL) {
@@ -762,7 +878,7 @@ int gphip_covariance(gphip_handle h, const double* theta, int p, double* K) {
 int gphip_predict(gphip_handle h, const void* Xs, int64_t M, double* mean, double* var) {
     if (!h || !Xs || !mean || !var) return fail(h, GPHIP_ERR_ARG, "null argument");
     if (M < 1) return fail(h, GPHIP_ERR_DIM, "M < 1");
-    std::lock_guard<std::mutex> lk(h->mu);
+    std::lock_guard<std::recursive_mutex> lk(h->mu);
     if (!h->fitted) return fail(h, GPHIP_ERR_STATE, "gphip_predict before a successful gphip_fit");
     HIPCHK(hipSetDevice(h->device));
     const double* X = static_cast<const double*>(Xs);
@@ -801,7 +917,7 @@ int gphip_predict_samples(gphip_handle h, const double* Thetas, int S, int p, co
     if (p != h->p) return fail(h, GPHIP_ERR_DIM, "theta has the wrong length");
     if (S < 1 || M < 1) return fail(h, GPHIP_ERR_DIM, "S < 1 or M < 1");
     if (h->kernel_id == GPHIP_KERNEL_NULL) return fail(h, GPHIP_ERR_UNSUPPORTED, "null kernel has no factor");
-    std::lock_guard<std::mutex> lk(h->mu);
+    std::lock_guard<std::recursive_mutex> lk(h->mu);
     HIPCHK(hipSetDevice(h->device));
     int rc = ensure_slots(h, S);
     if (rc) return rc;
@@ -855,7 +971,7 @@ int gphip_predict_samples(gphip_handle h, const double* Thetas, int S, int p, co
 int gphip_solve(gphip_handle h, const double* rhs, int64_t nrhs, double* out) {
     if (!h || !rhs || !out) return fail(h, GPHIP_ERR_ARG, "null argument");
     if (nrhs < 1) return fail(h, GPHIP_ERR_DIM, "nrhs < 1");
-    std::lock_guard<std::mutex> lk(h->mu);
+    std::lock_guard<std::recursive_mutex> lk(h->mu);
     if (!h->fitted) return fail(h, GPHIP_ERR_STATE, "gphip_solve before a successful gphip_fit");
     HIPCHK(hipSetDevice(h->device));
     const int64_t N = h->N, Npad = h->Npad, MC = 2048;
@@ -891,7 +1007,7 @@ int gphip_solve(gphip_handle h, const double* rhs, int64_t nrhs, double* out) {
 // ------------------------------------------------------------------------------------------
 int gphip_set_streams(gphip_handle h, void* main_stream, void* panel_stream) {
     if (!h || !main_stream || !panel_stream) return fail(h, GPHIP_ERR_ARG, "null stream");
-    std::lock_guard<std::mutex> lk(h->mu);
+    std::lock_guard<std::recursive_mutex> lk(h->mu);
     HIPCHK(hipSetDevice(h->device));
     if (h->own_streams) {
         HIPCHK(hipStreamSynchronize(h->pstream));
@@ -928,7 +1044,7 @@ int gphip_dist_begin(gphip_handle h, const double* theta, int p, int rank, int w
     if (p != h->p) return fail(h, GPHIP_ERR_DIM, "theta has the wrong length");
     if (world < 1 || rank < 0 || rank >= world) return fail(h, GPHIP_ERR_ARG, "bad rank/world");
     if (h->kernel_id == GPHIP_KERNEL_NULL) return fail(h, GPHIP_ERR_UNSUPPORTED, "null kernel needs no factorisation");
-    std::lock_guard<std::mutex> lk(h->mu);
+    std::lock_guard<std::recursive_mutex> lk(h->mu);
     HIPCHK(hipSetDevice(h->device));
     int rc = ensure_slots(h, 1);
     if (rc) return rc;
@@ -951,7 +1067,7 @@ int gphip_dist_factor_panel(gphip_handle h, int k, void* packed) {
     int64_t rows, cols;
     int rc = gphip_dist_panel_shape(h, k, &rows, &cols);
     if (rc) return rc;
-    std::lock_guard<std::mutex> lk(h->mu);
+    std::lock_guard<std::recursive_mutex> lk(h->mu);
     if (h->dist_world < 1) return fail(h, GPHIP_ERR_STATE, "gphip_dist_factor_panel outside dist_begin/dist_end");
     HIPCHK(hipSetDevice(h->device));
     const int64_t K0 = (int64_t)k * h->panel;
@@ -971,7 +1087,7 @@ int gphip_dist_update(gphip_handle h, int k, const void* packed, int j_first, in
     int64_t rows, cols;
     int rc = gphip_dist_panel_shape(h, k, &rows, &cols);
     if (rc) return rc;
-    std::lock_guard<std::mutex> lk(h->mu);
+    std::lock_guard<std::recursive_mutex> lk(h->mu);
     if (h->dist_world < 1) return fail(h, GPHIP_ERR_STATE, "gphip_dist_update outside dist_begin/dist_end");
     HIPCHK(hipSetDevice(h->device));
     const int Nt = (int)h->Nt, R = Nt + 1, P = h->panel;
@@ -997,7 +1113,7 @@ int gphip_dist_update(gphip_handle h, int k, const void* packed, int j_first, in
 // meaningful on rank 0 only (0 elsewhere); the host all-reduces (sum, sum, max).
 int gphip_dist_end(gphip_handle h, double* logdet_partial, double* quad, int* info) {
     if (!h || !logdet_partial || !quad || !info) return fail(h, GPHIP_ERR_ARG, "null argument");
-    std::lock_guard<std::mutex> lk(h->mu);
+    std::lock_guard<std::recursive_mutex> lk(h->mu);
     if (h->dist_world < 1) return fail(h, GPHIP_ERR_STATE, "gphip_dist_end without gphip_dist_begin");
     HIPCHK(hipSetDevice(h->device));
     DISPATCH(h, queue_finalize, h);
@@ -1016,7 +1132,7 @@ int gphip_dist_end(gphip_handle h, double* logdet_partial, double* quad, int* in
 
 int gphip_set_option(gphip_handle h, const char* name, double value) {
     if (!h || !name) return GPHIP_ERR_ARG;
-    std::lock_guard<std::mutex> lk(h->mu);
+    std::lock_guard<std::recursive_mutex> lk(h->mu);
     const int v = (int)value;
     if (!strcmp(name, "panel")) { if (v < 1 || v > 64) return fail(h, GPHIP_ERR_ARG, "panel out of range"); h->panel = v; }
     else if (!strcmp(name, "profile")) h->profile = v;
@@ -1030,7 +1146,7 @@ int gphip_set_option(gphip_handle h, const char* name, double value) {
 
 int gphip_get_profile(gphip_handle h, int cls, double* ms, double* launches, double* flops, double* bytes) {
     if (!h || cls < 0 || cls >= GPHIP_NCLASS) return GPHIP_ERR_ARG;
-    std::lock_guard<std::mutex> lk(h->mu);
+    std::lock_guard<std::recursive_mutex> lk(h->mu);
     if (ms) *ms = h->acc_ms[cls];
     if (launches) *launches = h->acc_n[cls];
     if (flops) *flops = h->acc_flops[cls];
@@ -1040,14 +1156,14 @@ int gphip_get_profile(gphip_handle h, int cls, double* ms, double* launches, dou
 
 int gphip_reset_profile(gphip_handle h) {
     if (!h) return GPHIP_ERR_ARG;
-    std::lock_guard<std::mutex> lk(h->mu);
+    std::lock_guard<std::recursive_mutex> lk(h->mu);
     for (int c = 0; c < GPHIP_NCLASS; ++c) h->acc_ms[c] = h->acc_n[c] = h->acc_flops[c] = h->acc_bytes[c] = 0;
     return GPHIP_OK;
 }
 
 int gphip_sync(gphip_handle h) {
     if (!h) return GPHIP_ERR_ARG;
-    std::lock_guard<std::mutex> lk(h->mu);
+    std::lock_guard<std::recursive_mutex> lk(h->mu);
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipStreamSynchronize(h->pstream));
     HIPCHK(hipStreamSynchronize(h->stream));

@@ -263,6 +263,12 @@ def defineGaussianProcess(data, kernel, nugget="Constant", meanFunction=None, va
     user_ll = rules.pop("LogLikelihoodFunction", None)
     loglik = user_ll if callable(user_ll) else make_log_likelihood(handle)
 
+    def log_likelihood_gradient(theta):
+        """(value, gradient) -- extension for gradient-based MAP / Laplace routes (LA:177-238 uses
+        NMaximize without gradients); sentinel and NaN gradient on numerical failure."""
+        ll, grad, info = handle.loglik_grad(theta)
+        return (ll, grad) if info == 0 else (MACHINE_LOG_ZERO, np.full(len(params), np.nan))
+
     def covariance_function(theta):                               # "CovarianceFunction", BGP:264-271
         return handle.covariance(theta)
 
@@ -288,6 +294,7 @@ def defineGaussianProcess(data, kernel, nugget="Constant", meanFunction=None, va
             "HIPHandle": handle,
         },
         **rules,
+        "LogLikelihoodGradientFunction": log_likelihood_gradient,
         "LogLikelihoodFunction": loglik,
     })
 

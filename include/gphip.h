@@ -75,6 +75,11 @@ int gphip_loglik_batch(gphip_handle h, const double* Theta, int B, int p, double
 int gphip_loglik_parts(gphip_handle h, const double* theta, int p, double* out, double* parts,
                        int* info);
 
+/* loglik and d loglik / d theta (grad: length p, same order as theta):
+ * 1/2 tr((alpha alpha^T - K^-1) dK/dtheta_p).  No reference counterpart (the
+ * reference maximises without gradients, LaplaceApproximation.wl:177-238).  grad = NaN if *info != 0. */
+int gphip_loglik_grad(gphip_handle h, const double* theta, int p, double* out, double* grad, int* info);
+
 /* Factor K(theta) and keep L and L^-1 r resident for predict / solve / logdet. */
 int gphip_fit(gphip_handle h, const double* theta, int p, int* info);
 /* Xs: row-major M x d fp64.  mean[j] = m(x*_j) + k*_j^T K^-1 r ; var[j] = k(x*,x*) + sn^2 -

@@ -180,6 +180,42 @@ def log_likelihood_mvn(kernel: str, theta, X, y, mean: str = "zero") -> float:
         np.asarray(y, dtype=np.float64).ravel()))
 
 
+def log_likelihood_grad(kernel: str, theta, X, y, mean: str = "zero") -> np.ndarray:
+    """d/dtheta of BGP:190-196 by the standard identity  1/2 tr((alpha alpha^T - K^-1) dK/dtheta),
+    alpha = K^-1 r  (no reference counterpart: the reference optimises with NMaximize and no
+    gradients, LA:177-238).  Dense numpy, small N only."""
+    X = np.atleast_2d(np.asarray(X, dtype=np.float64))
+    theta = np.asarray(theta, dtype=np.float64)
+    n, d = X.shape
+    ell, sf, sn, mu = split_theta(kernel, d, theta, mean)
+    nl = n_lengthscales(kernel, d)
+    K = covariance_matrix(kernel, theta, X, mean)
+    Kinv = np.linalg.inv(K)
+    r = np.asarray(y, dtype=np.float64).ravel() - mu
+    alpha = Kinv @ r
+    Wm = np.outer(alpha, alpha) - Kinv
+    U2 = ((X[:, None, :] - X[None, :, :]) / ell) ** 2             # u_d^2, n x n x d
+    r2 = U2.sum(axis=2)
+    if kernel in ("se", "se_ard"):
+        kpart = sf * sf * np.exp(-0.5 * r2)
+        fac = kpart                                               # dK/dl_d = fac * u_d^2 / l_d
+    else:
+        s5 = np.sqrt(5.0 * r2)
+        kpart = sf * sf * (1.0 + s5 + 5.0 / 3.0 * r2) * np.exp(-s5)
+        fac = sf * sf * (5.0 / 3.0) * (1.0 + s5) * np.exp(-s5)
+    grad = []
+    if nl == 1:
+        grad.append(0.5 * np.sum(Wm * fac * r2) / ell[0])
+    else:
+        for j in range(d):
+            grad.append(0.5 * np.sum(Wm * fac * U2[:, :, j]) / ell[j])
+    grad.append(0.5 * np.sum(Wm * kpart) * 2.0 / sf)
+    grad.append(0.5 * np.trace(Wm) * 2.0 * sn)
+    if mean == "const":
+        grad.append(float(alpha.sum()))
+    return np.array(grad)
+
+
 # --------------------------------------------------------------------------------------
 # Prediction: BGP:91-124 compiledKandKappa, BGP:396-422 predictFromGaussianProcessInternal
 # --------------------------------------------------------------------------------------

@@ -15,7 +15,7 @@ def test_define_gaussian_process_object_and_closure():
     obj = gp.defineGaussianProcess((X, y), "SEARD", "Constant", None, variables, "Uniform", Note="extra rule")
     assert not obj.failed
     for key in ("Data", "PriorDistribution", "Parameters", "ParameterSymbols", "GaussianProcessData",
-                "LogLikelihoodFunction", "LogPriorPDFFunction", "Note"):
+                "LogLikelihoodFunction", "LogPriorPDFFunction", "LogLikelihoodGradientFunction", "Note"):
         assert key in obj
     mf = obj["GaussianProcessData", "ModelFunctions"]
     assert set(mf) == {"KernelFunction", "NuggetFunction", "MeanFunction", "CovarianceFunction",
@@ -32,6 +32,9 @@ def test_define_gaussian_process_object_and_closure():
                                     LogLikelihoodFunction=None)
     assert obj2["LogLikelihoodFunction"]([1.0, 1.0, 1.0, 0.0]) == gp.MACHINE_LOG_ZERO
     np.testing.assert_allclose(mf["CovarianceFunction"](th), orc.covariance_matrix("se_ard", th, X), rtol=1e-12)
+    val, grad = obj["LogLikelihoodGradientFunction"](th)
+    assert val == pytest.approx(want, rel=1e-8)
+    np.testing.assert_allclose(grad, orc.log_likelihood_grad("se_ard", th, X, y), rtol=1e-6)
     inv = mf["InverseCovarianceFunction"](th)
     assert inv["LogDet"] == pytest.approx(orc.log_likelihood("se_ard", th, X, y, parts=True)[1], rel=1e-9)
 

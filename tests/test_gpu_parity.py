@@ -338,3 +338,41 @@ def test_create_destroy_does_not_leak_device_memory():
         h.predict(X[:10])
         h.close()
     assert used() - base < 64 * 2 ** 20
+
+
+@pytest.mark.parametrize("kernel,d,n,mean", [("se_ard", 3, 300, "zero"), ("matern52_ard", 2, 2500, "const"),
+                                             ("se", 1, 200, "const"), ("matern52", 2, 129, "zero"), ("se_ard", 11, 150, "zero")])
+def test_loglik_gradient_matches_oracle(kernel, d, n, mean):
+    X, y = syn.make_dataset(n, d)
+    th = syn.default_theta(kernel, d)
+    th[:-2] *= 1.0 + 0.1 * np.arange(len(th) - 2)
+    th[-1] = 0.25
+    if mean == "const":
+        th = np.append(th, 0.2)
+    h = _lib.Handle(X, y, kernel, mean)
+    ll, grad, info = h.loglik_grad(th)
+    assert info == 0 and close(ll, orc.log_likelihood(kernel, th, X, y, mean), n)
+    want = orc.log_likelihood_grad(kernel, th, X, y, mean)
+    np.testing.assert_allclose(grad, want, rtol=1e-7, atol=1e-7 * np.abs(want).max())
+    mu, var = h.predict(X[:3])                            # the factor stays resident after the gradient
+    mo, so = orc.predict_internal(kernel, th, X, y, X[:3], mean)
+    np.testing.assert_allclose(mu, mo, rtol=1e-7, atol=1e-9)
+    h.close()
+
+
+def test_gradient_null_kernel_and_fp32():
+    X, y = syn.make_dataset(50, 2)
+    h = _lib.Handle(X, y, "null", "const")
+    ll, grad, info = h.loglik_grad([0.7, 0.1])
+    e = 1e-6
+    fd0 = (orc.log_likelihood("null", [0.7 + e, 0.1], X, y, "const") - orc.log_likelihood("null", [0.7 - e, 0.1], X, y, "const")) / (2 * e)
+    fd1 = (orc.log_likelihood("null", [0.7, 0.1 + e], X, y, "const") - orc.log_likelihood("null", [0.7, 0.1 - e], X, y, "const")) / (2 * e)
+    assert info == 0 and grad[0] == pytest.approx(fd0, rel=1e-6) and grad[1] == pytest.approx(fd1, rel=1e-6)
+    h.close()
+    X, y = syn.make_dataset(400, 4)
+    th = syn.default_theta("matern52_ard", 4, dtype="f32")
+    h = _lib.Handle(X, y, "matern52_ard", dtype=32)
+    ll, grad, info = h.loglik_grad(th)
+    want = orc.log_likelihood_grad("matern52_ard", th, X, y)
+    np.testing.assert_allclose(grad, want, rtol=2e-2, atol=2e-2 * np.abs(want).max())     # fp32 device arithmetic
+    h.close()

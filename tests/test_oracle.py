@@ -123,3 +123,19 @@ def test_log_space_helpers():
     assert orc.log_sum_exp([-np.inf]) == -np.inf
     assert orc.log_add(math.log(2.0), math.log(3.0)) == pytest.approx(math.log(5.0))
     assert orc.log_subtract(math.log(5.0), math.log(3.0)) == pytest.approx(math.log(2.0))
+
+
+@pytest.mark.parametrize("kernel,d,mean", [("se", 1, "zero"), ("se_ard", 3, "const"), ("matern52_ard", 2, "zero"),
+                                           ("matern52", 2, "const")])
+def test_gradient_oracle_matches_finite_differences(kernel, d, mean):
+    X, y = syn.make_dataset(60, d)
+    th = syn.default_theta(kernel, d)
+    th[-1] = 0.25
+    if mean == "const":
+        th = np.append(th, 0.3)
+    g = orc.log_likelihood_grad(kernel, th, X, y, mean)
+    for i in range(len(th)):
+        e = np.zeros_like(th)
+        e[i] = 1e-6 * max(1.0, abs(th[i]))
+        fd = (orc.log_likelihood(kernel, th + e, X, y, mean) - orc.log_likelihood(kernel, th - e, X, y, mean)) / (2 * e[i])
+        assert g[i] == pytest.approx(fd, rel=2e-5, abs=1e-6)
