@@ -538,8 +538,12 @@ template <> __device__ __forceinline__ int lds_off<float>(int k, int row) {
 // 3 = "NN" form for the backward solve: the J operand is read transposed, B(j,k) at
 //     B[k + j*ldb] (k contiguous), through an XOR-swizzled [j][GK] LDS image; g.mode picks
 //     C -= A B (0) or C = A B (1).
-template <typename T, int ROLE>
-__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs<T> g) {
+// NWI x NWJ = wave grid of the workgroup over the 128x128 tile: 2x2 (256 threads, 64x64 per wave, the
+// throughput shape) or 4x4 (1024 threads, 32x32 per wave: a quarter of the MFMA chain per wave, for
+// the latency-bound launches of the panel stream where tiles <= CUs).
+template <typename T, int ROLE, int NWI, int NWJ>
+__global__ __launch_bounds__(64 * NWI * NWJ, (NWI * NWJ == 4) ? 2 : 4) void gemm_nt_kernel(GemmArgs<T> g) {
+    constexpr int NW = NWI * NWJ, FI = 8 / NWI, FJ = 8 / NWJ;      // MFMA tiles per wave along i / j
     extern __shared__ double smem_raw[];       // [2 stages][I tile | J tile]
     T* smem = reinterpret_cast<T*>(smem_raw);
     typedef typename Num<T>::acc_t acc_t;
@@ -548,7 +552,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs<T> g) {
     constexpr int JOFF = STAGE / 2;
     constexpr bool F64 = sizeof(T) == 8;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wi = wave & 1, wj = wave >> 1;
+    const int wi = wave % NWI, wj = wave / NWI;
     const int slot = blockIdx.y;
     int bid = blockIdx.x;
     int ti, tj;
@@ -586,8 +590,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs<T> g) {
         T* Is = smem + st * STAGE;
         T* Js = Is + JOFF;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int q = uw + 4 * s;           // instruction index 0..15 within the stage
+        for (int s = 0; s < (NW >= 16 ? 1 : 16 / NW); ++s) {
+            const int q = uw + NW * s;          // instruction index 0..15 within the stage
             if (F64) {
                 const long kcol = (long)kb * GK + q;
                 __builtin_amdgcn_global_load_lds((glb_void*)(Ag + kcol * g.lda + 2 * lane),
@@ -617,18 +621,19 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs<T> g) {
     };
 
     // C tile: lane holds i = i0 + y*16 + (lane&15), j = j0 + x*16 + drow(lane>>4, r)
-    T* Cg = g.C + (long)slot * g.c_bstride + ((long)tj * TB + wj * 64) * g.ldc + (long)ti * TB + wi * 64 + (lane & 15);
+    T* Cg = g.C + (long)slot * g.c_bstride + ((long)tj * TB + wj * (16 * FJ)) * g.ldc + (long)ti * TB +
+            wi * (16 * FI) + (lane & 15);
     const int l4 = lane >> 4;
     const int nk = g.K / GK;
     stage(0, 0);
     // Update roles start the accumulators AT C (loads fly with the first DMA stage) and feed the
     // MFMA the negated J fragment, so acc ends as C - A B^T and the epilogue is stores only.
     const bool from_zero = (ROLE == 2) || (ROLE == 3 && g.mode == 1);
-    acc_t acc[4][4];
+    acc_t acc[FJ][FI];
 #pragma unroll
-    for (int x = 0; x < 4; ++x)
+    for (int x = 0; x < FJ; ++x)
 #pragma unroll
-        for (int y = 0; y < 4; ++y) {
+        for (int y = 0; y < FI; ++y) {
             if (from_zero) {
                 acc[x][y] = (acc_t){0, 0, 0, 0};
             } else {
@@ -642,29 +647,30 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs<T> g) {
     for (int kb = 0; kb < nk; ++kb) {
         const int cur = kb & 1;
         if (kb + 1 < nk) stage(kb + 1, cur ^ 1);       // DMA of the next stage flies under the MFMAs
-        const T* Is = smem + cur * STAGE + wi * 64 + (lane & 15);
+        const T* Is = smem + cur * STAGE + wi * (16 * FI) + (lane & 15);
         const T* Js = smem + cur * STAGE + JOFF;
 #pragma unroll
         for (int kk = 0; kk < GK / 4; ++kk) {
-            T fi[4], fj[4];
+            T fi[FI], fj[FJ];
             const int k = 4 * kk + l4;
 #pragma unroll
-            for (int f = 0; f < 4; ++f) {
-                fi[f] = Is[lds_off<T>(k, f * 16)];
+            for (int f = 0; f < FI; ++f) fi[f] = Is[lds_off<T>(k, f * 16)];
+#pragma unroll
+            for (int f = 0; f < FJ; ++f) {
                 T v;
+                const int jrow = wj * (16 * FJ) + f * 16 + (lane & 15);
                 if (ROLE == 3) {
                     constexpr int G = 16 / (int)sizeof(T);
-                    const int jrow = wj * 64 + f * 16 + (lane & 15);
                     v = Js[jrow * GK + G * ((k / G) ^ (jrow & 7)) + (k % G)];
                 } else {
-                    v = Js[lds_off<T>(k, wj * 64 + f * 16 + (lane & 15))];
+                    v = Js[lds_off<T>(k, jrow)];
                 }
                 fj[f] = from_zero ? v : -v;
             }
 #pragma unroll
-            for (int x = 0; x < 4; ++x)
+            for (int x = 0; x < FJ; ++x)
 #pragma unroll
-                for (int y = 0; y < 4; ++y) acc[x][y] = Num<T>::mfma(fj[x], fi[y], acc[x][y]);
+                for (int y = 0; y < FI; ++y) acc[x][y] = Num<T>::mfma(fj[x], fi[y], acc[x][y]);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -672,12 +678,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs<T> g) {
 
     // epilogue: stores only
 #pragma unroll
-    for (int x = 0; x < 4; ++x)
+    for (int x = 0; x < FJ; ++x)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             T* cp = Cg + (long)(x * 16 + Num<T>::drow(l4, r)) * g.ldc;
 #pragma unroll
-            for (int y = 0; y < 4; ++y) cp[y * 16] = acc[x][y][r];
+            for (int y = 0; y < FI; ++y) cp[y * 16] = acc[x][y][r];
         }
 }
 

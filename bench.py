@@ -95,6 +95,48 @@ def pmc_traffic(kernel_substr: str = "gemm_nt_kernel<double, 0>"):
     return best
 
 
+def other_configs(local_rank: int) -> dict:
+    """Short measurements of the other BASELINE.json configs on one GPU (reported next to the headline,
+    never part of `value`): cfg 4 = 200 theta x N=4096 batched + nested-sampling driver, cfg 5 = Matern-5/2
+    N=65536 d=16 fp32 fit + prediction on 10k test points."""
+    from bayesianinference_amd import _lib, synthetic as syn
+    out = {}
+    try:
+        X, y = syn.make_dataset(4096, 8)
+        Th = syn.theta_batch(200, "se_ard", 8)
+        Th[:, -1] = np.maximum(Th[:, -1], 0.05)
+        h = _lib.Handle(X, y, "se_ard", device=local_rank)
+        h.loglik_batch(Th[:8])
+        h.loglik_batch(Th)
+        t0 = time.perf_counter()
+        _, info = h.loglik_batch(Th)
+        dt = time.perf_counter() - t0
+        out["cfg4_batch_200x4096_f64"] = {"evals_per_s": 200 / dt, "tflops": 200 * 4096 ** 3 / 3 / dt / 1e12,
+                                          "failed": int((info != 0).sum())}
+        h.close()
+    except Exception as exc:                                    # never let an extra break the headline
+        out["cfg4_error"] = repr(exc)
+    try:
+        n, d, m = 65536, 16, 10000
+        X, y = syn.make_dataset(n, d)
+        th = syn.default_theta("matern52_ard", d, dtype="f32")
+        h = _lib.Handle(X, y, "matern52_ard", dtype=32, device=local_rank)
+        h.loglik(th)
+        t0 = time.perf_counter()
+        info = h.fit(th)
+        tf = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        mu, var = h.predict(syn.make_test_points(m, d))
+        tp = time.perf_counter() - t0
+        out["cfg5_matern52_n65536_d16_f32"] = {"fit_ms": tf * 1e3, "cholesky_tflops": n ** 3 / 3 / tf / 1e12,
+                                               "predict_10k_ms": tp * 1e3, "info": int(info),
+                                               "finite": bool(np.all(np.isfinite(mu)) and np.all(var > 0))}
+        h.close()
+    except Exception as exc:
+        out["cfg5_error"] = repr(exc)
+    return out
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -109,6 +151,7 @@ def main() -> None:
                          "block-cyclic Cholesky (RCCL broadcast of factored panels), strong scaling.")
     ap.add_argument("--supertile", type=int, default=0, help="experiment: XCD-private 8x8 super-tile order")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the short BASELINE.json cfg-4 / cfg-5 measurements")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -209,6 +252,9 @@ def main() -> None:
             out["roofline"]["traffic"] = tr["bytes_per_launch"]
             out["roofline"]["traffic_unit"] = "HBM-side bytes per launch (rocprofv3 PMC, " + tr["source"] + ")"
             out["roofline"]["algorithmic_bytes_per_launch"] = syrk["bytes"] / max(syrk["launches"], 1)
+        if world == 1 and not args.no_extras:
+            h.close()                                           # free the 8.7 GB workspace first
+            out["other_configs"] = other_configs(local_rank)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(n, d)
         print(json.dumps(out), flush=True)

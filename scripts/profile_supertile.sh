@@ -5,9 +5,9 @@ OUT=$R/gpurun_out/supertile
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for ST in 0 1; do
-  timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch_$ST -o bench -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --supertile $ST > $OUT/fetch_$ST.log 2>&1
-  timeout 300 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/tcc_$ST -o bench -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --supertile $ST > $OUT/tcc_$ST.log 2>&1
-  timeout 300 python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --supertile $ST > $OUT/bench_$ST.json 2> $OUT/bench_$ST.err
+  timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch_$ST -o bench -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --supertile $ST > $OUT/fetch_$ST.log 2>&1
+  timeout 300 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/tcc_$ST -o bench -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --supertile $ST > $OUT/tcc_$ST.log 2>&1
+  timeout 300 python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-extras --supertile $ST > $OUT/bench_$ST.json 2> $OUT/bench_$ST.err
 done
 python3 - <<PY
 import csv, collections, json
