@@ -71,6 +71,9 @@ template <> struct Num<double> {
         return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
     }
     static __device__ __forceinline__ int drow(int l4, int r) { return l4 + 4 * r; }
+    // k index a lane group supplies in MFMA k-step kk such that accumulator register kk of a D-layout
+    // tile can be fed straight back as the B operand (row drow(l4, kk) of that tile)
+    static __device__ __forceinline__ int kidx(int kk, int l4) { return 4 * kk + l4; }
     static __device__ __forceinline__ double readlane(double v, int src) {
         int lo = __double2loint(v), hi = __double2hiint(v);
         lo = __builtin_amdgcn_readlane(lo, src);
@@ -88,6 +91,7 @@ template <> struct Num<float> {
         return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
     }
     static __device__ __forceinline__ int drow(int l4, int r) { return 4 * l4 + r; }
+    static __device__ __forceinline__ int kidx(int kk, int l4) { return 4 * l4 + kk; }
     static __device__ __forceinline__ float readlane(float v, int src) {
         return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
     }
@@ -273,9 +277,62 @@ __global__ __launch_bounds__(256) void kbuild_kernel(KBuildArgs<T> a) {
 // workgroup (look-ahead runs it concurrently with the trailing SYRK), and MFMA fragment reads
 // (lane -> row l&15, k = l>>4) are bank-conflict free.
 // ---------------------------------------------------------------------------------------------
+// developer instrumentation (scripts/micro/potrf_time.hip): phase stamps of workgroup 0, thread 0
+#ifdef GPHIP_TIMING
+__device__ long long g_stamps[64];
+#define GP_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_stamps[i] = clock64(); } while (0)
+#else
+#define GP_STAMP(i) do { } while (0)
+#endif
+
 constexpr int PT_LDS_ELEMS = 36 * 256 + TB;     // tiles + dinv[128]  (+ 2 doubles of reduction scratch)
 
 __device__ __forceinline__ int ptile(int bi, int bj) { return ((bi * (bi + 1) / 2) + bj) << 8; }
+
+// Block column PB of W = L^-1 (rows q = PB+1..7), computed by ONE wave with no barriers:
+//   W[q][PB] = -W_qq * sum_{r=PB}^{q-1} L[q][r] W[r][PB]
+// L tiles and the diagonal inverses W_rr are read from LDS; the W[r][PB] this wave has already
+// produced stay in registers in the MFMA D layout, which is exactly the B-operand layout of the
+// next product (Num<T>::kidx), and go straight to the Winv workspace.
+template <typename T, int PB>
+__device__ __forceinline__ void inv_block_column(const T* __restrict__ Ls, T* __restrict__ Wg, int l15, int l4) {
+    typedef typename Num<T>::acc_t acc_t;
+    constexpr int NQ = 7 - PB;
+    acc_t w[NQ > 0 ? NQ : 1];
+    const T* Wpp = Ls + ptile(PB, PB);
+#pragma unroll
+    for (int qq = 0; qq < NQ; ++qq) {
+        const int q = PB + 1 + qq;
+        acc_t sacc = (acc_t){0, 0, 0, 0};
+        {
+            const T* Lq = Ls + ptile(q, PB);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int k = Num<T>::kidx(kk, l4);
+                const T fb = (k >= l15) ? Wpp[l15 * 16 + k] : (T)0;              // W_pp(k, j = l15), lower
+                sacc = Num<T>::mfma(Lq[k * 16 + l15], fb, sacc);
+            }
+        }
+#pragma unroll
+        for (int rr = 0; rr < qq; ++rr) {
+            const T* Lqr = Ls + ptile(q, PB + 1 + rr);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+                sacc = Num<T>::mfma(Lqr[Num<T>::kidx(kk, l4) * 16 + l15], w[rr][kk], sacc);
+        }
+        const T* Wqq = Ls + ptile(q, q);
+        acc_t out = (acc_t){0, 0, 0, 0};
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int k = Num<T>::kidx(kk, l4);
+            const T fa = (l15 >= k) ? Wqq[k * 16 + l15] : (T)0;                  // W_qq(i = l15, k), lower
+            out = Num<T>::mfma(-fa, sacc[kk], out);
+        }
+        w[qq] = out;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Wg[(PB * 16 + l15) * TB + q * 16 + Num<T>::drow(l4, r)] = out[r];
+    }
+}
 
 template <typename T>
 __global__ __launch_bounds__(256) void potrf128_kernel(T* __restrict__ Abase, long ld, long bstride, int b,
@@ -297,11 +354,14 @@ __global__ __launch_bounds__(256) void potrf128_kernel(T* __restrict__ Abase, lo
             Ls[ptile(bi, bj) + tid] = Ad[(long)(bj * 16 + ec) * ld + bi * 16 + er];
     const T tol = (T)slotp[(long)slot * SLOTP + 3];
     bool bad = false;
+    GP_STAMP(0);
     __syncthreads();
+    GP_STAMP(1);
 
     // ------------------------------ factor phase ------------------------------
     for (int p = 0; p < 8; ++p) {
         T* Dpp = Ls + ptile(p, p);
+        GP_STAMP(2 + 3 * p);
         if (wave == 0) {                      // (a) 16x16 diagonal block, lane l15 owns row l15
             T a[16];
 #pragma unroll
@@ -327,6 +387,7 @@ __global__ __launch_bounds__(256) void potrf128_kernel(T* __restrict__ Abase, lo
             }
         }
         __syncthreads();
+        GP_STAMP(3 + 3 * p);
         if (p == 7) break;
         if (tid < TB - 16 * p - 16) {         // (b) rows below: x L_pp^T = a, one row per thread
             T* Xr = Ls + ptile(p + 1 + (tid >> 4), p) + (tid & 15);
@@ -344,6 +405,7 @@ __global__ __launch_bounds__(256) void potrf128_kernel(T* __restrict__ Abase, lo
             for (int c = 0; c < 16; ++c) Xr[c * 16] = x[c];
         }
         __syncthreads();
+        GP_STAMP(4 + 3 * p);
         {                                      // (c) trailing update C -= X X^T on MFMA
             const int t = 7 - p, ntile = t * (t + 1) / 2;
             for (int tt = wave; tt < ntile; tt += 4) {
@@ -363,6 +425,7 @@ __global__ __launch_bounds__(256) void potrf128_kernel(T* __restrict__ Abase, lo
         __syncthreads();
     }
 
+    GP_STAMP(30);
     // L back to HBM (lower-triangle tiles; diagonal tiles whole, their upper part is never read)
     for (int bi = 0; bi < 8; ++bi)
         for (int bj = 0; bj <= bi; ++bj)
@@ -374,6 +437,7 @@ __global__ __launch_bounds__(256) void potrf128_kernel(T* __restrict__ Abase, lo
         if (tid < TB && lane == 0) red[wave] = lg;
     }
 
+    GP_STAMP(31);
     // ------------------------------ inverse phase ------------------------------
     {   // (i) the eight 16x16 diagonal inverses: thread = (block, column)
         T w[16];
@@ -397,79 +461,33 @@ __global__ __launch_bounds__(256) void potrf128_kernel(T* __restrict__ Abase, lo
         }
         __syncthreads();
     }
-    for (int pb = 6; pb >= 0; --pb) {          // (ii) block column pb, rows q = pb+1..7
-        const int t = 7 - pb;
-        const T* Wpp = Ls + ptile(pb, pb);
-        // step 1: T'_r = T_r W_pp  (W_pp lower triangular: mask k < j)
-        acc_t t1[2];
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            t1[s] = (acc_t){0, 0, 0, 0};
-            const int rr = wave + 4 * s;
-            if (rr < t) {
-                const T* Tr = Ls + ptile(pb + 1 + rr, pb);
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-                    const int k = 4 * kk + l4;
-                    const T fa = Tr[k * 16 + l15];                               // T_r(i=l15, k)
-                    const T fb = (k >= l15) ? Wpp[l15 * 16 + k] : (T)0;          // W_pp(k, j=l15)
-                    t1[s] = Num<T>::mfma(fa, fb, t1[s]);
-                }
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const int rr = wave + 4 * s;
-            if (rr < t) {
-                T* Tr = Ls + ptile(pb + 1 + rr, pb);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) Tr[l15 * 16 + Num<T>::drow(l4, r)] = t1[s][r];
-            }
-        }
-        __syncthreads();
-        // step 2: W_q,pb = - sum_{r=pb+1..q} W_qr T'_r   (W_qq lower triangular: mask k > i)
-        acc_t t2[2];
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            t2[s] = (acc_t){0, 0, 0, 0};
-            const int qq = wave + 4 * s;
-            if (qq < t) {
-                const int q = pb + 1 + qq;
-                for (int r = pb + 1; r <= q; ++r) {
-                    const T* Wqr = Ls + ptile(q, r);
-                    const T* Tr = Ls + ptile(r, pb);
-#pragma unroll
-                    for (int kk = 0; kk < 4; ++kk) {
-                        const int k = 4 * kk + l4;
-                        T fa = Wqr[k * 16 + l15];                                // W_qr(i=l15, k)
-                        if (r == q && k > l15) fa = (T)0;
-                        const T fb = Tr[l15 * 16 + k];                           // T'_r(k, j=l15)
-                        t2[s] = Num<T>::mfma(fa, fb, t2[s]);
-                    }
-                }
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const int qq = wave + 4 * s;
-            if (qq < t) {
-                T* Wq = Ls + ptile(pb + 1 + qq, pb);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) Wq[l15 * 16 + Num<T>::drow(l4, r)] = -t2[s][r];
-            }
-        }
-        __syncthreads();
-    }
-    // W to the workspace, dense column-major 128x128 with an explicit zero upper triangle
+    GP_STAMP(32);
+    // (ii) the off-diagonal blocks: block columns are independent, wave w owns columns w and 7-w
     T* Wg = Winv + ((long)slot * nt + b) * TB * TB;
+    {
+        const int uw = __builtin_amdgcn_readfirstlane(wave);
+        if (uw == 0) {
+            inv_block_column<T, 0>(Ls, Wg, l15, l4);
+        } else if (uw == 1) {
+            inv_block_column<T, 1>(Ls, Wg, l15, l4);
+            inv_block_column<T, 6>(Ls, Wg, l15, l4);
+        } else if (uw == 2) {
+            inv_block_column<T, 2>(Ls, Wg, l15, l4);
+            inv_block_column<T, 5>(Ls, Wg, l15, l4);
+        } else {
+            inv_block_column<T, 3>(Ls, Wg, l15, l4);
+            inv_block_column<T, 4>(Ls, Wg, l15, l4);
+        }
+    }
+    GP_STAMP(33);
+    // diagonal blocks of W and an explicit zero upper triangle (the blocks below went out above)
     for (int bi = 0; bi < 8; ++bi)
-        for (int bj = 0; bj < 8; ++bj) {
+        for (int bj = bi; bj < 8; ++bj) {
             T v = (T)0;
-            if (bi > bj || (bi == bj && er >= ec)) v = Ls[ptile(bi, bj) + tid];
+            if (bi == bj && er >= ec) v = Ls[ptile(bi, bj) + tid];
             Wg[(bj * 16 + ec) * TB + bi * 16 + er] = v;
         }
+    GP_STAMP(34);
     if (tid == 0) {
         partial[(long)slot * nt + b] = red[0] + red[1];
         if (bad) info[slot] = 1;
@@ -541,7 +559,11 @@ template <> __device__ __forceinline__ int lds_off<float>(int k, int row) {
 // NWI x NWJ = wave grid of the workgroup over the 128x128 tile: 2x2 (256 threads, 64x64 per wave, the
 // throughput shape) or 4x4 (1024 threads, 32x32 per wave: a quarter of the MFMA chain per wave, for
 // the latency-bound launches of the panel stream where tiles <= CUs).
-template <typename T, int ROLE, int NWI, int NWJ>
+// NBUF = LDS stages: 2 = one stage ahead, vmcnt(0) + barrier per stage (2 workgroups per CU, the
+// throughput configuration); 4 = three stages ahead with COUNTED vmcnt waits and a raw s_barrier
+// (one workgroup per CU): for launches with <= 1 tile per CU, where a tile pass is bound by the
+// DMA round trip of every stage rather than by the MFMA pipe.
+template <typename T, int ROLE, int NWI, int NWJ, int NBUF>
 __global__ __launch_bounds__(64 * NWI * NWJ, (NWI * NWJ == 4) ? 2 : 4) void gemm_nt_kernel(GemmArgs<T> g) {
     constexpr int NW = NWI * NWJ, FI = 8 / NWI, FJ = 8 / NWJ;      // MFMA tiles per wave along i / j
     extern __shared__ double smem_raw[];       // [2 stages][I tile | J tile]
@@ -625,30 +647,27 @@ __global__ __launch_bounds__(64 * NWI * NWJ, (NWI * NWJ == 4) ? 2 : 4) void gemm
             wi * (16 * FI) + (lane & 15);
     const int l4 = lane >> 4;
     const int nk = g.K / GK;
-    stage(0, 0);
-    // Update roles start the accumulators AT C (loads fly with the first DMA stage) and feed the
-    // MFMA the negated J fragment, so acc ends as C - A B^T and the epilogue is stores only.
+    // Update roles start the accumulators AT C and feed the MFMA the negated J fragment, so acc ends
+    // as C - A B^T and the epilogue is stores only.
     const bool from_zero = (ROLE == 2) || (ROLE == 3 && g.mode == 1);
     acc_t acc[FJ][FI];
+    auto load_c = [&]() {
 #pragma unroll
-    for (int x = 0; x < FJ; ++x)
+        for (int x = 0; x < FJ; ++x)
 #pragma unroll
-        for (int y = 0; y < FI; ++y) {
-            if (from_zero) {
-                acc[x][y] = (acc_t){0, 0, 0, 0};
-            } else {
+            for (int y = 0; y < FI; ++y) {
+                if (from_zero) {
+                    acc[x][y] = (acc_t){0, 0, 0, 0};
+                } else {
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    acc[x][y][r] = Cg[(long)(x * 16 + Num<T>::drow(l4, r)) * g.ldc + y * 16];
+                    for (int r = 0; r < 4; ++r)
+                        acc[x][y][r] = Cg[(long)(x * 16 + Num<T>::drow(l4, r)) * g.ldc + y * 16];
+                }
             }
-        }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    for (int kb = 0; kb < nk; ++kb) {
-        const int cur = kb & 1;
-        if (kb + 1 < nk) stage(kb + 1, cur ^ 1);       // DMA of the next stage flies under the MFMAs
-        const T* Is = smem + cur * STAGE + wi * (16 * FI) + (lane & 15);
-        const T* Js = smem + cur * STAGE + JOFF;
+    };
+    auto compute = [&](int buf) {
+        const T* Is = smem + buf * STAGE + wi * (16 * FI) + (lane & 15);
+        const T* Js = smem + buf * STAGE + JOFF;
 #pragma unroll
         for (int kk = 0; kk < GK / 4; ++kk) {
             T fi[FI], fj[FJ];
@@ -672,8 +691,35 @@ __global__ __launch_bounds__(64 * NWI * NWJ, (NWI * NWJ == 4) ? 2 : 4) void gemm
 #pragma unroll
                 for (int y = 0; y < FI; ++y) acc[x][y] = Num<T>::mfma(fj[x], fi[y], acc[x][y]);
         }
+    };
+    if constexpr (NBUF == 2) {
+        stage(0, 0);
+        load_c();                                          // C loads fly with the first DMA stage
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        for (int kb = 0; kb < nk; ++kb) {
+            const int cur = kb & 1;
+            if (kb + 1 < nk) stage(kb + 1, cur ^ 1);       // DMA of the next stage flies under the MFMAs
+            compute(cur);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    } else {
+        // deep pipeline: NBUF-1 stages in flight; every wave issues IPS DMA instructions per stage
+        constexpr int AHEAD = NBUF - 1;
+        constexpr int IPS = 2 * ((16 + NW - 1) / NW);      // I + J instructions per wave per stage
+        static_assert(NBUF == 4 && IPS == 2, "counted waits below are written for 4 buffers, 16 waves");
+        load_c();
+        for (int st = 0; st < AHEAD && st < nk; ++st) stage(st, st);
+        for (int kb = 0; kb < nk; ++kb) {
+            const int rem = nk - 1 - kb;                   // stages issued beyond kb (capped at AHEAD-1)
+            if (rem >= 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else if (rem == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                  // stage kb landed for every wave; buffer (kb-1)%4 is free
+            if (kb + AHEAD < nk) stage(kb + AHEAD, (kb + AHEAD) % NBUF);
+            compute(kb % NBUF);
+        }
     }
 
     // epilogue: stores only

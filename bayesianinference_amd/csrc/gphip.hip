@@ -64,8 +64,7 @@ struct gphip_ctx {
     int* hInfo = nullptr;
     // options
     int panel = 4, profile = 0, swizzle = 1, max_slots = 256, lookahead = 1, supertile = 0;
-    int syrk_waves = 4, panel_waves = 4;   // 4 | 16 waves per gemm workgroup (16 = latency shape, measured
-                                           // <= 7 % at N=4096 and -7 % on the SYRK: off); panel_waves 0 = by tile count
+    int latency_gemm = 1, latency_tiles = 256;   // launches of <= latency_tiles tiles use the latency GEMM shape
     // fitted state (slot 0)
     bool fitted = false;
     std::vector<double> theta_fit;
@@ -287,13 +286,13 @@ void launch_gemm(gphip_ctx* h, int cls, T* C, long ldc, long cbs, const T* A, lo
     const double bytes = (double)sizeof(T) * nslots * (2.0 * TB * TB * g.ntiles + (double)(tri ? H : H + W) * TB * K);
     ProfScope ps(h, cls == 6 ? 3 : cls, flops, bytes);
     const dim3 grid(grid_x, nslots);
-    // wave grid: 2x2 (throughput) or 4x4 (latency: launches with few tiles per CU)
-    const bool wide = (cls == 4) ? (h->syrk_waves == 16)
-                                 : (h->panel_waves == 16 || (h->panel_waves == 0 && (long)g.ntiles * nslots <= 1024));
-#define GEMM_LAUNCH(ROLE)                                                                                     \
-    do {                                                                                                      \
-        if (wide) hipLaunchKernelGGL((gemm_nt_kernel<T, ROLE, 4, 4>), grid, dim3(1024), GEMM_LDS, h->cs, g);   \
-        else hipLaunchKernelGGL((gemm_nt_kernel<T, ROLE, 2, 2>), grid, dim3(256), GEMM_LDS, h->cs, g);         \
+    // shape: 2x2 waves / 2 LDS stages (throughput, 2 workgroups per CU) or, for launches with at most one
+    // tile per CU, 4x4 waves / 4 LDS stages with counted DMA waits (latency)
+    const bool lat = h->latency_gemm && !g.super && (long)grid_x * nslots <= h->latency_tiles;
+#define GEMM_LAUNCH(ROLE)                                                                                          \
+    do {                                                                                                           \
+        if (lat) hipLaunchKernelGGL((gemm_nt_kernel<T, ROLE, 4, 4, 4>), grid, dim3(1024), 2 * GEMM_LDS, h->cs, g);  \
+        else hipLaunchKernelGGL((gemm_nt_kernel<T, ROLE, 2, 2, 2>), grid, dim3(256), GEMM_LDS, h->cs, g);           \
     } while (0)
     if (cls == 6) GEMM_LAUNCH(3);
     else if (mode == 1) GEMM_LAUNCH(2);
@@ -489,10 +488,10 @@ int set_func_attrs(gphip_ctx* h) {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(potrf128_kernel<T>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)potrf_lds<T>()));
 #define GEMM_ATTR(ROLE)                                                                                   \
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<T, ROLE, 2, 2>),                \
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<T, ROLE, 2, 2, 2>),             \
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS));                  \
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<T, ROLE, 4, 4>),                \
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<T, ROLE, 4, 4, 4>),             \
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * GEMM_LDS)));
     GEMM_ATTR(0) GEMM_ATTR(1) GEMM_ATTR(2) GEMM_ATTR(3)
 #undef GEMM_ATTR
     return GPHIP_OK;
@@ -1149,8 +1148,8 @@ int gphip_set_option(gphip_handle h, const char* name, double value) {
     else if (!strcmp(name, "xcd_swizzle")) h->swizzle = v;
     else if (!strcmp(name, "lookahead")) h->lookahead = v;
     else if (!strcmp(name, "supertile")) h->supertile = v;
-    else if (!strcmp(name, "syrk_waves")) h->syrk_waves = v;
-    else if (!strcmp(name, "panel_waves")) h->panel_waves = v;
+    else if (!strcmp(name, "latency_gemm")) h->latency_gemm = v;
+    else if (!strcmp(name, "latency_tiles")) h->latency_tiles = v;
     else if (!strcmp(name, "max_slots")) { if (v < 1) return fail(h, GPHIP_ERR_ARG, "max_slots < 1"); h->max_slots = v; }
     else return fail(h, GPHIP_ERR_ARG, "unknown option");
     return GPHIP_OK;
