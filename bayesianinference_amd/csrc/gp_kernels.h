@@ -362,7 +362,44 @@ __global__ __launch_bounds__(256) void potrf128_kernel(T* __restrict__ Abase, lo
     for (int p = 0; p < 8; ++p) {
         T* Dpp = Ls + ptile(p, p);
         GP_STAMP(2 + 3 * p);
-        if (wave == 0) {                      // (a) 16x16 diagonal block, lane l15 owns row l15
+        if (wave == 0 && sizeof(T) == 8) {
+            // (a) fp64: the 16x16 diagonal block lives in the MFMA D layout -- lane (l15, l4) holds
+            // A[i = l15][j = l4 + 4r], r = 0..3 -- so after every 4 pivots the rank-4 update of the
+            // remaining columns is ONE v_mfma_f64_16x16x4 whose A and B operands are the lane's own
+            // column value.  Inside a group of 4 columns the few updates use ds_bpermute.
+            double a[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a[r] = (double)Dpp[(l4 + 4 * r) * 16 + l15];
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int c = 4 * s4 + t;
+                    double dj = Num<double>::readlane(a[s4], 16 * t + c);
+                    if (!(dj > (double)tol)) { bad = true; dj = 1.0; }
+                    const double rs = rsqrt(dj);
+                    const double scaled = (l15 == c) ? dj * rs : a[s4] * rs;
+                    a[s4] = (l4 == t) ? scaled : a[s4];
+                    if (lane == 0) dinv[16 * p + c] = (T)rs;
+                    if (t < 3) {
+                        const double xi = __shfl(a[s4], 16 * t + l15);          // L[i = l15][c]
+                        const double xc = __shfl(a[s4], 16 * t + 4 * s4 + l4);  // L[c' = 4 s4 + l4][c]
+                        if (l4 > t) a[s4] = __builtin_fma(-xi, xc, a[s4]);
+                    }
+                }
+                if (s4 < 3) {
+                    const double xop = (l15 >= 4 * s4 + l4) ? a[s4] : 0.0;      // L is zero above its diagonal
+                    d4 cacc = (d4){a[0], a[1], a[2], a[3]};
+                    cacc = __builtin_amdgcn_mfma_f64_16x16x4f64(-xop, xop, cacc, 0, 0, 0);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (r > s4) a[r] = cacc[r];
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (l15 >= l4 + 4 * r) Dpp[(l4 + 4 * r) * 16 + l15] = (T)a[r];
+        } else if (wave == 0) {               // (a) fp32: lane l15 owns row l15, v_readlane broadcasts
             T a[16];
 #pragma unroll
             for (int c = 0; c < 16; ++c) a[c] = Dpp[c * 16 + l15];
