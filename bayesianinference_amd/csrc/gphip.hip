@@ -288,7 +288,9 @@ void launch_gemm(gphip_ctx* h, int cls, T* C, long ldc, long cbs, const T* A, lo
     const dim3 grid(grid_x, nslots);
     // shape: 2x2 waves / 2 LDS stages (throughput, 2 workgroups per CU) or, for launches with at most one
     // tile per CU, 4x4 waves / 4 LDS stages with counted DMA waits (latency)
-    const bool lat = h->latency_gemm && !g.super && (long)grid_x * nslots <= h->latency_tiles;
+    // (measured: -8 % per evaluation at N=4096, neutral at 8192, +5 % at 32768 where its 147 KB of LDS keeps
+    //  trailing-SYRK workgroups off the CU -- so it is used for small problems only)
+    const bool lat = h->latency_gemm && !g.super && h->Nt <= 48 && (long)grid_x * nslots <= h->latency_tiles;
 #define GEMM_LAUNCH(ROLE)                                                                                          \
     do {                                                                                                           \
         if (lat) hipLaunchKernelGGL((gemm_nt_kernel<T, ROLE, 4, 4, 4>), grid, dim3(1024), 2 * GEMM_LDS, h->cs, g);  \
