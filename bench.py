@@ -73,7 +73,7 @@ def cpu_baseline(n_full: int, d: int, sample_n: int = 4096, reps: int = 2) -> di
                       f"(N/{sample_n})^3={scale:.0f} to N={n_full}"}
 
 
-def pmc_traffic(kernel_substr: str = "gemm_nt_kernel<double, 0>"):
+def pmc_traffic(kernel_substr: str = "gemm_nt_kernel<double, 0,"):
     """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
     (profiles/*_pmc_summary.csv: separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same command,
     FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM).  None if no summary is present."""
@@ -241,7 +241,7 @@ def main() -> None:
                        "N": n, "d": d, "kernel": "se_ard", "parallelism": (f"1-D block-cyclic Cholesky over {world} GPUs (RCCL panel broadcast)" if sharded
                                        else f"theta-sharded x{world}")},
             "cholesky_tflops_per_gpu": chol_flops * args.steps / dt / 1e12 / (world if sharded else 1),
-            "roofline": {"bound": "mfma", "kernel": "gemm_nt_kernel<double, 0> (trailing SYRK, v_mfma_f64_16x16x4_f64)",
+            "roofline": {"bound": "mfma", "kernel": "gemm_nt_kernel<double, 0, 2, 2, 2> (trailing SYRK, v_mfma_f64_16x16x4_f64)",
                          "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
                          "launches": int(syrk["launches"]), "avg_launch_ms": syrk["ms"] / max(syrk["launches"], 1),
