@@ -912,4 +912,33 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(GradArgs<T> a) {
     }
 }
 
+// Null kernel Function[0] (BGP:25-27, 156-159): K = diag(sn^2), so the quadratic form is
+// sum (y_i - mu)^2 / sn^2.  One workgroup per theta, fixed-order reduction (deterministic):
+// out[b] = { sum (y_i - mu_b), sum (y_i - mu_b)^2 }.
+template <typename T>
+__global__ __launch_bounds__(1024) void null_reduce_kernel(const T* __restrict__ y, int n, const double* __restrict__ mu,
+                                                           double* __restrict__ out) {
+    __shared__ double s1[16], s2[16];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const double m = mu[b];
+    double a1 = 0.0, a2 = 0.0;
+    for (int i = tid; i < n; i += 1024) {
+        const double r = (double)y[i] - m;
+        a1 += r;
+        a2 = __builtin_fma(r, r, a2);
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        a1 += __shfl_down(a1, off);
+        a2 += __shfl_down(a2, off);
+    }
+    if (lane == 0) { s1[wave] = a1; s2[wave] = a2; }
+    __syncthreads();
+    if (tid == 0) {
+        double t1 = 0.0, t2 = 0.0;
+        for (int w = 0; w < 16; ++w) { t1 += s1[w]; t2 += s2[w]; }
+        out[2 * b] = t1;
+        out[2 * b + 1] = t2;
+    }
+}
+
 }  // namespace gphip

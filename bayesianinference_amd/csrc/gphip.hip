@@ -53,7 +53,8 @@ struct gphip_ctx {
     bool dist_theta_ok = true;
     int64_t N = 0, d = 0, Npad = 0, Nt = 0, ld = 0;
     int kernel_id = 0, mean_id = 0, nl = 0, p = 0, kt = 0;
-    double sum_y = 0, sum_y2 = 0;
+    double *dNullMu = nullptr, *dNullOut = nullptr;          // null-kernel path: per-theta mu and the two sums
+    int null_cap = 0;
     void *dXt = nullptr, *dY = nullptr;                     // typed: [d][Npad], [Npad]
     // batch workspace
     int slots = 0;
@@ -420,17 +421,51 @@ bool stage_theta(gphip_ctx* h, int slot, const double* th) {
     return ok;
 }
 
-// null kernel (BGP:25-27, 156-159): K = diag(sn^2); O(1) from the cached sums of y
-void null_kernel_eval(const gphip_ctx* h, const double* th, double* out, double* parts, int* info) {
-    const double sn = th[0];
-    const double mu = (h->mean_id == GPHIP_MEAN_CONST) ? th[1] : 0.0;
-    const double v = sn * sn;
-    const double logdet = (double)h->N * std::log(std::fabs(v));
-    const double quad = (h->sum_y2 - 2.0 * mu * h->sum_y + (double)h->N * mu * mu) / v;
-    const double ll = -0.5 * ((double)h->N * LOG_TWO_PI + logdet + quad);
-    *info = std::isfinite(ll) ? (v > 0.0 ? GPHIP_INFO_OK : GPHIP_INFO_NOT_SPD) : GPHIP_INFO_NAN;
-    *out = ll;
-    if (parts) { parts[0] = logdet; parts[1] = quad; }
+template <typename T>
+int queue_null_reduce(gphip_ctx* h, int B) {
+    hipLaunchKernelGGL(null_reduce_kernel<T>, dim3(B), dim3(1024), 0, h->stream, (const T*)h->dY, (int)h->N, h->dNullMu,
+                       h->dNullOut);
+    return 0;
+}
+
+// null kernel Function[0] (BGP:25-27, 156-159): K = diag(sn^2).  The residual sums are reduced on the
+// device from the resident y (one workgroup per theta); the scalar epilogue is the usual host side of
+// the ABI.  grad (optional, B x p): d/dsn = (quad - N)/sn, d/dmu = sum(y - mu)/sn^2.
+int null_kernel_batch(gphip_ctx* h, const double* Theta, int B, double* out, double* parts, int* info, double* grad) {
+    if (B > h->null_cap) {
+        (void)hipFree(h->dNullMu); (void)hipFree(h->dNullOut);
+        h->dNullMu = h->dNullOut = nullptr; h->null_cap = 0;
+        HIPCHK(hipMalloc(&h->dNullMu, (size_t)B * 8));
+        HIPCHK(hipMalloc(&h->dNullOut, (size_t)B * 16));
+        h->null_cap = B;
+    }
+    std::vector<double> mu((size_t)B), sums((size_t)2 * B);
+    for (int s = 0; s < B; ++s) {
+        const double m = (h->mean_id == GPHIP_MEAN_CONST) ? Theta[(size_t)s * h->p + 1] : 0.0;
+        mu[(size_t)s] = std::isfinite(m) ? m : 0.0;
+    }
+    HIPCHK(hipMemcpyAsync(h->dNullMu, mu.data(), (size_t)B * 8, hipMemcpyHostToDevice, h->stream));
+    DISPATCH(h, queue_null_reduce, h, B);
+    HIPCHK(hipMemcpyAsync(sums.data(), h->dNullOut, (size_t)B * 16, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipGetLastError());
+    for (int s = 0; s < B; ++s) {
+        const double* th = Theta + (size_t)s * h->p;
+        const double sn = th[0], v = sn * sn;
+        const double logdet = (double)h->N * std::log(std::fabs(v));
+        const double quad = sums[(size_t)2 * s + 1] / v;
+        const double ll = -0.5 * ((double)h->N * LOG_TWO_PI + logdet + quad);
+        bool finite_theta = true;
+        for (int i = 0; i < h->p; ++i) finite_theta = finite_theta && std::isfinite(th[i]);
+        info[s] = (finite_theta && std::isfinite(ll)) ? (v > 0.0 ? GPHIP_INFO_OK : GPHIP_INFO_NOT_SPD) : GPHIP_INFO_NAN;
+        out[s] = ll;
+        if (parts) { parts[2 * s] = logdet; parts[2 * s + 1] = quad; }
+        if (grad) {
+            grad[(size_t)s * h->p] = (quad - (double)h->N) / sn;
+            if (h->mean_id == GPHIP_MEAN_CONST) grad[(size_t)s * h->p + 1] = sums[(size_t)2 * s] / v;
+        }
+    }
+    return GPHIP_OK;
 }
 
 int eval_chunk(gphip_ctx* h, const double* Theta, int nb, double* out, double* parts, int* info) {
@@ -469,11 +504,7 @@ int eval_batch(gphip_ctx* h, const double* Theta, int B, int p, double* out, dou
     if (B <= 0) return GPHIP_OK;
     std::lock_guard<std::recursive_mutex> lk(h->mu);
     HIPCHK(hipSetDevice(h->device));
-    if (h->kernel_id == GPHIP_KERNEL_NULL) {
-        for (int s = 0; s < B; ++s)
-            null_kernel_eval(h, Theta + (size_t)s * p, out + s, parts ? parts + 2 * s : nullptr, info + s);
-        return GPHIP_OK;
-    }
+    if (h->kernel_id == GPHIP_KERNEL_NULL) return null_kernel_batch(h, Theta, B, out, parts, info, nullptr);
     int rc = ensure_slots(h, B);
     if (rc) return rc;
     h->fitted = false;
@@ -708,7 +739,6 @@ int gphip_create(const void* X, const void* y, int64_t N, int64_t d, int kernel_
     h->p = (kernel_id == GPHIP_KERNEL_NULL ? 1 : h->nl + 2) + (mean_id == GPHIP_MEAN_CONST ? 1 : 0);
     const double* Xd = static_cast<const double*>(X);
     const double* yd = static_cast<const double*>(y);
-    for (int64_t i = 0; i < N; ++i) { h->sum_y += yd[i]; h->sum_y2 += yd[i] * yd[i]; }
     auto bail = [&](int code) { gphip_destroy(h); return code; };
     if (hipSetDevice(h->device) != hipSuccess) return bail(GPHIP_ERR_HIP);
     {
@@ -741,6 +771,7 @@ int gphip_destroy(gphip_handle h) {
     (void)hipFree(h->dXt); (void)hipFree(h->dY);
     (void)hipFree(h->dV); (void)hipFree(h->dXsT); (void)hipFree(h->dXsS); (void)hipFree(h->dMean);
     (void)hipFree(h->dVar); (void)hipFree(h->dAlpha); (void)hipFree(h->dGacc);
+    (void)hipFree(h->dNullMu); (void)hipFree(h->dNullOut);
     for (auto e : h->pool) (void)hipEventDestroy(e);
     for (auto e : h->sync_events) (void)hipEventDestroy(e);
     if (h->own_streams) {
@@ -775,15 +806,10 @@ int gphip_loglik_batch(gphip_handle h, const double* Theta, int B, int p, double
 int gphip_loglik_grad(gphip_handle h, const double* theta, int p, double* out, double* grad, int* info) {
     if (!h || !theta || !out || !grad || !info) return fail(h, GPHIP_ERR_ARG, "null argument");
     if (h->kernel_id == GPHIP_KERNEL_NULL) {
-        // closed form for K = diag(sn^2): d/dsn = -N/sn + quad/sn, d/dmu = sum(y - mu)/sn^2
         std::lock_guard<std::recursive_mutex> lk(h->mu);
         if (p != h->p) return fail(h, GPHIP_ERR_DIM, "theta has the wrong length");
-        double parts[2];
-        null_kernel_eval(h, theta, out, parts, info);
-        const double sn = theta[0], mu = (h->mean_id == GPHIP_MEAN_CONST) ? theta[1] : 0.0;
-        grad[0] = (-(double)h->N + parts[1]) / sn;
-        if (h->mean_id == GPHIP_MEAN_CONST) grad[1] = (h->sum_y - (double)h->N * mu) / (sn * sn);
-        return GPHIP_OK;
+        HIPCHK(hipSetDevice(h->device));
+        return null_kernel_batch(h, theta, 1, out, nullptr, info, grad);
     }
     std::lock_guard<std::recursive_mutex> lk(h->mu);
     int rc = eval_batch(h, theta, 1, p, out, nullptr, info);
