@@ -1,0 +1,12 @@
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bayesianinference_amd import _lib, synthetic as syn
+n = int(sys.argv[1]); la = int(sys.argv[2])
+X, y = syn.make_dataset(n, 8)
+th = syn.default_theta("se_ard", 8)
+h = _lib.Handle(X, y, "se_ard")
+h.set_option("lookahead", la)
+for _ in range(4):
+    h.loglik(th)
+h.close()
