@@ -270,11 +270,16 @@ class Handle:
         th = np.ascontiguousarray(np.asarray(theta, dtype=np.float64).ravel())
         self._check(self._lib.gphip_dist_begin(self._h, _d(th), th.size, rank, world))
 
-    def dist_factor_panel(self, k: int, packed_ptr: int):
-        self._check(self._lib.gphip_dist_factor_panel(self._h, k, C.c_void_p(packed_ptr)))
+    @staticmethod
+    def _dev_ptr(packed) -> int:
+        """device address of a packed-panel buffer: a torch tensor (data_ptr) or a raw integer"""
+        return int(packed.data_ptr()) if hasattr(packed, "data_ptr") else int(packed)
 
-    def dist_update(self, k: int, packed_ptr: int, j_first: int, j_last: int, on_panel_stream: bool):
-        self._check(self._lib.gphip_dist_update(self._h, k, C.c_void_p(packed_ptr), j_first, j_last,
+    def dist_factor_panel(self, k: int, packed):
+        self._check(self._lib.gphip_dist_factor_panel(self._h, k, C.c_void_p(self._dev_ptr(packed))))
+
+    def dist_update(self, k: int, packed, j_first: int, j_last: int, on_panel_stream: bool):
+        self._check(self._lib.gphip_dist_update(self._h, k, C.c_void_p(self._dev_ptr(packed)), j_first, j_last,
                                                 int(on_panel_stream)))
 
     def dist_end(self):

@@ -41,7 +41,8 @@ class TorchDistComm:
 
     def allreduce_scalars(self, vals: dict):
         import torch
-        t = torch.tensor(vals[self.rank], dtype=torch.float64, device="cuda")
+        dev = "cuda" if self.dist.get_backend() == "nccl" else "cpu"
+        t = torch.tensor(vals[self.rank], dtype=torch.float64, device=dev)
         s = t.clone()
         self.dist.all_reduce(s[:2], op=self.dist.ReduceOp.SUM)
         self.dist.all_reduce(s[2:], op=self.dist.ReduceOp.MAX)
@@ -66,8 +67,53 @@ class LoopbackComm:
         return np.concatenate([arr[:, :2].sum(axis=0), arr[:, 2:].max(axis=0)])
 
 
+class _HostStream:
+    """Stand-in for torch.cuda.Stream when the step backend is synchronous (CPU schedule tests):
+    every step has completed when its call returns, so waits are no-ops."""
+    cuda_stream = 0
+
+    def wait_event(self, ev):
+        pass
+
+    def wait_stream(self, st):
+        pass
+
+
+class _HostEvent:
+    def record(self, stream=None):
+        pass
+
+
+class _GpuRuntime:
+    def __init__(self, torch, device):
+        self.torch, self.device = torch, device
+
+    def stream(self, high_priority=False):
+        return self.torch.cuda.Stream(device=self.device, priority=-1 if high_priority else 0)
+
+    def event(self):
+        return self.torch.cuda.Event()
+
+    def on(self, stream):
+        return self.torch.cuda.stream(stream)
+
+
+class _HostRuntime:
+    def stream(self, high_priority=False):
+        return _HostStream()
+
+    def event(self):
+        return _HostEvent()
+
+    def on(self, stream):
+        import contextlib
+        return contextlib.nullcontext()
+
+
 class DistributedCholesky:
-    """handles: {rank: _lib.Handle} for the ranks local to this process (one in SPMD mode)."""
+    """handles: {rank: step backend} for the ranks local to this process (one in SPMD mode).  A step
+    backend is a `_lib.Handle` (HIP kernels; device="cuda") or any object with the same dist_* methods
+    taking torch tensors for the packed panels (the CPU schedule tests use a numpy one; device="cpu")."""
 
     def __init__(self, handles: dict, comm, device=None):
         import torch
@@ -75,16 +121,21 @@ class DistributedCholesky:
         self.handles = handles
         self.comm = comm
         self.world = comm.world
-        self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+        if device == "cpu":
+            self.device = torch.device("cpu")
+            self.rt = _HostRuntime()
+        else:
+            self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+            self.rt = _GpuRuntime(torch, self.device)
         any_h = next(iter(handles.values()))
         self.N = any_h.N
         self.nouter = any_h.dist_num_panels()
         self.shapes = [any_h.dist_panel_shape(k) for k in range(self.nouter)]
         self.main, self.panel, self.commst = {}, {}, {}
         for r, h in handles.items():
-            self.main[r] = torch.cuda.Stream(device=self.device)
-            self.panel[r] = torch.cuda.Stream(device=self.device, priority=-1)
-            self.commst[r] = torch.cuda.Stream(device=self.device)
+            self.main[r] = self.rt.stream()
+            self.panel[r] = self.rt.stream(high_priority=True)
+            self.commst[r] = self.rt.stream()
             h.set_streams(self.main[r].cuda_stream, self.panel[r].cuda_stream)
         nmax = max(r_ * c_ for r_, c_ in self.shapes)
         # three rotating packed-panel buffers per local rank: panel k+1 lands while panel k is read
@@ -111,9 +162,9 @@ class DistributedCholesky:
             o = self.owner(k)
             packed_ev = None
             if o in H:
-                with torch.cuda.stream(self.panel[o]):
-                    H[o].dist_factor_panel(k, view(o, k).data_ptr())
-                    packed_ev = torch.cuda.Event()
+                with self.rt.on(self.panel[o]):
+                    H[o].dist_factor_panel(k, view(o, k))
+                    packed_ev = self.rt.event()
                     packed_ev.record(self.panel[o])
             # every local rank's comm stream: wait until its copy of the buffer is free (REST(k-3)
             # was its last reader) and, on the owner, until the pack has finished
@@ -126,26 +177,26 @@ class DistributedCholesky:
                     self.commst[r].wait_event(packed_ev)
             if len(H) == 1:
                 r = next(iter(H))
-                with torch.cuda.stream(self.commst[r]):
+                with self.rt.on(self.commst[r]):
                     work = self.comm.broadcast({r: view(r, k)}, o)
                     if work is not None:
                         work.wait()                            # comm stream waits for RCCL; host does not block
-                    ev = torch.cuda.Event()
+                    ev = self.rt.event()
                     ev.record(self.commst[r])
                     ev_bcast[r][k] = ev
             else:                                              # loopback: copies issued from each receiver's stream
                 for r in H:
-                    with torch.cuda.stream(self.commst[r]):
+                    with self.rt.on(self.commst[r]):
                         if r != o:
                             view(r, k).copy_(view(o, k), non_blocking=True)
-                        ev = torch.cuda.Event()
+                        ev = self.rt.event()
                         ev.record(self.commst[r])
                         ev_bcast[r][k] = ev
 
         for r, h in H.items():
-            with torch.cuda.stream(self.main[r]):
+            with self.rt.on(self.main[r]):
                 h.dist_begin(theta, r, self.world)
-                built = torch.cuda.Event()
+                built = self.rt.event()
                 built.record(self.main[r])
             self.panel[r].wait_event(built)
         factor_and_broadcast(0)
@@ -156,15 +207,15 @@ class DistributedCholesky:
                     self.panel[o].wait_event(ev_bcast[o][k])
                     if k >= 1:
                         self.panel[o].wait_event(ev_rest[o][k - 1])
-                    with torch.cuda.stream(self.panel[o]):
-                        H[o].dist_update(k, view(o, k).data_ptr(), k + 1, k + 2, True)
+                    with self.rt.on(self.panel[o]):
+                        H[o].dist_update(k, view(o, k), k + 1, k + 2, True)
                 factor_and_broadcast(k + 1)
             for r, h in H.items():                             # REST(k) on everyone's main stream
                 self.main[r].wait_event(ev_bcast[r][k])
-                with torch.cuda.stream(self.main[r]):
+                with self.rt.on(self.main[r]):
                     # (the last panel has no look-ahead step: its REST starts at the corner tile)
-                    h.dist_update(k, view(r, k).data_ptr(), k + 2 if k + 1 < nouter else k + 1, nouter + 1, False)
-                    ev = torch.cuda.Event()
+                    h.dist_update(k, view(r, k), k + 2 if k + 1 < nouter else k + 1, nouter + 1, False)
+                    ev = self.rt.event()
                     ev.record(self.main[r])
                     ev_rest[r][k] = ev
         vals = {}
