@@ -3,7 +3,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}; N=${1:-8192}
 OUT=$R/gpurun_out/trace_n; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for LA in 1 0; do
-  timeout 200 rocprofv3 --kernel-trace --output-format csv -d $OUT/la$LA -o s -- python3 $R/scripts/gpu_trace_n.py $N $LA > $OUT/la$LA.log 2>&1
+  timeout 200 rocprofv3 --kernel-trace --output-format csv -d $OUT/la$LA -o s -- python3 $R/scripts/gpu_trace_n.py $N $LA $2 > $OUT/la$LA.log 2>&1
 done
 python3 - <<PY
 import csv
