@@ -7,8 +7,6 @@ X, y = syn.make_dataset(n, 8)
 th = syn.default_theta("se_ard", 8)
 h = _lib.Handle(X, y, "se_ard")
 h.set_option("lookahead", la)
-if len(sys.argv) > 3:
-    h.set_option("persistent_syrk", 1); h.set_option("reserve_slots", int(sys.argv[3]))
 for _ in range(4):
     h.loglik(th)
 h.close()
