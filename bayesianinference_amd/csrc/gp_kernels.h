@@ -600,6 +600,9 @@ template <> __device__ __forceinline__ int lds_off<float>(int k, int row) {
 // throughput configuration); 4 = three stages ahead with COUNTED vmcnt waits and a raw s_barrier
 // (one workgroup per CU): for launches with <= 1 tile per CU, where a tile pass is bound by the
 // DMA round trip of every stage rather than by the MFMA pipe.
+#ifndef GP_DIAG
+#define GP_DIAG 0          // developer timing experiments only (scripts/micro/syrk_time.hip): 1 = no DMA after the
+#endif                     // first two stages, 2 = no C load/store, 4 = no barrier in the main loop (results wrong)
 template <typename T, int ROLE, int NWI, int NWJ, int NBUF>
 __global__ __launch_bounds__(64 * NWI * NWJ, (NWI * NWJ == 4) ? 2 : 4) void gemm_nt_kernel(GemmArgs<T> g) {
     constexpr int NW = NWI * NWJ, FI = 8 / NWI, FJ = 8 / NWJ;      // MFMA tiles per wave along i / j
@@ -693,7 +696,7 @@ __global__ __launch_bounds__(64 * NWI * NWJ, (NWI * NWJ == 4) ? 2 : 4) void gemm
         for (int x = 0; x < FJ; ++x)
 #pragma unroll
             for (int y = 0; y < FI; ++y) {
-                if (from_zero) {
+                if (from_zero || (GP_DIAG & 2)) {
                     acc[x][y] = (acc_t){0, 0, 0, 0};
                 } else {
 #pragma unroll
@@ -702,44 +705,89 @@ __global__ __launch_bounds__(64 * NWI * NWJ, (NWI * NWJ == 4) ? 2 : 4) void gemm
                 }
             }
     };
-    auto compute = [&](int buf) {
+    // Fragments of one k-group of 4: lane (l15, l4) holds I[i = .. + l15][k = 4 kk + l4] and the
+    // same of J.  load_frags only ISSUES the LDS reads; the J fragment is negated where it is used
+    // so that nothing has to wait for the reads at issue time.
+    auto load_frags = [&](int buf, int kk, T* fi, T* fj) {
         const T* Is = smem + buf * STAGE + wi * (16 * FI) + (lane & 15);
         const T* Js = smem + buf * STAGE + JOFF;
+        const int k = 4 * kk + l4;
+#pragma unroll
+        for (int f = 0; f < FI; ++f) fi[f] = Is[lds_off<T>(k, f * 16)];
+#pragma unroll
+        for (int f = 0; f < FJ; ++f) {
+            const int jrow = wj * (16 * FJ) + f * 16 + (lane & 15);
+            if (ROLE == 3) {
+                constexpr int G = 16 / (int)sizeof(T);
+                fj[f] = Js[jrow * GK + G * ((k / G) ^ (jrow & 7)) + (k % G)];
+            } else {
+                fj[f] = Js[lds_off<T>(k, jrow)];
+            }
+        }
+    };
+    // While an LDS-DMA is in flight hipcc only ever waits with lgkmcnt(0), i.e. for ALL outstanding
+    // LDS reads.  An empty asm that "uses" a fragment set makes that wait happen at a chosen point:
+    // before the next set's reads are issued instead of after.
+    auto pin_frags = [&](T* fi, T* fj) {
+#pragma unroll
+        for (int f = 0; f < FI; ++f) asm volatile("" : "+v"(fi[f]));
+#pragma unroll
+        for (int f = 0; f < FJ; ++f) asm volatile("" : "+v"(fj[f]));
+    };
+    auto mfma_block = [&](const T* fi, const T* fj) {
+        T nj[FJ];
+#pragma unroll
+        for (int f = 0; f < FJ; ++f) nj[f] = from_zero ? fj[f] : -fj[f];
+#pragma unroll
+        for (int x = 0; x < FJ; ++x)
+#pragma unroll
+            for (int y = 0; y < FI; ++y) acc[x][y] = Num<T>::mfma(nj[x], fi[y], acc[x][y]);
+    };
+    auto compute = [&](int buf) {
+        T fi[FI], fj[FJ];
 #pragma unroll
         for (int kk = 0; kk < GK / 4; ++kk) {
-            T fi[FI], fj[FJ];
-            const int k = 4 * kk + l4;
-#pragma unroll
-            for (int f = 0; f < FI; ++f) fi[f] = Is[lds_off<T>(k, f * 16)];
-#pragma unroll
-            for (int f = 0; f < FJ; ++f) {
-                T v;
-                const int jrow = wj * (16 * FJ) + f * 16 + (lane & 15);
-                if (ROLE == 3) {
-                    constexpr int G = 16 / (int)sizeof(T);
-                    v = Js[jrow * GK + G * ((k / G) ^ (jrow & 7)) + (k % G)];
-                } else {
-                    v = Js[lds_off<T>(k, jrow)];
-                }
-                fj[f] = from_zero ? v : -v;
-            }
-#pragma unroll
-            for (int x = 0; x < FJ; ++x)
-#pragma unroll
-                for (int y = 0; y < FI; ++y) acc[x][y] = Num<T>::mfma(fj[x], fi[y], acc[x][y]);
+            load_frags(buf, kk, fi, fj);
+            mfma_block(fi, fj);
         }
     };
     if constexpr (NBUF == 2) {
+        // Software pipeline over k-groups: the LDS reads of group kk+1 are issued BEFORE the 16 MFMAs
+        // of group kk (two fragment register sets), and the first group of the next stage is read
+        // right after the barrier, under the last group's MFMAs -- no LDS latency is exposed.
+        constexpr int NKK = GK / 4;
+        static_assert(NKK % 2 == 0, "fragment set parity must repeat every stage");
+        T fa[2][FI], fb[2][FJ];
+#ifdef GP_STAGGER
+        if (ROLE == 0 && (blockIdx.x & 256) && blockIdx.x < 512)
+            for (int i = 0; i < GP_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
+#endif
         stage(0, 0);
         load_c();                                          // C loads fly with the first DMA stage
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        load_frags(0, 0, fa[0], fb[0]);
         for (int kb = 0; kb < nk; ++kb) {
             const int cur = kb & 1;
-            if (kb + 1 < nk) stage(kb + 1, cur ^ 1);       // DMA of the next stage flies under the MFMAs
-            compute(cur);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
+            if (kb + 1 < nk && !((GP_DIAG & 1) && kb >= 1)) stage(kb + 1, cur ^ 1);   // DMA of the next stage flies under the MFMAs
+#pragma unroll
+            for (int kk = 0; kk + 1 < NKK; ++kk) {
+                pin_frags(fa[kk & 1], fb[kk & 1]);         // the compiler's LDS wait lands HERE ...
+                __builtin_amdgcn_sched_barrier(0);
+                load_frags(cur, kk + 1, fa[(kk + 1) & 1], fb[(kk + 1) & 1]);   // ... before these reads
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_block(fa[kk & 1], fb[kk & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // every read of this stage has landed: once this wave's DMA has too, the barrier both
+            // publishes the next stage and frees this buffer for the DMA after next
+            pin_frags(fa[(NKK - 1) & 1], fb[(NKK - 1) & 1]);
+            if (!(GP_DIAG & 8)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (!(GP_DIAG & 4)) __builtin_amdgcn_s_barrier();
+            if (kb + 1 < nk) load_frags(cur ^ 1, 0, fa[0], fb[0]);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_block(fa[(NKK - 1) & 1], fb[(NKK - 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
         }
     } else {
         // deep pipeline: NBUF-1 stages in flight; every wave issues IPS DMA instructions per stage
@@ -760,6 +808,7 @@ __global__ __launch_bounds__(64 * NWI * NWJ, (NWI * NWJ == 4) ? 2 : 4) void gemm
     }
 
     // epilogue: stores only
+    if ((GP_DIAG & 2) && acc[0][0][0] != (typename Num<T>::acc_t){1, 2, 3, 4}[0]) return;
 #pragma unroll
     for (int x = 0; x < FJ; ++x)
 #pragma unroll
