@@ -285,6 +285,15 @@ __device__ long long g_stamps[64];
 #define GP_STAMP(i) do { } while (0)
 #endif
 
+// 1/sqrt(x) for the pivot chain: hardware seed (v_rsq_f64, ~5e-8) + one third-order correction
+// y (1 + e/2 + 3e^2/8), e = 1 - x y^2  ->  relative error ~1e-16 + O(e^3); shorter dependent chain
+// than the library rsqrt.  x is a checked positive pivot (> tol).
+__device__ __forceinline__ double fast_rsqrt(double x) {
+    const double y = __builtin_amdgcn_rsq(x);
+    const double e = __builtin_fma(-x * y, y, 1.0);
+    return __builtin_fma(y * e, __builtin_fma(0.375, e, 0.5), y);
+}
+
 constexpr int PT_LDS_ELEMS = 36 * 256 + TB;     // tiles + dinv[128]  (+ 2 doubles of reduction scratch)
 
 __device__ __forceinline__ int ptile(int bi, int bj) { return ((bi * (bi + 1) / 2) + bj) << 8; }
@@ -334,6 +343,51 @@ __device__ __forceinline__ void inv_block_column(const T* __restrict__ Ls, T* __
     }
 }
 
+// Trailing update of panel p inside the 128x128 block: C(u,v) -= X_u X_v^T over the 16x16 tiles below
+// and right of the panel.  Wave w owns tiles w, w+4, ..; its NR tiles are independent MFMA chains
+// issued interleaved (accumulators start AT C, operand negated), so the wave runs at MFMA
+// throughput instead of one tile's latency at a time.  A wave with fewer than NR tiles recomputes
+// the last tile and skips the store.
+template <typename T, int NR>
+__device__ __forceinline__ void potrf_update(T* __restrict__ Ls, int p, int uw, int l15, int l4) {
+    typedef typename Num<T>::acc_t acc_t;
+    const int t = 7 - p, ntile = t * (t + 1) / 2;
+    acc_t acc[NR];
+    T fa[NR][4], fb[NR][4];
+    T* Ct[NR];
+#pragma unroll
+    for (int m = 0; m < NR; ++m) {
+        int tt = uw + 4 * m;
+        if (tt >= ntile) tt = ntile - 1;
+        // tt -> (u, v), v <= u, tt = u(u+1)/2 + v < 28: branch-free (a taken scalar branch costs ~32 cycles)
+        const int u = (tt >= 1) + (tt >= 3) + (tt >= 6) + (tt >= 10) + (tt >= 15) + (tt >= 21);
+        const int v = tt - u * (u + 1) / 2;
+        const T* Xc = Ls + ptile(p + 1 + v, p) + l4 * 16 + l15;
+        const T* Xrw = Ls + ptile(p + 1 + u, p) + l4 * 16 + l15;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            fa[m][kk] = -Xc[kk * 64];
+            fb[m][kk] = Xrw[kk * 64];
+        }
+        Ct[m] = Ls + ptile(p + 1 + u, p + 1 + v) + l15;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[m][r] = Ct[m][Num<T>::drow(l4, r) * 16];
+    }
+    if (NR == 7) GP_STAMP(40);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int m = 0; m < NR; ++m) acc[m] = Num<T>::mfma(fa[m][kk], fb[m][kk], acc[m]);
+    if (NR == 7) GP_STAMP(41);
+#pragma unroll
+    for (int m = 0; m < NR; ++m)
+        if (uw + 4 * m < ntile) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Ct[m][Num<T>::drow(l4, r) * 16] = acc[m][r];
+        }
+    if (NR == 7) GP_STAMP(42);
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void potrf128_kernel(T* __restrict__ Abase, long ld, long bstride, int b,
                                                        T* __restrict__ Winv, double* __restrict__ partial,
@@ -364,31 +418,40 @@ __global__ __launch_bounds__(256) void potrf128_kernel(T* __restrict__ Abase, lo
         GP_STAMP(2 + 3 * p);
         if (wave == 0 && sizeof(T) == 8) {
             // (a) fp64: the 16x16 diagonal block lives in the MFMA D layout -- lane (l15, l4) holds
-            // A[i = l15][j = l4 + 4r], r = 0..3 -- so after every 4 pivots the rank-4 update of the
-            // remaining columns is ONE v_mfma_f64_16x16x4 whose A and B operands are the lane's own
-            // column value.  Inside a group of 4 columns the few updates use ds_bpermute.
+            // A[i = l15][j = l4 + 4r], r = 0..3.  Columns are eliminated four at a time: the 16x4 slab
+            // is gathered into row-per-lane form (one ds_bpermute round per slab), factored with
+            // v_readlane broadcasts only (pivot chain = readlane, rsq, mul, readlane, fma), and the
+            // rank-4 update of the remaining columns is one MFMA in the D layout.
             double a[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) a[r] = (double)Dpp[(l4 + 4 * r) * 16 + l15];
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4) {
+                // slab = columns 4 s4 .. 4 s4 + 3 in row-per-lane form: s[q] = A[l15][4 s4 + q], gathered
+                // from the lanes (l15, q); all four 16-lane groups hold the same copy
+                double sl[4];
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const int c = 4 * s4 + t;
-                    double dj = Num<double>::readlane(a[s4], 16 * t + c);
+                for (int q = 0; q < 4; ++q) sl[q] = __shfl(a[s4], 16 * q + l15);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int c = 4 * s4 + q;
+                    double dj = Num<double>::readlane(sl[q], c);
                     if (!(dj > (double)tol)) { bad = true; dj = 1.0; }
-                    const double rs = rsqrt(dj);
-                    const double scaled = (l15 == c) ? dj * rs : a[s4] * rs;
-                    a[s4] = (l4 == t) ? scaled : a[s4];
+                    const double rs = fast_rsqrt(dj);
+                    sl[q] = (l15 == c) ? dj * rs : sl[q] * rs;
                     if (lane == 0) dinv[16 * p + c] = (T)rs;
-                    if (t < 3) {
-                        const double xi = __shfl(a[s4], 16 * t + l15);          // L[i = l15][c]
-                        const double xc = __shfl(a[s4], 16 * t + 4 * s4 + l4);  // L[c' = 4 s4 + l4][c]
-                        if (l4 > t) a[s4] = __builtin_fma(-xi, xc, a[s4]);
+#pragma unroll
+                    for (int q2 = q + 1; q2 < 4; ++q2) {
+                        const double lc = Num<double>::readlane(sl[q], 4 * s4 + q2);   // L[4 s4 + q2][c]
+                        sl[q2] = __builtin_fma(-sl[q], lc, sl[q2]);
                     }
                 }
+                // back to the D layout; then the rank-4 update of the later column groups is ONE MFMA
+                // whose A and B operands are the lane's own column value (L is zero above its diagonal)
+                const double mine = (l4 == 0) ? sl[0] : (l4 == 1) ? sl[1] : (l4 == 2) ? sl[2] : sl[3];
+                a[s4] = mine;
                 if (s4 < 3) {
-                    const double xop = (l15 >= 4 * s4 + l4) ? a[s4] : 0.0;      // L is zero above its diagonal
+                    const double xop = (l15 >= 4 * s4 + l4) ? mine : 0.0;
                     d4 cacc = (d4){a[0], a[1], a[2], a[3]};
                     cacc = __builtin_amdgcn_mfma_f64_16x16x4f64(-xop, xop, cacc, 0, 0, 0);
 #pragma unroll
@@ -431,12 +494,13 @@ __global__ __launch_bounds__(256) void potrf128_kernel(T* __restrict__ Abase, lo
             T x[16];
 #pragma unroll
             for (int c = 0; c < 16; ++c) x[c] = Xr[c * 16];
+            // right-looking order: the dependent chain is one mul + one fma per column (16 x 2), the
+            // other 15-c fmas of a step are independent
 #pragma unroll
             for (int c = 0; c < 16; ++c) {
-                T sacc = x[c];
+                x[c] *= dinv[16 * p + c];
 #pragma unroll
-                for (int k = 0; k < c; ++k) sacc = __builtin_fma(-x[k], Dpp[k * 16 + c], sacc);
-                x[c] = sacc * dinv[16 * p + c];
+                for (int k = c + 1; k < 16; ++k) x[k] = __builtin_fma(-x[c], Dpp[c * 16 + k], x[k]);
             }
 #pragma unroll
             for (int c = 0; c < 16; ++c) Xr[c * 16] = x[c];
@@ -444,19 +508,15 @@ __global__ __launch_bounds__(256) void potrf128_kernel(T* __restrict__ Abase, lo
         __syncthreads();
         GP_STAMP(4 + 3 * p);
         {                                      // (c) trailing update C -= X X^T on MFMA
-            const int t = 7 - p, ntile = t * (t + 1) / 2;
-            for (int tt = wave; tt < ntile; tt += 4) {
-                int u = 0;
-                while ((u + 1) * (u + 2) / 2 <= tt) ++u;
-                const int v = tt - u * (u + 1) / 2;
-                const T* Xc = Ls + ptile(p + 1 + v, p) + l4 * 16 + l15;
-                const T* Xrw = Ls + ptile(p + 1 + u, p) + l4 * 16 + l15;
-                acc_t acc = (acc_t){0, 0, 0, 0};
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) acc = Num<T>::mfma(Xc[kk * 64], Xrw[kk * 64], acc);
-                T* Ct = Ls + ptile(p + 1 + u, p + 1 + v) + l15;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) Ct[Num<T>::drow(l4, r) * 16] -= acc[r];
+            const int nround = ((7 - p) * (8 - p) / 2 + 3) >> 2;
+            const int uw = __builtin_amdgcn_readfirstlane(wave);
+            switch (nround) {
+                case 7: potrf_update<T, 7>(Ls, p, uw, l15, l4); break;
+                case 6: potrf_update<T, 6>(Ls, p, uw, l15, l4); break;
+                case 4: potrf_update<T, 4>(Ls, p, uw, l15, l4); break;
+                case 3: potrf_update<T, 3>(Ls, p, uw, l15, l4); break;
+                case 2: potrf_update<T, 2>(Ls, p, uw, l15, l4); break;
+                default: potrf_update<T, 1>(Ls, p, uw, l15, l4); break;
             }
         }
         __syncthreads();
@@ -481,13 +541,14 @@ __global__ __launch_bounds__(256) void potrf128_kernel(T* __restrict__ Abase, lo
         const int blk = tid >> 4, c = tid & 15;
         T* Dbb = Ls + ptile(blk & 7, blk & 7);
         if (tid < TB) {
+            // column c of L_bb^-1 by forward substitution on e_c, right-looking (short dependent chain)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                T sacc = (T)0;
+            for (int i = 0; i < 16; ++i) w[i] = (i == c) ? (T)1 : (T)0;
 #pragma unroll
-                for (int k = 0; k < i; ++k) sacc = __builtin_fma(Dbb[k * 16 + i], w[k], sacc);
-                const T di = dinv[16 * blk + i];
-                w[i] = (i < c) ? (T)0 : ((i == c) ? di : -sacc * di);
+            for (int k = 0; k < 16; ++k) {
+                w[k] *= dinv[16 * blk + k];
+#pragma unroll
+                for (int i = k + 1; i < 16; ++i) w[i] = __builtin_fma(-w[k], Dbb[k * 16 + i], w[i]);
             }
         }
         __syncthreads();

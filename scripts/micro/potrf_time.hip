@@ -32,6 +32,7 @@ int main() {
     }
     printf("factor total %.2f | L store %.2f | diag inverses %.2f | block inverse %.2f | W store %.2f | total %.2f us\n",
            us(1, 30), us(30, 31), us(31, 32), us(32, 33), us(33, 34), us(0, 34));
+    printf("update p=0: entry->loads issued %.2f | mfma %.2f | stores %.2f | ->barrier+loop %.2f us\n", us(4, 40), us(40, 41), us(41, 42), us(42, 5));
     int info; hipMemcpy(&info, dI, 4, hipMemcpyDeviceToHost); printf("info %d\n", info);
     return 0;
 }
