@@ -388,12 +388,14 @@ __device__ __forceinline__ void potrf_update(T* __restrict__ Ls, int p, int uw, 
     if (NR == 7) GP_STAMP(42);
 }
 
+// Core of potrf128 on a tile-packed LDS image that is already in place (all 256 threads; the caller
+// has synchronised after filling Ls).  Writes L to Ad (global, leading dimension ld), W = L^-1 to Wg
+// (128x128, leading dimension 128, explicit zero upper triangle), sum log L_jj to *logdet_out and
+// 1 to *info_out on a bad pivot.
 template <typename T>
-__global__ __launch_bounds__(256) void potrf128_kernel(T* __restrict__ Abase, long ld, long bstride, int b,
-                                                       T* __restrict__ Winv, double* __restrict__ partial,
-                                                       int nt, int* __restrict__ info,
-                                                       const double* __restrict__ slotp) {
-    extern __shared__ double lds_raw[];
+__device__ __forceinline__ void potrf128_core(double* __restrict__ lds_raw, T* __restrict__ Ad, long ld,
+                                              T* __restrict__ Wg, double* __restrict__ logdet_out,
+                                              int* __restrict__ info_out, T tol) {
     double* red = lds_raw;                      // 2 doubles
     T* Ls = reinterpret_cast<T*>(lds_raw + 2);  // 36 tiles + dinv[128]
     T* dinv = Ls + 36 * 256;
@@ -401,15 +403,7 @@ __global__ __launch_bounds__(256) void potrf128_kernel(T* __restrict__ Abase, lo
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
     const int er = tid & 15, ec = tid >> 4;   // element (row, col) of a 16x16 tile owned in copies
-    const int slot = blockIdx.x;
-    T* Ad = Abase + (long)slot * bstride + (long)b * TB * (ld + 1);
-    for (int bi = 0; bi < 8; ++bi)
-        for (int bj = 0; bj <= bi; ++bj)
-            Ls[ptile(bi, bj) + tid] = Ad[(long)(bj * 16 + ec) * ld + bi * 16 + er];
-    const T tol = (T)slotp[(long)slot * SLOTP + 3];
     bool bad = false;
-    GP_STAMP(0);
-    __syncthreads();
     GP_STAMP(1);
 
     // ------------------------------ factor phase ------------------------------
@@ -561,7 +555,6 @@ __global__ __launch_bounds__(256) void potrf128_kernel(T* __restrict__ Abase, lo
     }
     GP_STAMP(32);
     // (ii) the off-diagonal blocks: block columns are independent, wave w owns columns w and 7-w
-    T* Wg = Winv + ((long)slot * nt + b) * TB * TB;
     {
         const int uw = __builtin_amdgcn_readfirstlane(wave);
         if (uw == 0) {
@@ -587,9 +580,37 @@ __global__ __launch_bounds__(256) void potrf128_kernel(T* __restrict__ Abase, lo
         }
     GP_STAMP(34);
     if (tid == 0) {
-        partial[(long)slot * nt + b] = red[0] + red[1];
-        if (bad) info[slot] = 1;
+        *logdet_out = red[0] + red[1];
+        if (bad) *info_out = 1;
     }
+}
+
+// Out-of-line copy for chol_dataflow_kernel: keeps the factorisation's register allocation apart from
+// the accumulator-heavy MFMA loops of that kernel (inlined, the allocator spills accumulators there).
+template <typename T>
+__device__ __noinline__ void potrf128_core_call(double* lds_raw, T* Ad, long ld, T* Wg, double* logdet_out,
+                                                int* info_out, T tol) {
+    potrf128_core<T>(lds_raw, Ad, ld, Wg, logdet_out, info_out, tol);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void potrf128_kernel(T* __restrict__ Abase, long ld, long bstride, int b,
+                                                       T* __restrict__ Winv, double* __restrict__ partial,
+                                                       int nt, int* __restrict__ info,
+                                                       const double* __restrict__ slotp) {
+    extern __shared__ double lds_raw[];
+    T* Ls = reinterpret_cast<T*>(lds_raw + 2);
+    const int tid = threadIdx.x;
+    const int er = tid & 15, ec = tid >> 4;
+    const int slot = blockIdx.x;
+    T* Ad = Abase + (long)slot * bstride + (long)b * TB * (ld + 1);
+    for (int bi = 0; bi < 8; ++bi)
+        for (int bj = 0; bj <= bi; ++bj)
+            Ls[ptile(bi, bj) + tid] = Ad[(long)(bj * 16 + ec) * ld + bi * 16 + er];
+    GP_STAMP(0);
+    __syncthreads();
+    potrf128_core<T>(lds_raw, Ad, ld, Winv + ((long)slot * nt + b) * TB * TB, partial + (long)slot * nt + b,
+                     info + slot, (T)slotp[(long)slot * SLOTP + 3]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -878,6 +899,249 @@ __global__ __launch_bounds__(64 * NWI * NWJ, (NWI * NWJ == 4) ? 2 : 4) void gemm
 #pragma unroll
             for (int y = 0; y < FI; ++y) cp[y * 16] = acc[x][y][r];
         }
+}
+
+// ---------------------------------------------------------------------------------------------
+// chol_dataflow: the whole bordered Cholesky of small / mid problems in ONE launch.
+//
+// The multi-kernel schedule above is bound, below N ~ 8k, by the serial chain of dependent launches
+// (potrf -> panel solve -> in-panel update, ~115 us per 128 columns).  Here every 128x128 tile (i,j),
+// i >= j, of the bordered matrix (tile row Nt = the rhs rows) is ONE workgroup that owns the tile for
+// its whole life (left-looking):
+//     acc  = K(i,j)
+//     for b < j:  wait X(i,b), X(j,b);  acc -= X(i,b) X(j,b)^T          (K = 128 slab on the MFMA)
+//     i == j:     L_jj, W_j = potrf128(acc);                 publish ready(j,j)
+//     i >  j:     wait ready(j,j);  X(i,j) = acc W_j^T;      publish ready(i,j)
+// Dependencies are flags in global memory (value = epoch of this evaluation; release/acquire at
+// agent scope).  Tasks are numbered in column-major order, a topological order of the DAG, and a
+// workgroup takes its task number from an atomic ticket when it STARTS: every dependency of a task
+// therefore belongs to a workgroup that started earlier and is resident, so the schedule cannot
+// deadlock whatever order the hardware dispatches workgroups in.  A spin limit turns any violation of
+// that argument into an error code (abort flag) instead of a hung GPU.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+struct DfArgs {
+    T* A; long ld; long bstride;              // workspace, (Nt+1) x (Nt+1) tiles per slot
+    T* W; long w_bstride;                     // W_b = L_bb^-1 tiles, [slot][Nt][128*128]
+    double* partial;                          // [slot][Nt] sum log L_jj per diagonal block
+    int* info;                                // [slot]
+    const double* slotp;
+    int* flags; long f_bstride;               // [slot][(Nt+1)^2]: ready(i,j) at i*(Nt+1)+j
+    unsigned long long* ticket;
+    unsigned long long ticket_base;           // value of *ticket before this launch
+    int* abort_flag;
+    int Nt, nslots, epoch;
+    long long* trace;                         // developer timing (scripts/micro/df_trace.hip): 8 stamps per task, or null
+};
+
+constexpr int DF_SPIN_LIMIT = 1 << 22;        // x ~1 us per poll: seconds, never reached by a live schedule
+
+__device__ __forceinline__ void df_wait(const int* f, int epoch, int* abort_flag) {
+    int spins = 0;
+    // "unlikely": keeps the register allocator from treating this poll loop as hotter than the MFMA
+    // loop it sits in (it would spill accumulators around it)
+    while (__builtin_expect(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch, 0)) {
+        __builtin_amdgcn_s_sleep(8);
+        if ((++spins & 63) == 0) {
+            if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+            if (spins > DF_SPIN_LIMIT) {
+                __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;                          // carry on with whatever is there: no divergent exits
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void chol_dataflow_kernel(DfArgs<T> g) {
+    constexpr int FI = 4, FJ = 4;
+    extern __shared__ double smem_raw[];
+    __shared__ int s_task;
+    T* smem = reinterpret_cast<T*>(smem_raw);
+    typedef typename Num<T>::acc_t acc_t;
+    constexpr int GK = Num<T>::GK;
+    constexpr int STAGE = STAGE_BYTES / (int)sizeof(T);
+    constexpr int JOFF = STAGE / 2;
+    constexpr bool F64 = sizeof(T) == 8;
+    constexpr int SPB = TB / GK;                            // LDS stages per 128-wide slab
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wi = wave & 1, wj = wave >> 1;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int uw = __builtin_amdgcn_readfirstlane(wave);
+
+    if (tid == 0) s_task = (int)(atomicAdd(g.ticket, 1ull) - g.ticket_base);
+    __syncthreads();
+    const int task = __builtin_amdgcn_readfirstlane(s_task);
+    const int R = g.Nt + 1;
+    const int slot = task % g.nslots, q = task / g.nslots;
+    // q -> (j, i): column-major over the lower triangle, column j starts at off(j) = jR - j(j-1)/2
+    int j = (int)(((double)(2 * R + 1) - sqrt((double)(2 * R + 1) * (2 * R + 1) - 8.0 * q)) * 0.5);
+    if (j < 0) j = 0;
+    if (j > R - 1) j = R - 1;
+    while (j + 1 < R && (j + 1) * R - (j + 1) * j / 2 <= q) ++j;
+    while (j > 0 && j * R - j * (j - 1) / 2 > q) --j;
+    const int i = j + (q - (j * R - j * (j - 1) / 2));
+
+    long long* tr = g.trace ? g.trace + (long)task * 8 : nullptr;
+    auto stamp = [&](int k) { if (tr && tid == 0) tr[k] = wall_clock64(); };
+    stamp(0);
+    T* As = g.A + (long)slot * g.bstride;
+    int* F = g.flags + (long)slot * g.f_bstride;
+    T* Wj = g.W + (long)slot * g.w_bstride + (long)j * TB * TB;
+    T* Ct = As + (long)j * TB * g.ld + (long)i * TB;      // tile (i,j)
+
+    acc_t acc[FJ][FI];
+    // D-layout address of this lane's accumulators inside a 128x128 tile with leading dimension ldc
+    auto c_ptr = [&](T* base, long ldc) { return base + (long)(wj * 64) * ldc + wi * 64 + l15; };
+    auto load_c = [&](const T* base, long ldc) {
+        const T* cp = c_ptr(const_cast<T*>(base), ldc);
+#pragma unroll
+        for (int x = 0; x < FJ; ++x)
+#pragma unroll
+            for (int y = 0; y < FI; ++y)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[x][y][r] = cp[(long)(x * 16 + Num<T>::drow(l4, r)) * ldc + y * 16];
+    };
+    auto store_c = [&](T* base, long ldc) {
+        T* cp0 = c_ptr(base, ldc);
+#pragma unroll
+        for (int x = 0; x < FJ; ++x)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                T* cp = cp0 + (long)(x * 16 + Num<T>::drow(l4, r)) * ldc;
+#pragma unroll
+                for (int y = 0; y < FI; ++y) cp[y * 16] = acc[x][y][r];
+            }
+    };
+    auto zero_c = [&]() {
+#pragma unroll
+        for (int x = 0; x < FJ; ++x)
+#pragma unroll
+            for (int y = 0; y < FI; ++y) acc[x][y] = (acc_t){0, 0, 0, 0};
+    };
+
+    // acc (+/-)= I J^T over nk LDS stages; I(i,k) at Ig[i + k*ldi], J(j,k) at Jg[j + k*ldj].  Same
+    // LDS-DMA double buffer as gemm_nt (see there).  No dependency waits in here: a poll loop nested in
+    // this loop makes the register allocator spill accumulators around it.
+    auto run_k = [&](const T* Ig, long ldi, const T* Jg, long ldj, int nk, bool negate) {
+        auto stage = [&](int kb, int st) {
+            T* Is = smem + st * STAGE;
+            T* Js = Is + JOFF;
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) {
+                const int qq = uw + 4 * s2;
+                if (F64) {
+                    const long kcol = (long)kb * GK + qq;
+                    __builtin_amdgcn_global_load_lds((glb_void*)(Ig + kcol * ldi + 2 * lane),
+                                                     (lds_void*)(Is + qq * LDT), 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds((glb_void*)(Jg + kcol * ldj + 2 * lane),
+                                                     (lds_void*)(Js + qq * LDT), 16, 0, 0);
+                } else {
+                    const long kcol = (long)kb * GK + 4 * (qq >> 1) + (qq & 1) + 2 * (lane >> 5);
+                    const int row = 4 * (lane & 31);
+                    __builtin_amdgcn_global_load_lds((glb_void*)(Ig + kcol * ldi + row),
+                                                     (lds_void*)(Is + qq * LDP), 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds((glb_void*)(Jg + kcol * ldj + row),
+                                                     (lds_void*)(Js + qq * LDP), 16, 0, 0);
+                }
+            }
+        };
+        auto load_frags = [&](int buf, int kk, T* fi, T* fj) {
+            const T* Is = smem + buf * STAGE + wi * 64 + l15;
+            const T* Js = smem + buf * STAGE + JOFF + wj * 64 + l15;
+            const int k = 4 * kk + l4;
+#pragma unroll
+            for (int f = 0; f < FI; ++f) fi[f] = Is[lds_off<T>(k, f * 16)];
+#pragma unroll
+            for (int f = 0; f < FJ; ++f) fj[f] = Js[lds_off<T>(k, f * 16)];
+        };
+        auto mfma_block = [&](const T* fi, const T* fj) {
+            T nj[FJ];
+#pragma unroll
+            for (int f = 0; f < FJ; ++f) nj[f] = negate ? -fj[f] : fj[f];
+#pragma unroll
+            for (int x = 0; x < FJ; ++x)
+#pragma unroll
+                for (int y = 0; y < FI; ++y) acc[x][y] = Num<T>::mfma(nj[x], fi[y], acc[x][y]);
+        };
+        // one fragment register set (the two-set pipeline of gemm_nt does not fit next to the flag /
+        // potrf state of this kernel without spilling, and buys ~0 there)
+        constexpr int NKK = GK / 4;
+        stage(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int kb = 0; kb < nk; ++kb) {
+            const int cur = kb & 1;
+            if (kb + 1 < nk) stage(kb + 1, cur ^ 1);
+#pragma unroll
+            for (int kk = 0; kk < NKK; ++kk) {
+                T fi[FI], fj[FJ];
+                load_frags(cur, kk, fi, fj);
+                mfma_block(fi, fj);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    };
+    auto publish = [&](int fi_, int fj_) {                  // everything this workgroup stored is visible first
+        __threadfence();
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(F + fi_ * R + fj_, g.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    };
+
+    // ---- accumulate the updates of all earlier columns
+    if (j > 0 || i == j) load_c(Ct, g.ld);
+    for (int b = 0; b < j; ++b) {                          // one 128-wide slab per finished column b
+        df_wait(F + i * R + b, g.epoch, g.abort_flag);
+        if (i != j) df_wait(F + j * R + b, g.epoch, g.abort_flag);
+        if (b == j - 1) stamp(6);
+        run_k(As + (long)b * TB * g.ld + (long)i * TB, g.ld, As + (long)b * TB * g.ld + (long)j * TB, g.ld, SPB, true);
+    }
+    stamp(1);
+
+    if (i == j) {
+        if (j == g.Nt) {                                    // corner of the border: -|z|^2 accumulates here
+            store_c(Ct, g.ld);
+            return;
+        }
+        // accumulators -> tile-packed LDS image of the lower triangle, then factor + invert in place
+        T* Ls = reinterpret_cast<T*>(smem_raw + 2);
+#pragma unroll
+        for (int x = 0; x < FJ; ++x)
+#pragma unroll
+            for (int y = 0; y < FI; ++y) {
+                const int bi = wi * 4 + y, bj = wj * 4 + x;
+                if (bi >= bj) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) Ls[ptile(bi, bj) + Num<T>::drow(l4, r) * 16 + l15] = acc[x][y][r];
+                }
+            }
+        __syncthreads();
+        stamp(2);
+        potrf128_core_call<T>(smem_raw, Ct, g.ld, Wj, g.partial + (long)slot * g.Nt + j, g.info + slot,
+                              (T)g.slotp[(long)slot * SLOTP + 3]);
+        stamp(3);
+        publish(j, j);
+        stamp(4);
+        return;
+    }
+
+    // ---- panel solve X(i,j) = acc W_j^T: the pre-solve tile goes through memory to become an MFMA operand
+    if (j > 0) {
+        store_c(Ct, g.ld);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    zero_c();
+    stamp(2);
+    df_wait(F + j * R + j, g.epoch, g.abort_flag);
+    stamp(5);
+    run_k(Ct, g.ld, Wj, TB, SPB, false);
+    stamp(3);
+    store_c(Ct, g.ld);
+    publish(i, j);
+    stamp(4);
 }
 
 // log det = 2 sum partial ; quad = -E(0,0) ; res[slot] = {logdet, quad}

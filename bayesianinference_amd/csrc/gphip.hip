@@ -14,6 +14,7 @@
 // Device arithmetic is fp64 (dtype 64) or fp32 (dtype 32); the ABI is fp64 either way.
 #include "gp_kernels.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -66,6 +67,11 @@ struct gphip_ctx {
     // options
     int panel = 4, profile = 0, swizzle = 1, max_slots = 256, lookahead = 1, supertile = 0;
     int latency_gemm = 1, latency_tiles = 256;   // launches of <= latency_tiles tiles use the latency GEMM shape
+    int dataflow = 1, dataflow_max_nt = 64, dataflow_max_slots = 8;   // single-launch dataflow Cholesky: latency regime only
+    int* dFlags = nullptr;                       // [slots][(Nt+1)^2] ready flags (value = epoch)
+    unsigned long long* dTicket = nullptr;       // task ticket counter (+ abort flag in the next word)
+    unsigned long long ticket_base = 0;
+    int epoch = 0;
     // fitted state (slot 0)
     bool fitted = false;
     std::vector<double> theta_fit;
@@ -162,6 +168,8 @@ void harvest(gphip_ctx* h) {   // call after stream sync
 void free_slots(gphip_ctx* h) {
     (void)hipFree(h->dA); (void)hipFree(h->dXs); (void)hipFree(h->dInvEll); (void)hipFree(h->dSlotp);
     (void)hipFree(h->dW); (void)hipFree(h->dPartial); (void)hipFree(h->dRes); (void)hipFree(h->dInfo);
+    (void)hipFree(h->dFlags); (void)hipFree(h->dTicket);
+    h->dFlags = nullptr; h->dTicket = nullptr; h->ticket_base = 0;
     (void)hipHostFree(h->hInvEll); (void)hipHostFree(h->hSlotp); (void)hipHostFree(h->hRes);
     (void)hipHostFree(h->hInfo);
     h->dA = h->dXs = h->dW = nullptr;
@@ -175,7 +183,7 @@ void free_slots(gphip_ctx* h) {
 
 size_t slot_bytes(const gphip_ctx* h) {
     return ((size_t)h->ld * h->ld + (size_t)h->d * h->Npad + (size_t)h->Nt * TB * TB) * h->es +
-           (size_t)h->Nt * 8 + 4096;
+           (size_t)h->Nt * 8 + (size_t)(h->Nt + 1) * (h->Nt + 1) * 4 + 4096;
 }
 
 int ensure_slots(gphip_ctx* h, int want) {
@@ -198,10 +206,14 @@ int ensure_slots(gphip_ctx* h, int want) {
     HIPCHK(hipMalloc(&h->dPartial, S * h->Nt * 8));
     HIPCHK(hipMalloc(&h->dRes, S * 2 * 8));
     HIPCHK(hipMalloc(&h->dInfo, S * 4));
+    HIPCHK(hipMalloc(&h->dFlags, S * (h->Nt + 1) * (h->Nt + 1) * 4));
+    HIPCHK(hipMemset(h->dFlags, 0, S * (h->Nt + 1) * (h->Nt + 1) * 4));
+    HIPCHK(hipMalloc(&h->dTicket, 16));
+    HIPCHK(hipMemset(h->dTicket, 0, 16));
     HIPCHK(hipHostMalloc(&h->hInvEll, S * h->d * 8));
     HIPCHK(hipHostMalloc(&h->hSlotp, S * SLOTP * 8));
     HIPCHK(hipHostMalloc(&h->hRes, S * 2 * 8));
-    HIPCHK(hipHostMalloc(&h->hInfo, S * 4));
+    HIPCHK(hipHostMalloc(&h->hInfo, (S + 1) * 4));          // + the dataflow abort flag
     h->slots = want;
     return GPHIP_OK;
 }
@@ -341,6 +353,43 @@ int queue_panel(gphip_ctx* h, int K0, int nin, int nslots) {
     return 0;
 }
 
+// Single-launch dataflow Cholesky (chol_dataflow_kernel): one workgroup per tile, flags instead of
+// launches.  Used for small / mid problems where the multi-kernel schedule is latency bound.
+template <typename T>
+size_t dataflow_lds() { return std::max((size_t)GEMM_LDS, potrf_lds<T>()); }
+
+bool use_dataflow(const gphip_ctx* h, int nslots) {
+    // measured: wins 10-17 % for one theta up to N = 8192, ties at 8-16 slots, loses 35 % at 200 slots
+    // (there the multi-kernel schedule's big launches are throughput bound, not latency bound)
+    if (!h->dataflow || h->dist_world > 0 || h->Nt > h->dataflow_max_nt || nslots > h->dataflow_max_slots) return false;
+    const long tasks = (long)(h->Nt + 1) * (h->Nt + 2) / 2 * nslots;
+    return tasks < (1l << 30);
+}
+
+template <typename T>
+int queue_factor_dataflow(gphip_ctx* h, int nslots) {
+    const int Nt = (int)h->Nt, R = Nt + 1;
+    const long ld = h->ld;
+    const long tasks = (long)R * (R + 1) / 2 * nslots;
+    DfArgs<T> g{};
+    g.A = (T*)h->dA; g.ld = ld; g.bstride = ld * ld;
+    g.W = (T*)h->dW; g.w_bstride = (long)Nt * TB * TB;
+    g.partial = h->dPartial; g.info = h->dInfo; g.slotp = h->dSlotp;
+    g.flags = h->dFlags; g.f_bstride = (long)R * R;
+    g.ticket = h->dTicket; g.ticket_base = h->ticket_base;
+    g.abort_flag = reinterpret_cast<int*>(h->dTicket + 1);
+    g.Nt = Nt; g.nslots = nslots; g.epoch = ++h->epoch;
+    h->ticket_base += (unsigned long long)tasks;
+    h->cs = h->stream;
+    {
+        ProfScope ps(h, 4, (double)h->Npad * h->Npad * h->Npad / 3.0 * nslots, 0.0);
+        hipLaunchKernelGGL(chol_dataflow_kernel<T>, dim3((unsigned)tasks), dim3(256), dataflow_lds<T>(), h->stream, g);
+    }
+    hipLaunchKernelGGL(finalize_kernel<T>, dim3(nslots), dim3(64), 0, h->stream, (const T*)h->dA, ld, ld * ld,
+                       (int)h->Npad, h->dPartial, Nt, h->dRes);
+    return 0;
+}
+
 // Two-level right-looking Cholesky of slots [0, nslots) (workspace already built on h->stream).
 // With look-ahead (default) the panel stream factors panel k+1 while the main stream is still
 // applying panel k to everything right of panel k+1:
@@ -359,6 +408,7 @@ int queue_factor(gphip_ctx* h, int nslots) {
         launch_gemm<T>(h, cls, A, ld, bs, Pk, ld, bs, Pk, ld, bs, (k0(k + 1) - k0(k)) * TB, c_lo, R, c_lo, c_hi, 1,
                        nslots);
     };
+    if (use_dataflow(h, nslots)) return queue_factor_dataflow<T>(h, nslots);
     if (!h->lookahead || nouter < 2) {
         h->cs = h->stream;
         for (int k = 0; k < nouter; ++k) {
@@ -482,9 +532,14 @@ int eval_chunk(gphip_ctx* h, const double* Theta, int nb, double* out, double* p
     }
     HIPCHK(hipMemcpyAsync(h->hRes, h->dRes, (size_t)nb * 16, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipMemcpyAsync(h->hInfo, h->dInfo, (size_t)nb * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(h->hInfo + nb, h->dTicket + 1, 4, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipGetLastError());
     harvest(h);
+    if (h->hInfo[nb] != 0) {                   // a dataflow dependency wait hit its spin limit: results are void
+        HIPCHK(hipMemsetAsync(h->dTicket + 1, 0, 8, h->stream));
+        return fail(h, GPHIP_ERR_HIP, "dataflow Cholesky schedule timed out (set option dataflow=0 and report)");
+    }
     for (int s = 0; s < nb; ++s) {
         const double logdet = h->hRes[2 * s], quad = h->hRes[2 * s + 1];
         const double ll = -0.5 * ((double)h->N * LOG_TWO_PI + logdet + quad);
@@ -520,6 +575,8 @@ template <typename T>
 int set_func_attrs(gphip_ctx* h) {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(potrf128_kernel<T>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)potrf_lds<T>()));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(chol_dataflow_kernel<T>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)dataflow_lds<T>()));
 #define GEMM_ATTR(ROLE)                                                                                   \
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<T, ROLE, 2, 2, 2>),             \
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS));                  \
@@ -1178,6 +1235,9 @@ int gphip_set_option(gphip_handle h, const char* name, double value) {
     else if (!strcmp(name, "supertile")) h->supertile = v;
     else if (!strcmp(name, "latency_gemm")) h->latency_gemm = v;
     else if (!strcmp(name, "latency_tiles")) h->latency_tiles = v;
+    else if (!strcmp(name, "dataflow")) h->dataflow = v;
+    else if (!strcmp(name, "dataflow_max_nt")) h->dataflow_max_nt = v;
+    else if (!strcmp(name, "dataflow_max_slots")) h->dataflow_max_slots = v;
     else if (!strcmp(name, "max_slots")) { if (v < 1) return fail(h, GPHIP_ERR_ARG, "max_slots < 1"); h->max_slots = v; }
     else return fail(h, GPHIP_ERR_ARG, "unknown option");
     return GPHIP_OK;

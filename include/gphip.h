@@ -96,8 +96,17 @@ int gphip_covariance(gphip_handle h, const double* theta, int p, double* K);
 int gphip_solve(gphip_handle h, const double* rhs, int64_t nrhs, double* out);
 int gphip_logdet(gphip_handle h, double* out);
 
-/* Options: "panel" (outer panel width in 128-tiles, default 4), "profile" (0/1),
- * "xcd_swizzle" (0/1), "max_slots" (cap on concurrently resident batch matrices). */
+/* Options (tuning knobs; results do not depend on them beyond rounding order):
+ *   "panel"        outer panel width in 128-tiles (default 4)
+ *   "profile"      0 off, 1 trailing SYRK + whole evaluation, 2 every kernel class
+ *   "xcd_swizzle"  0/1 XCD-aware tile order of the GEMM launches (default 1)
+ *   "supertile"    0/1 8x8 super-tile order of the trailing SYRK (default 0, measured slower)
+ *   "lookahead"    0/1 factor panel k+1 on a second stream under the trailing update of panel k (default 1)
+ *   "latency_gemm" / "latency_tiles"   4x4-wave GEMM shape for launches of <= latency_tiles tiles (small N)
+ *   "dataflow"     0/1 single-launch dataflow Cholesky (one workgroup per tile, flags instead of launches)
+ *                  for problems of <= "dataflow_max_nt" 128-tiles (default 64, N <= 8192) and
+ *                  <= "dataflow_max_slots" thetas per call (default 8); bit-identical results
+ *   "max_slots"    cap on concurrently resident batch matrices */
 int gphip_set_option(gphip_handle h, const char* name, double value);
 
 /* Per-kernel-class timing, measured with HIP events on the handle's stream while "profile"=1.

@@ -138,12 +138,56 @@ def test_panel_width_and_swizzle_invariance():
     th = syn.default_theta("se_ard", 4)
     want = orc.log_likelihood("se_ard", th, X, y)
     h = _lib.Handle(X, y, "se_ard")
+    h.set_option("dataflow", 0)                # the multi-kernel schedule is what these knobs shape
     for panel in (1, 2, 3, 4, 8):
         for swz in (0, 1):
             h.set_option("panel", panel)
             h.set_option("xcd_swizzle", swz)
             ll, info = h.loglik(th)
             assert info == 0 and close(ll, want, 1100), (panel, swz, ll, want)
+    h.close()
+
+
+@pytest.mark.parametrize("n,d,kernel,dtype", [(100, 2, "se_ard", 64), (128, 1, "se", 64), (777, 3, "matern52_ard", 64),
+                                               (2500, 8, "se_ard", 64), (1300, 4, "matern52", 32)])
+def test_dataflow_schedule_equals_multikernel(n, d, kernel, dtype):
+    """The single-launch dataflow Cholesky (one workgroup per tile, dependency flags) performs the same
+    arithmetic in the same order as the multi-kernel schedule: results must be IDENTICAL, for single
+    thetas, small batches, repeated calls (flag epochs), the fitted state behind predict/solve, and
+    the not-SPD verdict."""
+    X, y = syn.make_dataset(n, d)
+    th = syn.default_theta(kernel, d, dtype="f64" if dtype == 64 else "f32")
+    h = _lib.Handle(X, y, kernel, dtype=dtype)
+    Th = np.stack([th * (1.0 + 0.07 * k) for k in range(5)])
+    Xs = syn.make_test_points(40, d)
+    res = {}
+    for df in (0, 1, 1):                                   # second dataflow pass: flags carry older epochs
+        h.set_option("dataflow", df)
+        parts = h.loglik_parts(th)
+        batch = h.loglik_batch(Th)
+        assert h.fit(th) == 0
+        res.setdefault(df, []).append((parts, batch, h.predict(Xs), h.solve(y), h.logdet()))
+    (p0, b0, pr0, s0, l0), (p1, b1, pr1, s1, l1), (p2, b2, pr2, s2, l2) = res[0][0], res[1][0], res[1][1]
+    for pa, ba, pra, sa, la in ((p1, b1, pr1, s1, l1), (p2, b2, pr2, s2, l2)):
+        assert pa == p0 and la == l0
+        assert np.array_equal(ba[0], b0[0]) and np.array_equal(ba[1], b0[1])
+        assert np.array_equal(pra[0], pr0[0]) and np.array_equal(pra[1], pr0[1]) and np.array_equal(sa, s0)
+    if dtype == 64:
+        assert close(p1[0], orc.log_likelihood(kernel, th, X, y), n)
+    h.close()
+
+
+def test_dataflow_not_spd_verdict():
+    X, y = syn.make_dataset(300, 2)
+    X[150] = X[7]                                          # duplicate row, zero nugget: singular K (fixture F4 case)
+    th = np.array([1.0, 1.0, 1.0, 0.0])
+    h = _lib.Handle(X, y, "se_ard")
+    for df in (0, 1):
+        h.set_option("dataflow", df)
+        ll, info = h.loglik(th)
+        assert info == 1
+        ll2, info2 = h.loglik(np.array([1.0, 1.0, 1.0, 0.1]))      # and the handle keeps working
+        assert info2 == 0 and np.isfinite(ll2)
     h.close()
 
 
