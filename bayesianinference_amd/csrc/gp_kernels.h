@@ -285,13 +285,14 @@ __device__ long long g_stamps[64];
 #define GP_STAMP(i) do { } while (0)
 #endif
 
-// 1/sqrt(x) for the pivot chain: hardware seed (v_rsq_f64, ~5e-8) + one third-order correction
-// y (1 + e/2 + 3e^2/8), e = 1 - x y^2  ->  relative error ~1e-16 + O(e^3); shorter dependent chain
-// than the library rsqrt.  x is a checked positive pivot (> tol).
+// 1/sqrt(x) for the pivot chain: hardware seed (v_rsq_f64, relative error ~5e-8) + one Newton step
+// y + (y/2)(1 - x y^2)  ->  ~4e-15, far below the N eps backward error of the factorisation; three
+// dependent operations after the seed instead of the library rsqrt's ~dozen.
 __device__ __forceinline__ double fast_rsqrt(double x) {
     const double y = __builtin_amdgcn_rsq(x);
+    const double hy = 0.5 * y;
     const double e = __builtin_fma(-x * y, y, 1.0);
-    return __builtin_fma(y * e, __builtin_fma(0.375, e, 0.5), y);
+    return __builtin_fma(hy, e, y);
 }
 
 constexpr int PT_LDS_ELEMS = 36 * 256 + TB;     // tiles + dinv[128]  (+ 2 doubles of reduction scratch)
@@ -303,10 +304,10 @@ __device__ __forceinline__ int ptile(int bi, int bj) { return ((bi * (bi + 1) / 
 // L tiles and the diagonal inverses W_rr are read from LDS; the W[r][PB] this wave has already
 // produced stay in registers in the MFMA D layout, which is exactly the B-operand layout of the
 // next product (Num<T>::kidx), and go straight to the Winv workspace.
-template <typename T, int PB>
+template <typename T, int PB, int NB = 8>
 __device__ __forceinline__ void inv_block_column(const T* __restrict__ Ls, T* __restrict__ Wg, int l15, int l4) {
     typedef typename Num<T>::acc_t acc_t;
-    constexpr int NQ = 7 - PB;
+    constexpr int NQ = NB - 1 - PB;
     acc_t w[NQ > 0 ? NQ : 1];
     const T* Wpp = Ls + ptile(PB, PB);
 #pragma unroll
@@ -339,7 +340,7 @@ __device__ __forceinline__ void inv_block_column(const T* __restrict__ Ls, T* __
         }
         w[qq] = out;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) Wg[(PB * 16 + l15) * TB + q * 16 + Num<T>::drow(l4, r)] = out[r];
+        for (int r = 0; r < 4; ++r) Wg[(PB * 16 + l15) * (16 * NB) + q * 16 + Num<T>::drow(l4, r)] = out[r];
     }
 }
 
@@ -349,9 +350,9 @@ __device__ __forceinline__ void inv_block_column(const T* __restrict__ Ls, T* __
 // throughput instead of one tile's latency at a time.  A wave with fewer than NR tiles recomputes
 // the last tile and skips the store.
 template <typename T, int NR>
-__device__ __forceinline__ void potrf_update(T* __restrict__ Ls, int p, int uw, int l15, int l4) {
+__device__ __forceinline__ void potrf_update(T* __restrict__ Ls, int p, int t, int uw, int l15, int l4) {
     typedef typename Num<T>::acc_t acc_t;
-    const int t = 7 - p, ntile = t * (t + 1) / 2;
+    const int ntile = t * (t + 1) / 2;      // t = block rows below the panel
     acc_t acc[NR];
     T fa[NR][4], fb[NR][4];
     T* Ct[NR];
@@ -388,17 +389,86 @@ __device__ __forceinline__ void potrf_update(T* __restrict__ Ls, int p, int uw, 
     if (NR == 7) GP_STAMP(42);
 }
 
+// W = L^-1 of a factored block in the tile-packed LDS image (destroys the diagonal tiles of the
+// image): (i) the NB 16x16 diagonal inverses, (ii) the off-diagonal blocks column by column on the
+// MFMA, (iii) W (with an explicit zero upper triangle) to Wg, leading dimension 16 NB.
+// dinv[c] = 1 / L_cc.  All 256 threads; ends without a barrier.
+template <typename T, int NB>
+__device__ __forceinline__ void tri_inverse_lds(T* __restrict__ Ls, const T* __restrict__ dinv, T* __restrict__ Wg) {
+    constexpr int NE = 16 * NB;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int er = tid & 15, ec = tid >> 4;
+    // ------------------------------ inverse phase ------------------------------
+    {   // (i) the eight 16x16 diagonal inverses: thread = (block, column)
+        T w[16];
+        const int blk = tid >> 4, c = tid & 15;
+        T* Dbb = Ls + ptile(blk & (NB - 1), blk & (NB - 1));
+        if (tid < NE) {
+            // column c of L_bb^-1 by forward substitution on e_c, right-looking (short dependent chain)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) w[i] = (i == c) ? (T)1 : (T)0;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                w[k] *= dinv[16 * blk + k];
+#pragma unroll
+                for (int i = k + 1; i < 16; ++i) w[i] = __builtin_fma(-w[k], Dbb[k * 16 + i], w[i]);
+            }
+        }
+        __syncthreads();
+        if (tid < NE) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                if (i >= c) Dbb[c * 16 + i] = w[i];
+        }
+        __syncthreads();
+    }
+    GP_STAMP(32);
+    // (ii) the off-diagonal blocks: block columns are independent, wave w owns columns w and NB-1-w
+    {
+        const int uw = __builtin_amdgcn_readfirstlane(wave);
+        if constexpr (NB == 8) {
+            if (uw == 0) {
+                inv_block_column<T, 0, 8>(Ls, Wg, l15, l4);
+            } else if (uw == 1) {
+                inv_block_column<T, 1, 8>(Ls, Wg, l15, l4);
+                inv_block_column<T, 6, 8>(Ls, Wg, l15, l4);
+            } else if (uw == 2) {
+                inv_block_column<T, 2, 8>(Ls, Wg, l15, l4);
+                inv_block_column<T, 5, 8>(Ls, Wg, l15, l4);
+            } else {
+                inv_block_column<T, 3, 8>(Ls, Wg, l15, l4);
+                inv_block_column<T, 4, 8>(Ls, Wg, l15, l4);
+            }
+        } else {
+            if (uw == 0) inv_block_column<T, 0, 4>(Ls, Wg, l15, l4);
+            else if (uw == 1) inv_block_column<T, 1, 4>(Ls, Wg, l15, l4);
+            else if (uw == 2) inv_block_column<T, 2, 4>(Ls, Wg, l15, l4);
+        }
+    }
+    GP_STAMP(33);
+    // diagonal blocks of W and an explicit zero upper triangle (the blocks below went out above)
+    for (int bi = 0; bi < NB; ++bi)
+        for (int bj = bi; bj < NB; ++bj) {
+            T v = (T)0;
+            if (bi == bj && er >= ec) v = Ls[ptile(bi, bj) + tid];
+            Wg[(bj * 16 + ec) * NE + bi * 16 + er] = v;
+        }
+}
+
 // Core of potrf128 on a tile-packed LDS image that is already in place (all 256 threads; the caller
-// has synchronised after filling Ls).  Writes L to Ad (global, leading dimension ld), W = L^-1 to Wg
-// (128x128, leading dimension 128, explicit zero upper triangle), sum log L_jj to *logdet_out and
-// 1 to *info_out on a bad pivot.
-template <typename T>
+// has synchronised after filling Ls).  NB = 16-blocks per side: 8 (128x128, the tile of the
+// multi-kernel schedule) or 4 (64x64, the fine-grained dataflow schedule).  Writes L to Ad (global,
+// leading dimension ld), W = L^-1 to Wg (leading dimension 16 NB, explicit zero upper triangle),
+// sum log L_jj to *logdet_out and 1 to *info_out on a bad pivot.
+template <typename T, int NB = 8>
 __device__ __forceinline__ void potrf128_core(double* __restrict__ lds_raw, T* __restrict__ Ad, long ld,
                                               T* __restrict__ Wg, double* __restrict__ logdet_out,
                                               int* __restrict__ info_out, T tol) {
     double* red = lds_raw;                      // 2 doubles
-    T* Ls = reinterpret_cast<T*>(lds_raw + 2);  // 36 tiles + dinv[128]
-    T* dinv = Ls + 36 * 256;
+    constexpr int NE = 16 * NB;                 // block edge
+    T* Ls = reinterpret_cast<T*>(lds_raw + 2);  // NB(NB+1)/2 tiles + dinv[NE]
+    T* dinv = Ls + (NB * (NB + 1) / 2) * 256;
     typedef typename Num<T>::acc_t acc_t;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
@@ -407,7 +477,7 @@ __device__ __forceinline__ void potrf128_core(double* __restrict__ lds_raw, T* _
     GP_STAMP(1);
 
     // ------------------------------ factor phase ------------------------------
-    for (int p = 0; p < 8; ++p) {
+    for (int p = 0; p < NB; ++p) {
         T* Dpp = Ls + ptile(p, p);
         GP_STAMP(2 + 3 * p);
         if (wave == 0 && sizeof(T) == 8) {
@@ -426,20 +496,27 @@ __device__ __forceinline__ void potrf128_core(double* __restrict__ lds_raw, T* _
                 double sl[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) sl[q] = __shfl(a[s4], 16 * q + l15);
+                double rsv[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int c = 4 * s4 + q;
-                    double dj = Num<double>::readlane(sl[q], c);
-                    if (!(dj > (double)tol)) { bad = true; dj = 1.0; }
+                    // Pivot chain: readlane, rsq + one Newton step, mul, readlane, fma -- nothing else.
+                    // A bad pivot (<= tol, NaN) only raises the flag; its NaN/Inf flows on and the
+                    // caller discards the values (info != 0), so no select sits on the chain.  Lane c
+                    // already holds d = A[c][c], so scaling every lane by rs leaves sqrt(d) there.
+                    const double dj = Num<double>::readlane(sl[q], c);
+                    bad = bad || !(dj > (double)tol);
                     const double rs = fast_rsqrt(dj);
-                    sl[q] = (l15 == c) ? dj * rs : sl[q] * rs;
-                    if (lane == 0) dinv[16 * p + c] = (T)rs;
+                    rsv[q] = rs;
+                    sl[q] *= rs;
 #pragma unroll
                     for (int q2 = q + 1; q2 < 4; ++q2) {
                         const double lc = Num<double>::readlane(sl[q], 4 * s4 + q2);   // L[4 s4 + q2][c]
                         sl[q2] = __builtin_fma(-sl[q], lc, sl[q2]);
                     }
                 }
+                if (lane < 4)
+                    dinv[16 * p + 4 * s4 + lane] = (T)((lane == 0) ? rsv[0] : (lane == 1) ? rsv[1] : (lane == 2) ? rsv[2] : rsv[3]);
                 // back to the D layout; then the rank-4 update of the later column groups is ONE MFMA
                 // whose A and B operands are the lane's own column value (L is zero above its diagonal)
                 const double mine = (l4 == 0) ? sl[0] : (l4 == 1) ? sl[1] : (l4 == 2) ? sl[2] : sl[3];
@@ -482,8 +559,8 @@ __device__ __forceinline__ void potrf128_core(double* __restrict__ lds_raw, T* _
         }
         __syncthreads();
         GP_STAMP(3 + 3 * p);
-        if (p == 7) break;
-        if (tid < TB - 16 * p - 16) {         // (b) rows below: x L_pp^T = a, one row per thread
+        if (p == NB - 1) break;
+        if (tid < NE - 16 * p - 16) {         // (b) rows below: x L_pp^T = a, one row per thread
             T* Xr = Ls + ptile(p + 1 + (tid >> 4), p) + (tid & 15);
             T x[16];
 #pragma unroll
@@ -502,15 +579,15 @@ __device__ __forceinline__ void potrf128_core(double* __restrict__ lds_raw, T* _
         __syncthreads();
         GP_STAMP(4 + 3 * p);
         {                                      // (c) trailing update C -= X X^T on MFMA
-            const int nround = ((7 - p) * (8 - p) / 2 + 3) >> 2;
+            const int nround = ((NB - 1 - p) * (NB - p) / 2 + 3) >> 2;
             const int uw = __builtin_amdgcn_readfirstlane(wave);
             switch (nround) {
-                case 7: potrf_update<T, 7>(Ls, p, uw, l15, l4); break;
-                case 6: potrf_update<T, 6>(Ls, p, uw, l15, l4); break;
-                case 4: potrf_update<T, 4>(Ls, p, uw, l15, l4); break;
-                case 3: potrf_update<T, 3>(Ls, p, uw, l15, l4); break;
-                case 2: potrf_update<T, 2>(Ls, p, uw, l15, l4); break;
-                default: potrf_update<T, 1>(Ls, p, uw, l15, l4); break;
+                case 7: potrf_update<T, 7>(Ls, p, NB - 1 - p, uw, l15, l4); break;
+                case 6: potrf_update<T, 6>(Ls, p, NB - 1 - p, uw, l15, l4); break;
+                case 4: potrf_update<T, 4>(Ls, p, NB - 1 - p, uw, l15, l4); break;
+                case 3: potrf_update<T, 3>(Ls, p, NB - 1 - p, uw, l15, l4); break;
+                case 2: potrf_update<T, 2>(Ls, p, NB - 1 - p, uw, l15, l4); break;
+                default: potrf_update<T, 1>(Ls, p, NB - 1 - p, uw, l15, l4); break;
             }
         }
         __syncthreads();
@@ -518,66 +595,18 @@ __device__ __forceinline__ void potrf128_core(double* __restrict__ lds_raw, T* _
 
     GP_STAMP(30);
     // L back to HBM (lower-triangle tiles; diagonal tiles whole, their upper part is never read)
-    for (int bi = 0; bi < 8; ++bi)
+    for (int bi = 0; bi < NB; ++bi)
         for (int bj = 0; bj <= bi; ++bj)
             Ad[(long)(bj * 16 + ec) * ld + bi * 16 + er] = Ls[ptile(bi, bj) + tid];
     {   // sum log L_jj = -sum log dinv_j  (always accumulated in fp64)
         double lg = 0.0;
-        if (tid < TB) lg = -log((double)dinv[tid]);
+        if (tid < NE) lg = -log((double)dinv[tid]);
         for (int off = 32; off > 0; off >>= 1) lg += __shfl_down(lg, off);
-        if (tid < TB && lane == 0) red[wave] = lg;
+        if (wave < 2 && lane == 0) red[wave] = lg;
     }
 
     GP_STAMP(31);
-    // ------------------------------ inverse phase ------------------------------
-    {   // (i) the eight 16x16 diagonal inverses: thread = (block, column)
-        T w[16];
-        const int blk = tid >> 4, c = tid & 15;
-        T* Dbb = Ls + ptile(blk & 7, blk & 7);
-        if (tid < TB) {
-            // column c of L_bb^-1 by forward substitution on e_c, right-looking (short dependent chain)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) w[i] = (i == c) ? (T)1 : (T)0;
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                w[k] *= dinv[16 * blk + k];
-#pragma unroll
-                for (int i = k + 1; i < 16; ++i) w[i] = __builtin_fma(-w[k], Dbb[k * 16 + i], w[i]);
-            }
-        }
-        __syncthreads();
-        if (tid < TB) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i)
-                if (i >= c) Dbb[c * 16 + i] = w[i];
-        }
-        __syncthreads();
-    }
-    GP_STAMP(32);
-    // (ii) the off-diagonal blocks: block columns are independent, wave w owns columns w and 7-w
-    {
-        const int uw = __builtin_amdgcn_readfirstlane(wave);
-        if (uw == 0) {
-            inv_block_column<T, 0>(Ls, Wg, l15, l4);
-        } else if (uw == 1) {
-            inv_block_column<T, 1>(Ls, Wg, l15, l4);
-            inv_block_column<T, 6>(Ls, Wg, l15, l4);
-        } else if (uw == 2) {
-            inv_block_column<T, 2>(Ls, Wg, l15, l4);
-            inv_block_column<T, 5>(Ls, Wg, l15, l4);
-        } else {
-            inv_block_column<T, 3>(Ls, Wg, l15, l4);
-            inv_block_column<T, 4>(Ls, Wg, l15, l4);
-        }
-    }
-    GP_STAMP(33);
-    // diagonal blocks of W and an explicit zero upper triangle (the blocks below went out above)
-    for (int bi = 0; bi < 8; ++bi)
-        for (int bj = bi; bj < 8; ++bj) {
-            T v = (T)0;
-            if (bi == bj && er >= ec) v = Ls[ptile(bi, bj) + tid];
-            Wg[(bj * 16 + ec) * TB + bi * 16 + er] = v;
-        }
+    tri_inverse_lds<T, NB>(Ls, dinv, Wg);
     GP_STAMP(34);
     if (tid == 0) {
         *logdet_out = red[0] + red[1];
@@ -587,10 +616,10 @@ __device__ __forceinline__ void potrf128_core(double* __restrict__ lds_raw, T* _
 
 // Out-of-line copy for chol_dataflow_kernel: keeps the factorisation's register allocation apart from
 // the accumulator-heavy MFMA loops of that kernel (inlined, the allocator spills accumulators there).
-template <typename T>
+template <typename T, int NB>
 __device__ __noinline__ void potrf128_core_call(double* lds_raw, T* Ad, long ld, T* Wg, double* logdet_out,
                                                 int* info_out, T tol) {
-    potrf128_core<T>(lds_raw, Ad, ld, Wg, logdet_out, info_out, tol);
+    potrf128_core<T, NB>(lds_raw, Ad, ld, Wg, logdet_out, info_out, tol);
 }
 
 template <typename T>
@@ -611,6 +640,27 @@ __global__ __launch_bounds__(256) void potrf128_kernel(T* __restrict__ Abase, lo
     __syncthreads();
     potrf128_core<T>(lds_raw, Ad, ld, Winv + ((long)slot * nt + b) * TB * TB, partial + (long)slot * nt + b,
                      info + slot, (T)slotp[(long)slot * SLOTP + 3]);
+}
+
+// W_b = L_bb^-1 of every 128x128 diagonal block of an already factored matrix (grid = (Nt, slots)).
+// The fine-grained (64x64) dataflow schedule only produces inverses of 64-blocks; the solve /
+// prediction / gradient paths substitute with 128-blocks, so gphip_fit re-inverts once here.
+template <typename T>
+__global__ __launch_bounds__(256) void trtri128_kernel(const T* __restrict__ Abase, long ld, long bstride,
+                                                       T* __restrict__ Winv, int nt) {
+    extern __shared__ double lds_raw[];
+    T* Ls = reinterpret_cast<T*>(lds_raw + 2);
+    T* dinv = Ls + 36 * 256;
+    const int tid = threadIdx.x;
+    const int er = tid & 15, ec = tid >> 4;
+    const int b = blockIdx.x, slot = blockIdx.y;
+    const T* Ad = Abase + (long)slot * bstride + (long)b * TB * (ld + 1);
+    for (int bi = 0; bi < 8; ++bi)
+        for (int bj = 0; bj <= bi; ++bj)
+            Ls[ptile(bi, bj) + tid] = Ad[(long)(bj * 16 + ec) * ld + bi * 16 + er];
+    if (tid < TB) dinv[tid] = (T)1 / Ad[(long)tid * ld + tid];
+    __syncthreads();
+    tri_inverse_lds<T, 8>(Ls, dinv, Winv + ((long)slot * nt + b) * TB * TB);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -921,16 +971,16 @@ __global__ __launch_bounds__(64 * NWI * NWJ, (NWI * NWJ == 4) ? 2 : 4) void gemm
 // ---------------------------------------------------------------------------------------------
 template <typename T>
 struct DfArgs {
-    T* A; long ld; long bstride;              // workspace, (Nt+1) x (Nt+1) tiles per slot
-    T* W; long w_bstride;                     // W_b = L_bb^-1 tiles, [slot][Nt][128*128]
-    double* partial;                          // [slot][Nt] sum log L_jj per diagonal block
+    T* A; long ld; long bstride;              // workspace (column-major, leading dimension ld) per slot
+    T* W; long w_bstride;                     // W_b = L_bb^-1 blocks, [slot][nd][TBX*TBX]
+    double* partial;                          // [slot][nd] sum log L_jj per diagonal block
     int* info;                                // [slot]
     const double* slotp;
-    int* flags; long f_bstride;               // [slot][(Nt+1)^2]: ready(i,j) at i*(Nt+1)+j
+    int* flags; long f_bstride;               // [slot][(nd+1)^2]: ready(i,j) at i*(nd+1)+j
     unsigned long long* ticket;
     unsigned long long ticket_base;           // value of *ticket before this launch
     int* abort_flag;
-    int Nt, nslots, epoch;
+    int nd, nslots, epoch;                    // nd = diagonal blocks = Npad / TBX; tile row nd = the rhs rows
     long long* trace;                         // developer timing (scripts/micro/df_trace.hip): 8 stamps per task, or null
 };
 
@@ -953,18 +1003,38 @@ __device__ __forceinline__ void df_wait(const int* f, int epoch, int* abort_flag
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 }
 
-template <typename T>
+// LDS image of one staged operand tile of the dataflow kernel.  TBX = 128: the gemm_nt image.
+// TBX = 64 (fp64 only): one LDS-DMA instruction carries the 64 rows of k-columns {k0, k0+2}
+// (lanes 0-31 / 32-63), instruction q = 2 (k>>2) + (k&1) lands at q * 144 doubles -- the same pair
+// trick as the fp32 image, so MFMA fragment reads stay bank-conflict free.
+constexpr int LD64 = 144;
+template <typename T, int TBX> __device__ __forceinline__ int df_lds_off(int k, int row) {
+    if constexpr (TBX == 128) return lds_off<T>(k, row);
+    else return ((k >> 2) * 2 + (k & 1)) * LD64 + ((k >> 1) & 1) * 64 + row;
+}
+template <typename T, int TBX> constexpr int df_stage_elems() {
+    return TBX == 128 ? STAGE_BYTES / (int)sizeof(T) : 2 * 8 * LD64;
+}
+template <typename T, int TBX> constexpr size_t df_lds_bytes() {
+    constexpr size_t gemm = 2 * (size_t)df_stage_elems<T, TBX>() * sizeof(T);
+    constexpr size_t nb = TBX / 16;
+    constexpr size_t potrf = 16 + (nb * (nb + 1) / 2 * 256 + TBX) * sizeof(T);
+    return gemm > potrf ? gemm : potrf;
+}
+
+template <typename T, int TBX>
 __global__ __launch_bounds__(256, 2) void chol_dataflow_kernel(DfArgs<T> g) {
-    constexpr int FI = 4, FJ = 4;
+    static_assert(TBX == 128 || (TBX == 64 && sizeof(T) == 8), "64-tiles are implemented for fp64 only");
+    constexpr int FI = TBX / 32, FJ = TBX / 32, WT = TBX / 2;   // MFMA tiles per wave, wave tile edge
     extern __shared__ double smem_raw[];
     __shared__ int s_task;
     T* smem = reinterpret_cast<T*>(smem_raw);
     typedef typename Num<T>::acc_t acc_t;
     constexpr int GK = Num<T>::GK;
-    constexpr int STAGE = STAGE_BYTES / (int)sizeof(T);
+    constexpr int STAGE = df_stage_elems<T, TBX>();
     constexpr int JOFF = STAGE / 2;
     constexpr bool F64 = sizeof(T) == 8;
-    constexpr int SPB = TB / GK;                            // LDS stages per 128-wide slab
+    constexpr int SPB = TBX / GK;                           // LDS stages per TBX-wide slab
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wi = wave & 1, wj = wave >> 1;
     const int l15 = lane & 15, l4 = lane >> 4;
@@ -973,7 +1043,7 @@ __global__ __launch_bounds__(256, 2) void chol_dataflow_kernel(DfArgs<T> g) {
     if (tid == 0) s_task = (int)(atomicAdd(g.ticket, 1ull) - g.ticket_base);
     __syncthreads();
     const int task = __builtin_amdgcn_readfirstlane(s_task);
-    const int R = g.Nt + 1;
+    const int R = g.nd + 1;
     const int slot = task % g.nslots, q = task / g.nslots;
     // q -> (j, i): column-major over the lower triangle, column j starts at off(j) = jR - j(j-1)/2
     int j = (int)(((double)(2 * R + 1) - sqrt((double)(2 * R + 1) * (2 * R + 1) - 8.0 * q)) * 0.5);
@@ -988,12 +1058,12 @@ __global__ __launch_bounds__(256, 2) void chol_dataflow_kernel(DfArgs<T> g) {
     stamp(0);
     T* As = g.A + (long)slot * g.bstride;
     int* F = g.flags + (long)slot * g.f_bstride;
-    T* Wj = g.W + (long)slot * g.w_bstride + (long)j * TB * TB;
-    T* Ct = As + (long)j * TB * g.ld + (long)i * TB;      // tile (i,j)
+    T* Wj = g.W + (long)slot * g.w_bstride + (long)j * TBX * TBX;
+    T* Ct = As + (long)j * TBX * g.ld + (long)i * TBX;    // tile (i,j)
 
     acc_t acc[FJ][FI];
-    // D-layout address of this lane's accumulators inside a 128x128 tile with leading dimension ldc
-    auto c_ptr = [&](T* base, long ldc) { return base + (long)(wj * 64) * ldc + wi * 64 + l15; };
+    // D-layout address of this lane's accumulators inside a TBX x TBX tile with leading dimension ldc
+    auto c_ptr = [&](T* base, long ldc) { return base + (long)(wj * WT) * ldc + wi * WT + l15; };
     auto load_c = [&](const T* base, long ldc) {
         const T* cp = c_ptr(const_cast<T*>(base), ldc);
 #pragma unroll
@@ -1028,33 +1098,46 @@ __global__ __launch_bounds__(256, 2) void chol_dataflow_kernel(DfArgs<T> g) {
         auto stage = [&](int kb, int st) {
             T* Is = smem + st * STAGE;
             T* Js = Is + JOFF;
+            if constexpr (TBX == 128) {
 #pragma unroll
-            for (int s2 = 0; s2 < 4; ++s2) {
-                const int qq = uw + 4 * s2;
-                if (F64) {
-                    const long kcol = (long)kb * GK + qq;
-                    __builtin_amdgcn_global_load_lds((glb_void*)(Ig + kcol * ldi + 2 * lane),
-                                                     (lds_void*)(Is + qq * LDT), 16, 0, 0);
-                    __builtin_amdgcn_global_load_lds((glb_void*)(Jg + kcol * ldj + 2 * lane),
-                                                     (lds_void*)(Js + qq * LDT), 16, 0, 0);
-                } else {
+                for (int s2 = 0; s2 < 4; ++s2) {
+                    const int qq = uw + 4 * s2;
+                    if (F64) {
+                        const long kcol = (long)kb * GK + qq;
+                        __builtin_amdgcn_global_load_lds((glb_void*)(Ig + kcol * ldi + 2 * lane),
+                                                         (lds_void*)(Is + qq * LDT), 16, 0, 0);
+                        __builtin_amdgcn_global_load_lds((glb_void*)(Jg + kcol * ldj + 2 * lane),
+                                                         (lds_void*)(Js + qq * LDT), 16, 0, 0);
+                    } else {
+                        const long kcol = (long)kb * GK + 4 * (qq >> 1) + (qq & 1) + 2 * (lane >> 5);
+                        const int row = 4 * (lane & 31);
+                        __builtin_amdgcn_global_load_lds((glb_void*)(Ig + kcol * ldi + row),
+                                                         (lds_void*)(Is + qq * LDP), 16, 0, 0);
+                        __builtin_amdgcn_global_load_lds((glb_void*)(Jg + kcol * ldj + row),
+                                                         (lds_void*)(Js + qq * LDP), 16, 0, 0);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const int qq = uw + 4 * s2;           // 8 instructions per operand tile
                     const long kcol = (long)kb * GK + 4 * (qq >> 1) + (qq & 1) + 2 * (lane >> 5);
-                    const int row = 4 * (lane & 31);
+                    const int row = 2 * (lane & 31);
                     __builtin_amdgcn_global_load_lds((glb_void*)(Ig + kcol * ldi + row),
-                                                     (lds_void*)(Is + qq * LDP), 16, 0, 0);
+                                                     (lds_void*)(Is + qq * LD64), 16, 0, 0);
                     __builtin_amdgcn_global_load_lds((glb_void*)(Jg + kcol * ldj + row),
-                                                     (lds_void*)(Js + qq * LDP), 16, 0, 0);
+                                                     (lds_void*)(Js + qq * LD64), 16, 0, 0);
                 }
             }
         };
         auto load_frags = [&](int buf, int kk, T* fi, T* fj) {
-            const T* Is = smem + buf * STAGE + wi * 64 + l15;
-            const T* Js = smem + buf * STAGE + JOFF + wj * 64 + l15;
+            const T* Is = smem + buf * STAGE + wi * WT + l15;
+            const T* Js = smem + buf * STAGE + JOFF + wj * WT + l15;
             const int k = 4 * kk + l4;
 #pragma unroll
-            for (int f = 0; f < FI; ++f) fi[f] = Is[lds_off<T>(k, f * 16)];
+            for (int f = 0; f < FI; ++f) fi[f] = Is[df_lds_off<T, TBX>(k, f * 16)];
 #pragma unroll
-            for (int f = 0; f < FJ; ++f) fj[f] = Js[lds_off<T>(k, f * 16)];
+            for (int f = 0; f < FJ; ++f) fj[f] = Js[df_lds_off<T, TBX>(k, f * 16)];
         };
         auto mfma_block = [&](const T* fi, const T* fj) {
             T nj[FJ];
@@ -1092,16 +1175,16 @@ __global__ __launch_bounds__(256, 2) void chol_dataflow_kernel(DfArgs<T> g) {
 
     // ---- accumulate the updates of all earlier columns
     if (j > 0 || i == j) load_c(Ct, g.ld);
-    for (int b = 0; b < j; ++b) {                          // one 128-wide slab per finished column b
+    for (int b = 0; b < j; ++b) {                          // one TBX-wide slab per finished column b
         df_wait(F + i * R + b, g.epoch, g.abort_flag);
         if (i != j) df_wait(F + j * R + b, g.epoch, g.abort_flag);
         if (b == j - 1) stamp(6);
-        run_k(As + (long)b * TB * g.ld + (long)i * TB, g.ld, As + (long)b * TB * g.ld + (long)j * TB, g.ld, SPB, true);
+        run_k(As + (long)b * TBX * g.ld + (long)i * TBX, g.ld, As + (long)b * TBX * g.ld + (long)j * TBX, g.ld, SPB, true);
     }
     stamp(1);
 
     if (i == j) {
-        if (j == g.Nt) {                                    // corner of the border: -|z|^2 accumulates here
+        if (j == g.nd) {                                    // corner of the border: -|z|^2 accumulates here
             store_c(Ct, g.ld);
             return;
         }
@@ -1111,7 +1194,7 @@ __global__ __launch_bounds__(256, 2) void chol_dataflow_kernel(DfArgs<T> g) {
         for (int x = 0; x < FJ; ++x)
 #pragma unroll
             for (int y = 0; y < FI; ++y) {
-                const int bi = wi * 4 + y, bj = wj * 4 + x;
+                const int bi = wi * FI + y, bj = wj * FJ + x;
                 if (bi >= bj) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) Ls[ptile(bi, bj) + Num<T>::drow(l4, r) * 16 + l15] = acc[x][y][r];
@@ -1119,8 +1202,8 @@ __global__ __launch_bounds__(256, 2) void chol_dataflow_kernel(DfArgs<T> g) {
             }
         __syncthreads();
         stamp(2);
-        potrf128_core_call<T>(smem_raw, Ct, g.ld, Wj, g.partial + (long)slot * g.Nt + j, g.info + slot,
-                              (T)g.slotp[(long)slot * SLOTP + 3]);
+        potrf128_core_call<T, TBX / 16>(smem_raw, Ct, g.ld, Wj, g.partial + (long)slot * g.nd + j, g.info + slot,
+                                        (T)g.slotp[(long)slot * SLOTP + 3]);
         stamp(3);
         publish(j, j);
         stamp(4);
@@ -1137,7 +1220,7 @@ __global__ __launch_bounds__(256, 2) void chol_dataflow_kernel(DfArgs<T> g) {
     stamp(2);
     df_wait(F + j * R + j, g.epoch, g.abort_flag);
     stamp(5);
-    run_k(Ct, g.ld, Wj, TB, SPB, false);
+    run_k(Ct, g.ld, Wj, TBX, SPB, false);
     stamp(3);
     store_c(Ct, g.ld);
     publish(i, j);

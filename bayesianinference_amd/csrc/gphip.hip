@@ -68,6 +68,8 @@ struct gphip_ctx {
     int panel = 4, profile = 0, swizzle = 1, max_slots = 256, lookahead = 1, supertile = 0;
     int latency_gemm = 1, latency_tiles = 256;   // launches of <= latency_tiles tiles use the latency GEMM shape
     int dataflow = 1, dataflow_max_nt = 64, dataflow_max_slots = 8;   // single-launch dataflow Cholesky: latency regime only
+    int dataflow_fine_nt = 16;                   // ... with 64x64 tiles up to this many 128-tiles (fp64)
+    bool want_w = false;                         // the caller substitutes with W_b afterwards (fit / predict / gradient)
     int* dFlags = nullptr;                       // [slots][(Nt+1)^2] ready flags (value = epoch)
     unsigned long long* dTicket = nullptr;       // task ticket counter (+ abort flag in the next word)
     unsigned long long ticket_base = 0;
@@ -183,7 +185,7 @@ void free_slots(gphip_ctx* h) {
 
 size_t slot_bytes(const gphip_ctx* h) {
     return ((size_t)h->ld * h->ld + (size_t)h->d * h->Npad + (size_t)h->Nt * TB * TB) * h->es +
-           (size_t)h->Nt * 8 + (size_t)(h->Nt + 1) * (h->Nt + 1) * 4 + 4096;
+           (size_t)h->Nt * 16 + (size_t)(2 * h->Nt + 1) * (2 * h->Nt + 1) * 4 + 4096;
 }
 
 int ensure_slots(gphip_ctx* h, int want) {
@@ -203,11 +205,11 @@ int ensure_slots(gphip_ctx* h, int want) {
     HIPCHK(hipMalloc(&h->dW, S * h->Nt * TB * TB * h->es));
     HIPCHK(hipMalloc(&h->dInvEll, S * h->d * 8));
     HIPCHK(hipMalloc(&h->dSlotp, S * SLOTP * 8));
-    HIPCHK(hipMalloc(&h->dPartial, S * h->Nt * 8));
+    HIPCHK(hipMalloc(&h->dPartial, S * 2 * h->Nt * 8));           // per 64-block in the fine dataflow schedule
     HIPCHK(hipMalloc(&h->dRes, S * 2 * 8));
     HIPCHK(hipMalloc(&h->dInfo, S * 4));
-    HIPCHK(hipMalloc(&h->dFlags, S * (h->Nt + 1) * (h->Nt + 1) * 4));
-    HIPCHK(hipMemset(h->dFlags, 0, S * (h->Nt + 1) * (h->Nt + 1) * 4));
+    HIPCHK(hipMalloc(&h->dFlags, S * (2 * h->Nt + 1) * (2 * h->Nt + 1) * 4));
+    HIPCHK(hipMemset(h->dFlags, 0, S * (2 * h->Nt + 1) * (2 * h->Nt + 1) * 4));
     HIPCHK(hipMalloc(&h->dTicket, 16));
     HIPCHK(hipMemset(h->dTicket, 0, 16));
     HIPCHK(hipHostMalloc(&h->hInvEll, S * h->d * 8));
@@ -355,38 +357,53 @@ int queue_panel(gphip_ctx* h, int K0, int nin, int nslots) {
 
 // Single-launch dataflow Cholesky (chol_dataflow_kernel): one workgroup per tile, flags instead of
 // launches.  Used for small / mid problems where the multi-kernel schedule is latency bound.
-template <typename T>
-size_t dataflow_lds() { return std::max((size_t)GEMM_LDS, potrf_lds<T>()); }
-
+// 64x64 tiles (fp64, Nt <= dataflow_fine_nt) halve the serial chain per column once more; they leave
+// inverses of 64-blocks in dW, so callers that substitute afterwards (h->want_w) get the 128-block
+// inverses rebuilt by trtri128.
 bool use_dataflow(const gphip_ctx* h, int nslots) {
     // measured: wins 10-17 % for one theta up to N = 8192, ties at 8-16 slots, loses 35 % at 200 slots
     // (there the multi-kernel schedule's big launches are throughput bound, not latency bound)
     if (!h->dataflow || h->dist_world > 0 || h->Nt > h->dataflow_max_nt || nslots > h->dataflow_max_slots) return false;
-    const long tasks = (long)(h->Nt + 1) * (h->Nt + 2) / 2 * nslots;
+    const long tasks = (long)(2 * h->Nt + 1) * (2 * h->Nt + 2) / 2 * nslots;
     return tasks < (1l << 30);
 }
 
-template <typename T>
-int queue_factor_dataflow(gphip_ctx* h, int nslots) {
-    const int Nt = (int)h->Nt, R = Nt + 1;
+template <typename T, int TBX>
+void launch_dataflow(gphip_ctx* h, int nslots) {
+    const int nd = (int)(h->Npad / TBX), R = nd + 1;
     const long ld = h->ld;
     const long tasks = (long)R * (R + 1) / 2 * nslots;
     DfArgs<T> g{};
     g.A = (T*)h->dA; g.ld = ld; g.bstride = ld * ld;
-    g.W = (T*)h->dW; g.w_bstride = (long)Nt * TB * TB;
+    g.W = (T*)h->dW; g.w_bstride = (long)h->Nt * TB * TB;
     g.partial = h->dPartial; g.info = h->dInfo; g.slotp = h->dSlotp;
-    g.flags = h->dFlags; g.f_bstride = (long)R * R;
+    g.flags = h->dFlags; g.f_bstride = (long)(2 * h->Nt + 1) * (2 * h->Nt + 1);
     g.ticket = h->dTicket; g.ticket_base = h->ticket_base;
     g.abort_flag = reinterpret_cast<int*>(h->dTicket + 1);
-    g.Nt = Nt; g.nslots = nslots; g.epoch = ++h->epoch;
+    g.nd = nd; g.nslots = nslots; g.epoch = ++h->epoch;
     h->ticket_base += (unsigned long long)tasks;
-    h->cs = h->stream;
     {
         ProfScope ps(h, 4, (double)h->Npad * h->Npad * h->Npad / 3.0 * nslots, 0.0);
-        hipLaunchKernelGGL(chol_dataflow_kernel<T>, dim3((unsigned)tasks), dim3(256), dataflow_lds<T>(), h->stream, g);
+        constexpr size_t lds = df_lds_bytes<T, TBX>();
+        hipLaunchKernelGGL((chol_dataflow_kernel<T, TBX>), dim3((unsigned)tasks), dim3(256), lds, h->stream, g);
     }
     hipLaunchKernelGGL(finalize_kernel<T>, dim3(nslots), dim3(64), 0, h->stream, (const T*)h->dA, ld, ld * ld,
-                       (int)h->Npad, h->dPartial, Nt, h->dRes);
+                       (int)h->Npad, h->dPartial, nd, h->dRes);
+}
+
+template <typename T>
+int queue_factor_dataflow(gphip_ctx* h, int nslots) {
+    h->cs = h->stream;
+    if constexpr (sizeof(T) == 8) {
+        if (h->Nt <= h->dataflow_fine_nt) {
+            launch_dataflow<T, 64>(h, nslots);
+            if (h->want_w)
+                hipLaunchKernelGGL(trtri128_kernel<T>, dim3((unsigned)h->Nt, nslots), dim3(256), potrf_lds<T>(), h->stream,
+                                   (const T*)h->dA, h->ld, h->ld * h->ld, (T*)h->dW, (int)h->Nt);
+            return 0;
+        }
+    }
+    launch_dataflow<T, 128>(h, nslots);
     return 0;
 }
 
@@ -575,8 +592,16 @@ template <typename T>
 int set_func_attrs(gphip_ctx* h) {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(potrf128_kernel<T>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)potrf_lds<T>()));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(chol_dataflow_kernel<T>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)dataflow_lds<T>()));
+    constexpr int df128 = (int)df_lds_bytes<T, 128>();
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(chol_dataflow_kernel<T, 128>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, df128));
+    if constexpr (sizeof(T) == 8) {
+        constexpr int df64 = (int)df_lds_bytes<T, 64>();
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(chol_dataflow_kernel<T, 64>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, df64));
+    }
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trtri128_kernel<T>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)potrf_lds<T>()));
 #define GEMM_ATTR(ROLE)                                                                                   \
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<T, ROLE, 2, 2, 2>),             \
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS));                  \
@@ -869,7 +894,9 @@ int gphip_loglik_grad(gphip_handle h, const double* theta, int p, double* out, d
         return null_kernel_batch(h, theta, 1, out, nullptr, info, grad);
     }
     std::lock_guard<std::recursive_mutex> lk(h->mu);
+    h->want_w = true;
     int rc = eval_batch(h, theta, 1, p, out, nullptr, info);
+    h->want_w = false;
     if (rc) return rc;
     for (int i = 0; i < p; ++i) grad[i] = std::nan("");
     if (*info != 0) return GPHIP_OK;
@@ -922,9 +949,11 @@ int gphip_fit(gphip_handle h, const double* theta, int p, int* info) {
     if (!h || !theta || !info) return fail(h, GPHIP_ERR_ARG, "null argument");
     if (h->kernel_id == GPHIP_KERNEL_NULL) return fail(h, GPHIP_ERR_UNSUPPORTED, "fit: null kernel has no factor");
     double out, parts[2];
-    int rc = eval_batch(h, theta, 1, p, &out, parts, info);
-    if (rc) return rc;
     std::lock_guard<std::recursive_mutex> lk(h->mu);
+    h->want_w = true;                          // the substitutions that follow a fit use the 128-block inverses
+    int rc = eval_batch(h, theta, 1, p, &out, parts, info);
+    h->want_w = false;
+    if (rc) return rc;
     h->fitted = (*info == 0);
     h->theta_fit.assign(theta, theta + p);
     h->logdet_fit = parts[0];
@@ -1022,7 +1051,9 @@ int gphip_predict_samples(gphip_handle h, const double* Thetas, int S, int p, co
     for (int s0 = 0; s0 < S; s0 += h->slots) {
         const int nb = (S - s0 < h->slots) ? (S - s0) : h->slots;
         std::vector<double> ll(nb);
+        h->want_w = true;
         rc = eval_chunk(h, Thetas + (size_t)s0 * p, nb, ll.data(), nullptr, info + s0);   // build + factor, kept
+        h->want_w = false;
         if (rc) return rc;
         // test-point chunk so that the nb V blocks stay within ~8 GiB
         int64_t mcap = (int64_t)((8.0 * (1 << 30)) / ((double)nb * h->Npad * h->es)) / TB * TB;
@@ -1238,6 +1269,7 @@ int gphip_set_option(gphip_handle h, const char* name, double value) {
     else if (!strcmp(name, "dataflow")) h->dataflow = v;
     else if (!strcmp(name, "dataflow_max_nt")) h->dataflow_max_nt = v;
     else if (!strcmp(name, "dataflow_max_slots")) h->dataflow_max_slots = v;
+    else if (!strcmp(name, "dataflow_fine_nt")) h->dataflow_fine_nt = v;
     else if (!strcmp(name, "max_slots")) { if (v < 1) return fail(h, GPHIP_ERR_ARG, "max_slots < 1"); h->max_slots = v; }
     else return fail(h, GPHIP_ERR_ARG, "unknown option");
     return GPHIP_OK;

@@ -1,4 +1,4 @@
-// Per-task timeline of chol_dataflow_kernel<double> on a synthetic SPD matrix (developer tool).
+// Per-task timeline of chol_dataflow_kernel<double, DF_TBX> on a synthetic SPD matrix (developer tool).
 // Prints, for the tasks on the critical path, wall-clock stamps (100 MHz s_memrealtime) in us.
 #include "../../bayesianinference_amd/csrc/gp_kernels.h"
 #include <cstdio>
@@ -7,9 +7,12 @@
 #include <cmath>
 #include <algorithm>
 using namespace gphip;
+#ifndef DF_TBX
+#define DF_TBX 128
+#endif
 int main(int argc, char** argv) {
-    const int Nt = argc > 1 ? atoi(argv[1]) : 8, R = Nt + 1, n = Nt * TB;
-    const long ld = (long)R * TB;
+    const int Nt = argc > 1 ? atoi(argv[1]) : 8, n = Nt * TB, nd = n / DF_TBX, R = nd + 1;   // Nt counts 128-tiles
+    const long ld = (long)(Nt + 1) * TB;
     std::vector<double> A((size_t)ld * ld, 0.0);
     for (int j = 0; j < n; ++j)
         for (int i = j; i < n; ++i) A[(size_t)j * ld + i] = std::exp(-0.5 * (double)(i - j) * (i - j) / 900.0) + (i == j ? 0.1 : 0.0);
@@ -17,12 +20,12 @@ int main(int argc, char** argv) {
     for (int r = 1; r < TB; ++r) A[(size_t)(n + r) * ld + n + r] = 1.0;
     const long ntask = (long)R * (R + 1) / 2;
     double *dA, *dW, *dP, *dS; int *dI, *dF; unsigned long long* dT; long long* dTr;
-    hipMalloc(&dA, A.size() * 8); hipMalloc(&dW, (size_t)Nt * TB * TB * 8); hipMalloc(&dP, Nt * 8); hipMalloc(&dS, 64);
+    hipMalloc(&dA, A.size() * 8); hipMalloc(&dW, (size_t)Nt * TB * TB * 8); hipMalloc(&dP, nd * 8); hipMalloc(&dS, 64);
     hipMalloc(&dI, 4); hipMalloc(&dF, R * R * 4); hipMalloc(&dT, 16); hipMalloc(&dTr, ntask * 64);
     double sp[8] = {1.0, 0.1, 0.0, 1e-14, 0, 0, 0, 0};
     hipMemcpy(dS, sp, 64, hipMemcpyHostToDevice); hipMemset(dI, 0, 4); hipMemset(dF, 0, R * R * 4); hipMemset(dT, 0, 16);
-    const size_t lds = std::max((size_t)(2 * STAGE_BYTES), (size_t)16 + (size_t)PT_LDS_ELEMS * 8);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(chol_dataflow_kernel<double>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const size_t lds = df_lds_bytes<double, DF_TBX>();
+    hipFuncSetAttribute(reinterpret_cast<const void*>(chol_dataflow_kernel<double, DF_TBX>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     std::vector<long long> tr((size_t)ntask * 8);
     for (int rep = 0; rep < 3; ++rep) {
         hipMemcpy(dA, A.data(), A.size() * 8, hipMemcpyHostToDevice);
@@ -30,8 +33,8 @@ int main(int argc, char** argv) {
         DfArgs<double> g{};
         g.A = dA; g.ld = ld; g.bstride = ld * ld; g.W = dW; g.w_bstride = (long)Nt * TB * TB; g.partial = dP; g.info = dI;
         g.slotp = dS; g.flags = dF; g.f_bstride = (long)R * R; g.ticket = dT; g.ticket_base = (unsigned long long)rep * ntask;
-        g.abort_flag = (int*)(dT + 1); g.Nt = Nt; g.nslots = 1; g.epoch = rep + 1; g.trace = dTr;
-        hipLaunchKernelGGL(chol_dataflow_kernel<double>, dim3((unsigned)ntask), dim3(256), lds, 0, g);
+        g.abort_flag = (int*)(dT + 1); g.nd = nd; g.nslots = 1; g.epoch = rep + 1; g.trace = dTr;
+        hipLaunchKernelGGL((chol_dataflow_kernel<double, DF_TBX>), dim3((unsigned)ntask), dim3(256), lds, 0, g);
         hipDeviceSynchronize();
     }
     hipMemcpy(tr.data(), dTr, ntask * 64, hipMemcpyDeviceToHost);
@@ -39,7 +42,7 @@ int main(int argc, char** argv) {
     const long long t0 = tr[0];
     auto us = [&](long long v) { return v ? (v - t0) / 100.0 : -1.0; };
     printf("task(i,j): start | deps+acc done | [trsm: diag flag seen] | core begin | core end | published   (us)\n");
-    for (int j = 0; j < std::min(Nt, 6); ++j) {
+    for (int j = 0; j < std::min(nd, 6); ++j) {
         const long long* d = &tr[(size_t)off(j) * 8];
         printf("diag(%d,%d): %.2f | last slab flag %.2f | %.2f | - | %.2f | %.2f | %.2f\n", j, j, us(d[0]), us(d[6]), us(d[1]), us(d[2]), us(d[3]), us(d[4]));
         const long long* t = &tr[(size_t)(off(j) + 1) * 8];
