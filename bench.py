@@ -129,10 +129,25 @@ def pmc_traffic(kernel_substr: str = "gemm_nt_kernel<double, 0,"):
 
 def other_configs(local_rank: int) -> dict:
     """Short measurements of the other BASELINE.json configs on one GPU (reported next to the headline,
-    never part of `value`): cfg 4 = 200 theta x N=4096 batched + nested-sampling driver, cfg 5 = Matern-5/2
-    N=65536 d=16 fp32 fit + prediction on 10k test points."""
+    never part of `value`): cfg 1 / cfg 2 = one theta at a time at N=512 d=1 and N=8192 d=8 (the
+    reference's sequential-chain usage, latency bound), cfg 4 = 200 theta x N=4096 batched, cfg 5 =
+    Matern-5/2 N=65536 d=16 fp32 fit + prediction on 10k test points."""
     from bayesianinference_amd import _lib, synthetic as syn
     out = {}
+    try:
+        for name, n, d, kernel, reps in (("cfg1_n512_d1_f64", 512, 1, "se", 200), ("cfg2_n8192_d8_f64", 8192, 8, "se_ard", 10)):
+            X, y = syn.make_dataset(n, d)
+            th = syn.default_theta(kernel, d)
+            h = _lib.Handle(X, y, kernel, device=local_rank)
+            h.loglik(th); h.loglik(th)
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                _, info = h.loglik(th)
+            dt = (time.perf_counter() - t0) / reps
+            out[name] = {"ms_per_eval": dt * 1e3, "evals_per_s": 1.0 / dt, "info": int(info)}
+            h.close()
+    except Exception as exc:                                    # never let an extra break the headline
+        out["cfg1_cfg2_error"] = repr(exc)
     try:
         X, y = syn.make_dataset(4096, 8)
         Th = syn.theta_batch(200, "se_ard", 8)
