@@ -660,31 +660,47 @@ int ensure_vbuf(gphip_ctx* h, int64_t cap) {
 // every row of V becomes (L^-1 v)^T.  Panel solves and updates are the same MFMA GEMM kernel.
 template <typename T>
 int queue_forward_rows(gphip_ctx* h, int64_t mpad, int nslots, int b_start = 0) {
-    const int Nt = (int)h->Nt, Mt = (int)(mpad / TB);
+    // Two-level like the factorisation: inside an outer panel of `panel` tile columns the updates have
+    // K = 128 and touch the panel only; everything right of the panel is updated ONCE per panel with
+    // K = 128*panel.  (Single-level, every block column re-read and re-wrote all of V to its right:
+    // HBM bound -- 1.3 TB of traffic for N = 65536, M = 10000 in fp32.)
+    const int Nt = (int)h->Nt, Mt = (int)(mpad / TB), P = h->panel;
     const long ld = h->ld, vs = (long)mpad * h->Npad, bs = ld * ld, lrs = (long)Nt * TB * TB;
     T *V = (T*)h->dV, *A = (T*)h->dA, *W = (T*)h->dW;
-    for (int b = b_start; b < Nt; ++b) {     // b_start > 0: the rows are known to be zero left of tile column b_start
-        launch_gemm<T>(h, 2, V, mpad, vs, V + (long)b * TB * mpad, mpad, vs, W + (long)b * TB * TB - (long)b * TB, TB,
-                       lrs, TB, 0, Mt, b, b + 1, 0, nslots, 1);
-        if (b + 1 < Nt)
-            launch_gemm<T>(h, 3, V, mpad, vs, V + (long)b * TB * mpad, mpad, vs, A + (long)b * TB * ld, ld, bs, TB, 0,
-                           Mt, b + 1, Nt, 0, nslots);
+    for (int k0 = b_start; k0 < Nt; k0 += P) {   // b_start > 0: the rows are known to be zero left of tile column b_start
+        const int k1 = (k0 + P < Nt) ? k0 + P : Nt;
+        for (int b = k0; b < k1; ++b) {
+            launch_gemm<T>(h, 2, V, mpad, vs, V + (long)b * TB * mpad, mpad, vs, W + (long)b * TB * TB - (long)b * TB, TB,
+                           lrs, TB, 0, Mt, b, b + 1, 0, nslots, 1);
+            if (b + 1 < k1)
+                launch_gemm<T>(h, 3, V, mpad, vs, V + (long)b * TB * mpad, mpad, vs, A + (long)b * TB * ld, ld, bs, TB, 0,
+                               Mt, b + 1, k1, 0, nslots);
+        }
+        if (k1 < Nt)
+            launch_gemm<T>(h, 3, V, mpad, vs, V + (long)k0 * TB * mpad, mpad, vs, A + (long)k0 * TB * ld, ld, bs,
+                           (k1 - k0) * TB, 0, Mt, k1, Nt, 0, nslots);
     }
     return 0;
 }
 
 // V <- V L^-1 (backward substitution, block columns from last to first), "NN" GEMM role:
-//   X_b = Y_b W_b ;  Y_c -= X_b L(b,c) for c < b.
+//   X_b = Y_b W_b ;  Y_c -= X_b L(b,c) for c < b.   Two-level as above.
 template <typename T>
 int queue_backward_rows(gphip_ctx* h, int64_t mpad) {
-    const int Nt = (int)h->Nt, Mt = (int)(mpad / TB);
+    const int Nt = (int)h->Nt, Mt = (int)(mpad / TB), P = h->panel;
     const long ld = h->ld;
     T *V = (T*)h->dV, *A = (T*)h->dA, *W = (T*)h->dW;
-    for (int b = Nt - 1; b >= 0; --b) {
-        launch_gemm<T>(h, 6, V, mpad, 0, V + (long)b * TB * mpad, mpad, 0, W, TB, 0, TB, 0, Mt, b, b + 1, 0, 1, 1);
-        if (b > 0)
-            launch_gemm<T>(h, 6, V, mpad, 0, V + (long)b * TB * mpad, mpad, 0, A + (long)b * TB, ld, 0, TB, 0, Mt, 0, b,
-                           0, 1, 0);
+    for (int k1 = Nt; k1 > 0; k1 -= P) {         // outer panel = tile columns [k0, k1)
+        const int k0 = (k1 - P > 0) ? k1 - P : 0;
+        for (int b = k1 - 1; b >= k0; --b) {
+            launch_gemm<T>(h, 6, V, mpad, 0, V + (long)b * TB * mpad, mpad, 0, W, TB, 0, TB, 0, Mt, b, b + 1, 0, 1, 1);
+            if (b > k0)
+                launch_gemm<T>(h, 6, V, mpad, 0, V + (long)b * TB * mpad, mpad, 0, A + (long)b * TB, ld, 0, TB, 0, Mt,
+                               k0, b, 0, 1, 0);
+        }
+        if (k0 > 0)                             // Y_c -= X[:, k0..k1) L(k0..k1, c) for every c < k0
+            launch_gemm<T>(h, 6, V, mpad, 0, V + (long)k0 * TB * mpad, mpad, 0, A + (long)k0 * TB, ld, 0,
+                           (k1 - k0) * TB, 0, Mt, 0, k0, 0, 1, 0);
     }
     return 0;
 }
@@ -1006,8 +1022,18 @@ int gphip_predict(gphip_handle h, const void* Xs, int64_t M, double* mean, doubl
     HIPCHK(hipSetDevice(h->device));
     const double* X = static_cast<const double*>(Xs);
     const int64_t d = h->d;
-    const int64_t MC = 2048;                                   // test points per chunk
-    int rc = ensure_vbuf(h, M < MC ? (M + TB - 1) / TB * TB : MC);
+    // test points per chunk: as many as keep V (chunk x Npad) within ~8 GiB -- every chunk re-runs the whole
+    // substitution over L, and its per-block launches only fill the chip when the chunk has many row tiles
+    int64_t MC = (int64_t)((8.0 * (1 << 30)) / ((double)h->Npad * h->es)) / TB * TB;
+    if (MC < 2048) MC = 2048;
+    if (MC > 32768) MC = 32768;
+    if (M < MC) MC = (M + TB - 1) / TB * TB;
+    int rc = ensure_vbuf(h, MC);
+    while (rc == GPHIP_ERR_HIP && MC > 2048) {               // not enough free HBM next to the factor: smaller chunks
+        (void)hipGetLastError();
+        MC = (MC / 2 + TB - 1) / TB * TB;
+        rc = ensure_vbuf(h, MC);
+    }
     if (rc) return rc;
     h->cs = h->stream;
     std::vector<double> xt;
