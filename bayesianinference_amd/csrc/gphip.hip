@@ -899,7 +899,7 @@ int gphip_loglik_batch(gphip_handle h, const double* Theta, int B, int p, double
 }
 
 // log-likelihood and its gradient with respect to theta (same layout as theta).  One factorisation,
-// then K^-1 is streamed through the scratch block 2048 rows at a time (forward + backward
+// then K^-1 is streamed through the scratch block up to 8 GiB of rows at a time (forward + backward
 // substitution of identity rows) and contracted against dK/dtheta on the fly.
 int gphip_loglik_grad(gphip_handle h, const double* theta, int p, double* out, double* grad, int* info) {
     if (!h || !theta || !out || !grad || !info) return fail(h, GPHIP_ERR_ARG, "null argument");
@@ -917,8 +917,18 @@ int gphip_loglik_grad(gphip_handle h, const double* theta, int p, double* out, d
     for (int i = 0; i < p; ++i) grad[i] = std::nan("");
     if (*info != 0) return GPHIP_OK;
     HIPCHK(hipSetDevice(h->device));
-    const int64_t N = h->N, Npad = h->Npad, d = h->d, MC = 2048;
-    rc = ensure_vbuf(h, N < MC ? Npad : MC);
+    // rows of K^-1 per pass: as many as keep the scratch block within ~8 GiB (each pass runs a forward and a
+    // backward substitution over all of L; few, tall passes keep their launches chip-filling)
+    const int64_t N = h->N, Npad = h->Npad, d = h->d;
+    int64_t MC = (int64_t)((8.0 * (1 << 30)) / ((double)Npad * h->es)) / TB * TB;
+    if (MC < 2048) MC = 2048;
+    if (MC > Npad) MC = Npad;
+    rc = ensure_vbuf(h, MC);
+    while (rc == GPHIP_ERR_HIP && MC > 2048) {
+        (void)hipGetLastError();
+        MC = (MC / 2 + TB - 1) / TB * TB;
+        rc = ensure_vbuf(h, MC);
+    }
     if (rc) return rc;
     if (!h->dAlpha) HIPCHK(hipMalloc(&h->dAlpha, (size_t)Npad * h->es));
     if (!h->dGacc) HIPCHK(hipMalloc(&h->dGacc, (size_t)(d + 2) * 8));
