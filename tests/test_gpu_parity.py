@@ -188,6 +188,23 @@ def test_dataflow_schedule_equals_multikernel(n, d, kernel, dtype):
     h.close()
 
 
+@pytest.mark.parametrize("n,d,fine,batch", [(640, 3, 16, 1), (640, 3, 0, 1), (900, 2, 16, 6)])
+def test_dataflow_repeatability(n, d, fine, batch):
+    """Hundreds of back-to-back evaluations through the flag-synchronised schedule reproduce
+    bit-identical values per theta: a stale-cache or ordering bug would show up as an occasional
+    mismatch (scripts/gpu_df_stress.py runs thousands)."""
+    X, y = syn.make_dataset(n, d)
+    h = _lib.Handle(X, y, "se_ard")
+    h.set_option("dataflow_fine_nt", fine)
+    base = syn.default_theta("se_ard", d)
+    ths = [np.stack([base * (1 + 0.1 * k) * (1 + 0.01 * s) for s in range(batch)]) for k in range(3)]
+    ref = [h.loglik_batch(T)[0].copy() for T in ths]
+    for r in range(300):
+        out, info = h.loglik_batch(ths[r % 3])
+        assert np.array_equal(out, ref[r % 3]) and not info.any(), r
+    h.close()
+
+
 def test_dataflow_not_spd_verdict():
     X, y = syn.make_dataset(300, 2)
     X[150] = X[7]                                          # duplicate row, zero nugget: singular K (fixture F4 case)
