@@ -973,7 +973,7 @@ template <typename T>
 struct DfArgs {
     T* A; long ld; long bstride;              // workspace (column-major, leading dimension ld) per slot
     T* W; long w_bstride;                     // W_b = L_bb^-1 blocks, [slot][nd][TBX*TBX]
-    double* partial;                          // [slot][nd] sum log L_jj per diagonal block
+    double* partial; long p_bstride;          // sum log L_jj per diagonal block, [slot * p_bstride + j]
     int* info;                                // [slot]
     const double* slotp;
     int* flags; long f_bstride;               // [slot][(nd+1)^2]: ready(i,j) at i*(nd+1)+j
@@ -1202,7 +1202,7 @@ __global__ __launch_bounds__(256, 2) void chol_dataflow_kernel(DfArgs<T> g) {
             }
         __syncthreads();
         stamp(2);
-        potrf128_core_call<T, TBX / 16>(smem_raw, Ct, g.ld, Wj, g.partial + (long)slot * g.nd + j, g.info + slot,
+        potrf128_core_call<T, TBX / 16>(smem_raw, Ct, g.ld, Wj, g.partial + (long)slot * g.p_bstride + j, g.info + slot,
                                         (T)g.slotp[(long)slot * SLOTP + 3]);
         stamp(3);
         publish(j, j);

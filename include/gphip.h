@@ -105,7 +105,9 @@ int gphip_logdet(gphip_handle h, double* out);
  *   "latency_gemm" / "latency_tiles"   4x4-wave GEMM shape for launches of <= latency_tiles tiles (small N)
  *   "dataflow"     0/1 single-launch dataflow Cholesky (one workgroup per tile, flags instead of launches)
  *                  for problems of <= "dataflow_max_nt" 128-tiles (default 64, N <= 8192) and
- *                  <= "dataflow_max_slots" thetas per call (default 8); bit-identical results
+ *                  <= "dataflow_max_slots" thetas per call (default 8), with 64x64 tiles up to
+ *                  "dataflow_fine_nt" 128-tiles (default 16, fp64); larger problems hand their last
+ *                  "dataflow_tail" tile columns (default 64, 0 = off) to the same kernel
  *   "max_slots"    cap on concurrently resident batch matrices */
 int gphip_set_option(gphip_handle h, const char* name, double value);
 

@@ -264,6 +264,7 @@ def test_full_size_properties_n32768():
     assert info == 0 and np.isfinite(ll)
     h.set_option("lookahead", 0)
     h.set_option("panel", 2)
+    h.set_option("dataflow_tail", 0)                     # pure multi-kernel schedule vs look-ahead + dataflow tail
     ll2, ld2, qd2, info2 = h.loglik_parts(th)
     assert info2 == 0 and close(ld2, ld, n, 1e-10) and close(qd2, qd, n, 1e-9) and close(ll2, ll, n, 1e-10)
     h.set_option("lookahead", 1)
