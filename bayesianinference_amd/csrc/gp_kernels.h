@@ -1022,8 +1022,11 @@ template <typename T, int TBX> constexpr size_t df_lds_bytes() {
     return gemm > potrf ? gemm : potrf;
 }
 
-template <typename T, int TBX>
-__global__ __launch_bounds__(256, 2) void chol_dataflow_kernel(DfArgs<T> g) {
+// OCC = workgroups per CU the register budget is sized for: 2 (256 registers: the accumulators of a 128-tile
+// spill around each slab, fine while the schedule is chain bound) or 1 (512: no spills, better once it is
+// throughput bound, N > 4096).
+template <typename T, int TBX, int OCC = 2>
+__global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g) {
     static_assert(TBX == 128 || (TBX == 64 && sizeof(T) == 8), "64-tiles are implemented for fp64 only");
     constexpr int FI = TBX / 32, FJ = TBX / 32, WT = TBX / 2;   // MFMA tiles per wave, wave tile edge
     extern __shared__ double smem_raw[];

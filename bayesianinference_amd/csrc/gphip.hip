@@ -371,7 +371,7 @@ bool use_dataflow(const gphip_ctx* h, int nslots) {
 
 // c0 > 0 (128-tiles only): factor the trailing submatrix that starts at tile column c0 -- the tail of the
 // look-ahead schedule, already updated by every earlier panel.  No finalize here.
-template <typename T, int TBX>
+template <typename T, int TBX, int OCC = 2>
 void launch_dataflow(gphip_ctx* h, int nslots, int c0 = 0) {
     const int nd = (int)(h->Npad / TBX) - c0, R = nd + 1;
     const long ld = h->ld;
@@ -389,7 +389,7 @@ void launch_dataflow(gphip_ctx* h, int nslots, int c0 = 0) {
     // profile class 3 (panel work): class 4 stays the trailing SYRK alone, it is what the bench's roofline reads
     ProfScope ps(h, 3, ((double)nd * TBX) * ((double)nd * TBX) * ((double)nd * TBX) / 3.0 * nslots, 0.0);
     constexpr size_t lds = df_lds_bytes<T, TBX>();
-    hipLaunchKernelGGL((chol_dataflow_kernel<T, TBX>), dim3((unsigned)tasks), dim3(256), lds, h->stream, g);
+    hipLaunchKernelGGL((chol_dataflow_kernel<T, TBX, OCC>), dim3((unsigned)tasks), dim3(256), lds, h->stream, g);
 }
 
 template <typename T>
@@ -411,7 +411,8 @@ int queue_factor_dataflow(gphip_ctx* h, int nslots) {
             return 0;
         }
     }
-    launch_dataflow<T, 128>(h, nslots);
+    if (h->Nt <= 32) launch_dataflow<T, 128, 2>(h, nslots);
+    else launch_dataflow<T, 128, 1>(h, nslots);
     launch_finalize<T>(h, nslots, (int)h->Nt);
     return 0;
 }
@@ -463,7 +464,8 @@ int queue_factor(gphip_ctx* h, int nslots) {
                 h->cs = h->stream;
                 (void)hipStreamWaitEvent(h->stream, ev_panel, 0);
                 trailing(k, k0(k + 1), R, 4);
-                launch_dataflow<T, 128>(h, nslots, k0(kc));
+                if (Nt - k0(kc) <= 32) launch_dataflow<T, 128, 2>(h, nslots, k0(kc));
+                else launch_dataflow<T, 128, 1>(h, nslots, k0(kc));
                 break;
             }
             if (k + 1 < nouter) {
@@ -615,11 +617,13 @@ int set_func_attrs(gphip_ctx* h) {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(potrf128_kernel<T>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)potrf_lds<T>()));
     constexpr int df128 = (int)df_lds_bytes<T, 128>();
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(chol_dataflow_kernel<T, 128>),
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(chol_dataflow_kernel<T, 128, 2>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, df128));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(chol_dataflow_kernel<T, 128, 1>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, df128));
     if constexpr (sizeof(T) == 8) {
         constexpr int df64 = (int)df_lds_bytes<T, 64>();
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(chol_dataflow_kernel<T, 64>),
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(chol_dataflow_kernel<T, 64, 2>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, df64));
     }
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trtri128_kernel<T>),
