@@ -345,20 +345,20 @@ __device__ __forceinline__ void inv_block_column(const T* __restrict__ Ls, T* __
 }
 
 // Trailing update of panel p inside the 128x128 block: C(u,v) -= X_u X_v^T over the 16x16 tiles below
-// and right of the panel.  Wave w owns tiles w, w+4, ..; its NR tiles are independent MFMA chains
-// issued interleaved (accumulators start AT C, operand negated), so the wave runs at MFMA
-// throughput instead of one tile's latency at a time.  A wave with fewer than NR tiles recomputes
-// the last tile and skips the store.
+// and right of the panel.  A wave owns tiles first, first+stride, ..; NR of them at a time are
+// independent MFMA chains issued interleaved (accumulators start AT C, operand negated), so the
+// wave runs at MFMA throughput instead of one tile's latency at a time.  Past the last tile it
+// recomputes that tile and skips the store.
 template <typename T, int NR>
-__device__ __forceinline__ void potrf_update(T* __restrict__ Ls, int p, int t, int uw, int l15, int l4) {
+__device__ __forceinline__ void potrf_update(T* __restrict__ Ls, int p, int t, int first, int stride, int l15, int l4) {
     typedef typename Num<T>::acc_t acc_t;
-    const int ntile = t * (t + 1) / 2;      // t = block rows below the panel
+    const int ntile = t * (t + 1) / 2;      // t = block rows below the panel; this wave: tiles first, first+stride, ..
     acc_t acc[NR];
     T fa[NR][4], fb[NR][4];
     T* Ct[NR];
 #pragma unroll
     for (int m = 0; m < NR; ++m) {
-        int tt = uw + 4 * m;
+        int tt = first + stride * m;
         if (tt >= ntile) tt = ntile - 1;
         // tt -> (u, v), v <= u, tt = u(u+1)/2 + v < 28: branch-free (a taken scalar branch costs ~32 cycles)
         const int u = (tt >= 1) + (tt >= 3) + (tt >= 6) + (tt >= 10) + (tt >= 15) + (tt >= 21);
@@ -374,19 +374,16 @@ __device__ __forceinline__ void potrf_update(T* __restrict__ Ls, int p, int t, i
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[m][r] = Ct[m][Num<T>::drow(l4, r) * 16];
     }
-    if (NR == 7) GP_STAMP(40);
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
         for (int m = 0; m < NR; ++m) acc[m] = Num<T>::mfma(fa[m][kk], fb[m][kk], acc[m]);
-    if (NR == 7) GP_STAMP(41);
 #pragma unroll
     for (int m = 0; m < NR; ++m)
-        if (uw + 4 * m < ntile) {
+        if (first + stride * m < ntile) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) Ct[m][Num<T>::drow(l4, r) * 16] = acc[m][r];
         }
-    if (NR == 7) GP_STAMP(42);
 }
 
 // W = L^-1 of a factored block in the tile-packed LDS image (destroys the diagonal tiles of the
@@ -477,9 +474,21 @@ __device__ __forceinline__ void potrf128_core(double* __restrict__ lds_raw, T* _
     GP_STAMP(1);
 
     // ------------------------------ factor phase ------------------------------
+    // Panel p:  wave 0 brings the diagonal tile (p,p) up to date with panel p-1 and factors it (a) WHILE
+    // waves 1-3 apply panel p-1 to every other trailing tile (c); then all rows below solve against L_pp (b).
+    const int uwv = __builtin_amdgcn_readfirstlane(wave);
     for (int p = 0; p < NB; ++p) {
         T* Dpp = Ls + ptile(p, p);
         GP_STAMP(2 + 3 * p);
+        if (p > 0) {                           // (c) trailing update C -= X X^T of panel p-1 on MFMA
+            const int t = NB - p;              // block rows below panel p-1
+            if (uwv == 0) {
+                potrf_update<T, 1>(Ls, p - 1, t, 0, 1 << 20, l15, l4);        // tile (p,p) only
+            } else {
+                const int cnt = (t * (t + 1) / 2 - 1 + 2) / 3;                // tiles 1.. dealt to waves 1-3
+                for (int m0 = 0; m0 < cnt; m0 += 5) potrf_update<T, 5>(Ls, p - 1, t, uwv + 3 * m0, 3, l15, l4);
+            }
+        }
         if (wave == 0 && sizeof(T) == 8) {
             // (a) fp64: the 16x16 diagonal block lives in the MFMA D layout -- lane (l15, l4) holds
             // A[i = l15][j = l4 + 4r], r = 0..3.  Columns are eliminated four at a time: the 16x4 slab
@@ -578,19 +587,6 @@ __device__ __forceinline__ void potrf128_core(double* __restrict__ lds_raw, T* _
         }
         __syncthreads();
         GP_STAMP(4 + 3 * p);
-        {                                      // (c) trailing update C -= X X^T on MFMA
-            const int nround = ((NB - 1 - p) * (NB - p) / 2 + 3) >> 2;
-            const int uw = __builtin_amdgcn_readfirstlane(wave);
-            switch (nround) {
-                case 7: potrf_update<T, 7>(Ls, p, NB - 1 - p, uw, l15, l4); break;
-                case 6: potrf_update<T, 6>(Ls, p, NB - 1 - p, uw, l15, l4); break;
-                case 4: potrf_update<T, 4>(Ls, p, NB - 1 - p, uw, l15, l4); break;
-                case 3: potrf_update<T, 3>(Ls, p, NB - 1 - p, uw, l15, l4); break;
-                case 2: potrf_update<T, 2>(Ls, p, NB - 1 - p, uw, l15, l4); break;
-                default: potrf_update<T, 1>(Ls, p, NB - 1 - p, uw, l15, l4); break;
-            }
-        }
-        __syncthreads();
     }
 
     GP_STAMP(30);

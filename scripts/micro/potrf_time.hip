@@ -27,12 +27,11 @@ int main() {
     auto us = [&](int a, int b) { return (st[b] - st[a]) / 2400.0; };
     printf("load+barrier %.2f us\n", us(0, 1));
     for (int p = 0; p < 8; ++p) {
-        if (p < 7) printf("panel %d: diag %.2f  rowsolve %.2f  update %.2f us\n", p, us(2 + 3 * p, 3 + 3 * p), us(3 + 3 * p, 4 + 3 * p), us(4 + 3 * p, 2 + 3 * (p + 1)));
+        if (p < 7) printf("panel %d: update(p-1) || diag %.2f  rowsolve %.2f  (gap %.2f) us\n", p, us(2 + 3 * p, 3 + 3 * p), us(3 + 3 * p, 4 + 3 * p), us(4 + 3 * p, 2 + 3 * (p + 1)));
         else printf("panel 7: diag %.2f us\n", us(23, 24));
     }
     printf("factor total %.2f | L store %.2f | diag inverses %.2f | block inverse %.2f | W store %.2f | total %.2f us\n",
            us(1, 30), us(30, 31), us(31, 32), us(32, 33), us(33, 34), us(0, 34));
-    printf("update p=0: entry->loads issued %.2f | mfma %.2f | stores %.2f | ->barrier+loop %.2f us\n", us(4, 40), us(40, 41), us(41, 42), us(42, 5));
     int info; hipMemcpy(&info, dI, 4, hipMemcpyDeviceToHost); printf("info %d\n", info);
     return 0;
 }
