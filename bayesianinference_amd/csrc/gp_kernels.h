@@ -124,6 +124,29 @@ __global__ void k_scale(const T* __restrict__ Xt, T* __restrict__ xs, const doub
     }
 }
 
+// Same scaling with the hyper-parameters of the call passed BY VALUE (kernel arguments): for the
+// latency path (a few thetas per call) this replaces two host-to-device copies and a memset -- block
+// (0,0) also leaves inv_ell / the per-slot scalars in device memory for the kernels that follow and
+// clears the info words.  v = [nslots*d inverse length scales][nslots*SLOTP slot scalars].
+constexpr int THETA_PACK = 224;
+struct ThetaPack { double v[THETA_PACK]; };
+template <typename T>
+__global__ void k_scale_theta(const T* __restrict__ Xt, T* __restrict__ xs, ThetaPack tp, double* __restrict__ inv_ell_out,
+                              double* __restrict__ slotp_out, int* __restrict__ info_out, int d, int npad, int nslots) {
+    const int slot = blockIdx.y;
+    const long total = (long)d * npad;
+    if (blockIdx.x == 0 && slot == 0) {
+        for (int k = threadIdx.x; k < nslots * d; k += blockDim.x) inv_ell_out[k] = tp.v[k];
+        for (int k = threadIdx.x; k < nslots * SLOTP; k += blockDim.x) slotp_out[k] = tp.v[nslots * d + k];
+        for (int k = threadIdx.x; k < nslots; k += blockDim.x) info_out[k] = 0;
+    }
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long)gridDim.x * blockDim.x) {
+        const int dd = (int)(idx / npad);
+        xs[(long)slot * total + idx] = (T)((double)Xt[idx] * tp.v[slot * d + dd]);
+    }
+}
+
 // Decode linear index t of the lower triangle (incl. diagonal) of an n x n tile grid, enumerated
 // column by column: column c holds rows c..n-1.
 __device__ __forceinline__ void tri_decode(int t, int n, int& ti, int& tj) {
@@ -1226,17 +1249,28 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g) {
     stamp(4);
 }
 
-// log det = 2 sum partial ; quad = -E(0,0) ; res[slot] = {logdet, quad}
+// log det = 2 sum partial ; quad = -E(0,0) ; res[slot] = {logdet, quad}.  When hres is given the results,
+// the info words and the dataflow abort flag are ALSO written straight into pinned host memory
+// (hres[2*slots], hinfo[slots + 1]): the caller only synchronises the stream, no device-to-host copies.
 template <typename T>
 __global__ void finalize_kernel(const T* __restrict__ Abase, long ld, long bstride, int npad,
-                                const double* __restrict__ partial, int nt, double* __restrict__ res) {
+                                const double* __restrict__ partial, int nt, double* __restrict__ res,
+                                const int* __restrict__ info = nullptr, const int* __restrict__ abort_flag = nullptr,
+                                double* __restrict__ hres = nullptr, int* __restrict__ hinfo = nullptr) {
     const int slot = blockIdx.x;
     double s = 0.0;
     for (int b = threadIdx.x; b < nt; b += 64) s += partial[(long)slot * nt + b];
     for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
     if (threadIdx.x == 0) {
-        res[slot * 2 + 0] = 2.0 * s;
-        res[slot * 2 + 1] = -(double)Abase[(long)slot * bstride + (long)npad * ld + npad];
+        const double logdet = 2.0 * s, quad = -(double)Abase[(long)slot * bstride + (long)npad * ld + npad];
+        res[slot * 2 + 0] = logdet;
+        res[slot * 2 + 1] = quad;
+        if (hres) {
+            hres[slot * 2 + 0] = logdet;
+            hres[slot * 2 + 1] = quad;
+            hinfo[slot] = info[slot];
+            if (slot == 0) hinfo[gridDim.x] = *abort_flag;
+        }
     }
 }
 

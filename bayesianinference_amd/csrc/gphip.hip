@@ -70,6 +70,7 @@ struct gphip_ctx {
     int dataflow = 1, dataflow_max_nt = 64, dataflow_max_slots = 8;   // single-launch dataflow Cholesky: latency regime only
     int dataflow_fine_nt = 16;                   // ... with 64x64 tiles up to this many 128-tiles (fp64)
     int dataflow_tail = 64;                      // large N: the last <= dataflow_tail tile columns go to the dataflow kernel (0 = off)
+    bool theta_packed = false;                   // eval_chunk: hyper-parameters travel as kernel arguments (k_scale_theta)
     bool want_w = false;                         // the caller substitutes with W_b afterwards (fit / predict / gradient)
     int* dFlags = nullptr;                       // [slots][(Nt+1)^2] ready flags (value = epoch)
     unsigned long long* dTicket = nullptr;       // task ticket counter (+ abort flag in the next word)
@@ -252,8 +253,16 @@ int queue_build(gphip_ctx* h, int nslots) {
     const long tot = (long)h->d * h->Npad;
     int gx = (int)((tot + 255) / 256);
     if (gx > 1024) gx = 1024;
-    hipLaunchKernelGGL(k_scale<T>, dim3(gx, nslots), dim3(256), 0, h->cs, (const T*)h->dXt, (T*)h->dXs,
-                       h->dInvEll, (int)h->d, (int)h->Npad);
+    if (h->theta_packed) {
+        ThetaPack tp;
+        memcpy(tp.v, h->hInvEll, (size_t)nslots * h->d * 8);
+        memcpy(tp.v + (size_t)nslots * h->d, h->hSlotp, (size_t)nslots * SLOTP * 8);
+        hipLaunchKernelGGL(k_scale_theta<T>, dim3(gx, nslots), dim3(256), 0, h->cs, (const T*)h->dXt, (T*)h->dXs, tp,
+                           h->dInvEll, h->dSlotp, h->dInfo, (int)h->d, (int)h->Npad, nslots);
+    } else {
+        hipLaunchKernelGGL(k_scale<T>, dim3(gx, nslots), dim3(256), 0, h->cs, (const T*)h->dXt, (T*)h->dXs,
+                           h->dInvEll, (int)h->d, (int)h->Npad);
+    }
     KBuildArgs<T> a{};
     a.out = (T*)h->dA; a.ld = h->ld; a.bstride = h->ld * h->ld;
     a.xi = (const T*)h->dXs; a.xj = (const T*)h->dXs; a.xi_bstride = a.xj_bstride = tot;
@@ -395,7 +404,8 @@ void launch_dataflow(gphip_ctx* h, int nslots, int c0 = 0) {
 template <typename T>
 void launch_finalize(gphip_ctx* h, int nslots, int nparts) {
     hipLaunchKernelGGL(finalize_kernel<T>, dim3(nslots), dim3(64), 0, h->stream, (const T*)h->dA, h->ld, h->ld * h->ld,
-                       (int)h->Npad, h->dPartial, nparts, h->dRes);
+                       (int)h->Npad, h->dPartial, nparts, h->dRes, (const int*)h->dInfo,
+                       (const int*)reinterpret_cast<int*>(h->dTicket + 1), h->hRes, h->hInfo);
 }
 
 template <typename T>
@@ -485,8 +495,7 @@ int queue_factor(gphip_ctx* h, int nslots) {
         }
         h->cs = h->stream;
     }
-    hipLaunchKernelGGL(finalize_kernel<T>, dim3(nslots), dim3(64), 0, h->stream, (const T*)A, ld, bs, (int)h->Npad,
-                       h->dPartial, Nt, h->dRes);
+    launch_finalize<T>(h, nslots, Nt);
     return 0;
 }
 
@@ -562,18 +571,21 @@ int null_kernel_batch(gphip_ctx* h, const double* Theta, int B, double* out, dou
 int eval_chunk(gphip_ctx* h, const double* Theta, int nb, double* out, double* parts, int* info) {
     std::vector<char> okv(nb);
     for (int s = 0; s < nb; ++s) okv[s] = stage_theta(h, s, Theta + (size_t)s * h->p);
-    HIPCHK(hipMemcpyAsync(h->dInvEll, h->hInvEll, (size_t)nb * h->d * 8, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(h->dSlotp, h->hSlotp, (size_t)nb * SLOTP * 8, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemsetAsync(h->dInfo, 0, (size_t)nb * 4, h->stream));
+    // few thetas: they travel as kernel arguments of the first kernel (no copies, no memset); the results
+    // come back through pinned host memory written by the finalize kernel (no copies either)
+    h->theta_packed = (size_t)nb * (h->d + SLOTP) <= (size_t)THETA_PACK;
+    if (!h->theta_packed) {
+        HIPCHK(hipMemcpyAsync(h->dInvEll, h->hInvEll, (size_t)nb * h->d * 8, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(h->dSlotp, h->hSlotp, (size_t)nb * SLOTP * 8, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemsetAsync(h->dInfo, 0, (size_t)nb * 4, h->stream));
+    }
     h->cs = h->stream;
     {
         ProfScope ps(h, 5, 0.0, 0.0);
         DISPATCH(h, queue_build, h, nb);
         DISPATCH(h, queue_factor, h, nb);
     }
-    HIPCHK(hipMemcpyAsync(h->hRes, h->dRes, (size_t)nb * 16, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipMemcpyAsync(h->hInfo, h->dInfo, (size_t)nb * 4, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipMemcpyAsync(h->hInfo + nb, h->dTicket + 1, 4, hipMemcpyDeviceToHost, h->stream));
+    h->theta_packed = false;
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipGetLastError());
     harvest(h);
