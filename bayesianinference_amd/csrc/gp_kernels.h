@@ -715,6 +715,8 @@ struct GemmArgs {
     int super;                                   // 1: pure-triangle launch enumerated in 8x8 super-tiles,
                                                  //    one super-tile per XCD at a time (L2 reuse)
     int mode;                                    // ROLE 3 only: 0: C -= A B ; 1: C = A B
+    int ktri;                                    // 1: tile (ti,tj) contracts k >= ti*128 only (operands upper
+                                                 //    triangular in (row, k): the U U^T product of the gradient)
 };
 
 template <typename T>
@@ -792,8 +794,9 @@ __global__ __launch_bounds__(64 * NWI * NWJ, (NWI * NWJ == 4) ? 2 : 4) void gemm
         gemm_tile_decode(g, bid, ti, tj);
     }
 
-    const T* Ag = g.A + (long)slot * g.a_bstride + (long)ti * TB;
-    const T* Bg = g.B + (long)slot * g.b_bstride + (ROLE == 3 ? (long)tj * TB * g.ldb : (long)tj * TB);
+    const long koff = g.ktri ? (long)ti * TB : 0;          // first k of this tile's contraction
+    const T* Ag = g.A + (long)slot * g.a_bstride + (long)ti * TB + koff * g.lda;
+    const T* Bg = g.B + (long)slot * g.b_bstride + (ROLE == 3 ? (long)tj * TB * g.ldb + koff : (long)tj * TB + koff * g.ldb);
     // Staging: LDS-DMA (global_load_lds_dwordx4), no staging registers and no ds_write pass.  One
     // wave-instruction moves 1 KiB landing lane-linear at a wave-uniform LDS base: fp64 = one
     // k-column of 128 rows; fp32 = the two k-columns of one pair (lanes 0-31 / 32-63).  Wave w
@@ -837,7 +840,7 @@ __global__ __launch_bounds__(64 * NWI * NWJ, (NWI * NWJ == 4) ? 2 : 4) void gemm
     T* Cg = g.C + (long)slot * g.c_bstride + ((long)tj * TB + wj * (16 * FJ)) * g.ldc + (long)ti * TB +
             wi * (16 * FI) + (lane & 15);
     const int l4 = lane >> 4;
-    const int nk = g.K / GK;
+    const int nk = (g.K - (int)koff) / GK;
     // Update roles start the accumulators AT C and feed the MFMA the negated J fragment, so acc ends
     // as C - A B^T and the epilogue is stores only.
     const bool from_zero = (ROLE == 2) || (ROLE == 3 && g.mode == 1);
@@ -1321,6 +1324,8 @@ struct GradArgs {
     const T* alpha;                 // [npad]
     const T* xs;                    // scaled inputs [d][npad]
     int npad, n, c0, mc, d;
+    int tri;                        // 1: Kinv holds the lower triangle only (tile rows >= tile columns): skip the
+                                    //    upper tiles and count the strictly lower ones twice (everything is symmetric)
     const double* slotp;
     double* gacc;                   // [d + 2]
 };
@@ -1334,6 +1339,8 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(GradArgs<T> a) {
     T* aj = xjs + d * TB;
     const int tid = threadIdx.x, row = tid & 127, half = tid >> 7;
     const int ti = blockIdx.x, tj = blockIdx.y;
+    if (a.tri && tj > ti) return;
+    const double wt = (a.tri && tj < ti) ? 2.0 : 1.0;
     const int t = ti * TB + row, g = a.c0 + t;
     for (int idx = tid; idx < d * TB; idx += 256) xjs[idx] = a.xs[(long)(idx >> 7) * a.npad + tj * TB + (idx & 127)];
     if (tid < TB) aj[tid] = a.alpha[tj * TB + tid];
@@ -1373,7 +1380,7 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(GradArgs<T> a) {
                 kpart = sf2 * ((T)1.0 + s5 + (T)(5.0 / 3.0) * r2) * e;
                 fac = sf2 * (T)(5.0 / 3.0) * ((T)1.0 + s5) * e;
             }
-            const double w = (double)ag * (double)aj[jj] - (double)a.Kinv[(long)j * a.ldv + t];
+            const double w = wt * ((double)ag * (double)aj[jj] - (double)a.Kinv[(long)j * a.ldv + t]);
             const double wf = w * (double)fac;
 #pragma unroll
             for (int dd = 0; dd < DM; ++dd)

@@ -69,6 +69,7 @@ struct gphip_ctx {
     int latency_gemm = 1, latency_tiles = 256;   // launches of <= latency_tiles tiles use the latency GEMM shape
     int dataflow = 1, dataflow_max_nt = 64, dataflow_max_slots = 8;   // single-launch dataflow Cholesky: latency regime only
     int dataflow_fine_nt = 16;                   // ... with 64x64 tiles up to this many 128-tiles (fp64)
+    int grad_potri = 1;                          // gradient: K^-1 = U U^T in one go when the memory is there
     int dataflow_tail = 64;                      // large N: the last <= dataflow_tail tile columns go to the dataflow kernel (0 = off)
     bool theta_packed = false;                   // eval_chunk: hyper-parameters travel as kernel arguments (k_scale_theta)
     bool want_w = false;                         // the caller substitutes with W_b afterwards (fit / predict / gradient)
@@ -85,6 +86,7 @@ struct gphip_ctx {
     double *dMean = nullptr, *dVar = nullptr;
     int64_t vcap = 0;
     void* dAlpha = nullptr;                                  // typed [Npad] (gradient)
+    void* dKinv = nullptr;                                   // typed [Npad x Npad] lower tiles of K^-1 (gradient, potri route)
     double* dGacc = nullptr;                                 // [d + 2] gradient accumulators
     // profiling
     std::vector<ProfRec> recs;
@@ -279,9 +281,10 @@ int queue_build(gphip_ctx* h, int nslots) {
 // cls: profile class (2 panel solve, 3 in-panel/look-ahead GEMM, 4 trailing SYRK, 6 = "NN" role)
 template <typename T>
 void launch_gemm(gphip_ctx* h, int cls, T* C, long ldc, long cbs, const T* A, long lda, long abs_, const T* B,
-                 long ldb, long bbs, int K, int r0, int r1, int c0, int c1, int tri, int nslots, int mode = 0) {
+                 long ldb, long bbs, int K, int r0, int r1, int c0, int c1, int tri, int nslots, int mode = 0, int ktri = 0) {
     GemmArgs<T> g{};
     g.mode = mode;
+    g.ktri = ktri;
     g.C = C; g.ldc = ldc; g.c_bstride = cbs;
     g.A = A; g.lda = lda; g.a_bstride = abs_;
     g.B = B; g.ldb = ldb; g.b_bstride = bbs;
@@ -697,26 +700,29 @@ int ensure_vbuf(gphip_ctx* h, int64_t cap) {
 // V <- V L^-T for the mpad x Npad row block in dV (right-looking over the 128-tile columns of L):
 // every row of V becomes (L^-1 v)^T.  Panel solves and updates are the same MFMA GEMM kernel.
 template <typename T>
-int queue_forward_rows(gphip_ctx* h, int64_t mpad, int nslots, int b_start = 0) {
+int queue_forward_rows(gphip_ctx* h, int64_t mpad, int nslots, int b_start = 0, bool identity_rows = false) {
     // Two-level like the factorisation: inside an outer panel of `panel` tile columns the updates have
     // K = 128 and touch the panel only; everything right of the panel is updated ONCE per panel with
     // K = 128*panel.  (Single-level, every block column re-read and re-wrote all of V to its right:
     // HBM bound -- 1.3 TB of traffic for N = 65536, M = 10000 in fp32.)
+    // identity_rows: V holds rows b_start*128.. of the identity, so the result (rows of L^-T) is upper
+    // triangular -- at tile column b only the row tiles <= b - b_start are non-zero and are touched.
     const int Nt = (int)h->Nt, Mt = (int)(mpad / TB), P = h->panel;
     const long ld = h->ld, vs = (long)mpad * h->Npad, bs = ld * ld, lrs = (long)Nt * TB * TB;
     T *V = (T*)h->dV, *A = (T*)h->dA, *W = (T*)h->dW;
+    auto rows_at = [&](int b) { return identity_rows ? std::min(Mt, b - b_start + 1) : Mt; };
     for (int k0 = b_start; k0 < Nt; k0 += P) {   // b_start > 0: the rows are known to be zero left of tile column b_start
         const int k1 = (k0 + P < Nt) ? k0 + P : Nt;
         for (int b = k0; b < k1; ++b) {
             launch_gemm<T>(h, 2, V, mpad, vs, V + (long)b * TB * mpad, mpad, vs, W + (long)b * TB * TB - (long)b * TB, TB,
-                           lrs, TB, 0, Mt, b, b + 1, 0, nslots, 1);
+                           lrs, TB, 0, rows_at(b), b, b + 1, 0, nslots, 1);
             if (b + 1 < k1)
                 launch_gemm<T>(h, 3, V, mpad, vs, V + (long)b * TB * mpad, mpad, vs, A + (long)b * TB * ld, ld, bs, TB, 0,
-                               Mt, b + 1, k1, 0, nslots);
+                               rows_at(b), b + 1, k1, 0, nslots);
         }
         if (k1 < Nt)
             launch_gemm<T>(h, 3, V, mpad, vs, V + (long)k0 * TB * mpad, mpad, vs, A + (long)k0 * TB * ld, ld, bs,
-                           (k1 - k0) * TB, 0, Mt, k1, Nt, 0, nslots);
+                           (k1 - k0) * TB, 0, rows_at(k1 - 1), k1, Nt, 0, nslots);
     }
     return 0;
 }
@@ -818,13 +824,37 @@ int queue_grad_chunk(gphip_ctx* h, int64_t c0, int64_t mc, int64_t mpad) {
     if (gx > 4096) gx = 4096;
     hipLaunchKernelGGL(identity_rows_kernel<T>, dim3(gx), dim3(256), 0, h->stream, (T*)h->dV, (long)mpad, (int)h->Npad,
                        (int)c0, (int)mc);
-    queue_forward_rows<T>(h, mpad, 1, (int)(c0 / TB));
+    queue_forward_rows<T>(h, mpad, 1, (int)(c0 / TB), true);
     queue_backward_rows<T>(h, mpad);
     GradArgs<T> a{};
     a.Kinv = (const T*)h->dV; a.ldv = mpad; a.alpha = (const T*)h->dAlpha; a.xs = (const T*)h->dXs;
     a.npad = (int)h->Npad; a.n = (int)h->N; a.c0 = (int)c0; a.mc = (int)mc; a.d = (int)h->d;
     a.slotp = h->dSlotp; a.gacc = h->dGacc;
     const dim3 grid((unsigned)(mpad / TB), (unsigned)h->Nt);
+    if (h->kt == 0) launch_grad_kt<T, 0>(h, a, grid);
+    else launch_grad_kt<T, 1>(h, a, grid);
+    return GPHIP_OK;
+}
+
+// The whole of K^-1 at once, LAPACK potri style (2/3 N^3 instead of the 4/3 N^3 of forward + backward
+// substitution): U = L^-T from a forward pass over all identity rows (upper triangular, zero tiles
+// skipped), then the lower tiles of K^-1 = U U^T as ONE triangular launch whose tile (i,j) contracts
+// k >= 128 i only, then the reduction over the lower triangle (strictly lower tiles counted twice).
+template <typename T>
+int queue_grad_potri(gphip_ctx* h) {
+    const long npad = h->Npad;
+    const long tot = npad * npad;
+    int gx = (int)((tot + 255) / 256);
+    if (gx > 4096) gx = 4096;
+    hipLaunchKernelGGL(identity_rows_kernel<T>, dim3(gx), dim3(256), 0, h->stream, (T*)h->dV, npad, (int)npad, 0, (int)h->N);
+    queue_forward_rows<T>(h, npad, 1, 0, true);
+    launch_gemm<T>(h, 2, (T*)h->dKinv, npad, 0, (const T*)h->dV, npad, 0, (const T*)h->dV, npad, 0, (int)npad, 0,
+                   (int)h->Nt, 0, (int)h->Nt, 1, 1, 1, 1);
+    GradArgs<T> a{};
+    a.Kinv = (const T*)h->dKinv; a.ldv = npad; a.alpha = (const T*)h->dAlpha; a.xs = (const T*)h->dXs;
+    a.npad = (int)npad; a.n = (int)h->N; a.c0 = 0; a.mc = (int)h->N; a.d = (int)h->d; a.tri = 1;
+    a.slotp = h->dSlotp; a.gacc = h->dGacc;
+    const dim3 grid((unsigned)h->Nt, (unsigned)h->Nt);
     if (h->kt == 0) launch_grad_kt<T, 0>(h, a, grid);
     else launch_grad_kt<T, 1>(h, a, grid);
     return GPHIP_OK;
@@ -906,7 +936,7 @@ int gphip_destroy(gphip_handle h) {
     free_slots(h);
     (void)hipFree(h->dXt); (void)hipFree(h->dY);
     (void)hipFree(h->dV); (void)hipFree(h->dXsT); (void)hipFree(h->dXsS); (void)hipFree(h->dMean);
-    (void)hipFree(h->dVar); (void)hipFree(h->dAlpha); (void)hipFree(h->dGacc);
+    (void)hipFree(h->dVar); (void)hipFree(h->dAlpha); (void)hipFree(h->dGacc); (void)hipFree(h->dKinv);
     (void)hipFree(h->dNullMu); (void)hipFree(h->dNullOut);
     for (auto e : h->pool) (void)hipEventDestroy(e);
     for (auto e : h->sync_events) (void)hipEventDestroy(e);
@@ -955,30 +985,56 @@ int gphip_loglik_grad(gphip_handle h, const double* theta, int p, double* out, d
     for (int i = 0; i < p; ++i) grad[i] = std::nan("");
     if (*info != 0) return GPHIP_OK;
     HIPCHK(hipSetDevice(h->device));
-    // rows of K^-1 per pass: as many as keep the scratch block within ~8 GiB (each pass runs a forward and a
-    // backward substitution over all of L; few, tall passes keep their launches chip-filling)
     const int64_t N = h->N, Npad = h->Npad, d = h->d;
-    int64_t MC = (int64_t)((8.0 * (1 << 30)) / ((double)Npad * h->es)) / TB * TB;
-    if (MC < 2048) MC = 2048;
-    if (MC > Npad) MC = Npad;
-    rc = ensure_vbuf(h, MC);
-    while (rc == GPHIP_ERR_HIP && MC > 2048) {
-        (void)hipGetLastError();
-        MC = (MC / 2 + TB - 1) / TB * TB;
-        rc = ensure_vbuf(h, MC);
-    }
-    if (rc) return rc;
     if (!h->dAlpha) HIPCHK(hipMalloc(&h->dAlpha, (size_t)Npad * h->es));
     if (!h->dGacc) HIPCHK(hipMalloc(&h->dGacc, (size_t)(d + 2) * 8));
+    // potri route when U (Npad x Npad scratch) and the lower tiles of K^-1 both fit in a quarter of the HBM
+    // that is free right now; otherwise K^-1 is streamed in row blocks through forward + backward substitution
+    bool potri = h->grad_potri != 0;
+    if (potri && !(h->dKinv && h->vcap >= Npad)) {
+        size_t fr = 0, tot = 0;
+        HIPCHK(hipMemGetInfo(&fr, &tot));
+        const size_t need = (size_t)(h->dKinv ? 1 : 2) * Npad * Npad * h->es;
+        potri = need <= fr / 4;
+    }
+    if (potri) {
+        rc = ensure_vbuf(h, Npad);
+        if (rc == GPHIP_OK && !h->dKinv && hipMalloc(&h->dKinv, (size_t)Npad * Npad * h->es) != hipSuccess) {
+            (void)hipGetLastError();
+            h->dKinv = nullptr;
+            potri = false;
+        }
+        if (rc != GPHIP_OK) { (void)hipGetLastError(); potri = false; }
+    }
+    int64_t MC = 0;
+    if (!potri) {
+        // rows of K^-1 per pass: as many as keep the scratch block within ~8 GiB (each pass runs a forward and a
+        // backward substitution over all of L; few, tall passes keep their launches chip-filling)
+        MC = (int64_t)((8.0 * (1 << 30)) / ((double)Npad * h->es)) / TB * TB;
+        if (MC < 2048) MC = 2048;
+        if (MC > Npad) MC = Npad;
+        rc = ensure_vbuf(h, MC);
+        while (rc == GPHIP_ERR_HIP && MC > 2048) {
+            (void)hipGetLastError();
+            MC = (MC / 2 + TB - 1) / TB * TB;
+            rc = ensure_vbuf(h, MC);
+        }
+        if (rc) return rc;
+    }
     h->cs = h->stream;
     rc = DISPATCH(h, queue_alpha, h);
     if (rc) return rc;
     HIPCHK(hipMemsetAsync(h->dGacc, 0, (size_t)(d + 2) * 8, h->stream));
-    for (int64_t c0 = 0; c0 < N; c0 += MC) {
-        const int64_t mc = (N - c0 < MC) ? (N - c0) : MC;
-        const int64_t mpad = (mc + TB - 1) / TB * TB;
-        rc = DISPATCH(h, queue_grad_chunk, h, c0, mc, mpad);
+    if (potri) {
+        rc = DISPATCH(h, queue_grad_potri, h);
         if (rc) return rc;
+    } else {
+        for (int64_t c0 = 0; c0 < N; c0 += MC) {
+            const int64_t mc = (N - c0 < MC) ? (N - c0) : MC;
+            const int64_t mpad = (mc + TB - 1) / TB * TB;
+            rc = DISPATCH(h, queue_grad_chunk, h, c0, mc, mpad);
+            if (rc) return rc;
+        }
     }
     std::vector<double> gacc((size_t)d + 2), alpha;
     HIPCHK(hipMemcpyAsync(gacc.data(), h->dGacc, gacc.size() * 8, hipMemcpyDeviceToHost, h->stream));
@@ -1345,6 +1401,7 @@ int gphip_set_option(gphip_handle h, const char* name, double value) {
     else if (!strcmp(name, "dataflow_max_slots")) h->dataflow_max_slots = v;
     else if (!strcmp(name, "dataflow_fine_nt")) h->dataflow_fine_nt = v;
     else if (!strcmp(name, "dataflow_tail")) h->dataflow_tail = v;
+    else if (!strcmp(name, "grad_potri")) h->grad_potri = v;
     else if (!strcmp(name, "max_slots")) { if (v < 1) return fail(h, GPHIP_ERR_ARG, "max_slots < 1"); h->max_slots = v; }
     else return fail(h, GPHIP_ERR_ARG, "unknown option");
     return GPHIP_OK;

@@ -426,10 +426,12 @@ def test_loglik_gradient_matches_oracle(kernel, d, n, mean):
     if mean == "const":
         th = np.append(th, 0.2)
     h = _lib.Handle(X, y, kernel, mean)
-    ll, grad, info = h.loglik_grad(th)
-    assert info == 0 and close(ll, orc.log_likelihood(kernel, th, X, y, mean), n)
     want = orc.log_likelihood_grad(kernel, th, X, y, mean)
-    np.testing.assert_allclose(grad, want, rtol=1e-7, atol=1e-7 * np.abs(want).max())
+    for potri in (1, 0):          # K^-1 = U U^T in one go (potri) / streamed through forward + backward substitution
+        h.set_option("grad_potri", potri)
+        ll, grad, info = h.loglik_grad(th)
+        assert info == 0 and close(ll, orc.log_likelihood(kernel, th, X, y, mean), n)
+        np.testing.assert_allclose(grad, want, rtol=1e-7, atol=1e-7 * np.abs(want).max())
     mu, var = h.predict(X[:3])                            # the factor stays resident after the gradient
     mo, so = orc.predict_internal(kernel, th, X, y, X[:3], mean)
     np.testing.assert_allclose(mu, mo, rtol=1e-7, atol=1e-9)
