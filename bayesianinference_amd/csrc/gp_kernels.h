@@ -1044,9 +1044,9 @@ template <typename T, int TBX> constexpr size_t df_lds_bytes() {
     return gemm > potrf ? gemm : potrf;
 }
 
-// OCC = workgroups per CU the register budget is sized for: 2 (256 registers: the accumulators of a 128-tile
-// spill around each slab, fine while the schedule is chain bound) or 1 (512: no spills, better once it is
-// throughput bound, N > 4096).
+// OCC = workgroups per CU the register budget is sized for: 2 (256 registers: 64-tiles, fp32 128-tiles) or
+// 1 (512 registers: fp64 128-tiles -- 128 accumulator registers plus the out-of-line potrf body do not fit
+// in 256 without spilling accumulators around every slab).
 template <typename T, int TBX, int OCC = 2>
 __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g) {
     static_assert(TBX == 128 || (TBX == 64 && sizeof(T) == 8), "64-tiles are implemented for fp64 only");

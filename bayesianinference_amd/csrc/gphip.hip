@@ -424,7 +424,10 @@ int queue_factor_dataflow(gphip_ctx* h, int nslots) {
             return 0;
         }
     }
-    if (h->Nt <= 32) launch_dataflow<T, 128, 2>(h, nslots);
+    // fp64 128-tiles: the out-of-line potrf body needs 232 + 40 registers, so only the 512-register
+    // (1 workgroup per CU) build is real -- a 256-register build falls to occupancy 1 anyway AND spills.
+    // fp32 accumulators are half the size: 2 workgroups per CU while the schedule is chain bound.
+    if (sizeof(T) == 4 && h->Nt <= 32) launch_dataflow<T, 128, 2>(h, nslots);
     else launch_dataflow<T, 128, 1>(h, nslots);
     launch_finalize<T>(h, nslots, (int)h->Nt);
     return 0;
@@ -477,8 +480,7 @@ int queue_factor(gphip_ctx* h, int nslots) {
                 h->cs = h->stream;
                 (void)hipStreamWaitEvent(h->stream, ev_panel, 0);
                 trailing(k, k0(k + 1), R, 4);
-                if (Nt - k0(kc) <= 32) launch_dataflow<T, 128, 2>(h, nslots, k0(kc));
-                else launch_dataflow<T, 128, 1>(h, nslots, k0(kc));
+                launch_dataflow<T, 128, 1>(h, nslots, k0(kc));
                 break;
             }
             if (k + 1 < nouter) {
