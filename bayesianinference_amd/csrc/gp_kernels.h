@@ -500,6 +500,53 @@ __device__ __forceinline__ void potrf128_core(double* __restrict__ lds_raw, T* _
     // Panel p:  wave 0 brings the diagonal tile (p,p) up to date with panel p-1 and factors it (a) WHILE
     // waves 1-3 apply panel p-1 to every other trailing tile (c); then all rows below solve against L_pp (b).
     const int uwv = __builtin_amdgcn_readfirstlane(wave);
+    if constexpr (NB == 4 && sizeof(T) == 8) {
+        // 64x64 block: a whole 16-column panel (<= 64 rows) fits ONE wave with lane = row, so the
+        // diagonal factor (a) and the row solves (b) are the same elimination: x[c] *= rs_c, then
+        // x[c2] -= x[c] L[c2][c] with the pivot row's values broadcast by v_readlane.  No D-layout
+        // gather, no separate row-solve pass, one barrier per panel.  Wave 0 first applies panel p-1 to
+        // its own block column (<= 3 tiles) while waves 1-3 take the other trailing tiles.
+        for (int p = 0; p < NB; ++p) {
+            GP_STAMP(2 + 3 * p);
+            if (p > 0) {
+                const int t = NB - p;
+                if (uwv == 0) {
+                    for (int u = 0; u < t; ++u) potrf_update<T, 1>(Ls, p - 1, t, u * (u + 1) / 2, 1 << 20, l15, l4);
+                } else {
+                    const int tt = (t == 3) ? (uwv == 1 ? 2 : (uwv == 2 ? 4 : 5)) : ((t == 2 && uwv == 1) ? 2 : -1);
+                    if (tt >= 0) potrf_update<T, 1>(Ls, p - 1, t, tt, 1 << 20, l15, l4);
+                }
+            }
+            if (uwv == 0) {
+                const int nrows = NE - 16 * p;
+                const bool live = lane < nrows;
+                T* Xr = Ls + ptile(live ? p + (lane >> 4) : p, p) + (lane & 15);
+                double x[16], dv = 0.0;
+#pragma unroll
+                for (int c = 0; c < 16; ++c) x[c] = (double)Xr[c * 16];
+#pragma unroll
+                for (int c = 0; c < 16; ++c) {
+                    const double dj = Num<double>::readlane(x[c], c);
+                    bad = bad || !(dj > (double)tol);
+                    const double rs = fast_rsqrt(dj);
+                    dv = (lane == c) ? rs : dv;
+                    x[c] *= rs;
+#pragma unroll
+                    for (int c2 = c + 1; c2 < 16; ++c2) {
+                        const double lc = Num<double>::readlane(x[c], c2);          // L[c2][c]
+                        x[c2] = __builtin_fma(-x[c], lc, x[c2]);
+                    }
+                }
+                if (live) {
+#pragma unroll
+                    for (int c = 0; c < 16; ++c) Xr[c * 16] = (T)x[c];
+                }
+                if (lane < 16) dinv[16 * p + lane] = (T)dv;
+            }
+            __syncthreads();
+            GP_STAMP(3 + 3 * p);
+        }
+    } else
     for (int p = 0; p < NB; ++p) {
         T* Dpp = Ls + ptile(p, p);
         GP_STAMP(2 + 3 * p);
