@@ -205,6 +205,27 @@ def test_dataflow_repeatability(n, d, fine, batch):
     h.close()
 
 
+def test_dataflow_tail_of_large_problem():
+    """N above the dataflow range (Nt = 71 > 64 tiles): the look-ahead schedule hands its last tile
+    columns to the dataflow kernel.  Same values as the pure multi-kernel schedule (summation order of
+    the tail's trailing updates differs: 1e-10), for every cut-over point."""
+    n, d = 9000, 4
+    X, y = syn.make_dataset(n, d)
+    th = syn.default_theta("se_ard", d)
+    h = _lib.Handle(X, y, "se_ard")
+    h.set_option("dataflow_tail", 0)
+    ref = h.loglik_parts(th)
+    assert ref[3] == 0
+    for tail in (64, 40, 7):
+        h.set_option("dataflow_tail", tail)
+        got = h.loglik_parts(th)
+        assert got[3] == 0 and all(close(got[k], ref[k], n, 1e-10) for k in range(3)), (tail, got, ref)
+        assert h.fit(th) == 0                               # the factor left behind serves solve / predict
+        alpha = h.solve(y)
+        assert close(float(y @ alpha), got[2], n, 1e-9)
+    h.close()
+
+
 def test_dataflow_not_spd_verdict():
     X, y = syn.make_dataset(300, 2)
     X[150] = X[7]                                          # duplicate row, zero nugget: singular K (fixture F4 case)
