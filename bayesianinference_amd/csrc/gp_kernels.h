@@ -1084,8 +1084,12 @@ template <typename T, int TBX> __device__ __forceinline__ int df_lds_off(int k, 
 template <typename T, int TBX> constexpr int df_stage_elems() {
     return TBX == 128 ? STAGE_BYTES / (int)sizeof(T) : 2 * 8 * LD64;
 }
-template <typename T, int TBX> constexpr size_t df_lds_bytes() {
-    constexpr size_t gemm = 2 * (size_t)df_stage_elems<T, TBX>() * sizeof(T);
+// LDS stages of the slab pipeline: 2 (double buffer) when two workgroups share a CU, 4 with counted DMA
+// waits when the workgroup has the CU to itself (fp64 128-tiles): its on-chain products have no
+// co-resident workgroup to hide the DMA latency behind.
+template <int TBX, int OCC> constexpr int df_stages() { return (TBX == 128 && OCC == 1) ? 4 : 2; }
+template <typename T, int TBX, int OCC = 2> constexpr size_t df_lds_bytes() {
+    constexpr size_t gemm = df_stages<TBX, OCC>() * (size_t)df_stage_elems<T, TBX>() * sizeof(T);
     constexpr size_t nb = TBX / 16;
     constexpr size_t potrf = 16 + (nb * (nb + 1) / 2 * 256 + TBX) * sizeof(T);
     return gemm > potrf ? gemm : potrf;
@@ -1220,23 +1224,43 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g) {
 #pragma unroll
                 for (int y = 0; y < FI; ++y) acc[x][y] = Num<T>::mfma(nj[x], fi[y], acc[x][y]);
         };
-        // one fragment register set (the two-set pipeline of gemm_nt does not fit next to the flag /
-        // potrf state of this kernel without spilling, and buys ~0 there)
         constexpr int NKK = GK / 4;
-        stage(0, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        for (int kb = 0; kb < nk; ++kb) {
-            const int cur = kb & 1;
-            if (kb + 1 < nk) stage(kb + 1, cur ^ 1);
+        auto compute = [&](int buf) {
 #pragma unroll
             for (int kk = 0; kk < NKK; ++kk) {
                 T fi[FI], fj[FJ];
-                load_frags(cur, kk, fi, fj);
+                load_frags(buf, kk, fi, fj);
                 mfma_block(fi, fj);
             }
+        };
+        if constexpr (df_stages<TBX, OCC>() == 4) {
+            // deep pipeline: 3 stages of DMA in flight, counted vmcnt waits, one raw barrier per stage
+            constexpr int NST = 4, AHEAD = NST - 1;
+            static_assert(TBX == 128, "8 DMA instructions per wave and stage");
+            for (int st = 0; st < AHEAD && st < nk; ++st) stage(st, st);
+            for (int kb = 0; kb < nk; ++kb) {
+                const int rem = nk - 1 - kb;               // stages issued beyond kb (capped at AHEAD - 1)
+                if (rem >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                else if (rem == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();              // stage kb landed for every wave; buffer (kb-1)%4 is free
+                if (kb + AHEAD < nk) stage(kb + AHEAD, (kb + AHEAD) % NST);
+                compute(kb % NST);       // (two fragment register sets were measured here too: no change)
+            }
+            __syncthreads();                               // LDS is free again
+        } else {
+            // one fragment register set (the two-set pipeline of gemm_nt does not fit next to the flag /
+            // potrf state of this kernel without spilling, and buys ~0 there)
+            stage(0, 0);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
+            for (int kb = 0; kb < nk; ++kb) {
+                const int cur = kb & 1;
+                if (kb + 1 < nk) stage(kb + 1, cur ^ 1);
+                compute(cur);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+            }
         }
     };
     auto publish = [&](int fi_, int fj_) {                  // everything this workgroup stored is visible first

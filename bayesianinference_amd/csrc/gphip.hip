@@ -400,7 +400,7 @@ void launch_dataflow(gphip_ctx* h, int nslots, int c0 = 0) {
     h->ticket_base += (unsigned long long)tasks;
     // profile class 3 (panel work): class 4 stays the trailing SYRK alone, it is what the bench's roofline reads
     ProfScope ps(h, 3, ((double)nd * TBX) * ((double)nd * TBX) * ((double)nd * TBX) / 3.0 * nslots, 0.0);
-    constexpr size_t lds = df_lds_bytes<T, TBX>();
+    constexpr size_t lds = df_lds_bytes<T, TBX, OCC>();
     hipLaunchKernelGGL((chol_dataflow_kernel<T, TBX, OCC>), dim3((unsigned)tasks), dim3(256), lds, h->stream, g);
 }
 
@@ -633,13 +633,13 @@ template <typename T>
 int set_func_attrs(gphip_ctx* h) {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(potrf128_kernel<T>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)potrf_lds<T>()));
-    constexpr int df128 = (int)df_lds_bytes<T, 128>();
+    constexpr int df128 = (int)df_lds_bytes<T, 128, 2>(), df128x = (int)df_lds_bytes<T, 128, 1>();
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(chol_dataflow_kernel<T, 128, 2>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, df128));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(chol_dataflow_kernel<T, 128, 1>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, df128));
+                               hipFuncAttributeMaxDynamicSharedMemorySize, df128x));
     if constexpr (sizeof(T) == 8) {
-        constexpr int df64 = (int)df_lds_bytes<T, 64>();
+        constexpr int df64 = (int)df_lds_bytes<T, 64, 2>();
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(chol_dataflow_kernel<T, 64, 2>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, df64));
     }

@@ -24,7 +24,7 @@ int main(int argc, char** argv) {
     hipMalloc(&dI, 4); hipMalloc(&dF, R * R * 4); hipMalloc(&dT, 16); hipMalloc(&dTr, ntask * 64);
     double sp[8] = {1.0, 0.1, 0.0, 1e-14, 0, 0, 0, 0};
     hipMemcpy(dS, sp, 64, hipMemcpyHostToDevice); hipMemset(dI, 0, 4); hipMemset(dF, 0, R * R * 4); hipMemset(dT, 0, 16);
-    const size_t lds = df_lds_bytes<double, DF_TBX>();
+    const size_t lds = df_lds_bytes<double, DF_TBX, (DF_TBX == 128 ? 1 : 2)>();
     hipFuncSetAttribute(reinterpret_cast<const void*>(chol_dataflow_kernel<double, DF_TBX, (DF_TBX == 128 ? 1 : 2)>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     std::vector<long long> tr((size_t)ntask * 8);
     for (int rep = 0; rep < 3; ++rep) {
