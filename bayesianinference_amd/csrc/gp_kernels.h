@@ -1084,12 +1084,11 @@ template <typename T, int TBX> __device__ __forceinline__ int df_lds_off(int k, 
 template <typename T, int TBX> constexpr int df_stage_elems() {
     return TBX == 128 ? STAGE_BYTES / (int)sizeof(T) : 2 * 8 * LD64;
 }
-// LDS stages of the slab pipeline: 2 (double buffer) when two workgroups share a CU, 4 with counted DMA
-// waits when the workgroup has the CU to itself (fp64 128-tiles): its on-chain products have no
-// co-resident workgroup to hide the DMA latency behind.
-template <int TBX, int OCC> constexpr int df_stages() { return (TBX == 128 && OCC == 1) ? 4 : 2; }
-template <typename T, int TBX, int OCC = 2> constexpr size_t df_lds_bytes() {
-    constexpr size_t gemm = df_stages<TBX, OCC>() * (size_t)df_stage_elems<T, TBX>() * sizeof(T);
+// NST = LDS stages of the slab pipeline: 2 (double buffer), or 4 with counted DMA waits for a workgroup that
+// has the CU to itself (fp64 128-tiles) while the schedule is chain bound: its on-chain products have no
+// co-resident workgroup to hide the DMA latency behind (N=4096 -6 %; at N=8192, throughput bound, +4 %).
+template <typename T, int TBX, int NST = 2> constexpr size_t df_lds_bytes() {
+    constexpr size_t gemm = NST * (size_t)df_stage_elems<T, TBX>() * sizeof(T);
     constexpr size_t nb = TBX / 16;
     constexpr size_t potrf = 16 + (nb * (nb + 1) / 2 * 256 + TBX) * sizeof(T);
     return gemm > potrf ? gemm : potrf;
@@ -1098,7 +1097,7 @@ template <typename T, int TBX, int OCC = 2> constexpr size_t df_lds_bytes() {
 // OCC = workgroups per CU the register budget is sized for: 2 (256 registers: 64-tiles, fp32 128-tiles) or
 // 1 (512 registers: fp64 128-tiles -- 128 accumulator registers plus the out-of-line potrf body do not fit
 // in 256 without spilling accumulators around every slab).
-template <typename T, int TBX, int OCC = 2>
+template <typename T, int TBX, int OCC = 2, int NST = 2>
 __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g) {
     static_assert(TBX == 128 || (TBX == 64 && sizeof(T) == 8), "64-tiles are implemented for fp64 only");
     constexpr int FI = TBX / 32, FJ = TBX / 32, WT = TBX / 2;   // MFMA tiles per wave, wave tile edge
@@ -1233,9 +1232,9 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g) {
                 mfma_block(fi, fj);
             }
         };
-        if constexpr (df_stages<TBX, OCC>() == 4) {
+        if constexpr (NST == 4) {
             // deep pipeline: 3 stages of DMA in flight, counted vmcnt waits, one raw barrier per stage
-            constexpr int NST = 4, AHEAD = NST - 1;
+            constexpr int AHEAD = NST - 1;
             static_assert(TBX == 128, "8 DMA instructions per wave and stage");
             for (int st = 0; st < AHEAD && st < nk; ++st) stage(st, st);
             for (int kb = 0; kb < nk; ++kb) {

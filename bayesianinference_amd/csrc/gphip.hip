@@ -383,7 +383,7 @@ bool use_dataflow(const gphip_ctx* h, int nslots) {
 
 // c0 > 0 (128-tiles only): factor the trailing submatrix that starts at tile column c0 -- the tail of the
 // look-ahead schedule, already updated by every earlier panel.  No finalize here.
-template <typename T, int TBX, int OCC = 2>
+template <typename T, int TBX, int OCC = 2, int NST = 2>
 void launch_dataflow(gphip_ctx* h, int nslots, int c0 = 0) {
     const int nd = (int)(h->Npad / TBX) - c0, R = nd + 1;
     const long ld = h->ld;
@@ -400,8 +400,8 @@ void launch_dataflow(gphip_ctx* h, int nslots, int c0 = 0) {
     h->ticket_base += (unsigned long long)tasks;
     // profile class 3 (panel work): class 4 stays the trailing SYRK alone, it is what the bench's roofline reads
     ProfScope ps(h, 3, ((double)nd * TBX) * ((double)nd * TBX) * ((double)nd * TBX) / 3.0 * nslots, 0.0);
-    constexpr size_t lds = df_lds_bytes<T, TBX, OCC>();
-    hipLaunchKernelGGL((chol_dataflow_kernel<T, TBX, OCC>), dim3((unsigned)tasks), dim3(256), lds, h->stream, g);
+    constexpr size_t lds = df_lds_bytes<T, TBX, NST>();
+    hipLaunchKernelGGL((chol_dataflow_kernel<T, TBX, OCC, NST>), dim3((unsigned)tasks), dim3(256), lds, h->stream, g);
 }
 
 template <typename T>
@@ -428,6 +428,7 @@ int queue_factor_dataflow(gphip_ctx* h, int nslots) {
     // (1 workgroup per CU) build is real -- a 256-register build falls to occupancy 1 anyway AND spills.
     // fp32 accumulators are half the size: 2 workgroups per CU while the schedule is chain bound.
     if (sizeof(T) == 4 && h->Nt <= 32) launch_dataflow<T, 128, 2>(h, nslots);
+    else if (h->Nt <= 48) launch_dataflow<T, 128, 1, 4>(h, nslots);        // chain bound: deep DMA pipeline
     else launch_dataflow<T, 128, 1>(h, nslots);
     launch_finalize<T>(h, nslots, (int)h->Nt);
     return 0;
@@ -633,10 +634,12 @@ template <typename T>
 int set_func_attrs(gphip_ctx* h) {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(potrf128_kernel<T>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)potrf_lds<T>()));
-    constexpr int df128 = (int)df_lds_bytes<T, 128, 2>(), df128x = (int)df_lds_bytes<T, 128, 1>();
+    constexpr int df128 = (int)df_lds_bytes<T, 128, 2>(), df128x = (int)df_lds_bytes<T, 128, 4>();
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(chol_dataflow_kernel<T, 128, 2>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, df128));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(chol_dataflow_kernel<T, 128, 1>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, df128));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>((chol_dataflow_kernel<T, 128, 1, 4>)),
                                hipFuncAttributeMaxDynamicSharedMemorySize, df128x));
     if constexpr (sizeof(T) == 8) {
         constexpr int df64 = (int)df_lds_bytes<T, 64, 2>();

@@ -1,4 +1,4 @@
-// Per-task timeline of chol_dataflow_kernel<double, DF_TBX, (DF_TBX == 128 ? 1 : 2)> on a synthetic SPD matrix (developer tool).
+// Per-task timeline of chol_dataflow_kernel<double, DF_TBX, (DF_TBX == 128 ? 1 : 2), (DF_TBX == 128 ? 4 : 2)> on a synthetic SPD matrix (developer tool).
 // Prints, for the tasks on the critical path, wall-clock stamps (100 MHz s_memrealtime) in us.
 #include "../../bayesianinference_amd/csrc/gp_kernels.h"
 #include <cstdio>
@@ -24,8 +24,8 @@ int main(int argc, char** argv) {
     hipMalloc(&dI, 4); hipMalloc(&dF, R * R * 4); hipMalloc(&dT, 16); hipMalloc(&dTr, ntask * 64);
     double sp[8] = {1.0, 0.1, 0.0, 1e-14, 0, 0, 0, 0};
     hipMemcpy(dS, sp, 64, hipMemcpyHostToDevice); hipMemset(dI, 0, 4); hipMemset(dF, 0, R * R * 4); hipMemset(dT, 0, 16);
-    const size_t lds = df_lds_bytes<double, DF_TBX, (DF_TBX == 128 ? 1 : 2)>();
-    hipFuncSetAttribute(reinterpret_cast<const void*>(chol_dataflow_kernel<double, DF_TBX, (DF_TBX == 128 ? 1 : 2)>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const size_t lds = df_lds_bytes<double, DF_TBX, (DF_TBX == 128 ? 4 : 2)>();
+    hipFuncSetAttribute(reinterpret_cast<const void*>(chol_dataflow_kernel<double, DF_TBX, (DF_TBX == 128 ? 1 : 2), (DF_TBX == 128 ? 4 : 2)>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     std::vector<long long> tr((size_t)ntask * 8);
     for (int rep = 0; rep < 3; ++rep) {
         hipMemcpy(dA, A.data(), A.size() * 8, hipMemcpyHostToDevice);
@@ -34,7 +34,7 @@ int main(int argc, char** argv) {
         g.A = dA; g.ld = ld; g.bstride = ld * ld; g.W = dW; g.w_bstride = (long)Nt * TB * TB; g.partial = dP; g.info = dI;
         g.slotp = dS; g.flags = dF; g.f_bstride = (long)R * R; g.ticket = dT; g.ticket_base = (unsigned long long)rep * ntask;
         g.abort_flag = (int*)(dT + 1); g.nd = nd; g.nslots = 1; g.epoch = rep + 1; g.trace = dTr;
-        hipLaunchKernelGGL((chol_dataflow_kernel<double, DF_TBX, (DF_TBX == 128 ? 1 : 2)>), dim3((unsigned)ntask), dim3(256), lds, 0, g);
+        hipLaunchKernelGGL((chol_dataflow_kernel<double, DF_TBX, (DF_TBX == 128 ? 1 : 2), (DF_TBX == 128 ? 4 : 2)>), dim3((unsigned)ntask), dim3(256), lds, 0, g);
         hipDeviceSynchronize();
     }
     hipMemcpy(tr.data(), dTr, ntask * 64, hipMemcpyDeviceToHost);
