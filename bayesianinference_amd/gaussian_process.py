@@ -387,6 +387,63 @@ def mixture_moments(pred: Mapping):
     return m, w @ (sd ** 2 + mu ** 2) - m ** 2
 
 
+def mixture_percentiles(pred: Mapping, levels: Sequence[float] = (0.95, 0.5, 0.05)):
+    """InverseCDF of every per-point MixtureDistribution at `levels` -- the curves regressionPlot1D draws
+    by default ("DistributionPercentiles" -> {0.95, 0.5, 0.05}, BV:303-308, 351-352).  Returns an array
+    len(levels) x M.  The mixture CDF is monotone, so a bracketed bisection + Newton polish per point
+    is exact to the last bits; everything is vectorised over the M test points."""
+    from scipy.special import ndtr
+    levels = np.asarray(levels, dtype=np.float64)
+    if levels.ndim != 1 or levels.size == 0 or levels.min() <= 0.0 or levels.max() >= 1.0:
+        raise ValueError("levels must lie strictly between 0 and 1 (BV:351)")
+    w = np.asarray(pred["Weights"], dtype=np.float64)
+    w = w / w.sum()
+    mu = np.asarray(pred["Mean"], dtype=np.float64)
+    sd = np.asarray(pred["StandardDeviation"], dtype=np.float64)
+    keep = w > 0.0
+    w, mu, sd = w[keep], mu[keep], sd[keep]
+
+    def cdf(x):                                            # x: (M,) -> (M,)
+        return np.einsum("s,sm->m", w, ndtr((x[None, :] - mu) / sd))
+
+    def pdf(x):
+        z = (x[None, :] - mu) / sd
+        return np.einsum("s,sm->m", w, np.exp(-0.5 * z * z) / (sd * np.sqrt(2.0 * np.pi)))
+
+    out = np.empty((levels.size, mu.shape[1]))
+    span = 9.0 * sd                                       # every component's mass to ~1e-19 lies inside
+    for k, q in enumerate(levels):
+        lo, hi = (mu - span).min(axis=0), (mu + span).max(axis=0)
+        for _ in range(60):                               # bisection: brackets shrink by 2^-60
+            mid = 0.5 * (lo + hi)
+            below = cdf(mid) < q
+            lo = np.where(below, mid, lo)
+            hi = np.where(below, hi, mid)
+        x = 0.5 * (lo + hi)
+        for _ in range(2):                                # Newton polish inside the bracket
+            step = (cdf(x) - q) / np.maximum(pdf(x), 1e-300)
+            x = np.clip(x - step, lo, hi)
+        out[k] = x
+    return out
+
+
+def mixture_plot_moments(pred: Mapping):
+    """The "Moments" option of regressionPlot1D (BV:340-349): per point the three curves
+    {mean + sd + m3^(1/3), mean, mean - sd + m3^(1/3)} with m3 the third central moment of the mixture
+    and the real cube root (Surd)."""
+    w = np.asarray(pred["Weights"], dtype=np.float64)
+    w = w / w.sum()
+    mu = np.asarray(pred["Mean"], dtype=np.float64)
+    sd = np.asarray(pred["StandardDeviation"], dtype=np.float64)
+    m = w @ mu
+    var = w @ (sd ** 2 + mu ** 2) - m ** 2
+    dm = mu - m
+    m3 = w @ (dm ** 3 + 3.0 * dm * sd ** 2)               # third central moment of a normal mixture
+    s = np.sqrt(np.maximum(var, 0.0))
+    skew = np.cbrt(m3)
+    return np.stack([m + s + skew, m, m - s + skew])
+
+
 # ---------------------------------------------------------------------------------------------
 # persistence (SURVEY.md §8f rank 4): an inferenceObject is a plain Association the user may
 # Put/Export (BU:125); the device state (X, y resident; L, z after a fit) is rebuildable from it.

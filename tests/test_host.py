@@ -97,3 +97,39 @@ def test_normalize_data_and_posterior_fraction():
     top = gp.takePosteriorFraction(obj, 0.7)["Samples"]                          # BU:298-316
     assert [s["Point"][0] for s in top] == [1, 3]
     assert [s["Point"][0] for s in gp.takePosteriorFraction(obj, 1)["Samples"]] == [1, 3, 2, 0]
+
+
+def test_mixture_percentiles_and_plot_moments():
+    """What regressionPlot1D draws from the per-point MixtureDistribution (BV:303-374): InverseCDF at the
+    percentile levels (default {0.95, 0.5, 0.05}) or the "Moments" triple with the real cube root of the
+    third central moment.  Pure host arithmetic: checked against the CDF itself, closed forms and quadrature."""
+    from scipy.special import ndtr, ndtri
+    rng = np.random.default_rng(3)
+    S, M = 9, 13
+    pred = {"Weights": rng.random(S), "Mean": rng.normal(size=(S, M)), "StandardDeviation": 0.1 + rng.random((S, M))}
+    levels = (0.95, 0.5, 0.05)
+    q = gp.mixture_percentiles(pred, levels)
+    w = pred["Weights"] / pred["Weights"].sum()
+    for k, lev in enumerate(levels):
+        cdf = np.einsum("s,sm->m", w, ndtr((q[k][None, :] - pred["Mean"]) / pred["StandardDeviation"]))
+        np.testing.assert_allclose(cdf, lev, rtol=0, atol=1e-13)
+    assert np.all(q[0] > q[1]) and np.all(q[1] > q[2])
+    # one component: plain normal quantiles; zero-weight components are ignored
+    one = {"Weights": np.array([2.0, 0.0]), "Mean": np.array([[1.5, -2.0], [9.0, 9.0]]),
+           "StandardDeviation": np.array([[0.5, 3.0], [1.0, 1.0]])}
+    np.testing.assert_allclose(gp.mixture_percentiles(one, (0.9, 0.2)),
+                               np.array([[1.5, -2.0]]) + ndtri(np.array([[0.9], [0.2]])) * np.array([[0.5, 3.0]]), rtol=1e-12)
+    with pytest.raises(ValueError):
+        gp.mixture_percentiles(one, (0.5, 1.0))
+    # "Moments": symmetric single normal -> {m + s, m, m - s}; skewed mixture -> third moment by quadrature
+    np.testing.assert_allclose(gp.mixture_plot_moments(one), [[2.0, 1.0], [1.5, -2.0], [1.0, -5.0]], atol=1e-12)
+    hi, mid, lo = gp.mixture_plot_moments(pred)
+    m, v = gp.mixture_moments(pred)
+    np.testing.assert_allclose(mid, m, rtol=1e-14)
+    x = np.linspace(-12, 12, 200001)
+    j = 4
+    pdf = sum(w[s] * np.exp(-0.5 * ((x - pred["Mean"][s, j]) / pred["StandardDeviation"][s, j]) ** 2)
+              / (pred["StandardDeviation"][s, j] * np.sqrt(2 * np.pi)) for s in range(S))
+    m3 = np.trapezoid((x - m[j]) ** 3 * pdf, x)
+    np.testing.assert_allclose(hi[j], m[j] + np.sqrt(v[j]) + np.cbrt(m3), rtol=1e-8)
+    np.testing.assert_allclose(lo[j], m[j] - np.sqrt(v[j]) + np.cbrt(m3), rtol=1e-8)
