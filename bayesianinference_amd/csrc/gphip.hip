@@ -69,6 +69,7 @@ struct gphip_ctx {
     int latency_gemm = 1, latency_tiles = 256;   // launches of <= latency_tiles tiles use the latency GEMM shape
     int dataflow = 1, dataflow_max_nt = 64, dataflow_max_slots = 8;   // single-launch dataflow Cholesky: latency regime only
     int dataflow_fine_nt = 16;                   // ... with 64x64 tiles up to this many 128-tiles (fp64)
+    int panel_left = -1;                         // in-panel updates left-looking: -1 auto (batches), 0 never, 1 always
     int grad_potri = 1;                          // gradient: K^-1 = U U^T in one go when the memory is there
     int dataflow_tail = 64;                      // large N: the last <= dataflow_tail tile columns go to the dataflow kernel (0 = off)
     bool theta_packed = false;                   // eval_chunk: hyper-parameters travel as kernel arguments (k_scale_theta)
@@ -350,8 +351,17 @@ int queue_panel(gphip_ctx* h, int K0, int nin, int nslots) {
     const long ld = h->ld, bs = ld * ld, lrs = (long)Nt * TB * TB;
     T* A = (T*)h->dA;
     T* W = (T*)h->dW;
+    // In-panel updates: right-looking (after column b, K = 128 onto every remaining column of the panel: few,
+    // wide launches -- shortest chain for one theta) or left-looking (before column b, ONE update of that
+    // column with K = 128 (b - K0): each tile read and written once per panel, longer contractions --
+    // better throughput once a batch of thetas fills the chip anyway).
+    const bool left = h->panel_left > 0 || (h->panel_left < 0 && nslots > h->dataflow_max_slots);
     for (int s = 0; s < nin; ++s) {
         const int b = K0 + s;
+        if (left && s > 0) {
+            const T* P = A + (long)K0 * TB * ld;
+            launch_gemm<T>(h, 3, A, ld, bs, P, ld, bs, P, ld, bs, s * TB, b, R, b, b + 1, 1, nslots);
+        }
         {
             ProfScope ps(h, 1, 2.0 * TB * TB * TB / 3.0 * nslots, 0.0);
             hipLaunchKernelGGL(potrf128_kernel<T>, dim3(nslots), dim3(256), potrf_lds<T>(), h->cs, A, ld, bs, b, W,
@@ -360,7 +370,7 @@ int queue_panel(gphip_ctx* h, int K0, int nin, int nslots) {
         // panel solve X <- X W_b^T for every row tile below the diagonal block (incl. rhs rows)
         launch_gemm<T>(h, 2, A, ld, bs, A + (long)b * TB * ld, ld, bs, W + (long)b * TB * TB - (long)b * TB, TB, lrs,
                        TB, b + 1, R, b, b + 1, 0, nslots, 1);
-        if (s + 1 < nin) {
+        if (!left && s + 1 < nin) {
             const T* P = A + (long)b * TB * ld;
             launch_gemm<T>(h, 3, A, ld, bs, P, ld, bs, P, ld, bs, TB, b + 1, R, b + 1, K0 + nin, 1, nslots);
         }
@@ -1407,6 +1417,7 @@ int gphip_set_option(gphip_handle h, const char* name, double value) {
     else if (!strcmp(name, "dataflow_fine_nt")) h->dataflow_fine_nt = v;
     else if (!strcmp(name, "dataflow_tail")) h->dataflow_tail = v;
     else if (!strcmp(name, "grad_potri")) h->grad_potri = v;
+    else if (!strcmp(name, "panel_left")) h->panel_left = v;
     else if (!strcmp(name, "max_slots")) { if (v < 1) return fail(h, GPHIP_ERR_ARG, "max_slots < 1"); h->max_slots = v; }
     else return fail(h, GPHIP_ERR_ARG, "unknown option");
     return GPHIP_OK;

@@ -108,6 +108,8 @@ int gphip_logdet(gphip_handle h, double* out);
  *                  <= "dataflow_max_slots" thetas per call (default 8), with 64x64 tiles up to
  *                  "dataflow_fine_nt" 128-tiles (default 16, fp64); larger problems hand their last
  *                  "dataflow_tail" tile columns (default 64, 0 = off) to the same kernel
+ *   "panel_left"   -1 auto / 0 / 1: left-looking in-panel updates (one K = 128 s update per column instead of
+ *                  K = 128 updates after every column); auto = for batches of more than "dataflow_max_slots"
  *   "grad_potri"   0/1 gradient: form K^-1 = U U^T in one go when 2 N^2 of scratch fits (default 1), else
  *                  stream it in row blocks through forward + backward substitution
  *   "max_slots"    cap on concurrently resident batch matrices */
