@@ -687,7 +687,6 @@ __device__ __noinline__ void potrf128_core_call(double* lds_raw, T* Ad, long ld,
                                                 int* info_out, T tol) {
     potrf128_core<T, NB>(lds_raw, Ad, ld, Wg, logdet_out, info_out, tol);
 }
-
 template <typename T>
 __global__ __launch_bounds__(256) void potrf128_kernel(T* __restrict__ Abase, long ld, long bstride, int b,
                                                        T* __restrict__ Winv, double* __restrict__ partial,
@@ -1270,9 +1269,36 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g) {
 
     // ---- accumulate the updates of all earlier columns
     if (j > 0 || i == j) load_c(Ct, g.ld);
+    // A task that starts late finds most of its columns finished already.  Polling them one by one costs a
+    // dependent ~1 us flag load (and an L2 invalidate) per slab -- more than a 64-wide slab's MFMA work --
+    // so wave 0 peeks at all of them in parallel ONCE, and the leading run of finished columns is taken
+    // without further polls (one acquire for the lot).
+    int known = 0;
+    if (j > 1) {
+        if (wave == 0) {
+            int run = 0;
+            for (int c0 = 0; c0 < j; c0 += 64) {
+                const int c = c0 + lane;
+                bool ready = false;
+                if (c < j)
+                    ready = __hip_atomic_load(F + i * R + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == g.epoch &&
+                            __hip_atomic_load(F + j * R + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == g.epoch;
+                const unsigned long long miss = ~__ballot(ready);
+                const int lead = miss ? __builtin_ctzll(miss) : 64;
+                run += lead;
+                if (lead < 64) break;
+            }
+            if (lane == 0) s_task = run < j ? run : j;
+        }
+        __syncthreads();
+        known = __builtin_amdgcn_readfirstlane(s_task);
+        if (known > 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
     for (int b = 0; b < j; ++b) {                          // one TBX-wide slab per finished column b
-        df_wait(F + i * R + b, g.epoch, g.abort_flag);
-        if (i != j) df_wait(F + j * R + b, g.epoch, g.abort_flag);
+        if (b >= known) {
+            df_wait(F + i * R + b, g.epoch, g.abort_flag);
+            if (i != j) df_wait(F + j * R + b, g.epoch, g.abort_flag);
+        }
         if (b == j - 1) stamp(6);
         run_k(As + (long)b * TBX * g.ld + (long)i * TBX, g.ld, As + (long)b * TBX * g.ld + (long)j * TBX, g.ld, SPB, true);
     }

@@ -68,7 +68,7 @@ struct gphip_ctx {
     int panel = 4, profile = 0, swizzle = 1, max_slots = 256, lookahead = 1, supertile = 0;
     int latency_gemm = 1, latency_tiles = 256;   // launches of <= latency_tiles tiles use the latency GEMM shape
     int dataflow = 1, dataflow_max_nt = 64, dataflow_max_slots = 8;   // single-launch dataflow Cholesky: latency regime only
-    int dataflow_fine_nt = 16;                   // ... with 64x64 tiles up to this many 128-tiles (fp64)
+    int dataflow_fine_nt = 32;                   // ... with 64x64 tiles up to this many 128-tiles (fp64, N <= 4096)
     int panel_left = -1;                         // in-panel updates left-looking: -1 auto (batches), 0 never, 1 always
     int grad_potri = 1;                          // gradient: K^-1 = U U^T in one go when the memory is there
     int dataflow_tail = 64;                      // large N: the last <= dataflow_tail tile columns go to the dataflow kernel (0 = off)
@@ -437,8 +437,14 @@ int queue_factor_dataflow(gphip_ctx* h, int nslots) {
     // fp64 128-tiles: the out-of-line potrf body needs 232 + 40 registers, so only the 512-register
     // (1 workgroup per CU) build is real -- a 256-register build falls to occupancy 1 anyway AND spills.
     // fp32 accumulators are half the size: 2 workgroups per CU while the schedule is chain bound.
-    if (sizeof(T) == 4 && h->Nt <= 32) launch_dataflow<T, 128, 2>(h, nslots);
-    else if (h->Nt <= 48) launch_dataflow<T, 128, 1, 4>(h, nslots);        // chain bound: deep DMA pipeline
+    if constexpr (sizeof(T) == 4) {
+        if (h->Nt <= 32) {
+            launch_dataflow<T, 128, 2>(h, nslots);
+            launch_finalize<T>(h, nslots, (int)h->Nt);
+            return 0;
+        }
+    }
+    if (h->Nt <= 48) launch_dataflow<T, 128, 1, 4>(h, nslots);             // chain bound: deep DMA pipeline
     else launch_dataflow<T, 128, 1>(h, nslots);
     launch_finalize<T>(h, nslots, (int)h->Nt);
     return 0;
@@ -645,8 +651,9 @@ int set_func_attrs(gphip_ctx* h) {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(potrf128_kernel<T>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)potrf_lds<T>()));
     constexpr int df128 = (int)df_lds_bytes<T, 128, 2>(), df128x = (int)df_lds_bytes<T, 128, 4>();
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(chol_dataflow_kernel<T, 128, 2>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, df128));
+    if constexpr (sizeof(T) == 4)
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(chol_dataflow_kernel<T, 128, 2>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, df128));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(chol_dataflow_kernel<T, 128, 1>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, df128));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>((chol_dataflow_kernel<T, 128, 1, 4>)),
