@@ -1294,7 +1294,17 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g) {
         known = __builtin_amdgcn_readfirstlane(s_task);
         if (known > 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
-    for (int b = 0; b < j; ++b) {                          // one TBX-wide slab per finished column b
+    int b0 = 0;
+    if constexpr (TBX == 64) {
+        // 64-tiles: the finished run is ONE pipelined pass (a K = 64 slab is only 4 stages, its pipeline fill
+        // would cost as much as its MFMAs).  Not for 128-tiles: with 128 accumulator registers a variable
+        // trip count makes the allocator spill inside the stage loop.
+        if (known > 0) {
+            run_k(As + (long)i * TBX, g.ld, As + (long)j * TBX, g.ld, known * SPB, true);
+            b0 = known;
+        }
+    }
+    for (int b = b0; b < j; ++b) {                         // one TBX-wide slab per finished column b
         if (b >= known) {
             df_wait(F + i * R + b, g.epoch, g.abort_flag);
             if (i != j) df_wait(F + j * R + b, g.epoch, g.abort_flag);
