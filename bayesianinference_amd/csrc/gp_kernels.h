@@ -1059,7 +1059,7 @@ __device__ __forceinline__ void df_wait(const int* f, int epoch, int* abort_flag
     // "unlikely": keeps the register allocator from treating this poll loop as hotter than the MFMA
     // loop it sits in (it would spill accumulators around it)
     while (__builtin_expect(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch, 0)) {
-        __builtin_amdgcn_s_sleep(8);
+        __builtin_amdgcn_s_sleep(8);                        // (a longer back-off for long waits was measured: no gain)
         if ((++spins & 63) == 0) {
             if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
             if (spins > DF_SPIN_LIMIT) {
@@ -1305,9 +1305,12 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g) {
         }
     }
     for (int b = b0; b < j; ++b) {                         // one TBX-wide slab per finished column b
-        if (b >= known) {
-            df_wait(F + i * R + b, g.epoch, g.abort_flag);
-            if (i != j) df_wait(F + j * R + b, g.epoch, g.abort_flag);
+        if (b >= known) {                                  // ONE wave polls (hundreds of waiting workgroups hammer
+            if (wave == 0) {                               // the same few flag lines: 4x fewer pollers), the rest
+                df_wait(F + i * R + b, g.epoch, g.abort_flag);             // wait at the barrier
+                if (i != j) df_wait(F + j * R + b, g.epoch, g.abort_flag);
+            }
+            __syncthreads();
         }
         if (b == j - 1) stamp(6);
         run_k(As + (long)b * TBX * g.ld + (long)i * TBX, g.ld, As + (long)b * TBX * g.ld + (long)j * TBX, g.ld, SPB, true);
@@ -1349,7 +1352,8 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g) {
     }
     zero_c();
     stamp(2);
-    df_wait(F + j * R + j, g.epoch, g.abort_flag);
+    if (wave == 0) df_wait(F + j * R + j, g.epoch, g.abort_flag);
+    __syncthreads();
     stamp(5);
     run_k(Ct, g.ld, Wj, TBX, SPB, false);
     stamp(3);

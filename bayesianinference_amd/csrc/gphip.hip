@@ -68,7 +68,7 @@ struct gphip_ctx {
     int panel = 4, profile = 0, swizzle = 1, max_slots = 256, lookahead = 1, supertile = 0;
     int latency_gemm = 1, latency_tiles = 256;   // launches of <= latency_tiles tiles use the latency GEMM shape
     int dataflow = 1, dataflow_max_nt = 64, dataflow_max_slots = 8;   // single-launch dataflow Cholesky: latency regime only
-    int dataflow_fine_nt = 32;                   // ... with 64x64 tiles up to this many 128-tiles (fp64, N <= 4096)
+    int dataflow_fine_nt = 64;                   // ... with 64x64 tiles up to this many 128-tiles (fp64; measured best up to N = 8192)
     int panel_left = -1;                         // in-panel updates left-looking: -1 auto (batches), 0 never, 1 always
     int grad_potri = 1;                          // gradient: K^-1 = U U^T in one go when the memory is there
     int dataflow_tail = 64;                      // large N: the last <= dataflow_tail tile columns go to the dataflow kernel (0 = off)
