@@ -1147,6 +1147,9 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[x][y][r] = cp[(long)(x * 16 + Num<T>::drow(l4, r)) * ldc + y * 16];
     };
+    // Tile stores are write-through at agent scope (sc1): the release fence of publish() writes back every
+    // dirty line of the XCD's L2 -- with plain stores that is the tiles of every workgroup on the XCD, again
+    // and again (5 us per publish under load); with write-through stores there is nothing left to flush.
     auto store_c = [&](T* base, long ldc) {
         T* cp0 = c_ptr(base, ldc);
 #pragma unroll
@@ -1155,7 +1158,8 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g) {
             for (int r = 0; r < 4; ++r) {
                 T* cp = cp0 + (long)(x * 16 + Num<T>::drow(l4, r)) * ldc;
 #pragma unroll
-                for (int y = 0; y < FI; ++y) cp[y * 16] = acc[x][y][r];
+                for (int y = 0; y < FI; ++y)
+                    __hip_atomic_store(cp + y * 16, acc[x][y][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
     };
     auto zero_c = [&]() {
@@ -1264,7 +1268,9 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g) {
     auto publish = [&](int fi_, int fj_) {                  // everything this workgroup stored is visible first
         __threadfence();
         __syncthreads();
-        if (tid == 0) __hip_atomic_store(F + fi_ * R + fj_, g.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        // relaxed: every thread's own agent-scope fence above has already pushed its stores out, and the barrier
+        // orders them before this store -- a second release here would only repeat the L2 write-back
+        if (tid == 0) __hip_atomic_store(F + fi_ * R + fj_, g.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
 
     // ---- accumulate the updates of all earlier columns

@@ -48,6 +48,10 @@ int main(int argc, char** argv) {
         const long long* t = &tr[(size_t)(off(j) + 1) * 8];
         printf("trsm(%d,%d): %.2f | last slab flag %.2f | %.2f | %.2f | %.2f | %.2f | %.2f\n", j + 1, j, us(t[0]), us(t[6]), us(t[1]), us(t[5]), us(t[2]), us(t[3]), us(t[4]));
     }
+    if (nd > 40) for (int j = 30; j < 33; ++j) {
+        const long long* d = &tr[(size_t)off(j) * 8]; const long long* x = &tr[(size_t)(off(j) + 1) * 8];
+        printf("mid diag(%d): start %.1f lastflag %.1f accdone %.1f corebeg %.1f coreend %.1f pub %.1f | trsm(%d,%d): start %.1f accdone %.1f flag %.1f end %.1f pub %.1f\n", j, us(d[0]), us(d[6]), us(d[1]), us(d[2]), us(d[3]), us(d[4]), j + 1, j, us(x[0]), us(x[1]), us(x[5]), us(x[3]), us(x[4]));
+    }
     // pace of the diagonal: potrf end of every 8th diagonal task
     for (int j = 0; j < nd; j += 8) { const long long* d = &tr[(size_t)off(j) * 8]; printf("diag %d: start %.1f flagseen %.1f accdone %.1f potrf_end %.1f\n", j, us(d[0]), us(d[6]), us(d[1]), us(d[3])); }
     long long tend = 0; for (long q = 0; q < ntask; ++q) for (int k = 0; k < 8; ++k) tend = std::max(tend, tr[(size_t)q * 8 + k]);
