@@ -1138,19 +1138,19 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g) {
     acc_t acc[FJ][FI];
     // D-layout address of this lane's accumulators inside a TBX x TBX tile with leading dimension ldc
     auto c_ptr = [&](T* base, long ldc) { return base + (long)(wj * WT) * ldc + wi * WT + l15; };
-    auto load_c = [&](const T* base, long ldc) {
+    auto load_c = [&](acc_t (&A)[FJ][FI], const T* base, long ldc) {
         const T* cp = c_ptr(const_cast<T*>(base), ldc);
 #pragma unroll
         for (int x = 0; x < FJ; ++x)
 #pragma unroll
             for (int y = 0; y < FI; ++y)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc[x][y][r] = cp[(long)(x * 16 + Num<T>::drow(l4, r)) * ldc + y * 16];
+                for (int r = 0; r < 4; ++r) A[x][y][r] = cp[(long)(x * 16 + Num<T>::drow(l4, r)) * ldc + y * 16];
     };
     // Tile stores are write-through at agent scope (sc1): the release fence of publish() writes back every
     // dirty line of the XCD's L2 -- with plain stores that is the tiles of every workgroup on the XCD, again
     // and again (5 us per publish under load); with write-through stores there is nothing left to flush.
-    auto store_c = [&](T* base, long ldc) {
+    auto store_c = [&](acc_t (&A)[FJ][FI], T* base, long ldc) {
         T* cp0 = c_ptr(base, ldc);
 #pragma unroll
         for (int x = 0; x < FJ; ++x)
@@ -1159,20 +1159,20 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g) {
                 T* cp = cp0 + (long)(x * 16 + Num<T>::drow(l4, r)) * ldc;
 #pragma unroll
                 for (int y = 0; y < FI; ++y)
-                    __hip_atomic_store(cp + y * 16, acc[x][y][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(cp + y * 16, A[x][y][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
     };
-    auto zero_c = [&]() {
+    auto zero_c = [&](acc_t (&A)[FJ][FI]) {
 #pragma unroll
         for (int x = 0; x < FJ; ++x)
 #pragma unroll
-            for (int y = 0; y < FI; ++y) acc[x][y] = (acc_t){0, 0, 0, 0};
+            for (int y = 0; y < FI; ++y) A[x][y] = (acc_t){0, 0, 0, 0};
     };
 
     // acc (+/-)= I J^T over nk LDS stages; I(i,k) at Ig[i + k*ldi], J(j,k) at Jg[j + k*ldj].  Same
     // LDS-DMA double buffer as gemm_nt (see there).  No dependency waits in here: a poll loop nested in
     // this loop makes the register allocator spill accumulators around it.
-    auto run_k = [&](const T* Ig, long ldi, const T* Jg, long ldj, int nk, bool negate) {
+    auto run_k = [&](acc_t (&A)[FJ][FI], const T* Ig, long ldi, const T* Jg, long ldj, int nk, bool negate) {
         auto stage = [&](int kb, int st) {
             T* Is = smem + st * STAGE;
             T* Js = Is + JOFF;
@@ -1224,7 +1224,7 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g) {
 #pragma unroll
             for (int x = 0; x < FJ; ++x)
 #pragma unroll
-                for (int y = 0; y < FI; ++y) acc[x][y] = Num<T>::mfma(nj[x], fi[y], acc[x][y]);
+                for (int y = 0; y < FI; ++y) A[x][y] = Num<T>::mfma(nj[x], fi[y], A[x][y]);
         };
         constexpr int NKK = GK / 4;
         auto compute = [&](int buf) {
@@ -1273,20 +1273,28 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g) {
         if (tid == 0) __hip_atomic_store(F + fi_ * R + fj_, g.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
 
+    // 64-tiles fuse the critical chain: the diagonal task (j,j) ALSO solves its own sub-diagonal tile (j,j-1)
+    // (whose owner only accumulates it and hands the pre-solve tile over through memory) and applies that
+    // last slab straight from LDS -- one flag hop per column on the chain instead of two.
+    constexpr bool FUSE = TBX == 64;
+    const bool diagx = FUSE && i == j && j >= 1 && j < g.nd;     // solves (j,j-1) itself
+    const bool accp = FUSE && i == j + 1 && i < g.nd;            // tile (j+1,j): accumulate only
+    const int jacc = diagx ? j - 1 : j;                          // slabs taken from memory
+
     // ---- accumulate the updates of all earlier columns
-    if (j > 0 || i == j) load_c(Ct, g.ld);
+    if (j > 0 || i == j) load_c(acc, Ct, g.ld);
     // A task that starts late finds most of its columns finished already.  Polling them one by one costs a
     // dependent ~1 us flag load (and an L2 invalidate) per slab -- more than a 64-wide slab's MFMA work --
     // so wave 0 peeks at all of them in parallel ONCE, and the leading run of finished columns is taken
     // without further polls (one acquire for the lot).
     int known = 0;
-    if (j > 1) {
+    if (jacc > 1) {
         if (wave == 0) {
             int run = 0;
-            for (int c0 = 0; c0 < j; c0 += 64) {
+            for (int c0 = 0; c0 < jacc; c0 += 64) {
                 const int c = c0 + lane;
                 bool ready = false;
-                if (c < j)
+                if (c < jacc)
                     ready = __hip_atomic_load(F + i * R + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == g.epoch &&
                             __hip_atomic_load(F + j * R + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == g.epoch;
                 const unsigned long long miss = ~__ballot(ready);
@@ -1294,7 +1302,7 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g) {
                 run += lead;
                 if (lead < 64) break;
             }
-            if (lane == 0) s_task = run < j ? run : j;
+            if (lane == 0) s_task = run < jacc ? run : jacc;
         }
         __syncthreads();
         known = __builtin_amdgcn_readfirstlane(s_task);
@@ -1306,11 +1314,11 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g) {
         // would cost as much as its MFMAs).  Not for 128-tiles: with 128 accumulator registers a variable
         // trip count makes the allocator spill inside the stage loop.
         if (known > 0) {
-            run_k(As + (long)i * TBX, g.ld, As + (long)j * TBX, g.ld, known * SPB, true);
+            run_k(acc, As + (long)i * TBX, g.ld, As + (long)j * TBX, g.ld, known * SPB, true);
             b0 = known;
         }
     }
-    for (int b = b0; b < j; ++b) {                         // one TBX-wide slab per finished column b
+    for (int b = b0; b < jacc; ++b) {                      // one TBX-wide slab per finished column b
         if (b >= known) {                                  // ONE wave polls (hundreds of waiting workgroups hammer
             if (wave == 0) {                               // the same few flag lines: 4x fewer pollers), the rest
                 df_wait(F + i * R + b, g.epoch, g.abort_flag);             // wait at the barrier
@@ -1319,13 +1327,65 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g) {
             __syncthreads();
         }
         if (b == j - 1) stamp(6);
-        run_k(As + (long)b * TBX * g.ld + (long)i * TBX, g.ld, As + (long)b * TBX * g.ld + (long)j * TBX, g.ld, SPB, true);
+        run_k(acc, As + (long)b * TBX * g.ld + (long)i * TBX, g.ld, As + (long)b * TBX * g.ld + (long)j * TBX, g.ld, SPB, true);
     }
     stamp(1);
 
+    if constexpr (FUSE) {
+        if (accp) {                                         // hand the pre-solve tile (j+1,j) to the diagonal task
+            if (j > 0) store_c(acc, Ct, g.ld);
+            publish(j, i);                                  // "pre" flag lives in the unused upper slot (j, j+1)
+            stamp(4);
+            return;
+        }
+        if (diagx) {
+            const int jm = j - 1;
+            T* Xt = As + (long)jm * TBX * g.ld + (long)j * TBX;            // tile (j, j-1)
+            if (wave == 0) {
+                df_wait(F + jm * R + j, g.epoch, g.abort_flag);           // pre-solve tile stored by its owner
+                df_wait(F + jm * R + jm, g.epoch, g.abort_flag);          // W_{j-1}
+            }
+            __syncthreads();
+            stamp(5);
+            acc_t accx[FJ][FI];
+            zero_c(accx);
+            run_k(accx, Xt, g.ld, g.W + (long)slot * g.w_bstride + (long)jm * TBX * TBX, TBX, SPB, false);
+            store_c(accx, Xt, g.ld);                        // X(j,j-1): the column below waits for it
+            // X -> four LDS stage images [k][row] (both MFMA operands of X X^T read the same image)
+#pragma unroll
+            for (int x = 0; x < FJ; ++x)
+#pragma unroll
+                for (int y = 0; y < FI; ++y)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int c = wj * WT + x * 16 + Num<T>::drow(l4, r), irow = wi * WT + y * 16 + l15;
+                        smem[(c >> 4) * JOFF + df_lds_off<T, TBX>(c & 15, irow)] = accx[x][y][r];
+                    }
+            publish(j, jm);                                 // (its barrier also orders the LDS image)
+#pragma unroll
+            for (int st = 0; st < TBX / GK; ++st)
+#pragma unroll
+                for (int kk = 0; kk < GK / 4; ++kk) {
+                    const T* Im = smem + st * JOFF + l15;
+                    const int kq = 4 * kk + l4;
+                    T fi[FI], fj[FJ];
+#pragma unroll
+                    for (int f = 0; f < FI; ++f) fi[f] = Im[df_lds_off<T, TBX>(kq, wi * WT + f * 16)];
+#pragma unroll
+                    for (int f = 0; f < FJ; ++f) fj[f] = -Im[df_lds_off<T, TBX>(kq, wj * WT + f * 16)];
+#pragma unroll
+                    for (int x = 0; x < FJ; ++x)
+#pragma unroll
+                        for (int y = 0; y < FI; ++y) acc[x][y] = Num<T>::mfma(fj[x], fi[y], acc[x][y]);
+                }
+            __syncthreads();                                // the images make way for the potrf image
+            stamp(6);
+        }
+    }
+
     if (i == j) {
         if (j == g.nd) {                                    // corner of the border: -|z|^2 accumulates here
-            store_c(Ct, g.ld);
+            store_c(acc, Ct, g.ld);
             return;
         }
         // accumulators -> tile-packed LDS image of the lower triangle, then factor + invert in place
@@ -1352,18 +1412,18 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g) {
 
     // ---- panel solve X(i,j) = acc W_j^T: the pre-solve tile goes through memory to become an MFMA operand
     if (j > 0) {
-        store_c(Ct, g.ld);
+        store_c(acc, Ct, g.ld);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
-    zero_c();
+    zero_c(acc);
     stamp(2);
     if (wave == 0) df_wait(F + j * R + j, g.epoch, g.abort_flag);
     __syncthreads();
     stamp(5);
-    run_k(Ct, g.ld, Wj, TBX, SPB, false);
+    run_k(acc, Ct, g.ld, Wj, TBX, SPB, false);
     stamp(3);
-    store_c(Ct, g.ld);
+    store_c(acc, Ct, g.ld);
     publish(i, j);
     stamp(4);
 }

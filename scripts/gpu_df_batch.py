@@ -4,7 +4,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
 from bayesianinference_amd import _lib, synthetic as syn
-for n, d, B, dtype in ((4096, 3, 200, 64), (1024, 3, 200, 64), (512, 1, 200, 64), (2048, 8, 16, 64), (4096, 8, 8, 32), (512, 1, 1, 32)):
+for n, d, B, dtype in ((4096, 3, 200, 64), (1024, 3, 200, 64), (512, 1, 200, 64), (2048, 8, 16, 64), (2048, 8, 32, 64), (1024, 8, 32, 64), (4096, 8, 16, 64), (512, 1, 32, 64)):
     kernel = "se" if d == 1 else "se_ard"
     X, y = syn.make_dataset(n, d)
     Th = syn.theta_batch(B, kernel, d)
@@ -12,6 +12,7 @@ for n, d, B, dtype in ((4096, 3, 200, 64), (1024, 3, 200, 64), (512, 1, 200, 64)
     out = {}
     for df in (0, 1):
         h.set_option("dataflow", df)
+        h.set_option("dataflow_max_slots", 100000)
         h.loglik_batch(Th)
         t0 = time.perf_counter()
         ll, info = h.loglik_batch(Th)
