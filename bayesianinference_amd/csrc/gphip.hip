@@ -67,8 +67,8 @@ struct gphip_ctx {
     // options
     int panel = 4, profile = 0, swizzle = 1, max_slots = 256, lookahead = 1, supertile = 0;
     int latency_gemm = 1, latency_tiles = 256;   // launches of <= latency_tiles tiles use the latency GEMM shape
-    int dataflow = 1, dataflow_max_nt = 64, dataflow_max_slots = 8;   // single-launch dataflow Cholesky: latency regime only
-    int dataflow_fine_nt = 64;                   // ... with 64x64 tiles up to this many 128-tiles (fp64; measured best up to N = 8192)
+    int dataflow = 1, dataflow_max_nt = 96, dataflow_max_slots = 8;   // single-launch dataflow Cholesky: latency regime only
+    int dataflow_fine_nt = 96;                   // ... with 64x64 tiles up to this many 128-tiles (fp64; measured best up to N = 12288)
     int panel_left = -1;                         // in-panel updates left-looking: -1 auto (batches), 0 never, 1 always
     int grad_potri = 1;                          // gradient: K^-1 = U U^T in one go when the memory is there
     int dataflow_tail = 64;                      // large N: the last <= dataflow_tail tile columns go to the dataflow kernel (0 = off)
@@ -384,9 +384,10 @@ int queue_panel(gphip_ctx* h, int K0, int nin, int nslots) {
 // inverses of 64-blocks in dW, so callers that substitute afterwards (h->want_w) get the 128-block
 // inverses rebuilt by trtri128.
 bool use_dataflow(const gphip_ctx* h, int nslots) {
-    // measured: wins 10-17 % for one theta up to N = 8192, ties at 8-16 slots, loses 35 % at 200 slots
+    // measured: wins 1.05-2.3x for one theta up to N = 12288, ties at 8-16 slots, loses 2x at 200 slots
     // (there the multi-kernel schedule's big launches are throughput bound, not latency bound)
     if (!h->dataflow || h->dist_world > 0 || h->Nt > h->dataflow_max_nt || nslots > h->dataflow_max_slots) return false;
+    if (h->dtype == 32 && h->Nt > 64) return false;        // fp32 has 128-tiles only: measured range ends at N = 8192
     const long tasks = (long)(2 * h->Nt + 1) * (2 * h->Nt + 2) / 2 * nslots;
     return tasks < (1l << 30);
 }

@@ -104,9 +104,9 @@ int gphip_logdet(gphip_handle h, double* out);
  *   "lookahead"    0/1 factor panel k+1 on a second stream under the trailing update of panel k (default 1)
  *   "latency_gemm" / "latency_tiles"   4x4-wave GEMM shape for launches of <= latency_tiles tiles (small N)
  *   "dataflow"     0/1 single-launch dataflow Cholesky (one workgroup per tile, flags instead of launches)
- *                  for problems of <= "dataflow_max_nt" 128-tiles (default 64, N <= 8192) and
+ *                  for problems of <= "dataflow_max_nt" 128-tiles (default 96, N <= 12288) and
  *                  <= "dataflow_max_slots" thetas per call (default 8), with 64x64 tiles up to
- *                  "dataflow_fine_nt" 128-tiles (default 64, fp64); larger problems hand their last
+ *                  "dataflow_fine_nt" 128-tiles (default 96, fp64); larger problems hand their last
  *                  "dataflow_tail" tile columns (default 64, 0 = off) to the same kernel
  *   "panel_left"   -1 auto / 0 / 1: left-looking in-panel updates (one K = 128 s update per column instead of
  *                  K = 128 updates after every column); auto = for batches of more than "dataflow_max_slots"
