@@ -1023,15 +1023,21 @@ __global__ __launch_bounds__(64 * NWI * NWJ, (NWI * NWJ == 4) ? 2 : 4) void gemm
 // chol_dataflow: the whole bordered Cholesky of small / mid problems in ONE launch.
 //
 // The multi-kernel schedule above is bound, below N ~ 8k, by the serial chain of dependent launches
-// (potrf -> panel solve -> in-panel update, ~115 us per 128 columns).  Here every 128x128 tile (i,j),
-// i >= j, of the bordered matrix (tile row Nt = the rhs rows) is ONE workgroup that owns the tile for
+// (potrf -> panel solve -> in-panel update, ~115 us per 128 columns).  Here every TBX x TBX tile (i,j),
+// i >= j, of the bordered matrix (tile row nd = the rhs rows) is ONE workgroup that owns the tile for
 // its whole life (left-looking):
 //     acc  = K(i,j)
-//     for b < j:  wait X(i,b), X(j,b);  acc -= X(i,b) X(j,b)^T          (K = 128 slab on the MFMA)
+//     for b < j:  wait X(i,b), X(j,b);  acc -= X(i,b) X(j,b)^T          (K = TBX slab on the MFMA)
 //     i == j:     L_jj, W_j = potrf128(acc);                 publish ready(j,j)
 //     i >  j:     wait ready(j,j);  X(i,j) = acc W_j^T;      publish ready(i,j)
-// Dependencies are flags in global memory (value = epoch of this evaluation; release/acquire at
-// agent scope).  Tasks are numbered in column-major order, a topological order of the DAG, and a
+// With 64x64 tiles (fp64) the critical chain is fused: the diagonal task (j,j) also solves its own
+// sub-diagonal tile (j,j-1) -- whose owner only accumulates it, stores the pre-solve tile and raises a
+// "pre" flag kept in the unused upper slot (j-1,j) -- and applies that last slab from LDS images of
+// the freshly solved tile: one flag hop per column on the chain instead of two.
+// Dependencies are flags in global memory (value = epoch of this evaluation; write-through tile
+// stores + an agent-scope fence before the flag store, acquire after the poll).  One wave per
+// workgroup polls; a task first peeks at all its column flags in parallel and consumes the leading
+// run of finished columns without further polls.  Tasks are numbered in column-major order, a topological order of the DAG, and a
 // workgroup takes its task number from an atomic ticket when it STARTS: every dependency of a task
 // therefore belongs to a workgroup that started earlier and is resident, so the schedule cannot
 // deadlock whatever order the hardware dispatches workgroups in.  A spin limit turns any violation of
