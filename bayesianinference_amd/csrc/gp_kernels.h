@@ -1056,6 +1056,10 @@ struct DfArgs {
     int* abort_flag;
     int nd, nslots, epoch;                    // nd = diagonal blocks = Npad / TBX; tile row nd = the rhs rows
     long long* trace;                         // developer timing (scripts/micro/df_trace.hip): 8 stamps per task, or null
+    // BUILD variant only (one launch per evaluation: tiles built in-kernel, results exported by the corner task)
+    const T* xt; const T* yv;                 // unscaled inputs [d][npad], outputs [npad]
+    int n, npad, d, kt;                       // true N, padded N, input dimension, kernel family (0 SE, 1 Matern-5/2)
+    double* hres; int* hinfo;                 // pinned host: {logdet, quad} per slot; info per slot + abort flag
 };
 
 constexpr int DF_SPIN_LIMIT = 1 << 22;        // x ~1 us per poll: seconds, never reached by a live schedule
@@ -1102,8 +1106,11 @@ template <typename T, int TBX, int NST = 2> constexpr size_t df_lds_bytes() {
 // OCC = workgroups per CU the register budget is sized for: 2 (256 registers: 64-tiles, fp32 128-tiles) or
 // 1 (512 registers: fp64 128-tiles -- 128 accumulator registers plus the out-of-line potrf body do not fit
 // in 256 without spilling accumulators around every slab).
-template <typename T, int TBX, int OCC = 2, int NST = 2>
-__global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g) {
+// BUILD: the evaluation is this ONE launch -- every task builds its own tile of K(theta) from the resident
+// inputs (same arithmetic as kbuild_kernel, hyper-parameters passed by value), and the corner task, which
+// depends on everything, reduces log det / quadratic form and writes them to pinned host memory.
+template <typename T, int TBX, int OCC = 2, int NST = 2, bool BUILD = false>
+__global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g, ThetaPack tp) {
     static_assert(TBX == 128 || (TBX == 64 && sizeof(T) == 8), "64-tiles are implemented for fp64 only");
     constexpr int FI = TBX / 32, FJ = TBX / 32, WT = TBX / 2;   // MFMA tiles per wave, wave tile edge
     extern __shared__ double smem_raw[];
@@ -1140,6 +1147,9 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g) {
     int* F = g.flags + (long)slot * g.f_bstride;
     T* Wj = g.W + (long)slot * g.w_bstride + (long)j * TBX * TBX;
     T* Ct = As + (long)j * TBX * g.ld + (long)i * TBX;    // tile (i,j)
+    // per-slot scalars {sf2, sn2, mu, pivot tol, ..}: from the argument pack (BUILD) or from device memory
+    const double* sp = BUILD ? tp.v + g.nslots * g.d + slot * SLOTP : g.slotp + (long)slot * SLOTP;
+    if (BUILD && q == 0 && tid == 0) g.info[slot] = 0;     // task 0 of the slot precedes every potrf of the slot
 
     acc_t acc[FJ][FI];
     // D-layout address of this lane's accumulators inside a TBX x TBX tile with leading dimension ldc
@@ -1156,6 +1166,67 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g) {
     // Tile stores are write-through at agent scope (sc1): the release fence of publish() writes back every
     // dirty line of the XCD's L2 -- with plain stores that is the tiles of every workgroup on the XCD, again
     // and again (5 us per publish under load); with write-through stores there is nothing left to flush.
+    // K(theta) tile (i,j) straight into the accumulators: element for element the arithmetic of kbuild_kernel
+    // (inputs scaled as (T)((double)x * 1/l), squared distance accumulated over the dimensions in order,
+    // nugget on the diagonal, identity padding, rhs rows = {r^T, 0, ..})
+    auto build_tile = [&](acc_t (&A)[FJ][FI]) {
+        const int d = g.d;
+        const double* ie = tp.v + slot * d;
+        const T sf2 = (T)sp[0], sn2 = (T)sp[1], mu = (T)sp[2];
+        const long gi0 = (long)i * TBX + wi * WT + l15, gj0 = (long)j * TBX + wj * WT;
+        if (i == g.nd) {
+#pragma unroll
+            for (int x = 0; x < FJ; ++x)
+#pragma unroll
+                for (int y = 0; y < FI; ++y)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const long gj = gj0 + x * 16 + Num<T>::drow(l4, r);
+                        const bool first = (wi * WT + y * 16 + l15) == 0;
+                        A[x][y][r] = (first && j < g.nd && gj < g.n) ? g.yv[gj] - mu : (T)0;
+                    }
+            return;
+        }
+        T r2[FJ][FI][4];
+#pragma unroll
+        for (int x = 0; x < FJ; ++x)
+#pragma unroll
+            for (int y = 0; y < FI; ++y)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) r2[x][y][r] = (T)0;
+        for (int dd = 0; dd < d; ++dd) {
+            const double sc = ie[dd];
+            const T* xr = g.xt + (long)dd * g.npad;
+            T xi[FI], xj[FJ][4];
+#pragma unroll
+            for (int y = 0; y < FI; ++y) xi[y] = (T)__dmul_rn((double)xr[gi0 + y * 16], sc);   // rounded product, as k_scale stores it
+#pragma unroll
+            for (int x = 0; x < FJ; ++x)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) xj[x][r] = (T)__dmul_rn((double)xr[gj0 + x * 16 + Num<T>::drow(l4, r)], sc);
+#pragma unroll
+            for (int x = 0; x < FJ; ++x)
+#pragma unroll
+                for (int y = 0; y < FI; ++y)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const T dl = xi[y] - xj[x][r];
+                        r2[x][y][r] = __builtin_fma(dl, dl, r2[x][y][r]);
+                    }
+        }
+#pragma unroll
+        for (int x = 0; x < FJ; ++x)
+#pragma unroll
+            for (int y = 0; y < FI; ++y)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const long gi = gi0 + y * 16, gj = gj0 + x * 16 + Num<T>::drow(l4, r);
+                    T v = (g.kt == 0) ? kfun<0, T>(r2[x][y][r], sf2) : kfun<1, T>(r2[x][y][r], sf2);
+                    if (gi == gj) v += sn2;
+                    if (gj >= g.n || gi >= g.n) v = (gi == gj) ? (T)1 : (T)0;
+                    A[x][y][r] = v;
+                }
+    };
     auto store_c = [&](acc_t (&A)[FJ][FI], T* base, long ldc) {
         T* cp0 = c_ptr(base, ldc);
 #pragma unroll
@@ -1288,7 +1359,8 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g) {
     const int jacc = diagx ? j - 1 : j;                          // slabs taken from memory
 
     // ---- accumulate the updates of all earlier columns
-    if (j > 0 || i == j) load_c(acc, Ct, g.ld);
+    if constexpr (BUILD) build_tile(acc);
+    else if (j > 0 || i == j) load_c(acc, Ct, g.ld);
     // A task that starts late finds most of its columns finished already.  Polling them one by one costs a
     // dependent ~1 us flag load (and an L2 invalidate) per slab -- more than a 64-wide slab's MFMA work --
     // so wave 0 peeks at all of them in parallel ONCE, and the leading run of finished columns is taken
@@ -1339,7 +1411,7 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g) {
 
     if constexpr (FUSE) {
         if (accp) {                                         // hand the pre-solve tile (j+1,j) to the diagonal task
-            if (j > 0) store_c(acc, Ct, g.ld);
+            if (BUILD || j > 0) store_c(acc, Ct, g.ld);
             publish(j, i);                                  // "pre" flag lives in the unused upper slot (j, j+1)
             stamp(4);
             return;
@@ -1392,6 +1464,21 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g) {
     if (i == j) {
         if (j == g.nd) {                                    // corner of the border: -|z|^2 accumulates here
             store_c(acc, Ct, g.ld);
+            if constexpr (BUILD) {
+                // this task depends (transitively) on every other task of the slot: everything is final
+                if (wave == 0) {
+                    double sum = 0.0;
+                    for (int b2 = lane; b2 < g.nd; b2 += 64) sum += g.partial[(long)slot * g.p_bstride + b2];
+                    for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off);
+                    if (lane == 0) {
+                        g.hres[2 * slot + 0] = 2.0 * sum;
+                        g.hres[2 * slot + 1] = -(double)acc[0][0][0];          // lane 0 of wave 0 holds entry [0][0]
+                        g.hinfo[slot] = __hip_atomic_load(g.info + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (__hip_atomic_load(g.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
+                            g.hinfo[g.nslots] = 1;
+                    }
+                }
+            }
             return;
         }
         // accumulators -> tile-packed LDS image of the lower triangle, then factor + invert in place
@@ -1409,7 +1496,7 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g) {
         __syncthreads();
         stamp(2);
         potrf128_core_call<T, TBX / 16>(smem_raw, Ct, g.ld, Wj, g.partial + (long)slot * g.p_bstride + j, g.info + slot,
-                                        (T)g.slotp[(long)slot * SLOTP + 3]);
+                                        (T)sp[3]);
         stamp(3);
         publish(j, j);
         stamp(4);
@@ -1417,7 +1504,7 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g) {
     }
 
     // ---- panel solve X(i,j) = acc W_j^T: the pre-solve tile goes through memory to become an MFMA operand
-    if (j > 0) {
+    if (BUILD || j > 0) {
         store_c(acc, Ct, g.ld);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();

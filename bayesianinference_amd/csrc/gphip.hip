@@ -70,8 +70,10 @@ struct gphip_ctx {
     int dataflow = 1, dataflow_max_nt = 96, dataflow_max_slots = 8;   // single-launch dataflow Cholesky: latency regime only
     int dataflow_fine_nt = 96;                   // ... with 64x64 tiles up to this many 128-tiles (fp64; measured best up to N = 12288)
     int panel_left = -1;                         // in-panel updates left-looking: -1 auto (batches), 0 never, 1 always
+    int fuse_option = 1;                         // allow the single-launch evaluation (option "fused_eval")
     int grad_potri = 1;                          // gradient: K^-1 = U U^T in one go when the memory is there
     int dataflow_tail = 64;                      // large N: the last <= dataflow_tail tile columns go to the dataflow kernel (0 = off)
+    bool fused_eval = false;                     // eval_chunk: the whole evaluation is ONE dataflow launch (build + factor + results)
     bool theta_packed = false;                   // eval_chunk: hyper-parameters travel as kernel arguments (k_scale_theta)
     bool want_w = false;                         // the caller substitutes with W_b afterwards (fit / predict / gradient)
     int* dFlags = nullptr;                       // [slots][(Nt+1)^2] ready flags (value = epoch)
@@ -394,7 +396,7 @@ bool use_dataflow(const gphip_ctx* h, int nslots) {
 
 // c0 > 0 (128-tiles only): factor the trailing submatrix that starts at tile column c0 -- the tail of the
 // look-ahead schedule, already updated by every earlier panel.  No finalize here.
-template <typename T, int TBX, int OCC = 2, int NST = 2>
+template <typename T, int TBX, int OCC = 2, int NST = 2, bool BUILD = false>
 void launch_dataflow(gphip_ctx* h, int nslots, int c0 = 0) {
     const int nd = (int)(h->Npad / TBX) - c0, R = nd + 1;
     const long ld = h->ld;
@@ -411,8 +413,17 @@ void launch_dataflow(gphip_ctx* h, int nslots, int c0 = 0) {
     h->ticket_base += (unsigned long long)tasks;
     // profile class 3 (panel work): class 4 stays the trailing SYRK alone, it is what the bench's roofline reads
     ProfScope ps(h, 3, ((double)nd * TBX) * ((double)nd * TBX) * ((double)nd * TBX) / 3.0 * nslots, 0.0);
+    ThetaPack tp;
+    if constexpr (BUILD) {
+        memcpy(tp.v, h->hInvEll, (size_t)nslots * h->d * 8);
+        memcpy(tp.v + (size_t)nslots * h->d, h->hSlotp, (size_t)nslots * SLOTP * 8);
+        g.xt = (const T*)h->dXt; g.yv = (const T*)h->dY;
+        g.n = (int)h->N; g.npad = (int)h->Npad; g.d = (int)h->d; g.kt = h->kt;
+        g.hres = h->hRes; g.hinfo = h->hInfo;
+        h->hInfo[nslots] = 0;                  // the abort word: only ever SET by the kernel
+    }
     constexpr size_t lds = df_lds_bytes<T, TBX, NST>();
-    hipLaunchKernelGGL((chol_dataflow_kernel<T, TBX, OCC, NST>), dim3((unsigned)tasks), dim3(256), lds, h->stream, g);
+    hipLaunchKernelGGL((chol_dataflow_kernel<T, TBX, OCC, NST, BUILD>), dim3((unsigned)tasks), dim3(256), lds, h->stream, g, tp);
 }
 
 template <typename T>
@@ -427,6 +438,10 @@ int queue_factor_dataflow(gphip_ctx* h, int nslots) {
     h->cs = h->stream;
     if constexpr (sizeof(T) == 8) {
         if (h->Nt <= h->dataflow_fine_nt) {
+            if (h->fused_eval) {               // tiles built in-kernel, results exported by the corner task
+                launch_dataflow<T, 64, 2, 2, true>(h, nslots);
+                return 0;
+            }
             launch_dataflow<T, 64>(h, nslots);
             launch_finalize<T>(h, nslots, 2 * (int)h->Nt);
             if (h->want_w)
@@ -602,12 +617,17 @@ int eval_chunk(gphip_ctx* h, const double* Theta, int nb, double* out, double* p
         HIPCHK(hipMemcpyAsync(h->dSlotp, h->hSlotp, (size_t)nb * SLOTP * 8, hipMemcpyHostToDevice, h->stream));
         HIPCHK(hipMemsetAsync(h->dInfo, 0, (size_t)nb * 4, h->stream));
     }
+    // one theta (or a few), fp64, small enough for 64-tiles and nobody needs the scaled inputs / 128-block
+    // inverses afterwards: the evaluation is ONE launch
+    h->fused_eval = h->fuse_option && h->theta_packed && h->dtype == 64 && !h->want_w && h->profile < 2 &&
+                    use_dataflow(h, nb) && h->Nt <= h->dataflow_fine_nt;
     h->cs = h->stream;
     {
         ProfScope ps(h, 5, 0.0, 0.0);
-        DISPATCH(h, queue_build, h, nb);
+        if (!h->fused_eval) DISPATCH(h, queue_build, h, nb);
         DISPATCH(h, queue_factor, h, nb);
     }
+    h->fused_eval = false;
     h->theta_packed = false;
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipGetLastError());
@@ -662,6 +682,8 @@ int set_func_attrs(gphip_ctx* h) {
     if constexpr (sizeof(T) == 8) {
         constexpr int df64 = (int)df_lds_bytes<T, 64, 2>();
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(chol_dataflow_kernel<T, 64, 2>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, df64));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>((chol_dataflow_kernel<T, 64, 2, 2, true>)),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, df64));
     }
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trtri128_kernel<T>),
@@ -1425,6 +1447,7 @@ int gphip_set_option(gphip_handle h, const char* name, double value) {
     else if (!strcmp(name, "dataflow_fine_nt")) h->dataflow_fine_nt = v;
     else if (!strcmp(name, "dataflow_tail")) h->dataflow_tail = v;
     else if (!strcmp(name, "grad_potri")) h->grad_potri = v;
+    else if (!strcmp(name, "fused_eval")) h->fuse_option = v;
     else if (!strcmp(name, "panel_left")) h->panel_left = v;
     else if (!strcmp(name, "max_slots")) { if (v < 1) return fail(h, GPHIP_ERR_ARG, "max_slots < 1"); h->max_slots = v; }
     else return fail(h, GPHIP_ERR_ARG, "unknown option");

@@ -110,6 +110,9 @@ int gphip_logdet(gphip_handle h, double* out);
  *                  "dataflow_tail" tile columns (default 64, 0 = off) to the same kernel
  *   "panel_left"   -1 auto / 0 / 1: left-looking in-panel updates (one K = 128 s update per column instead of
  *                  K = 128 updates after every column); auto = for batches of more than "dataflow_max_slots"
+ *   "fused_eval"   0/1 (default 1): a pure likelihood call of <= 8 thetas that qualifies for 64-tile dataflow
+ *                  runs as ONE kernel launch (K(theta) tiles built inside the kernel, results written to
+ *                  pinned host memory by its last task)
  *   "grad_potri"   0/1 gradient: form K^-1 = U U^T in one go when 2 N^2 of scratch fits (default 1), else
  *                  stream it in row blocks through forward + backward substitution
  *   "max_slots"    cap on concurrently resident batch matrices */

@@ -34,7 +34,7 @@ int main(int argc, char** argv) {
         g.A = dA; g.ld = ld; g.bstride = ld * ld; g.W = dW; g.w_bstride = (long)Nt * TB * TB; g.partial = dP; g.info = dI;
         g.slotp = dS; g.flags = dF; g.f_bstride = (long)R * R; g.ticket = dT; g.ticket_base = (unsigned long long)rep * ntask;
         g.abort_flag = (int*)(dT + 1); g.nd = nd; g.nslots = 1; g.epoch = rep + 1; g.trace = dTr;
-        hipLaunchKernelGGL((chol_dataflow_kernel<double, DF_TBX, (DF_TBX == 128 ? 1 : 2), (DF_TBX == 128 ? 4 : 2)>), dim3((unsigned)ntask), dim3(256), lds, 0, g);
+        hipLaunchKernelGGL((chol_dataflow_kernel<double, DF_TBX, (DF_TBX == 128 ? 1 : 2), (DF_TBX == 128 ? 4 : 2)>), dim3((unsigned)ntask), dim3(256), lds, 0, g, ThetaPack{});
         hipDeviceSynchronize();
     }
     hipMemcpy(tr.data(), dTr, ntask * 64, hipMemcpyDeviceToHost);

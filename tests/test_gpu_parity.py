@@ -205,6 +205,35 @@ def test_dataflow_repeatability(n, d, fine, batch):
     h.close()
 
 
+@pytest.mark.parametrize("n,d,kernel,mean", [(300, 2, "se_ard", "zero"), (1000, 5, "matern52_ard", "const"),
+                                             (129, 1, "se", "zero"), (2050, 8, "se_ard", "zero")])
+def test_single_launch_evaluation_equals_four_kernel_path(n, d, kernel, mean):
+    """Pure likelihood calls run as ONE launch: every tile of K(theta) is built inside the dataflow kernel
+    (the arithmetic of kbuild_kernel; hipcc contracts a mul+add into an fma in one and not the other, so
+    entries may differ in the last bit) and the corner task exports log det / quadratic form / info.
+    Must agree with the k_scale + kbuild + dataflow + finalize sequence to rounding (1e-13), single thetas
+    and small batches, and be bit-repeatable."""
+    X, y = syn.make_dataset(n, d)
+    th = syn.default_theta(kernel, d)
+    if mean == "const":
+        th = np.append(th, 0.3)
+    Th = np.stack([th * (1.0 + 0.05 * k) for k in range(4)])
+    h = _lib.Handle(X, y, kernel, mean)
+    out = {}
+    for fused in (0, 1, 1):
+        h.set_option("fused_eval", fused)
+        out.setdefault(fused, []).append((h.loglik_parts(th), h.loglik_batch(Th)))
+    ref_parts, (ref_b, ref_i) = out[0][0]
+    for parts, (bl, bi) in out[1]:
+        assert parts[3] == ref_parts[3] == 0
+        assert all(close(parts[k], ref_parts[k], n, 1e-13) for k in range(3))
+        np.testing.assert_allclose(bl, ref_b, rtol=1e-13, atol=1e-13 * n)
+        assert np.array_equal(bi, ref_i)
+    assert out[1][0][0] == out[1][1][0] and np.array_equal(out[1][0][1][0], out[1][1][1][0])     # repeatable
+    assert close(out[1][0][0][0], orc.log_likelihood(kernel, th, X, y, mean), n)
+    h.close()
+
+
 def test_dataflow_tail_of_large_problem():
     """N above the dataflow range (Nt = 71 > 64 tiles): the look-ahead schedule hands its last tile
     columns to the dataflow kernel.  Same values as the pure multi-kernel schedule (summation order of
