@@ -3,12 +3,12 @@ import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from bayesianinference_amd import _lib, synthetic as syn
-for n in (12288, 16384, 32768):
+for n in (16384, 24576, 32768):
     X, y = syn.make_dataset(n, 8)
     th = syn.default_theta("se_ard", 8)
     h = _lib.Handle(X, y, "se_ard")
     h.loglik(th)
-    for tail in (0, 8, 16, 32, 48, 64, 0, 32):
+    for tail in (0, 32, 64, 80, 96, 64):
         h.set_option("dataflow_tail", tail)
         h.loglik(th)
         reps = 6 if n <= 16384 else 4
