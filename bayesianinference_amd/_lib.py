@@ -51,6 +51,7 @@ _SIGNATURES = {
     "gphip_solve": (C.c_int, [_h, _dp, C.c_int64, _dp]),
     "gphip_logdet": (C.c_int, [_h, _dp]),
     "gphip_set_option": (C.c_int, [_h, C.c_char_p, C.c_double]),
+    "gphip_get_option": (C.c_int, [_h, C.c_char_p, C.POINTER(C.c_double)]),
     "gphip_get_profile": (C.c_int, [_h, C.c_int, _dp, _dp, _dp, _dp]),
     "gphip_reset_profile": (C.c_int, [_h]),
     "gphip_sync": (C.c_int, [_h]),
@@ -158,6 +159,11 @@ class Handle:
 
     def set_option(self, name: str, value: float):
         self._check(self._lib.gphip_set_option(self._h, name.encode(), float(value)))
+
+    def get_option(self, name: str) -> float:
+        v = C.c_double()
+        self._check(self._lib.gphip_get_option(self._h, name.encode(), C.byref(v)))
+        return v.value
 
     # -- hot path ------------------------------------------------------------------------
     def loglik(self, theta):

@@ -17,6 +17,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -925,6 +926,8 @@ int queue_grad_potri(gphip_ctx* h) {
     return GPHIP_OK;
 }
 
+void apply_env_options(gphip_ctx* h);        // GPHIP_OPTIONS, defined next to gphip_set_option
+
 }  // namespace
 
 extern "C" {
@@ -989,6 +992,7 @@ int gphip_create(const void* X, const void* y, int64_t N, int64_t d, int kernel_
     if (DISPATCH(h, upload, h, h->dXt, xt, h->stream) != GPHIP_OK) return bail(GPHIP_ERR_HIP);
     if (DISPATCH(h, upload, h, h->dY, yp, h->stream) != GPHIP_OK) return bail(GPHIP_ERR_HIP);
     if (DISPATCH(h, set_func_attrs, h) != GPHIP_OK) return bail(GPHIP_ERR_HIP);
+    apply_env_options(h);
     *out = h;
     return GPHIP_OK;
 }
@@ -1450,27 +1454,67 @@ int gphip_dist_end(gphip_handle h, double* logdet_partial, double* quad, int* in
     return GPHIP_OK;
 }
 
+namespace {
+// one table for set / get / the GPHIP_OPTIONS environment override
+int* option_slot(gphip_ctx* h, const char* name) {
+    struct Entry { const char* name; int gphip_ctx::*field; };
+    static const Entry table[] = {
+        {"panel", &gphip_ctx::panel}, {"profile", &gphip_ctx::profile}, {"xcd_swizzle", &gphip_ctx::swizzle},
+        {"lookahead", &gphip_ctx::lookahead}, {"supertile", &gphip_ctx::supertile},
+        {"latency_gemm", &gphip_ctx::latency_gemm}, {"latency_tiles", &gphip_ctx::latency_tiles},
+        {"dataflow", &gphip_ctx::dataflow}, {"dataflow_max_nt", &gphip_ctx::dataflow_max_nt},
+        {"dataflow_max_slots", &gphip_ctx::dataflow_max_slots}, {"dataflow_fine_nt", &gphip_ctx::dataflow_fine_nt},
+        {"dataflow_tail", &gphip_ctx::dataflow_tail}, {"grad_potri", &gphip_ctx::grad_potri},
+        {"fused_eval", &gphip_ctx::fuse_option}, {"panel_left", &gphip_ctx::panel_left},
+        {"max_slots", &gphip_ctx::max_slots},
+    };
+    for (const Entry& e : table)
+        if (!strcmp(name, e.name)) return &(h->*(e.field));
+    return nullptr;
+}
+
+// GPHIP_OPTIONS="dataflow=0,panel=6": defaults for every handle of the process (hosts that cannot call
+// gphip_set_option, e.g. through the LibraryLink shim; debugging).  Unknown names / bad values are ignored.
+void apply_env_options(gphip_ctx* h) {
+    const char* env = getenv("GPHIP_OPTIONS");
+    if (!env) return;
+    std::string str(env);
+    size_t pos = 0;
+    while (pos < str.size()) {
+        size_t end = str.find(',', pos);
+        if (end == std::string::npos) end = str.size();
+        const std::string item = str.substr(pos, end - pos);
+        const size_t eq = item.find('=');
+        if (eq != std::string::npos) {
+            const std::string key = item.substr(0, eq);
+            char* stop = nullptr;
+            const double v = strtod(item.c_str() + eq + 1, &stop);
+            if (stop != item.c_str() + eq + 1) (void)gphip_set_option(h, key.c_str(), v);
+        }
+        pos = end + 1;
+    }
+    h->err.clear();
+}
+}  // namespace
+
 int gphip_set_option(gphip_handle h, const char* name, double value) {
     if (!h || !name) return GPHIP_ERR_ARG;
     std::lock_guard<std::recursive_mutex> lk(h->mu);
     const int v = (int)value;
-    if (!strcmp(name, "panel")) { if (v < 1 || v > 64) return fail(h, GPHIP_ERR_ARG, "panel out of range"); h->panel = v; }
-    else if (!strcmp(name, "profile")) h->profile = v;
-    else if (!strcmp(name, "xcd_swizzle")) h->swizzle = v;
-    else if (!strcmp(name, "lookahead")) h->lookahead = v;
-    else if (!strcmp(name, "supertile")) h->supertile = v;
-    else if (!strcmp(name, "latency_gemm")) h->latency_gemm = v;
-    else if (!strcmp(name, "latency_tiles")) h->latency_tiles = v;
-    else if (!strcmp(name, "dataflow")) h->dataflow = v;
-    else if (!strcmp(name, "dataflow_max_nt")) h->dataflow_max_nt = v;
-    else if (!strcmp(name, "dataflow_max_slots")) h->dataflow_max_slots = v;
-    else if (!strcmp(name, "dataflow_fine_nt")) h->dataflow_fine_nt = v;
-    else if (!strcmp(name, "dataflow_tail")) h->dataflow_tail = v;
-    else if (!strcmp(name, "grad_potri")) h->grad_potri = v;
-    else if (!strcmp(name, "fused_eval")) h->fuse_option = v;
-    else if (!strcmp(name, "panel_left")) h->panel_left = v;
-    else if (!strcmp(name, "max_slots")) { if (v < 1) return fail(h, GPHIP_ERR_ARG, "max_slots < 1"); h->max_slots = v; }
-    else return fail(h, GPHIP_ERR_ARG, "unknown option");
+    int* slot = option_slot(h, name);
+    if (!slot) return fail(h, GPHIP_ERR_ARG, "unknown option");
+    if (!strcmp(name, "panel") && (v < 1 || v > 64)) return fail(h, GPHIP_ERR_ARG, "panel out of range");
+    if (!strcmp(name, "max_slots") && v < 1) return fail(h, GPHIP_ERR_ARG, "max_slots < 1");
+    *slot = v;
+    return GPHIP_OK;
+}
+
+int gphip_get_option(gphip_handle h, const char* name, double* value) {
+    if (!h || !name || !value) return GPHIP_ERR_ARG;
+    std::lock_guard<std::recursive_mutex> lk(h->mu);
+    const int* slot = option_slot(h, name);
+    if (!slot) return fail(h, GPHIP_ERR_ARG, "unknown option");
+    *value = (double)*slot;
     return GPHIP_OK;
 }
 

@@ -117,6 +117,9 @@ int gphip_logdet(gphip_handle h, double* out);
  *                  stream it in row blocks through forward + backward substitution
  *   "max_slots"    cap on concurrently resident batch matrices */
 int gphip_set_option(gphip_handle h, const char* name, double value);
+int gphip_get_option(gphip_handle h, const char* name, double* value);
+/* The environment variable GPHIP_OPTIONS="name=value,name=value" presets options for every handle the process
+ * creates (for hosts that bind only the evaluation entry points, e.g. the LibraryLink shim). */
 
 /* Per-kernel-class timing, measured with HIP events on the handle's stream while "profile"=1.
  * class: 0 kbuild, 1 potrf, 2 trsm, 3 gemm (in-panel), 4 gemm/syrk (trailing), 5 total eval.

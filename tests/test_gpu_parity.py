@@ -282,6 +282,25 @@ def test_dataflow_not_spd_verdict():
     h.close()
 
 
+def test_options_roundtrip_and_environment_presets(monkeypatch):
+    X, y = syn.make_dataset(40, 2)
+    h = _lib.Handle(X, y, "se_ard")
+    assert h.get_option("dataflow") == 1 and h.get_option("panel") == 4
+    h.set_option("panel", 6)
+    assert h.get_option("panel") == 6
+    with pytest.raises(_lib.GphipError):
+        h.set_option("no_such_option", 1)
+    with pytest.raises(_lib.GphipError):
+        h.get_option("no_such_option")
+    h.close()
+    monkeypatch.setenv("GPHIP_OPTIONS", "dataflow=0, panel=8,bogus=3,fused_eval=x")     # unknown / malformed items are ignored
+    h = _lib.Handle(X, y, "se_ard")
+    assert h.get_option("dataflow") == 0 and h.get_option("panel") == 8 and h.get_option("fused_eval") == 1
+    ll, info = h.loglik(np.array([1.0, 1.0, 1.0, 0.1]))
+    assert info == 0 and close(ll, orc.log_likelihood("se_ard", [1.0, 1.0, 1.0, 0.1], X, y), 40)
+    h.close()
+
+
 def test_argument_errors():
     X, y = syn.make_dataset(10, 2)
     h = _lib.Handle(X, y, "se_ard")
