@@ -1486,7 +1486,9 @@ void apply_env_options(gphip_ctx* h) {
         const std::string item = str.substr(pos, end - pos);
         const size_t eq = item.find('=');
         if (eq != std::string::npos) {
-            const std::string key = item.substr(0, eq);
+            std::string key = item.substr(0, eq);
+            key.erase(0, key.find_first_not_of(" \t"));
+            key.erase(key.find_last_not_of(" \t") + 1);
             char* stop = nullptr;
             const double v = strtod(item.c_str() + eq + 1, &stop);
             if (stop != item.c_str() + eq + 1) (void)gphip_set_option(h, key.c_str(), v);
