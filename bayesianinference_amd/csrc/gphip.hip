@@ -389,7 +389,13 @@ int queue_panel(gphip_ctx* h, int K0, int nin, int nslots) {
 bool use_dataflow(const gphip_ctx* h, int nslots) {
     // measured: wins 1.05-2.3x for one theta up to N = 12288, ties at 8-16 slots, loses 2x at 200 slots
     // (there the multi-kernel schedule's big launches are throughput bound, not latency bound)
-    if (!h->dataflow || h->dist_world > 0 || h->Nt > h->dataflow_max_nt || nslots > h->dataflow_max_slots) return false;
+    if (!h->dataflow || h->dist_world > 0 || h->Nt > h->dataflow_max_nt) return false;
+    if (nslots > h->dataflow_max_slots) {
+        // a few more thetas of a SMALL problem still win (fp64 64-tiles): measured crossover at ~2500 tile tasks
+        // (N=512: 16 thetas +42 %, 32 +15 %, 64 -16 %; N=1024: 16 +34 %, 32 -9 %)
+        const long t64 = (long)(2 * h->Nt + 1) * (2 * h->Nt + 2) / 2 * nslots;
+        if (h->dtype != 64 || nslots > 4 * h->dataflow_max_slots || t64 > 2500 || h->Nt > h->dataflow_fine_nt) return false;
+    }
     if (h->dtype == 32 && h->Nt > 64) return false;        // fp32 has 128-tiles only: measured range ends at N = 8192
     const long tasks = (long)(2 * h->Nt + 1) * (2 * h->Nt + 2) / 2 * nslots;
     return tasks < (1l << 30);

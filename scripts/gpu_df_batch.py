@@ -4,7 +4,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
 from bayesianinference_amd import _lib, synthetic as syn
-for n, d, B, dtype in ((4096, 3, 200, 64), (1024, 3, 200, 64), (512, 1, 200, 64), (2048, 8, 16, 64), (2048, 8, 32, 64), (1024, 8, 32, 64), (4096, 8, 16, 64), (512, 1, 32, 64)):
+for n, d, B, dtype in ((256, 2, 16, 64), (256, 2, 32, 64), (256, 2, 64, 64), (512, 1, 16, 64), (512, 1, 32, 64), (512, 1, 64, 64), (1024, 3, 16, 64), (1024, 3, 32, 64), (2048, 8, 16, 64)):
     kernel = "se" if d == 1 else "se_ard"
     X, y = syn.make_dataset(n, d)
     Th = syn.theta_batch(B, kernel, d)
