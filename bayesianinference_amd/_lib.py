@@ -19,7 +19,8 @@ OK = 0
 INFO_OK, INFO_NOT_SPD, INFO_NAN = 0, 1, 2
 KERNEL_IDS = {"se": 0, "se_ard": 1, "matern52": 2, "matern52_ard": 3, "null": 4}
 MEAN_IDS = {"zero": 0, "const": 1}
-PROFILE_CLASSES = ("kbuild", "potrf", "trsm", "gemm_panel", "syrk_trailing", "eval_total")
+PROFILE_CLASSES = ("kbuild", "potrf", "trsm", "gemm_panel", "syrk_trailing", "eval_total", "predict_epilogue")
+COMM_ID_BYTES = 128
 
 _STATUS = {1: "bad argument", 2: "dimension mismatch", 3: "HIP runtime failure",
            4: "handle not fitted", 5: "no gfx950 device", 6: "unsupported"}
@@ -38,6 +39,10 @@ _h = C.c_void_p
 _SIGNATURES = {
     "gphip_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int,
                                _ip, C.c_int, C.POINTER(_h)]),
+    "gphip_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "gphip_create_rank": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int,
+                                    C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(_h)]),
+    "gphip_comm_info": (C.c_int, [_h, _ip, _ip, C.POINTER(C.c_char_p)]),
     "gphip_destroy": (C.c_int, [_h]),
     "gphip_num_params": (C.c_int, [_h, _ip]),
     "gphip_loglik": (C.c_int, [_h, _dp, C.c_int, _dp, _ip]),
@@ -48,6 +53,7 @@ _SIGNATURES = {
     "gphip_predict": (C.c_int, [_h, C.c_void_p, C.c_int64, _dp, _dp]),
     "gphip_predict_samples": (C.c_int, [_h, _dp, C.c_int, C.c_int, C.c_void_p, C.c_int64, _dp, _dp, _ip]),
     "gphip_covariance": (C.c_int, [_h, _dp, C.c_int, _dp]),
+    "gphip_cross_covariance": (C.c_int, [_h, _dp, C.c_int, C.c_void_p, C.c_int64, _dp, _dp]),
     "gphip_solve": (C.c_int, [_h, _dp, C.c_int64, _dp]),
     "gphip_logdet": (C.c_int, [_h, _dp]),
     "gphip_set_option": (C.c_int, [_h, C.c_char_p, C.c_double]),
@@ -109,6 +115,15 @@ def device_count() -> int:
     return n.value
 
 
+def comm_unique_id() -> bytes:
+    """RCCL unique id (rank 0 creates it, the host distributes it to every rank: gphip_create_rank)."""
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    rc = load().gphip_comm_unique_id(buf)
+    if rc != OK:
+        raise GphipError(rc, "gphip_comm_unique_id: no RCCL could be bound (set GPHIP_RCCL_PATH)")
+    return buf.raw
+
+
 def _d(a: np.ndarray):
     return a.ctypes.data_as(_dp)
 
@@ -116,7 +131,11 @@ def _d(a: np.ndarray):
 class Handle:
     """Owns one gphip_handle: training data resident on the device (gphip_create .. gphip_destroy)."""
 
-    def __init__(self, X, y, kernel: str = "se_ard", mean: str = "zero", dtype: int = 64, device=None):
+    def __init__(self, X, y, kernel: str = "se_ard", mean: str = "zero", dtype: int = 64, device=None,
+                 rank=None, world=None, comm_id: bytes | None = None):
+        """device: None (current device), one ordinal, or a LIST of ordinals = one multi-device handle in this
+        process (a repeated ordinal = virtual ranks sharing a GPU).  rank/world/comm_id: this process is one
+        rank of a multi-process job (gphip_create_rank; comm_id from comm_unique_id() of rank 0)."""
         lib = load()
         X = np.ascontiguousarray(np.atleast_2d(np.asarray(X, dtype=np.float64)))
         y = np.ascontiguousarray(np.asarray(y, dtype=np.float64).ravel())
@@ -130,10 +149,17 @@ class Handle:
         self._h = _h()
         devs, nd = (None, 0)
         if device is not None:
-            arr = (C.c_int * 1)(int(device))
-            devs, nd = arr, 1
-        rc = lib.gphip_create(X.ctypes.data, y.ctypes.data, self.N, self.d, KERNEL_IDS[kernel],
-                              MEAN_IDS[mean], dtype, devs, nd, C.byref(self._h))
+            lst = [int(v) for v in device] if isinstance(device, (list, tuple)) else [int(device)]
+            devs, nd = (C.c_int * len(lst))(*lst), len(lst)
+        if comm_id is not None:
+            if rank is None or world is None or len(comm_id) != COMM_ID_BYTES:
+                raise GphipError(1, "rank, world and a 128-byte comm_id go together")
+            rc = lib.gphip_create_rank(X.ctypes.data, y.ctypes.data, self.N, self.d, KERNEL_IDS[kernel], MEAN_IDS[mean],
+                                       dtype, -1 if device is None else int(devs[0]), int(rank), int(world),
+                                       C.c_char_p(comm_id), C.byref(self._h))
+        else:
+            rc = lib.gphip_create(X.ctypes.data, y.ctypes.data, self.N, self.d, KERNEL_IDS[kernel],
+                                  MEAN_IDS[mean], dtype, devs, nd, C.byref(self._h))
         if rc != OK:
             self._h = None
             raise GphipError(rc, "gphip_create failed (is a gfx950 GPU visible?)")
@@ -229,6 +255,22 @@ class Handle:
         K = np.zeros((self.N, self.N))
         self._check(self._lib.gphip_covariance(self._h, _d(th), th.size, _d(K)))
         return K
+
+    def cross_covariance(self, theta, Xs):
+        """compiledKandKappa (BGP:91-124): (k[N, M], kappa[M])."""
+        th = np.ascontiguousarray(np.asarray(theta, dtype=np.float64).ravel())
+        Xs = np.ascontiguousarray(np.atleast_2d(np.asarray(Xs, dtype=np.float64)))
+        if Xs.shape[1] != self.d:
+            raise GphipError(2, "test points have the wrong dimension")
+        M = Xs.shape[0]
+        k, kappa = np.zeros((self.N, M)), np.zeros(M)
+        self._check(self._lib.gphip_cross_covariance(self._h, _d(th), th.size, Xs.ctypes.data, M, _d(k), _d(kappa)))
+        return k, kappa
+
+    def comm_info(self) -> dict:
+        w, nl, name = C.c_int(0), C.c_int(0), C.c_char_p()
+        self._check(self._lib.gphip_comm_info(self._h, C.byref(w), C.byref(nl), C.byref(name)))
+        return {"world": w.value, "local": nl.value, "comm": (name.value or b"").decode()}
 
     def solve(self, rhs):
         rhs = np.asarray(rhs, dtype=np.float64)

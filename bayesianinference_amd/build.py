@@ -12,8 +12,8 @@ import sys
 
 PKG = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(PKG, "csrc", "gphip.hip")
-DEPS = [SRC, os.path.join(PKG, "csrc", "gp_kernels.h"),
-        os.path.join(os.path.dirname(PKG), "include", "gphip.h")]
+DEPS = [SRC, os.path.join(PKG, "csrc", "gp_kernels.h"), os.path.join(PKG, "csrc", "gphip_multi.inc"),
+        os.path.join(PKG, "csrc", "rccl_dyn.h"), os.path.join(os.path.dirname(PKG), "include", "gphip.h")]
 LIB = os.path.join(PKG, "lib", "libgphip.so")
 
 
@@ -36,7 +36,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         return LIB
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
     cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-Wall", "-Wno-unused-function", "-o", LIB, SRC]
+           "-Wall", "-Wno-unused-function", "-o", LIB, SRC, "-ldl", "-lpthread"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     res = subprocess.run(cmd, capture_output=True, text=True)

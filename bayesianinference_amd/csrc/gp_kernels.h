@@ -8,7 +8,7 @@
 //   gemm_nt        K2b/K2c on MFMA: mode 1 = panel solve X <- X W^T (also carries r -> z = L^-1 r,
 //                  K4), mode 0 = C -= A B^T SYRK/GEMM trailing update
 //   finalize       log det = 2 sum log L_ii, quad = |z|^2, info
-//   predict_reduce K9/K10 epilogue: mu* and var* from V = k*^T L^-T and z
+//   predict_partial / predict_finish   K9/K10 epilogue: mu* and var* from V = k*^T L^-T and z (V streamed once)
 //
 // Every kernel is templated on the arithmetic type T: double (v_mfma_f64_16x16x4_f64, the headline
 // path) or float (v_mfma_f32_16x16x4_f32, BASELINE.json config 5).  The two MFMA forms share the A/B
@@ -1550,25 +1550,73 @@ __global__ void finalize_kernel(const T* __restrict__ Abase, long ld, long bstri
     }
 }
 
-// V: column-major [mpad x npad] (ld = mpad) per slot, V(t, j) = (L^-1 k*_t)_j.  z: row npad of the
-// slot's factor.  mean[t] = mu + sum_j V(t,j) z_j ; var[t] = kappa - sum_j V(t,j)^2, with mu and
-// kappa = sf^2 + sn^2 of the slot's theta (fp64 accumulation).  grid.y = slot.
+// Prediction epilogue (K9/K10 of SURVEY.md §2.1; BGP:407-417).  V: column-major [mpad x npad] (ld = mpad)
+// per slot, V(t, j) = (L^-1 k*_t)_j;  z = L^-1 r sits in row npad of the slot's factor (stride ldz).
+//     mean[t] = mu + sum_j V(t,j) z_j ;   var[t] = kappa - sum_j V(t,j)^2      (fp64 accumulation)
+// HBM bound: V is streamed exactly once (mpad * npad elements).  Stage 1: one workgroup per
+// 128 test points x strip of `js` columns -- the strip's z values are staged once in LDS, wave w takes
+// columns w, w+4, .. of the strip, a lane loads 2 adjacent test points per column (fp64: one 16-byte
+// dwordx4, a wave covers a full 1 KiB column segment), four columns in flight per wave; the four waves'
+// partial sums meet in LDS in a fixed order.  Stage 2 adds the strips in order (deterministic: no atomics).
+// grid = (mpad/128, nstrips, nslots); part: [slot][strip][2][mpad].
 template <typename T>
-__global__ void predict_reduce_kernel(const T* __restrict__ V, long ldv, long v_bstride, int n,
-                                      const T* __restrict__ zrow, long ldz, long z_bstride,
-                                      const double* __restrict__ slotp, int m, long out_bstride,
-                                      double* __restrict__ mean, double* __restrict__ var) {
+__global__ __launch_bounds__(256) void predict_partial_kernel(const T* __restrict__ V, long ldv, long v_bstride, int ncols,
+                                                              const T* __restrict__ zrow, long ldz, long z_bstride,
+                                                              int js, double* __restrict__ part, int nstrips) {
+    extern __shared__ double pr_lds[];            // z strip [js] + reduction scratch [4][2][128]
+    typedef typename Num<T>::pair_t pair_t;
+    double* zs = pr_lds;
+    double* red = pr_lds + js;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tb = blockIdx.x, strip = blockIdx.y, slot = blockIdx.z;
+    const int j0 = strip * js;
+    const int jn = (ncols - j0 < js) ? (ncols - j0) : js;       // columns of this strip (<= 0: nothing to add)
+    V += (long)slot * v_bstride + (long)tb * TB + 2 * lane;
+    zrow += (long)slot * z_bstride;
+    for (int j = tid; j < jn; j += 256) zs[j] = (double)zrow[(long)(j0 + j) * ldz];
+    __syncthreads();
+    double d0 = 0.0, d1 = 0.0, n0 = 0.0, n1 = 0.0;
+    int j = wave;
+    for (; j + 12 < jn; j += 16) {                // four independent 16-byte loads in flight per lane
+        pair_t v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const pair_t*>(V + (long)(j0 + j + 4 * u) * ldv);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const double z = zs[j + 4 * u], a = (double)v[u].x, b = (double)v[u].y;
+            d0 = __builtin_fma(a, z, d0); d1 = __builtin_fma(b, z, d1);
+            n0 = __builtin_fma(a, a, n0); n1 = __builtin_fma(b, b, n1);
+        }
+    }
+    for (; j < jn; j += 4) {
+        const pair_t v = *reinterpret_cast<const pair_t*>(V + (long)(j0 + j) * ldv);
+        const double z = zs[j], a = (double)v.x, b = (double)v.y;
+        d0 = __builtin_fma(a, z, d0); d1 = __builtin_fma(b, z, d1);
+        n0 = __builtin_fma(a, a, n0); n1 = __builtin_fma(b, b, n1);
+    }
+    red[(wave * 2 + 0) * TB + 2 * lane] = d0; red[(wave * 2 + 0) * TB + 2 * lane + 1] = d1;
+    red[(wave * 2 + 1) * TB + 2 * lane] = n0; red[(wave * 2 + 1) * TB + 2 * lane + 1] = n1;
+    __syncthreads();
+    {
+        const int which = tid >> 7, t = tid & 127;            // threads 0-127: dot, 128-255: norm
+        double s = 0.0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) s += red[(w * 2 + which) * TB + t];
+        part[(((long)slot * nstrips + strip) * 2 + which) * ldv + (long)tb * TB + t] = s;
+    }
+}
+
+// Stage 2: mean / var per test point from the strip partials, mu and kappa = sf^2 + sn^2 of the slot's theta.
+__global__ void predict_finish_kernel(const double* __restrict__ part, int nstrips, long mpad, const double* __restrict__ slotp,
+                                      int m, long out_bstride, double* __restrict__ mean, double* __restrict__ var) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int slot = blockIdx.y;
     if (t >= m) return;
-    V += (long)slot * v_bstride;
-    zrow += (long)slot * z_bstride;
     const double* sp = slotp + (long)slot * SLOTP;
     double dot = 0.0, nrm = 0.0;
-    for (int j = 0; j < n; ++j) {
-        const double v = (double)V[(long)j * ldv + t];
-        dot = __builtin_fma(v, (double)zrow[(long)j * ldz], dot);
-        nrm = __builtin_fma(v, v, nrm);
+    for (int s = 0; s < nstrips; ++s) {
+        dot += part[(((long)slot * nstrips + s) * 2 + 0) * mpad + t];
+        nrm += part[(((long)slot * nstrips + s) * 2 + 1) * mpad + t];
     }
     mean[(long)slot * out_bstride + t] = sp[2] + dot;
     var[(long)slot * out_bstride + t] = sp[0] + sp[1] - nrm;

@@ -13,6 +13,7 @@
 // Work is queued on two handle-owned HIP streams (main + panel/look-ahead); X, y stay resident.
 // Device arithmetic is fp64 (dtype 64) or fp32 (dtype 32); the ABI is fp64 either way.
 #include "gp_kernels.h"
+#include "rccl_dyn.h"
 
 #include <algorithm>
 #include <cmath>
@@ -88,6 +89,8 @@ struct gphip_ctx {
     // prediction / solve scratch
     void *dV = nullptr, *dXsT = nullptr, *dXsS = nullptr;   // typed
     double *dMean = nullptr, *dVar = nullptr;
+    double* dPart = nullptr;                                 // strip partials of the prediction epilogue
+    size_t part_cap = 0;
     int64_t vcap = 0;
     void* dAlpha = nullptr;                                  // typed [Npad] (gradient)
     void* dKinv = nullptr;                                   // typed [Npad x Npad] lower tiles of K^-1 (gradient, potri route)
@@ -98,6 +101,16 @@ struct gphip_ctx {
     double acc_ms[GPHIP_NCLASS] = {0}, acc_n[GPHIP_NCLASS] = {0}, acc_flops[GPHIP_NCLASS] = {0},
            acc_bytes[GPHIP_NCLASS] = {0};
     std::string err;
+    // multi-device ("group") handle: see gphip_multi.inc.  Only the public handle owns a group; its peers are plain
+    // contexts (one per further rank living in this process).
+    struct gphip_group* group = nullptr;
+    int shard_min_n = 16384;                     // one factorisation is sharded over the group's devices from this N on
+    hipStream_t cstream = nullptr;               // communication stream (panel broadcasts), group members only
+    void* packed[3] = {nullptr, nullptr, nullptr};   // rotating packed-panel buffers, group members only
+    size_t packed_bytes = 0;
+    double* dScal = nullptr;                     // 4 doubles for the scalar all-reduce (multi-process groups)
+    bool in_group_call = false;                  // set on a member while the group handle runs a sharded call on it
+    bool null_fit = false;                       // fitted state of a null-kernel handle (no factor: K = diag(sn^2))
 };
 
 namespace {
@@ -676,7 +689,7 @@ int eval_chunk(gphip_ctx* h, const double* Theta, int nb, double* out, double* p
     return GPHIP_OK;
 }
 
-int eval_batch(gphip_ctx* h, const double* Theta, int B, int p, double* out, double* parts, int* info) {
+int eval_batch_local(gphip_ctx* h, const double* Theta, int B, int p, double* out, double* parts, int* info) {
     if (!h || !Theta || !out || !info) return fail(h, GPHIP_ERR_ARG, "null argument");
     if (p != h->p) return fail(h, GPHIP_ERR_DIM, "theta has the wrong length for this kernel/mean");
     if (B <= 0) return GPHIP_OK;
@@ -821,6 +834,17 @@ int queue_backward_rows(gphip_ctx* h, int64_t mpad) {
     return 0;
 }
 
+// slot 0's scaled training inputs xs = x / l (what queue_build leaves behind), without building K
+template <typename T>
+int queue_scale_train(gphip_ctx* h) {
+    const long tot = (long)h->d * h->Npad;
+    int gx = (int)((tot + 255) / 256);
+    if (gx > 1024) gx = 1024;
+    hipLaunchKernelGGL(k_scale<T>, dim3(gx, 1), dim3(256), 0, h->cs, (const T*)h->dXt, (T*)h->dXs, h->dInvEll, (int)h->d,
+                       (int)h->Npad);
+    return 0;
+}
+
 // V(t, j) = k_theta_s(x*_t, x_j) for every slot s: the (unscaled) test points in dXsT are scaled by
 // each slot's 1/l into dXsS[slot]
 template <typename T>
@@ -837,11 +861,34 @@ int queue_cross(gphip_ctx* h, int64_t mc, int64_t mpad, int nslots) {
     return 0;
 }
 
+// mu*, var* from V and z: V streamed once (HBM bound) -- strips of columns x 128 test points per workgroup,
+// then the strips are added in order.  Profile class 6: bytes = V once.
 template <typename T>
 int queue_predict_reduce(gphip_ctx* h, int64_t mc, int64_t mpad, int nslots) {
-    hipLaunchKernelGGL(predict_reduce_kernel<T>, dim3((unsigned)((mc + 63) / 64), nslots), dim3(64), 0, h->stream,
-                       (const T*)h->dV, (long)mpad, (long)mpad * h->Npad, (int)h->N, (const T*)h->dA + h->Npad,
-                       (long)h->ld, (long)h->ld * h->ld, h->dSlotp, (int)mc, (long)mpad, h->dMean, h->dVar);
+    const int Mt = (int)(mpad / TB), Nt = (int)h->Nt;
+    int nstrips = (2048 + Mt * nslots - 1) / (Mt * nslots);          // enough workgroups to fill 256 CUs several times
+    if (nstrips > Nt) nstrips = Nt;
+    if (nstrips > 64) nstrips = 64;
+    if (nstrips < 1) nstrips = 1;
+    int js = (Nt + nstrips - 1) / nstrips * TB;
+    if (js > 4096) js = 4096;
+    nstrips = (int)((h->Npad + js - 1) / js);
+    const size_t need = (size_t)nslots * nstrips * 2 * mpad * 8;
+    if (need > h->part_cap) {
+        (void)hipFree(h->dPart);
+        h->dPart = nullptr; h->part_cap = 0;
+        HIPCHK(hipMalloc(&h->dPart, need));
+        h->part_cap = need;
+    }
+    {
+        ProfScope ps(h, 6, 4.0 * (double)mpad * h->Npad * nslots, (double)sizeof(T) * mpad * h->Npad * nslots);
+        hipLaunchKernelGGL(predict_partial_kernel<T>, dim3((unsigned)Mt, (unsigned)nstrips, (unsigned)nslots), dim3(256),
+                           (size_t)js * 8 + 8 * TB * 8, h->stream, (const T*)h->dV, (long)mpad, (long)mpad * h->Npad, (int)h->N,
+                           (const T*)h->dA + h->Npad, (long)h->ld, (long)h->ld * h->ld, js, h->dPart, nstrips);
+        hipLaunchKernelGGL(predict_finish_kernel, dim3((unsigned)((mc + 255) / 256), (unsigned)nslots), dim3(256), 0, h->stream,
+                           (const double*)h->dPart, nstrips, (long)mpad, (const double*)h->dSlotp, (int)mc, (long)mpad,
+                           h->dMean, h->dVar);
+    }
     return 0;
 }
 
@@ -936,6 +983,23 @@ void apply_env_options(gphip_ctx* h);        // GPHIP_OPTIONS, defined next to g
 
 }  // namespace
 
+static int create_ctx(const void* X, const void* y, int64_t N, int64_t d, int kernel_id, int mean_id, int dtype, int device,
+                      gphip_handle* out);
+#include "gphip_multi.inc"
+
+namespace {
+// every likelihood-type entry point lands here: a plain handle evaluates locally; a group handle shards ONE
+// factorisation over its ranks (N >= shard_min_n) or deals a batch of thetas to its local devices
+int eval_batch(gphip_ctx* h, const double* Theta, int B, int p, double* out, double* parts, int* info) {
+    if (h && h->group && Theta && out && info && B >= 1 && h->kernel_id != GPHIP_KERNEL_NULL) {
+        if (p != h->p) return fail(h, GPHIP_ERR_DIM, "theta has the wrong length for this kernel/mean");
+        if (B == 1 && group_shards(h)) return group_eval(h, Theta, p, h->want_w, out, parts, info);
+        if (B > 1 && !h->want_w) return group_eval_batch(h, Theta, B, p, out, parts, info);
+    }
+    return eval_batch_local(h, Theta, B, p, out, parts, info);
+}
+}  // namespace
+
 extern "C" {
 
 const char* gphip_version(void) { return "gphip 0.2.0 (gfx950; fp64 + fp32)"; }
@@ -950,8 +1014,9 @@ int gphip_device_count(int* n) {
 
 const char* gphip_last_error(gphip_handle h) { return h ? h->err.c_str() : "null handle"; }
 
-int gphip_create(const void* X, const void* y, int64_t N, int64_t d, int kernel_id, int mean_id,
-                 int dtype, const int* devices, int ndev, gphip_handle* out) {
+// one plain context on one device: data upload, streams, kernel attributes
+static int create_ctx(const void* X, const void* y, int64_t N, int64_t d, int kernel_id, int mean_id, int dtype,
+                      int device /* < 0: current */, gphip_handle* out) {
     if (!out) return GPHIP_ERR_ARG;
     *out = nullptr;
     if (!X || !y) return GPHIP_ERR_ARG;
@@ -963,7 +1028,7 @@ int gphip_create(const void* X, const void* y, int64_t N, int64_t d, int kernel_
     int ndevs = 0;
     if (hipGetDeviceCount(&ndevs) != hipSuccess || ndevs < 1) return GPHIP_ERR_NODEVICE;
     gphip_ctx* h = new gphip_ctx;
-    if (devices && ndev > 0) h->device = devices[0];
+    if (device >= 0) h->device = device;
     else (void)hipGetDevice(&h->device);
     if (h->device < 0 || h->device >= ndevs) { delete h; return GPHIP_ERR_NODEVICE; }
     h->dtype = dtype;
@@ -1003,16 +1068,56 @@ int gphip_create(const void* X, const void* y, int64_t N, int64_t d, int kernel_
     return GPHIP_OK;
 }
 
+// devices/ndev: NULL/0 = the current device; one ordinal = that device; several = a multi-device handle
+// (one context per listed device; a repeated ordinal gives several virtual ranks on
+// one GPU -- how the sharded schedule is exercised on a single-GPU box).
+int gphip_create(const void* X, const void* y, int64_t N, int64_t d, int kernel_id, int mean_id,
+                 int dtype, const int* devices, int ndev, gphip_handle* out) {
+    if (!out) return GPHIP_ERR_ARG;
+    *out = nullptr;
+    if (ndev < 0 || (ndev > 0 && !devices)) return GPHIP_ERR_ARG;
+    if (ndev <= 1) return create_ctx(X, y, N, d, kernel_id, mean_id, dtype, ndev == 1 ? devices[0] : -1, out);
+    if (kernel_id == GPHIP_KERNEL_NULL) return GPHIP_ERR_UNSUPPORTED;   // nothing to shard: K is diagonal
+    std::vector<int> ranks(ndev);
+    for (int i = 0; i < ndev; ++i) ranks[i] = i;
+    return group_create(X, y, N, d, kernel_id, mean_id, dtype, devices, ranks.data(), ndev, ndev, nullptr, out);
+}
+
+int gphip_comm_unique_id(void* id128) {
+    if (!id128) return GPHIP_ERR_ARG;
+    const RcclApi& api = rccl();
+    if (!api.ok()) return GPHIP_ERR_UNSUPPORTED;
+    NcclUniqueId id;
+    if (api.GetUniqueId(&id) != 0) return GPHIP_ERR_HIP;
+    memcpy(id128, id.internal, GPHIP_COMM_ID_BYTES);
+    return GPHIP_OK;
+}
+
+int gphip_create_rank(const void* X, const void* y, int64_t N, int64_t d, int kernel_id, int mean_id, int dtype,
+                      int device, int rank, int world, const void* id128, gphip_handle* out) {
+    if (!out) return GPHIP_ERR_ARG;
+    *out = nullptr;
+    if (world < 1 || rank < 0 || rank >= world || !id128) return GPHIP_ERR_ARG;
+    if (kernel_id == GPHIP_KERNEL_NULL) return GPHIP_ERR_UNSUPPORTED;
+    return group_create(X, y, N, d, kernel_id, mean_id, dtype, &device, &rank, 1, world, id128, out);
+}
+
 int gphip_destroy(gphip_handle h) {
     if (!h) return GPHIP_OK;
     (void)hipSetDevice(h->device);
+    if (h->cstream) (void)hipStreamSynchronize(h->cstream);
     if (h->pstream) (void)hipStreamSynchronize(h->pstream);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    group_destroy(h);                          // communicators + the other members of a multi-device handle
+    (void)hipSetDevice(h->device);
+    for (void* pk : h->packed) (void)hipFree(pk);
+    (void)hipFree(h->dScal);
+    if (h->cstream) (void)hipStreamDestroy(h->cstream);
     free_slots(h);
     (void)hipFree(h->dXt); (void)hipFree(h->dY);
     (void)hipFree(h->dV); (void)hipFree(h->dXsT); (void)hipFree(h->dXsS); (void)hipFree(h->dMean);
     (void)hipFree(h->dVar); (void)hipFree(h->dAlpha); (void)hipFree(h->dGacc); (void)hipFree(h->dKinv);
-    (void)hipFree(h->dNullMu); (void)hipFree(h->dNullOut);
+    (void)hipFree(h->dNullMu); (void)hipFree(h->dNullOut); (void)hipFree(h->dPart);
     for (auto e : h->pool) (void)hipEventDestroy(e);
     for (auto e : h->sync_events) (void)hipEventDestroy(e);
     if (h->own_streams) {
@@ -1053,8 +1158,9 @@ int gphip_loglik_grad(gphip_handle h, const double* theta, int p, double* out, d
         return null_kernel_batch(h, theta, 1, out, nullptr, info, grad);
     }
     std::lock_guard<std::recursive_mutex> lk(h->mu);
+    double parts[2] = {0, 0};
     h->want_w = true;
-    int rc = eval_batch(h, theta, 1, p, out, nullptr, info);
+    int rc = eval_batch(h, theta, 1, p, out, parts, info);
     h->want_w = false;
     if (rc) return rc;
     for (int i = 0; i < p; ++i) grad[i] = std::nan("");
@@ -1134,7 +1240,7 @@ int gphip_loglik_grad(gphip_handle h, const double* theta, int p, double* out, d
     }
     h->fitted = true;                                         // the factor of theta is still resident
     h->theta_fit.assign(theta, theta + p);
-    h->logdet_fit = h->hRes[0];
+    h->logdet_fit = parts[0];
     h->mu_fit = h->hSlotp[2];
     h->kappa_fit = h->hSlotp[0] + h->hSlotp[1];
     return GPHIP_OK;
@@ -1142,9 +1248,23 @@ int gphip_loglik_grad(gphip_handle h, const double* theta, int p, double* out, d
 
 int gphip_fit(gphip_handle h, const double* theta, int p, int* info) {
     if (!h || !theta || !info) return fail(h, GPHIP_ERR_ARG, "null argument");
-    if (h->kernel_id == GPHIP_KERNEL_NULL) return fail(h, GPHIP_ERR_UNSUPPORTED, "fit: null kernel has no factor");
     double out, parts[2];
     std::lock_guard<std::recursive_mutex> lk(h->mu);
+    if (h->kernel_id == GPHIP_KERNEL_NULL) {
+        // null kernel Function[0] (BGP:25-27, 63-89, 156-159): K = diag(sn^2) -- nothing to factor.  "Inverse" is a
+        // division by the diagonal, LogDet = N log sn^2, and prediction has k = 0 (empty sparse array, BGP:72-74)
+        // and kappa = nugget only (BGP:75-80): mu* = m(x*), var* = sn^2.
+        if (p != h->p) return fail(h, GPHIP_ERR_DIM, "theta has the wrong length for this kernel/mean");
+        const double sn = theta[0], mu = (h->mean_id == GPHIP_MEAN_CONST) ? theta[1] : 0.0;
+        const bool finite = std::isfinite(sn) && std::isfinite(mu);
+        *info = !finite ? GPHIP_INFO_NAN : (sn * sn > 0.0 && std::isfinite(std::log(sn * sn)) ? GPHIP_INFO_OK : GPHIP_INFO_NOT_SPD);
+        h->fitted = h->null_fit = (*info == 0);
+        h->theta_fit.assign(theta, theta + p);
+        h->logdet_fit = (double)h->N * std::log(sn * sn);
+        h->mu_fit = mu;
+        h->kappa_fit = sn * sn;
+        return GPHIP_OK;
+    }
     h->want_w = true;                          // the substitutions that follow a fit use the 128-block inverses
     int rc = eval_batch(h, theta, 1, p, &out, parts, info);
     h->want_w = false;
@@ -1193,11 +1313,94 @@ int gphip_covariance(gphip_handle h, const double* theta, int p, double* K) {
     return GPHIP_OK;
 }
 
+// compiledKandKappa (BGP:91-124; null kernel BGP:63-89): k = Table[kernel[i, j], {i, points1}, {j, points2}]
+// (row-major N x M: rows = training points, columns = test points) and kappa_j = kernel[x*_j, x*_j] +
+// nugget[x*_j].  Needs no fit; leaves the handle un-fitted (the scaled inputs of slot 0 are overwritten).
+int gphip_cross_covariance(gphip_handle h, const double* theta, int p, const void* Xs, int64_t M, double* k, double* kappa) {
+    if (!h || !theta || !Xs || !k || !kappa) return fail(h, GPHIP_ERR_ARG, "null argument");
+    if (p != h->p) return fail(h, GPHIP_ERR_DIM, "theta has the wrong length");
+    if (M < 1) return fail(h, GPHIP_ERR_DIM, "M < 1");
+    std::lock_guard<std::recursive_mutex> lk(h->mu);
+    const int64_t N = h->N, d = h->d;
+    if (h->kernel_id == GPHIP_KERNEL_NULL) {   // k = SparseArray[{}, {N, M}], kappa = nugget (BGP:72-80)
+        for (int64_t i = 0; i < N * M; ++i) k[i] = 0.0;
+        for (int64_t t = 0; t < M; ++t) kappa[t] = theta[0] * theta[0];
+        return GPHIP_OK;
+    }
+    HIPCHK(hipSetDevice(h->device));
+    int rc = ensure_slots(h, 1);
+    if (rc) return rc;
+    h->fitted = false;
+    if (!stage_theta(h, 0, theta)) return fail(h, GPHIP_ERR_ARG, "non-finite or zero hyper-parameter");
+    HIPCHK(hipMemcpyAsync(h->dInvEll, h->hInvEll, (size_t)d * 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->dSlotp, h->hSlotp, SLOTP * 8, hipMemcpyHostToDevice, h->stream));
+    h->cs = h->stream;
+    DISPATCH(h, queue_scale_train, h);
+    const double* X = static_cast<const double*>(Xs);
+    const int64_t MC = 2048;
+    rc = ensure_vbuf(h, M < MC ? (M + TB - 1) / TB * TB : MC);
+    if (rc) return rc;
+    std::vector<double> xt, v;
+    for (int64_t m0 = 0; m0 < M; m0 += MC) {
+        const int64_t mc = (M - m0 < MC) ? (M - m0) : MC;
+        const int64_t mpad = (mc + TB - 1) / TB * TB;
+        xt.assign((size_t)d * mpad, 0.0);
+        for (int64_t i = 0; i < mc; ++i)
+            for (int64_t j = 0; j < d; ++j) xt[(size_t)j * mpad + i] = X[(m0 + i) * d + j];
+        rc = DISPATCH(h, upload, h, h->dXsT, xt, h->stream);
+        if (rc) return rc;
+        DISPATCH(h, queue_cross, h, mc, mpad, 1);
+        rc = DISPATCH(h, download, h, v, h->dV, (size_t)mpad * (size_t)N, h->stream);   // V(t, j) at j*mpad + t
+        if (rc) return rc;
+        HIPCHK(hipGetLastError());
+        harvest(h);
+        for (int64_t j = 0; j < N; ++j)
+            for (int64_t t = 0; t < mc; ++t) k[j * M + m0 + t] = v[(size_t)j * mpad + t];
+    }
+    for (int64_t t = 0; t < M; ++t) kappa[t] = h->hSlotp[0] + h->hSlotp[1];
+    return GPHIP_OK;
+}
+
+// world = ranks of the job this handle belongs to (1 for a plain handle), nlocal = ranks in this process,
+// *comm = "none" / "device copies" / "rccl (..)" (owned by the library)
+int gphip_comm_info(gphip_handle h, int* world, int* nlocal, const char** comm) {
+    if (!h) return GPHIP_ERR_ARG;
+    if (world) *world = h->group ? h->group->world : 1;
+    if (nlocal) *nlocal = h->group ? (int)h->group->members.size() : 1;
+    if (comm) *comm = h->group ? h->group->comm_name.c_str() : "none";
+    return GPHIP_OK;
+}
+
+static int predict_local(gphip_handle h, const void* Xs, int64_t M, double* mean, double* var);
+
 int gphip_predict(gphip_handle h, const void* Xs, int64_t M, double* mean, double* var) {
     if (!h || !Xs || !mean || !var) return fail(h, GPHIP_ERR_ARG, "null argument");
     if (M < 1) return fail(h, GPHIP_ERR_DIM, "M < 1");
     std::lock_guard<std::recursive_mutex> lk(h->mu);
     if (!h->fitted) return fail(h, GPHIP_ERR_STATE, "gphip_predict before a successful gphip_fit");
+    if (h->null_fit) {                         // null kernel (BGP:63-89): k = 0, kappa = nugget
+        for (int64_t t = 0; t < M; ++t) { mean[t] = h->mu_fit; var[t] = h->kappa_fit; }
+        return GPHIP_OK;
+    }
+    // multi-device handle whose members all hold the factor (sharded fit): test points shard, no collective
+    if (h->group && h->group->members.size() > 1 && M >= 2 * TB * (int64_t)h->group->members.size()) {
+        gphip_group* g = h->group;
+        bool all = true;
+        for (gphip_ctx* m : g->members) all = all && m->fitted && m->theta_fit == h->theta_fit;
+        if (all) {
+            const int64_t nl = (int64_t)g->members.size(), d = h->d;
+            const double* X = static_cast<const double*>(Xs);
+            return group_parallel(h, [&](int i) {
+                const int64_t m0 = M * i / nl, m1 = M * (i + 1) / nl;
+                return predict_local(g->members[(size_t)i], X + m0 * d, m1 - m0, mean + m0, var + m0);
+            });
+        }
+    }
+    return predict_local(h, Xs, M, mean, var);
+}
+
+static int predict_local(gphip_handle h, const void* Xs, int64_t M, double* mean, double* var) {
+    std::lock_guard<std::recursive_mutex> lk(h->mu);
     HIPCHK(hipSetDevice(h->device));
     const double* X = static_cast<const double*>(Xs);
     const int64_t d = h->d;
@@ -1244,8 +1447,31 @@ int gphip_predict_samples(gphip_handle h, const double* Thetas, int S, int p, co
     if (!h || !Thetas || !Xs || !mean || !var || !info) return fail(h, GPHIP_ERR_ARG, "null argument");
     if (p != h->p) return fail(h, GPHIP_ERR_DIM, "theta has the wrong length");
     if (S < 1 || M < 1) return fail(h, GPHIP_ERR_DIM, "S < 1 or M < 1");
-    if (h->kernel_id == GPHIP_KERNEL_NULL) return fail(h, GPHIP_ERR_UNSUPPORTED, "null kernel has no factor");
     std::lock_guard<std::recursive_mutex> lk(h->mu);
+    if (h->kernel_id == GPHIP_KERNEL_NULL) {   // BGP:63-89: one Normal[m(x*), sn] per sample, no factorisation
+        for (int s = 0; s < S; ++s) {
+            const double sn = Thetas[(size_t)s * p], mu = (h->mean_id == GPHIP_MEAN_CONST) ? Thetas[(size_t)s * p + 1] : 0.0;
+            const bool finite = std::isfinite(sn) && std::isfinite(mu);
+            info[s] = !finite ? GPHIP_INFO_NAN : (sn * sn > 0.0 ? GPHIP_INFO_OK : GPHIP_INFO_NOT_SPD);
+            for (int64_t t = 0; t < M; ++t) { mean[(size_t)s * M + t] = mu; var[(size_t)s * M + t] = sn * sn; }
+        }
+        return GPHIP_OK;
+    }
+    if (h->group && h->group->members.size() > 1 && S >= 2 && !h->in_group_call) {
+        // posterior samples are independent units: contiguous blocks to the local devices, no collective
+        gphip_group* g = h->group;
+        const int nl = (int)g->members.size();
+        return group_parallel(h, [&](int i) {
+            const int s0 = (int)((long)S * i / nl), s1 = (int)((long)S * (i + 1) / nl);
+            if (s1 <= s0) return (int)GPHIP_OK;
+            gphip_ctx* m = g->members[(size_t)i];
+            m->in_group_call = true;
+            const int c = gphip_predict_samples(m, Thetas + (size_t)s0 * p, s1 - s0, p, Xs, M, mean + (size_t)s0 * M,
+                                                var + (size_t)s0 * M, info + s0);
+            m->in_group_call = false;
+            return c;
+        });
+    }
     HIPCHK(hipSetDevice(h->device));
     int rc = ensure_slots(h, S);
     if (rc) return rc;
@@ -1303,6 +1529,10 @@ int gphip_solve(gphip_handle h, const double* rhs, int64_t nrhs, double* out) {
     if (nrhs < 1) return fail(h, GPHIP_ERR_DIM, "nrhs < 1");
     std::lock_guard<std::recursive_mutex> lk(h->mu);
     if (!h->fitted) return fail(h, GPHIP_ERR_STATE, "gphip_solve before a successful gphip_fit");
+    if (h->null_fit) {                         // "Inverse" -> Function[Divide[#, matrixDiagonal]]  (BGP:156-159)
+        for (int64_t i = 0; i < nrhs * h->N; ++i) out[i] = rhs[i] / h->kappa_fit;
+        return GPHIP_OK;
+    }
     HIPCHK(hipSetDevice(h->device));
     const int64_t N = h->N, Npad = h->Npad, MC = 2048;
     int rc = ensure_vbuf(h, nrhs < MC ? (nrhs + TB - 1) / TB * TB : MC);
@@ -1472,7 +1702,7 @@ int* option_slot(gphip_ctx* h, const char* name) {
         {"dataflow_max_slots", &gphip_ctx::dataflow_max_slots}, {"dataflow_fine_nt", &gphip_ctx::dataflow_fine_nt},
         {"dataflow_tail", &gphip_ctx::dataflow_tail}, {"grad_potri", &gphip_ctx::grad_potri},
         {"fused_eval", &gphip_ctx::fuse_option}, {"panel_left", &gphip_ctx::panel_left},
-        {"max_slots", &gphip_ctx::max_slots},
+        {"max_slots", &gphip_ctx::max_slots}, {"shard_min_n", &gphip_ctx::shard_min_n},
     };
     for (const Entry& e : table)
         if (!strcmp(name, e.name)) return &(h->*(e.field));
@@ -1514,6 +1744,8 @@ int gphip_set_option(gphip_handle h, const char* name, double value) {
     if (!strcmp(name, "panel") && (v < 1 || v > 64)) return fail(h, GPHIP_ERR_ARG, "panel out of range");
     if (!strcmp(name, "max_slots") && v < 1) return fail(h, GPHIP_ERR_ARG, "max_slots < 1");
     *slot = v;
+    if (h->group)                              // every member of a multi-device handle runs the same schedule
+        for (size_t i = 1; i < h->group->members.size(); ++i) (void)gphip_set_option(h->group->members[i], name, value);
     return GPHIP_OK;
 }
 

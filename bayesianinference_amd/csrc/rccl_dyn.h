@@ -1,0 +1,83 @@
+// rccl_dyn.h -- RCCL bound at run time (dlopen), so libgphip.so carries no link-time dependency on it.
+//
+// Why not -lrccl: a host process may already hold a copy of RCCL (PyTorch-ROCm wheels bundle their own
+// librccl.so next to their own HIP runtime).  Two RCCLs -- or an RCCL linked against a second
+// libamdhip64 -- in one process do not work.  So the library first looks for an RCCL that is ALREADY
+// mapped (RTLD_NOLOAD), then for $GPHIP_RCCL_PATH, then for the system one.  A single-GPU handle never
+// touches this file's code; a multi-device handle without any usable RCCL falls back to peer copies
+// (CopyComm in gphip_multi.inc) when all its ranks live in this process, and fails loudly otherwise.
+#pragma once
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+#include <mutex>
+#include <string>
+
+namespace gphip {
+
+// the handful of declarations used, with RCCL's ABI (rccl.h: ncclUniqueId is 128 opaque bytes; ncclChar = 0,
+// ncclFloat64 = 8, ncclSum = 0; every call returns ncclResult_t, 0 = ncclSuccess)
+struct NcclUniqueId { char internal[128]; };
+typedef struct ncclComm* nccl_comm_t;
+constexpr int NCCL_CHAR = 0, NCCL_FLOAT64 = 8, NCCL_SUM = 0;
+
+struct RcclApi {
+    void* so = nullptr;
+    std::string origin;          // which library was bound (for gphip_last_error / diagnostics)
+    int (*GetUniqueId)(NcclUniqueId*) = nullptr;
+    int (*CommInitRank)(nccl_comm_t*, int, NcclUniqueId, int) = nullptr;
+    int (*CommInitAll)(nccl_comm_t*, int, const int*) = nullptr;
+    int (*CommDestroy)(nccl_comm_t) = nullptr;
+    int (*Broadcast)(const void*, void*, size_t, int, int, nccl_comm_t, hipStream_t) = nullptr;
+    int (*AllReduce)(const void*, void*, size_t, int, int, nccl_comm_t, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    bool ok() const { return so != nullptr; }
+};
+
+inline const RcclApi& rccl() {
+    static RcclApi api;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        struct Cand { const char* name; int flags; };
+        const char* env = getenv("GPHIP_RCCL_PATH");
+        const Cand cands[] = {
+            {"librccl.so", RTLD_NOW | RTLD_NOLOAD},      // PyTorch's bundled copy, if the host process mapped it
+            {"librccl.so.1", RTLD_NOW | RTLD_NOLOAD},
+            {env, RTLD_NOW},
+            {"librccl.so.1", RTLD_NOW},
+            {"librccl.so", RTLD_NOW},
+            {"/opt/rocm/lib/librccl.so.1", RTLD_NOW},
+        };
+        for (const Cand& c : cands) {
+            if (!c.name || !*c.name) continue;
+            void* so = dlopen(c.name, c.flags);
+            if (!so) continue;
+            RcclApi a;
+            a.so = so;
+            a.origin = c.name;
+#define GP_SYM(field, sym) a.field = reinterpret_cast<decltype(a.field)>(dlsym(so, sym))
+            GP_SYM(GetUniqueId, "ncclGetUniqueId");
+            GP_SYM(CommInitRank, "ncclCommInitRank");
+            GP_SYM(CommInitAll, "ncclCommInitAll");
+            GP_SYM(CommDestroy, "ncclCommDestroy");
+            GP_SYM(Broadcast, "ncclBroadcast");
+            GP_SYM(AllReduce, "ncclAllReduce");
+            GP_SYM(GroupStart, "ncclGroupStart");
+            GP_SYM(GroupEnd, "ncclGroupEnd");
+            GP_SYM(GetErrorString, "ncclGetErrorString");
+#undef GP_SYM
+            if (a.GetUniqueId && a.CommInitRank && a.CommInitAll && a.CommDestroy && a.Broadcast && a.AllReduce &&
+                a.GroupStart && a.GroupEnd && a.GetErrorString) {
+                api = a;
+                return;
+            }
+            dlclose(so);
+        }
+    });
+    return api;
+}
+
+}  // namespace gphip

@@ -8,6 +8,7 @@
  *   gphip_loglik        the "LogLikelihoodFunction" closure theta -> R     BGP:295-306 (+181-199)
  *   gphip_loglik_batch  the same closure mapped over a theta matrix        BS:276-298, BS:902-916
  *   gphip_fit           matrixInverseAndDet[covarianceFunction[theta]]     BGP:308 (invCovFun)
+ *   gphip_cross_covariance  compiledKandKappa[points1, kernel, nugget][X*]     BGP:63-124
  *   gphip_predict       predictFromGaussianProcessInternal                 BGP:396-422
  *   gphip_predict_samples  predictFromGaussianProcess over all samples     BGP:343-376
  *   gphip_covariance    "CovarianceFunction" = compiledCovarianceMatrix    BGP:45-61
@@ -59,10 +60,35 @@ typedef struct gphip_ctx* gphip_handle;
 /* X: row-major N x d, y: length N, always fp64 host arrays.  dtype selects the DEVICE arithmetic:
  * 64 = fp64 (v_mfma_f64_16x16x4_f64, the 1e-8 parity path) or 32 = fp32 (v_mfma_f32_16x16x4_f32,
  * BASELINE.json config 5; ~1e-3 relative vs the fp64 oracle).  theta and every result stay fp64.
- * devices/ndev: HIP device ordinals this handle may use (NULL/0 = current device). */
+ * devices/ndev: HIP device ordinals this handle may use.  NULL/0 = the current device; one ordinal = that
+ * device; SEVERAL ordinals = a multi-device handle living in this one process (one context per listed
+ * device, communicator = RCCL ncclCommInitAll, bound at run time; a repeated ordinal makes several virtual
+ * ranks share a GPU -- device copies instead of RCCL -- which is how the sharded schedule is tested on a
+ * 1-GPU box).  Every entry point below works unchanged on a multi-device handle:
+ *   gphip_loglik / _parts / gphip_fit   N >= option "shard_min_n" (default 16384): ONE factorisation sharded
+ *                                       over the devices, 1-D block-cyclic over outer panels, one broadcast of
+ *                                       the factored panel per step; smaller N: first device
+ *   gphip_loglik_batch, gphip_predict_samples   thetas / posterior samples dealt to the devices, no collective
+ *   gphip_predict                       after a sharded fit every device holds the whole factor (each received
+ *                                       panel is unpacked on arrival): test points shard, no collective
+ *   everything else                     first device
+ * The reference-side caller this serves: ONE WL kernel process (nestedSampling, BS:1099-1136). */
 int gphip_create(const void* X, const void* y, int64_t N, int64_t d, int kernel_id, int mean_id,
                  int dtype, const int* devices, int ndev, gphip_handle* out);
 int gphip_destroy(gphip_handle h);
+
+/* One process PER device (WL sub-kernels of parallelNestedSampling, BS:1349-1357; torchrun ranks): rank 0 calls
+ * gphip_comm_unique_id, the host hands the GPHIP_COMM_ID_BYTES bytes to every process by its own means, and each
+ * process creates its handle with gphip_create_rank (collective: ncclCommInitRank).  Afterwards gphip_loglik /
+ * gphip_fit on these handles are COLLECTIVE calls (every rank, same theta, same order) whenever
+ * N >= "shard_min_n"; results are identical on every rank.  GPHIP_ERR_UNSUPPORTED if no RCCL can be bound. */
+#define GPHIP_COMM_ID_BYTES 128
+int gphip_comm_unique_id(void* id128);
+int gphip_create_rank(const void* X, const void* y, int64_t N, int64_t d, int kernel_id, int mean_id, int dtype,
+                      int device, int rank, int world, const void* id128, gphip_handle* out);
+/* world = ranks of the job (1 for a plain handle), nlocal = ranks in this process, *comm = "none" /
+ * "device copies" / "rccl (..)" (string owned by the library); any pointer may be NULL */
+int gphip_comm_info(gphip_handle h, int* world, int* nlocal, const char** comm);
 
 /* number of hyper-parameters p expected for this handle */
 int gphip_num_params(gphip_handle h, int* p);
@@ -92,6 +118,10 @@ int gphip_predict_samples(gphip_handle h, const double* Thetas, int S, int p, co
                           double* mean, double* var, int* info);
 /* K: row-major N x N fp64 (full, both triangles), for parity tests at small N. */
 int gphip_covariance(gphip_handle h, const double* theta, int p, double* K);
+/* compiledKandKappa (BGP:91-124, null kernel BGP:63-89): k row-major N x M (rows = training points, columns =
+ * test points, the layout of BGP:103-107), kappa[M] = k(x*,x*) + nugget.  No fit needed; un-fits the handle. */
+int gphip_cross_covariance(gphip_handle h, const double* theta, int p, const void* Xs, int64_t M, double* k,
+                           double* kappa);
 /* rhs, out: column-major N x nrhs (each right-hand side contiguous); out = K^-1 rhs. */
 int gphip_solve(gphip_handle h, const double* rhs, int64_t nrhs, double* out);
 int gphip_logdet(gphip_handle h, double* out);
@@ -115,24 +145,27 @@ int gphip_logdet(gphip_handle h, double* out);
  *                  pinned host memory by its last task)
  *   "grad_potri"   0/1 gradient: form K^-1 = U U^T in one go when 2 N^2 of scratch fits (default 1), else
  *                  stream it in row blocks through forward + backward substitution
- *   "max_slots"    cap on concurrently resident batch matrices */
+ *   "max_slots"    cap on concurrently resident batch matrices
+ *   "shard_min_n"  multi-device handles: shard ONE factorisation over the devices from this N on (default 16384;
+ *                  0 = always, even for a world of one) */
 int gphip_set_option(gphip_handle h, const char* name, double value);
 int gphip_get_option(gphip_handle h, const char* name, double* value);
 /* The environment variable GPHIP_OPTIONS="name=value,name=value" presets options for every handle the process
  * creates (for hosts that bind only the evaluation entry points, e.g. the LibraryLink shim). */
 
 /* Per-kernel-class timing, measured with HIP events on the handle's stream while "profile"=1.
- * class: 0 kbuild, 1 potrf, 2 trsm, 3 gemm (in-panel), 4 gemm/syrk (trailing), 5 total eval.
+ * class: 0 kbuild, 1 potrf, 2 trsm, 3 gemm (in-panel), 4 gemm/syrk (trailing), 5 total eval, 6 prediction epilogue.
  * Returns accumulated milliseconds, launches, algorithmic flops and bytes since the last reset. */
-#define GPHIP_NCLASS 6
+#define GPHIP_NCLASS 7
 int gphip_get_profile(gphip_handle h, int cls, double* ms, double* launches, double* flops,
                       double* bytes);
 int gphip_reset_profile(gphip_handle h);
 
-/* ---- multi-GPU 1-D block-cyclic Cholesky; no reference equivalent (the
- * reference never shards one factorisation).  One handle per rank/GPU; the host schedules the
- * steps and broadcasts packed panels between ranks (torch.distributed / RCCL over xGMI).  Outer
- * panel j ("panel" option tile columns) belongs to rank j % world; see dist_cholesky.py. ---- */
+/* ---- the per-rank compute STEPS of the multi-GPU 1-D block-cyclic Cholesky; no reference
+ * equivalent (the reference never shards one factorisation).  A multi-device / per-rank handle (gphip_create
+ * with ndev > 1, gphip_create_rank) drives these itself; they stay exported so that a host may run the schedule
+ * with its own collective instead -- dist_cholesky.py does (torch.distributed: RCCL on GPUs, gloo in the CPU
+ * schedule tests).  Outer panel j ("panel" option tile columns) belongs to rank j % world. ---- */
 int gphip_set_streams(gphip_handle h, void* main_stream, void* panel_stream); /* adopt hipStream_t's */
 int gphip_dist_num_panels(gphip_handle h, int* nouter);
 int gphip_dist_panel_shape(gphip_handle h, int k, int64_t* rows, int64_t* cols);

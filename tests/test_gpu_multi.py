@@ -1,0 +1,143 @@
+"""Multi-device handles behind the C ABI (include/gphip.h: gphip_create with ndev > 1, gphip_create_rank),
+SURVEY.md §8b/§8e.  A 1-GPU box exercises them by listing the same device ordinal several times: every
+listed entry becomes a rank with its own context, workspace, three streams and packed-panel buffers; the
+schedule, ownership (panel j -> rank j % world), packing, look-ahead ordering, unpack-on-receive replication of
+L and the scalar reduction are exactly what runs on 8 GPUs -- only the transport differs (device copies for
+virtual ranks; RCCL, bound with dlopen, once the ordinals are distinct).  The RCCL binding itself is exercised
+at world size 1 through gphip_create_rank (ncclCommInitRank / ncclBroadcast / ncclAllReduce on one GPU)."""
+import numpy as np
+import pytest
+
+from bayesianinference_amd import _lib, synthetic as syn
+from oracle import gp_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def close(a, b, n, rtol=1e-8):
+    return abs(a - b) <= rtol * max(abs(b), float(n))
+
+
+@pytest.mark.parametrize("n,d,kernel,world,panel", [(1500, 3, "se_ard", 2, 2), (1500, 3, "matern52_ard", 3, 1),
+                                                    (8192, 8, "se_ard", 8, 4), (700, 2, "se", 4, 1)])
+def test_sharded_loglik_matches_oracle_and_single_device(n, d, kernel, world, panel):
+    X, y = syn.make_dataset(n, d)
+    th = syn.default_theta(kernel, d)
+    g = _lib.Handle(X, y, kernel, device=[0] * world)
+    info = g.comm_info()
+    assert info == {"world": world, "local": world, "comm": "device copies"}
+    g.set_option("panel", panel)
+    g.set_option("shard_min_n", 0)                       # force the sharded schedule at test sizes
+    ll, ld, qd, inf = g.loglik_parts(th)
+    assert inf == 0
+    h = _lib.Handle(X, y, kernel)
+    l1, ld1, qd1, inf1 = h.loglik_parts(th)
+    assert inf1 == 0 and close(ll, l1, n, 1e-10) and close(ld, ld1, n, 1e-10) and close(qd, qd1, n, 1e-9)
+    if n <= 2000:
+        want = orc.log_likelihood(kernel, th, X, y, parts=True)
+        assert close(ll, want[0], n) and close(ld, want[1], n) and close(qd, want[2], n)
+    else:                                                # F3-style scalar from the single-device path (oracle-pinned there)
+        assert close(ll, l1, n, 1e-10)
+    # repeated calls reuse events / buffers; a second theta; bit-repeatable
+    ll2, *_ = g.loglik_parts(th)
+    assert ll2 == ll
+    th2 = th * 1.07
+    assert close(g.loglik(th2)[0], h.loglik(th2)[0], n, 1e-10)
+    # not-SPD verdict travels through the reduction
+    bad = th.copy()
+    bad[-1] = 0.0
+    Xd = X.copy()
+    Xd[n // 2] = Xd[3]
+    gd = _lib.Handle(Xd, y, kernel, device=[0] * world)
+    gd.set_option("shard_min_n", 0)
+    gd.set_option("panel", panel)
+    assert gd.loglik(bad)[1] == _lib.INFO_NOT_SPD
+    assert gd.loglik(np.full_like(th, np.nan))[1] == _lib.INFO_NAN
+    assert gd.loglik(th)[1] == 0                          # and the handle keeps working
+    gd.close(); g.close(); h.close()
+
+
+def test_sharded_fit_replicates_factor_and_predict_shards_test_points():
+    """C3: after a sharded fit EVERY rank holds all of L, z and the block inverses
+    (each received panel is unpacked on arrival -- no extra collective), so test points shard with no further
+    traffic and solve / logdet work on the first device."""
+    n, d, world = 2300, 4, 4
+    X, y = syn.make_dataset(n, d)
+    th = syn.default_theta("matern52_ard", d)
+    Xs = syn.make_test_points(1500, d)                   # >= 2 * 128 * world: sharded over the ranks
+    g = _lib.Handle(X, y, "matern52_ard", device=[0] * world)
+    g.set_option("shard_min_n", 0)
+    g.set_option("panel", 2)
+    assert g.fit(th) == 0
+    mu, var = g.predict(Xs)
+    mo, so = orc.predict_internal("matern52_ard", th, X, y, Xs)
+    np.testing.assert_allclose(mu, mo, rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(np.sqrt(var), so, rtol=1e-7)
+    mu_few, _ = g.predict(Xs[:5])                        # too few to shard: first device alone, same factor
+    np.testing.assert_allclose(mu_few, mo[:5], rtol=1e-7, atol=1e-9)
+    K = orc.covariance_matrix("matern52_ard", th, X)
+    np.testing.assert_allclose(g.solve(y), np.linalg.solve(K, y), rtol=1e-8, atol=1e-9)
+    assert close(g.logdet(), np.linalg.slogdet(K)[1], n)
+    g.close()
+
+
+def test_group_handle_deals_batches_and_samples_to_its_devices():
+    """Axis (1): thetas / posterior samples are independent units -- contiguous blocks per device, one host
+    thread each, no collective.  Below shard_min_n single evaluations stay on the first device."""
+    n, d, world = 900, 3, 3
+    X, y = syn.make_dataset(n, d)
+    g = _lib.Handle(X, y, "se_ard", device=[0] * world)
+    h = _lib.Handle(X, y, "se_ard")
+    Th = syn.theta_batch(25, "se_ard", d)
+    Th[:, -1] = np.maximum(Th[:, -1], 0.05)
+    Th[11, 0] = np.nan
+    out, info = g.loglik_batch(Th)
+    o1, i1 = h.loglik_batch(Th)
+    assert np.array_equal(info, i1) and info[11] == _lib.INFO_NAN
+    keep = info == 0
+    np.testing.assert_allclose(out[keep], o1[keep], rtol=1e-9, atol=1e-9 * n)
+    assert close(g.loglik(Th[0])[0], orc.log_likelihood("se_ard", Th[0], X, y), n)     # N < shard_min_n: local
+    Xs = syn.make_test_points(60, d)
+    mean, var, inf = g.predict_samples(Th[:7], Xs)
+    m1, v1, inf1 = h.predict_samples(Th[:7], Xs)
+    assert np.array_equal(inf, inf1)
+    np.testing.assert_allclose(mean, m1, rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(var, v1, rtol=1e-8, atol=1e-12)
+    g.close(); h.close()
+
+
+def test_rank_handle_over_rccl_world_size_one():
+    """gphip_create_rank binds RCCL at run time (dlopen) and runs the SAME schedule with ncclBroadcast on the
+    comm stream and the 4-double ncclAllReduce; a world of one rank is what a 1-GPU box can host."""
+    n, d = 1500, 3
+    X, y = syn.make_dataset(n, d)
+    th = syn.default_theta("se_ard", d)
+    cid = _lib.comm_unique_id()
+    assert len(cid) == _lib.COMM_ID_BYTES
+    g = _lib.Handle(X, y, "se_ard", device=0, rank=0, world=1, comm_id=cid)
+    ci = g.comm_info()
+    assert ci["world"] == 1 and ci["local"] == 1 and ci["comm"].startswith("rccl (ncclCommInitRank")
+    g.set_option("shard_min_n", 0)
+    g.set_option("panel", 2)
+    ll, ld, qd, inf = g.loglik_parts(th)
+    want = orc.log_likelihood("se_ard", th, X, y, parts=True)
+    assert inf == 0 and close(ll, want[0], n) and close(ld, want[1], n) and close(qd, want[2], n)
+    assert g.fit(th) == 0
+    Xs = syn.make_test_points(40, d)
+    mu, var = g.predict(Xs)
+    mo, so = orc.predict_internal("se_ard", th, X, y, Xs)
+    np.testing.assert_allclose(mu, mo, rtol=1e-7, atol=1e-9)
+    g.close()
+
+
+def test_ndev_is_honoured_or_rejected_never_ignored():
+    X, y = syn.make_dataset(64, 2)
+    with pytest.raises(_lib.GphipError) as e:            # a device that does not exist
+        _lib.Handle(X, y, "se_ard", device=[0, 4096])
+    assert e.value.status == 5
+    with pytest.raises(_lib.GphipError) as e:            # null kernel: K is diagonal, nothing to shard
+        _lib.Handle(X, y, "null", device=[0, 0])
+    assert e.value.status == 6
+    g = _lib.Handle(X, y, "se_ard", device=[0, 0])
+    assert g.comm_info()["world"] == 2
+    g.close()

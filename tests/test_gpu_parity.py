@@ -535,3 +535,72 @@ def test_gradient_null_kernel_and_fp32():
     want = orc.log_likelihood_grad("matern52_ard", th, X, y)
     np.testing.assert_allclose(grad, want, rtol=2e-2, atol=2e-2 * np.abs(want).max())     # fp32 device arithmetic
     h.close()
+
+
+@pytest.mark.parametrize("kernel,d,n,m,dtype", [("se_ard", 3, 300, 70, 64), ("matern52", 2, 129, 1, 64),
+                                                 ("matern52_ard", 16, 200, 2100, 64), ("se", 1, 50, 5, 32)])
+def test_cross_covariance_matches_oracle(kernel, d, n, m, dtype):
+    """a6, compiledKandKappa (BGP:91-124) checked DIRECTLY: k is N x M with rows = training points
+    (BGP:103-107), kappa_j = k(x*_j, x*_j) + nugget(x*_j) (BGP:113)."""
+    X, y = syn.make_dataset(n, d)
+    Xs = syn.make_test_points(m, d)
+    h = _lib.Handle(X, y, kernel, dtype=dtype)
+    for th in syn.theta_batch(2, kernel, d):
+        k, kappa = h.cross_covariance(th, Xs)
+        ko, kappao = orc.k_and_kappa(kernel, th, X, Xs)
+        assert k.shape == (n, m) and kappa.shape == (m,)
+        if dtype == 64:
+            np.testing.assert_allclose(k, ko, rtol=1e-12, atol=1e-300)
+            np.testing.assert_allclose(kappa, kappao, rtol=1e-15)
+        else:
+            np.testing.assert_allclose(k, ko, rtol=2e-5, atol=1e-6)
+    h.close()
+
+
+def test_null_kernel_fit_predict_solve():
+    """Null kernel Function[0] (BGP:25-27, 63-89, 156-159): K = diag(sn^2); k = empty sparse array, kappa =
+    nugget only -> predictFromGaussianProcess returns Normal[m(x*), sn] at every point."""
+    X, y = syn.make_dataset(40, 2)
+    Xs = syn.make_test_points(7, 2)
+    th = np.array([0.7, 0.1])
+    h = _lib.Handle(X, y, "null", "const")
+    assert h.fit(th) == 0
+    mu, var = h.predict(Xs)
+    mo, so = orc.predict_internal("null", th, X, y, Xs, "const")
+    np.testing.assert_allclose(mu, mo, rtol=1e-15)
+    np.testing.assert_allclose(np.sqrt(var), so, rtol=1e-15)
+    assert np.all(mu == 0.1) and np.allclose(var, 0.49)
+    assert close(h.logdet(), 40 * np.log(0.49), 40)                 # logTotal[matrixDiagonal], BGP:158
+    np.testing.assert_allclose(h.solve(y), y / 0.49, rtol=1e-15)    # Divide[#, matrixDiagonal], BGP:157
+    k, kappa = h.cross_covariance(th, Xs)
+    assert k.shape == (40, 7) and not k.any() and np.allclose(kappa, 0.49)
+    mean, v, info = h.predict_samples(np.array([[0.7, 0.1], [0.0, 0.3], [np.nan, 0.0]]), Xs)
+    assert info.tolist() == [0, 1, 2] and np.all(mean[0] == 0.1) and np.allclose(v[0], 0.49)
+    assert h.fit([0.0, 0.1]) == 1                                   # sn = 0: singular diagonal
+    with pytest.raises(_lib.GphipError):
+        h.predict(Xs)
+    h.close()
+
+
+def test_prediction_epilogue_strips_and_profile():
+    """The tiled two-stage prediction epilogue: strips of columns x 128 test points, fixed-order sums --
+    values independent of the strip split (1 strip at M = 3000, N = 700; many at M = 40, N = 5000) and its
+    profile class reports V streamed once."""
+    for n, m, d in ((700, 3000, 2), (5000, 40, 4)):
+        X, y = syn.make_dataset(n, d)
+        Xs = syn.make_test_points(m, d)
+        th = syn.default_theta("se_ard", d)
+        h = _lib.Handle(X, y, "se_ard")
+        assert h.fit(th) == 0
+        h.set_option("profile", 1)
+        h.reset_profile()
+        mu, var = h.predict(Xs)
+        mu2, var2 = h.predict(Xs)
+        assert np.array_equal(mu, mu2) and np.array_equal(var, var2)          # deterministic (no atomics)
+        mo, so = orc.predict_internal("se_ard", th, X, y, Xs)
+        np.testing.assert_allclose(mu, mo, rtol=1e-7, atol=1e-9)
+        np.testing.assert_allclose(np.sqrt(var), so, rtol=1e-7)
+        prof = h.profile()["predict_epilogue"]
+        mpad, npad = -(-m // 128) * 128, -(-n // 128) * 128
+        assert prof["launches"] == 2 and prof["bytes"] == 2 * 8.0 * mpad * npad and prof["ms"] > 0
+        h.close()
