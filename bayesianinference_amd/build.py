@@ -45,5 +45,34 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+ROOT = os.path.dirname(PKG)
+WL_SHIM = os.path.join(PKG, "csrc", "librarylink_shim.cpp")
+WL_STUB_DIR = os.path.join(ROOT, "tests", "wl_stub")
+WL_STUB_LIB = os.path.join(WL_STUB_DIR, "libgphip_wl_stub.so")
+
+
+def build_wl_stub(force: bool = False, verbose: bool = False) -> str:
+    """TEST build of the LibraryLink shim: the production source csrc/librarylink_shim.cpp compiled with g++ against
+    the tests-only stand-in tests/wl_stub/WolframLibrary.h, together with the fake WolframLibraryData driver, linked
+    to the in-tree libgphip.so.  (A production build uses the real header of a Wolfram installation, INTEGRATION.md.)"""
+    srcs = [WL_SHIM, os.path.join(WL_STUB_DIR, "shim_driver.cpp")]
+    deps = srcs + [os.path.join(WL_STUB_DIR, "WolframLibrary.h"), os.path.join(ROOT, "include", "gphip.h"), LIB]
+    if not force and os.path.exists(WL_STUB_LIB) and all(os.path.getmtime(p) <= os.path.getmtime(WL_STUB_LIB) for p in deps):
+        return WL_STUB_LIB
+    cxx = shutil.which("g++") or shutil.which("c++")
+    if not cxx:
+        raise RuntimeError("g++ not found: cannot build the LibraryLink shim test library")
+    cmd = [cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wextra", "-I" + WL_STUB_DIR,
+           "-I" + os.path.join(ROOT, "include"), "-o", WL_STUB_LIB] + srcs + \
+          ["-L" + os.path.dirname(LIB), "-lgphip", "-Wl,-rpath,$ORIGIN/../../bayesianinference_amd/lib"]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("g++ failed on the LibraryLink shim:\n" + res.stdout + res.stderr)
+    return WL_STUB_LIB
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    print(build_wl_stub(force="--force" in sys.argv, verbose=True))

@@ -254,13 +254,29 @@ def defineGaussianProcess(data, kernel, nugget="Constant", meanFunction=None, va
     params = [tuple(v) for v in variables]
     if not params or any(len(v) != 3 for v in params):            # paramSpecPattern, BS:19
         return inferenceObject(None)
-    device = rules.pop("Device", None)
-    handle = _lib.Handle(X, Y[:, 0], kname, mean, device=device)  # raises loudly without the library / GPU
+    # Device = one ordinal; Devices = a list of ordinals -> ONE multi-device handle (the library shards a large
+    # factorisation over them and deals batches / posterior samples / test points to them, include/gphip.h);
+    # Precision = "Double" (fp64, the parity path) | "Single" (fp32 device arithmetic, BASELINE.json cfg 5)
+    device = rules.pop("Devices", rules.pop("Device", None))
+    precision = str(rules.pop("Precision", "Double")).lower()
+    if precision not in ("double", "single"):
+        raise ValueError('Precision must be "Double" or "Single"')
+    handle = _lib.Handle(X, Y[:, 0], kname, mean, dtype=64 if precision == "double" else 32,
+                         device=device)                           # raises loudly without the library / GPU
     if handle.p != len(params):
         handle.close()
         raise ValueError(f"kernel {kname!r} with mean {mean!r} on d={X.shape[1]} needs {handle.p} "
                          f"hyper-parameters (l.., sigma_f, sigma_n[, mu]); got {len(params)}")
+    # Switch[logLikelihood, Automatic, .., _Function | _CompiledFunction, .., _, ..]  (BGP:272-307):
+    #   callable      installed verbatim (BGP:293-294)
+    #   "Automatic"   LogLikelihood[MultinormalDistribution[m, K], {y}], unevaluated -> $MachineLogZero (BGP:273-292):
+    #                 the multivariate-normal log-pdf IS -1/2 (N log 2pi + log det K + r.K^-1 r), and "stays
+    #                 unevaluated" = K not positive definite = info != 0 -- so on this path both branches are the
+    #                 same device computation; the branch taken is recorded under "LikelihoodBranch"
+    #   anything else the default closure (BGP:296-305)
     user_ll = rules.pop("LogLikelihoodFunction", None)
+    branch = "UserFunction" if callable(user_ll) else ("Automatic" if isinstance(user_ll, str) and
+                                                       user_ll.lower() == "automatic" else "Default")
     loglik = user_ll if callable(user_ll) else make_log_likelihood(handle)
 
     def log_likelihood_gradient(theta):
@@ -282,7 +298,7 @@ def defineGaussianProcess(data, kernel, nugget="Constant", meanFunction=None, va
         "Data": (X, Y),
         "PriorDistribution": variablePrior,
         "Parameters": params,
-        "KernelName": kname, "MeanName": mean,
+        "KernelName": kname, "MeanName": mean, "LikelihoodBranch": branch,
         "GaussianProcessData": {
             "ModelFunctions": {
                 "KernelFunction": (kname, WL_KERNEL_EXPRESSIONS[kname]),
@@ -366,6 +382,26 @@ def predictFromGaussianProcess(obj_or_examples, pts, kernel=None, theta=None, me
         return _predict_samples(handle, np.atleast_2d(np.asarray(theta, dtype=np.float64)), np.ones(1), P)
     finally:
         handle.close()
+
+
+def predictiveDistribution(obj, inputs=None, estimate=None):
+    """BS:1373-1416 for GP objects.  The reference's predictiveDistribution needs a "GeneratingDistribution"
+    (BS:1381-1387), which a GP object does not carry; BASELINE.json's north_star names predictiveDistribution as the
+    prediction API, so for objects with "GaussianProcessData" it forwards to predictFromGaussianProcess.
+    estimate = "MaximumLikelihood" / "MAP" first reduces "Samples" to the single best sample (BS:1389-1416:
+    TakeLargestBy LogLikelihood resp. LogLikelihood + LogPriorPDF).  Returns None ($Failed) for an unsampled object
+    (BS:1375-1380) or a missing `inputs`."""
+    if not isinstance(obj, inferenceObject) or obj.failed or "Samples" not in obj:
+        return None                                               # predictiveDistribution::unsampled
+    if "GaussianProcessData" not in obj or inputs is None:
+        return None                                               # predictiveDistribution::MissGenDist
+    if estimate is not None:
+        key = {"maximumlikelihood": lambda smp: smp["LogLikelihood"],
+               "map": lambda smp: smp["LogLikelihood"] + smp.get("LogPriorPDF", 0.0)}.get(str(estimate).lower())
+        if key is None:
+            raise ValueError('estimate must be None, "MaximumLikelihood" or "MAP"')
+        obj = obj.append({"Samples": [max(obj["Samples"], key=key)]})
+    return predictFromGaussianProcess(obj, inputs)
 
 
 def _predict_samples(handle, points, weights, P):

@@ -32,6 +32,7 @@ MACHINE_LOG_ZERO = -1.7976931348623157e308
 DEFAULTS = {                                   # BS:833-855
     "SamplePoolSize": 100, "MaxIterations": 10000, "MinIterations": 100, "MonteCarloSteps": 200,
     "TerminationFraction": 0.01, "PostProcessSamplingRuns": 100, "Walkers": 32, "Seed": 0,
+    "MinMaxAcceptanceRate": (0.0, 1.0),
 }
 
 
@@ -168,11 +169,17 @@ def nested_sampling_internal(loglik, logprior, starting_points, params, **opts):
         keep = cand_ll > threshold                                # exact rejection of stale candidates
         cand_pts, cand_ll = cand_pts[keep], cand_ll[keep]
         factor, rate = 1.0, np.nan
+        rmin, rmax = o["MinMaxAcceptanceRate"]
         while len(cand_ll) == 0:
             steps = int(math.ceil(factor * o["MonteCarloSteps"]))
             cand_pts, cand_ll, rate = constrained_walkers(loglik_batch, logprior, pts[best], threshold, cov,
                                                           lo, hi, o["Walkers"], steps, rng)
             n_evals += o["Walkers"] * steps
+            # BS:990-1004: the chain is re-run with 1.25x the steps until its acceptance rate lies inside
+            # "MinMaxAcceptanceRate" (Between[rate, {min, max}], default {0, 1} = always); here the rate is that of
+            # the whole walker batch, and a batch outside the window is discarded like the reference's chain
+            if not (rmin <= rate <= rmax):
+                cand_pts, cand_ll = cand_pts[:0], cand_ll[:0]
             factor *= 1.25                                        # BS:1003 step inflation on failure
             if factor > 50:
                 return "Bad likelihood function"
@@ -241,6 +248,9 @@ def evidence_sampling(result: dict, param_names, n_runs=100, rng=None) -> dict:
     out["Samples"] = [{"Point": pts[i], "LogLikelihood": float(ll[i]), "X": float(out["X"][i]),
                        "LogX": float(logx[i]), "CrudeLogPosteriorWeight": float(out["CrudeLogPosteriorWeight"][i]),
                        "CrudePosteriorWeight": float(out["CrudePosteriorWeight"][i])} for i in by_w]
+    if "LogPriorPDF" in out and len(out["LogPriorPDF"]) == len(ll):          # BS:884-886 keeps it per sample
+        for smp, i in zip(out["Samples"], by_w):
+            smp["LogPriorPDF"] = float(out["LogPriorPDF"][i])
     return out
 
 

@@ -95,3 +95,56 @@ def test_normalized_data_and_persistence_roundtrip(tmp_path):
     np.testing.assert_allclose(mu, a["Mean"][0], rtol=1e-12)
     back = nd["Output"]["InverseFunction"](mu)[:, 0]                                     # original units
     assert np.sqrt(np.mean((back - y[:7]) ** 2)) < 0.3
+
+
+def test_automatic_branch_precision_and_device_rules():
+    """BGP:272-292: "LogLikelihoodFunction" -> Automatic selects LogLikelihood[MultinormalDistribution[m, K], {y}]
+    (unevaluated -> $MachineLogZero).  On the HIP path that is the same device computation; it must equal the
+    MVN log-pdf the oracle evaluates with scipy (the second formulation the reference itself sanctions)."""
+    X, y = syn.make_dataset(180, 2)
+    variables = [("l1", 0.1, 10.0), ("l2", 0.1, 10.0), ("sf", 0.1, 10.0), ("sn", 0.05, 1.0), ("mu", -1.0, 1.0)]
+    obj = gp.defineGaussianProcess((X, y), "Matern52ARD", "Constant", "Constant", variables,
+                                   LogLikelihoodFunction="Automatic", Devices=[0])
+    assert not obj.failed and obj["LikelihoodBranch"] == "Automatic"
+    th = np.array([0.9, 1.4, 1.1, 0.2, 0.15])
+    want = orc.log_likelihood_mvn("matern52_ard", th, X, y, "const")
+    assert obj["LogLikelihoodFunction"](th) == pytest.approx(want, rel=1e-8)
+    Xd = X.copy()
+    Xd[3] = Xd[77]                                               # MultinormalDistribution refuses a singular covariance
+    bad = gp.defineGaussianProcess((Xd, y), "Matern52ARD", "Constant", "Constant", variables,
+                                   LogLikelihoodFunction="Automatic")
+    assert bad["LogLikelihoodFunction"]([1.0, 1.0, 1.0, 0.0, 0.0]) == gp.MACHINE_LOG_ZERO
+    # Precision -> "Single": fp32 device arithmetic (BASELINE.json cfg 5), 1e-3 against the fp64 oracle
+    single = gp.defineGaussianProcess((X, y), "Matern52ARD", "Constant", "Constant", variables, Precision="Single")
+    assert single["GaussianProcessData"]["HIPHandle"].dtype == 32
+    assert single["LogLikelihoodFunction"](th) == pytest.approx(want, rel=1e-3)
+    with pytest.raises(ValueError):
+        gp.defineGaussianProcess((X, y), "Matern52ARD", "Constant", "Constant", variables, Precision="Half")
+
+
+def test_predictive_distribution_forwards_for_gp_objects():
+    """BS:1373-1416: predictiveDistribution[obj, inputs] and its "MaximumLikelihood" / "MAP" forms."""
+    X, y = syn.make_dataset(120, 1)
+    variables = [("l", 0.05, 5.0), ("sf", 0.1, 5.0), ("sn", 0.05, 1.0)]
+    obj = gp.defineGaussianProcess((X, y), "SE", variables=variables)
+    pts = np.linspace(-1, 1, 6)
+    assert gp.predictiveDistribution(obj, pts) is None                        # ::unsampled (BS:1375-1380)
+    samples = [{"Point": [0.3, 1.0, 0.1], "CrudePosteriorWeight": 0.2, "LogLikelihood": -10.0, "LogPriorPDF": -1.0},
+               {"Point": [0.5, 1.3, 0.2], "CrudePosteriorWeight": 0.5, "LogLikelihood": -12.0, "LogPriorPDF": 3.0},
+               {"Point": [0.4, 0.9, 0.3], "CrudePosteriorWeight": 0.3, "LogLikelihood": -11.0, "LogPriorPDF": -1.0}]
+    sampled = obj.append({"Samples": samples})
+    full = gp.predictiveDistribution(sampled, pts)
+    ref = gp.predictFromGaussianProcess(sampled, pts)
+    np.testing.assert_array_equal(full["Mean"], ref["Mean"])
+    ml = gp.predictiveDistribution(sampled, pts, "MaximumLikelihood")         # TakeLargestBy LogLikelihood
+    mo, so = orc.predict_internal("se", samples[0]["Point"], X, y, pts[:, None])
+    assert ml["Mean"].shape == (1, 6)
+    np.testing.assert_allclose(ml["Mean"][0], mo, rtol=1e-7, atol=1e-9)
+    mp = gp.predictiveDistribution(sampled, pts, "MAP")                       # LogLikelihood + LogPriorPDF
+    mo, so = orc.predict_internal("se", samples[1]["Point"], X, y, pts[:, None])
+    np.testing.assert_allclose(mp["StandardDeviation"][0], so, rtol=1e-7)
+    assert gp.predictiveDistribution(sampled) is None                         # no inputs: ::MissGenDist
+    # null-kernel object: Normal[m(x*), sn] at every point (BGP:63-89)
+    nobj = gp.defineGaussianProcess((X, y), None, "Constant", "Constant", [("sn", 0.05, 2.0), ("mu", -1.0, 1.0)])
+    pred = gp.predictFromGaussianProcess(nobj.append({"Samples": [{"Point": [0.7, 0.1], "CrudePosteriorWeight": 1.0}]}), pts)
+    assert np.all(pred["Mean"] == 0.1) and np.allclose(pred["StandardDeviation"], 0.7)

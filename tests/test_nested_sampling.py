@@ -92,3 +92,19 @@ def test_parallel_runs_combine():
                                     MinIterations=50)
     assert res["SamplePoolSize"] == 120                   # pool sizes add, BS:1306
     assert abs(res["LogEvidence"]["Mean"] - want) < 4 * res["LogEvidence"]["StandardError"] + 0.2
+
+
+def test_min_max_acceptance_rate_window():
+    """BS:990-1004: a chain whose acceptance rate falls outside "MinMaxAcceptanceRate" is re-run with 1.25x the
+    steps; the default {0, 1} accepts every chain.  A reachable window leaves the evidence intact and every
+    recorded rate inside it; an unreachable one ends like the reference would never end -- reported, not hung."""
+    obj, _, want = _gauss_problem()
+    res = ns.nestedSampling(obj, SamplePoolSize=60, MonteCarloSteps=20, Walkers=16, Seed=9,
+                            MinMaxAcceptanceRate=(0.02, 0.95), MinIterations=60)
+    assert not isinstance(res, str)
+    rates = np.asarray(res["AcceptanceRate"], dtype=np.float64)
+    rates = rates[np.isfinite(rates)]
+    assert rates.size > 0 and np.all((rates >= 0.02) & (rates <= 0.95))
+    assert abs(res["LogEvidence"]["Mean"] - want) < 4 * res["LogEvidence"]["StandardError"] + 0.25
+    out = ns.nestedSampling(obj, SamplePoolSize=20, MonteCarloSteps=2, Walkers=4, Seed=1, MinMaxAcceptanceRate=(2.0, 3.0))
+    assert out == "Bad likelihood function"

@@ -139,3 +139,53 @@ def test_gradient_oracle_matches_finite_differences(kernel, d, mean):
         e[i] = 1e-6 * max(1.0, abs(th[i]))
         fd = (orc.log_likelihood(kernel, th + e, X, y, mean) - orc.log_likelihood(kernel, th - e, X, y, mean)) / (2 * e[i])
         assert g[i] == pytest.approx(fd, rel=2e-5, abs=1e-6)
+
+
+def _reference_fixtures(golden_dir):
+    import glob
+    import json
+    files = sorted(f for f in glob.glob(os.path.join(golden_dir, "reference_*.json"))
+                   if not f.endswith("reference_inputs.json"))
+    inputs = {c["name"]: c for c in json.load(open(os.path.join(golden_dir, "reference_inputs.json")))["cases"]}
+    return [(json.load(open(f)), inputs) for f in files]
+
+
+def test_reference_inputs_match_the_committed_goldens(golden_dir):
+    """The hand-over file of oracle/make_reference_golden.wl carries exactly the golden fixtures' inputs."""
+    import json
+    cases = {c["name"]: c for c in json.load(open(os.path.join(golden_dir, "reference_inputs.json")))["cases"]}
+    g = np.load(os.path.join(golden_dir, "f2_matern52_ard_n256_d8.npz"))
+    c = cases["f2_matern52_ard_n256_d8"]
+    assert np.array_equal(np.array(c["X"]), g["X"]) and np.array_equal(np.array(c["y"]), g["y"])
+    assert np.array_equal(np.array(c["thetas"]), g["thetas"]) and c["kernel"] == "matern52_ard"
+    assert set(cases) >= {"f1_se_n96_d1", "f1_se_n512_d1", "f2_se_ard_n256_d8", "f2_matern52_const_n333_d3",
+                          "f4_dup", "f4_ill", "f4_ok"}
+
+
+def test_oracle_matches_reference_fixture(golden_dir):
+    """The pin: outputs of the REAL reference (oracle/make_reference_golden.wl, needs a Wolfram kernel) against the
+    oracle at 1e-10 relative.  No such file can be produced in the build containers; until one is committed the
+    oracle is pinned only by closed forms / MVN / mpmath and parity is reported as UNPINNED."""
+    fixtures = _reference_fixtures(golden_dir)
+    if not fixtures:
+        pytest.skip("parity unpinned: no reference-produced fixture (tests/golden/reference_<case>.json) present -- "
+                    "run `wolframscript -file oracle/make_reference_golden.wl <BayesianInference dir>`")
+    for ref, inputs in fixtures:
+        c = inputs[ref["name"]]
+        X, y, Xs = np.array(c["X"]), np.array(c["y"]), np.array(c["Xs"])
+        n = len(y)
+        for i, th in enumerate(np.array(ref["thetas"])):
+            ll, ld, qd, info = orc.log_likelihood(c["kernel"], th, X, y, c["mean"], parts=True)
+            if ref["loglik_is_sentinel"][i]:
+                assert info != 0, (ref["name"], i)
+                continue
+            assert info == 0
+            assert abs(ll - ref["loglik"][i]) <= 1e-10 * max(abs(ref["loglik"][i]), n), (ref["name"], i)
+            if ref["logdet"][i] is not None:
+                assert abs(ld - ref["logdet"][i]) <= 1e-10 * max(abs(ref["logdet"][i]), n)
+                assert abs(qd - ref["quad"][i]) <= 1e-9 * max(abs(ref["quad"][i]), n)
+        for i, (mu, sd) in enumerate(zip(ref["pred_mu"], ref["pred_sd"])):
+            pts = np.array(ref["pred_points"])             # DeleteDuplicates'd inputs, in the reference's order
+            mo, so = orc.predict_internal(c["kernel"], np.array(ref["thetas"])[i], X, y, pts, c["mean"])
+            np.testing.assert_allclose(mo, mu, rtol=1e-9, atol=1e-10)
+            np.testing.assert_allclose(so, sd, rtol=1e-9)

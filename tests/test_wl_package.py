@@ -1,0 +1,86 @@
+"""Static consistency of the Wolfram-Language side of the boundary (no Wolfram kernel exists here, so the
+package itself cannot run): every LibraryFunctionLoad in bayesianinference_amd/wl/GPHIP.wl must name a function
+the LibraryLink shim exports, with the argument count the shim checks; the shim must compile (g++, against the
+tests-only stand-in header) and reject a wrong argument count with LIBRARY_FUNCTION_ERROR; and the package must
+keep the reference-shaped keys of "GaussianProcessData" (BayesianGaussianProcess.wl:314-321)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WL = os.path.join(ROOT, "bayesianinference_amd", "wl", "GPHIP.wl")
+SHIM = os.path.join(ROOT, "bayesianinference_amd", "csrc", "librarylink_shim.cpp")
+
+
+def wl_bindings():
+    """{shim function name: number of arguments} from the LibraryFunctionLoad calls of GPHIP.wl."""
+    text = open(WL).read()
+    text = re.sub(r"\(\*.*?\*\)", "", text, flags=re.S)
+    out = {}
+    for m in re.finditer(r'LibraryFunctionLoad\[\$GPHIPLibrary,\s*"(\w+)",\s*\{', text):
+        i, depth, args, cur = m.end(), 1, 0, False
+        while depth:                                   # count top-level elements of the argument list
+            ch = text[i]
+            if ch in "{[":
+                depth += 1
+                cur = True
+            elif ch in "}]":
+                depth -= 1
+            elif ch == "," and depth == 1:
+                args += 1
+                cur = False
+            elif not ch.isspace():
+                cur = True
+            i += 1
+        out[m.group(1)] = args + 1
+    return out
+
+
+def shim_argc():
+    """{function name: N} from `if (argc != N)` at the top of every entry point of the shim."""
+    text = open(SHIM).read()
+    return {m.group(1): int(m.group(2)) for m in re.finditer(
+        r"EXTERN_C DLLEXPORT int (gphip_wl_\w+)\([^)]*\)\s*\{\s*if \(argc != (\d+)\)", text)}
+
+
+def test_every_wl_binding_matches_a_shim_entry_point():
+    wl, shim = wl_bindings(), shim_argc()
+    assert len(wl) == 13 and set(wl) == set(shim), (sorted(wl), sorted(shim))
+    assert wl == shim, {k: (wl[k], shim[k]) for k in wl if wl[k] != shim[k]}
+
+
+def test_shim_compiles_against_stub_header_and_exports_the_lifecycle():
+    from bayesianinference_amd import _lib, build
+    _lib.load()                                        # maps libgphip.so (and its HIP runtime) first
+    path = build.build_wl_stub()
+    lib = C.CDLL(path)
+    for name in list(shim_argc()) + ["WolframLibrary_getVersion", "WolframLibrary_initialize",
+                                      "WolframLibrary_uninitialize"]:
+        assert hasattr(lib, name), name
+    lib.WolframLibrary_getVersion.restype = C.c_int64
+    assert lib.WolframLibrary_getVersion() >= 1
+    lib.drv_libdata.restype = C.c_void_p
+    data = C.c_void_p(lib.drv_libdata())
+    assert lib.WolframLibrary_initialize(data) == 0
+    # a wrong argument count is LIBRARY_FUNCTION_ERROR (6) before anything is touched
+    for name, n in shim_argc().items():
+        fn = getattr(lib, name)
+        fn.restype = C.c_int
+        fn.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+        assert fn(data, n + 1, None, None) == 6, name
+
+
+def test_wl_package_keeps_reference_shapes():
+    text = open(WL).read()
+    for key in ('"KernelFunction"', '"NuggetFunction"', '"MeanFunction"', '"CovarianceFunction"',
+                '"InverseCovarianceFunction"', '"LogLikelihoodFunction"', '"Data"', '"PriorDistribution"',
+                '"Parameters"'):                       # BGP:310-325
+        assert key in text, key
+    assert '"Inverse" ->' in text and '"LogDet" ->' in text            # BGP:137-141
+    assert 'Throw[$MachineLogZero, "MatInv"]' in text                  # BGP:133
+    # the HIP prediction rule must be PREPENDED to the reference's down-values (an appended rule
+    # of equal specificity is never reached)
+    assert re.search(r"DownValues\[predictFromGaussianProcess\]\s*=\s*Prepend\[", text)
+    assert re.search(r"DownValues\[predictiveDistribution\]\s*=\s*Prepend\[", text)
