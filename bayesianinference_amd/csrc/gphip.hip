@@ -150,13 +150,13 @@ hipEvent_t get_event(gphip_ctx* h) {
     return e;
 }
 
-// profile levels: 1 = trailing SYRK + whole eval, 2 = every class
+// profile levels: 1 = kbuild + trailing SYRK + whole eval + prediction epilogue, 2 = every class
 struct ProfScope {
     gphip_ctx* h;
     bool on;
     ProfRec r;
     ProfScope(gphip_ctx* h_, int cls, double flops, double bytes) : h(h_) {
-        on = h->profile >= 2 || (h->profile == 1 && cls >= 4);
+        on = h->profile >= 2 || (h->profile == 1 && (cls >= 4 || cls == 0));   // 1: kbuild, trailing SYRK, totals, epilogue
         if (on) {
             r.cls = cls;
             r.flops = flops;
@@ -326,7 +326,16 @@ void launch_gemm(gphip_ctx* h, int cls, T* C, long ldc, long cbs, const T* A, lo
         g.super = 1;
         grid_x = nsuper * 64;
     }
-    const double flops = 2.0 * TB * TB * (double)K * g.ntiles * nslots;
+    double flops = 2.0 * TB * TB * (double)K * g.ntiles * nslots;       // tile-granular (what the MFMA pipe executes)
+    if (cls == 4 && tri && r0 == c0) {
+        // trailing SYRK: report ALGORITHMIC flops (m (m+1) nb for a trailing matrix of m true
+        // columns and a panel of width nb) -- full diagonal tiles, identity padding and the bordered rhs block-row
+        // are executed but not counted.  General form for the tile columns [c0, c1) of an N-column matrix:
+        // 2 K sum_{j = a}^{b-1} (N - j),  a = 128 c0, b = min(128 c1, N)
+        const double a = (double)c0 * TB, b = std::min((double)c1 * TB, (double)h->N);
+        const double cnt = b > a ? b - a : 0.0;
+        flops = 2.0 * (double)K * (cnt * (double)h->N - (a + b - 1.0) * cnt / 2.0) * nslots;
+    }
     // algorithmic bytes: C tiles read + written once, each operand panel streamed once
     const double bytes = (double)sizeof(T) * nslots * (2.0 * TB * TB * g.ntiles + (double)(tri ? H : H + W) * TB * K);
     ProfScope ps(h, cls == 6 ? 3 : cls, flops, bytes);

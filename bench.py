@@ -21,6 +21,7 @@ from __future__ import annotations
 
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -32,13 +33,28 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 FP64_MFMA_PEAK_TFLOPS = 78.6      # 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz (v_mfma_f64_16x16x4_f64)
+FP32_MFMA_PEAK_TFLOPS = 157.3     # v_mfma_f32_16x16x4_f32: 64 flop/clk/SIMD
+HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 
 
-def cpu_baseline(n_full: int, d: int, sample_n: int = 4096, reps: int = 2) -> dict:
-    """Times the CPU oracle (scipy LAPACK LU, the algorithm LinearSolve uses) on a bounded sample
-    and scales it to the metric's unit (evals/s at n_full): the kernel-matrix build with its
-    quadratic cost, the factorisation + solve with its cubic cost, timed separately.  For
-    information it also times a Cholesky variant of the same sample and cfg 1 (N=512, d=1) whole."""
+def _roof(cls: dict, peak: float, unit: str, what: str) -> dict:
+    """roofline entry from one profile class (HIP events on the library's own stream): algorithmic flops or bytes
+    per launch / average launch time"""
+    if cls["ms"] <= 0 or cls["launches"] <= 0:
+        return {}
+    work = cls["flops"] if unit == "TFLOP/s" else cls["bytes"]
+    ach = work / (cls["ms"] * 1e-3) / (1e12 if unit == "TFLOP/s" else 1e9)
+    return {"kernel": what, "bound": "mfma" if unit == "TFLOP/s" else "hbm", "achieved": ach, "peak": peak, "unit": unit,
+            "frac": ach / peak, "launches": int(cls["launches"]), "avg_launch_ms": cls["ms"] / cls["launches"],
+            "algorithmic_per_launch": work / cls["launches"]}
+
+
+def cpu_baseline(n_full: int, d: int, sizes=(4096, 8192)) -> dict:
+    """Times the CPU oracle (numpy kernel-matrix build + scipy LAPACK LU, the algorithm LinearSolve uses) on a
+    BOUNDED sample -- whole evaluations at N = 4096 and N = 8192 -- and scales the larger one to the metric's unit
+    (evals/s at n_full): the build with its quadratic cost, the factorisation + solve with its cubic cost.  The
+    exponents fitted between the two sizes are printed so the extrapolation can be checked.  For information it
+    also times a Cholesky variant and cfg 1 (N=512, d=1) whole."""
     from oracle import gp_oracle as orc
     from bayesianinference_amd import synthetic as syn
     import scipy.linalg as sla
@@ -47,9 +63,6 @@ def cpu_baseline(n_full: int, d: int, sample_n: int = 4096, reps: int = 2) -> di
         threads = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
     except Exception:
         threads = os.cpu_count() or 1
-    X, y = syn.make_dataset(sample_n, d)
-    th = syn.default_theta("se_ard", d)
-    orc.log_likelihood("se_ard", th, X[:512], y[:512])
 
     def limited(nthreads):
         from contextlib import nullcontext
@@ -59,8 +72,13 @@ def cpu_baseline(n_full: int, d: int, sample_n: int = 4096, reps: int = 2) -> di
         except Exception:
             return nullcontext()
 
-    def timed(nthreads):
+    th = syn.default_theta("se_ard", d)
+    data = {n: syn.make_dataset(n, d) for n in sizes}
+    orc.log_likelihood("se_ard", th, data[sizes[0]][0][:512], data[sizes[0]][1][:512])
+
+    def timed(n, nthreads, reps):
         """(build s, LU factor + solve + formula s) per evaluation, oracle functions only."""
+        X, y = data[n]
         tb = tf = 0.0
         with limited(nthreads):
             for i in range(reps):
@@ -76,15 +94,20 @@ def cpu_baseline(n_full: int, d: int, sample_n: int = 4096, reps: int = 2) -> di
                 tf += t2 - t1
         return tb / reps, tf / reps
 
-    # LAPACK on very many threads can be slower than on fewer: report the best of a short ladder
+    # LAPACK on very many threads can be slower than on fewer: pick the best of a short ladder at the small size
     ladder = sorted({t for t in (16, 32, 64, threads) if t <= threads})
-    results = {t: timed(t) for t in ladder}
-    threads = min(results, key=lambda t: sum(results[t]))
-    tb, tf = results[threads]
-    s2, s3 = (n_full / sample_n) ** 2, (n_full / sample_n) ** 3
-    est = tb * s2 + tf * s3
+    small = {t: timed(sizes[0], t, 2) for t in ladder}
+    threads = min(small, key=lambda t: sum(small[t]))
+    tb0, tf0 = small[threads]
+    tb1, tf1 = timed(sizes[1], threads, 1)
+    ratio = math.log(sizes[1] / sizes[0])
+    exp_build, exp_lu = math.log(tb1 / tb0) / ratio, math.log(tf1 / tf0) / ratio
+    s2, s3 = (n_full / sizes[1]) ** 2, (n_full / sizes[1]) ** 3
+    est = tb1 * s2 + tf1 * s3
+    est_fitted = tb1 * (n_full / sizes[1]) ** exp_build + tf1 * (n_full / sizes[1]) ** exp_lu
 
     with limited(threads):                       # information only: SPD-aware variant, and cfg 1 as is
+        X, y = data[sizes[0]]
         K = orc.covariance_matrix("se_ard", th, X)
         t0 = time.perf_counter()
         c = sla.cho_factor(K, lower=True, overwrite_a=True, check_finite=False)
@@ -98,10 +121,17 @@ def cpu_baseline(n_full: int, d: int, sample_n: int = 4096, reps: int = 2) -> di
         t_cfg1 = (time.perf_counter() - t0) / 5
     return {"value": 1.0 / est, "unit": "evals/s", "cores": int(threads), "kind": "port",
             "sample": f"CPU oracle (numpy build + scipy dgetrf/dgetrs LU restatement of BGP:29-43,130-141,"
-                      f"181-199; not Mathematica) timed at N={sample_n} d={d} x{reps}: build {tb:.3f} s "
-                      f"scaled by (N/{sample_n})^2={s2:.0f}, LU+solve {tf:.3f} s scaled by "
-                      f"(N/{sample_n})^3={s3:.0f} => {est:.1f} s/eval at N={n_full}",
-            "also": {"cholesky_variant_s_at_sample": round(t_chol, 4),
+                      f"181-199; not Mathematica) timed whole at N={sizes[0]} (x2) and N={sizes[1]} (x1), d={d}: "
+                      f"N={sizes[1]}: build {tb1:.3f} s, LU+solve {tf1:.3f} s; scaled by (N/{sizes[1]})^2={s2:.0f} and "
+                      f"^3={s3:.0f} => {est:.1f} s/eval at N={n_full}",
+            "measured": {f"N{sizes[0]}": {"build_s": round(tb0, 4), "lu_solve_s": round(tf0, 4)},
+                         f"N{sizes[1]}": {"build_s": round(tb1, 4), "lu_solve_s": round(tf1, 4)}},
+            "fitted_exponents": {"build": round(exp_build, 3), "lu_solve": round(exp_lu, 3),
+                                 "s_per_eval_at_n_full_with_fitted_exponents": round(est_fitted, 1),
+                                 "note": "value uses the asymptotic laws (N^2 build, N^3 LU) from the larger sample; an "
+                                         "LU exponent below 3 means the threaded LAPACK is still gaining efficiency at "
+                                         "this size, so the true CPU time at n_full lies between the two estimates"},
+            "also": {"cholesky_variant_s_at_N%d" % sizes[0]: round(t_chol, 4),
                      "cfg1_N512_d1_evals_per_s": round(1.0 / t_cfg1, 2)}}
 
 
@@ -169,15 +199,23 @@ def other_configs(local_rank: int) -> dict:
         th = syn.default_theta("matern52_ard", d, dtype="f32")
         h = _lib.Handle(X, y, "matern52_ard", dtype=32, device=local_rank)
         h.loglik(th)
+        h.set_option("profile", 1)
+        h.reset_profile()
         t0 = time.perf_counter()
         info = h.fit(th)
         tf = time.perf_counter() - t0
         t0 = time.perf_counter()
         mu, var = h.predict(syn.make_test_points(m, d))
         tp = time.perf_counter() - t0
-        out["cfg5_matern52_n65536_d16_f32"] = {"fit_ms": tf * 1e3, "cholesky_tflops": n ** 3 / 3 / tf / 1e12,
-                                               "predict_10k_ms": tp * 1e3, "info": int(info),
-                                               "finite": bool(np.all(np.isfinite(mu)) and np.all(var > 0))}
+        prof = h.profile()
+        out["cfg5_matern52_n65536_d16_f32"] = {
+            "fit_ms": tf * 1e3, "cholesky_tflops": n ** 3 / 3 / tf / 1e12, "predict_10k_ms": tp * 1e3, "info": int(info),
+            "finite": bool(np.all(np.isfinite(mu)) and np.all(var > 0)),
+            "roofline_syrk_f32": _roof(prof["syrk_trailing"], FP32_MFMA_PEAK_TFLOPS, "TFLOP/s",
+                                       "gemm_nt_kernel<float, 0, 2, 2, 2> (trailing SYRK, v_mfma_f32_16x16x4_f32)"),
+            "roofline_kbuild_f32": _roof(prof["kbuild"], HBM_PEAK_GBS, "GB/s", "kbuild_kernel<float, 16, 1> (Matern-5/2, d=16)"),
+            "roofline_predict_epilogue_f32": _roof(prof["predict_epilogue"], HBM_PEAK_GBS, "GB/s",
+                                                   "predict_partial_kernel<float> + predict_finish_kernel (V streamed once)")}
         h.close()
     except Exception as exc:
         out["cfg5_error"] = repr(exc)
@@ -192,10 +230,12 @@ def main() -> None:
     ap.add_argument("--n", type=int, default=32768)
     ap.add_argument("--d", type=int, default=8)
     ap.add_argument("--panel", type=int, default=0)
-    ap.add_argument("--mode", choices=["theta", "cholesky"], default="theta",
+    ap.add_argument("--mode", choices=["theta", "cholesky", "cholesky-torch"], default="theta",
                     help="N>1 only. theta (default): ranks evaluate disjoint theta, no data-path collective, "
                          "weak scaling.  cholesky: ONE evaluation per step sharded over all ranks with the 1-D "
-                         "block-cyclic Cholesky (RCCL broadcast of factored panels), strong scaling.")
+                         "block-cyclic Cholesky (RCCL broadcast of factored panels) run INSIDE the library through "
+                         "the C ABI (gphip_create_rank), strong scaling.  cholesky-torch: the same schedule driven by "
+                         "the Python harness (dist_cholesky.py, torch.distributed broadcasts).")
     ap.add_argument("--supertile", type=int, default=0, help="experiment: XCD-private 8x8 super-tile order")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the short BASELINE.json cfg-4 / cfg-5 measurements")
@@ -222,7 +262,17 @@ def main() -> None:
 
     n, d = args.n, args.d
     X, y = syn.make_dataset(n, d)                      # every rank regenerates the same data
-    h = _lib.Handle(X, y, "se_ard", device=local_rank)
+    sharded = dist is not None and args.mode in ("cholesky", "cholesky-torch")
+    if sharded and args.mode == "cholesky":
+        # ONE likelihood factored by all GPUs together, entirely behind the C ABI: rank 0 draws the RCCL id
+        # (gphip_comm_unique_id), torch.distributed only hands the 128 bytes round, every rank creates its handle
+        # with gphip_create_rank, and gphip_loglik is then a collective call (include/gphip.h)
+        box = [_lib.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        h = _lib.Handle(X, y, "se_ard", device=local_rank, rank=rank, world=world, comm_id=box[0])
+        h.set_option("shard_min_n", 0)
+    else:
+        h = _lib.Handle(X, y, "se_ard", device=local_rank)
     if args.panel:
         h.set_option("panel", args.panel)
     if args.supertile:
@@ -238,19 +288,18 @@ def main() -> None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    sharded = dist is not None and args.mode == "cholesky"
+    evaluate = h.loglik
     if sharded:
-        # every rank steps through the SAME theta; one likelihood is factored by all GPUs together
-        from bayesianinference_amd.dist_cholesky import DistributedCholesky, TorchDistComm
+        # every rank steps through the SAME theta
         jit0 = syn.uniform(syn.STREAM_THETA, 1000, total_steps * (d + 2))
         thetas = base[None, :] * (1.0 + 0.05 * (jit0.reshape(total_steps, d + 2) - 0.5))
-        dc = DistributedCholesky({rank: h}, TorchDistComm(dist), device=local_rank)
+        if args.mode == "cholesky-torch":              # the Python/torch.distributed harness of the same schedule
+            from bayesianinference_amd.dist_cholesky import DistributedCholesky, TorchDistComm
+            dc = DistributedCholesky({rank: h}, TorchDistComm(dist), device=local_rank)
 
-        def evaluate(th):
-            ll, _, _, info = dc.loglik(th)
-            return ll, info
-    else:
-        evaluate = h.loglik
+            def evaluate(th):
+                ll, _, _, info = dc.loglik(th)
+                return ll, info
 
     for i in range(args.warmup):
         evaluate(thetas[i])
@@ -291,13 +340,19 @@ def main() -> None:
             "roofline": {"bound": "mfma", "kernel": "gemm_nt_kernel<double, 0, 2, 2, 2> (trailing SYRK, v_mfma_f64_16x16x4_f64)",
                          "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
+                         "flops": "algorithmic m(m+1) nb per launch (SURVEY.md 8d), summed over the timed launches",
                          "launches": int(syrk["launches"]), "avg_launch_ms": syrk["ms"] / max(syrk["launches"], 1),
                          "traffic": None},
+            # second target of north_star: >= 60 % of the HBM roofline on the kernel-matrix build, measured in THIS run
+            "roofline_kbuild": _roof(prof["kbuild"], HBM_PEAK_GBS, "GB/s",
+                                     "kbuild_kernel<double, 8, 0> (SE-ARD d=8; bytes = 8 [N(N+1)/2 + N d])"),
         }
         tr = pmc_traffic()
         if tr is not None:
+            # NOT measured in this run: PMC counters need their own rocprofv3 passes (profiles/); replayed for reference
             out["roofline"]["traffic"] = tr["bytes_per_launch"]
-            out["roofline"]["traffic_unit"] = "HBM-side bytes per launch (rocprofv3 PMC, " + tr["source"] + ")"
+            out["roofline"]["traffic_replayed_from"] = "profiles/" + tr["source"]
+            out["roofline"]["traffic_unit"] = "HBM-side bytes per launch (rocprofv3 PMC: 2 x FETCH_SIZE + WRITE_SIZE, KiB -> B)"
             out["roofline"]["algorithmic_bytes_per_launch"] = syrk["bytes"] / max(syrk["launches"], 1)
         if world == 1 and not args.no_extras:
             h.close()                                           # free the 8.7 GB workspace first

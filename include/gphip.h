@@ -128,7 +128,7 @@ int gphip_logdet(gphip_handle h, double* out);
 
 /* Options (tuning knobs; results do not depend on them beyond rounding order):
  *   "panel"        outer panel width in 128-tiles (default 4)
- *   "profile"      0 off, 1 trailing SYRK + whole evaluation, 2 every kernel class
+ *   "profile"      0 off, 1 kernel build + trailing SYRK + whole evaluation + prediction epilogue, 2 every kernel class
  *   "xcd_swizzle"  0/1 XCD-aware tile order of the GEMM launches (default 1)
  *   "supertile"    0/1 8x8 super-tile order of the trailing SYRK (default 0, measured slower)
  *   "lookahead"    0/1 factor panel k+1 on a second stream under the trailing update of panel k (default 1)
@@ -155,7 +155,8 @@ int gphip_get_option(gphip_handle h, const char* name, double* value);
 
 /* Per-kernel-class timing, measured with HIP events on the handle's stream while "profile"=1.
  * class: 0 kbuild, 1 potrf, 2 trsm, 3 gemm (in-panel), 4 gemm/syrk (trailing), 5 total eval, 6 prediction epilogue.
- * Returns accumulated milliseconds, launches, algorithmic flops and bytes since the last reset. */
+ * Returns accumulated milliseconds, launches, algorithmic flops and bytes since the last reset (class 4: flops =
+ * m (m+1) nb per launch, SURVEY.md §8d -- not the tile-granular count the MFMA pipe executes). */
 #define GPHIP_NCLASS 7
 int gphip_get_profile(gphip_handle h, int cls, double* ms, double* launches, double* flops,
                       double* bytes);

@@ -25,4 +25,4 @@ print(f"N={n} single: {dt*1e3:.2f} ms/eval, {1/dt:.1f} evals/s, {n**3/3/dt/1e12:
 h.set_option("profile", 2); h.reset_profile(); h.loglik_batch(Th)
 for k, v in h.profile().items():
     if v["launches"]:
-        print(f"   {k:14s} {v['ms']:9.3f} ms  {int(v['launches']):5d} launches")
+        print(f"   {k:14s} {v['ms']:9.3f} ms  {int(v['launches']):5d} launches  {v['flops']/max(v['ms'],1e-9)/1e9:8.2f} TFLOP/s")

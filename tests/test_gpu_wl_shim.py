@@ -142,10 +142,10 @@ def test_every_shim_entry_point_through_a_fake_wolfram_library_data():
     np.testing.assert_allclose(r[2:], g, rtol=1e-7, atol=1e-7 * np.abs(g).max())
 
     # fit -> info; then "Inverse" (vector AND matrix, BGP:194, 416), "LogDet", predict
-    assert K.call("gphip_wl_logdet", [h], "real")[0] == FUNCTION_ERROR                    # nothing fitted: GPHIP_ERR_STATE
     sing = th.copy(); sing[-1] = 0.0
     Xd = X.copy(); Xd[5] = Xd[200]
     rc, hd = K.call("gphip_wl_create", [Xd, y, 1, 0, 64, np.array([0])], "int")
+    assert K.call("gphip_wl_logdet", [hd], "real")[0] == FUNCTION_ERROR                   # nothing fitted: GPHIP_ERR_STATE
     assert K.call("gphip_wl_fit", [hd, sing], "int") == (NO_ERROR, 1)                     # not SPD: a value
     assert K.call("gphip_wl_fit", [h, th], "int") == (NO_ERROR, 0)
     Kmat = orc.covariance_matrix("se_ard", th, X)
