@@ -31,18 +31,20 @@ def needs_build() -> bool:
     return any(os.path.getmtime(p) > t for p in DEPS if os.path.exists(p))
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    if not force and not needs_build():
+def build(force: bool = False, verbose: bool = False, out: str | None = None) -> str:
+    """out: build to this path instead of the in-tree library (always a full compile; tests/test_clean_build.py)."""
+    if out is None and not force and not needs_build():
         return LIB
-    os.makedirs(os.path.dirname(LIB), exist_ok=True)
+    target = out or LIB
+    os.makedirs(os.path.dirname(target), exist_ok=True)
     cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-Wall", "-Wno-unused-function", "-o", LIB, SRC, "-ldl", "-lpthread"]
+           "-Wall", "-Wno-unused-function", "-o", target, SRC, "-ldl", "-lpthread"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
         raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
-    return LIB
+    return target
 
 
 ROOT = os.path.dirname(PKG)
