@@ -23,6 +23,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 namespace gphip {
 
 constexpr int TB = 128;         // tile edge
@@ -763,6 +765,11 @@ struct GemmArgs {
     int mode;                                    // ROLE 3 only: 0: C -= A B ; 1: C = A B
     int ktri;                                    // 1: tile (ti,tj) contracts k >= ti*128 only (operands upper
                                                  //    triangular in (row, k): the U U^T product of the gradient)
+    int thin_row;                                // tile row whose rows beyond the first are zero and stay zero (the bordered
+                                                 //    right-hand-side block-row of the factorisation: only r^T is real); -1: none
+    int skip_upper;                              // 1: diagonal tiles of a triangular update leave their strictly-upper 64x64
+                                                 //    quadrant alone (nothing reads it: potrf128 and the dataflow tail take the
+                                                 //    lower sub-tiles only)
 };
 
 template <typename T>
@@ -891,12 +898,25 @@ __global__ __launch_bounds__(64 * NWI * NWJ, (NWI * NWJ == 4) ? 2 : 4) void gemm
     // as C - A B^T and the epilogue is stores only.
     const bool from_zero = (ROLE == 2) || (ROLE == 3 && g.mode == 1);
     acc_t acc[FJ][FI];
-    auto load_c = [&]() {
+    // MFMA row-tiles (of FI) this wave really has to compute -- wave-uniform, decided once:
+    //   thin row tile: only row 0 of the 128 bordered rows is non-zero -> wave column wi = 0 computes its first
+    //     16-row MFMA tile (FJ MFMAs per k-group instead of FJ*FI), wave column wi = 1 none; the skipped rows are
+    //     zero in memory and are neither loaded nor stored;
+    //   diagonal tile of a triangular update: the wave that owns the strictly-upper quadrant computes nothing.
+    // A skipping wave still stages its share of the LDS-DMA and meets every barrier.
+    int ny = FI;
+    if (NW == 4) {
+        const int uwi = uw % NWI, uwj = uw / NWI;
+        if (g.thin_row == ti) ny = (uwi == 0) ? 1 : 0;
+        else if (g.skip_upper && g.tri && ti == tj && uwi == 0 && uwj == 1) ny = 0;
+    }
+    auto load_c = [&](auto nyc) {
+        constexpr int NY = decltype(nyc)::value;
 #pragma unroll
         for (int x = 0; x < FJ; ++x)
 #pragma unroll
             for (int y = 0; y < FI; ++y) {
-                if (from_zero || (GP_DIAG & 2)) {
+                if (from_zero || (GP_DIAG & 2) || y >= NY) {
                     acc[x][y] = (acc_t){0, 0, 0, 0};
                 } else {
 #pragma unroll
@@ -934,21 +954,22 @@ __global__ __launch_bounds__(64 * NWI * NWJ, (NWI * NWJ == 4) ? 2 : 4) void gemm
 #pragma unroll
         for (int f = 0; f < FJ; ++f) asm volatile("" : "+v"(fj[f]));
     };
-    auto mfma_block = [&](const T* fi, const T* fj) {
+    auto mfma_block = [&](const T* fi, const T* fj, auto nyc) {
+        constexpr int NY = decltype(nyc)::value;
         T nj[FJ];
 #pragma unroll
         for (int f = 0; f < FJ; ++f) nj[f] = from_zero ? fj[f] : -fj[f];
 #pragma unroll
         for (int x = 0; x < FJ; ++x)
 #pragma unroll
-            for (int y = 0; y < FI; ++y) acc[x][y] = Num<T>::mfma(nj[x], fi[y], acc[x][y]);
+            for (int y = 0; y < NY; ++y) acc[x][y] = Num<T>::mfma(nj[x], fi[y], acc[x][y]);
     };
     auto compute = [&](int buf) {
         T fi[FI], fj[FJ];
 #pragma unroll
         for (int kk = 0; kk < GK / 4; ++kk) {
             load_frags(buf, kk, fi, fj);
-            mfma_block(fi, fj);
+            mfma_block(fi, fj, std::integral_constant<int, FI>{});
         }
     };
     if constexpr (NBUF == 2) {
@@ -957,44 +978,65 @@ __global__ __launch_bounds__(64 * NWI * NWJ, (NWI * NWJ == 4) ? 2 : 4) void gemm
         // right after the barrier, under the last group's MFMAs -- no LDS latency is exposed.
         constexpr int NKK = GK / 4;
         static_assert(NKK % 2 == 0, "fragment set parity must repeat every stage");
-        T fa[2][FI], fb[2][FJ];
+        auto pipeline = [&](auto nyc) {
+            constexpr int NY = decltype(nyc)::value;
+            T fa[2][FI], fb[2][FJ];
 #ifdef GP_STAGGER
-        if (ROLE == 0 && (blockIdx.x & 256) && blockIdx.x < 512)
-            for (int i = 0; i < GP_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
+            if (ROLE == 0 && (blockIdx.x & 256) && blockIdx.x < 512)
+                for (int i = 0; i < GP_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
 #endif
-        stage(0, 0);
-        load_c();                                          // C loads fly with the first DMA stage
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        load_frags(0, 0, fa[0], fb[0]);
-        for (int kb = 0; kb < nk; ++kb) {
-            const int cur = kb & 1;
-            if (kb + 1 < nk && !((GP_DIAG & 1) && kb >= 1)) stage(kb + 1, cur ^ 1);   // DMA of the next stage flies under the MFMAs
+            stage(0, 0);
+            load_c(nyc);                                       // C loads fly with the first DMA stage
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (NY > 0) load_frags(0, 0, fa[0], fb[0]);
+            for (int kb = 0; kb < nk; ++kb) {
+                const int cur = kb & 1;
+                if (kb + 1 < nk && !((GP_DIAG & 1) && kb >= 1)) stage(kb + 1, cur ^ 1);   // DMA of the next stage flies under the MFMAs
+                if (NY > 0) {
 #pragma unroll
-            for (int kk = 0; kk + 1 < NKK; ++kk) {
-                pin_frags(fa[kk & 1], fb[kk & 1]);         // the compiler's LDS wait lands HERE ...
-                __builtin_amdgcn_sched_barrier(0);
-                load_frags(cur, kk + 1, fa[(kk + 1) & 1], fb[(kk + 1) & 1]);   // ... before these reads
-                __builtin_amdgcn_sched_barrier(0);
-                mfma_block(fa[kk & 1], fb[kk & 1]);
-                __builtin_amdgcn_sched_barrier(0);
+                    for (int kk = 0; kk + 1 < NKK; ++kk) {
+                        pin_frags(fa[kk & 1], fb[kk & 1]);     // the compiler's LDS wait lands HERE ...
+                        __builtin_amdgcn_sched_barrier(0);
+                        load_frags(cur, kk + 1, fa[(kk + 1) & 1], fb[(kk + 1) & 1]);   // ... before these reads
+                        __builtin_amdgcn_sched_barrier(0);
+                        mfma_block(fa[kk & 1], fb[kk & 1], nyc);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    // every read of this stage has landed: once this wave's DMA has too, the barrier both
+                    // publishes the next stage and frees this buffer for the DMA after next
+                    pin_frags(fa[(NKK - 1) & 1], fb[(NKK - 1) & 1]);
+                }
+                if (!(GP_DIAG & 8)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (!(GP_DIAG & 4)) __builtin_amdgcn_s_barrier();
+                if (NY > 0) {
+                    if (kb + 1 < nk) load_frags(cur ^ 1, 0, fa[0], fb[0]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mfma_block(fa[(NKK - 1) & 1], fb[(NKK - 1) & 1], nyc);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
-            // every read of this stage has landed: once this wave's DMA has too, the barrier both
-            // publishes the next stage and frees this buffer for the DMA after next
-            pin_frags(fa[(NKK - 1) & 1], fb[(NKK - 1) & 1]);
-            if (!(GP_DIAG & 8)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (!(GP_DIAG & 4)) __builtin_amdgcn_s_barrier();
-            if (kb + 1 < nk) load_frags(cur ^ 1, 0, fa[0], fb[0]);
-            __builtin_amdgcn_sched_barrier(0);
-            mfma_block(fa[(NKK - 1) & 1], fb[(NKK - 1) & 1]);
-            __builtin_amdgcn_sched_barrier(0);
-        }
+            // epilogue: stores only
+            if ((GP_DIAG & 2) && acc[0][0][0] != (typename Num<T>::acc_t){1, 2, 3, 4}[0]) return;
+#pragma unroll
+            for (int x = 0; x < FJ; ++x)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    T* cp = Cg + (long)(x * 16 + Num<T>::drow(l4, r)) * g.ldc;
+#pragma unroll
+                    for (int y = 0; y < NY; ++y) cp[y * 16] = acc[x][y][r];
+                }
+        };
+        if (ny == FI) pipeline(std::integral_constant<int, FI>{});
+        else if (ny == 1) pipeline(std::integral_constant<int, 1>{});
+        else pipeline(std::integral_constant<int, 0>{});
+        return;
     } else {
         // deep pipeline: NBUF-1 stages in flight; every wave issues IPS DMA instructions per stage
         constexpr int AHEAD = NBUF - 1;
         constexpr int IPS = 2 * ((16 + NW - 1) / NW);      // I + J instructions per wave per stage
         static_assert(NBUF == 4 && IPS == 2, "counted waits below are written for 4 buffers, 16 waves");
-        load_c();
+        load_c(std::integral_constant<int, FI>{});
         for (int st = 0; st < AHEAD && st < nk; ++st) stage(st, st);
         for (int kb = 0; kb < nk; ++kb) {
             const int rem = nk - 1 - kb;                   // stages issued beyond kb (capped at AHEAD-1)

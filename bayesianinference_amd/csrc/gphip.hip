@@ -74,6 +74,7 @@ struct gphip_ctx {
     int panel_left = -1;                         // in-panel updates left-looking: -1 auto (batches), 0 never, 1 always
     int fuse_option = 1;                         // allow the single-launch evaluation (option "fused_eval")
     int grad_potri = 1;                          // gradient: K^-1 = U U^T in one go when the memory is there
+    int thin_tiles = 1;                          // gemm_nt: skip the zero rows of the rhs block-row and the unread upper quadrant of diagonal tiles
     int dataflow_tail = 64;                      // large N: the last <= dataflow_tail tile columns go to the dataflow kernel (0 = off)
     bool fused_eval = false;                     // eval_chunk: the whole evaluation is ONE dataflow launch (build + factor + results)
     bool theta_packed = false;                   // eval_chunk: hyper-parameters travel as kernel arguments (k_scale_theta)
@@ -298,10 +299,15 @@ int queue_build(gphip_ctx* h, int nslots) {
 // cls: profile class (2 panel solve, 3 in-panel/look-ahead GEMM, 4 trailing SYRK, 6 = "NN" role)
 template <typename T>
 void launch_gemm(gphip_ctx* h, int cls, T* C, long ldc, long cbs, const T* A, long lda, long abs_, const T* B,
-                 long ldb, long bbs, int K, int r0, int r1, int c0, int c1, int tri, int nslots, int mode = 0, int ktri = 0) {
+                 long ldb, long bbs, int K, int r0, int r1, int c0, int c1, int tri, int nslots, int mode = 0, int ktri = 0,
+                 int thin_row = -1) {
     GemmArgs<T> g{};
     g.mode = mode;
     g.ktri = ktri;
+    // factorisation launches only (thin_row given): the bordered rhs block-row carries ONE real row, and nothing reads
+    // the strictly-upper quadrant of a diagonal tile -- both are skipped inside the kernel (option "thin_tiles")
+    g.thin_row = h->thin_tiles ? thin_row : -1;
+    g.skip_upper = (h->thin_tiles && thin_row >= 0 && tri && mode == 0 && !ktri) ? 1 : 0;
     g.C = C; g.ldc = ldc; g.c_bstride = cbs;
     g.A = A; g.lda = lda; g.a_bstride = abs_;
     g.B = B; g.ldb = ldb; g.b_bstride = bbs;
@@ -385,7 +391,7 @@ int queue_panel(gphip_ctx* h, int K0, int nin, int nslots) {
         const int b = K0 + s;
         if (left && s > 0) {
             const T* P = A + (long)K0 * TB * ld;
-            launch_gemm<T>(h, 3, A, ld, bs, P, ld, bs, P, ld, bs, s * TB, b, R, b, b + 1, 1, nslots);
+            launch_gemm<T>(h, 3, A, ld, bs, P, ld, bs, P, ld, bs, s * TB, b, R, b, b + 1, 1, nslots, 0, 0, Nt);
         }
         {
             ProfScope ps(h, 1, 2.0 * TB * TB * TB / 3.0 * nslots, 0.0);
@@ -394,10 +400,10 @@ int queue_panel(gphip_ctx* h, int K0, int nin, int nslots) {
         }
         // panel solve X <- X W_b^T for every row tile below the diagonal block (incl. rhs rows)
         launch_gemm<T>(h, 2, A, ld, bs, A + (long)b * TB * ld, ld, bs, W + (long)b * TB * TB - (long)b * TB, TB, lrs,
-                       TB, b + 1, R, b, b + 1, 0, nslots, 1);
+                       TB, b + 1, R, b, b + 1, 0, nslots, 1, 0, Nt);
         if (!left && s + 1 < nin) {
             const T* P = A + (long)b * TB * ld;
-            launch_gemm<T>(h, 3, A, ld, bs, P, ld, bs, P, ld, bs, TB, b + 1, R, b + 1, K0 + nin, 1, nslots);
+            launch_gemm<T>(h, 3, A, ld, bs, P, ld, bs, P, ld, bs, TB, b + 1, R, b + 1, K0 + nin, 1, nslots, 0, 0, Nt);
         }
     }
     return 0;
@@ -512,7 +518,7 @@ int queue_factor(gphip_ctx* h, int nslots) {
     auto trailing = [&](int k, int c_lo, int c_hi, int cls) {      // apply panel k to tile columns [c_lo,c_hi)
         const T* Pk = A + (long)k0(k) * TB * ld;
         launch_gemm<T>(h, cls, A, ld, bs, Pk, ld, bs, Pk, ld, bs, (k0(k + 1) - k0(k)) * TB, c_lo, R, c_lo, c_hi, 1,
-                       nslots);
+                       nslots, 0, 0, Nt);
     };
     if (use_dataflow(h, nslots)) return queue_factor_dataflow<T>(h, nslots);
     double* tail_part = nullptr;               // a 64-tile dataflow tail keeps its block partials here
@@ -905,7 +911,7 @@ template <typename T>
 int queue_dist_update(gphip_ctx* h, const void* packed, long K0, long rows, long cols, int c_lo, int c_hi, int cls) {
     const T* base = (const T*)packed - K0 * TB;     // so that absolute tile row t sits at base + t*128
     launch_gemm<T>(h, cls, (T*)h->dA, h->ld, 0, base, rows, 0, base, rows, 0, (int)cols, c_lo, (int)h->Nt + 1, c_lo,
-                   c_hi, 1, 1);
+                   c_hi, 1, 1, 0, 0, (int)h->Nt);
     return 0;
 }
 
@@ -1712,6 +1718,7 @@ int* option_slot(gphip_ctx* h, const char* name) {
         {"dataflow_tail", &gphip_ctx::dataflow_tail}, {"grad_potri", &gphip_ctx::grad_potri},
         {"fused_eval", &gphip_ctx::fuse_option}, {"panel_left", &gphip_ctx::panel_left},
         {"max_slots", &gphip_ctx::max_slots}, {"shard_min_n", &gphip_ctx::shard_min_n},
+        {"thin_tiles", &gphip_ctx::thin_tiles},
     };
     for (const Entry& e : table)
         if (!strcmp(name, e.name)) return &(h->*(e.field));

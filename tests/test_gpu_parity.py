@@ -604,3 +604,34 @@ def test_prediction_epilogue_strips_and_profile():
         mpad, npad = -(-m // 128) * 128, -(-n // 128) * 128
         assert prof["launches"] == 2 and prof["bytes"] == 2 * 8.0 * mpad * npad and prof["ms"] > 0
         h.close()
+
+
+@pytest.mark.parametrize("n,d,dtype,batch", [(1100, 4, 64, 1), (700, 3, 64, 12), (1500, 5, 32, 3), (9000, 4, 64, 1)])
+def test_thin_tiles_skip_only_work_nobody_reads(n, d, dtype, batch):
+    """gemm_nt skips (a) all but the first 16 of the 128 bordered right-hand-side rows (rows 1.. are zero and
+    stay zero) and (b) the strictly-upper 64x64 quadrant of diagonal tiles (no kernel reads it).  Everything
+    that IS computed uses the same arithmetic in the same order, so results are bit-identical with the option off
+    -- likelihood parts and the fitted state behind predict / solve (and the gradient to rounding)."""
+    X, y = syn.make_dataset(n, d)
+    th = syn.default_theta("se_ard", d, dtype="f64" if dtype == 64 else "f32")
+    Th = np.stack([th * (1.0 + 0.03 * k) for k in range(batch)])
+    h = _lib.Handle(X, y, "se_ard", dtype=dtype)
+    h.set_option("dataflow", 0)                      # the multi-kernel schedule is what runs gemm_nt (bulk of N = 9000 too)
+    res = {}
+    for thin in (0, 1):
+        h.set_option("thin_tiles", thin)
+        parts = [h.loglik_parts(t) for t in Th[:2]]
+        out, info = h.loglik_batch(Th)
+        assert h.fit(th) == 0
+        mu, var = h.predict(X[:9])
+        alpha = h.solve(y)
+        grad = h.loglik_grad(th)[1] if n <= 2000 else None
+        res[thin] = (parts, out, info, mu, var, alpha, grad)
+    a, b = res[0], res[1]
+    assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    assert np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4]) and np.array_equal(a[5], b[5])
+    if a[6] is not None:                              # (the gradient's reduction uses fp64 atomics: order varies run to run)
+        np.testing.assert_allclose(a[6], b[6], rtol=1e-11 if dtype == 64 else 1e-4)
+    if dtype == 64 and n <= 2000:
+        assert close(b[0][0][0], orc.log_likelihood("se_ard", Th[0], X, y), n)
+    h.close()
