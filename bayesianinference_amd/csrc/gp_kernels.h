@@ -63,6 +63,35 @@ __device__ __forceinline__ double exp_nonpos(double x) {
 // fp32: v_exp_f32 (2^x) exists in hardware
 __device__ __forceinline__ float exp_nonpos(float x) { return __expf(fmaxf(x, -100.0f)); }
 
+// Table-driven variant for the HBM-bound kernel build, where the exp above is what the VALU spends its time on
+// (23 of the 82 instructions per pair of entries; the kernel runs at the post-idle shader clock and every VALU
+// instruction shows):   sf2 exp(-a w),  w >= 0,  a = 1/2 (squared exponential of r^2) or 1 (Matern's exp(-s5)).
+//   k = rint(-a w 512/ln2)                (round-to-integer by adding 1.5 2^52: k sits in the low mantissa bits)
+//   r = -a w - k ln2/512                  (|r| <= ln2/1024 = 6.8e-4; Cody-Waite split, k hi exact)
+//   sf2 exp = 2^(k >> 9) * TAB[k & 511] * (1 + r + r^2/2 + r^3/6 + r^4/24)      truncation r^5/120 < 1.3e-18
+// TAB[j] = sf2 2^(j/512) lives in LDS (4 KiB, filled per workgroup from a 512-entry device table of 2^(j/512)).
+// 15 VALU instructions instead of 23; <= 2.5 ulp.
+constexpr int EXP_TAB = 512;
+template <bool HALF>
+__device__ __forceinline__ double exp_tab(double w, const double* __restrict__ tab) {
+    constexpr double A = HALF ? 0.5 : 1.0;
+    constexpr double S = 738.6598609351493;                  // 512 / ln 2
+    constexpr double C_HI = 0.0013538030862036976;           // ln2 / 512, upper 31 bits (0x1.62e42fecp-10)
+    constexpr double C_LO = 8.274455792596258e-13;
+    constexpr double MAGIC = 6755399441055744.0;             // 1.5 * 2^52
+    w = fmin(w, 1600.0 / A);                                 // exp(-800) = 0 in fp64: keeps k inside the int range
+    const double t = __builtin_fma(w, -A * S, MAGIC);
+    const double kd = t - MAGIC;
+    double r = __builtin_fma(w, -A, kd * -C_HI);
+    r = __builtin_fma(kd, -C_LO, r);
+    double p = __builtin_fma(4.1666666666666664e-02, r, 1.6666666666666666e-01);
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    p = __builtin_fma(p, r, 1.0);
+    const int ki = __double2loint(t);
+    return __builtin_ldexp(tab[ki & (EXP_TAB - 1)] * p, ki >> 9);
+}
+
 // Per-type numerics and MFMA shape
 template <typename T> struct Num;
 template <> struct Num<double> {
@@ -84,6 +113,7 @@ template <> struct Num<double> {
     }
     static __device__ __forceinline__ double sqrt_(double x) { return __builtin_sqrt(x); }
     static __device__ __forceinline__ double rsqrt_(double x) { return rsqrt(x); }
+    static __device__ __forceinline__ double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
 };
 template <> struct Num<float> {
     typedef f4 acc_t;
@@ -99,6 +129,8 @@ template <> struct Num<float> {
     }
     static __device__ __forceinline__ float sqrt_(float x) { return __builtin_sqrtf(x); }
     static __device__ __forceinline__ float rsqrt_(float x) { return rsqrtf(x); }
+    // (__builtin_fma on floats silently promotes to fp64: three conversions per term)
+    static __device__ __forceinline__ float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 };
 
 // KT = 0: squared exponential  sf2 * exp(-r2/2)
@@ -179,6 +211,7 @@ struct KBuildArgs {
     int mode;               // 0: train x train (lower-tri tiles, nugget, identity padding, rhs rows)
                             // 1: cross  (rectangular tiles, zero padding)
     int nt_i, nt_j;         // tile counts; mode 0: nt_i = nt_j + 1 (extra rhs block-row)
+    const double* exp2tab;  // [EXP_TAB] 2^(j/512) (fp64 build only)
     int own_panel, own_world, own_rank;   // own_world > 0 (multi-GPU 1-D block-cyclic layout): build
                             // only tile columns whose outer panel (tj / own_panel) belongs to own_rank;
                             // the rhs x rhs corner tile belongs to rank 0
@@ -227,6 +260,10 @@ __global__ __launch_bounds__(256) void kbuild_kernel(KBuildArgs<T> a) {
     const T* xig = a.xi + (long)slot * a.xi_bstride + (long)ti * TB;
     T* xjs = lds;
     T* xis = lds + d * TB;
+    // fp64: sf2 2^(j/512) table behind the point tiles (see exp_tab)
+    double* etab = lds_raw + ((D > 0) ? D : 2 * d) * TB;
+    if (sizeof(T) == 8)
+        for (int idx = tid; idx < EXP_TAB; idx += 256) etab[idx] = sp[0] * a.exp2tab[idx];
     for (int idx = tid; idx < d * TB; idx += 256) {
         const int dd = idx >> 7, c = idx & 127;
         xjs[idx] = xjg[(long)dd * a.npad_j + c];
@@ -253,18 +290,31 @@ __global__ __launch_bounds__(256) void kbuild_kernel(KBuildArgs<T> a) {
             for (int dd = 0; dd < D; ++dd) {
                 const T xjv = xjs[dd * TB + jj];
                 const T da = xa[dd] - xjv, db = xb[dd] - xjv;
-                ra = __builtin_fma(da, da, ra);
-                rb = __builtin_fma(db, db, rb);
+                ra = Num<T>::fma_(da, da, ra);
+                rb = Num<T>::fma_(db, db, rb);
             }
         } else {
             for (int dd = 0; dd < d; ++dd) {
                 const T xjv = xjs[dd * TB + jj];
                 const T da = xis[dd * TB + r0] - xjv, db = xis[dd * TB + r0 + 1] - xjv;
-                ra = __builtin_fma(da, da, ra);
-                rb = __builtin_fma(db, db, rb);
+                ra = Num<T>::fma_(da, da, ra);
+                rb = Num<T>::fma_(db, db, rb);
             }
         }
-        T va = kfun<KT, T>(ra, sf2), vb = kfun<KT, T>(rb, sf2);
+        T va, vb;
+        if constexpr (sizeof(T) == 8) {
+            if (KT == 0) {
+                va = exp_tab<true>(ra, etab);
+                vb = exp_tab<true>(rb, etab);
+            } else {
+                const double sa = __builtin_sqrt(5.0 * ra), sb = __builtin_sqrt(5.0 * rb);
+                va = (1.0 + sa + (5.0 / 3.0) * ra) * exp_tab<false>(sa, etab);
+                vb = (1.0 + sb + (5.0 / 3.0) * rb) * exp_tab<false>(sb, etab);
+            }
+        } else {
+            va = kfun<KT, T>(ra, sf2);
+            vb = kfun<KT, T>(rb, sf2);
+        }
         if (edge) {
             const int gj = tj * TB + jj;
             if (a.mode == 0) {

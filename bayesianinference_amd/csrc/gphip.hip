@@ -59,6 +59,7 @@ struct gphip_ctx {
     double *dNullMu = nullptr, *dNullOut = nullptr;          // null-kernel path: per-theta mu and the two sums
     int null_cap = 0;
     void *dXt = nullptr, *dY = nullptr;                     // typed: [d][Npad], [Npad]
+    double* dExp2 = nullptr;                                // [EXP_TAB] 2^(j/512): the kernel build's exp table
     // batch workspace
     int slots = 0;
     void *dA = nullptr, *dXs = nullptr, *dW = nullptr;      // typed
@@ -248,15 +249,16 @@ int ensure_slots(gphip_ctx* h, int want) {
 template <typename T, int KT>
 void launch_kbuild_kt(gphip_ctx* h, const KBuildArgs<T>& a, dim3 grid) {
     const int d = a.d;
+    const size_t etab = sizeof(T) == 8 ? (size_t)EXP_TAB * 8 : 0;      // fp64: the sf2 2^(j/512) table behind the point tiles
 #define KB_CASE(DD)                                                                                 \
     case DD:                                                                                        \
-        hipLaunchKernelGGL((kbuild_kernel<T, DD, KT>), grid, dim3(256), (size_t)DD * TB * sizeof(T), h->cs, a); \
+        hipLaunchKernelGGL((kbuild_kernel<T, DD, KT>), grid, dim3(256), (size_t)DD * TB * sizeof(T) + etab, h->cs, a); \
         break;
     switch (d) {
         KB_CASE(1) KB_CASE(2) KB_CASE(3) KB_CASE(4) KB_CASE(5) KB_CASE(6) KB_CASE(7) KB_CASE(8)
         KB_CASE(16)
         default:
-            hipLaunchKernelGGL((kbuild_kernel<T, 0, KT>), grid, dim3(256), (size_t)2 * d * TB * sizeof(T), h->cs, a);
+            hipLaunchKernelGGL((kbuild_kernel<T, 0, KT>), grid, dim3(256), (size_t)2 * d * TB * sizeof(T) + etab, h->cs, a);
     }
 #undef KB_CASE
 }
@@ -287,7 +289,7 @@ int queue_build(gphip_ctx* h, int nslots) {
     a.out = (T*)h->dA; a.ld = h->ld; a.bstride = h->ld * h->ld;
     a.xi = (const T*)h->dXs; a.xj = (const T*)h->dXs; a.xi_bstride = a.xj_bstride = tot;
     a.npad_i = a.npad_j = (int)h->Npad; a.n_i = a.n_j = (int)h->N;
-    a.y = (const T*)h->dY; a.slotp = h->dSlotp; a.d = (int)h->d; a.mode = 0;
+    a.y = (const T*)h->dY; a.slotp = h->dSlotp; a.d = (int)h->d; a.mode = 0; a.exp2tab = h->dExp2;
     a.nt_i = (int)h->Nt + 1; a.nt_j = (int)h->Nt;
     a.own_panel = h->panel; a.own_world = h->dist_world; a.own_rank = h->dist_rank;
     const long ntiles = (long)(h->Nt + 1) * (h->Nt + 2) / 2;
@@ -872,6 +874,7 @@ int queue_cross(gphip_ctx* h, int64_t mc, int64_t mpad, int nslots) {
     a.xi = (const T*)h->dXsS; a.xj = (const T*)h->dXs; a.xi_bstride = tot; a.xj_bstride = (long)h->d * h->Npad;
     a.npad_i = (int)mpad; a.npad_j = (int)h->Npad; a.n_i = (int)mc; a.n_j = (int)h->N;
     a.y = nullptr; a.slotp = h->dSlotp; a.d = (int)h->d; a.mode = 1; a.nt_i = (int)(mpad / TB); a.nt_j = (int)h->Nt;
+    a.exp2tab = h->dExp2;
     launch_kbuild<T>(h, a, dim3((unsigned)((mpad / TB) * h->Nt), nslots));
     return 0;
 }
@@ -1075,6 +1078,12 @@ static int create_ctx(const void* X, const void* y, int64_t N, int64_t d, int ke
     }
     if (hipMalloc(&h->dXt, xt.size() * h->es) != hipSuccess) return bail(GPHIP_ERR_HIP);
     if (hipMalloc(&h->dY, yp.size() * h->es) != hipSuccess) return bail(GPHIP_ERR_HIP);
+    {
+        std::vector<double> tab(EXP_TAB);
+        for (int j = 0; j < EXP_TAB; ++j) tab[(size_t)j] = std::exp2((double)j / EXP_TAB);
+        if (hipMalloc(&h->dExp2, tab.size() * 8) != hipSuccess) return bail(GPHIP_ERR_HIP);
+        if (hipMemcpy(h->dExp2, tab.data(), tab.size() * 8, hipMemcpyHostToDevice) != hipSuccess) return bail(GPHIP_ERR_HIP);
+    }
     if (DISPATCH(h, upload, h, h->dXt, xt, h->stream) != GPHIP_OK) return bail(GPHIP_ERR_HIP);
     if (DISPATCH(h, upload, h, h->dY, yp, h->stream) != GPHIP_OK) return bail(GPHIP_ERR_HIP);
     if (DISPATCH(h, set_func_attrs, h) != GPHIP_OK) return bail(GPHIP_ERR_HIP);
@@ -1129,7 +1138,7 @@ int gphip_destroy(gphip_handle h) {
     (void)hipFree(h->dScal);
     if (h->cstream) (void)hipStreamDestroy(h->cstream);
     free_slots(h);
-    (void)hipFree(h->dXt); (void)hipFree(h->dY);
+    (void)hipFree(h->dXt); (void)hipFree(h->dY); (void)hipFree(h->dExp2);
     (void)hipFree(h->dV); (void)hipFree(h->dXsT); (void)hipFree(h->dXsS); (void)hipFree(h->dMean);
     (void)hipFree(h->dVar); (void)hipFree(h->dAlpha); (void)hipFree(h->dGacc); (void)hipFree(h->dKinv);
     (void)hipFree(h->dNullMu); (void)hipFree(h->dNullOut); (void)hipFree(h->dPart);
