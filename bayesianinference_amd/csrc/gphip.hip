@@ -1678,6 +1678,14 @@ int gphip_dist_update(gphip_handle h, int k, const void* packed, int j_first, in
     const int nouter = (Nt + P - 1) / P;
     const long K0 = (long)k * P;
     h->cs = on_panel_stream ? h->pstream : h->stream;
+    // one launch per RUN of adjacent owned panels (a world of one / the tail of a small world owns long runs: one
+    // triangular launch instead of one per 512-column strip, whose last wave of workgroups would idle the chip)
+    int run_lo = -1, run_hi = -1;
+    auto flush = [&]() {
+        if (run_lo >= 0)
+            DISPATCH(h, queue_dist_update, h, packed, K0, (long)rows, (long)cols, run_lo, run_hi, on_panel_stream ? 3 : 4);
+        run_lo = run_hi = -1;
+    };
     for (int j = (j_first > k + 1 ? j_first : k + 1); j < j_last && j <= nouter; ++j) {
         int c_lo, c_hi;
         if (j == nouter) {
@@ -1687,8 +1695,11 @@ int gphip_dist_update(gphip_handle h, int k, const void* packed, int j_first, in
             if (j % h->dist_world != h->dist_rank) continue;
             c_lo = j * P; c_hi = (c_lo + P < Nt) ? c_lo + P : Nt;
         }
-        DISPATCH(h, queue_dist_update, h, packed, K0, (long)rows, (long)cols, c_lo, c_hi, on_panel_stream ? 3 : 4);
+        if (run_lo >= 0 && c_lo == run_hi) { run_hi = c_hi; continue; }
+        flush();
+        run_lo = c_lo; run_hi = c_hi;
     }
+    flush();
     h->cs = h->stream;
     return GPHIP_OK;
 }

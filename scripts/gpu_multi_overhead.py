@@ -1,0 +1,36 @@
+"""What the in-library sharded schedule costs on ONE GPU (no xGMI involved): N=32768 evaluated by a plain handle, by a
+rank handle over RCCL at world size 1, and by 2 / 4 / 8 virtual ranks sharing the device (same total work, device copies
+for the panel exchange).  Differences = packing, unpacking, the broadcast calls, host-side scheduling, lost look-ahead."""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bayesianinference_amd import _lib, synthetic as syn
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 32768
+X, y = syn.make_dataset(n, 8)
+th = syn.default_theta("se_ard", 8)
+
+def timeit(h, reps=3, fit=False):
+    f = (lambda: h.fit(th)) if fit else (lambda: h.loglik(th))
+    f()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        r = f()
+    return (time.perf_counter() - t0) / reps, r
+
+h = _lib.Handle(X, y, "se_ard")
+dt, r = timeit(h); print(f"N={n} plain handle:                {dt*1e3:8.2f} ms  ll={r[0]:.10g}", flush=True)
+h.set_option("dataflow_tail", 0)
+dt, r = timeit(h); print(f"N={n} plain, no dataflow tail:     {dt*1e3:8.2f} ms  ll={r[0]:.10g}", flush=True)
+h.close()
+g = _lib.Handle(X, y, "se_ard", device=0, rank=0, world=1, comm_id=_lib.comm_unique_id())
+g.set_option("shard_min_n", 0)
+dt, r = timeit(g); print(f"N={n} rank handle, RCCL world 1:   {dt*1e3:8.2f} ms  ll={r[0]:.10g}  {g.comm_info()['comm']}", flush=True)
+dt, r = timeit(g, fit=True); print(f"N={n}   ... fit (keeps factor):    {dt*1e3:8.2f} ms", flush=True)
+g.close()
+for w in (2, 4, 8):
+    g = _lib.Handle(X, y, "se_ard", device=[0] * w)
+    g.set_option("shard_min_n", 0)
+    dt, r = timeit(g); print(f"N={n} {w} virtual ranks (copies):    {dt*1e3:8.2f} ms  ll={r[0]:.10g}", flush=True)
+    dt, r = timeit(g, fit=True); print(f"N={n}   ... fit (replicates L x{w}):  {dt*1e3:8.2f} ms", flush=True)
+    g.close()
