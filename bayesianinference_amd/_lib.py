@@ -53,6 +53,7 @@ _SIGNATURES = {
     "gphip_predict": (C.c_int, [_h, C.c_void_p, C.c_int64, _dp, _dp]),
     "gphip_predict_samples": (C.c_int, [_h, _dp, C.c_int, C.c_int, C.c_void_p, C.c_int64, _dp, _dp, _ip]),
     "gphip_covariance": (C.c_int, [_h, _dp, C.c_int, _dp]),
+    "gphip_covariance_batch": (C.c_int, [_h, _dp, C.c_int, C.c_int, _dp]),
     "gphip_cross_covariance": (C.c_int, [_h, _dp, C.c_int, C.c_void_p, C.c_int64, _dp, _dp]),
     "gphip_solve": (C.c_int, [_h, _dp, C.c_int64, _dp]),
     "gphip_logdet": (C.c_int, [_h, _dp]),
@@ -251,7 +252,13 @@ class Handle:
         return mean, var, info
 
     def covariance(self, theta):
-        th = np.ascontiguousarray(np.asarray(theta, dtype=np.float64).ravel())
+        """theta[p] -> K[N, N]; Theta[B, p] -> K[B, N, N] (the Listable form, BGP:59)."""
+        th = np.ascontiguousarray(np.asarray(theta, dtype=np.float64))
+        if th.ndim == 2:
+            K = np.zeros((th.shape[0], self.N, self.N))
+            self._check(self._lib.gphip_covariance_batch(self._h, _d(th), th.shape[0], th.shape[1], _d(K)))
+            return K
+        th = th.ravel()
         K = np.zeros((self.N, self.N))
         self._check(self._lib.gphip_covariance(self._h, _d(th), th.size, _d(K)))
         return K

@@ -1395,6 +1395,18 @@ int gphip_comm_info(gphip_handle h, int* world, int* nlocal, const char** comm) 
     return GPHIP_OK;
 }
 
+// the Listable form of compiledCovarianceMatrix (BGP:59: a B x p matrix of thetas gives B matrices): K row-major
+// B x N x N; a theta that cannot be used (non-finite / zero length scale) fails the whole call like gphip_covariance
+int gphip_covariance_batch(gphip_handle h, const double* Theta, int B, int p, double* K) {
+    if (!h || !Theta || !K) return fail(h, GPHIP_ERR_ARG, "null argument");
+    if (B < 1) return fail(h, GPHIP_ERR_DIM, "B < 1");
+    for (int b = 0; b < B; ++b) {
+        const int rc = gphip_covariance(h, Theta + (size_t)b * p, p, K + (size_t)b * h->N * h->N);
+        if (rc) return rc;
+    }
+    return GPHIP_OK;
+}
+
 static int predict_local(gphip_handle h, const void* Xs, int64_t M, double* mean, double* var);
 
 int gphip_predict(gphip_handle h, const void* Xs, int64_t M, double* mean, double* var) {

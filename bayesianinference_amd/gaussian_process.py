@@ -286,7 +286,10 @@ def defineGaussianProcess(data, kernel, nugget="Constant", meanFunction=None, va
         return (ll, grad) if info == 0 else (MACHINE_LOG_ZERO, np.full(len(params), np.nan))
 
     def covariance_function(theta):                               # "CovarianceFunction", BGP:264-271
-        return handle.covariance(theta)
+        K = handle.covariance(theta)                              # Listable: B x p -> B matrices (BGP:59)
+        if kname == "null":                                       # covarianceMatrix[.., nullKernel, ..] = nugget /@ points:
+            return np.diagonal(K, axis1=-2, axis2=-1).copy()      # the DIAGONAL as a vector (BGP:27)
+        return K
 
     def inverse_covariance_function(theta):                       # "InverseCovarianceFunction", BGP:308
         info = handle.fit(theta)

@@ -118,6 +118,8 @@ int gphip_predict_samples(gphip_handle h, const double* Thetas, int S, int p, co
                           double* mean, double* var, int* info);
 /* K: row-major N x N fp64 (full, both triangles), for parity tests at small N. */
 int gphip_covariance(gphip_handle h, const double* theta, int p, double* K);
+/* Listable form (BGP:59): Theta row-major B x p -> K row-major B x N x N. */
+int gphip_covariance_batch(gphip_handle h, const double* Theta, int B, int p, double* K);
 /* compiledKandKappa (BGP:91-124, null kernel BGP:63-89): k row-major N x M (rows = training points, columns =
  * test points, the layout of BGP:103-107), kappa[M] = k(x*,x*) + nugget.  No fit needed; un-fits the handle. */
 int gphip_cross_covariance(gphip_handle h, const double* theta, int p, const void* Xs, int64_t M, double* k,

@@ -148,3 +148,22 @@ def test_predictive_distribution_forwards_for_gp_objects():
     nobj = gp.defineGaussianProcess((X, y), None, "Constant", "Constant", [("sn", 0.05, 2.0), ("mu", -1.0, 1.0)])
     pred = gp.predictFromGaussianProcess(nobj.append({"Samples": [{"Point": [0.7, 0.1], "CrudePosteriorWeight": 1.0}]}), pts)
     assert np.all(pred["Mean"] == 0.1) and np.allclose(pred["StandardDeviation"], 0.7)
+
+
+def test_covariance_function_listable_and_null_kernel_vector():
+    """compiledCovarianceMatrix is Listable (BGP:59): a B x p matrix of thetas gives B matrices; with the null
+    kernel covarianceMatrix returns the diagonal as a VECTOR (BGP:27), which matrixInverseAndDet's third form takes."""
+    X, y = syn.make_dataset(90, 2)
+    variables = [("l1", 0.1, 10.0), ("l2", 0.1, 10.0), ("sf", 0.1, 10.0), ("sn", 0.05, 1.0)]
+    obj = gp.defineGaussianProcess((X, y), "SEARD", variables=variables)
+    cov = obj["GaussianProcessData", "ModelFunctions", "CovarianceFunction"]
+    Th = np.array([[0.8, 1.7, 1.2, 0.3], [1.1, 0.6, 0.9, 0.2], [2.0, 2.0, 0.5, 0.1]])
+    Ks = cov(Th)
+    assert Ks.shape == (3, 90, 90)
+    for b in range(3):
+        np.testing.assert_allclose(Ks[b], orc.covariance_matrix("se_ard", Th[b], X), rtol=1e-12)
+        np.testing.assert_array_equal(Ks[b], cov(Th[b]))
+    nobj = gp.defineGaussianProcess((X, y), None, "Constant", None, [("sn", 0.05, 2.0)])
+    diag = nobj["GaussianProcessData", "ModelFunctions", "CovarianceFunction"]([0.7])
+    np.testing.assert_allclose(diag, orc.covariance_matrix("null", [0.7], X), rtol=1e-15)
+    assert diag.shape == (90,)
