@@ -815,6 +815,10 @@ struct GemmArgs {
     int mode;                                    // ROLE 3 only: 0: C -= A B ; 1: C = A B
     int ktri;                                    // 1: tile (ti,tj) contracts k >= ti*128 only (operands upper
                                                  //    triangular in (row, k): the U U^T product of the gradient)
+    int grp_stride, grp_width;                   // grp_stride > 0: GROUPED triangular launch (multi-GPU block-cyclic layout):
+                                                 //    blockIdx.y = g-th owned outer panel = tile columns [c0 + g stride,
+                                                 //    + grp_width) clipped to c1, rows from the panel's own diagonal to r1;
+                                                 //    grid.x = tiles of the first (largest) panel, surplus workgroups exit
     int thin_row;                                // tile row whose rows beyond the first are zero and stay zero (the bordered
                                                  //    right-hand-side block-row of the factorisation: only r^T is real); -1: none
     int skip_upper;                              // 1: diagonal tiles of a triangular update leave their strictly-upper 64x64
@@ -823,16 +827,16 @@ struct GemmArgs {
 };
 
 template <typename T>
-__device__ __forceinline__ void gemm_tile_decode(const GemmArgs<T>& g, int t, int& ti, int& tj) {
-    const int H = g.r1 - g.r0;
-    if (!g.tri || t < g.nrect) {
-        tj = g.c0 + t / H;
-        ti = g.r0 + t % H;
+__device__ __forceinline__ void gemm_tile_decode(const GemmArgs<T>& g, int t, int r0, int c0, int nrect, int& ti, int& tj) {
+    const int H = g.r1 - r0;
+    if (!g.tri || t < nrect) {
+        tj = c0 + t / H;
+        ti = r0 + t % H;
     } else {
         int u, v;
-        tri_decode(t - g.nrect, H, u, v);      // u >= v in an H x H triangle anchored at (r0, r0)
-        ti = g.r0 + u;
-        tj = g.r0 + v;
+        tri_decode(t - nrect, H, u, v);        // u >= v in an H x H triangle anchored at (r0, r0)
+        ti = r0 + u;
+        tj = r0 + v;
     }
 }
 
@@ -871,9 +875,20 @@ __global__ __launch_bounds__(64 * NWI * NWJ, (NWI * NWJ == 4) ? 2 : 4) void gemm
     constexpr bool F64 = sizeof(T) == 8;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wi = wave % NWI, wj = wave / NWI;
-    const int slot = blockIdx.y;
+    int slot = blockIdx.y;
     int bid = blockIdx.x;
     int ti, tj;
+    int r0 = g.r0, c0 = g.c0, nrect = g.nrect, ntiles = g.ntiles;
+    if (g.grp_stride > 0) {                    // grouped launch: this workgroup works on owned panel blockIdx.y
+        slot = 0;
+        c0 = g.c0 + (int)blockIdx.y * g.grp_stride;
+        const int c1 = (c0 + g.grp_width < g.c1) ? c0 + g.grp_width : g.c1;
+        r0 = c0;
+        const int H = g.r1 - r0, ntc = c1 - c0;
+        nrect = 0;
+        ntiles = ntc * H - ntc * (ntc - 1) / 2;
+        if (bid >= ntiles) return;
+    }
     if (g.super) {
         // Blocks b, b+8, b+16, .. run on XCD b % 8 (observed dispatch rule; speed only).  Give each
         // XCD whole 8x8 super-tiles: its 64 resident workgroups then share 8 row panels and 8
@@ -890,11 +905,11 @@ __global__ __launch_bounds__(64 * NWI * NWJ, (NWI * NWJ == 4) ? 2 : 4) void gemm
         tj = g.r0 + v;
     } else {
         if (g.swizzle) {                       // give each XCD a contiguous chunk of the tile list
-            const int nx = 8, n = g.ntiles;
+            const int nx = 8, n = ntiles;
             const int q = n / nx, rem = n % nx, x = bid % nx, o = bid / nx;
             bid = (x < rem ? x * (q + 1) : rem * (q + 1) + (x - rem) * q) + o;
         }
-        gemm_tile_decode(g, bid, ti, tj);
+        gemm_tile_decode(g, bid, r0, c0, nrect, ti, tj);
     }
 
     const long koff = g.ktri ? (long)ti * TB : 0;          // first k of this tile's contraction

@@ -302,8 +302,10 @@ int queue_build(gphip_ctx* h, int nslots) {
 template <typename T>
 void launch_gemm(gphip_ctx* h, int cls, T* C, long ldc, long cbs, const T* A, long lda, long abs_, const T* B,
                  long ldb, long bbs, int K, int r0, int r1, int c0, int c1, int tri, int nslots, int mode = 0, int ktri = 0,
-                 int thin_row = -1) {
+                 int thin_row = -1, int groups = 1, int grp_stride = 0, int grp_width = 0) {
     GemmArgs<T> g{};
+    g.grp_stride = groups > 1 ? grp_stride : 0;
+    g.grp_width = grp_width;
     g.mode = mode;
     g.ktri = ktri;
     // factorisation launches only (thin_row given): the bordered rhs block-row carries ONE real row, and nothing reads
@@ -335,7 +337,24 @@ void launch_gemm(gphip_ctx* h, int cls, T* C, long ldc, long cbs, const T* A, lo
         grid_x = nsuper * 64;
     }
     double flops = 2.0 * TB * TB * (double)K * g.ntiles * nslots;       // tile-granular (what the MFMA pipe executes)
-    if (cls == 4 && tri && r0 == c0) {
+    if (g.grp_stride > 0) {
+        // grouped triangular launch: `groups` panels of width grp_width starting at c0, c0 + stride, .. (clipped to c1), each
+        // from its own diagonal down to r1; grid.x = the first panel's tile count
+        double fl = 0.0;
+        long tiles = 0;
+        for (int q = 0; q < groups; ++q) {
+            const int a0 = c0 + q * grp_stride, a1 = std::min(a0 + grp_width, c1);
+            const int Hq = r1 - a0, wq = a1 - a0;
+            tiles += (long)wq * Hq - (long)wq * (wq - 1) / 2;
+            const double a = (double)a0 * TB, b = std::min((double)a1 * TB, (double)h->N);
+            const double cnt = b > a ? b - a : 0.0;
+            fl += 2.0 * (double)K * (cnt * (double)h->N - (a + b - 1.0) * cnt / 2.0);
+        }
+        const int w0 = std::min(grp_width, c1 - c0);
+        g.nrect = 0;
+        g.ntiles = w0 * H - w0 * (w0 - 1) / 2;
+        flops = cls == 4 ? fl : 2.0 * TB * TB * (double)K * (double)tiles;
+    } else if (cls == 4 && tri && r0 == c0) {
         // trailing SYRK: report ALGORITHMIC flops (m (m+1) nb for a trailing matrix of m true
         // columns and a panel of width nb) -- full diagonal tiles, identity padding and the bordered rhs block-row
         // are executed but not counted.  General form for the tile columns [c0, c1) of an N-column matrix:
@@ -347,7 +366,7 @@ void launch_gemm(gphip_ctx* h, int cls, T* C, long ldc, long cbs, const T* A, lo
     // algorithmic bytes: C tiles read + written once, each operand panel streamed once
     const double bytes = (double)sizeof(T) * nslots * (2.0 * TB * TB * g.ntiles + (double)(tri ? H : H + W) * TB * K);
     ProfScope ps(h, cls == 6 ? 3 : cls, flops, bytes);
-    const dim3 grid(grid_x, nslots);
+    const dim3 grid(g.grp_stride > 0 ? (unsigned)g.ntiles : (unsigned)grid_x, g.grp_stride > 0 ? (unsigned)groups : (unsigned)nslots);
     // shape: 2x2 waves / 2 LDS stages (throughput, 2 workgroups per CU) or, for launches with at most one
     // tile per CU, 4x4 waves / 4 LDS stages with counted DMA waits (latency)
     // (measured: -8 % per evaluation at N=4096, neutral at 8192, +5 % at 32768 where its 147 KB of LDS keeps
@@ -911,10 +930,11 @@ int queue_predict_reduce(gphip_ctx* h, int64_t mc, int64_t mpad, int nslots) {
 }
 
 template <typename T>
-int queue_dist_update(gphip_ctx* h, const void* packed, long K0, long rows, long cols, int c_lo, int c_hi, int cls) {
+int queue_dist_update(gphip_ctx* h, const void* packed, long K0, long rows, long cols, int c_lo, int c_hi, int cls,
+                      int groups = 1, int grp_stride = 0) {
     const T* base = (const T*)packed - K0 * TB;     // so that absolute tile row t sits at base + t*128
     launch_gemm<T>(h, cls, (T*)h->dA, h->ld, 0, base, rows, 0, base, rows, 0, (int)cols, c_lo, (int)h->Nt + 1, c_lo,
-                   c_hi, 1, 1, 0, 0, (int)h->Nt);
+                   c_hi, 1, 1, 0, 0, (int)h->Nt, groups, grp_stride, h->panel);
     return 0;
 }
 
@@ -1690,28 +1710,27 @@ int gphip_dist_update(gphip_handle h, int k, const void* packed, int j_first, in
     const int nouter = (Nt + P - 1) / P;
     const long K0 = (long)k * P;
     h->cs = on_panel_stream ? h->pstream : h->stream;
-    // one launch per RUN of adjacent owned panels (a world of one / the tail of a small world owns long runs: one
-    // triangular launch instead of one per 512-column strip, whose last wave of workgroups would idle the chip)
-    int run_lo = -1, run_hi = -1;
-    auto flush = [&]() {
-        if (run_lo >= 0)
-            DISPATCH(h, queue_dist_update, h, packed, K0, (long)rows, (long)cols, run_lo, run_hi, on_panel_stream ? 3 : 4);
-        run_lo = run_hi = -1;
-    };
-    for (int j = (j_first > k + 1 ? j_first : k + 1); j < j_last && j <= nouter; ++j) {
-        int c_lo, c_hi;
-        if (j == nouter) {
-            if (h->dist_rank != 0) continue;
-            c_lo = Nt; c_hi = R;
+    // The owned panels j = j0, j0 + world, .. of this update go out as ONE grouped launch (blockIdx.y = owned panel;
+    // gemm_nt decodes its own column range) instead of one launch per 512-column strip: a rank of an 8-GPU job owns
+    // up to 8 strips per step, and a world of one owns them all (then they are adjacent: one plain triangular launch).
+    const int W = h->dist_world, jb = (j_first > k + 1 ? j_first : k + 1), je = (j_last < nouter ? j_last : nouter);
+    int j0 = -1, cnt = 0;
+    for (int j = jb; j < je; ++j)
+        if (j % W == h->dist_rank) { if (j0 < 0) j0 = j; ++cnt; }
+    const int cls = on_panel_stream ? 3 : 4;
+    const bool corner = j_last > nouter && nouter >= jb && h->dist_rank == 0;
+    if (cnt > 0) {
+        if (W == 1) {            // adjacent panels (and the corner tile right behind them): one triangular launch
+            DISPATCH(h, queue_dist_update, h, packed, K0, (long)rows, (long)cols, j0 * P,
+                     (corner && je == nouter) ? R : std::min(je * P, Nt), cls);
+        } else if (cnt == 1) {
+            DISPATCH(h, queue_dist_update, h, packed, K0, (long)rows, (long)cols, j0 * P, std::min(j0 * P + P, Nt), cls);
         } else {
-            if (j % h->dist_world != h->dist_rank) continue;
-            c_lo = j * P; c_hi = (c_lo + P < Nt) ? c_lo + P : Nt;
+            DISPATCH(h, queue_dist_update, h, packed, K0, (long)rows, (long)cols, j0 * P, Nt, cls, cnt, W * P);
         }
-        if (run_lo >= 0 && c_lo == run_hi) { run_hi = c_hi; continue; }
-        flush();
-        run_lo = c_lo; run_hi = c_hi;
     }
-    flush();
+    if (corner && !(cnt > 0 && W == 1 && je == nouter))
+        DISPATCH(h, queue_dist_update, h, packed, K0, (long)rows, (long)cols, Nt, R, cls);
     h->cs = h->stream;
     return GPHIP_OK;
 }
