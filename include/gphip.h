@@ -130,6 +130,8 @@ int gphip_logdet(gphip_handle h, double* out);
 
 /* Options (tuning knobs; results do not depend on them beyond rounding order):
  *   "panel"        outer panel width in 128-tiles (default 4)
+ *   "panel_wide"   0/1 (default 1): single-device schedule uses 2x / 1.5x that width while >= 192 / >= 128 tile columns
+ *                  remain (the long trailing update hides the wider panel and is read-modify-written less often)
  *   "profile"      0 off, 1 kernel build + trailing SYRK + whole evaluation + prediction epilogue, 2 every kernel class
  *   "xcd_swizzle"  0/1 XCD-aware tile order of the GEMM launches (default 1)
  *   "supertile"    0/1 8x8 super-tile order of the trailing SYRK (default 0, measured slower)

@@ -31,4 +31,9 @@ def test_bench_json_contract(n):
     assert r["bound"] == "mfma" and r["peak"] == 78.6 and abs(r["frac"] * r["peak"] - r["achieved"]) < 1e-9
     if n >= 16384:
         assert r["launches"] > 0 and 20.0 < r["achieved"] < 78.6      # the trailing SYRK ran and was timed
+        kb, al = j["roofline_kbuild"], j["roofline_syrk_alone"]
+        assert kb["bound"] == "hbm" and kb["peak"] == 8000.0 and 500.0 < kb["achieved"] < 8000.0
+        assert kb["algorithmic_per_launch"] == 8.0 * (n * (n + 1) / 2 + n * 8)     # 8 [N(N+1)/2 + N d]
+        assert al["bound"] == "mfma" and 20.0 < al["achieved"] < 78.6 and al["launches"] > 0
+        assert 0.0 < j["cholesky_frac_of_fp64_mfma_peak"] < 1.0
     assert "workload" in j["config"] and "model" not in j["config"]

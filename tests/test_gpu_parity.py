@@ -350,6 +350,11 @@ def test_full_size_properties_n32768():
     assert info2 == 0 and close(ld2, ld, n, 1e-10) and close(qd2, qd, n, 1e-9) and close(ll2, ll, n, 1e-10)
     h.set_option("lookahead", 1)
     h.set_option("panel", 4)
+    h.set_option("dataflow_tail", 64)
+    h.set_option("panel_wide", 0)                        # uniform 512-wide panels vs the default wide-then-narrow schedule
+    ll3, ld3, qd3, info3 = h.loglik_parts(th)
+    assert info3 == 0 and close(ld3, ld, n, 1e-10) and close(qd3, qd, n, 1e-9) and close(ll3, ll, n, 1e-10)
+    h.set_option("panel_wide", 1)
     assert h.fit(th) == 0
     alpha = h.solve(y)                                   # K^-1 y by forward + backward substitution
     assert close(float(y @ alpha), qd, n, 1e-9)          # == r^T K^-1 r from the bordered row
