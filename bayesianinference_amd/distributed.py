@@ -69,10 +69,13 @@ def shard_slice(n_items: int, rank: int, world: int) -> slice:
 
 
 def sharded_predict(predict, Xs: np.ndarray, dist=None):
-    """Test-point sharding of the prediction: every rank holds the full factor
-    (each rank calls gphip_fit itself -- replicas; or received L once), predicts its contiguous
-    shard of the test points with `predict(Xs_shard) -> (mean, var)` and the shards are concatenated
-    on every rank with one all_gather.  No collective inside the solve."""
+    """Test-point sharding of the prediction: every rank holds the full factor -- either each
+    rank fitted on its own (small N: replicas) or the ranks fitted ONE factorisation together through per-rank
+    handles (`_lib.Handle(.., rank=, world=, comm_id=)`: the collective gphip_fit unpacks every received panel, so
+    L ends up replicated with no extra traffic) -- predicts its contiguous shard of the test points with
+    `predict(Xs_shard) -> (mean, var)` and the shards are concatenated on every rank with one all_gather of the
+    RESULTS.  No collective inside the solve.  (A multi-device handle in ONE process shards test points by itself
+    inside gphip_predict.)"""
     Xs = np.atleast_2d(np.asarray(Xs, dtype=np.float64))
     m = len(Xs)
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:

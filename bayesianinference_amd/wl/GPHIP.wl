@@ -79,8 +79,10 @@ hipMeanFunction[name_, d_, False] := Function[theta, Function[0]];
 hipMeanFunction[name_, d_, True] := With[{i = If[name === None, 2, nLengthScales[name, d] + 3]},
 	Function[theta, With[{mu = theta[[i]]}, Function[mu]]]];
 
-(* the handle keeps ONE factor resident: refit only when theta changed since the last fit *)
+(* the handle keeps ONE factor resident: refit only when theta changed since the last fit.  Every other call into the
+   library reuses the handle's workspace, so it first forgets the fit (touch). *)
 $fitted = <||>;
+touch[h_] := ($fitted[h] = None);
 ensureFit[h_, theta_] := If[ Lookup[$fitted, h, None] === theta,
 	0,
 	With[{info = gpFit[h, theta]},
@@ -111,6 +113,7 @@ defineGaussianProcessHIP[
 	If[ !IntegerQ[h] || h < 0, Return[inferenceObject[$Failed]]];
 	KeyValueMap[gpSetOpt[h, #1, N[#2]]&, Association @ Lookup[{rest}, "LibraryOptions", {}]];
 	loglik = Function[theta,
+		touch[h];
 		If[ MatrixQ[theta], toLogLik /@ gpLogLikB[h, N @ theta], toLogLik @ gpLogLik[h, N @ theta]]
 	];
 	(* matrixInverseAndDet[covarianceFunction[theta]] (BayesianGaussianProcess.wl:130-141, 308): an Association with
@@ -134,14 +137,14 @@ defineGaussianProcessHIP[
 				"KernelFunction" -> hipKernelFunction[kernelName, d],
 				"NuggetFunction" -> hipNuggetFunction[kernelName, d],
 				"MeanFunction" -> hipMeanFunction[kernelName, d, constMean],
-				"CovarianceFunction" -> Function[theta, gpCov[h, N @ theta]],
+				"CovarianceFunction" -> Function[theta, touch[h]; gpCov[h, N @ theta]],
 				"InverseCovarianceFunction" -> invCov
 			|>,
 			"KernelName" -> kernelName,
 			"HIPHandle" -> h
 		|>,
 		Sequence @@ FilterRules[{rest}, Except[own]],
-		"LogLikelihoodGradientFunction" -> Function[theta, gpGrad[h, N @ theta]],
+		"LogLikelihoodGradientFunction" -> Function[theta, touch[h]; gpGrad[h, N @ theta]],
 		"LogLikelihoodFunction" -> loglik
 	]
 ];
@@ -165,7 +168,7 @@ hipPredict[result_, pts_List] := Module[{
 			{mv[[1]], mv[[2]]}
 		]
 	];
-	$fitted[h] = None;                                       (* the batched pass reused the handle's workspace *)
+	touch[h];                                                (* the batched pass reused the handle's workspace *)
 	AssociationThread[points, MixtureDistribution[weights, #]& /@ Transpose[perSample]]
 ];
 
@@ -183,10 +186,18 @@ DownValues[predictFromGaussianProcess] = Prepend[
 (* predictiveDistribution (BayesianStatistics.wl:1373-1387) needs a "GeneratingDistribution", which a GP object does
    not carry; for HIP-backed GP objects it forwards to the prediction above.  The "MaximumLikelihood" / "MAP"
    forms (:1389-1416) reduce "Samples" to one element and re-enter here. *)
+bestSample[result_, f_] := Append[result, "Samples" -> TakeLargestBy[result["Samples"], f, 1]];
 Unprotect[predictiveDistribution];
-DownValues[predictiveDistribution] = Prepend[
-	DownValues[predictiveDistribution],
-	HoldPattern[predictiveDistribution[inferenceObject[result_?hipObjectQ], pts_List]] :> hipPredict[result, pts]
+DownValues[predictiveDistribution] = Join[
+	{
+		HoldPattern[predictiveDistribution[inferenceObject[result_?hipObjectQ], pts_List]] :>
+			hipPredict[result, pts],
+		HoldPattern[predictiveDistribution[inferenceObject[result_?hipObjectQ], pts_List, "MaximumLikelihood"]] :>
+			hipPredict[bestSample[result, #LogLikelihood &], pts],
+		HoldPattern[predictiveDistribution[inferenceObject[result_?hipObjectQ], pts_List, "MAP"]] :>
+			hipPredict[bestSample[result, #LogLikelihood + #LogPriorPDF &], pts]
+	},
+	DownValues[predictiveDistribution]
 ];
 
 End[]

@@ -83,4 +83,10 @@ def test_wl_package_keeps_reference_shapes():
     # the HIP prediction rule must be PREPENDED to the reference's down-values (an appended rule
     # of equal specificity is never reached)
     assert re.search(r"DownValues\[predictFromGaussianProcess\]\s*=\s*Prepend\[", text)
-    assert re.search(r"DownValues\[predictiveDistribution\]\s*=\s*Prepend\[", text)
+    assert re.search(r"DownValues\[predictiveDistribution\]\s*=\s*Join\[\s*\{", text)      # new rules FIRST
+    # brackets balance (the nearest thing to a syntax check available without a Wolfram kernel)
+    code = re.sub(r"\(\*.*?\*\)", "", text, flags=re.S)
+    code = re.sub(r'"(?:[^"\\]|\\.)*"', '""', code)
+    for a, b in ("[]", "{}", "()"):
+        assert code.count(a) == code.count(b), (a, code.count(a), code.count(b))
+    assert code.count("<|") == code.count("|>")
