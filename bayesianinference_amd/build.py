@@ -75,6 +75,26 @@ def build_wl_stub(force: bool = False, verbose: bool = False) -> str:
     return WL_STUB_LIB
 
 
+FAKE_RCCL_SRC = os.path.join(ROOT, "tests", "fake_rccl", "fake_rccl.cpp")
+FAKE_RCCL_LIB = os.path.join(ROOT, "tests", "fake_rccl", "libfake_rccl.so")
+
+
+def build_fake_rccl(force: bool = False, verbose: bool = False) -> str:
+    """TESTS-ONLY collective library over shared memory (tests/fake_rccl/fake_rccl.cpp): lets the multi-PROCESS path
+    (gphip_create_rank) run with two ranks on a one-GPU box, where real RCCL refuses two ranks on one device."""
+    if not force and os.path.exists(FAKE_RCCL_LIB) and os.path.getmtime(FAKE_RCCL_SRC) <= os.path.getmtime(FAKE_RCCL_LIB):
+        return FAKE_RCCL_LIB
+    cmd = [hipcc_path(), "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-x", "c++", "-D__HIP_PLATFORM_AMD__",
+           "-I/opt/rocm/include", "-o", FAKE_RCCL_LIB, FAKE_RCCL_SRC, "-L/opt/rocm/lib", "-lamdhip64", "-lpthread", "-lrt"]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("building the fake collective library failed:\n" + res.stdout + res.stderr)
+    return FAKE_RCCL_LIB
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
     print(build_wl_stub(force="--force" in sys.argv, verbose=True))
+    print(build_fake_rccl(force="--force" in sys.argv, verbose=True))

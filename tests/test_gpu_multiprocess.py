@@ -1,0 +1,67 @@
+"""The MULTI-PROCESS path of the library -- gphip_create_rank: one process per rank, gphip_loglik / gphip_fit as
+collective calls -- with world_size 2 on ONE GPU.  Real RCCL refuses two ranks on the same device, so the two worker
+processes (tests/multiproc_worker.py, torch-free) bind a tests-only collective library over POSIX shared memory
+(tests/fake_rccl/fake_rccl.cpp) through $GPHIP_RCCL_PATH -- the run-time binding of csrc/rccl_dyn.h.  Everything else
+is the product path: per-rank ownership of the outer panels, a rank that owns NOTHING of a step, packing, broadcast
+order, unpack-on-receive replication of L, the 4-double all-reduce, verdicts travelling through the reduction, and
+each rank predicting its own shard of the test points with no further exchange."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from bayesianinference_amd import build, synthetic as syn
+from oracle import gp_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def close(a, b, n, rtol=1e-8):
+    return abs(a - b) <= rtol * max(abs(b), float(n))
+
+
+@pytest.mark.parametrize("n,d,kernel,panel,world", [(1500, 3, "se_ard", 2, 2), (900, 2, "matern52_ard", 1, 3),
+                                                    (100, 2, "se_ard", 4, 2)])     # last: rank 1 owns no panel at all
+def test_rank_handles_in_separate_processes(tmp_path, n, d, kernel, panel, world):
+    fake = build.build_fake_rccl()
+    env = dict(os.environ, GPHIP_NO_TORCH="1", GPHIP_RCCL_PATH=fake, FAKE_RCCL_SHM=f"/gphip_fake_{os.getpid()}_{n}",
+               LD_LIBRARY_PATH="/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+    outs = [str(tmp_path / f"rank{r}.json") for r in range(world)]
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "multiproc_worker.py"), str(r), str(world),
+                               outs[r], str(n), str(d), kernel, str(panel)], env=env, cwd=ROOT,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    logs = []
+    for p in procs:
+        try:
+            logs.append(p.communicate(timeout=300)[0])
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            pytest.fail("a rank hung (collective call order differs between ranks?)")
+    assert all(p.returncode == 0 for p in procs), "\n".join(logs)[-3000:]
+    res = [json.load(open(o)) for o in outs]
+    X, y = syn.make_dataset(n, d)
+    th = syn.default_theta(kernel, d)
+    want = orc.log_likelihood(kernel, th, X, y, parts=True)
+    want2 = orc.log_likelihood(kernel, th * 1.05, X, y, parts=True)
+    Xs = syn.make_test_points(64, d)
+    mo, so = orc.predict_internal(kernel, th, X, y, Xs)
+    alpha = np.linalg.solve(orc.covariance_matrix(kernel, th, X), y)
+    for r in res:
+        assert r["comm"]["world"] == world and r["comm"]["local"] == 1 and r["comm"]["comm"].startswith("rccl (ncclCommInitRank")
+        ll, ld, qd, info = r["parts"]
+        assert info == 0 and close(ll, want[0], n) and close(ld, want[1], n) and close(qd, want[2], n)
+        assert r["parts2"][3] == 0 and close(r["parts2"][0], want2[0], n)
+        assert r["nan"][1] == 2                                        # the verdict is the same on every rank
+        assert r["fit"] == 0 and close(r["logdet"], want[1], n)
+        lo, hi = r["shard"]
+        np.testing.assert_allclose(r["mu"], mo[lo:hi], rtol=1e-7, atol=1e-9)      # L was replicated on this rank
+        np.testing.assert_allclose(np.sqrt(r["var"]), so[lo:hi], rtol=1e-7)
+        np.testing.assert_allclose(r["alpha_head"], alpha[:5], rtol=1e-7, atol=1e-9)
+    # identical on every rank, bit for bit (same reduction result broadcast back)
+    assert all(r["parts"] == res[0]["parts"] for r in res)
