@@ -238,6 +238,8 @@ def main() -> None:
                          "the Python harness (dist_cholesky.py, torch.distributed broadcasts).")
     ap.add_argument("--supertile", type=int, default=0, help="experiment: XCD-private 8x8 super-tile order")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-alone", action="store_true", help="skip the extra look-ahead-off evaluation behind roofline_syrk_alone "
+                                                            "(profiling runs: keeps the rocprof launch statistics those of the timed schedule)")
     ap.add_argument("--no-extras", action="store_true", help="skip the short BASELINE.json cfg-4 / cfg-5 measurements")
     args = ap.parse_args()
 
@@ -325,7 +327,7 @@ def main() -> None:
     # trailing SYRK shares the CUs with the look-ahead stream (LA update + potrf + panel solves of the next panel), so
     # its event time there includes that contention; one extra evaluation with look-ahead off times it alone.
     alone = None
-    if world == 1 and not sharded:
+    if world == 1 and not sharded and not args.no_alone:
         h.set_option("lookahead", 0)
         h.reset_profile()
         evaluate(thetas[0])

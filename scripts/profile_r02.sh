@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="$R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras"
+ARGS="$R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras --no-alone"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- python3 $ARGS > $OUT/trace.log 2>&1
 echo "trace rc=$?"
 timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o bench -- python3 $ARGS > $OUT/pmc_fetch.log 2>&1
