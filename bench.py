@@ -51,7 +51,7 @@ def _roof(cls: dict, peak: float, unit: str, what: str) -> dict:
 
 def cpu_baseline(n_full: int, d: int, sizes=(4096, 8192)) -> dict:
     """Times the CPU oracle (numpy kernel-matrix build + scipy LAPACK LU, the algorithm LinearSolve uses) on a
-    BOUNDED sample -- whole evaluations at N = 4096 and N = 8192 -- and scales the larger one to the metric's unit
+    BOUNDED sample -- whole evaluations at N = 4096 and N = 8192, median of three each -- and scales the larger one to the metric's unit
     (evals/s at n_full): the build with its quadratic cost, the factorisation + solve with its cubic cost.  The
     exponents fitted between the two sizes are printed so the extrapolation can be checked.  For information it
     also times a Cholesky variant and cfg 1 (N=512, d=1) whole."""
@@ -94,12 +94,18 @@ def cpu_baseline(n_full: int, d: int, sizes=(4096, 8192)) -> dict:
                 tf += t2 - t1
         return tb / reps, tf / reps
 
-    # LAPACK on very many threads can be slower than on fewer: pick the best of a short ladder at the small size
+    # LAPACK on very many threads can be slower than on fewer: pick the best of a short ladder at the small size, then
+    # take the MEDIAN of three whole evaluations at each size
     ladder = sorted({t for t in (16, 32, 64, threads) if t <= threads})
-    small = {t: timed(sizes[0], t, 2) for t in ladder}
-    threads = min(small, key=lambda t: sum(small[t]))
-    tb0, tf0 = small[threads]
-    tb1, tf1 = timed(sizes[1], threads, 1)
+    probe = {t: timed(sizes[0], t, 1) for t in ladder}
+    threads = min(probe, key=lambda t: sum(probe[t]))
+
+    def median3(n):
+        runs = sorted((timed(n, threads, 1) for _ in range(3)), key=sum)
+        return runs[1]
+
+    tb0, tf0 = median3(sizes[0])
+    tb1, tf1 = median3(sizes[1])
     ratio = math.log(sizes[1] / sizes[0])
     exp_build, exp_lu = math.log(tb1 / tb0) / ratio, math.log(tf1 / tf0) / ratio
     s2, s3 = (n_full / sizes[1]) ** 2, (n_full / sizes[1]) ** 3
@@ -121,7 +127,7 @@ def cpu_baseline(n_full: int, d: int, sizes=(4096, 8192)) -> dict:
         t_cfg1 = (time.perf_counter() - t0) / 5
     return {"value": 1.0 / est, "unit": "evals/s", "cores": int(threads), "kind": "port",
             "sample": f"CPU oracle (numpy build + scipy dgetrf/dgetrs LU restatement of BGP:29-43,130-141,"
-                      f"181-199; not Mathematica) timed whole at N={sizes[0]} (x2) and N={sizes[1]} (x1), d={d}: "
+                      f"181-199; not Mathematica) timed whole at N={sizes[0]} and N={sizes[1]} (median of 3 each, {threads} threads), d={d}: "
                       f"N={sizes[1]}: build {tb1:.3f} s, LU+solve {tf1:.3f} s; scaled by (N/{sizes[1]})^2={s2:.0f} and "
                       f"^3={s3:.0f} => {est:.1f} s/eval at N={n_full}",
             "measured": {f"N{sizes[0]}": {"build_s": round(tb0, 4), "lu_solve_s": round(tf0, 4)},
