@@ -840,7 +840,9 @@ int queue_forward_rows(gphip_ctx* h, int64_t mpad, int nslots, int b_start = 0, 
     // HBM bound -- 1.3 TB of traffic for N = 65536, M = 10000 in fp32.)
     // identity_rows: V holds rows b_start*128.. of the identity, so the result (rows of L^-T) is upper
     // triangular -- at tile column b only the row tiles <= b - b_start are non-zero and are touched.
-    const int Nt = (int)h->Nt, Mt = (int)(mpad / TB), P = h->panel;
+    // many rows (prediction of thousands of test points, K^-1 for the gradient): every pass over the columns right of a
+    // panel reads and writes all of V there, so wider panels pay (cfg 5, M = 10 000: 374 -> 359 ms from 4 to 12 tiles)
+    const int Nt = (int)h->Nt, Mt = (int)(mpad / TB), P = (Mt >= 8 && h->panel_wide) ? std::max(h->panel, 12) : h->panel;
     const long ld = h->ld, vs = (long)mpad * h->Npad, bs = ld * ld, lrs = (long)Nt * TB * TB;
     T *V = (T*)h->dV, *A = (T*)h->dA, *W = (T*)h->dW;
     auto rows_at = [&](int b) { return identity_rows ? std::min(Mt, b - b_start + 1) : Mt; };
@@ -864,7 +866,7 @@ int queue_forward_rows(gphip_ctx* h, int64_t mpad, int nslots, int b_start = 0, 
 //   X_b = Y_b W_b ;  Y_c -= X_b L(b,c) for c < b.   Two-level as above.
 template <typename T>
 int queue_backward_rows(gphip_ctx* h, int64_t mpad) {
-    const int Nt = (int)h->Nt, Mt = (int)(mpad / TB), P = h->panel;
+    const int Nt = (int)h->Nt, Mt = (int)(mpad / TB), P = (Mt >= 8 && h->panel_wide) ? std::max(h->panel, 12) : h->panel;
     const long ld = h->ld;
     T *V = (T*)h->dV, *A = (T*)h->dA, *W = (T*)h->dW;
     for (int k1 = Nt; k1 > 0; k1 -= P) {         // outer panel = tile columns [k0, k1)
