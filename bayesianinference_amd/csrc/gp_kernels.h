@@ -1250,6 +1250,12 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g, Th
     long long* tr = g.trace ? g.trace + (long)task * 8 : nullptr;
     auto stamp = [&](int k) { if (tr && tid == 0) tr[k] = wall_clock64(); };
     stamp(0);
+    // The diagonal task IS the critical chain (and with 64-tiles the sub-diagonal one feeds it): let the SIMD arbiter
+    // prefer their waves over the co-resident workgroup's accumulation waves (N=8192: 5.2 -> 4.9 ms)
+#ifndef GP_DF_PRIO
+#define GP_DF_PRIO 3
+#endif
+    if (GP_DF_PRIO > 0 && (i == j || (TBX == 64 && i == j + 1))) __builtin_amdgcn_s_setprio(GP_DF_PRIO);
     T* As = g.A + (long)slot * g.bstride;
     int* F = g.flags + (long)slot * g.f_bstride;
     T* Wj = g.W + (long)slot * g.w_bstride + (long)j * TBX * TBX;
