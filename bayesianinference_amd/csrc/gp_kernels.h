@@ -1553,6 +1553,7 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g, Th
                         smem[(c >> 4) * JOFF + df_lds_off<T, TBX>(c & 15, irow)] = accx[x][y][r];
                     }
             publish(j, jm);                                 // (its barrier also orders the LDS image)
+            stamp(7);
 #pragma unroll
             for (int st = 0; st < TBX / GK; ++st)
 #pragma unroll

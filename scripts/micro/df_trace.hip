@@ -48,6 +48,12 @@ int main(int argc, char** argv) {
         const long long* t = &tr[(size_t)(off(j) + 1) * 8];
         printf("trsm(%d,%d): %.2f | last slab flag %.2f | %.2f | %.2f | %.2f | %.2f | %.2f\n", j + 1, j, us(t[0]), us(t[6]), us(t[1]), us(t[5]), us(t[2]), us(t[3]), us(t[4]));
     }
+    if (nd > 40) for (int j = 60; j < 64; ++j) {      // the hop of a mid diagonal task, split: (times relative to the previous diagonal's publish)
+        const long long* d = &tr[(size_t)off(j) * 8]; const long long* p = &tr[(size_t)off(j - 1) * 8];
+        const double t = us(p[4]);
+        printf("hop diag(%d): prev pub %.1f | flags seen +%.1f | solve+store+publish +%.1f | slab +%.1f | packed +%.1f | potrf +%.1f | pub +%.1f   (pre flag owner published at %+.1f)\n",
+               j, t, us(d[5]) - t, us(d[7]) - t, us(d[6]) - t, us(d[2]) - t, us(d[3]) - t, us(d[4]) - t, us(tr[(size_t)(off(j - 1) + 1) * 8 + 4]) - t);
+    }
     if (nd > 40) for (int j = 30; j < 33; ++j) {
         const long long* d = &tr[(size_t)off(j) * 8]; const long long* x = &tr[(size_t)(off(j) + 1) * 8];
         printf("mid diag(%d): start %.1f lastflag %.1f accdone %.1f corebeg %.1f coreend %.1f pub %.1f | trsm(%d,%d): start %.1f accdone %.1f flag %.1f end %.1f pub %.1f\n", j, us(d[0]), us(d[6]), us(d[1]), us(d[2]), us(d[3]), us(d[4]), j + 1, j, us(x[0]), us(x[1]), us(x[5]), us(x[3]), us(x[4]));
