@@ -75,6 +75,7 @@ struct gphip_ctx {
     int panel_left = -1;                         // in-panel updates left-looking: -1 auto (batches), 0 never, 1 always
     int fuse_option = 1;                         // allow the single-launch evaluation (option "fused_eval")
     int grad_potri = 1;                          // gradient: K^-1 = U U^T in one go when the memory is there
+    int la_main = 0;                             // 1: look-ahead update LA(k) on the main stream ahead of REST(k) (measured slower: 189.4 vs 186.2 ms)
     int panel_wide = 1;                          // wider outer panels while the trailing matrix is large (queue_factor)
     int thin_tiles = 1;                          // gemm_nt: skip the zero rows of the rhs block-row and the unread upper quadrant of diagonal tiles
     int dataflow_tail = 64;                      // large N: the last <= dataflow_tail tile columns go to the dataflow kernel (0 = off)
@@ -597,7 +598,23 @@ int queue_factor(gphip_ctx* h, int nslots) {
                 launch_dataflow<T, 128, 1>(h, nslots, k0(kc));
                 break;
             }
-            if (k + 1 < nouter) {
+            if (k + 1 < nouter && h->la_main) {
+                // experiment (option "la_main", off): LA(k) FIRST on the main stream, with the chip to itself, the panel
+                // stream factoring panel k+1 when it is done -- under REST(k).  The contended SYRK number rises (0.74 ->
+                // 0.78 of peak in-run) because REST(k) no longer shares the CUs with LA(k), but the evaluation gets
+                // SLOWER (186.2 -> 189.4 ms): run back to back, LA(k) and REST(k) each pay their own partial last wave
+                // of workgroups; run together they fill each other's tails.
+                h->cs = h->stream;
+                (void)hipStreamWaitEvent(h->stream, ev_panel, 0);
+                trailing(k, k0(k + 1), k0(k + 2), 4);                          // LA(k)
+                hipEvent_t ev_la = sync_event(h);
+                (void)hipEventRecord(ev_la, h->stream);
+                h->cs = h->pstream;
+                (void)hipStreamWaitEvent(h->pstream, ev_la, 0);
+                queue_panel<T>(h, k0(k + 1), k0(k + 2) - k0(k + 1), nslots);    // factor panel k+1
+                ev_next = sync_event(h);
+                (void)hipEventRecord(ev_next, h->pstream);
+            } else if (k + 1 < nouter) {
                 h->cs = h->pstream;
                 if (ev_rest) (void)hipStreamWaitEvent(h->pstream, ev_rest, 0);
                 trailing(k, k0(k + 1), k0(k + 2), 3);                          // LA(k)
@@ -1784,6 +1801,7 @@ int* option_slot(gphip_ctx* h, const char* name) {
         {"fused_eval", &gphip_ctx::fuse_option}, {"panel_left", &gphip_ctx::panel_left},
         {"max_slots", &gphip_ctx::max_slots}, {"shard_min_n", &gphip_ctx::shard_min_n},
         {"thin_tiles", &gphip_ctx::thin_tiles}, {"panel_wide", &gphip_ctx::panel_wide},
+        {"la_main", &gphip_ctx::la_main},
     };
     for (const Entry& e : table)
         if (!strcmp(name, e.name)) return &(h->*(e.field));
