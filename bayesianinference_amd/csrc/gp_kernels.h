@@ -815,10 +815,9 @@ struct GemmArgs {
     int mode;                                    // ROLE 3 only: 0: C -= A B ; 1: C = A B
     int ktri;                                    // 1: tile (ti,tj) contracts k >= ti*128 only (operands upper
                                                  //    triangular in (row, k): the U U^T product of the gradient)
-    int grp_stride, grp_width;                   // grp_stride > 0: GROUPED triangular launch (multi-GPU block-cyclic layout):
-                                                 //    blockIdx.y = g-th owned outer panel = tile columns [c0 + g stride,
-                                                 //    + grp_width) clipped to c1, rows from the panel's own diagonal to r1;
-                                                 //    grid.x = tiles of the first (largest) panel, surplus workgroups exit
+    int grp_stride, grp_width, grp_count;        // grp_stride > 0: GROUPED triangular launch (multi-GPU block-cyclic layout):
+                                                 //    group q = tile columns [c0 + q stride, + grp_width) clipped to c1, rows
+                                                 //    from the group's own diagonal to r1; one dense 1-D grid over all groups
     int thin_row;                                // tile row whose rows beyond the first are zero and stay zero (the bordered
                                                  //    right-hand-side block-row of the factorisation: only r^T is real); -1: none
     int skip_upper;                              // 1: diagonal tiles of a triangular update leave their strictly-upper 64x64
@@ -879,15 +878,28 @@ __global__ __launch_bounds__(64 * NWI * NWJ, (NWI * NWJ == 4) ? 2 : 4) void gemm
     int bid = blockIdx.x;
     int ti, tj;
     int r0 = g.r0, c0 = g.c0, nrect = g.nrect, ntiles = g.ntiles;
-    if (g.grp_stride > 0) {                    // grouped launch: this workgroup works on owned panel blockIdx.y
+    if (g.grp_stride > 0) {
+        // grouped launch, ONE dense 1-D grid over all groups: group q holds the tile columns [c0 + q stride, + width)
+        // (clipped to c1) from its own diagonal down to r1, i.e. T(q) = w H_q - w(w-1)/2 tiles with H_q = H_0 - q stride.
+        // The prefix P(q) = q (B + a) - a q^2  (B = w H_0 - w(w-1)/2, a = w stride / 2) is inverted in closed form.
         slot = 0;
-        c0 = g.c0 + (int)blockIdx.y * g.grp_stride;
-        const int c1 = (c0 + g.grp_width < g.c1) ? c0 + g.grp_width : g.c1;
+        const int w = g.grp_width, st = g.grp_stride, H0 = g.r1 - g.c0;
+        const double a = 0.5 * w * st, B = (double)w * H0 - 0.5 * w * (w - 1);
+        auto prefix = [&](int q) { return (long)q * (long)(w * H0 - w * (w - 1) / 2) - (long)w * st * ((long)q * (q - 1) / 2); };
+        const double disc = (B + a) * (B + a) - 4.0 * a * (double)bid;
+        int q = (int)(((B + a) - __builtin_sqrt(disc > 0.0 ? disc : 0.0)) / (2.0 * a));
+        if (q < 0) q = 0;
+        if (q > g.grp_count - 1) q = g.grp_count - 1;
+        while (q > 0 && prefix(q) > bid) --q;
+        while (q + 1 < g.grp_count && prefix(q + 1) <= bid) ++q;
+        bid -= (int)prefix(q);
+        c0 = g.c0 + q * st;
+        const int c1 = (c0 + w < g.c1) ? c0 + w : g.c1;
         r0 = c0;
         const int H = g.r1 - r0, ntc = c1 - c0;
         nrect = 0;
         ntiles = ntc * H - ntc * (ntc - 1) / 2;
-        if (bid >= ntiles) return;
+        if (bid >= ntiles) return;             // (only the clipped last group can come up short)
     }
     if (g.super) {
         // Blocks b, b+8, b+16, .. run on XCD b % 8 (observed dispatch rule; speed only).  Give each

@@ -308,6 +308,7 @@ void launch_gemm(gphip_ctx* h, int cls, T* C, long ldc, long cbs, const T* A, lo
     GemmArgs<T> g{};
     g.grp_stride = groups > 1 ? grp_stride : 0;
     g.grp_width = grp_width;
+    g.grp_count = groups;
     g.mode = mode;
     g.ktri = ktri;
     // factorisation launches only (thin_row given): the bordered rhs block-row carries ONE real row, and nothing reads
@@ -352,9 +353,14 @@ void launch_gemm(gphip_ctx* h, int cls, T* C, long ldc, long cbs, const T* A, lo
             const double cnt = b > a ? b - a : 0.0;
             fl += 2.0 * (double)K * (cnt * (double)h->N - (a + b - 1.0) * cnt / 2.0);
         }
-        const int w0 = std::min(grp_width, c1 - c0);
+        // dense grid: every group at full width (only the last one can be clipped: its surplus workgroups exit)
+        long dense = 0;
+        for (int q = 0; q < groups; ++q) {
+            const int a0 = c0 + q * grp_stride, wq = std::min(grp_width, c1 - a0), Hq = r1 - a0;
+            dense += (long)wq * Hq - (long)wq * (wq - 1) / 2;            // (only the last group can be narrower)
+        }
         g.nrect = 0;
-        g.ntiles = w0 * H - w0 * (w0 - 1) / 2;
+        g.ntiles = (int)dense;
         flops = cls == 4 ? fl : 2.0 * TB * TB * (double)K * (double)tiles;
     } else if (cls == 4 && tri && r0 == c0) {
         // trailing SYRK: report ALGORITHMIC flops (m (m+1) nb for a trailing matrix of m true
@@ -368,7 +374,7 @@ void launch_gemm(gphip_ctx* h, int cls, T* C, long ldc, long cbs, const T* A, lo
     // algorithmic bytes: C tiles read + written once, each operand panel streamed once
     const double bytes = (double)sizeof(T) * nslots * (2.0 * TB * TB * g.ntiles + (double)(tri ? H : H + W) * TB * K);
     ProfScope ps(h, cls == 6 ? 3 : cls, flops, bytes);
-    const dim3 grid(g.grp_stride > 0 ? (unsigned)g.ntiles : (unsigned)grid_x, g.grp_stride > 0 ? (unsigned)groups : (unsigned)nslots);
+    const dim3 grid(g.grp_stride > 0 ? (unsigned)g.ntiles : (unsigned)grid_x, g.grp_stride > 0 ? 1u : (unsigned)nslots);
     // shape: 2x2 waves / 2 LDS stages (throughput, 2 workgroups per CU) or, for launches with at most one
     // tile per CU, 4x4 waves / 4 LDS stages with counted DMA waits (latency)
     // (measured: -8 % per evaluation at N=4096, neutral at 8192, +5 % at 32768 where its 147 KB of LDS keeps
