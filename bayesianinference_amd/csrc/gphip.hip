@@ -48,6 +48,7 @@ struct gphip_ctx {
     size_t es = 8;                     // element size of the device arithmetic type
     hipStream_t stream = nullptr;      // main stream: build, trailing updates, copies
     hipStream_t pstream = nullptr;     // panel stream (high priority): look-ahead panel factorisation
+    hipStream_t stream2 = nullptr;     // second trailing-update stream (split REST: the two halves fill each other's launch tails)
     hipStream_t cs = nullptr;          // stream the launch helpers currently target
     std::vector<hipEvent_t> sync_events;
     size_t sync_used = 0;
@@ -75,6 +76,7 @@ struct gphip_ctx {
     int panel_left = -1;                         // in-panel updates left-looking: -1 auto (batches), 0 never, 1 always
     int fuse_option = 1;                         // allow the single-launch evaluation (option "fused_eval")
     int grad_potri = 1;                          // gradient: K^-1 = U U^T in one go when the memory is there
+    int rest_split = 0;                          // REST(k) as two grouped launches (even / odd 2-tile column groups) on two streams
     int la_main = 0;                             // 1: look-ahead update LA(k) on the main stream ahead of REST(k) (measured slower: 189.4 vs 186.2 ms)
     int panel_wide = 1;                          // wider outer panels while the trailing matrix is large (queue_factor)
     int thin_tiles = 1;                          // gemm_nt: skip the zero rows of the rhs block-row and the unread upper quadrant of diagonal tiles
@@ -560,6 +562,28 @@ int queue_factor(gphip_ctx* h, int nslots) {
         launch_gemm<T>(h, cls, A, ld, bs, Pk, ld, bs, Pk, ld, bs, (k0(k + 1) - k0(k)) * TB, c_lo, R, c_lo, c_hi, 1,
                        nslots, 0, 0, Nt);
     };
+    // Option "rest_split" (off by default): REST(k) as TWO grouped launches on two streams -- tile-column groups of
+    // width 2 alternate between them.  Each half depends only on the panel and on ITS OWN half of REST(k-1), so half A
+    // of step k+1 starts while half B of step k still runs and a launch's partial last wave of workgroups is filled by
+    // the other half: 187.7 -> 185.6 ms at N=32768 on the same box.  Off because it makes the per-launch SYRK statistic
+    // meaningless (two concurrent launches each last the whole step: the HIP-event / rocprof "average launch duration"
+    // doubles while the job gets faster) for a gain inside the box-to-box spread.
+    auto trailing_half = [&](int k, int c_lo, int parity) {       // columns >= c_lo (even), groups with (col/2) % 2 == parity
+        const T* Pk = A + (long)k0(k) * TB * ld;
+        int first = c_lo / 2;
+        if ((first & 1) != parity) ++first;
+        const int c0 = 2 * first;
+        if (c0 >= R) return;
+        const int groups = (R - c0 + 3) / 4;                        // group starts c0, c0 + 4, .. < R
+        if (groups == 1)
+            launch_gemm<T>(h, 4, A, ld, bs, Pk, ld, bs, Pk, ld, bs, (k0(k + 1) - k0(k)) * TB, c0, R, c0, std::min(c0 + 2, R), 1,
+                           nslots, 0, 0, Nt);
+        else
+            launch_gemm<T>(h, 4, A, ld, bs, Pk, ld, bs, Pk, ld, bs, (k0(k + 1) - k0(k)) * TB, c0, R, c0, R, 1, nslots, 0, 0, Nt,
+                           groups, 4, 2);
+    };
+    bool split = h->rest_split && nslots == 1 && h->lookahead && h->stream2 && !h->supertile;
+    for (int b : bnd) split = split && (b % 2 == 0 || b == Nt);
     if (use_dataflow(h, nslots)) return queue_factor_dataflow<T>(h, nslots);
     double* tail_part = nullptr;               // a 64-tile dataflow tail keeps its block partials here
     int tail_n = 0, tail_k0 = -1;
@@ -578,7 +602,7 @@ int queue_factor(gphip_ctx* h, int nslots) {
         queue_panel<T>(h, 0, k0(1), nslots);
         hipEvent_t ev_panel = sync_event(h);
         (void)hipEventRecord(ev_panel, h->pstream);
-        hipEvent_t ev_rest = nullptr;
+        hipEvent_t ev_rest = nullptr, ev_rest2 = nullptr;
         // tail: once only `dataflow_tail` tile columns are left the dataflow kernel finishes the job in one
         // launch -- the last panels are chain bound, the regime the dataflow schedule wins
         int kc = nouter;
@@ -590,6 +614,7 @@ int queue_factor(gphip_ctx* h, int nslots) {
             if (k + 1 == kc) {                  // last multi-kernel panel: apply it to everything, then cut over
                 h->cs = h->stream;
                 (void)hipStreamWaitEvent(h->stream, ev_panel, 0);
+                if (ev_rest2) (void)hipStreamWaitEvent(h->stream, ev_rest2, 0);
                 trailing(k, k0(k + 1), R, 4);
                 const int rem = Nt - k0(kc);                       // tile columns left
                 if constexpr (sizeof(T) == 8) {
@@ -623,19 +648,33 @@ int queue_factor(gphip_ctx* h, int nslots) {
             } else if (k + 1 < nouter) {
                 h->cs = h->pstream;
                 if (ev_rest) (void)hipStreamWaitEvent(h->pstream, ev_rest, 0);
+                if (ev_rest2) (void)hipStreamWaitEvent(h->pstream, ev_rest2, 0);
                 trailing(k, k0(k + 1), k0(k + 2), 3);                          // LA(k)
                 queue_panel<T>(h, k0(k + 1), k0(k + 2) - k0(k + 1), nslots);    // factor panel k+1
                 ev_next = sync_event(h);
                 (void)hipEventRecord(ev_next, h->pstream);
             }
-            h->cs = h->stream;
-            (void)hipStreamWaitEvent(h->stream, ev_panel, 0);
-            trailing(k, k0(k + 2), R, 4);                                      // REST(k)
+            if (split && k0(k + 2) % 2 == 0) {
+                h->cs = h->stream2;
+                (void)hipStreamWaitEvent(h->stream2, ev_panel, 0);
+                trailing_half(k, k0(k + 2), 1);                                // REST(k), odd groups
+                ev_rest2 = sync_event(h);
+                (void)hipEventRecord(ev_rest2, h->stream2);
+                h->cs = h->stream;
+                (void)hipStreamWaitEvent(h->stream, ev_panel, 0);
+                trailing_half(k, k0(k + 2), 0);                                // REST(k), even groups
+            } else {
+                h->cs = h->stream;
+                (void)hipStreamWaitEvent(h->stream, ev_panel, 0);
+                if (ev_rest2) (void)hipStreamWaitEvent(h->stream, ev_rest2, 0);
+                trailing(k, k0(k + 2), R, 4);                                  // REST(k)
+            }
             ev_rest = sync_event(h);
             (void)hipEventRecord(ev_rest, h->stream);
             ev_panel = ev_next;
         }
         h->cs = h->stream;
+        if (ev_rest2) (void)hipStreamWaitEvent(h->stream, ev_rest2, 0);
     }
     if (tail_k0 >= 0) {
         launch_finalize<T>(h, nslots, tail_k0, Nt, tail_part, tail_n);
@@ -1126,6 +1165,7 @@ static int create_ctx(const void* X, const void* y, int64_t N, int64_t d, int ke
         (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
         if (hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, least) != hipSuccess) return bail(GPHIP_ERR_HIP);
         if (hipStreamCreateWithPriority(&h->pstream, hipStreamNonBlocking, greatest) != hipSuccess) return bail(GPHIP_ERR_HIP);
+        if (hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, least) != hipSuccess) return bail(GPHIP_ERR_HIP);
         h->cs = h->stream;
     }
     std::vector<double> xt((size_t)d * h->Npad, 0.0), yp((size_t)h->Npad, 0.0);
@@ -1201,6 +1241,7 @@ int gphip_destroy(gphip_handle h) {
     (void)hipFree(h->dNullMu); (void)hipFree(h->dNullOut); (void)hipFree(h->dPart);
     for (auto e : h->pool) (void)hipEventDestroy(e);
     for (auto e : h->sync_events) (void)hipEventDestroy(e);
+    if (h->stream2) { (void)hipStreamSynchronize(h->stream2); (void)hipStreamDestroy(h->stream2); }
     if (h->own_streams) {
         if (h->pstream) (void)hipStreamDestroy(h->pstream);
         if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -1807,7 +1848,7 @@ int* option_slot(gphip_ctx* h, const char* name) {
         {"fused_eval", &gphip_ctx::fuse_option}, {"panel_left", &gphip_ctx::panel_left},
         {"max_slots", &gphip_ctx::max_slots}, {"shard_min_n", &gphip_ctx::shard_min_n},
         {"thin_tiles", &gphip_ctx::thin_tiles}, {"panel_wide", &gphip_ctx::panel_wide},
-        {"la_main", &gphip_ctx::la_main},
+        {"la_main", &gphip_ctx::la_main}, {"rest_split", &gphip_ctx::rest_split},
     };
     for (const Entry& e : table)
         if (!strcmp(name, e.name)) return &(h->*(e.field));

@@ -149,6 +149,8 @@ int gphip_logdet(gphip_handle h, double* out);
  *                  pinned host memory by its last task)
  *   "grad_potri"   0/1 gradient: form K^-1 = U U^T in one go when 2 N^2 of scratch fits (default 1), else
  *                  stream it in row blocks through forward + backward substitution
+ *   "rest_split"   0/1 (default 0): experiment -- each trailing update as two grouped launches (alternating 2-tile column
+ *                  groups) on two streams, so that consecutive steps overlap their launch tails (-1.1 % at N=32768)
  *   "la_main"      0/1 (default 0): experiment -- look-ahead update on the main stream ahead of the trailing update instead of
  *                  beside it on the panel stream (higher contended SYRK rate, slower evaluation)
  *   "thin_tiles"   0/1 (default 1): the GEMM kernel skips work whose result is known or never read -- all but the first

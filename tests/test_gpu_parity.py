@@ -640,3 +640,21 @@ def test_thin_tiles_skip_only_work_nobody_reads(n, d, dtype, batch):
     if dtype == 64 and n <= 2000:
         assert close(b[0][0][0], orc.log_likelihood("se_ard", Th[0], X, y), n)
     h.close()
+
+
+def test_experimental_schedules_give_the_same_factorisation():
+    """Options kept for the record: `la_main` (look-ahead update ahead of the trailing update on the
+    main stream) and `rest_split` (each trailing update as two grouped launches on two streams).  Different launch
+    structure, same arithmetic per tile: results agree with the default schedule to rounding."""
+    n, d = 20000, 4                                      # Nt = 157: wide early panels, look-ahead, dataflow tail
+    X, y = syn.make_dataset(n, d)
+    th = syn.default_theta("se_ard", d)
+    h = _lib.Handle(X, y, "se_ard")
+    ref = h.loglik_parts(th)
+    assert ref[3] == 0
+    for opt in ("la_main", "rest_split"):
+        h.set_option(opt, 1)
+        got = h.loglik_parts(th)
+        h.set_option(opt, 0)
+        assert got[3] == 0 and all(close(got[k], ref[k], n, 1e-11) for k in range(3)), (opt, got, ref)
+    h.close()
