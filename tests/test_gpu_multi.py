@@ -147,3 +147,26 @@ def test_ndev_is_honoured_or_rejected_never_ignored():
     g = _lib.Handle(X, y, "se_ard", device=[0, 0])
     assert g.comm_info()["world"] == 2
     g.close()
+
+
+def test_gradient_and_cross_covariance_on_a_sharding_group_handle():
+    """gphip_loglik_grad on a multi-device handle: the factorisation is sharded (keep = the first device ends up with
+    the whole factor and the block inverses), the K^-1 contraction runs on the first device."""
+    n, d, world = 1500, 3, 3
+    X, y = syn.make_dataset(n, d)
+    th = syn.default_theta("se_ard", d)
+    th[-1] = 0.25
+    g = _lib.Handle(X, y, "se_ard", device=[0] * world)
+    g.set_option("shard_min_n", 0)
+    g.set_option("panel", 2)
+    ll, grad, info = g.loglik_grad(th)
+    want = orc.log_likelihood_grad("se_ard", th, X, y)
+    assert info == 0 and close(ll, orc.log_likelihood("se_ard", th, X, y), n)
+    np.testing.assert_allclose(grad, want, rtol=1e-7, atol=1e-7 * np.abs(want).max())
+    mu, var = g.predict(X[:4])                           # the factor of theta is still resident after the gradient
+    mo, so = orc.predict_internal("se_ard", th, X, y, X[:4])
+    np.testing.assert_allclose(mu, mo, rtol=1e-7, atol=1e-9)
+    k, kappa = g.cross_covariance(th, X[:6])
+    ko, kap = orc.k_and_kappa("se_ard", th, X, X[:6])
+    np.testing.assert_allclose(k, ko, rtol=1e-12, atol=1e-300)
+    g.close()
