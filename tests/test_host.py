@@ -133,3 +133,13 @@ def test_mixture_percentiles_and_plot_moments():
     m3 = np.trapezoid((x - m[j]) ** 3 * pdf, x)
     np.testing.assert_allclose(hi[j], m[j] + np.sqrt(v[j]) + np.cbrt(m3), rtol=1e-8)
     np.testing.assert_allclose(lo[j], m[j] - np.sqrt(v[j]) + np.cbrt(m3), rtol=1e-8)
+
+
+def test_laplace_log_evidence_formula():
+    """LA:22-30: max + (p log 2pi - log det P)/2, Missing[] unless det P > 0 -- exact for a Gaussian density."""
+    from bayesianinference_amd import laplace
+    P = np.array([[4.0, 1.0], [1.0, 3.0]])
+    # unnormalised Gaussian exp(c - x'Px/2): Z = e^c (2pi)^(p/2) det(P)^(-1/2)
+    assert laplace.laplaceLogEvidence(1.5, P) == pytest.approx(1.5 + np.log(2 * np.pi) - 0.5 * np.log(11.0), rel=1e-14)
+    assert laplace.laplaceLogEvidence(0.0, 2.0) == pytest.approx(0.5 * (np.log(2 * np.pi) - np.log(2.0)))
+    assert laplace.laplaceLogEvidence(0.0, [[1.0, 2.0], [2.0, 1.0]]) is None        # det < 0
