@@ -236,9 +236,13 @@ int ensure_slots(gphip_ctx* h, int want) {
     HIPCHK(hipMalloc(&h->dRes, S * 2 * 8));
     HIPCHK(hipMalloc(&h->dInfo, S * 4));
     HIPCHK(hipMalloc(&h->dFlags, S * (2 * h->Nt + 1) * (2 * h->Nt + 1) * 4));
-    HIPCHK(hipMemset(h->dFlags, 0, S * (2 * h->Nt + 1) * (2 * h->Nt + 1) * 4));
+    // ON THE HANDLE'S STREAM: the handle's streams are non-blocking, so a null-stream hipMemset is not ordered before
+    // the kernels queued next -- a dataflow task could read a recycled allocation's stale flags (another handle's epoch
+    // numbers) or tickets before the clear landed.  Found by scripts/gpu_api_fuzz.py (wrong likelihood / memory fault
+    // right after a batch grew the slot count), present since round 1.
+    HIPCHK(hipMemsetAsync(h->dFlags, 0, S * (2 * h->Nt + 1) * (2 * h->Nt + 1) * 4, h->stream));
     HIPCHK(hipMalloc(&h->dTicket, 16));
-    HIPCHK(hipMemset(h->dTicket, 0, 16));
+    HIPCHK(hipMemsetAsync(h->dTicket, 0, 16, h->stream));
     HIPCHK(hipHostMalloc(&h->hInvEll, S * h->d * 8));
     HIPCHK(hipHostMalloc(&h->hSlotp, S * SLOTP * 8));
     HIPCHK(hipHostMalloc(&h->hRes, S * 2 * 8));

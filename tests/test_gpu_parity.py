@@ -658,3 +658,32 @@ def test_experimental_schedules_give_the_same_factorisation():
         h.set_option(opt, 0)
         assert got[3] == 0 and all(close(got[k], ref[k], n, 1e-11) for k in range(3)), (opt, got, ref)
     h.close()
+
+
+def test_growing_the_slot_count_mid_handle_is_ordered_before_the_next_launch():
+    """Regression (found by scripts/gpu_api_fuzz.py, present since round 1): when a bigger batch re-allocates the
+    workspace slots, the dependency flags and the task ticket of the dataflow schedule are cleared -- that clear used
+    to run on the null stream, which is not ordered before kernels on the handle's non-blocking streams, so the next
+    launch could see a recycled allocation's stale flags (wrong likelihood, info = 0) or a garbage ticket (memory
+    fault).  Many short-lived handles recycle device memory quickly: each one evaluates a few thetas, then a batch
+    that grows the slot count, and every value is checked against numpy on the covariance the library returns."""
+    rng = np.random.default_rng(3)
+    log2pi = np.log(2 * np.pi)
+    for it in range(120):
+        n = int(rng.choice([300, 513, 777, 1100]))
+        d = int(rng.choice([1, 3]))
+        kernel = str(rng.choice(["se_ard", "matern52"]))
+        X, y = syn.make_dataset(n, d, seed=1000 + it)
+        h = _lib.Handle(X, y, kernel)
+        base = syn.default_theta(kernel, d)
+        thetas = lambda B: np.stack([base * (0.7 + 0.6 * rng.random(len(base))) for _ in range(B)])   # noqa: E731
+        h.loglik_batch(thetas(int(rng.integers(1, 4))))              # small slot count first
+        Th = thetas(int(rng.integers(9, 14)))                        # 9-13 thetas: re-allocation + dataflow with many slots
+        out, info = h.loglik_batch(Th)
+        for b in (0, len(Th) - 1):
+            K = h.covariance(Th[b])
+            L = np.linalg.cholesky(K)
+            z = np.linalg.solve(L, y)
+            want = -0.5 * (n * log2pi + 2 * np.log(np.diag(L)).sum() + z @ z)
+            assert info[b] == 0 and close(out[b], want, n), (it, n, kernel, b, out[b], want)
+        h.close()
