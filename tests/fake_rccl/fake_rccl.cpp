@@ -7,7 +7,11 @@
 //     root:   stream-ordered D2H copy of its buffer into the segment, wait, barrier
 //     others: barrier, stream-ordered H2D copy out of the segment, wait;  barrier again before the segment is reused
 // Blocking the host inside a collective is slower than RCCL's asynchronous kernels but orders the data the same way.
-// Segment name: $FAKE_RCCL_SHM (every rank of a job gets the same value); capacity FAKE_RCCL_CAP bytes.
+// Segment name: $FAKE_RCCL_SHM (every rank of a job gets the same value).
+// In-process mode (ncclCommInitAll: ONE process, several "devices" -- here the same GPU listed several times, which the
+// library accepts for RCCL only under GPHIP_COMM=rccl): calls between ncclGroupStart and ncclGroupEnd are recorded and
+// executed together at ncclGroupEnd -- the root's stream is drained, then every other rank's buffer is filled by a
+// device-to-device copy on ITS stream.  That exercises the library's grouped single-process broadcast path.
 #include <fcntl.h>
 #include <hip/hip_runtime.h>
 #include <pthread.h>
@@ -28,6 +32,10 @@ struct Segment {
     char data[CAP];
 };
 struct Comm { int rank, nranks; Segment* seg; };
+struct Op { const void* send; void* recv; size_t bytes; int root; Comm* comm; hipStream_t st; };
+int g_depth = 0;
+Op g_ops[64];
+int g_nops = 0;
 size_t type_size(int t) { return (t == 0 || t == 1) ? 1 : (t == 7 ? 4 : 8); }     // ncclChar/Uint8, Float32, Float64
 }  // namespace
 
@@ -66,9 +74,14 @@ int ncclCommInitRank(void** comm, int nranks, FakeId, int rank) {
     pthread_barrier_wait(&seg->bar);
     return 0;
 }
-int ncclCommInitAll(void**, int, const int*) { return 4; }      // single-process multi-device: not what this fake is for
+int ncclCommInitAll(void** comms, int n, const int*) {
+    if (n > 64) return 3;
+    for (int i = 0; i < n; ++i) comms[i] = new Comm{i, n, nullptr};
+    return 0;
+}
 int ncclCommDestroy(void* c) {
     Comm* comm = static_cast<Comm*>(c);
+    if (!comm->seg) { delete comm; return 0; }
     munmap(comm->seg, sizeof(Segment));
     if (comm->rank == 0 && getenv("FAKE_RCCL_SHM")) shm_unlink(getenv("FAKE_RCCL_SHM"));
     delete comm;
@@ -77,6 +90,11 @@ int ncclCommDestroy(void* c) {
 int ncclBroadcast(const void* send, void* recv, size_t count, int dtype, int root, void* c, hipStream_t st) {
     Comm* comm = static_cast<Comm*>(c);
     const size_t bytes = count * type_size(dtype);
+    if (!comm->seg) {                               // in-process communicator: executed at ncclGroupEnd
+        if (g_depth < 1 || g_nops >= 64) return 4;
+        g_ops[g_nops++] = Op{send, recv, bytes, root, comm, st};
+        return 0;
+    }
     if (bytes > CAP) return 3;
     if (comm->rank == root) {
         if (hipMemcpyAsync(comm->seg->data, send, bytes, hipMemcpyDeviceToHost, st) != hipSuccess) return 1;
@@ -104,8 +122,25 @@ int ncclAllReduce(const void* send, void* recv, size_t count, int dtype, int /*o
     if (hipMemcpyAsync(recv, tot, count * 8, hipMemcpyHostToDevice, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return 1;
     return 0;
 }
-int ncclGroupStart() { return 0; }
-int ncclGroupEnd() { return 0; }
+int ncclGroupStart() { ++g_depth; return 0; }
+int ncclGroupEnd() {
+    if (--g_depth > 0) return 0;
+    int rc = 0;
+    const Op* src = nullptr;
+    for (int i = 0; i < g_nops; ++i)
+        if (g_ops[i].comm->rank == g_ops[i].root) src = &g_ops[i];
+    if (g_nops > 0 && !src) rc = 4;
+    if (src) {
+        if (hipStreamSynchronize(src->st) != hipSuccess) rc = 1;       // the root's data is final
+        for (int i = 0; i < g_nops && rc == 0; ++i) {
+            const Op& o = g_ops[i];
+            const void* from = (&o == src) ? o.send : src->send;
+            if (o.recv != from && hipMemcpyAsync(o.recv, from, o.bytes, hipMemcpyDeviceToDevice, o.st) != hipSuccess) rc = 1;
+        }
+    }
+    g_nops = 0;
+    return rc;
+}
 const char* ncclGetErrorString(int r) {
     static const char* names[] = {"success", "hip error", "shared-memory setup failed", "message too large for the fake",
                                   "not supported by the fake", "FAKE_RCCL_SHM not set"};

@@ -65,3 +65,30 @@ def test_rank_handles_in_separate_processes(tmp_path, n, d, kernel, panel, world
         np.testing.assert_allclose(r["alpha_head"], alpha[:5], rtol=1e-7, atol=1e-9)
     # identical on every rank, bit for bit (same reduction result broadcast back)
     assert all(r["parts"] == res[0]["parts"] for r in res)
+
+
+def test_single_process_grouped_rccl_path(tmp_path):
+    """gphip_create(.., devices, ndev > 1) with RCCL: ncclCommInitAll, one communicator per local rank, the panel
+    broadcast as ncclGroupStart / per-rank ncclBroadcast / ncclGroupEnd issued by ONE host thread.  Real RCCL needs
+    distinct devices, so on a one-GPU box the run binds the tests-only collective library (in-process mode) and
+    GPHIP_COMM=rccl lets virtual ranks use it."""
+    n, d, kernel, world, panel = 1500, 3, "se_ard", 3, 2
+    fake = build.build_fake_rccl()
+    env = dict(os.environ, GPHIP_NO_TORCH="1", GPHIP_RCCL_PATH=fake, GPHIP_COMM="rccl",
+               LD_LIBRARY_PATH="/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+    out = str(tmp_path / "inproc.json")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "inproc_worker.py"), out, str(n), str(d), kernel,
+                        str(world), str(panel)], env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
+    res = json.load(open(out))
+    assert res["comm"]["world"] == world and res["comm"]["local"] == world
+    assert res["comm"]["comm"].startswith("rccl (ncclCommInitAll")
+    X, y = syn.make_dataset(n, d)
+    th = syn.default_theta(kernel, d)
+    want = orc.log_likelihood(kernel, th, X, y, parts=True)
+    ll, ld, qd, info = res["parts"]
+    assert info == 0 and close(ll, want[0], n) and close(ld, want[1], n) and close(qd, want[2], n)
+    assert res["again"] == res["parts"] and res["fit"] == 0
+    mo, so = orc.predict_internal(kernel, th, X, y, syn.make_test_points(700, d))
+    np.testing.assert_allclose(res["mu"], mo, rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(np.sqrt(res["var"]), so, rtol=1e-7)
