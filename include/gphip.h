@@ -143,7 +143,8 @@ int gphip_logdet(gphip_handle h, double* out);
  *                  "dataflow_fine_nt" 128-tiles (default 96, fp64); larger problems hand their last
  *                  "dataflow_tail" tile columns (default 64, 0 = off) to the same kernel
  *   "panel_left"   -1 auto / 0 / 1: left-looking in-panel updates (one K = 128 s update per column instead of
- *                  K = 128 updates after every column); auto = for batches of more than "dataflow_max_slots"
+ *                  K = 128 updates after every column); auto = for batches of more than "dataflow_max_slots" and
+ *                  for panels of >= 8 tiles (the wide early panels of a large factorisation)
  *   "fused_eval"   0/1 (default 1): a pure likelihood call of <= 8 thetas that qualifies for 64-tile dataflow
  *                  runs as ONE kernel launch (K(theta) tiles built inside the kernel, results written to
  *                  pinned host memory by its last task)
