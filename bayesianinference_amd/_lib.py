@@ -13,6 +13,8 @@ import numpy as np
 
 PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG, "lib", "libgphip.so")
+if os.environ.get("GPHIP_LIB"):        # developer A/B runs: another BUILD of the same HIP library (scripts/ab_build.py)
+    LIB_PATH = os.environ["GPHIP_LIB"]
 HEADER = os.path.join(os.path.dirname(PKG), "include", "gphip.h")
 
 OK = 0

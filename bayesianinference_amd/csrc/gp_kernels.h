@@ -15,10 +15,17 @@
 // operand layout (lane -> row l&15, k = l>>4) but NOT the C/D layout -- f64: row = (l>>4) + 4 reg,
 // f32: row = 4 (l>>4) + reg -- which is what Num<T>::drow encodes.
 //
-// Storage: one column-major workspace matrix per batch slot, leading dimension ld = Npad + 128
-// (Npad = N rounded up to the 128 tile).  Rows [Npad, Npad+128) carry right-hand sides as extra
-// ROWS (row Npad = r^T): the panel solve and the trailing update then produce z^T = (L^-1 r)^T in
-// that row and -|z|^2 in element (Npad, Npad) with no extra kernels ("bordered" Cholesky).
+// Storage: one workspace per batch slot in TILE-MAJOR PACKED LOWER-TRIANGULAR form.  The bordered matrix has
+// R = Nt + 1 tile rows (Nt = Npad / 128, Npad = N rounded up to the 128 tile); only the tiles (ti, tj) with
+// ti >= tj exist, each one a contiguous 128 KiB (fp64) block, column-major inside (leading dimension 128), stored
+// tile column by tile column from the diagonal down: tile (ti, tj) sits at tile_index(ti, tj, R) * 128 * 128
+// elements.  So a workgroup's C tile, every LDS-DMA stage of an operand tile and every tile the kernel build
+// writes is ONE contiguous chunk, an outer panel (consecutive tile columns) is one contiguous range (the
+// multi-GPU exchange needs no pack), and a slot costs R (R + 1) / 2 tiles instead of (R * 128)^2 elements.
+// Tile row Nt carries right-hand sides as extra ROWS (row Npad = r^T): the panel solve and the trailing update
+// then produce z^T = (L^-1 r)^T in that row and -|z|^2 in element (Npad, Npad) with no extra kernels
+// ("bordered" Cholesky).  Scratch blocks that are not the factor (V of the substitutions, W_b, K^-1) stay plain
+// column-major with a leading dimension; GEMM operands are described as either form.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -28,6 +35,18 @@
 namespace gphip {
 
 constexpr int TB = 128;         // tile edge
+// Elements between consecutive tiles of the packed workspace: 128 x 128 plus a pad.  Without the pad every tile starts on
+// a 128 KiB (fp64) boundary and the workgroups of a launch, which walk their operand tiles in lock step, all touch the
+// same offsets modulo 128 KiB at the same time -- the same few HBM channels (measured: see DESIGN.md section 3).
+#ifndef GP_TILE_PAD
+#define GP_TILE_PAD 0
+#endif
+constexpr long TS = (long)TB * TB + GP_TILE_PAD;
+
+// index (in tiles) of tile (ti, tj), ti >= tj, in the packed lower-triangular tile-major workspace of R tile rows
+__host__ __device__ __forceinline__ long tile_index(int ti, int tj, int R) {
+    return (long)tj * R - ((long)tj * (tj - 1)) / 2 + (ti - tj);
+}
 constexpr int SLOTP = 8;        // doubles of per-slot scalars: sf2, sn2, mu, pivot_tol, bad_theta
 
 typedef double d4 __attribute__((ext_vector_type(4)));
@@ -197,8 +216,8 @@ __device__ __forceinline__ void tri_decode(int t, int n, int& ti, int& tj) {
 
 template <typename T>
 struct KBuildArgs {
-    T* out;                 // workspace base (slot 0)
-    long ld;                // leading dimension (elements)
+    T* out;                 // mode 0: tiled workspace base (slot 0); mode 1: column-major block
+    long ld;                // mode 1: leading dimension (elements)
     long bstride;           // elements between slots
     const T* xi;            // scaled I-operand points [slot][D][npad_i]  (rows of the output)
     const T* xj;            // scaled J-operand points [slot][D][npad_j]  (columns of the output)
@@ -212,6 +231,9 @@ struct KBuildArgs {
                             // 1: cross  (rectangular tiles, zero padding)
     int nt_i, nt_j;         // tile counts; mode 0: nt_i = nt_j + 1 (extra rhs block-row)
     const double* exp2tab;  // [EXP_TAB] 2^(j/512) (fp64 build only)
+    // Point-dependent nugget / mean (BGP:37 nugget[points[[i]]], BGP:300 meanFunction /@ inputData): values the host
+    // evaluated for this call's theta, [slot][pw_bstride]; null = the constant forms sn^2 / mu of the slot scalars
+    const T* pw_nug; const T* pw_mean; long pw_bstride;
     int own_panel, own_world, own_rank;   // own_world > 0 (multi-GPU 1-D block-cyclic layout): build
                             // only tile columns whose outer panel (tj / own_panel) belongs to own_rank;
                             // the rhs x rhs corner tile belongs to rank 0
@@ -240,7 +262,11 @@ __global__ __launch_bounds__(256) void kbuild_kernel(KBuildArgs<T> a) {
     }
     const double* sp = a.slotp + (long)slot * SLOTP;
     const T sf2 = (T)sp[0], sn2 = (T)sp[1], mu = (T)sp[2];
-    T* out = a.out + (long)slot * a.bstride + (long)tj * TB * a.ld + (long)ti * TB;
+    // mode 0 writes one whole tile of the packed workspace (128 KiB contiguous in fp64); mode 1 a tile of a
+    // column-major block
+    const long ldo = (a.mode == 0) ? (long)TB : a.ld;
+    T* out = a.out + (long)slot * a.bstride +
+             ((a.mode == 0) ? tile_index(ti, tj, a.nt_i) * TS : (long)tj * TB * a.ld + (long)ti * TB);
     const int r0 = 2 * lane;
 
     if (a.mode == 0 && ti == a.nt_i - 1) {      // right-hand-side block-row: row 0 = r^T, rest 0
@@ -249,8 +275,9 @@ __global__ __launch_bounds__(256) void kbuild_kernel(KBuildArgs<T> a) {
             pair_t v;
             v.x = (T)0;
             v.y = (T)0;
-            if (lane == 0 && tj < a.nt_j && gj < a.n_j) v.x = a.y[gj] - mu;
-            *reinterpret_cast<pair_t*>(out + (long)jj * a.ld + r0) = v;
+            if (lane == 0 && tj < a.nt_j && gj < a.n_j)
+                v.x = a.y[gj] - (a.pw_mean ? a.pw_mean[(long)slot * a.pw_bstride + gj] : mu);
+            *reinterpret_cast<pair_t*>(out + (long)jj * ldo + r0) = v;
         }
         return;
     }
@@ -283,7 +310,12 @@ __global__ __launch_bounds__(256) void kbuild_kernel(KBuildArgs<T> a) {
     const int gi = ti * TB + r0;
     const bool edge = (a.mode == 0) ? (ti == tj || (ti + 1) * TB > a.n_i)
                                     : ((ti + 1) * TB > a.n_i || (tj + 1) * TB > a.n_j);
-    for (int jj = wave * 32; jj < wave * 32 + 32; ++jj) {
+#ifndef GP_KB_INTERLEAVE
+#define GP_KB_INTERLEAVE 1
+#endif
+    // columns of the tile dealt round-robin to the four waves: at any moment the workgroup writes four ADJACENT 1 KiB
+    // column segments (one contiguous 4 KiB of the tile) instead of four segments 32 KiB apart
+    for (int jj = GP_KB_INTERLEAVE ? wave : wave * 32; jj < (GP_KB_INTERLEAVE ? TB : wave * 32 + 32); jj += GP_KB_INTERLEAVE ? 4 : 1) {
         T ra = (T)0, rb = (T)0;
         if (D > 0) {
 #pragma unroll
@@ -318,8 +350,11 @@ __global__ __launch_bounds__(256) void kbuild_kernel(KBuildArgs<T> a) {
         if (edge) {
             const int gj = tj * TB + jj;
             if (a.mode == 0) {
-                if (gi == gj) va += sn2;
-                if (gi + 1 == gj) vb += sn2;
+                if (gi == gj || gi + 1 == gj) {
+                    const T nug = a.pw_nug ? a.pw_nug[(long)slot * a.pw_bstride + gj] : sn2;
+                    if (gi == gj) va += nug;
+                    else vb += nug;
+                }
                 if (gj >= a.n_j || gi >= a.n_i) va = (gi == gj) ? (T)1 : (T)0;       // identity pad
                 if (gj >= a.n_j || gi + 1 >= a.n_i) vb = (gi + 1 == gj) ? (T)1 : (T)0;
             } else {
@@ -330,7 +365,7 @@ __global__ __launch_bounds__(256) void kbuild_kernel(KBuildArgs<T> a) {
         pair_t v;
         v.x = va;
         v.y = vb;
-        *reinterpret_cast<pair_t*>(out + (long)jj * a.ld + r0) = v;
+        *reinterpret_cast<pair_t*>(out + (long)jj * ldo + r0) = v;
     }
 }
 
@@ -740,7 +775,7 @@ __device__ __noinline__ void potrf128_core_call(double* lds_raw, T* Ad, long ld,
     potrf128_core<T, NB>(lds_raw, Ad, ld, Wg, logdet_out, info_out, tol);
 }
 template <typename T>
-__global__ __launch_bounds__(256) void potrf128_kernel(T* __restrict__ Abase, long ld, long bstride, int b,
+__global__ __launch_bounds__(256) void potrf128_kernel(T* __restrict__ Abase, long bstride, int b,
                                                        T* __restrict__ Winv, double* __restrict__ partial,
                                                        int nt, int* __restrict__ info,
                                                        const double* __restrict__ slotp) {
@@ -749,7 +784,8 @@ __global__ __launch_bounds__(256) void potrf128_kernel(T* __restrict__ Abase, lo
     const int tid = threadIdx.x;
     const int er = tid & 15, ec = tid >> 4;
     const int slot = blockIdx.x;
-    T* Ad = Abase + (long)slot * bstride + (long)b * TB * (ld + 1);
+    constexpr long ld = TB;
+    T* Ad = Abase + (long)slot * bstride + tile_index(b, b, nt + 1) * TS;       // diagonal tile b of the packed workspace
     for (int bi = 0; bi < 8; ++bi)
         for (int bj = 0; bj <= bi; ++bj)
             Ls[ptile(bi, bj) + tid] = Ad[(long)(bj * 16 + ec) * ld + bi * 16 + er];
@@ -763,7 +799,7 @@ __global__ __launch_bounds__(256) void potrf128_kernel(T* __restrict__ Abase, lo
 // The fine-grained (64x64) dataflow schedule only produces inverses of 64-blocks; the solve /
 // prediction / gradient paths substitute with 128-blocks, so gphip_fit re-inverts once here.
 template <typename T>
-__global__ __launch_bounds__(256) void trtri128_kernel(const T* __restrict__ Abase, long ld, long bstride,
+__global__ __launch_bounds__(256) void trtri128_kernel(const T* __restrict__ Abase, long bstride,
                                                        T* __restrict__ Winv, int nt) {
     extern __shared__ double lds_raw[];
     T* Ls = reinterpret_cast<T*>(lds_raw + 2);
@@ -771,7 +807,8 @@ __global__ __launch_bounds__(256) void trtri128_kernel(const T* __restrict__ Aba
     const int tid = threadIdx.x;
     const int er = tid & 15, ec = tid >> 4;
     const int b = blockIdx.x, slot = blockIdx.y;
-    const T* Ad = Abase + (long)slot * bstride + (long)b * TB * (ld + 1);
+    constexpr long ld = TB;
+    const T* Ad = Abase + (long)slot * bstride + tile_index(b, b, nt + 1) * TS;
     for (int bi = 0; bi < 8; ++bi)
         for (int bj = 0; bj <= bi; ++bj)
             Ls[ptile(bi, bj) + tid] = Ad[(long)(bj * 16 + ec) * ld + bi * 16 + er];
@@ -804,6 +841,15 @@ struct GemmArgs {
     T* C; long ldc; long c_bstride;
     const T* A; long lda; long a_bstride;        // I operand: A(i,k) at A[i + k*lda]
     const T* B; long ldb; long b_bstride;        // J operand: B(j,k) at B[j + k*ldb]
+    // Each of C / A / B is either a column-major block (x_R = 0: pointer + leading dimension, as above) or lives in
+    // the packed tile-major workspace (x_R = R > 0 tile rows: pointer = slot base, ld ignored):
+    //   C tile (ti, tj)                          -> tile_index(ti, tj, c_R)
+    //   A(i,k), i in tile row ti                 -> tile (ti, a_k0 + k/128), element (i % 128, k % 128)
+    //   B(j,k), j in tile row tj                 -> tile (tj, b_k0 + k/128)
+    //   ROLE 3 (B read transposed), B(j,k) = L(b_k0*128 + k, tj*128 + j) -> tile (b_k0 + k/128, tj), element (k % 128, j)
+    // a_k0 / b_k0 = tile column where the operand panel starts.  The base pointer may be shifted so that a panel kept
+    // OUTSIDE the workspace (a received panel of the multi-GPU schedule) is addressed with its global tile indices.
+    int c_R, a_R, b_R, a_k0, b_k0;
     int K;                                       // multiple of GK
     int r0, r1, c0, c1;                          // tile ranges: rows [r0,r1), cols [c0,c1)
     int tri;                                     // 1: keep only tiles with ti >= tj (needs r0 >= c0)
@@ -865,6 +911,7 @@ template <> __device__ __forceinline__ int lds_off<float>(int k, int row) {
 template <typename T, int ROLE, int NWI, int NWJ, int NBUF>
 __global__ __launch_bounds__(64 * NWI * NWJ, (NWI * NWJ == 4) ? 2 : 4) void gemm_nt_kernel(GemmArgs<T> g) {
     constexpr int NW = NWI * NWJ, FI = 8 / NWI, FJ = 8 / NWJ;      // MFMA tiles per wave along i / j
+    const bool c_tiled = g.c_R > 0, a_tiled = g.a_R > 0, b_tiled = g.b_R > 0;
     extern __shared__ double smem_raw[];       // [2 stages][I tile | J tile]
     T* smem = reinterpret_cast<T*>(smem_raw);
     typedef typename Num<T>::acc_t acc_t;
@@ -923,36 +970,79 @@ __global__ __launch_bounds__(64 * NWI * NWJ, (NWI * NWJ == 4) ? 2 : 4) void gemm
         }
         gemm_tile_decode(g, bid, r0, c0, nrect, ti, tj);
     }
+    // the decode goes through a floating-point square root, i.e. the vector ALU: hand the (wave-uniform) tile indices back
+    // to the scalar unit, or every tile address below -- one per operand and LDS stage -- is 64-bit VECTOR arithmetic
+    // issued between the MFMAs (measured: -1.8 % on the trailing SYRK)
+    ti = __builtin_amdgcn_readfirstlane(ti);
+    tj = __builtin_amdgcn_readfirstlane(tj);
+    slot = __builtin_amdgcn_readfirstlane(slot);
 
     const long koff = g.ktri ? (long)ti * TB : 0;          // first k of this tile's contraction
-    const T* Ag = g.A + (long)slot * g.a_bstride + (long)ti * TB + koff * g.lda;
-    const T* Bg = g.B + (long)slot * g.b_bstride + (ROLE == 3 ? (long)tj * TB * g.ldb + koff : (long)tj * TB + koff * g.ldb);
+    const T* Abase = g.A + (long)slot * g.a_bstride;
+    const T* Bbase = g.B + (long)slot * g.b_bstride;
+    const long lda = a_tiled ? (long)TB : g.lda, ldb = b_tiled ? (long)TB : g.ldb;
+    // address of A(ti*128, k) / B(tj*128, k) (ROLE 3: of B(j = tj*128, k) = L(.. + k, tj*128)) for a stage start k; a stage
+    // (GK columns) never straddles a k-tile
+    auto a_at = [&](long k) -> const T* {
+        if (a_tiled) return Abase + tile_index(ti, g.a_k0 + (int)(k >> 7), g.a_R) * TS + (k & 127) * TB;
+        return Abase + (long)ti * TB + k * g.lda;
+    };
+    auto b_at = [&](long k) -> const T* {
+        if (ROLE == 3) {
+            if (b_tiled) return Bbase + tile_index(g.b_k0 + (int)(k >> 7), tj, g.b_R) * TS + (k & 127);
+            return Bbase + (long)tj * TB * g.ldb + k;
+        }
+        if (b_tiled) return Bbase + tile_index(tj, g.b_k0 + (int)(k >> 7), g.b_R) * TS + (k & 127) * TB;
+        return Bbase + (long)tj * TB + k * g.ldb;
+    };
     // Staging: LDS-DMA (global_load_lds_dwordx4), no staging registers and no ds_write pass.  One
     // wave-instruction moves 1 KiB landing lane-linear at a wave-uniform LDS base: fp64 = one
     // k-column of 128 rows; fp32 = the two k-columns of one pair (lanes 0-31 / 32-63).  Wave w
     // issues instructions w, w+4, w+8, w+12 of both tiles.
     const int uw = __builtin_amdgcn_readfirstlane(wave);
+    // Stages are issued strictly in order kb = 0, 1, 2, ..: the operand addresses are RUNNING scalar pointers (one add per
+    // stage; at a k-tile boundary of a tiled operand one jump to the next tile of the row: tile (ti, kt + 1) follows tile
+    // (ti, kt) by R - kt - 1 tiles, and for ROLE 3's transposed J operand tile (kt + 1, tj) follows (kt, tj) directly)
+    const T* a_run = a_at(koff);
+    const T* b_run = b_at(koff);
+    int a_left = a_tiled ? g.a_R - (g.a_k0 + (int)(koff >> 7)) - 1 : 0;       // tiles from (ti, kt) to (ti, kt + 1)
+    int b_left = b_tiled ? g.b_R - (g.b_k0 + (int)(koff >> 7)) - 1 : 0;
+    int kin = 0;                                                               // columns of the current k-tile already staged
     auto stage = [&](int kb, int st) {
+        (void)kb;
         T* Is = smem + st * STAGE;
         T* Js = Is + JOFF;
+        const T* Ag = a_run;                       // column kb*GK of this tile's contraction, row 0 of the tile
+        const T* Bg = b_run;
+        a_run += (long)GK * lda;
+        b_run += (ROLE == 3) ? (long)GK : (long)GK * ldb;
+        kin += GK;
+        if (kin == TB) {
+            kin = 0;
+            if (a_tiled) { a_run += (long)a_left * TS - (long)TB * TB; --a_left; }
+            if (b_tiled) {
+                if (ROLE == 3) b_run += TS - TB;
+                else { b_run += (long)b_left * TS - (long)TB * TB; --b_left; }
+            }
+        }
 #pragma unroll
         for (int s = 0; s < (NW >= 16 ? 1 : 16 / NW); ++s) {
             const int q = uw + NW * s;          // instruction index 0..15 within the stage
             if (F64) {
-                const long kcol = (long)kb * GK + q;
-                __builtin_amdgcn_global_load_lds((glb_void*)(Ag + kcol * g.lda + 2 * lane),
+                const long kcol = q;
+                __builtin_amdgcn_global_load_lds((glb_void*)(Ag + kcol * lda + 2 * lane),
                                                  (lds_void*)(Is + q * LDT), 16, 0, 0);
                 if (ROLE != 3)
-                    __builtin_amdgcn_global_load_lds((glb_void*)(Bg + kcol * g.ldb + 2 * lane),
+                    __builtin_amdgcn_global_load_lds((glb_void*)(Bg + kcol * ldb + 2 * lane),
                                                      (lds_void*)(Js + q * LDT), 16, 0, 0);
             } else {
                 // pair q holds columns k0 = 4(q>>1) + (q&1) (lanes 0-31) and k0 + 2 (lanes 32-63)
-                const long kcol = (long)kb * GK + 4 * (q >> 1) + (q & 1) + 2 * (lane >> 5);
+                const long kcol = 4 * (q >> 1) + (q & 1) + 2 * (lane >> 5);
                 const int row = 4 * (lane & 31);
-                __builtin_amdgcn_global_load_lds((glb_void*)(Ag + kcol * g.lda + row),
+                __builtin_amdgcn_global_load_lds((glb_void*)(Ag + kcol * lda + row),
                                                  (lds_void*)(Is + q * LDP), 16, 0, 0);
                 if (ROLE != 3)
-                    __builtin_amdgcn_global_load_lds((glb_void*)(Bg + kcol * g.ldb + row),
+                    __builtin_amdgcn_global_load_lds((glb_void*)(Bg + kcol * ldb + row),
                                                      (lds_void*)(Js + q * LDP), 16, 0, 0);
             }
             if (ROLE == 3) {
@@ -960,15 +1050,17 @@ __global__ __launch_bounds__(64 * NWI * NWJ, (NWI * NWJ == 4) ? 2 : 4) void gemm
                 // image Js[j*GK + G*((k/G) ^ (j&7)) + k%G], G = elements per 16 B (swizzle on the source)
                 constexpr int G = 16 / (int)sizeof(T);
                 const int j = 8 * q + (lane >> 3), kg = (lane & 7) ^ (j & 7);
-                __builtin_amdgcn_global_load_lds((glb_void*)(Bg + (long)kb * GK + G * kg + (long)j * g.ldb),
+                __builtin_amdgcn_global_load_lds((glb_void*)(Bg + G * kg + (long)j * ldb),
                                                  (lds_void*)(Js + q * 8 * GK), 16, 0, 0);
             }
         }
     };
 
     // C tile: lane holds i = i0 + y*16 + (lane&15), j = j0 + x*16 + drow(lane>>4, r)
-    T* Cg = g.C + (long)slot * g.c_bstride + ((long)tj * TB + wj * (16 * FJ)) * g.ldc + (long)ti * TB +
-            wi * (16 * FI) + (lane & 15);
+    const long ldc = c_tiled ? (long)TB : g.ldc;
+    T* Cg = g.C + (long)slot * g.c_bstride +
+            (c_tiled ? tile_index(ti, tj, g.c_R) * TS : (long)tj * TB * g.ldc + (long)ti * TB) +
+            (long)(wj * (16 * FJ)) * ldc + wi * (16 * FI) + (lane & 15);
     const int l4 = lane >> 4;
     const int nk = (g.K - (int)koff) / GK;
     // Update roles start the accumulators AT C and feed the MFMA the negated J fragment, so acc ends
@@ -998,7 +1090,7 @@ __global__ __launch_bounds__(64 * NWI * NWJ, (NWI * NWJ == 4) ? 2 : 4) void gemm
                 } else {
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        acc[x][y][r] = Cg[(long)(x * 16 + Num<T>::drow(l4, r)) * g.ldc + y * 16];
+                        acc[x][y][r] = Cg[(long)(x * 16 + Num<T>::drow(l4, r)) * ldc + y * 16];
                 }
             }
     };
@@ -1099,7 +1191,7 @@ __global__ __launch_bounds__(64 * NWI * NWJ, (NWI * NWJ == 4) ? 2 : 4) void gemm
             for (int x = 0; x < FJ; ++x)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    T* cp = Cg + (long)(x * 16 + Num<T>::drow(l4, r)) * g.ldc;
+                    T* cp = Cg + (long)(x * 16 + Num<T>::drow(l4, r)) * ldc;
 #pragma unroll
                     for (int y = 0; y < NY; ++y) cp[y * 16] = acc[x][y][r];
                 }
@@ -1132,7 +1224,7 @@ __global__ __launch_bounds__(64 * NWI * NWJ, (NWI * NWJ == 4) ? 2 : 4) void gemm
     for (int x = 0; x < FJ; ++x)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            T* cp = Cg + (long)(x * 16 + Num<T>::drow(l4, r)) * g.ldc;
+            T* cp = Cg + (long)(x * 16 + Num<T>::drow(l4, r)) * ldc;
 #pragma unroll
             for (int y = 0; y < FI; ++y) cp[y * 16] = acc[x][y][r];
         }
@@ -1164,7 +1256,9 @@ __global__ __launch_bounds__(64 * NWI * NWJ, (NWI * NWJ == 4) ? 2 : 4) void gemm
 // ---------------------------------------------------------------------------------------------
 template <typename T>
 struct DfArgs {
-    T* A; long ld; long bstride;              // workspace (column-major, leading dimension ld) per slot
+    T* A; long bstride;                       // packed tile-major workspace (slot 0 base), elements between slots
+    int R128, c0;                             // R128 = Nt + 1 tile rows of the workspace (128-tiles); c0 = first tile column
+                                              // (in TBX units) of the trailing submatrix this launch factors
     T* W; long w_bstride;                     // W_b = L_bb^-1 blocks, [slot][nd][TBX*TBX]
     double* partial; long p_bstride;          // sum log L_jj per diagonal block, [slot * p_bstride + j]
     int* info;                                // [slot]
@@ -1257,7 +1351,8 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g, Th
     if (j > R - 1) j = R - 1;
     while (j + 1 < R && (j + 1) * R - (j + 1) * j / 2 <= q) ++j;
     while (j > 0 && j * R - j * (j - 1) / 2 > q) --j;
-    const int i = j + (q - (j * R - j * (j - 1) / 2));
+    j = __builtin_amdgcn_readfirstlane(j);                 // (through the vector sqrt: back to the scalar unit)
+    const int i = __builtin_amdgcn_readfirstlane(j + (q - (j * R - j * (j - 1) / 2)));
 
     long long* tr = g.trace ? g.trace + (long)task * 8 : nullptr;
     auto stamp = [&](int k) { if (tr && tid == 0) tr[k] = wall_clock64(); };
@@ -1271,7 +1366,15 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g, Th
     T* As = g.A + (long)slot * g.bstride;
     int* F = g.flags + (long)slot * g.f_bstride;
     T* Wj = g.W + (long)slot * g.w_bstride + (long)j * TBX * TBX;
-    T* Ct = As + (long)j * TBX * g.ld + (long)i * TBX;    // tile (i,j)
+    // TBX-tile (ti, tj) of this launch's submatrix inside the packed tile-major workspace; leading dimension 128
+    // either way (a 64-tile is a quadrant of its 128-tile)
+    auto tptr = [&](int ti_, int tj_) -> T* {
+        const int gi = ti_ + g.c0, gj = tj_ + g.c0;
+        if constexpr (TBX == 128) return As + tile_index(gi, gj, g.R128) * TS;
+        else return As + tile_index(gi >> 1, gj >> 1, g.R128) * TS + (long)(gj & 1) * 64 * TB + (gi & 1) * 64;
+    };
+    constexpr long LDA = TB;
+    T* Ct = tptr(i, j);                                    // tile (i,j)
     // per-slot scalars {sf2, sn2, mu, pivot tol, ..}: from the argument pack (BUILD) or from device memory
     const double* sp = BUILD ? tp.v + g.nslots * g.d + slot * SLOTP : g.slotp + (long)slot * SLOTP;
     if (BUILD && q == 0 && tid == 0) g.info[slot] = 0;     // task 0 of the slot precedes every potrf of the slot
@@ -1374,22 +1477,36 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g, Th
     // acc (+/-)= I J^T over nk LDS stages; I(i,k) at Ig[i + k*ldi], J(j,k) at Jg[j + k*ldj].  Same
     // LDS-DMA double buffer as gemm_nt (see there).  No dependency waits in here: a poll loop nested in
     // this loop makes the register allocator spill accumulators around it.
-    auto run_k = [&](acc_t (&A)[FJ][FI], const T* Ig, long ldi, const T* Jg, long ldj, int nk, bool negate) {
+    // mi >= 0: both operands walk the finished tile columns 0, 1, .. of tile rows mi / mj (one TBX-wide slab = SPB
+    // stages per column; the columns are separate tiles of the packed workspace); otherwise Ig / Jg are contiguous in k.
+    auto run_k_impl = [&](auto multi_c, acc_t (&A)[FJ][FI], const T* Ig0, long ldi, const T* Jg0, long ldj, int nk, bool negate,
+                          int mi, int mj) {
+        constexpr bool MULTI = decltype(multi_c)::value;
         auto stage = [&](int kb, int st) {
             T* Is = smem + st * STAGE;
             T* Js = Is + JOFF;
+            const T *Ig, *Jg;                               // column 0 of stage kb
+            if constexpr (MULTI) {
+                const int bcol = kb / SPB;
+                const long o = (long)(kb % SPB) * GK * LDA;
+                Ig = tptr(mi, bcol) + o;
+                Jg = tptr(mj, bcol) + o;
+            } else {
+                Ig = Ig0 + (long)kb * GK * ldi;
+                Jg = Jg0 + (long)kb * GK * ldj;
+            }
             if constexpr (TBX == 128) {
 #pragma unroll
                 for (int s2 = 0; s2 < 4; ++s2) {
                     const int qq = uw + 4 * s2;
                     if (F64) {
-                        const long kcol = (long)kb * GK + qq;
+                        const long kcol = qq;
                         __builtin_amdgcn_global_load_lds((glb_void*)(Ig + kcol * ldi + 2 * lane),
                                                          (lds_void*)(Is + qq * LDT), 16, 0, 0);
                         __builtin_amdgcn_global_load_lds((glb_void*)(Jg + kcol * ldj + 2 * lane),
                                                          (lds_void*)(Js + qq * LDT), 16, 0, 0);
                     } else {
-                        const long kcol = (long)kb * GK + 4 * (qq >> 1) + (qq & 1) + 2 * (lane >> 5);
+                        const long kcol = 4 * (qq >> 1) + (qq & 1) + 2 * (lane >> 5);
                         const int row = 4 * (lane & 31);
                         __builtin_amdgcn_global_load_lds((glb_void*)(Ig + kcol * ldi + row),
                                                          (lds_void*)(Is + qq * LDP), 16, 0, 0);
@@ -1401,7 +1518,7 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g, Th
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
                     const int qq = uw + 4 * s2;           // 8 instructions per operand tile
-                    const long kcol = (long)kb * GK + 4 * (qq >> 1) + (qq & 1) + 2 * (lane >> 5);
+                    const long kcol = 4 * (qq >> 1) + (qq & 1) + 2 * (lane >> 5);
                     const int row = 2 * (lane & 31);
                     __builtin_amdgcn_global_load_lds((glb_void*)(Ig + kcol * ldi + row),
                                                      (lds_void*)(Is + qq * LD64), 16, 0, 0);
@@ -1467,6 +1584,9 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g, Th
             }
         }
     };
+    auto run_k = [&](acc_t (&A)[FJ][FI], const T* Ig0, long ldi, const T* Jg0, long ldj, int nk, bool negate) {
+        run_k_impl(std::false_type{}, A, Ig0, ldi, Jg0, ldj, nk, negate, 0, 0);
+    };
     auto publish = [&](int fi_, int fj_) {                  // everything this workgroup stored is visible first
         __threadfence();
         __syncthreads();
@@ -1485,7 +1605,7 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g, Th
 
     // ---- accumulate the updates of all earlier columns
     if constexpr (BUILD) build_tile(acc);
-    else if (j > 0 || i == j) load_c(acc, Ct, g.ld);
+    else if (j > 0 || i == j) load_c(acc, Ct, LDA);
     // A task that starts late finds most of its columns finished already.  Polling them one by one costs a
     // dependent ~1 us flag load (and an L2 invalidate) per slab -- more than a 64-wide slab's MFMA work --
     // so wave 0 peeks at all of them in parallel ONCE, and the leading run of finished columns is taken
@@ -1517,7 +1637,7 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g, Th
         // would cost as much as its MFMAs).  Not for 128-tiles: with 128 accumulator registers a variable
         // trip count makes the allocator spill inside the stage loop.
         if (known > 0) {
-            run_k(acc, As + (long)i * TBX, g.ld, As + (long)j * TBX, g.ld, known * SPB, true);
+            run_k_impl(std::true_type{}, acc, nullptr, LDA, nullptr, LDA, known * SPB, true, i, j);
             b0 = known;
         }
     }
@@ -1530,20 +1650,20 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g, Th
             __syncthreads();
         }
         if (b == j - 1) stamp(6);
-        run_k(acc, As + (long)b * TBX * g.ld + (long)i * TBX, g.ld, As + (long)b * TBX * g.ld + (long)j * TBX, g.ld, SPB, true);
+        run_k(acc, tptr(i, b), LDA, tptr(j, b), LDA, SPB, true);
     }
     stamp(1);
 
     if constexpr (FUSE) {
         if (accp) {                                         // hand the pre-solve tile (j+1,j) to the diagonal task
-            if (BUILD || j > 0) store_c(acc, Ct, g.ld);
+            if (BUILD || j > 0) store_c(acc, Ct, LDA);
             publish(j, i);                                  // "pre" flag lives in the unused upper slot (j, j+1)
             stamp(4);
             return;
         }
         if (diagx) {
             const int jm = j - 1;
-            T* Xt = As + (long)jm * TBX * g.ld + (long)j * TBX;            // tile (j, j-1)
+            T* Xt = tptr(j, jm);                                           // tile (j, j-1)
             if (wave == 0) {
                 df_wait(F + jm * R + j, g.epoch, g.abort_flag);           // pre-solve tile stored by its owner
                 df_wait(F + jm * R + jm, g.epoch, g.abort_flag);          // W_{j-1}
@@ -1552,8 +1672,8 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g, Th
             stamp(5);
             acc_t accx[FJ][FI];
             zero_c(accx);
-            run_k(accx, Xt, g.ld, g.W + (long)slot * g.w_bstride + (long)jm * TBX * TBX, TBX, SPB, false);
-            store_c(accx, Xt, g.ld);                        // X(j,j-1): the column below waits for it
+            run_k(accx, Xt, LDA, g.W + (long)slot * g.w_bstride + (long)jm * TBX * TBX, TBX, SPB, false);
+            store_c(accx, Xt, LDA);                        // X(j,j-1): the column below waits for it
             // X -> four LDS stage images [k][row] (both MFMA operands of X X^T read the same image)
 #pragma unroll
             for (int x = 0; x < FJ; ++x)
@@ -1589,7 +1709,7 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g, Th
 
     if (i == j) {
         if (j == g.nd) {                                    // corner of the border: -|z|^2 accumulates here
-            store_c(acc, Ct, g.ld);
+            store_c(acc, Ct, LDA);
             if constexpr (BUILD) {
                 // this task depends (transitively) on every other task of the slot: everything is final
                 if (wave == 0) {
@@ -1621,7 +1741,7 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g, Th
             }
         __syncthreads();
         stamp(2);
-        potrf128_core_call<T, TBX / 16>(smem_raw, Ct, g.ld, Wj, g.partial + (long)slot * g.p_bstride + j, g.info + slot,
+        potrf128_core_call<T, TBX / 16>(smem_raw, Ct, LDA, Wj, g.partial + (long)slot * g.p_bstride + j, g.info + slot,
                                         (T)sp[3]);
         stamp(3);
         publish(j, j);
@@ -1631,7 +1751,7 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g, Th
 
     // ---- panel solve X(i,j) = acc W_j^T: the pre-solve tile goes through memory to become an MFMA operand
     if (BUILD || j > 0) {
-        store_c(acc, Ct, g.ld);
+        store_c(acc, Ct, LDA);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
@@ -1640,9 +1760,9 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g, Th
     if (wave == 0) df_wait(F + j * R + j, g.epoch, g.abort_flag);
     __syncthreads();
     stamp(5);
-    run_k(acc, Ct, g.ld, Wj, TBX, SPB, false);
+    run_k(acc, Ct, LDA, Wj, TBX, SPB, false);
     stamp(3);
-    store_c(acc, Ct, g.ld);
+    store_c(acc, Ct, LDA);
     publish(i, j);
     stamp(4);
 }
@@ -1651,7 +1771,7 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g, Th
 // the info words and the dataflow abort flag are ALSO written straight into pinned host memory
 // (hres[2*slots], hinfo[slots + 1]): the caller only synchronises the stream, no device-to-host copies.
 template <typename T>
-__global__ void finalize_kernel(const T* __restrict__ Abase, long ld, long bstride, int npad,
+__global__ void finalize_kernel(const T* __restrict__ Abase, long bstride, long corner,
                                 const double* __restrict__ partial, int nt, double* __restrict__ res,
                                 const int* __restrict__ info = nullptr, const int* __restrict__ abort_flag = nullptr,
                                 double* __restrict__ hres = nullptr, int* __restrict__ hinfo = nullptr,
@@ -1664,7 +1784,8 @@ __global__ void finalize_kernel(const T* __restrict__ Abase, long ld, long bstri
     for (int b = threadIdx.x; b < n2; b += 64) s += partial2[(long)slot * n2 + b];
     for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
     if (threadIdx.x == 0) {
-        const double logdet = 2.0 * s, quad = -(double)Abase[(long)slot * bstride + (long)npad * ld + npad];
+        // corner = element offset of (Npad, Npad): the first element of the workspace's last tile (Nt, Nt)
+        const double logdet = 2.0 * s, quad = -(double)Abase[(long)slot * bstride + corner];
         res[slot * 2 + 0] = logdet;
         res[slot * 2 + 1] = quad;
         if (hres) {
@@ -1687,7 +1808,7 @@ __global__ void finalize_kernel(const T* __restrict__ Abase, long ld, long bstri
 // grid = (mpad/128, nstrips, nslots); part: [slot][strip][2][mpad].
 template <typename T>
 __global__ __launch_bounds__(256) void predict_partial_kernel(const T* __restrict__ V, long ldv, long v_bstride, int ncols,
-                                                              const T* __restrict__ zrow, long ldz, long z_bstride,
+                                                              const T* __restrict__ zbase, int zR, long z_bstride,
                                                               int js, double* __restrict__ part, int nstrips) {
     extern __shared__ double pr_lds[];            // z strip [js] + reduction scratch [4][2][128]
     typedef typename Num<T>::pair_t pair_t;
@@ -1698,8 +1819,12 @@ __global__ __launch_bounds__(256) void predict_partial_kernel(const T* __restric
     const int j0 = strip * js;
     const int jn = (ncols - j0 < js) ? (ncols - j0) : js;       // columns of this strip (<= 0: nothing to add)
     V += (long)slot * v_bstride + (long)tb * TB + 2 * lane;
-    zrow += (long)slot * z_bstride;
-    for (int j = tid; j < jn; j += 256) zs[j] = (double)zrow[(long)(j0 + j) * ldz];
+    // z_j = element (Npad, j) of the slot's factor: row 0 of tile (Nt, j / 128) of the packed workspace (zR = Nt + 1)
+    zbase += (long)slot * z_bstride;
+    for (int j = tid; j < jn; j += 256) {
+        const int gj = j0 + j;
+        zs[j] = (double)zbase[tile_index(zR - 1, gj >> 7, zR) * TS + (long)(gj & 127) * TB];
+    }
     __syncthreads();
     double d0 = 0.0, d1 = 0.0, n0 = 0.0, n1 = 0.0;
     int j = wave;
@@ -1733,8 +1858,10 @@ __global__ __launch_bounds__(256) void predict_partial_kernel(const T* __restric
 }
 
 // Stage 2: mean / var per test point from the strip partials, mu and kappa = sf^2 + sn^2 of the slot's theta.
+// pw_mean / pw_nug (optional, [slot][out_bstride]): m(x*_t) and nugget(x*_t) evaluated by the host (BGP:113, 408).
 __global__ void predict_finish_kernel(const double* __restrict__ part, int nstrips, long mpad, const double* __restrict__ slotp,
-                                      int m, long out_bstride, double* __restrict__ mean, double* __restrict__ var) {
+                                      int m, long out_bstride, double* __restrict__ mean, double* __restrict__ var,
+                                      const double* __restrict__ pw_mean = nullptr, const double* __restrict__ pw_nug = nullptr) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int slot = blockIdx.y;
     if (t >= m) return;
@@ -1744,8 +1871,9 @@ __global__ void predict_finish_kernel(const double* __restrict__ part, int nstri
         dot += part[(((long)slot * nstrips + s) * 2 + 0) * mpad + t];
         nrm += part[(((long)slot * nstrips + s) * 2 + 1) * mpad + t];
     }
-    mean[(long)slot * out_bstride + t] = sp[2] + dot;
-    var[(long)slot * out_bstride + t] = sp[0] + sp[1] - nrm;
+    const long o = (long)slot * out_bstride + t;
+    mean[o] = (pw_mean ? pw_mean[o] : sp[2]) + dot;
+    var[o] = sp[0] + (pw_nug ? pw_nug[o] : sp[1]) - nrm;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1756,6 +1884,13 @@ __global__ void predict_finish_kernel(const double* __restrict__ part, int nstri
 // the fly from the scaled inputs and accumulates   gacc[dd] += w fac u_dd^2  (length scales),
 // gacc[d] += w k  (sigma_f),  gacc[d+1] += w_gg  (sigma_n)   with fp64 atomics.
 // ---------------------------------------------------------------------------------------------
+// row `row` (0..127) of tile row Nt of the packed workspace (z = L^-1 r sits in row 0) -> out[j * ldo], j < npad
+template <typename T>
+__global__ void gather_rhs_row_kernel(const T* __restrict__ Abase, int R, int row, int npad, T* __restrict__ out, long ldo) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < npad) out[(long)j * ldo] = Abase[tile_index(R - 1, j >> 7, R) * TS + (long)(j & 127) * TB + row];
+}
+
 template <typename T>
 __global__ void identity_rows_kernel(T* __restrict__ V, long ldv, int npad, int c0, int mc) {
     const long total = ldv * (long)npad;
@@ -1882,6 +2017,38 @@ __global__ __launch_bounds__(1024) void null_reduce_kernel(const T* __restrict__
         for (int w = 0; w < 16; ++w) { t1 += s1[w]; t2 += s2[w]; }
         out[2 * b] = t1;
         out[2 * b + 1] = t2;
+    }
+}
+
+// Null kernel with point-dependent nugget / mean: K = diag(nu_i) (BGP:25-27, 156-159):
+// out[b] = { sum log |nu_i|, sum (y_i - m_i)^2 / nu_i, #(nu_i not > 0) }; nug / mean: [b][n] (null = constant c_nug[b] / mu[b]).
+template <typename T>
+__global__ __launch_bounds__(1024) void null_reduce_pw_kernel(const T* __restrict__ y, int n, const double* __restrict__ mu,
+                                                              const double* __restrict__ c_nug, const double* __restrict__ nug,
+                                                              const double* __restrict__ mean, double* __restrict__ out) {
+    __shared__ double s1[16], s2[16], s3[16];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    for (int i = tid; i < n; i += 1024) {
+        const double v = nug ? nug[(long)b * n + i] : c_nug[b];
+        const double r = (double)y[i] - (mean ? mean[(long)b * n + i] : mu[b]);
+        a1 += log(fabs(v));
+        a2 += r * r / v;
+        a3 += (v > 0.0) ? 0.0 : 1.0;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        a1 += __shfl_down(a1, off);
+        a2 += __shfl_down(a2, off);
+        a3 += __shfl_down(a3, off);
+    }
+    if (lane == 0) { s1[wave] = a1; s2[wave] = a2; s3[wave] = a3; }
+    __syncthreads();
+    if (tid == 0) {
+        double t1 = 0.0, t2 = 0.0, t3 = 0.0;
+        for (int w = 0; w < 16; ++w) { t1 += s1[w]; t2 += s2[w]; t3 += s3[w]; }
+        out[3 * b] = t1;
+        out[3 * b + 1] = t2;
+        out[3 * b + 2] = t3;
     }
 }
 

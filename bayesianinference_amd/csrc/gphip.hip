@@ -55,7 +55,8 @@ struct gphip_ctx {
     bool own_streams = true;
     int dist_rank = 0, dist_world = 0;  // > 0 between gphip_dist_begin and gphip_dist_end
     bool dist_theta_ok = true;
-    int64_t N = 0, d = 0, Npad = 0, Nt = 0, ld = 0;
+    int64_t N = 0, d = 0, Npad = 0, Nt = 0;
+    int64_t R = 0, slot_elems = 0;     // packed tile-major workspace: R = Nt + 1 tile rows, R (R + 1) / 2 tiles of 128 x 128 per slot
     int kernel_id = 0, mean_id = 0, nl = 0, p = 0, kt = 0;
     double *dNullMu = nullptr, *dNullOut = nullptr;          // null-kernel path: per-theta mu and the two sums
     int null_cap = 0;
@@ -117,6 +118,16 @@ struct gphip_ctx {
     double* dScal = nullptr;                     // 4 doubles for the scalar all-reduce (multi-process groups)
     bool in_group_call = false;                  // set on a member while the group handle runs a sharded call on it
     bool null_fit = false;                       // fitted state of a null-kernel handle (no factor: K = diag(sn^2))
+    // Point-dependent nugget / mean of the CURRENT call (gphip_*_pw, BGP:37, 113, 300, 408): host rows [B][N] (training
+    // points) and [S][M] (test points), null = the constant forms; device copies per workspace slot / prediction chunk
+    const double *pw_mean_host = nullptr, *pw_nug_host = nullptr;
+    const double *pw_mean_test = nullptr, *pw_nug_test = nullptr;
+    long pw_test_stride = 0;                     // elements between the samples' rows of pw_*_test
+    void *dPwMean = nullptr, *dPwNug = nullptr;  // typed [pw_cap][Npad]
+    int pw_cap = 0;
+    bool pw_mean_on = false, pw_nug_on = false;  // queue_build reads the device copies
+    double *dPwMeanT = nullptr, *dPwNugT = nullptr;   // [vcap] test-point values of the current prediction chunk
+    std::vector<double> null_diag, null_mean_test;    // fitted null kernel with a point-dependent nugget: the diagonal
 };
 
 namespace {
@@ -198,6 +209,8 @@ void free_slots(gphip_ctx* h) {
     (void)hipFree(h->dA); (void)hipFree(h->dXs); (void)hipFree(h->dInvEll); (void)hipFree(h->dSlotp);
     (void)hipFree(h->dW); (void)hipFree(h->dPartial); (void)hipFree(h->dRes); (void)hipFree(h->dInfo);
     (void)hipFree(h->dFlags); (void)hipFree(h->dTicket);
+    (void)hipFree(h->dPwMean); (void)hipFree(h->dPwNug);
+    h->dPwMean = h->dPwNug = nullptr; h->pw_cap = 0;
     h->dFlags = nullptr; h->dTicket = nullptr; h->ticket_base = 0;
     (void)hipHostFree(h->hInvEll); (void)hipHostFree(h->hSlotp); (void)hipHostFree(h->hRes);
     (void)hipHostFree(h->hInfo);
@@ -211,7 +224,7 @@ void free_slots(gphip_ctx* h) {
 }
 
 size_t slot_bytes(const gphip_ctx* h) {
-    return ((size_t)h->ld * h->ld + (size_t)h->d * h->Npad + (size_t)h->Nt * TB * TB) * h->es +
+    return ((size_t)h->slot_elems + (size_t)h->d * h->Npad + (size_t)h->Nt * TB * TB) * h->es +
            (size_t)h->Nt * 16 + (size_t)(2 * h->Nt + 1) * (2 * h->Nt + 1) * 4 + 4096;
 }
 
@@ -227,7 +240,7 @@ int ensure_slots(gphip_ctx* h, int want) {
     if (want <= h->slots) return GPHIP_OK;
     free_slots(h);
     const size_t S = (size_t)want;
-    HIPCHK(hipMalloc(&h->dA, S * h->ld * h->ld * h->es));
+    HIPCHK(hipMalloc(&h->dA, S * (size_t)h->slot_elems * h->es));
     HIPCHK(hipMalloc(&h->dXs, S * h->d * h->Npad * h->es));
     HIPCHK(hipMalloc(&h->dW, S * h->Nt * TB * TB * h->es));
     HIPCHK(hipMalloc(&h->dInvEll, S * h->d * 8));
@@ -294,12 +307,15 @@ int queue_build(gphip_ctx* h, int nslots) {
                            h->dInvEll, (int)h->d, (int)h->Npad);
     }
     KBuildArgs<T> a{};
-    a.out = (T*)h->dA; a.ld = h->ld; a.bstride = h->ld * h->ld;
+    a.out = (T*)h->dA; a.ld = TB; a.bstride = h->slot_elems;
     a.xi = (const T*)h->dXs; a.xj = (const T*)h->dXs; a.xi_bstride = a.xj_bstride = tot;
     a.npad_i = a.npad_j = (int)h->Npad; a.n_i = a.n_j = (int)h->N;
     a.y = (const T*)h->dY; a.slotp = h->dSlotp; a.d = (int)h->d; a.mode = 0; a.exp2tab = h->dExp2;
     a.nt_i = (int)h->Nt + 1; a.nt_j = (int)h->Nt;
     a.own_panel = h->panel; a.own_world = h->dist_world; a.own_rank = h->dist_rank;
+    a.pw_nug = h->pw_nug_on ? (const T*)h->dPwNug : nullptr;
+    a.pw_mean = h->pw_mean_on ? (const T*)h->dPwMean : nullptr;
+    a.pw_bstride = h->Npad;
     const long ntiles = (long)(h->Nt + 1) * (h->Nt + 2) / 2;
     ProfScope ps(h, 0, 0.0, (double)sizeof(T) * nslots * ((double)h->N * (h->N + 1) / 2 + (double)h->N * h->d));
     launch_kbuild<T>(h, a, dim3((unsigned)ntiles, nslots));
@@ -307,10 +323,24 @@ int queue_build(gphip_ctx* h, int nslots) {
 }
 
 // cls: profile class (2 panel solve, 3 in-panel/look-ahead GEMM, 4 trailing SYRK, 6 = "NN" role)
+// GEMM operand / result: a column-major block (R = 0: pointer, leading dimension, elements between slots) or the
+// packed tile-major workspace (R = tile rows; p = slot-0 base, possibly shifted for a panel held outside the
+// workspace; k0 = tile column at which the operand panel starts)
 template <typename T>
-void launch_gemm(gphip_ctx* h, int cls, T* C, long ldc, long cbs, const T* A, long lda, long abs_, const T* B,
-                 long ldb, long bbs, int K, int r0, int r1, int c0, int c1, int tri, int nslots, int mode = 0, int ktri = 0,
-                 int thin_row = -1, int groups = 1, int grp_stride = 0, int grp_width = 0) {
+struct Opnd {
+    const T* p; long ld; long bs; int R; int k0;
+};
+template <typename T>
+Opnd<T> cm(const T* p, long ld, long bs) { return Opnd<T>{p, ld, bs, 0, 0}; }
+template <typename T>
+Opnd<T> tl(const gphip_ctx* h, int k0 = 0, bool all_slots = true) {
+    return Opnd<T>{(const T*)h->dA, TB, all_slots ? (long)h->slot_elems : 0l, (int)h->R, k0};
+}
+
+template <typename T>
+void launch_gemm(gphip_ctx* h, int cls, Opnd<T> Co, Opnd<T> Ao, Opnd<T> Bo, int K, int r0, int r1, int c0, int c1, int tri,
+                 int nslots, int mode = 0, int ktri = 0, int thin_row = -1, int groups = 1, int grp_stride = 0,
+                 int grp_width = 0) {
     GemmArgs<T> g{};
     g.grp_stride = groups > 1 ? grp_stride : 0;
     g.grp_width = grp_width;
@@ -321,9 +351,9 @@ void launch_gemm(gphip_ctx* h, int cls, T* C, long ldc, long cbs, const T* A, lo
     // the strictly-upper quadrant of a diagonal tile -- both are skipped inside the kernel (option "thin_tiles")
     g.thin_row = h->thin_tiles ? thin_row : -1;
     g.skip_upper = (h->thin_tiles && thin_row >= 0 && tri && mode == 0 && !ktri) ? 1 : 0;
-    g.C = C; g.ldc = ldc; g.c_bstride = cbs;
-    g.A = A; g.lda = lda; g.a_bstride = abs_;
-    g.B = B; g.ldb = ldb; g.b_bstride = bbs;
+    g.C = const_cast<T*>(Co.p); g.ldc = Co.ld; g.c_bstride = Co.bs; g.c_R = Co.R;
+    g.A = Ao.p; g.lda = Ao.ld; g.a_bstride = Ao.bs; g.a_R = Ao.R; g.a_k0 = Ao.k0;
+    g.B = Bo.p; g.ldb = Bo.ld; g.b_bstride = Bo.bs; g.b_R = Bo.R; g.b_k0 = Bo.k0;
     g.K = K; g.r0 = r0; g.r1 = r1; g.c0 = c0; g.c1 = c1; g.tri = tri;
     const int H = r1 - r0, W = c1 - c0;
     if (H <= 0 || W <= 0) return;
@@ -414,7 +444,7 @@ size_t potrf_lds() { return 16 + (size_t)PT_LDS_ELEMS * sizeof(T); }
 template <typename T>
 int queue_panel(gphip_ctx* h, int K0, int nin, int nslots) {
     const int Nt = (int)h->Nt, R = Nt + 1;
-    const long ld = h->ld, bs = ld * ld, lrs = (long)Nt * TB * TB;
+    const long bs = h->slot_elems, lrs = (long)Nt * TB * TB;
     T* A = (T*)h->dA;
     T* W = (T*)h->dW;
     // In-panel updates: right-looking (after column b, K = 128 onto every remaining column of the panel: few,
@@ -426,22 +456,18 @@ int queue_panel(gphip_ctx* h, int K0, int nin, int nslots) {
     const bool left = h->panel_left > 0 || (h->panel_left < 0 && (nslots > h->dataflow_max_slots || nin >= 8));
     for (int s = 0; s < nin; ++s) {
         const int b = K0 + s;
-        if (left && s > 0) {
-            const T* P = A + (long)K0 * TB * ld;
-            launch_gemm<T>(h, 3, A, ld, bs, P, ld, bs, P, ld, bs, s * TB, b, R, b, b + 1, 1, nslots, 0, 0, Nt);
-        }
+        if (left && s > 0)
+            launch_gemm<T>(h, 3, tl<T>(h), tl<T>(h, K0), tl<T>(h, K0), s * TB, b, R, b, b + 1, 1, nslots, 0, 0, Nt);
         {
             ProfScope ps(h, 1, 2.0 * TB * TB * TB / 3.0 * nslots, 0.0);
-            hipLaunchKernelGGL(potrf128_kernel<T>, dim3(nslots), dim3(256), potrf_lds<T>(), h->cs, A, ld, bs, b, W,
+            hipLaunchKernelGGL(potrf128_kernel<T>, dim3(nslots), dim3(256), potrf_lds<T>(), h->cs, A, bs, b, W,
                                h->dPartial, Nt, h->dInfo, h->dSlotp);
         }
         // panel solve X <- X W_b^T for every row tile below the diagonal block (incl. rhs rows)
-        launch_gemm<T>(h, 2, A, ld, bs, A + (long)b * TB * ld, ld, bs, W + (long)b * TB * TB - (long)b * TB, TB, lrs,
-                       TB, b + 1, R, b, b + 1, 0, nslots, 1, 0, Nt);
-        if (!left && s + 1 < nin) {
-            const T* P = A + (long)b * TB * ld;
-            launch_gemm<T>(h, 3, A, ld, bs, P, ld, bs, P, ld, bs, TB, b + 1, R, b + 1, K0 + nin, 1, nslots, 0, 0, Nt);
-        }
+        launch_gemm<T>(h, 2, tl<T>(h), tl<T>(h, b), cm<T>(W + (long)b * TB * TB - (long)b * TB, TB, lrs), TB, b + 1, R, b, b + 1,
+                       0, nslots, 1, 0, Nt);
+        if (!left && s + 1 < nin)
+            launch_gemm<T>(h, 3, tl<T>(h), tl<T>(h, b), tl<T>(h, b), TB, b + 1, R, b + 1, K0 + nin, 1, nslots, 0, 0, Nt);
     }
     return 0;
 }
@@ -471,10 +497,9 @@ bool use_dataflow(const gphip_ctx* h, int nslots) {
 template <typename T, int TBX, int OCC = 2, int NST = 2, bool BUILD = false>
 void launch_dataflow(gphip_ctx* h, int nslots, int c0 = 0, double* part = nullptr, long pstride = 0) {
     const int nd = (int)(h->Npad / TBX) - c0, R = nd + 1;
-    const long ld = h->ld;
     const long tasks = (long)R * (R + 1) / 2 * nslots;
     DfArgs<T> g{};
-    g.A = (T*)h->dA + (long)c0 * TBX * (ld + 1); g.ld = ld; g.bstride = ld * ld;
+    g.A = (T*)h->dA; g.bstride = h->slot_elems; g.R128 = (int)h->R; g.c0 = c0;
     g.W = (T*)h->dW + (long)c0 * TBX * TBX; g.w_bstride = (long)h->Nt * TB * TB;
     g.partial = h->dPartial + c0; g.p_bstride = h->Npad / TBX;
     if (part) { g.partial = part; g.p_bstride = pstride; }       // (a 64-tile tail keeps its own list of blocks)
@@ -501,8 +526,8 @@ void launch_dataflow(gphip_ctx* h, int nslots, int c0 = 0, double* part = nullpt
 
 template <typename T>
 void launch_finalize(gphip_ctx* h, int nslots, int nparts, int pstride = 0, const double* part2 = nullptr, int n2 = 0) {
-    hipLaunchKernelGGL(finalize_kernel<T>, dim3(nslots), dim3(64), 0, h->stream, (const T*)h->dA, h->ld, h->ld * h->ld,
-                       (int)h->Npad, h->dPartial, nparts, h->dRes, (const int*)h->dInfo,
+    hipLaunchKernelGGL(finalize_kernel<T>, dim3(nslots), dim3(64), 0, h->stream, (const T*)h->dA, (long)h->slot_elems,
+                       (long)(h->slot_elems - TS), h->dPartial, nparts, h->dRes, (const int*)h->dInfo,
                        (const int*)reinterpret_cast<int*>(h->dTicket + 1), h->hRes, h->hInfo, pstride, part2, n2);
 }
 
@@ -519,7 +544,7 @@ int queue_factor_dataflow(gphip_ctx* h, int nslots) {
             launch_finalize<T>(h, nslots, 2 * (int)h->Nt);
             if (h->want_w)
                 hipLaunchKernelGGL(trtri128_kernel<T>, dim3((unsigned)h->Nt, nslots), dim3(256), potrf_lds<T>(), h->stream,
-                                   (const T*)h->dA, h->ld, h->ld * h->ld, (T*)h->dW, (int)h->Nt);
+                                   (const T*)h->dA, (long)h->slot_elems, (T*)h->dW, (int)h->Nt);
             return 0;
         }
     }
@@ -547,7 +572,6 @@ int queue_factor_dataflow(gphip_ctx* h, int nslots) {
 template <typename T>
 int queue_factor(gphip_ctx* h, int nslots) {
     const int Nt = (int)h->Nt, R = Nt + 1;     // R = tile rows incl. the rhs block-row
-    const long ld = h->ld, bs = ld * ld;
     const int P = h->panel;
     // Outer panel boundaries.  Far from the end the trailing update is long and hides a wider panel's factorisation
     // behind it, and a wider panel means fewer read-modify-write passes over the trailing matrix (measured, one theta,
@@ -561,11 +585,9 @@ int queue_factor(gphip_ctx* h, int nslots) {
         bnd.push_back(std::min(Nt, bnd.back() + w));
     }
     const int nouter = (int)bnd.size() - 1;
-    T* A = (T*)h->dA;
     auto k0 = [&](int k) { return bnd[(size_t)std::min(k, nouter)]; };
     auto trailing = [&](int k, int c_lo, int c_hi, int cls) {      // apply panel k to tile columns [c_lo,c_hi)
-        const T* Pk = A + (long)k0(k) * TB * ld;
-        launch_gemm<T>(h, cls, A, ld, bs, Pk, ld, bs, Pk, ld, bs, (k0(k + 1) - k0(k)) * TB, c_lo, R, c_lo, c_hi, 1,
+        launch_gemm<T>(h, cls, tl<T>(h), tl<T>(h, k0(k)), tl<T>(h, k0(k)), (k0(k + 1) - k0(k)) * TB, c_lo, R, c_lo, c_hi, 1,
                        nslots, 0, 0, Nt);
     };
     // Option "rest_split" (off by default): REST(k) as TWO grouped launches on two streams -- tile-column groups of
@@ -575,18 +597,17 @@ int queue_factor(gphip_ctx* h, int nslots) {
     // meaningless (two concurrent launches each last the whole step: the HIP-event / rocprof "average launch duration"
     // doubles while the job gets faster) for a gain inside the box-to-box spread.
     auto trailing_half = [&](int k, int c_lo, int parity) {       // columns >= c_lo (even), groups with (col/2) % 2 == parity
-        const T* Pk = A + (long)k0(k) * TB * ld;
         int first = c_lo / 2;
         if ((first & 1) != parity) ++first;
         const int c0 = 2 * first;
         if (c0 >= R) return;
         const int groups = (R - c0 + 3) / 4;                        // group starts c0, c0 + 4, .. < R
         if (groups == 1)
-            launch_gemm<T>(h, 4, A, ld, bs, Pk, ld, bs, Pk, ld, bs, (k0(k + 1) - k0(k)) * TB, c0, R, c0, std::min(c0 + 2, R), 1,
-                           nslots, 0, 0, Nt);
+            launch_gemm<T>(h, 4, tl<T>(h), tl<T>(h, k0(k)), tl<T>(h, k0(k)), (k0(k + 1) - k0(k)) * TB, c0, R, c0,
+                           std::min(c0 + 2, R), 1, nslots, 0, 0, Nt);
         else
-            launch_gemm<T>(h, 4, A, ld, bs, Pk, ld, bs, Pk, ld, bs, (k0(k + 1) - k0(k)) * TB, c0, R, c0, R, 1, nslots, 0, 0, Nt,
-                           groups, 4, 2);
+            launch_gemm<T>(h, 4, tl<T>(h), tl<T>(h, k0(k)), tl<T>(h, k0(k)), (k0(k + 1) - k0(k)) * TB, c0, R, c0, R, 1, nslots,
+                           0, 0, Nt, groups, 4, 2);
     };
     bool split = h->rest_split && nslots == 1 && h->lookahead && h->stream2 && !h->supertile;
     for (int b : bnd) split = split && (b % 2 == 0 || b == Nt);
@@ -686,7 +707,7 @@ int queue_factor(gphip_ctx* h, int nslots) {
         launch_finalize<T>(h, nslots, tail_k0, Nt, tail_part, tail_n);
         if (h->want_w)                             // the tail left 64-block inverses over part of dW: rebuild the 128-blocks
             hipLaunchKernelGGL(trtri128_kernel<T>, dim3((unsigned)Nt, nslots), dim3(256), potrf_lds<T>(), h->stream,
-                               (const T*)h->dA, h->ld, h->ld * h->ld, (T*)h->dW, Nt);
+                               (const T*)h->dA, (long)h->slot_elems, (T*)h->dW, Nt);
     } else {
         launch_finalize<T>(h, nslots, Nt);
     }
@@ -694,7 +715,7 @@ int queue_factor(gphip_ctx* h, int nslots) {
 }
 
 // stage theta of one slot into the pinned host buffers; returns false if theta is unusable
-bool stage_theta(gphip_ctx* h, int slot, const double* th) {
+bool stage_theta(gphip_ctx* h, int slot, const double* th, const double* nug_row = nullptr, const double* mean_row = nullptr) {
     double* ie = h->hInvEll + (size_t)slot * h->d;
     double* sp = h->hSlotp + (size_t)slot * SLOTP;
     bool ok = true;
@@ -709,7 +730,19 @@ bool stage_theta(gphip_ctx* h, int slot, const double* th) {
     double mu = (h->mean_id == GPHIP_MEAN_CONST) ? th[h->nl + 2] : 0.0;
     if (!ok) { sf = 1.0; sn = 1.0; mu = 0.0; }
     sp[0] = sf * sf; sp[1] = sn * sn; sp[2] = mu;
-    sp[3] = pivot_tol_rel(h) * (sf * sf + sn * sn);
+    double nug_scale = sn * sn;
+    if (nug_row) {                             // point-dependent nugget: the pivot tolerance scales with its largest value
+        nug_scale = 0.0;
+        for (int64_t i = 0; i < h->N; ++i) {
+            if (!std::isfinite(nug_row[i])) ok = false;
+            nug_scale = std::max(nug_scale, std::fabs(nug_row[i]));
+        }
+    }
+    if (mean_row)
+        for (int64_t i = 0; i < h->N; ++i)
+            if (!std::isfinite(mean_row[i])) ok = false;
+    if (!ok) nug_scale = 1.0;
+    sp[3] = pivot_tol_rel(h) * (sf * sf + nug_scale);
     if (!std::isfinite(sp[0]) || !std::isfinite(sp[1])) { ok = false; sp[0] = sp[1] = 1.0; sp[3] = 1e-14; }
     sp[4] = ok ? 0.0 : 1.0;
     return ok;
@@ -911,21 +944,21 @@ int queue_forward_rows(gphip_ctx* h, int64_t mpad, int nslots, int b_start = 0, 
     // many rows (prediction of thousands of test points, K^-1 for the gradient): every pass over the columns right of a
     // panel reads and writes all of V there, so wider panels pay (cfg 5, M = 10 000: 374 -> 359 ms from 4 to 12 tiles)
     const int Nt = (int)h->Nt, Mt = (int)(mpad / TB), P = (Mt >= 8 && h->panel_wide) ? std::max(h->panel, 12) : h->panel;
-    const long ld = h->ld, vs = (long)mpad * h->Npad, bs = ld * ld, lrs = (long)Nt * TB * TB;
-    T *V = (T*)h->dV, *A = (T*)h->dA, *W = (T*)h->dW;
+    const long vs = (long)mpad * h->Npad, lrs = (long)Nt * TB * TB;
+    T *V = (T*)h->dV, *W = (T*)h->dW;
     auto rows_at = [&](int b) { return identity_rows ? std::min(Mt, b - b_start + 1) : Mt; };
     for (int k0 = b_start; k0 < Nt; k0 += P) {   // b_start > 0: the rows are known to be zero left of tile column b_start
         const int k1 = (k0 + P < Nt) ? k0 + P : Nt;
         for (int b = k0; b < k1; ++b) {
-            launch_gemm<T>(h, 2, V, mpad, vs, V + (long)b * TB * mpad, mpad, vs, W + (long)b * TB * TB - (long)b * TB, TB,
-                           lrs, TB, 0, rows_at(b), b, b + 1, 0, nslots, 1);
+            launch_gemm<T>(h, 2, cm<T>(V, mpad, vs), cm<T>(V + (long)b * TB * mpad, mpad, vs),
+                           cm<T>(W + (long)b * TB * TB - (long)b * TB, TB, lrs), TB, 0, rows_at(b), b, b + 1, 0, nslots, 1);
             if (b + 1 < k1)
-                launch_gemm<T>(h, 3, V, mpad, vs, V + (long)b * TB * mpad, mpad, vs, A + (long)b * TB * ld, ld, bs, TB, 0,
-                               rows_at(b), b + 1, k1, 0, nslots);
+                launch_gemm<T>(h, 3, cm<T>(V, mpad, vs), cm<T>(V + (long)b * TB * mpad, mpad, vs), tl<T>(h, b), TB, 0, rows_at(b),
+                               b + 1, k1, 0, nslots);
         }
         if (k1 < Nt)
-            launch_gemm<T>(h, 3, V, mpad, vs, V + (long)k0 * TB * mpad, mpad, vs, A + (long)k0 * TB * ld, ld, bs,
-                           (k1 - k0) * TB, 0, rows_at(k1 - 1), k1, Nt, 0, nslots);
+            launch_gemm<T>(h, 3, cm<T>(V, mpad, vs), cm<T>(V + (long)k0 * TB * mpad, mpad, vs), tl<T>(h, k0), (k1 - k0) * TB, 0,
+                           rows_at(k1 - 1), k1, Nt, 0, nslots);
     }
     return 0;
 }
@@ -935,19 +968,19 @@ int queue_forward_rows(gphip_ctx* h, int64_t mpad, int nslots, int b_start = 0, 
 template <typename T>
 int queue_backward_rows(gphip_ctx* h, int64_t mpad) {
     const int Nt = (int)h->Nt, Mt = (int)(mpad / TB), P = (Mt >= 8 && h->panel_wide) ? std::max(h->panel, 12) : h->panel;
-    const long ld = h->ld;
-    T *V = (T*)h->dV, *A = (T*)h->dA, *W = (T*)h->dW;
+    T *V = (T*)h->dV, *W = (T*)h->dW;
     for (int k1 = Nt; k1 > 0; k1 -= P) {         // outer panel = tile columns [k0, k1)
         const int k0 = (k1 - P > 0) ? k1 - P : 0;
         for (int b = k1 - 1; b >= k0; --b) {
-            launch_gemm<T>(h, 6, V, mpad, 0, V + (long)b * TB * mpad, mpad, 0, W, TB, 0, TB, 0, Mt, b, b + 1, 0, 1, 1);
-            if (b > k0)
-                launch_gemm<T>(h, 6, V, mpad, 0, V + (long)b * TB * mpad, mpad, 0, A + (long)b * TB, ld, 0, TB, 0, Mt,
-                               k0, b, 0, 1, 0);
+            launch_gemm<T>(h, 6, cm<T>(V, mpad, 0), cm<T>(V + (long)b * TB * mpad, mpad, 0), cm<T>(W, TB, 0), TB, 0, Mt, b, b + 1, 0,
+                           1, 1);
+            if (b > k0)                         // (the J operand is L(b, c) read transposed: tile (b, c) of the workspace)
+                launch_gemm<T>(h, 6, cm<T>(V, mpad, 0), cm<T>(V + (long)b * TB * mpad, mpad, 0), tl<T>(h, b, false), TB, 0, Mt, k0, b,
+                               0, 1, 0);
         }
         if (k0 > 0)                             // Y_c -= X[:, k0..k1) L(k0..k1, c) for every c < k0
-            launch_gemm<T>(h, 6, V, mpad, 0, V + (long)k0 * TB * mpad, mpad, 0, A + (long)k0 * TB, ld, 0,
-                           (k1 - k0) * TB, 0, Mt, 0, k0, 0, 1, 0);
+            launch_gemm<T>(h, 6, cm<T>(V, mpad, 0), cm<T>(V + (long)k0 * TB * mpad, mpad, 0), tl<T>(h, k0, false), (k1 - k0) * TB, 0,
+                           Mt, 0, k0, 0, 1, 0);
     }
     return 0;
 }
@@ -1003,7 +1036,7 @@ int queue_predict_reduce(gphip_ctx* h, int64_t mc, int64_t mpad, int nslots) {
         ProfScope ps(h, 6, 4.0 * (double)mpad * h->Npad * nslots, (double)sizeof(T) * mpad * h->Npad * nslots);
         hipLaunchKernelGGL(predict_partial_kernel<T>, dim3((unsigned)Mt, (unsigned)nstrips, (unsigned)nslots), dim3(256),
                            (size_t)js * 8 + 8 * TB * 8, h->stream, (const T*)h->dV, (long)mpad, (long)mpad * h->Npad, (int)h->N,
-                           (const T*)h->dA + h->Npad, (long)h->ld, (long)h->ld * h->ld, js, h->dPart, nstrips);
+                           (const T*)h->dA, (int)h->R, (long)h->slot_elems, js, h->dPart, nstrips);
         hipLaunchKernelGGL(predict_finish_kernel, dim3((unsigned)((mc + 255) / 256), (unsigned)nslots), dim3(256), 0, h->stream,
                            (const double*)h->dPart, nstrips, (long)mpad, (const double*)h->dSlotp, (int)mc, (long)mpad,
                            h->dMean, h->dVar);
@@ -1014,16 +1047,18 @@ int queue_predict_reduce(gphip_ctx* h, int64_t mc, int64_t mpad, int nslots) {
 template <typename T>
 int queue_dist_update(gphip_ctx* h, const void* packed, long K0, long rows, long cols, int c_lo, int c_hi, int cls,
                       int groups = 1, int grp_stride = 0) {
-    const T* base = (const T*)packed - K0 * TB;     // so that absolute tile row t sits at base + t*128
-    launch_gemm<T>(h, cls, (T*)h->dA, h->ld, 0, base, rows, 0, base, rows, 0, (int)cols, c_lo, (int)h->Nt + 1, c_lo,
-                   c_hi, 1, 1, 0, 0, (int)h->Nt, groups, grp_stride, h->panel);
+    // the packed panel is the panel's own contiguous range of the tile-major workspace: shifted base, global tile indices
+    (void)rows;
+    Opnd<T> pk{(const T*)packed - tile_index((int)K0, (int)K0, (int)h->R) * TS, TB, 0, (int)h->R, (int)K0};
+    launch_gemm<T>(h, cls, tl<T>(h, 0, false), pk, pk, (int)cols, c_lo, (int)h->Nt + 1, c_lo, c_hi, 1, 1, 0, 0, (int)h->Nt, groups,
+                   grp_stride, h->panel);
     return 0;
 }
 
 template <typename T>
 int queue_finalize(gphip_ctx* h) {
-    hipLaunchKernelGGL(finalize_kernel<T>, dim3(1), dim3(64), 0, h->stream, (const T*)h->dA, h->ld, h->ld * h->ld,
-                       (int)h->Npad, h->dPartial, (int)h->Nt, h->dRes);
+    hipLaunchKernelGGL(finalize_kernel<T>, dim3(1), dim3(64), 0, h->stream, (const T*)h->dA, (long)h->slot_elems,
+                       (long)(h->slot_elems - TS), h->dPartial, (int)h->Nt, h->dRes);
     return 0;
 }
 
@@ -1047,8 +1082,8 @@ template <typename T>
 int queue_alpha(gphip_ctx* h) {
     const int64_t mpad = TB, Npad = h->Npad;
     HIPCHK(hipMemsetAsync(h->dV, 0, (size_t)mpad * Npad * sizeof(T), h->stream));
-    HIPCHK(hipMemcpy2DAsync(h->dV, (size_t)mpad * sizeof(T), (const T*)h->dA + Npad, (size_t)h->ld * sizeof(T), sizeof(T),
-                            (size_t)Npad, hipMemcpyDeviceToDevice, h->stream));
+    hipLaunchKernelGGL(gather_rhs_row_kernel<T>, dim3((unsigned)((Npad + 255) / 256)), dim3(256), 0, h->stream, (const T*)h->dA,
+                       (int)h->R, 0, (int)Npad, (T*)h->dV, (long)mpad);
     queue_backward_rows<T>(h, mpad);
     HIPCHK(hipMemcpy2DAsync(h->dAlpha, sizeof(T), h->dV, (size_t)mpad * sizeof(T), sizeof(T), (size_t)Npad,
                             hipMemcpyDeviceToDevice, h->stream));
@@ -1087,8 +1122,8 @@ int queue_grad_potri(gphip_ctx* h) {
     if (gx > 4096) gx = 4096;
     hipLaunchKernelGGL(identity_rows_kernel<T>, dim3(gx), dim3(256), 0, h->stream, (T*)h->dV, npad, (int)npad, 0, (int)h->N);
     queue_forward_rows<T>(h, npad, 1, 0, true);
-    launch_gemm<T>(h, 2, (T*)h->dKinv, npad, 0, (const T*)h->dV, npad, 0, (const T*)h->dV, npad, 0, (int)npad, 0,
-                   (int)h->Nt, 0, (int)h->Nt, 1, 1, 1, 1);
+    launch_gemm<T>(h, 2, cm<T>((const T*)h->dKinv, npad, 0), cm<T>((const T*)h->dV, npad, 0), cm<T>((const T*)h->dV, npad, 0),
+                   (int)npad, 0, (int)h->Nt, 0, (int)h->Nt, 1, 1, 1, 1);
     GradArgs<T> a{};
     a.Kinv = (const T*)h->dKinv; a.ldv = npad; a.alpha = (const T*)h->dAlpha; a.xs = (const T*)h->dXs;
     a.npad = (int)npad; a.n = (int)h->N; a.c0 = 0; a.mc = (int)h->N; a.d = (int)h->d; a.tri = 1;
@@ -1156,7 +1191,8 @@ static int create_ctx(const void* X, const void* y, int64_t N, int64_t d, int ke
     h->N = N; h->d = d;
     h->Npad = (N + TB - 1) / TB * TB;
     h->Nt = h->Npad / TB;
-    h->ld = h->Npad + TB;
+    h->R = h->Nt + 1;
+    h->slot_elems = h->R * (h->R + 1) / 2 * TS;
     h->kernel_id = kernel_id; h->mean_id = mean_id;
     h->kt = (kernel_id == GPHIP_KERNEL_MATERN52 || kernel_id == GPHIP_KERNEL_MATERN52_ARD) ? 1 : 0;
     h->nl = (kernel_id == GPHIP_KERNEL_SE || kernel_id == GPHIP_KERNEL_MATERN52) ? 1
@@ -1431,13 +1467,16 @@ int gphip_covariance(gphip_handle h, const double* theta, int p, double* K) {
     HIPCHK(hipMemcpyAsync(h->dSlotp, h->hSlotp, SLOTP * 8, hipMemcpyHostToDevice, h->stream));
     h->cs = h->stream;
     DISPATCH(h, queue_build, h, 1);
-    // the lower triangle of the leading N columns, column-major with leading dimension ld
+    // the lower-triangle tiles of the packed workspace (tile (ti, tj) at tile_index(ti, tj, R), column-major inside)
     std::vector<double> tmp;
-    rc = DISPATCH(h, download, h, tmp, h->dA, (size_t)h->ld * (size_t)N, h->stream);
+    rc = DISPATCH(h, download, h, tmp, h->dA, (size_t)h->slot_elems, h->stream);
     if (rc) return rc;
     harvest(h);
     for (int64_t j = 0; j < N; ++j)
-        for (int64_t i = j; i < N; ++i) K[i * N + j] = K[j * N + i] = tmp[(size_t)j * h->ld + i];
+        for (int64_t i = j; i < N; ++i) {
+            const size_t off = (size_t)tile_index((int)(i / TB), (int)(j / TB), (int)h->R) * TS + (size_t)(j % TB) * TB + (size_t)(i % TB);
+            K[i * N + j] = K[j * N + i] = tmp[off];
+        }
     return GPHIP_OK;
 }
 
@@ -1734,8 +1773,10 @@ int gphip_dist_panel_shape(gphip_handle h, int k, int64_t* rows, int64_t* cols) 
     if (!h || !rows || !cols) return GPHIP_ERR_ARG;
     const int64_t K0 = (int64_t)k * h->panel, K1 = (K0 + h->panel < h->Nt) ? K0 + h->panel : h->Nt;
     if (k < 0 || K0 >= h->Nt) return fail(h, GPHIP_ERR_DIM, "panel index out of range");
-    *rows = (h->Nt + 1 - K0) * TB;
-    *cols = (K1 - K0) * TB;
+    // a packed panel IS the panel's contiguous range of the tile-major workspace (tile columns K0 .. K1-1, each from its
+    // diagonal tile down to the rhs tile row): rows x cols = its element count x 1, opaque to the host
+    *rows = (tile_index((int)K1, (int)K1, (int)h->R) - tile_index((int)K0, (int)K0, (int)h->R)) * TS;
+    *cols = 1;
     return GPHIP_OK;
 }
 
@@ -1772,10 +1813,11 @@ int gphip_dist_factor_panel(gphip_handle h, int k, void* packed) {
     HIPCHK(hipSetDevice(h->device));
     const int64_t K0 = (int64_t)k * h->panel;
     h->cs = h->pstream;
-    DISPATCH(h, queue_panel, h, (int)K0, (int)(cols / TB), 1);
-    const char* src = static_cast<const char*>(h->dA) + (size_t)(K0 * TB * h->ld + K0 * TB) * h->es;
-    HIPCHK(hipMemcpy2DAsync(packed, (size_t)rows * h->es, src, (size_t)h->ld * h->es, (size_t)rows * h->es,
-                            (size_t)cols, hipMemcpyDeviceToDevice, h->pstream));
+    const int64_t K1 = (K0 + h->panel < h->Nt) ? K0 + h->panel : h->Nt;
+    DISPATCH(h, queue_panel, h, (int)K0, (int)(K1 - K0), 1);
+    const char* src = static_cast<const char*>(h->dA) + (size_t)tile_index((int)K0, (int)K0, (int)h->R) * TS * h->es;
+    if (packed != (void*)src)                  // (a caller may hand the workspace range itself: nothing to pack)
+        HIPCHK(hipMemcpyAsync(packed, src, (size_t)rows * cols * h->es, hipMemcpyDeviceToDevice, h->pstream));
     h->cs = h->stream;
     return GPHIP_OK;
 }
@@ -1793,6 +1835,7 @@ int gphip_dist_update(gphip_handle h, int k, const void* packed, int j_first, in
     const int Nt = (int)h->Nt, R = Nt + 1, P = h->panel;
     const int nouter = (Nt + P - 1) / P;
     const long K0 = (long)k * P;
+    cols = (std::min<long>(K0 + P, Nt) - K0) * TB;         // contraction length = the panel's width in columns
     h->cs = on_panel_stream ? h->pstream : h->stream;
     // The owned panels j = j0, j0 + world, .. of this update go out as ONE grouped launch (blockIdx.y = owned panel;
     // gemm_nt decodes its own column range) instead of one launch per 512-column strip: a rank of an 8-GPU job owns

@@ -49,12 +49,13 @@ def _roof(cls: dict, peak: float, unit: str, what: str) -> dict:
             "algorithmic_per_launch": work / cls["launches"]}
 
 
-def cpu_baseline(n_full: int, d: int, sizes=(4096, 8192)) -> dict:
-    """Times the CPU oracle (numpy kernel-matrix build + scipy LAPACK LU, the algorithm LinearSolve uses) on a
-    BOUNDED sample -- whole evaluations at N = 4096 and N = 8192, median of three each -- and scales the larger one to the metric's unit
-    (evals/s at n_full): the build with its quadratic cost, the factorisation + solve with its cubic cost.  The
-    exponents fitted between the two sizes are printed so the extrapolation can be checked.  For information it
-    also times a Cholesky variant and cfg 1 (N=512, d=1) whole."""
+def cpu_baseline(n_full: int, d: int, max_full_s: float = 600.0) -> dict:
+    """Times the CPU oracle (numpy kernel-matrix build + scipy LAPACK LU, the algorithm LinearSolve uses) WHOLE, on the
+    host cores of this box: one evaluation at N = 8192 (thread-count ladder), one at N = 16384 and -- unless the N = 16384
+    sample predicts more than `max_full_s` seconds ("32768 if < 10 min") -- one at the metric's own
+    size N = n_full.  `value` is then MEASURED, not extrapolated; the cubic-law prediction from the smaller samples is
+    kept under `also` so the two can be compared.  For information it also times a Cholesky variant and cfg 1
+    (N=512, d=1) whole."""
     from oracle import gp_oracle as orc
     from bayesianinference_amd import synthetic as syn
     import scipy.linalg as sla
@@ -73,47 +74,51 @@ def cpu_baseline(n_full: int, d: int, sizes=(4096, 8192)) -> dict:
             return nullcontext()
 
     th = syn.default_theta("se_ard", d)
-    data = {n: syn.make_dataset(n, d) for n in sizes}
-    orc.log_likelihood("se_ard", th, data[sizes[0]][0][:512], data[sizes[0]][1][:512])
+    Xw, yw = syn.make_dataset(512, d)
+    orc.log_likelihood("se_ard", th, Xw, yw)                   # warm the BLAS threads
 
-    def timed(n, nthreads, reps):
-        """(build s, LU factor + solve + formula s) per evaluation, oracle functions only."""
-        X, y = data[n]
-        tb = tf = 0.0
+    def timed(n, nthreads):
+        """(build s, LU factor + solve + formula s, log-likelihood) of ONE whole evaluation, oracle functions only (the
+        same calls orc.log_likelihood makes, split so that the two phases can be reported separately)."""
+        X, y = syn.make_dataset(n, d)
         with limited(nthreads):
-            for i in range(reps):
-                thi = th * (1.0 + 0.01 * i)
-                t0 = time.perf_counter()
-                r = orc.residual("se_ard", thi, X, y)
-                K = orc.covariance_matrix("se_ard", thi, X)
-                t1 = time.perf_counter()
-                solve, logdet = orc.matrix_inverse_and_det(K)
-                orc.gp_log_likelihood_from_parts(r, solve, logdet)
-                t2 = time.perf_counter()
-                tb += t1 - t0
-                tf += t2 - t1
-        return tb / reps, tf / reps
+            t0 = time.perf_counter()
+            r = orc.residual("se_ard", th, X, y)
+            K = orc.covariance_matrix("se_ard", th, X)
+            t1 = time.perf_counter()
+            big = K.size > orc._BLOCK_ELEMS                      # large N: LU in place (K is symmetric bit for bit)
+            solve, logdet = orc.matrix_inverse_and_det(K.T if big else K, overwrite=big)
+            del K
+            ll = orc.gp_log_likelihood_from_parts(r, solve, logdet)
+            t2 = time.perf_counter()
+        return t1 - t0, t2 - t1, ll
 
-    # LAPACK on very many threads can be slower than on fewer: pick the best of a short ladder at the small size, then
-    # take the MEDIAN of three whole evaluations at each size (BASELINE.md section 4)
+    # LAPACK on very many threads can be slower than on fewer: pick the best of a short ladder at N = 4096
     ladder = sorted({t for t in (16, 32, 64, threads) if t <= threads})
-    probe = {t: timed(sizes[0], t, 1) for t in ladder}
-    threads = min(probe, key=lambda t: sum(probe[t]))
-
-    def median3(n):
-        runs = sorted((timed(n, threads, 1) for _ in range(3)), key=sum)
-        return runs[1]
-
-    tb0, tf0 = median3(sizes[0])
-    tb1, tf1 = median3(sizes[1])
-    ratio = math.log(sizes[1] / sizes[0])
-    exp_build, exp_lu = math.log(tb1 / tb0) / ratio, math.log(tf1 / tf0) / ratio
-    s2, s3 = (n_full / sizes[1]) ** 2, (n_full / sizes[1]) ** 3
-    est = tb1 * s2 + tf1 * s3
-    est_fitted = tb1 * (n_full / sizes[1]) ** exp_build + tf1 * (n_full / sizes[1]) ** exp_lu
+    probe = {t: timed(4096, t) for t in ladder}
+    threads = min(probe, key=lambda t: probe[t][0] + probe[t][1])
+    measured = {}
+    for n in (8192, 16384):
+        if n < n_full:
+            tb, tf, ll = timed(n, threads)
+            measured[n] = (tb, tf, ll)
+    n_ref = max(measured) if measured else None
+    predicted = None
+    if n_ref is not None:
+        predicted = measured[n_ref][0] * (n_full / n_ref) ** 2 + measured[n_ref][1] * (n_full / n_ref) ** 3
+    if predicted is None or predicted <= max_full_s:
+        tb, tf, ll = timed(n_full, threads)
+        measured[n_full] = (tb, tf, ll)
+        est = tb + tf
+        how = (f"MEASURED: one whole evaluation at N={n_full} ({threads} threads): build {tb:.2f} s, LU+solve {tf:.2f} s "
+               f"= {est:.1f} s/eval")
+    else:
+        est = predicted
+        how = (f"N={n_full} NOT measured (the N={n_ref} sample predicts {predicted:.0f} s > {max_full_s:.0f} s): scaled from the "
+               f"measured N={n_ref} evaluation by (N/{n_ref})^2 (build) and ^3 (LU)")
 
     with limited(threads):                       # information only: SPD-aware variant, and cfg 1 as is
-        X, y = data[sizes[0]]
+        X, y = syn.make_dataset(4096, d)
         K = orc.covariance_matrix("se_ard", th, X)
         t0 = time.perf_counter()
         c = sla.cho_factor(K, lower=True, overwrite_a=True, check_finite=False)
@@ -126,19 +131,14 @@ def cpu_baseline(n_full: int, d: int, sizes=(4096, 8192)) -> dict:
             orc.log_likelihood("se", th1, X1, y1)
         t_cfg1 = (time.perf_counter() - t0) / 5
     return {"value": 1.0 / est, "unit": "evals/s", "cores": int(threads), "kind": "port",
-            "sample": f"CPU oracle (numpy build + scipy dgetrf/dgetrs LU restatement of BGP:29-43,130-141,"
-                      f"181-199; not Mathematica) timed whole at N={sizes[0]} and N={sizes[1]} (median of 3 each, {threads} threads), d={d}: "
-                      f"N={sizes[1]}: build {tb1:.3f} s, LU+solve {tf1:.3f} s; scaled by (N/{sizes[1]})^2={s2:.0f} and "
-                      f"^3={s3:.0f} => {est:.1f} s/eval at N={n_full}",
-            "measured": {f"N{sizes[0]}": {"build_s": round(tb0, 4), "lu_solve_s": round(tf0, 4)},
-                         f"N{sizes[1]}": {"build_s": round(tb1, 4), "lu_solve_s": round(tf1, 4)}},
-            "fitted_exponents": {"build": round(exp_build, 3), "lu_solve": round(exp_lu, 3),
-                                 "s_per_eval_at_n_full_with_fitted_exponents": round(est_fitted, 1),
-                                 "note": "value uses the asymptotic laws (N^2 build, N^3 LU) from the larger sample; an "
-                                         "LU exponent below 3 means the threaded LAPACK is still gaining efficiency at "
-                                         "this size, so the true CPU time at n_full lies between the two estimates"},
-            "also": {"cholesky_variant_s_at_N%d" % sizes[0]: round(t_chol, 4),
-                     "cfg1_N512_d1_evals_per_s": round(1.0 / t_cfg1, 2)}}
+            "sample": "CPU oracle (numpy build + scipy dgetrf/dgetrs LU restatement of BGP:29-43,130-141,181-199; not "
+                      f"Mathematica), d={d}, whole evaluations. " + how,
+            "measured": {f"N{n}": {"build_s": round(v[0], 3), "lu_solve_s": round(v[1], 3), "loglik": v[2]}
+                         for n, v in sorted(measured.items())},
+            "also": {"predicted_s_at_n_full_from_smaller_sample": None if predicted is None else round(predicted, 1),
+                     "cholesky_variant_s_at_N4096": round(t_chol, 4),
+                     "cfg1_N512_d1_evals_per_s": round(1.0 / t_cfg1, 2),
+                     "host_logical_cpus": os.cpu_count()}}
 
 
 def pmc_traffic(kernel_substr: str = "gemm_nt_kernel<double, 0,"):

@@ -80,6 +80,22 @@ def kernel_matrix(kernel: str, ell, sf: float, A: np.ndarray, B: np.ndarray) -> 
     differences (no |a|^2+|b|^2-2ab expansion: cancellation would cost the 1e-8 parity)."""
     A = np.asarray(A, dtype=np.float64) / ell
     B = np.asarray(B, dtype=np.float64) / ell
+    if A.shape[0] * B.shape[0] > _BLOCK_ELEMS:
+        # large problems (golden scalars at N = 16384 / 32768, the bench's CPU baseline): the same arithmetic,
+        # element for element, in row blocks so that the temporaries stay small next to the result
+        out = np.empty((A.shape[0], B.shape[0]))
+        step = max(1, _BLOCK_ELEMS // B.shape[0])
+        for i0 in range(0, A.shape[0], step):
+            out[i0:i0 + step] = _kernel_block(kernel, sf, A[i0:i0 + step], B)
+        return out
+    return _kernel_block(kernel, sf, A, B)
+
+
+_BLOCK_ELEMS = 1 << 26          # 512 MiB of fp64 per temporary
+
+
+def _kernel_block(kernel: str, sf: float, A: np.ndarray, B: np.ndarray) -> np.ndarray:
+    """A, B already divided by the length scales."""
     r2 = np.zeros((A.shape[0], B.shape[0]))
     for j in range(A.shape[1]):          # O(N*M) memory, not O(N*M*d)
         diff = A[:, j][:, None] - B[:, j][None, :]
@@ -113,7 +129,7 @@ def covariance_matrix(kernel: str, theta, X: np.ndarray, mean: str = "zero"):
 RCOND_FAIL = 2.220446049250313e-16   # stands for the LinearSolve::luc warning threshold
 
 
-def matrix_inverse_and_det(matrix: np.ndarray):
+def matrix_inverse_and_det(matrix: np.ndarray, overwrite: bool = False):
     """Returns (solve, logdet).  Dense: LU (``LinearSolve[matrix]``, BGP:132), log-det =
     Total@Log@Abs@Diagonal[U] (BGP:126-128,139).  Vector argument = diagonal matrix (BGP:156-159).
     Raises MatInvFailure where the reference Throws on LinearSolve::sing1 / ::luc."""
@@ -123,11 +139,12 @@ def matrix_inverse_and_det(matrix: np.ndarray):
         return (lambda b: (b.T / diag).T if b.ndim == 2 else b / diag), float(np.sum(np.log(np.abs(diag))))
     if not np.all(np.isfinite(matrix)):
         raise MatInvFailure("non-finite covariance")
-    lu, piv = sla.lu_factor(matrix, check_finite=False)
+    anorm = float(np.abs(matrix).sum(axis=0).max()) if not overwrite else _norm1_blocked(matrix)
+    # overwrite: factor in place (the caller gives the matrix up) -- large-N golden scalars / CPU baseline only
+    lu, piv = sla.lu_factor(matrix, overwrite_a=overwrite, check_finite=False)
     u = np.diag(lu)
     if np.any(u == 0.0) or not np.all(np.isfinite(u)):
         raise MatInvFailure("sing1")
-    anorm = np.linalg.norm(matrix, 1)
     rcond, _ = sla.lapack.dgecon(lu, anorm, norm="1")
     if rcond < RCOND_FAIL:
         raise MatInvFailure("luc")
@@ -137,6 +154,15 @@ def matrix_inverse_and_det(matrix: np.ndarray):
         return sla.lu_solve((lu, piv), b, check_finite=False)
 
     return solve, logdet
+
+
+def _norm1_blocked(matrix: np.ndarray) -> float:
+    """max column sum of |a_ij| without an N x N temporary."""
+    acc = np.zeros(matrix.shape[1])
+    step = max(1, _BLOCK_ELEMS // matrix.shape[1])
+    for i0 in range(0, matrix.shape[0], step):
+        acc += np.abs(matrix[i0:i0 + step]).sum(axis=0)
+    return float(acc.max())
 
 
 def gp_log_likelihood_from_parts(r: np.ndarray, solve, logdet: float) -> float:
@@ -159,7 +185,12 @@ def log_likelihood(kernel: str, theta, X, y, mean: str = "zero", parts: bool = F
     X = np.atleast_2d(np.asarray(X, dtype=np.float64))
     r = residual(kernel, theta, X, y, mean)
     try:
-        solve, logdet = matrix_inverse_and_det(covariance_matrix(kernel, theta, X, mean))
+        K = covariance_matrix(kernel, theta, X, mean)
+        big = K.ndim == 2 and K.size > _BLOCK_ELEMS
+        # (K is symmetric bit for bit, so its transpose view is the same matrix in the column-major order LAPACK
+        #  factors in place)
+        solve, logdet = matrix_inverse_and_det(K.T if big else K, overwrite=big)
+        del K
     except MatInvFailure:
         return (MACHINE_LOG_ZERO, float("nan"), float("nan"), 1) if parts else MACHINE_LOG_ZERO
     ll = gp_log_likelihood_from_parts(r, solve, logdet)

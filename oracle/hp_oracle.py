@@ -71,3 +71,49 @@ def predict(kernel, theta, X, y, Xs, mean="zero"):
         mus.append(float(mu + sum(alpha[i] * k[i] for i in range(n))))
         sds.append(float(mp.sqrt(kappa - sum(k[i] * v[i] for i in range(n)))))
     return mus, sds
+
+
+def cholesky_pin(kernel, theta, X, y, Xs=(), mean="zero", dps=30):
+    """The same formulas for a problem of a few hundred points (cfg 1: N = 512, d = 1) -- arithmetic-independent
+    truth for the size the reference's own CPU-runnable configuration has.  Plain-list Cholesky with mp.fdot inner
+    products (mp.matrix element access would dominate), forward substitution for z = L^-1 r and the test points.
+    Returns (loglik, logdet, quad, mu*[..], sd*[..]) as floats; `dps` significant digits (30 leaves > 10 digits of
+    margin over fp64 at cond(K) ~ 1e5)."""
+    old = mp.mp.dps
+    mp.mp.dps = dps
+    try:
+        n, d = len(X), len(X[0])
+        ell, sf, sn, mu = _split(kernel, d, theta, mean)
+        L = [[None] * (i + 1) for i in range(n)]
+        for i in range(n):
+            for j in range(i + 1):
+                L[i][j] = _kernel(kernel, ell, sf, X[i], X[j])
+            L[i][i] += sn * sn
+        for j in range(n):
+            Lj = L[j]
+            dj = mp.sqrt(Lj[j] - mp.fdot(Lj[:j], Lj[:j]))
+            Lj[j] = dj
+            for i in range(j + 1, n):
+                Li = L[i]
+                Li[j] = (Li[j] - mp.fdot(Li[:j], Lj[:j])) / dj
+        r = [mp.mpf(float(v)) - mu for v in y]
+
+        def forward(b):
+            z = [None] * n
+            for i in range(n):
+                z[i] = (b[i] - mp.fdot(L[i][:i], z[:i])) / L[i][i]
+            return z
+
+        z = forward(r)
+        logdet = 2 * sum(mp.log(L[i][i]) for i in range(n))
+        quad = mp.fdot(z, z)
+        ll = -(n * mp.log(2 * mp.pi) + logdet + quad) / 2
+        mus, sds = [], []
+        for xs in Xs:
+            k = [_kernel(kernel, ell, sf, X[i], xs) for i in range(n)]
+            v = forward(k)
+            mus.append(float(mu + mp.fdot(v, z)))
+            sds.append(float(mp.sqrt(sf * sf + sn * sn - mp.fdot(v, v))))
+        return float(ll), float(logdet), float(quad), mus, sds
+    finally:
+        mp.mp.dps = old

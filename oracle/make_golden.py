@@ -70,7 +70,13 @@ def f2():
 
 def f3():
     rows = []
-    for n, kernel in ((2048, "se_ard"), (4096, "se_ard"), (8192, "se_ard"), (2048, "matern52_ard")):
+    # N = 16384 / 32768 / 49152: the sizes at which the look-ahead / wide-panel / dataflow-tail schedule of the HIP path
+    # is active (N = 32768 is the BASELINE metric's own size): LU in place, 8.6 GB / 19.3 GB of matrix, minutes of CPU
+    sizes = [(2048, "se_ard"), (4096, "se_ard"), (8192, "se_ard"), (2048, "matern52_ard"), (16384, "se_ard"),
+             (32768, "se_ard"), (16384, "matern52_ard")]
+    if os.environ.get("GOLDEN_F3_HUGE") == "1":
+        sizes.append((49152, "se_ard"))
+    for n, kernel in sizes:
         X, y = syn.make_dataset(n, 8)
         th = syn.default_theta(kernel, 8)
         ll, ld, qd, info = orc.log_likelihood(kernel, th, X, y, parts=True)
@@ -122,5 +128,8 @@ def fhp():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
+    if "--f3" in sys.argv:
+        f3()
+        sys.exit(0)
     f1(), f2(), f4(), fhp(), f3()
     print("golden fixtures written to", OUT)

@@ -84,10 +84,19 @@ def test_f3_scalars_medium_sizes(golden_dir):
         X, y = syn.make_dataset(n, d)
         assert float(X.sum()) == float(g["xsum"][i])
         h = _lib.Handle(X, y, kernel)
-        ll, ld, qd, info = h.loglik_parts(syn.default_theta(kernel, d))
-        assert info == 0
-        assert close(ld, float(g["logdet"][i]), n) and close(qd, float(g["quad"][i]), n)
-        assert close(ll, float(g["loglik"][i]), n)
+        # N >= 16384 runs the schedule that earns the headline number (look-ahead, wide early panels with left-looking
+        # in-panel updates, 64-tile dataflow tail): each of its switches is also turned off in turn, every variant against
+        # the ORACLE's scalars (LU, oracle/make_golden.py f3) at the 1e-8 bar -- not HIP against HIP
+        variants = [{}] if n < 16384 else [{}, {"panel_wide": 0}, {"lookahead": 0}, {"dataflow_tail": 0}]
+        for opts in variants:
+            for k, v in opts.items():
+                h.set_option(k, v)
+            ll, ld, qd, info = h.loglik_parts(syn.default_theta(kernel, d))
+            assert info == 0, (n, kernel, opts)
+            assert close(ld, float(g["logdet"][i]), n) and close(qd, float(g["quad"][i]), n), (n, kernel, opts)
+            assert close(ll, float(g["loglik"][i]), n), (n, kernel, opts)
+            for k in opts:
+                h.set_option(k, {"panel_wide": 1, "lookahead": 1, "dataflow_tail": 64}[k])
         h.close()
 
 
@@ -333,16 +342,20 @@ def test_solve_and_logdet_match_numpy(kernel, d, n, nrhs):
     h.close()
 
 
-def test_full_size_properties_n32768():
-    """BASELINE.json's full size (N=32768, d=8): no oracle run is affordable, so check
-    size-independent properties: schedule invariance (look-ahead / panel width), the bordered
-    quadratic form against an independent K^-1 y solve, and the K K^-1 residual."""
+def test_full_size_properties_n32768(golden_dir):
+    """BASELINE.json's full size (N=32768, d=8): the oracle's scalars for this very problem (one LU evaluation,
+    tests/golden/f3_scalars.npz) at the 1e-8 bar, plus size-independent properties: schedule invariance (look-ahead /
+    panel width), the bordered quadratic form against an independent K^-1 y solve, and the K K^-1 residual."""
     n, d = 32768, 8
     X, y = syn.make_dataset(n, d)
     th = syn.default_theta("se_ard", d)
     h = _lib.Handle(X, y, "se_ard")
     ll, ld, qd, info = h.loglik_parts(th)
     assert info == 0 and np.isfinite(ll)
+    g = np.load(os.path.join(golden_dir, "f3_scalars.npz"))
+    row = [i for i in range(len(g["n"])) if int(g["n"][i]) == n and str(g["kernel"][i]) == "se_ard"][0]
+    assert float(X.sum()) == float(g["xsum"][row])
+    assert close(ll, float(g["loglik"][row]), n) and close(ld, float(g["logdet"][row]), n) and close(qd, float(g["quad"][row]), n)
     h.set_option("lookahead", 0)
     h.set_option("panel", 2)
     h.set_option("dataflow_tail", 0)                     # pure multi-kernel schedule vs look-ahead + dataflow tail
