@@ -54,6 +54,10 @@ _SIGNATURES = {
     "gphip_fit": (C.c_int, [_h, _dp, C.c_int, _ip]),
     "gphip_predict": (C.c_int, [_h, C.c_void_p, C.c_int64, _dp, _dp]),
     "gphip_predict_samples": (C.c_int, [_h, _dp, C.c_int, C.c_int, C.c_void_p, C.c_int64, _dp, _dp, _ip]),
+    "gphip_loglik_batch_pw": (C.c_int, [_h, _dp, C.c_int, C.c_int, _dp, _dp, _dp, _ip]),
+    "gphip_fit_pw": (C.c_int, [_h, _dp, C.c_int, _dp, _dp, _ip]),
+    "gphip_predict_pw": (C.c_int, [_h, C.c_void_p, C.c_int64, _dp, _dp, _dp, _dp]),
+    "gphip_predict_samples_pw": (C.c_int, [_h, _dp, C.c_int, C.c_int, _dp, _dp, C.c_void_p, C.c_int64, _dp, _dp, _dp, _dp, _ip]),
     "gphip_covariance": (C.c_int, [_h, _dp, C.c_int, _dp]),
     "gphip_covariance_batch": (C.c_int, [_h, _dp, C.c_int, C.c_int, _dp]),
     "gphip_cross_covariance": (C.c_int, [_h, _dp, C.c_int, C.c_void_p, C.c_int64, _dp, _dp]),
@@ -216,6 +220,63 @@ class Handle:
         info = np.zeros(B, dtype=np.int32)
         self._check(self._lib.gphip_loglik_batch(self._h, _d(Th), B, p, _d(out), info.ctypes.data_as(_ip)))
         return out, info
+
+    @staticmethod
+    def _rows(a, rows: int, cols: int, what: str):
+        """optional per-point array -> (contiguous float64 [rows, cols] or None, ctypes pointer or None)"""
+        if a is None:
+            return None, None
+        arr = np.ascontiguousarray(np.asarray(a, dtype=np.float64).reshape(rows, -1))
+        if arr.shape != (rows, cols):
+            raise GphipError(2, f"{what} must have shape ({rows}, {cols})")
+        return arr, _d(arr)
+
+    def loglik_batch_pw(self, Theta, mean_train=None, nugget_train=None):
+        """gphip_loglik_batch_pw: point-dependent mean m(x_i) / nugget nu(x_i) VALUES per theta, each [B, N] or None
+        (BGP:37, 300: the host evaluates the functions, the device gets the values)."""
+        Th = np.ascontiguousarray(np.atleast_2d(np.asarray(Theta, dtype=np.float64)))
+        B, p = Th.shape
+        mt, mtp = self._rows(mean_train, B, self.N, "mean_train")
+        nt, ntp = self._rows(nugget_train, B, self.N, "nugget_train")
+        out = np.zeros(B)
+        info = np.zeros(B, dtype=np.int32)
+        self._check(self._lib.gphip_loglik_batch_pw(self._h, _d(Th), B, p, mtp, ntp, _d(out), info.ctypes.data_as(_ip)))
+        return out, info
+
+    def fit_pw(self, theta, mean_train=None, nugget_train=None) -> int:
+        th = np.ascontiguousarray(np.asarray(theta, dtype=np.float64).ravel())
+        mt, mtp = self._rows(mean_train, 1, self.N, "mean_train")
+        nt, ntp = self._rows(nugget_train, 1, self.N, "nugget_train")
+        info = C.c_int(0)
+        self._check(self._lib.gphip_fit_pw(self._h, _d(th), th.size, mtp, ntp, C.byref(info)))
+        return info.value
+
+    def predict_pw(self, Xs, mean_test=None, nugget_test=None):
+        Xs = np.ascontiguousarray(np.atleast_2d(np.asarray(Xs, dtype=np.float64)))
+        if Xs.shape[1] != self.d:
+            raise GphipError(2, "test points have the wrong dimension")
+        M = Xs.shape[0]
+        ms, msp = self._rows(mean_test, 1, M, "mean_test")
+        ns, nsp = self._rows(nugget_test, 1, M, "nugget_test")
+        mean, var = np.zeros(M), np.zeros(M)
+        self._check(self._lib.gphip_predict_pw(self._h, Xs.ctypes.data, M, msp, nsp, _d(mean), _d(var)))
+        return mean, var
+
+    def predict_samples_pw(self, Thetas, Xs, mean_train=None, nugget_train=None, mean_test=None, nugget_test=None):
+        Th = np.ascontiguousarray(np.atleast_2d(np.asarray(Thetas, dtype=np.float64)))
+        Xs = np.ascontiguousarray(np.atleast_2d(np.asarray(Xs, dtype=np.float64)))
+        if Xs.shape[1] != self.d:
+            raise GphipError(2, "test points have the wrong dimension")
+        S, M = Th.shape[0], Xs.shape[0]
+        mt, mtp = self._rows(mean_train, S, self.N, "mean_train")
+        nt, ntp = self._rows(nugget_train, S, self.N, "nugget_train")
+        ms, msp = self._rows(mean_test, S, M, "mean_test")
+        ns, nsp = self._rows(nugget_test, S, M, "nugget_test")
+        mean, var = np.zeros((S, M)), np.zeros((S, M))
+        info = np.zeros(S, dtype=np.int32)
+        self._check(self._lib.gphip_predict_samples_pw(self._h, _d(Th), S, Th.shape[1], mtp, ntp, Xs.ctypes.data, M, msp, nsp,
+                                                       _d(mean), _d(var), info.ctypes.data_as(_ip)))
+        return mean, var, info
 
     def loglik_grad(self, theta):
         """(loglik, grad[p], info)."""

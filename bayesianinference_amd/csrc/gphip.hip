@@ -755,10 +755,101 @@ int queue_null_reduce(gphip_ctx* h, int B) {
     return 0;
 }
 
+template <typename T>
+int upload_rows(gphip_ctx* h, void* dst, const double* src, int nb, int64_t n, int64_t npad) {
+    std::vector<T> tmp((size_t)nb * npad, (T)0);
+    for (int s = 0; s < nb; ++s)
+        for (int64_t i = 0; i < n; ++i) tmp[(size_t)s * npad + i] = (T)src[(size_t)s * n + i];
+    HIPCHK(hipMemcpyAsync(dst, tmp.data(), tmp.size() * sizeof(T), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return GPHIP_OK;
+}
+
+// device copies of the point-dependent nugget / mean rows [s0, s0 + nb) of the current call (one row per workspace slot)
+int upload_pw(gphip_ctx* h, int s0, int nb) {
+    h->pw_mean_on = h->pw_nug_on = false;
+    if (!h->pw_mean_host && !h->pw_nug_host) return GPHIP_OK;
+    const int cap = std::max(h->slots, nb);
+    if (h->pw_cap < cap) {
+        (void)hipFree(h->dPwMean); (void)hipFree(h->dPwNug);
+        h->dPwMean = h->dPwNug = nullptr; h->pw_cap = 0;
+        HIPCHK(hipMalloc(&h->dPwMean, (size_t)cap * h->Npad * h->es));
+        HIPCHK(hipMalloc(&h->dPwNug, (size_t)cap * h->Npad * h->es));
+        h->pw_cap = cap;
+    }
+    int rc = GPHIP_OK;
+    if (h->pw_mean_host) {
+        rc = DISPATCH(h, upload_rows, h, h->dPwMean, h->pw_mean_host + (size_t)s0 * h->N, nb, h->N, h->Npad);
+        if (rc) return rc;
+        h->pw_mean_on = true;
+    }
+    if (h->pw_nug_host) {
+        rc = DISPATCH(h, upload_rows, h, h->dPwNug, h->pw_nug_host + (size_t)s0 * h->N, nb, h->N, h->Npad);
+        if (rc) return rc;
+        h->pw_nug_on = true;
+    }
+    return GPHIP_OK;
+}
+
+template <typename T>
+int queue_null_reduce_pw(gphip_ctx* h, int B, const double* c_nug, const double* nug, const double* mean, double* out) {
+    hipLaunchKernelGGL(null_reduce_pw_kernel<T>, dim3(B), dim3(1024), 0, h->stream, (const T*)h->dY, (int)h->N, h->dNullMu, c_nug,
+                       nug, mean, out);
+    return 0;
+}
+
+// null kernel with a point-dependent nugget and / or mean: K = diag(nu_i) (BGP:25-27, 156-159 with nugget /@ points)
+int null_kernel_batch_pw(gphip_ctx* h, const double* Theta, int B, double* out, double* parts, int* info) {
+    const int64_t N = h->N;
+    double *dNug = nullptr, *dMean = nullptr, *dC = nullptr, *dMu = nullptr, *dOut = nullptr;
+    auto cleanup = [&]() { (void)hipFree(dNug); (void)hipFree(dMean); (void)hipFree(dC); (void)hipFree(dMu); (void)hipFree(dOut); };
+    std::vector<double> cn((size_t)B), mu((size_t)B), sums((size_t)3 * B);
+    for (int s = 0; s < B; ++s) {
+        const double sn = Theta[(size_t)s * h->p];
+        cn[(size_t)s] = sn * sn;
+        const double m = (h->mean_id == GPHIP_MEAN_CONST) ? Theta[(size_t)s * h->p + 1] : 0.0;
+        mu[(size_t)s] = std::isfinite(m) ? m : 0.0;
+    }
+    int rc = GPHIP_OK;
+    auto chk = [&](hipError_t e) { if (e != hipSuccess && rc == GPHIP_OK) { h->err = hipGetErrorString(e); rc = GPHIP_ERR_HIP; } };
+    chk(hipMalloc(&dC, (size_t)B * 8)); chk(hipMalloc(&dMu, (size_t)B * 8)); chk(hipMalloc(&dOut, (size_t)B * 24));
+    if (h->pw_nug_host) chk(hipMalloc(&dNug, (size_t)B * N * 8));
+    if (h->pw_mean_host) chk(hipMalloc(&dMean, (size_t)B * N * 8));
+    if (rc == GPHIP_OK) {
+        chk(hipMemcpyAsync(dC, cn.data(), (size_t)B * 8, hipMemcpyHostToDevice, h->stream));
+        chk(hipMemcpyAsync(dMu, mu.data(), (size_t)B * 8, hipMemcpyHostToDevice, h->stream));
+        if (dNug) chk(hipMemcpyAsync(dNug, h->pw_nug_host, (size_t)B * N * 8, hipMemcpyHostToDevice, h->stream));
+        if (dMean) chk(hipMemcpyAsync(dMean, h->pw_mean_host, (size_t)B * N * 8, hipMemcpyHostToDevice, h->stream));
+    }
+    if (rc == GPHIP_OK) {
+        double* keep = h->dNullMu;
+        h->dNullMu = dMu;
+        DISPATCH(h, queue_null_reduce_pw, h, B, dC, dNug, dMean, dOut);
+        h->dNullMu = keep;
+        chk(hipMemcpyAsync(sums.data(), dOut, (size_t)B * 24, hipMemcpyDeviceToHost, h->stream));
+        chk(hipStreamSynchronize(h->stream));
+        chk(hipGetLastError());
+    }
+    cleanup();
+    if (rc) return rc;
+    for (int s = 0; s < B; ++s) {
+        const double* th = Theta + (size_t)s * h->p;
+        const double logdet = sums[(size_t)3 * s], quad = sums[(size_t)3 * s + 1];
+        const double ll = -0.5 * ((double)N * LOG_TWO_PI + logdet + quad);
+        bool finite_theta = true;
+        for (int i = 0; i < h->p; ++i) finite_theta = finite_theta && std::isfinite(th[i]);
+        info[s] = (finite_theta && std::isfinite(ll)) ? (sums[(size_t)3 * s + 2] == 0.0 ? GPHIP_INFO_OK : GPHIP_INFO_NOT_SPD) : GPHIP_INFO_NAN;
+        out[s] = ll;
+        if (parts) { parts[2 * s] = logdet; parts[2 * s + 1] = quad; }
+    }
+    return GPHIP_OK;
+}
+
 // null kernel Function[0] (BGP:25-27, 156-159): K = diag(sn^2).  The residual sums are reduced on the
 // device from the resident y (one workgroup per theta); the scalar epilogue is the usual host side of
 // the ABI.  grad (optional, B x p): d/dsn = (quad - N)/sn, d/dmu = sum(y - mu)/sn^2.
 int null_kernel_batch(gphip_ctx* h, const double* Theta, int B, double* out, double* parts, int* info, double* grad) {
+    if ((h->pw_mean_host || h->pw_nug_host) && !grad) return null_kernel_batch_pw(h, Theta, B, out, parts, info);
     if (B > h->null_cap) {
         (void)hipFree(h->dNullMu); (void)hipFree(h->dNullOut);
         h->dNullMu = h->dNullOut = nullptr; h->null_cap = 0;
@@ -795,9 +886,16 @@ int null_kernel_batch(gphip_ctx* h, const double* Theta, int B, double* out, dou
     return GPHIP_OK;
 }
 
-int eval_chunk(gphip_ctx* h, const double* Theta, int nb, double* out, double* parts, int* info) {
+// s0: index of the chunk's first theta within the call (rows of the call's point-dependent nugget / mean arrays)
+int eval_chunk(gphip_ctx* h, const double* Theta, int nb, double* out, double* parts, int* info, int s0 = 0) {
     std::vector<char> okv(nb);
-    for (int s = 0; s < nb; ++s) okv[s] = stage_theta(h, s, Theta + (size_t)s * h->p);
+    for (int s = 0; s < nb; ++s)
+        okv[s] = stage_theta(h, s, Theta + (size_t)s * h->p, h->pw_nug_host ? h->pw_nug_host + (size_t)(s0 + s) * h->N : nullptr,
+                             h->pw_mean_host ? h->pw_mean_host + (size_t)(s0 + s) * h->N : nullptr);
+    {
+        const int rc = upload_pw(h, s0, nb);
+        if (rc) return rc;
+    }
     // few thetas: they travel as kernel arguments of the first kernel (no copies, no memset); the results
     // come back through pinned host memory written by the finalize kernel (no copies either)
     h->theta_packed = (size_t)nb * (h->d + SLOTP) <= (size_t)THETA_PACK;
@@ -809,7 +907,7 @@ int eval_chunk(gphip_ctx* h, const double* Theta, int nb, double* out, double* p
     // one theta (or a few), fp64, small enough for 64-tiles and nobody needs the scaled inputs / 128-block
     // inverses afterwards: the evaluation is ONE launch
     h->fused_eval = h->fuse_option && h->theta_packed && h->dtype == 64 && !h->want_w && h->profile < 2 &&
-                    use_dataflow(h, nb) && h->Nt <= h->dataflow_fine_nt;
+                    !h->pw_mean_on && !h->pw_nug_on && use_dataflow(h, nb) && h->Nt <= h->dataflow_fine_nt;
     h->cs = h->stream;
     {
         ProfScope ps(h, 5, 0.0, 0.0);
@@ -818,6 +916,7 @@ int eval_chunk(gphip_ctx* h, const double* Theta, int nb, double* out, double* p
     }
     h->fused_eval = false;
     h->theta_packed = false;
+    h->pw_mean_on = h->pw_nug_on = false;
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipGetLastError());
     harvest(h);
@@ -850,7 +949,7 @@ int eval_batch_local(gphip_ctx* h, const double* Theta, int B, int p, double* ou
     h->fitted = false;
     for (int s0 = 0; s0 < B; s0 += h->slots) {
         const int nb = (B - s0 < h->slots) ? (B - s0) : h->slots;
-        rc = eval_chunk(h, Theta + (size_t)s0 * p, nb, out + s0, parts ? parts + 2 * s0 : nullptr, info + s0);
+        rc = eval_chunk(h, Theta + (size_t)s0 * p, nb, out + s0, parts ? parts + 2 * s0 : nullptr, info + s0, s0);
         if (rc) return rc;
     }
     return GPHIP_OK;
@@ -919,14 +1018,17 @@ int download(gphip_ctx* h, std::vector<double>& dst, const void* src, size_t n, 
 int ensure_vbuf(gphip_ctx* h, int64_t cap) {
     if (cap <= h->vcap) return GPHIP_OK;
     (void)hipFree(h->dV); (void)hipFree(h->dXsT); (void)hipFree(h->dXsS); (void)hipFree(h->dMean); (void)hipFree(h->dVar);
+    (void)hipFree(h->dPwMeanT); (void)hipFree(h->dPwNugT);
     h->dV = h->dXsT = h->dXsS = nullptr;
-    h->dMean = h->dVar = nullptr;
+    h->dMean = h->dVar = h->dPwMeanT = h->dPwNugT = nullptr;
     h->vcap = 0;
     HIPCHK(hipMalloc(&h->dV, (size_t)cap * h->Npad * h->es));
     HIPCHK(hipMalloc(&h->dXsT, (size_t)cap * h->d * h->es));
     HIPCHK(hipMalloc(&h->dXsS, (size_t)cap * h->d * h->es));
     HIPCHK(hipMalloc(&h->dMean, (size_t)cap * 8));
     HIPCHK(hipMalloc(&h->dVar, (size_t)cap * 8));
+    HIPCHK(hipMalloc(&h->dPwMeanT, (size_t)cap * 8));
+    HIPCHK(hipMalloc(&h->dPwNugT, (size_t)cap * 8));
     h->vcap = cap;
     return GPHIP_OK;
 }
@@ -1013,6 +1115,21 @@ int queue_cross(gphip_ctx* h, int64_t mc, int64_t mpad, int nslots) {
     return 0;
 }
 
+// m(x*) / nugget(x*) of the test points [m0, m0 + mc) of the samples [s0, s0 + nb) -> device [nb][mpad] (pw_*_test rows are
+// pw_test_stride apart)
+int upload_pw_test(gphip_ctx* h, int s0, int nb, int64_t m0, int64_t mc, int64_t mpad) {
+    for (int which = 0; which < 2; ++which) {
+        const double* src = which ? h->pw_nug_test : h->pw_mean_test;
+        if (!src) continue;
+        std::vector<double> tmp((size_t)nb * mpad, 0.0);
+        for (int s = 0; s < nb; ++s)
+            for (int64_t t = 0; t < mc; ++t) tmp[(size_t)s * mpad + t] = src[(size_t)(s0 + s) * h->pw_test_stride + m0 + t];
+        HIPCHK(hipMemcpyAsync(which ? h->dPwNugT : h->dPwMeanT, tmp.data(), tmp.size() * 8, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    return GPHIP_OK;
+}
+
 // mu*, var* from V and z: V streamed once (HBM bound) -- strips of columns x 128 test points per workgroup,
 // then the strips are added in order.  Profile class 6: bytes = V once.
 template <typename T>
@@ -1039,7 +1156,8 @@ int queue_predict_reduce(gphip_ctx* h, int64_t mc, int64_t mpad, int nslots) {
                            (const T*)h->dA, (int)h->R, (long)h->slot_elems, js, h->dPart, nstrips);
         hipLaunchKernelGGL(predict_finish_kernel, dim3((unsigned)((mc + 255) / 256), (unsigned)nslots), dim3(256), 0, h->stream,
                            (const double*)h->dPart, nstrips, (long)mpad, (const double*)h->dSlotp, (int)mc, (long)mpad,
-                           h->dMean, h->dVar);
+                           h->dMean, h->dVar, h->pw_mean_test ? (const double*)h->dPwMeanT : nullptr,
+                           h->pw_nug_test ? (const double*)h->dPwNugT : nullptr);
     }
     return 0;
 }
@@ -1422,9 +1540,18 @@ int gphip_fit(gphip_handle h, const double* theta, int p, int* info) {
         const double sn = theta[0], mu = (h->mean_id == GPHIP_MEAN_CONST) ? theta[1] : 0.0;
         const bool finite = std::isfinite(sn) && std::isfinite(mu);
         *info = !finite ? GPHIP_INFO_NAN : (sn * sn > 0.0 && std::isfinite(std::log(sn * sn)) ? GPHIP_INFO_OK : GPHIP_INFO_NOT_SPD);
+        h->logdet_fit = (double)h->N * std::log(sn * sn);
+        h->null_diag.clear();
+        if (h->pw_nug_host) {                  // nugget /@ points (BGP:27): the diagonal itself
+            h->null_diag.assign(h->pw_nug_host, h->pw_nug_host + h->N);
+            double ld = 0.0;
+            bool pos = true, fin = finite;
+            for (double v : h->null_diag) { ld += std::log(std::fabs(v)); pos = pos && v > 0.0; fin = fin && std::isfinite(v); }
+            h->logdet_fit = ld;
+            *info = !fin ? GPHIP_INFO_NAN : (pos && std::isfinite(ld) ? GPHIP_INFO_OK : GPHIP_INFO_NOT_SPD);
+        }
         h->fitted = h->null_fit = (*info == 0);
         h->theta_fit.assign(theta, theta + p);
-        h->logdet_fit = (double)h->N * std::log(sn * sn);
         h->mu_fit = mu;
         h->kappa_fit = sn * sn;
         return GPHIP_OK;
@@ -1558,7 +1685,10 @@ int gphip_predict(gphip_handle h, const void* Xs, int64_t M, double* mean, doubl
     std::lock_guard<std::recursive_mutex> lk(h->mu);
     if (!h->fitted) return fail(h, GPHIP_ERR_STATE, "gphip_predict before a successful gphip_fit");
     if (h->null_fit) {                         // null kernel (BGP:63-89): k = 0, kappa = nugget
-        for (int64_t t = 0; t < M; ++t) { mean[t] = h->mu_fit; var[t] = h->kappa_fit; }
+        for (int64_t t = 0; t < M; ++t) {
+            mean[t] = h->pw_mean_test ? h->pw_mean_test[t] : h->mu_fit;
+            var[t] = h->pw_nug_test ? h->pw_nug_test[t] : h->kappa_fit;
+        }
         return GPHIP_OK;
     }
     // multi-device handle whose members all hold the factor (sharded fit): test points shard, no collective
@@ -1569,10 +1699,18 @@ int gphip_predict(gphip_handle h, const void* Xs, int64_t M, double* mean, doubl
         if (all) {
             const int64_t nl = (int64_t)g->members.size(), d = h->d;
             const double* X = static_cast<const double*>(Xs);
-            return group_parallel(h, [&](int i) {
+            const double *pm = h->pw_mean_test, *pn = h->pw_nug_test;
+            const int rc = group_parallel(h, [&](int i) {
                 const int64_t m0 = M * i / nl, m1 = M * (i + 1) / nl;
-                return predict_local(g->members[(size_t)i], X + m0 * d, m1 - m0, mean + m0, var + m0);
+                gphip_ctx* m = g->members[(size_t)i];
+                m->pw_mean_test = pm ? pm + m0 : nullptr;      // each member's shard of m(x*), nugget(x*)
+                m->pw_nug_test = pn ? pn + m0 : nullptr;
+                const int c = predict_local(m, X + m0 * d, m1 - m0, mean + m0, var + m0);
+                if (m != h) m->pw_mean_test = m->pw_nug_test = nullptr;
+                return c;
             });
+            h->pw_mean_test = pm; h->pw_nug_test = pn;
+            return rc;
         }
     }
     return predict_local(h, Xs, M, mean, var);
@@ -1606,6 +1744,8 @@ static int predict_local(gphip_handle h, const void* Xs, int64_t M, double* mean
             for (int64_t j = 0; j < d; ++j) xt[(size_t)j * mpad + i] = X[(m0 + i) * d + j];
         rc = DISPATCH(h, upload, h, h->dXsT, xt, h->stream);
         if (rc) return rc;
+        rc = upload_pw_test(h, 0, 1, m0, mc, mpad);
+        if (rc) return rc;
         DISPATCH(h, queue_cross, h, mc, mpad, 1);
         DISPATCH(h, queue_forward_rows, h, mpad, 1);
         DISPATCH(h, queue_predict_reduce, h, mc, mpad, 1);
@@ -1632,7 +1772,10 @@ int gphip_predict_samples(gphip_handle h, const double* Thetas, int S, int p, co
             const double sn = Thetas[(size_t)s * p], mu = (h->mean_id == GPHIP_MEAN_CONST) ? Thetas[(size_t)s * p + 1] : 0.0;
             const bool finite = std::isfinite(sn) && std::isfinite(mu);
             info[s] = !finite ? GPHIP_INFO_NAN : (sn * sn > 0.0 ? GPHIP_INFO_OK : GPHIP_INFO_NOT_SPD);
-            for (int64_t t = 0; t < M; ++t) { mean[(size_t)s * M + t] = mu; var[(size_t)s * M + t] = sn * sn; }
+            for (int64_t t = 0; t < M; ++t) {
+                mean[(size_t)s * M + t] = h->pw_mean_test ? h->pw_mean_test[(size_t)s * h->pw_test_stride + t] : mu;
+                var[(size_t)s * M + t] = h->pw_nug_test ? h->pw_nug_test[(size_t)s * h->pw_test_stride + t] : sn * sn;
+            }
         }
         return GPHIP_OK;
     }
@@ -1644,10 +1787,19 @@ int gphip_predict_samples(gphip_handle h, const double* Thetas, int S, int p, co
             const int s0 = (int)((long)S * i / nl), s1 = (int)((long)S * (i + 1) / nl);
             if (s1 <= s0) return (int)GPHIP_OK;
             gphip_ctx* m = g->members[(size_t)i];
+            const double *a0 = h->pw_mean_host, *a1 = h->pw_nug_host, *a2 = h->pw_mean_test, *a3 = h->pw_nug_test;
+            if (m != h) {                                                  // the member's block of every per-sample row
+                m->pw_mean_host = a0 ? a0 + (size_t)s0 * h->N : nullptr;
+                m->pw_nug_host = a1 ? a1 + (size_t)s0 * h->N : nullptr;
+                m->pw_mean_test = a2 ? a2 + (size_t)s0 * h->pw_test_stride : nullptr;
+                m->pw_nug_test = a3 ? a3 + (size_t)s0 * h->pw_test_stride : nullptr;
+                m->pw_test_stride = h->pw_test_stride;
+            }
             m->in_group_call = true;
             const int c = gphip_predict_samples(m, Thetas + (size_t)s0 * p, s1 - s0, p, Xs, M, mean + (size_t)s0 * M,
                                                 var + (size_t)s0 * M, info + s0);
             m->in_group_call = false;
+            if (m != h) m->pw_mean_host = m->pw_nug_host = m->pw_mean_test = m->pw_nug_test = nullptr;
             return c;
         });
     }
@@ -1662,7 +1814,7 @@ int gphip_predict_samples(gphip_handle h, const double* Thetas, int S, int p, co
         const int nb = (S - s0 < h->slots) ? (S - s0) : h->slots;
         std::vector<double> ll(nb);
         h->want_w = true;
-        rc = eval_chunk(h, Thetas + (size_t)s0 * p, nb, ll.data(), nullptr, info + s0);   // build + factor, kept
+        rc = eval_chunk(h, Thetas + (size_t)s0 * p, nb, ll.data(), nullptr, info + s0, s0);   // build + factor, kept
         h->want_w = false;
         if (rc) return rc;
         // test-point chunk so that the nb V blocks stay within ~8 GiB
@@ -1680,6 +1832,8 @@ int gphip_predict_samples(gphip_handle h, const double* Thetas, int S, int p, co
             for (int64_t i = 0; i < mc; ++i)
                 for (int64_t j = 0; j < d; ++j) xt[(size_t)j * mpad + i] = X[(m0 + i) * d + j];
             rc = DISPATCH(h, upload, h, h->dXsT, xt, h->stream);
+            if (rc) return rc;
+            rc = upload_pw_test(h, s0, nb, m0, mc, mpad);
             if (rc) return rc;
             DISPATCH(h, queue_cross, h, mc, mpad, nb);
             DISPATCH(h, queue_forward_rows, h, mpad, nb);
@@ -1701,6 +1855,55 @@ int gphip_predict_samples(gphip_handle h, const double* Thetas, int S, int p, co
     return GPHIP_OK;
 }
 
+// ---- point-dependent nugget and mean (BGP:37 nugget[points[[i]]], BGP:171/300 meanFunction /@ inputData, BGP:113 nugget at
+// the test points, BGP:408 meanFunction /@ inputs): the host evaluates the two functions for the theta(s) of the call and
+// hands the VALUES over; a null pointer keeps the constant form (sn^2, mu) read from theta.  The arrays only have to
+// live for the duration of the call.
+namespace {
+struct PwScope {                               // installs the call's arrays on the handle, removes them on every exit path
+    gphip_ctx* h;
+    PwScope(gphip_ctx* h_, const double* mt, const double* nt, const double* ms, const double* ns, long stride) : h(h_) {
+        h->pw_mean_host = mt; h->pw_nug_host = nt; h->pw_mean_test = ms; h->pw_nug_test = ns; h->pw_test_stride = stride;
+    }
+    ~PwScope() {
+        h->pw_mean_host = h->pw_nug_host = h->pw_mean_test = h->pw_nug_test = nullptr;
+        h->pw_mean_on = h->pw_nug_on = false;
+    }
+};
+}  // namespace
+
+int gphip_loglik_batch_pw(gphip_handle h, const double* Theta, int B, int p, const double* mean_train, const double* nugget_train,
+                          double* out, int* info) {
+    if (!h) return GPHIP_ERR_ARG;
+    std::lock_guard<std::recursive_mutex> lk(h->mu);
+    PwScope pw(h, mean_train, nugget_train, nullptr, nullptr, 0);
+    return eval_batch(h, Theta, B, p, out, nullptr, info);
+}
+
+int gphip_fit_pw(gphip_handle h, const double* theta, int p, const double* mean_train, const double* nugget_train, int* info) {
+    if (!h) return GPHIP_ERR_ARG;
+    std::lock_guard<std::recursive_mutex> lk(h->mu);
+    PwScope pw(h, mean_train, nugget_train, nullptr, nullptr, 0);
+    return gphip_fit(h, theta, p, info);
+}
+
+int gphip_predict_pw(gphip_handle h, const void* Xs, int64_t M, const double* mean_test, const double* nugget_test, double* mean,
+                     double* var) {
+    if (!h) return GPHIP_ERR_ARG;
+    std::lock_guard<std::recursive_mutex> lk(h->mu);
+    PwScope pw(h, nullptr, nullptr, mean_test, nugget_test, (long)M);
+    return gphip_predict(h, Xs, M, mean, var);
+}
+
+int gphip_predict_samples_pw(gphip_handle h, const double* Thetas, int S, int p, const double* mean_train, const double* nugget_train,
+                             const void* Xs, int64_t M, const double* mean_test, const double* nugget_test, double* mean, double* var,
+                             int* info) {
+    if (!h) return GPHIP_ERR_ARG;
+    std::lock_guard<std::recursive_mutex> lk(h->mu);
+    PwScope pw(h, mean_train, nugget_train, mean_test, nugget_test, (long)M);
+    return gphip_predict_samples(h, Thetas, S, p, Xs, M, mean, var, info);
+}
+
 // out = K^-1 rhs = L^-T (L^-1 rhs): right-hand sides ride as ROWS of the scratch block V
 // (V(t, j) = rhs_t[j]), forward pass V <- V L^-T, backward pass V <- V L^-1.
 int gphip_solve(gphip_handle h, const double* rhs, int64_t nrhs, double* out) {
@@ -1709,7 +1912,8 @@ int gphip_solve(gphip_handle h, const double* rhs, int64_t nrhs, double* out) {
     std::lock_guard<std::recursive_mutex> lk(h->mu);
     if (!h->fitted) return fail(h, GPHIP_ERR_STATE, "gphip_solve before a successful gphip_fit");
     if (h->null_fit) {                         // "Inverse" -> Function[Divide[#, matrixDiagonal]]  (BGP:156-159)
-        for (int64_t i = 0; i < nrhs * h->N; ++i) out[i] = rhs[i] / h->kappa_fit;
+        for (int64_t i = 0; i < nrhs * h->N; ++i)
+            out[i] = rhs[i] / (h->null_diag.empty() ? h->kappa_fit : h->null_diag[(size_t)(i % h->N)]);
         return GPHIP_OK;
     }
     HIPCHK(hipSetDevice(h->device));
@@ -1791,13 +1995,16 @@ int gphip_dist_begin(gphip_handle h, const double* theta, int p, int rank, int w
     if (rc) return rc;
     h->fitted = false;
     h->dist_rank = rank; h->dist_world = world;
-    h->dist_theta_ok = stage_theta(h, 0, theta);
+    h->dist_theta_ok = stage_theta(h, 0, theta, h->pw_nug_host, h->pw_mean_host);
+    rc = upload_pw(h, 0, 1);                   // point-dependent nugget / mean of this evaluation, if the caller set them
+    if (rc) return rc;
     HIPCHK(hipMemcpyAsync(h->dInvEll, h->hInvEll, (size_t)h->d * 8, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->dSlotp, h->hSlotp, SLOTP * 8, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemsetAsync(h->dInfo, 0, 4, h->stream));
     HIPCHK(hipMemsetAsync(h->dPartial, 0, (size_t)h->Nt * 8, h->stream));
     h->cs = h->stream;
     DISPATCH(h, queue_build, h, 1);
+    h->pw_mean_on = h->pw_nug_on = false;
     return GPHIP_OK;
 }
 

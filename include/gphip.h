@@ -11,6 +11,7 @@
  *   gphip_cross_covariance  compiledKandKappa[points1, kernel, nugget][X*]     BGP:63-124
  *   gphip_predict       predictFromGaussianProcessInternal                 BGP:396-422
  *   gphip_predict_samples  predictFromGaussianProcess over all samples     BGP:343-376
+ *   gphip_*_pw          the same with point-dependent nugget[x] / mean[x]  BGP:37, 113, 171, 300, 408
  *   gphip_covariance    "CovarianceFunction" = compiledCovarianceMatrix    BGP:45-61
  *   gphip_solve         "InverseCovarianceFunction"[theta]["Inverse"][b]   BGP:130-141
  *   gphip_logdet        "InverseCovarianceFunction"[theta]["LogDet"]       BGP:126-128,139
@@ -116,6 +117,24 @@ int gphip_predict(gphip_handle h, const void* Xs, int64_t M, double* mean, doubl
  * are factored and solved in one batched pass (one workspace slot per sample). */
 int gphip_predict_samples(gphip_handle h, const double* Thetas, int S, int p, const void* Xs, int64_t M,
                           double* mean, double* var, int* info);
+/* ---- Point-dependent nugget and mean functions.  The reference evaluates nugget[points[[i]]] (BGP:37), meanFunction /@
+ * inputData (BGP:171, 300), kernel[p, p] + nugget[p] at the test points (BGP:113) and meanFunction /@ inputs (BGP:408) for
+ * ANY functions of the point (heteroscedastic noise, any m(x)).  Those functions live on the host (WL / Python); the host
+ * evaluates them for the theta(s) of the call and hands the VALUES over:
+ *   mean_train, nugget_train   row-major B x N (S x N for the samples form): m_theta_b(x_i), nu_theta_b(x_i) at the training
+ *                              points; nugget values are VARIANCES (they take the place of sn^2 on the diagonal)
+ *   mean_test,  nugget_test    length M (gphip_predict_pw) / row-major S x M (samples form): the same at the test points
+ * A NULL pointer keeps the constant form read from theta (sn^2 resp. mu / 0).  theta keeps its layout; the entries a vector
+ * replaces are not used (sn^2 still scales nothing: the pivot tolerance uses sf^2 + max|nugget|).  Arrays are read during
+ * the call only.  Gradients (gphip_loglik_grad) are defined for the constant forms only. */
+int gphip_loglik_batch_pw(gphip_handle h, const double* Theta, int B, int p, const double* mean_train,
+                          const double* nugget_train, double* out, int* info);
+int gphip_fit_pw(gphip_handle h, const double* theta, int p, const double* mean_train, const double* nugget_train, int* info);
+int gphip_predict_pw(gphip_handle h, const void* Xs, int64_t M, const double* mean_test, const double* nugget_test,
+                     double* mean, double* var);
+int gphip_predict_samples_pw(gphip_handle h, const double* Thetas, int S, int p, const double* mean_train,
+                             const double* nugget_train, const void* Xs, int64_t M, const double* mean_test,
+                             const double* nugget_test, double* mean, double* var, int* info);
 /* K: row-major N x N fp64 (full, both triangles), for parity tests at small N. */
 int gphip_covariance(gphip_handle h, const double* theta, int p, double* K);
 /* Listable form (BGP:59): Theta row-major B x p -> K row-major B x N x N. */

@@ -111,15 +111,18 @@ def _kernel_block(kernel: str, sf: float, A: np.ndarray, B: np.ndarray) -> np.nd
     raise ValueError(kernel)
 
 
-def covariance_matrix(kernel: str, theta, X: np.ndarray, mean: str = "zero"):
+def covariance_matrix(kernel: str, theta, X: np.ndarray, mean: str = "zero", nugget_fn=None):
     """BGP:27-43 covarianceMatrix: K_ij = k(x_i,x_j) + delta_ij nugget(x_i).
-    Null kernel (BGP:25-27): returns the diagonal *vector* nugget /@ points."""
+    Null kernel (BGP:25-27): returns the diagonal *vector* nugget /@ points.
+    nugget_fn: optional function of ONE point (`nugget[points[[i]]]`, BGP:37) returning a variance; None = the constant
+    Function[sn^2]."""
     X = np.atleast_2d(np.asarray(X, dtype=np.float64))
     ell, sf, sn, _ = split_theta(kernel, X.shape[1], theta, mean)
+    nug = np.full(X.shape[0], sn * sn) if nugget_fn is None else np.array([float(nugget_fn(x)) for x in X])
     if kernel == "null":
-        return np.full(X.shape[0], sn * sn)
+        return nug
     K = kernel_matrix(kernel, ell, sf, X, X)
-    K[np.diag_indices_from(K)] += sn * sn
+    K[np.diag_indices_from(K)] += nug
     return K
 
 
@@ -172,20 +175,22 @@ def gp_log_likelihood_from_parts(r: np.ndarray, solve, logdet: float) -> float:
     return float(min(max(val, -lim), lim))
 
 
-def residual(kernel, theta, X, y, mean="zero"):
-    """BGP:300 Subtract[outputData, mean[#] /@ inputData]."""
+def residual(kernel, theta, X, y, mean="zero", mean_fn=None):
+    """BGP:300 Subtract[outputData, mean[#] /@ inputData].  mean_fn: optional function of ONE point (any m(x))."""
     X = np.atleast_2d(np.asarray(X, dtype=np.float64))
     _, _, _, mu = split_theta(kernel, X.shape[1], theta, mean)
+    if mean_fn is not None:
+        return np.asarray(y, dtype=np.float64).ravel() - np.array([float(mean_fn(x)) for x in X])
     return np.asarray(y, dtype=np.float64).ravel() - mu
 
 
-def log_likelihood(kernel: str, theta, X, y, mean: str = "zero", parts: bool = False):
+def log_likelihood(kernel: str, theta, X, y, mean: str = "zero", parts: bool = False, nugget_fn=None, mean_fn=None):
     """The closure assembled at BGP:297-305 (default branch) with Catch "MatInv" -> sentinel.
-    parts=True additionally returns (logdet, quad, info)."""
+    parts=True additionally returns (logdet, quad, info).  nugget_fn / mean_fn: point-dependent forms (BGP:37, 300)."""
     X = np.atleast_2d(np.asarray(X, dtype=np.float64))
-    r = residual(kernel, theta, X, y, mean)
+    r = residual(kernel, theta, X, y, mean, mean_fn)
     try:
-        K = covariance_matrix(kernel, theta, X, mean)
+        K = covariance_matrix(kernel, theta, X, mean, nugget_fn)
         big = K.ndim == 2 and K.size > _BLOCK_ELEMS
         # (K is symmetric bit for bit, so its transpose view is the same matrix in the column-major order LAPACK
         #  factors in place)
@@ -250,24 +255,28 @@ def log_likelihood_grad(kernel: str, theta, X, y, mean: str = "zero") -> np.ndar
 # --------------------------------------------------------------------------------------
 # Prediction: BGP:91-124 compiledKandKappa, BGP:396-422 predictFromGaussianProcessInternal
 # --------------------------------------------------------------------------------------
-def k_and_kappa(kernel: str, theta, X, Xs, mean: str = "zero"):
-    """k: N x M (rows = train, cols = test; BGP:100-109), kappa_j = k(x*_j,x*_j)+nugget (BGP:110-115)."""
+def k_and_kappa(kernel: str, theta, X, Xs, mean: str = "zero", nugget_fn=None):
+    """k: N x M (rows = train, cols = test; BGP:100-109), kappa_j = k(x*_j,x*_j)+nugget[x*_j] (BGP:110-115)."""
     X = np.atleast_2d(np.asarray(X, dtype=np.float64))
     Xs = np.atleast_2d(np.asarray(Xs, dtype=np.float64))
     ell, sf, sn, _ = split_theta(kernel, X.shape[1], theta, mean)
     k = kernel_matrix(kernel, ell, sf, X, Xs)
-    kappa = np.full(Xs.shape[0], (0.0 if kernel == "null" else sf * sf) + sn * sn)
+    nug = np.full(Xs.shape[0], sn * sn) if nugget_fn is None else np.array([float(nugget_fn(x)) for x in Xs])
+    kappa = (0.0 if kernel == "null" else sf * sf) + nug
     return k, kappa
 
 
-def predict_internal(kernel: str, theta, X, y, Xs, mean: str = "zero"):
+def predict_internal(kernel: str, theta, X, y, Xs, mean: str = "zero", nugget_fn=None, mean_fn=None):
     """BGP:396-422: mu* = m(X*) + (K^-1 r).k (407-412); sigma* = Sqrt[kappa - Total[k * K^-1 k]]
-    (414-417).  Returns (mu, sigma).  The variance includes the test-point nugget (BGP:113)."""
+    (414-417).  Returns (mu, sigma).  The variance includes the test-point nugget (BGP:113).
+    nugget_fn / mean_fn: point-dependent nugget[x] / meanFunction[x] (BGP:37, 113, 300, 408)."""
     X = np.atleast_2d(np.asarray(X, dtype=np.float64))
     _, _, _, mu0 = split_theta(kernel, X.shape[1], theta, mean)
-    solve, _ = matrix_inverse_and_det(covariance_matrix(kernel, theta, X, mean))
-    k, kappa = k_and_kappa(kernel, theta, X, Xs, mean)
-    r = residual(kernel, theta, X, y, mean)
+    solve, _ = matrix_inverse_and_det(covariance_matrix(kernel, theta, X, mean, nugget_fn))
+    k, kappa = k_and_kappa(kernel, theta, X, Xs, mean, nugget_fn)
+    r = residual(kernel, theta, X, y, mean, mean_fn)
+    if mean_fn is not None:
+        mu0 = np.array([float(mean_fn(x)) for x in np.atleast_2d(np.asarray(Xs, dtype=np.float64))])
     mu = mu0 + solve(r) @ k
     var = kappa - np.sum(k * solve(k), axis=0)
     with np.errstate(invalid="ignore"):

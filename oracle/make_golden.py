@@ -4,8 +4,9 @@ Run from the repo root:  python oracle/make_golden.py
 The reference (Wolfram Language) cannot run here, so these vectors come from the oracle after it
 has been pinned by closed forms, the MVN second formulation and mpmath (tests/test_oracle.py).
 Fixtures (SURVEY.md §8c): F1 cfg-1 (N=512,d=1,SE); F2 N=256,d=8 SE-ARD + Matern-5/2-ARD;
-F3 scalars only for N=2048/4096/8192 (data regenerated from the seeded generator, checksummed);
-F4 sentinel cases; HP mpmath 50-digit values for N=24/48.
+F3 scalars only for N=2048 ... 49152 (data regenerated from the seeded generator, checksummed; the N >= 16384 rows are
+one in-place LU each: minutes of CPU, `--f3` regenerates only this file);
+F4 sentinel cases; HP mpmath 50-digit values for N=24/32/48 and 30-digit values for cfg 1 itself (N=512, d=1).
 """
 from __future__ import annotations
 
@@ -123,6 +124,15 @@ def fhp():
                     f"{key}_loglik": ll, f"{key}_logdet": ld, f"{key}_quad": qd,
                     f"{key}_mu": np.array(mu), f"{key}_sd": np.array(sd)})
         print("HP", key, ll)
+    # cfg 1's own size (N = 512, d = 1, BASELINE.json configs[0]) at 30 digits: plain-list Cholesky, ~20 s
+    X, y = syn.make_dataset(512, 1)
+    Xs = np.linspace(-1.2, 1.2, 7)[:, None]
+    th = syn.default_theta("se", 1)
+    ll, ld, qd, mu, sd = hp.cholesky_pin("se", th, X.tolist(), y.tolist(), Xs.tolist(), dps=30)
+    key = "se_n512"
+    out.update({f"{key}_X": X, f"{key}_y": y, f"{key}_Xs": Xs, f"{key}_theta": th, f"{key}_loglik": ll, f"{key}_logdet": ld,
+                f"{key}_quad": qd, f"{key}_mu": np.array(mu), f"{key}_sd": np.array(sd)})
+    print("HP", key, ll)
     np.savez_compressed(os.path.join(OUT, "hp_mpmath.npz"), **out)
 
 

@@ -77,6 +77,26 @@ def test_hp_mpmath_golden(golden_dir):
         h.close()
 
 
+def test_cfg1_against_mpmath_pin(golden_dir):
+    """cfg 1 itself (N=512, d=1, SE) against 30-digit mpmath arithmetic (oracle/hp_oracle.cholesky_pin): truth that does
+    not depend on any fp64 factorisation -- log-likelihood, log det, quadratic form 1e-10, prediction 1e-9."""
+    g = np.load(os.path.join(golden_dir, "hp_mpmath.npz"))
+    key = "se_n512"
+    for opts in ({}, {"dataflow": 0}, {"fused_eval": 0}):           # single-launch, multi-kernel and 4-kernel dataflow paths
+        h = _lib.Handle(g[f"{key}_X"], g[f"{key}_y"], "se")
+        for k, v in opts.items():
+            h.set_option(k, v)
+        ll, ld, qd, info = h.loglik_parts(g[f"{key}_theta"])
+        assert info == 0
+        assert close(ll, float(g[f"{key}_loglik"]), h.N, 1e-10), (opts, ll)
+        assert close(ld, float(g[f"{key}_logdet"]), h.N, 1e-10) and close(qd, float(g[f"{key}_quad"]), h.N, 1e-10)
+        assert h.fit(g[f"{key}_theta"]) == 0
+        mu, var = h.predict(g[f"{key}_Xs"])
+        np.testing.assert_allclose(mu, g[f"{key}_mu"], rtol=1e-9, atol=1e-11)
+        np.testing.assert_allclose(np.sqrt(var), g[f"{key}_sd"], rtol=1e-9)
+        h.close()
+
+
 def test_f3_scalars_medium_sizes(golden_dir):
     g = np.load(os.path.join(golden_dir, "f3_scalars.npz"))
     for i in range(len(g["n"])):

@@ -79,6 +79,24 @@ def test_against_mpmath_golden(golden_dir):
         np.testing.assert_allclose(sd, g[f"{key}_sd"], rtol=1e-10)
 
 
+def test_oracle_against_mpmath_at_cfg1_size(golden_dir):
+    """The LU restatement against 30-digit arithmetic at cfg 1's own size (N=512, d=1; oracle/make_golden.py fhp)."""
+    g = np.load(os.path.join(golden_dir, "hp_mpmath.npz"))
+    key = "se_n512"
+    X, y, th = g[f"{key}_X"], g[f"{key}_y"], g[f"{key}_theta"]
+    ll, ld, qd, info = orc.log_likelihood("se", th, X, y, parts=True)
+    assert info == 0
+    assert ll == pytest.approx(float(g[f"{key}_loglik"]), rel=1e-11)
+    assert ld == pytest.approx(float(g[f"{key}_logdet"]), rel=1e-11)
+    assert qd == pytest.approx(float(g[f"{key}_quad"]), rel=1e-10)
+    mu, sd = orc.predict_internal("se", th, X, y, g[f"{key}_Xs"])
+    np.testing.assert_allclose(mu, g[f"{key}_mu"], rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(sd, g[f"{key}_sd"], rtol=1e-9)
+    # and the committed F1 fixture's first theta is this very problem
+    f1 = np.load(os.path.join(golden_dir, "f1_se_n512_d1.npz"))
+    assert np.array_equal(f1["thetas"][0], th) and float(f1["loglik"][0]) == pytest.approx(float(g[f"{key}_loglik"]), rel=1e-11)
+
+
 def test_mpmath_live_small():
     from oracle import hp_oracle as hp
     X, y = syn.make_dataset(12, 2)
@@ -189,3 +207,26 @@ def test_oracle_matches_reference_fixture(golden_dir):
             mo, so = orc.predict_internal(c["kernel"], np.array(ref["thetas"])[i], X, y, pts, c["mean"])
             np.testing.assert_allclose(mo, mu, rtol=1e-9, atol=1e-10)
             np.testing.assert_allclose(so, sd, rtol=1e-9)
+
+
+def test_point_dependent_nugget_and_mean_functions_reduce_to_the_constant_forms():
+    """nugget_fn / mean_fn (BGP:37, 300) with constant functions are the default path; a heteroscedastic nugget changes K's
+    diagonal only; kappa carries the test-point nugget (BGP:113)."""
+    X, y = syn.make_dataset(40, 2)
+    Xs = syn.make_test_points(5, 2)
+    th = np.array([0.7, 1.1, 1.2, 0.3, 0.25])
+    base = orc.log_likelihood("se_ard", th, X, y, "const")
+    same = orc.log_likelihood("se_ard", th, X, y, "const", nugget_fn=lambda x: 0.09, mean_fn=lambda x: 0.25)
+    assert same == pytest.approx(base, rel=1e-14)
+    nf = lambda x: 0.09 * (1 + x[0] ** 2)                     # noqa: E731
+    K0 = orc.covariance_matrix("se_ard", th, X, "const")
+    K1 = orc.covariance_matrix("se_ard", th, X, "const", nugget_fn=nf)
+    off = ~np.eye(40, dtype=bool)
+    assert np.array_equal(K0[off], K1[off])
+    np.testing.assert_allclose(np.diag(K1) - np.diag(K0), 0.09 * X[:, 0] ** 2, rtol=1e-12, atol=1e-15)
+    _, kappa = orc.k_and_kappa("se_ard", th, X, Xs, "const", nugget_fn=nf)
+    np.testing.assert_allclose(kappa, 1.2 ** 2 + 0.09 * (1 + Xs[:, 0] ** 2))
+    mu, sd = orc.predict_internal("se_ard", th, X, y, Xs, "const", nugget_fn=lambda x: 0.09, mean_fn=lambda x: 0.25)
+    mu0, sd0 = orc.predict_internal("se_ard", th, X, y, Xs, "const")
+    np.testing.assert_allclose(mu, mu0, rtol=1e-13)
+    np.testing.assert_allclose(sd, sd0, rtol=1e-13)
