@@ -19,7 +19,32 @@ HEADER = os.path.join(os.path.dirname(PKG), "include", "gphip.h")
 
 OK = 0
 INFO_OK, INFO_NOT_SPD, INFO_NAN = 0, 1, 2
-KERNEL_IDS = {"se": 0, "se_ard": 1, "matern52": 2, "matern52_ard": 3, "null": 4}
+KERNEL_IDS = {"se": 0, "se_ard": 1, "matern52": 2, "matern52_ard": 3, "null": 4, "matern32": 5, "matern32_ard": 6,
+              "rq": 7, "rq_ard": 8}
+_OPS = {"+": 1, "*": 2}
+
+
+def kernel_id(name: str) -> int:
+    """Named kernel or a composed form -> the integer of include/gphip.h.  Grammar (spaces ignored):
+        term [(+|*) term] [+const]      term in se, se_ard, matern52, matern52_ard, matern32, matern32_ard, rq, rq_ard
+    e.g. "se+const" (the reference's own example, BGP:16), "se_ard+matern32", "rq*se_ard+const".  theta layout:
+    [term 1: l.., (alpha), sf] [term 2: l.., (alpha), sf] [c] sn [mu]."""
+    key = name.replace(" ", "").lower()
+    if key in KERNEL_IDS:
+        return KERNEL_IDS[key]
+    offset = 0
+    if key.endswith("+const"):
+        key, offset = key[:-len("+const")], 1
+    for sym, op in _OPS.items():
+        if sym in key:
+            a, b = key.split(sym, 1)
+            break
+    else:
+        a, b, op = key, None, 0
+    if a not in KERNEL_IDS or a == "null" or (b is not None and (b not in KERNEL_IDS or b == "null")):
+        raise GphipError(1, f"unknown kernel {name!r}")
+    return KERNEL_IDS[a] | ((KERNEL_IDS[b] if b else 0) << 8) | (op << 16) | (offset << 20) | (1 << 24)
+
 MEAN_IDS = {"zero": 0, "const": 1}
 PROFILE_CLASSES = ("kbuild", "potrf", "trsm", "gemm_panel", "syrk_trailing", "eval_total", "predict_epilogue")
 COMM_ID_BYTES = 128
@@ -148,8 +173,9 @@ class Handle:
         y = np.ascontiguousarray(np.asarray(y, dtype=np.float64).ravel())
         if X.shape[0] != y.shape[0]:
             raise GphipError(2, "Input and output data are not of same length")     # BGP:251-253
-        if kernel not in KERNEL_IDS or mean not in MEAN_IDS:
-            raise GphipError(1, f"unknown kernel/mean {kernel!r}/{mean!r}")
+        if mean not in MEAN_IDS:
+            raise GphipError(1, f"unknown mean {mean!r}")
+        kid = kernel_id(kernel)
         self.N, self.d = X.shape
         self.kernel, self.mean, self.dtype = kernel, mean, int(dtype)
         self._lib = lib
@@ -161,11 +187,11 @@ class Handle:
         if comm_id is not None:
             if rank is None or world is None or len(comm_id) != COMM_ID_BYTES:
                 raise GphipError(1, "rank, world and a 128-byte comm_id go together")
-            rc = lib.gphip_create_rank(X.ctypes.data, y.ctypes.data, self.N, self.d, KERNEL_IDS[kernel], MEAN_IDS[mean],
+            rc = lib.gphip_create_rank(X.ctypes.data, y.ctypes.data, self.N, self.d, kid, MEAN_IDS[mean],
                                        dtype, -1 if device is None else int(devs[0]), int(rank), int(world),
                                        C.c_char_p(comm_id), C.byref(self._h))
         else:
-            rc = lib.gphip_create(X.ctypes.data, y.ctypes.data, self.N, self.d, KERNEL_IDS[kernel],
+            rc = lib.gphip_create(X.ctypes.data, y.ctypes.data, self.N, self.d, kid,
                                   MEAN_IDS[mean], dtype, devs, nd, C.byref(self._h))
         if rc != OK:
             self._h = None

@@ -47,7 +47,9 @@ constexpr long TS = (long)TB * TB + GP_TILE_PAD;
 __host__ __device__ __forceinline__ long tile_index(int ti, int tj, int R) {
     return (long)tj * R - ((long)tj * (tj - 1)) / 2 + (ti - tj);
 }
-constexpr int SLOTP = 8;        // doubles of per-slot scalars: sf2, sn2, mu, pivot_tol, bad_theta
+constexpr int SLOTP = 16;       // doubles of per-slot scalars: [0] sf2 (term 1), [1] sn2, [2] mu, [3] pivot_tol, [4] bad_theta,
+                                // [5] sf2 of term 2, [6] alpha of term 1, [7] alpha of term 2 (rational quadratic), [8] constant
+                                // offset c, [9] k(x, x) (prior variance without the nugget)
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 typedef float f4 __attribute__((ext_vector_type(4)));
@@ -164,6 +166,59 @@ __device__ __forceinline__ T kfun(T r2, T sf2) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The general covariance form (KT = 2 instantiations; the reference takes ANY kernel[p, q], BGP:32 -- its own example is a
+// constant plus a squared exponential, BGP:16):
+//     k(p, q) = c + k1(p, q)  [ + or * k2(p, q) ],     k_t = sf_t^2 g_fam(r_t^2 [, alpha_t]),  r_t^2 = sum ((p_j - q_j) / l_tj)^2
+// families: 0 squared exponential exp(-r2/2), 1 Matern-5/2, 2 Matern-3/2 (1 + s3) exp(-s3), s3 = sqrt(3 r2),
+// 3 rational quadratic (1 + r2 / (2 alpha))^-alpha.  Each term has its own length scales (its own scaled copy of the
+// inputs).  The two-family fast paths above (KT = 0 / 1, one term, no offset) stay as they are.
+// ---------------------------------------------------------------------------------------------
+struct KSpec {
+    int fam1, fam2;     // family of term 1 / term 2
+    int op;             // 0: one term, 1: k1 + k2, 2: k1 * k2
+    int offset;         // 1: + c
+};
+constexpr int SP_SF2B = 5, SP_ALPHA1 = 6, SP_ALPHA2 = 7, SP_OFFSET = 8, SP_KXX = 9;
+
+// g_fam(r2) and  -2 dg/dr2  (the factor the length-scale derivative needs: dk/dl_j = sf2 (-2 dg/dr2) u_j^2 / l_j) and dg/dalpha
+template <typename T>
+__device__ __forceinline__ void kfamily(int fam, T r2, T alpha, T& g, T& m2dg, T& dga) {
+    dga = (T)0;
+    if (fam == 0) {
+        g = exp_nonpos((T)-0.5 * r2);
+        m2dg = g;
+    } else if (fam == 1) {
+        const T s5 = Num<T>::sqrt_((T)5.0 * r2), e = exp_nonpos(-s5);
+        g = ((T)1.0 + s5 + (T)(5.0 / 3.0) * r2) * e;
+        m2dg = (T)(5.0 / 3.0) * ((T)1.0 + s5) * e;
+    } else if (fam == 2) {
+        const T s3 = Num<T>::sqrt_((T)3.0 * r2), e = exp_nonpos(-s3);
+        g = ((T)1.0 + s3) * e;
+        m2dg = (T)3.0 * e;
+    } else {
+        const double q = (double)r2 / (2.0 * (double)alpha), l1p = log1p(q);
+        const double gd = exp(-(double)alpha * l1p);
+        g = (T)gd;
+        m2dg = (T)(gd / (1.0 + q));
+        dga = (T)(gd * (q / (1.0 + q) - l1p));
+    }
+}
+
+// k(p, q) of the general form from the two squared scaled distances; sp = the slot's scalars
+template <typename T>
+__device__ __forceinline__ T kgeneral(const KSpec& ks, T r2a, T r2b, const double* __restrict__ sp) {
+    T g, m2, da;
+    kfamily<T>(ks.fam1, r2a, (T)sp[SP_ALPHA1], g, m2, da);
+    T k = (T)sp[0] * g;
+    if (ks.op != 0) {
+        kfamily<T>(ks.fam2, r2b, (T)sp[SP_ALPHA2], g, m2, da);
+        const T k2 = (T)sp[SP_SF2B] * g;
+        k = (ks.op == 1) ? k + k2 : k * k2;
+    }
+    return ks.offset ? k + (T)sp[SP_OFFSET] : k;
+}
+
 // xs[slot][dd][i] = X[dd][i] * inv_ell[slot][dd]      (Xt is the transposed copy [d][npad])
 template <typename T>
 __global__ void k_scale(const T* __restrict__ Xt, T* __restrict__ xs, const double* __restrict__ inv_ell,
@@ -181,7 +236,7 @@ __global__ void k_scale(const T* __restrict__ Xt, T* __restrict__ xs, const doub
 // latency path (a few thetas per call) this replaces two host-to-device copies and a memset -- block
 // (0,0) also leaves inv_ell / the per-slot scalars in device memory for the kernels that follow and
 // clears the info words.  v = [nslots*d inverse length scales][nslots*SLOTP slot scalars].
-constexpr int THETA_PACK = 224;
+constexpr int THETA_PACK = 320;
 struct ThetaPack { double v[THETA_PACK]; };
 template <typename T>
 __global__ void k_scale_theta(const T* __restrict__ Xt, T* __restrict__ xs, ThetaPack tp, double* __restrict__ inv_ell_out,
@@ -234,6 +289,9 @@ struct KBuildArgs {
     // Point-dependent nugget / mean (BGP:37 nugget[points[[i]]], BGP:300 meanFunction /@ inputData): values the host
     // evaluated for this call's theta, [slot][pw_bstride]; null = the constant forms sn^2 / mu of the slot scalars
     const T* pw_nug; const T* pw_mean; long pw_bstride;
+    // general form (KT = 2): the inputs scaled by the SECOND term's length scales (null for one term) and the spec
+    const T* xi2; const T* xj2;
+    KSpec ks;
     int own_panel, own_world, own_rank;   // own_world > 0 (multi-GPU 1-D block-cyclic layout): build
                             // only tile columns whose outer panel (tj / own_panel) belongs to own_rank;
                             // the rhs x rhs corner tile belongs to rank 0
@@ -287,14 +345,22 @@ __global__ __launch_bounds__(256) void kbuild_kernel(KBuildArgs<T> a) {
     const T* xig = a.xi + (long)slot * a.xi_bstride + (long)ti * TB;
     T* xjs = lds;
     T* xis = lds + d * TB;
+    // general form (KT = 2, D = 0): the second term's scaled points behind the first term's
+    T* xjs2 = lds + 2 * d * TB;
+    T* xis2 = lds + 3 * d * TB;
+    const bool two = KT == 2 && a.ks.op != 0;
     // fp64: sf2 2^(j/512) table behind the point tiles (see exp_tab)
     double* etab = lds_raw + ((D > 0) ? D : 2 * d) * TB;
-    if (sizeof(T) == 8)
+    if (sizeof(T) == 8 && KT != 2)
         for (int idx = tid; idx < EXP_TAB; idx += 256) etab[idx] = sp[0] * a.exp2tab[idx];
     for (int idx = tid; idx < d * TB; idx += 256) {
         const int dd = idx >> 7, c = idx & 127;
         xjs[idx] = xjg[(long)dd * a.npad_j + c];
         if (D == 0) xis[idx] = xig[(long)dd * a.npad_i + c];
+        if (KT == 2 && two) {
+            xjs2[idx] = a.xj2[(long)slot * a.xj_bstride + (long)tj * TB + (long)dd * a.npad_j + c];
+            xis2[idx] = a.xi2[(long)slot * a.xi_bstride + (long)ti * TB + (long)dd * a.npad_i + c];
+        }
     }
     T xa[D > 0 ? D : 1], xb[D > 0 ? D : 1];
     if (D > 0) {
@@ -310,12 +376,9 @@ __global__ __launch_bounds__(256) void kbuild_kernel(KBuildArgs<T> a) {
     const int gi = ti * TB + r0;
     const bool edge = (a.mode == 0) ? (ti == tj || (ti + 1) * TB > a.n_i)
                                     : ((ti + 1) * TB > a.n_i || (tj + 1) * TB > a.n_j);
-#ifndef GP_KB_INTERLEAVE
-#define GP_KB_INTERLEAVE 1
-#endif
     // columns of the tile dealt round-robin to the four waves: at any moment the workgroup writes four ADJACENT 1 KiB
-    // column segments (one contiguous 4 KiB of the tile) instead of four segments 32 KiB apart
-    for (int jj = GP_KB_INTERLEAVE ? wave : wave * 32; jj < (GP_KB_INTERLEAVE ? TB : wave * 32 + 32); jj += GP_KB_INTERLEAVE ? 4 : 1) {
+    // column segments (one contiguous 4 KiB of the tile)
+    for (int jj = wave; jj < TB; jj += 4) {
         T ra = (T)0, rb = (T)0;
         if (D > 0) {
 #pragma unroll
@@ -334,7 +397,18 @@ __global__ __launch_bounds__(256) void kbuild_kernel(KBuildArgs<T> a) {
             }
         }
         T va, vb;
-        if constexpr (sizeof(T) == 8) {
+        if constexpr (KT == 2) {
+            T ra2 = (T)0, rb2 = (T)0;
+            if (two)
+                for (int dd = 0; dd < d; ++dd) {
+                    const T xjv = xjs2[dd * TB + jj];
+                    const T da = xis2[dd * TB + r0] - xjv, db = xis2[dd * TB + r0 + 1] - xjv;
+                    ra2 = Num<T>::fma_(da, da, ra2);
+                    rb2 = Num<T>::fma_(db, db, rb2);
+                }
+            va = kgeneral<T>(a.ks, ra, ra2, sp);
+            vb = kgeneral<T>(a.ks, rb, rb2, sp);
+        } else if constexpr (sizeof(T) == 8) {
             if (KT == 0) {
                 va = exp_tab<true>(ra, etab);
                 vb = exp_tab<true>(rb, etab);
@@ -1873,7 +1947,7 @@ __global__ void predict_finish_kernel(const double* __restrict__ part, int nstri
     }
     const long o = (long)slot * out_bstride + t;
     mean[o] = (pw_mean ? pw_mean[o] : sp[2]) + dot;
-    var[o] = sp[0] + (pw_nug ? pw_nug[o] : sp[1]) - nrm;
+    var[o] = sp[SP_KXX] + (pw_nug ? pw_nug[o] : sp[1]) - nrm;            // kappa = k(x*, x*) + nugget (BGP:110-115)
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1909,7 +1983,9 @@ struct GradArgs {
     int tri;                        // 1: Kinv holds the lower triangle only (tile rows >= tile columns): skip the
                                     //    upper tiles and count the strictly lower ones twice (everything is symmetric)
     const double* slotp;
-    double* gacc;                   // [d + 2]
+    double* gacc;                   // [d + 2]; general form: [2 d + 6], see grad_reduce_general_kernel
+    const T* xs2;                   // general form: inputs scaled by the second term's length scales (or null)
+    KSpec ks;
 };
 
 // One 128 (rows of the block) x 128 (columns) tile per workgroup; thread = one row, 64 columns.
@@ -1989,6 +2065,111 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(GradArgs<T> a) {
         atomicAdd(a.gacc + d, acc_sf);
         atomicAdd(a.gacc + d + 1, acc_dg);
     }
+}
+
+// The same reduction for the general covariance form (KSpec): w = wt (alpha_g alpha_j - Kinv_gj) contracted with every
+// dk/dtheta.  Accumulators (the host applies the chain-rule factors of its theta layout):
+//   gacc[dd]           sum w (dk/dk1) sf1^2 (-2 dg1/dr2) u1_dd^2          -> d/dl_1dd = 1/2 gacc / l
+//   gacc[d]            sum w (dk/dk1) k1                                  -> d/dsf1  = gacc / sf1
+//   gacc[d + 1]        sum_g w_gg                                         -> d/dsn   = gacc sn
+//   gacc[d + 2 + dd]   the same for term 2's length scales,  gacc[2 d + 2] for sf2
+//   gacc[2 d + 3], gacc[2 d + 4]   sum w (dk/dk_t) sf_t^2 dg_t/dalpha_t   -> d/dalpha_t = 1/2 gacc
+//   gacc[2 d + 5]      sum w                                              -> d/dc = 1/2 gacc
+// One 128 x 128 tile per workgroup, thread = one row x 64 columns; row and column points of both terms sit in LDS.
+template <typename T>
+__global__ __launch_bounds__(256) void grad_reduce_general_kernel(GradArgs<T> a) {
+    extern __shared__ double lds_raw[];
+    const int d = a.d;
+    T* xjs = reinterpret_cast<T*>(lds_raw);      // [d][128] column points (term 1), then rows, then the same for term 2
+    T* xis = xjs + d * TB;
+    T* xjs2 = xis + d * TB;
+    T* xis2 = xjs2 + d * TB;
+    T* aj = xis2 + d * TB;
+    const bool two = a.ks.op != 0;
+    const int tid = threadIdx.x, row = tid & 127, half = tid >> 7;
+    const int ti = blockIdx.x, tj = blockIdx.y;
+    if (a.tri && tj > ti) return;
+    const double wt = (a.tri && tj < ti) ? 2.0 : 1.0;
+    const int t = ti * TB + row, g = a.c0 + t;
+    const int g0 = a.c0 + ti * TB;               // first row point of this tile
+    for (int idx = tid; idx < d * TB; idx += 256) {
+        const int dd = idx >> 7, c = idx & 127;
+        xjs[idx] = a.xs[(long)dd * a.npad + tj * TB + c];
+        xis[idx] = (g0 + c < a.npad) ? a.xs[(long)dd * a.npad + g0 + c] : (T)0;
+        if (two) {
+            xjs2[idx] = a.xs2[(long)dd * a.npad + tj * TB + c];
+            xis2[idx] = (g0 + c < a.npad) ? a.xs2[(long)dd * a.npad + g0 + c] : (T)0;
+        }
+    }
+    if (tid < TB) aj[tid] = a.alpha[tj * TB + tid];
+    double acc1[32], acc2[32];
+#pragma unroll
+    for (int dd = 0; dd < 32; ++dd) acc1[dd] = acc2[dd] = 0.0;
+    double acc_sf1 = 0.0, acc_sf2 = 0.0, acc_dg = 0.0, acc_a1 = 0.0, acc_a2 = 0.0, acc_c = 0.0;
+    const T ag = (t < a.mc) ? a.alpha[g] : (T)0;
+    const double* sp = a.slotp;
+    const T sf2a = (T)sp[0], sf2b = (T)sp[SP_SF2B];
+    __syncthreads();
+    if (t < a.mc && g < a.n) {
+        for (int jj = half * 64; jj < half * 64 + 64; ++jj) {
+            const int j = tj * TB + jj;
+            if (j >= a.n) break;
+            T r2a = (T)0, r2b = (T)0;
+            for (int dd = 0; dd < d; ++dd) {
+                const T u = xis[dd * TB + row] - xjs[dd * TB + jj];
+                r2a += u * u;
+            }
+            if (two)
+                for (int dd = 0; dd < d; ++dd) {
+                    const T u = xis2[dd * TB + row] - xjs2[dd * TB + jj];
+                    r2b += u * u;
+                }
+            T g1, m1, da1, g2 = (T)0, m2 = (T)0, da2 = (T)0;
+            kfamily<T>(a.ks.fam1, r2a, (T)sp[SP_ALPHA1], g1, m1, da1);
+            if (two) kfamily<T>(a.ks.fam2, r2b, (T)sp[SP_ALPHA2], g2, m2, da2);
+            const double k1 = (double)sf2a * (double)g1, k2 = (double)sf2b * (double)g2;
+            const double dk1 = (a.ks.op == 2) ? k2 : 1.0, dk2 = (a.ks.op == 2) ? k1 : 1.0;       // dk/dk1, dk/dk2
+            const double w = wt * ((double)ag * (double)aj[jj] - (double)a.Kinv[(long)j * a.ldv + t]);
+            const double f1 = w * dk1 * (double)sf2a * (double)m1, f2 = w * dk2 * (double)sf2b * (double)m2;
+#pragma unroll
+            for (int dd = 0; dd < 32; ++dd)            // (static indices: the accumulators stay in registers)
+                if (dd < d) {
+                    const double u = (double)(xis[dd * TB + row] - xjs[dd * TB + jj]);
+                    acc1[dd] = __builtin_fma(f1, u * u, acc1[dd]);
+                }
+            if (two) {
+#pragma unroll
+                for (int dd = 0; dd < 32; ++dd)
+                    if (dd < d) {
+                        const double u = (double)(xis2[dd * TB + row] - xjs2[dd * TB + jj]);
+                        acc2[dd] = __builtin_fma(f2, u * u, acc2[dd]);
+                    }
+            }
+            acc_sf1 = __builtin_fma(w * dk1, k1, acc_sf1);
+            acc_sf2 = __builtin_fma(w * dk2, k2, acc_sf2);
+            acc_a1 = __builtin_fma(w * dk1, (double)sf2a * (double)da1, acc_a1);
+            acc_a2 = __builtin_fma(w * dk2, (double)sf2b * (double)da2, acc_a2);
+            acc_c += w;
+            if (j == g) acc_dg += w;
+        }
+    }
+    const int lane = tid & 63;
+    auto wave_add = [&](double v, double* dst) {
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+        if (lane == 0) atomicAdd(dst, v);
+    };
+#pragma unroll
+    for (int dd = 0; dd < 32; ++dd)
+        if (dd < d) {
+            wave_add(acc1[dd], a.gacc + dd);
+            if (two) wave_add(acc2[dd], a.gacc + d + 2 + dd);
+        }
+    wave_add(acc_sf1, a.gacc + d);
+    wave_add(acc_dg, a.gacc + d + 1);
+    if (two) wave_add(acc_sf2, a.gacc + 2 * d + 2);
+    wave_add(acc_a1, a.gacc + 2 * d + 3);
+    if (two) wave_add(acc_a2, a.gacc + 2 * d + 4);
+    wave_add(acc_c, a.gacc + 2 * d + 5);
 }
 
 // Null kernel Function[0] (BGP:25-27, 156-159): K = diag(sn^2), so the quadratic form is

@@ -57,7 +57,14 @@ struct gphip_ctx {
     bool dist_theta_ok = true;
     int64_t N = 0, d = 0, Npad = 0, Nt = 0;
     int64_t R = 0, slot_elems = 0;     // packed tile-major workspace: R = Nt + 1 tile rows, R (R + 1) / 2 tiles of 128 x 128 per slot
-    int kernel_id = 0, mean_id = 0, nl = 0, p = 0, kt = 0;
+    int kernel_id = 0, mean_id = 0, nl = 0, p = 0, kt = 0;   // kt: 0 SE / 1 Matern-5/2 fast paths, 2 the general form (ks)
+    // theta layout: [term 1: l_1..l_nl, (alpha), sf] [term 2: the same] [c] sn [mu]   (one plain term: l.., sf, sn[, mu])
+    KSpec ks{0, 0, 0, 0};
+    int nl2 = 0;                       // length scales of term 2 (0: no second term)
+    bool has_a1 = false, has_a2 = false;
+    void* dXs2 = nullptr;              // typed [slots][d][Npad]: inputs scaled by term 2's length scales
+    void* dXsS2 = nullptr;             // typed [vcap][d]: test points scaled by term 2's length scales
+    double *dInvEll2 = nullptr, *hInvEll2 = nullptr;
     double *dNullMu = nullptr, *dNullOut = nullptr;          // null-kernel path: per-theta mu and the two sums
     int null_cap = 0;
     void *dXt = nullptr, *dY = nullptr;                     // typed: [d][Npad], [Npad]
@@ -211,6 +218,8 @@ void free_slots(gphip_ctx* h) {
     (void)hipFree(h->dFlags); (void)hipFree(h->dTicket);
     (void)hipFree(h->dPwMean); (void)hipFree(h->dPwNug);
     h->dPwMean = h->dPwNug = nullptr; h->pw_cap = 0;
+    (void)hipFree(h->dXs2); (void)hipFree(h->dInvEll2); (void)hipHostFree(h->hInvEll2);
+    h->dXs2 = nullptr; h->dInvEll2 = h->hInvEll2 = nullptr;
     h->dFlags = nullptr; h->dTicket = nullptr; h->ticket_base = 0;
     (void)hipHostFree(h->hInvEll); (void)hipHostFree(h->hSlotp); (void)hipHostFree(h->hRes);
     (void)hipHostFree(h->hInfo);
@@ -224,7 +233,7 @@ void free_slots(gphip_ctx* h) {
 }
 
 size_t slot_bytes(const gphip_ctx* h) {
-    return ((size_t)h->slot_elems + (size_t)h->d * h->Npad + (size_t)h->Nt * TB * TB) * h->es +
+    return ((size_t)h->slot_elems + (size_t)(h->nl2 > 0 ? 2 : 1) * h->d * h->Npad + (size_t)h->Nt * TB * TB) * h->es +
            (size_t)h->Nt * 16 + (size_t)(2 * h->Nt + 1) * (2 * h->Nt + 1) * 4 + 4096;
 }
 
@@ -244,6 +253,11 @@ int ensure_slots(gphip_ctx* h, int want) {
     HIPCHK(hipMalloc(&h->dXs, S * h->d * h->Npad * h->es));
     HIPCHK(hipMalloc(&h->dW, S * h->Nt * TB * TB * h->es));
     HIPCHK(hipMalloc(&h->dInvEll, S * h->d * 8));
+    if (h->nl2 > 0) {                          // second term of a sum / product kernel: its own scaled copy of the inputs
+        HIPCHK(hipMalloc(&h->dXs2, S * h->d * h->Npad * h->es));
+        HIPCHK(hipMalloc(&h->dInvEll2, S * h->d * 8));
+        HIPCHK(hipHostMalloc(&h->hInvEll2, S * h->d * 8));
+    }
     HIPCHK(hipMalloc(&h->dSlotp, S * SLOTP * 8));
     HIPCHK(hipMalloc(&h->dPartial, S * 2 * h->Nt * 8));           // per 64-block in the fine dataflow schedule
     HIPCHK(hipMalloc(&h->dRes, S * 2 * 8));
@@ -287,7 +301,9 @@ void launch_kbuild_kt(gphip_ctx* h, const KBuildArgs<T>& a, dim3 grid) {
 template <typename T>
 void launch_kbuild(gphip_ctx* h, const KBuildArgs<T>& a, dim3 grid) {
     if (h->kt == 0) launch_kbuild_kt<T, 0>(h, a, grid);
-    else launch_kbuild_kt<T, 1>(h, a, grid);
+    else if (h->kt == 1) launch_kbuild_kt<T, 1>(h, a, grid);
+    else        // general form: row and column points of both terms in LDS
+        hipLaunchKernelGGL((kbuild_kernel<T, 0, 2>), grid, dim3(256), (size_t)4 * a.d * TB * sizeof(T), h->cs, a);
 }
 
 // queue k_scale + kbuild for nslots slots (theta already staged in dInvEll / dSlotp)
@@ -306,7 +322,11 @@ int queue_build(gphip_ctx* h, int nslots) {
         hipLaunchKernelGGL(k_scale<T>, dim3(gx, nslots), dim3(256), 0, h->cs, (const T*)h->dXt, (T*)h->dXs,
                            h->dInvEll, (int)h->d, (int)h->Npad);
     }
+    if (h->nl2 > 0)
+        hipLaunchKernelGGL(k_scale<T>, dim3(gx, nslots), dim3(256), 0, h->cs, (const T*)h->dXt, (T*)h->dXs2, h->dInvEll2,
+                           (int)h->d, (int)h->Npad);
     KBuildArgs<T> a{};
+    a.ks = h->ks; a.xi2 = a.xj2 = (const T*)h->dXs2;
     a.out = (T*)h->dA; a.ld = TB; a.bstride = h->slot_elems;
     a.xi = (const T*)h->dXs; a.xj = (const T*)h->dXs; a.xi_bstride = a.xj_bstride = tot;
     a.npad_i = a.npad_j = (int)h->Npad; a.n_i = a.n_j = (int)h->N;
@@ -714,22 +734,49 @@ int queue_factor(gphip_ctx* h, int nslots) {
     return 0;
 }
 
+// the staged hyper-parameters of slots [0, nb) -> device (the launches that follow read them there)
+int copy_theta(gphip_ctx* h, int nb) {
+    HIPCHK(hipMemcpyAsync(h->dInvEll, h->hInvEll, (size_t)nb * h->d * 8, hipMemcpyHostToDevice, h->stream));
+    if (h->nl2 > 0) HIPCHK(hipMemcpyAsync(h->dInvEll2, h->hInvEll2, (size_t)nb * h->d * 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->dSlotp, h->hSlotp, (size_t)nb * SLOTP * 8, hipMemcpyHostToDevice, h->stream));
+    return GPHIP_OK;
+}
+
 // stage theta of one slot into the pinned host buffers; returns false if theta is unusable
 bool stage_theta(gphip_ctx* h, int slot, const double* th, const double* nug_row = nullptr, const double* mean_row = nullptr) {
     double* ie = h->hInvEll + (size_t)slot * h->d;
+    double* ie2 = h->nl2 > 0 ? h->hInvEll2 + (size_t)slot * h->d : nullptr;
     double* sp = h->hSlotp + (size_t)slot * SLOTP;
     bool ok = true;
     for (int i = 0; i < h->p; ++i)
         if (!std::isfinite(th[i])) ok = false;
-    for (int j = 0; j < h->d; ++j) {
-        const double l = th[h->nl == 1 ? 0 : j];
-        if (!(std::fabs(l) > 0.0) || !std::isfinite(1.0 / l)) ok = false;
-        ie[j] = ok ? 1.0 / std::fabs(l) : 1.0;
+    // theta = [term 1: l.., (alpha), sf] [term 2: l.., (alpha), sf] [c] sn [mu]; only |l| matters (l enters squared)
+    int o = 0;
+    auto lengths = [&](int nl, double* dst) {
+        for (int j = 0; j < h->d; ++j) {
+            const double l = th[o + (nl == 1 ? 0 : j)];
+            if (!(std::fabs(l) > 0.0) || !std::isfinite(1.0 / l)) ok = false;
+            dst[j] = ok ? 1.0 / std::fabs(l) : 1.0;
+        }
+        o += nl;
+    };
+    double a1 = 1.0, a2 = 1.0, sf2 = 0.0, c = 0.0;
+    lengths(h->nl, ie);
+    if (h->has_a1) { a1 = th[o++]; if (!(a1 > 0.0)) ok = false; }
+    double sf = th[o++];
+    if (h->nl2 > 0) {
+        lengths(h->nl2, ie2);
+        if (h->has_a2) { a2 = th[o++]; if (!(a2 > 0.0)) ok = false; }
+        sf2 = th[o++];
     }
-    double sf = th[h->nl], sn = th[h->nl + 1];
-    double mu = (h->mean_id == GPHIP_MEAN_CONST) ? th[h->nl + 2] : 0.0;
-    if (!ok) { sf = 1.0; sn = 1.0; mu = 0.0; }
-    sp[0] = sf * sf; sp[1] = sn * sn; sp[2] = mu;
+    if (h->ks.offset) c = th[o++];
+    double sn = th[o++];
+    double mu = (h->mean_id == GPHIP_MEAN_CONST) ? th[o++] : 0.0;
+    if (!ok) { sf = 1.0; sf2 = 1.0; sn = 1.0; mu = 0.0; a1 = a2 = 1.0; c = 0.0; }
+    const double k1 = sf * sf, k2 = sf2 * sf2;
+    const double kxx = (h->ks.op == 1 ? k1 + k2 : (h->ks.op == 2 ? k1 * k2 : k1)) + c;      // k(x, x): every family is 1 at r = 0
+    sp[0] = k1; sp[1] = sn * sn; sp[2] = mu;
+    sp[SP_SF2B] = k2; sp[SP_ALPHA1] = a1; sp[SP_ALPHA2] = a2; sp[SP_OFFSET] = c; sp[SP_KXX] = kxx;
     double nug_scale = sn * sn;
     if (nug_row) {                             // point-dependent nugget: the pivot tolerance scales with its largest value
         nug_scale = 0.0;
@@ -742,8 +789,11 @@ bool stage_theta(gphip_ctx* h, int slot, const double* th, const double* nug_row
         for (int64_t i = 0; i < h->N; ++i)
             if (!std::isfinite(mean_row[i])) ok = false;
     if (!ok) nug_scale = 1.0;
-    sp[3] = pivot_tol_rel(h) * (sf * sf + nug_scale);
-    if (!std::isfinite(sp[0]) || !std::isfinite(sp[1])) { ok = false; sp[0] = sp[1] = 1.0; sp[3] = 1e-14; }
+    sp[3] = pivot_tol_rel(h) * (std::fabs(kxx) + nug_scale);
+    if (!std::isfinite(kxx) || !std::isfinite(sp[1]) || !std::isfinite(k1) || !std::isfinite(k2)) {
+        ok = false;
+        sp[0] = sp[1] = sp[SP_KXX] = 1.0; sp[SP_SF2B] = 0.0; sp[SP_OFFSET] = 0.0; sp[3] = 1e-14;
+    }
     sp[4] = ok ? 0.0 : 1.0;
     return ok;
 }
@@ -898,15 +948,15 @@ int eval_chunk(gphip_ctx* h, const double* Theta, int nb, double* out, double* p
     }
     // few thetas: they travel as kernel arguments of the first kernel (no copies, no memset); the results
     // come back through pinned host memory written by the finalize kernel (no copies either)
-    h->theta_packed = (size_t)nb * (h->d + SLOTP) <= (size_t)THETA_PACK;
+    h->theta_packed = h->kt != 2 && (size_t)nb * (h->d + SLOTP) <= (size_t)THETA_PACK;
     if (!h->theta_packed) {
-        HIPCHK(hipMemcpyAsync(h->dInvEll, h->hInvEll, (size_t)nb * h->d * 8, hipMemcpyHostToDevice, h->stream));
-        HIPCHK(hipMemcpyAsync(h->dSlotp, h->hSlotp, (size_t)nb * SLOTP * 8, hipMemcpyHostToDevice, h->stream));
+        const int rc = copy_theta(h, nb);
+        if (rc) return rc;
         HIPCHK(hipMemsetAsync(h->dInfo, 0, (size_t)nb * 4, h->stream));
     }
     // one theta (or a few), fp64, small enough for 64-tiles and nobody needs the scaled inputs / 128-block
     // inverses afterwards: the evaluation is ONE launch
-    h->fused_eval = h->fuse_option && h->theta_packed && h->dtype == 64 && !h->want_w && h->profile < 2 &&
+    h->fused_eval = h->fuse_option && h->theta_packed && h->kt != 2 && h->dtype == 64 && !h->want_w && h->profile < 2 &&
                     !h->pw_mean_on && !h->pw_nug_on && use_dataflow(h, nb) && h->Nt <= h->dataflow_fine_nt;
     h->cs = h->stream;
     {
@@ -976,6 +1026,12 @@ int set_func_attrs(gphip_ctx* h) {
     }
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trtri128_kernel<T>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)potrf_lds<T>()));
+    if (h->kt == 2) {                          // general covariance form: both terms' row and column points in LDS
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>((kbuild_kernel<T, 0, 2>)),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * h->d * TB * sizeof(T))));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(grad_reduce_general_kernel<T>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)((4 * h->d + 1) * TB * sizeof(T))));
+    }
 #define GEMM_ATTR(ROLE)                                                                                   \
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<T, ROLE, 2, 2, 2>),             \
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS));                  \
@@ -1018,13 +1074,15 @@ int download(gphip_ctx* h, std::vector<double>& dst, const void* src, size_t n, 
 int ensure_vbuf(gphip_ctx* h, int64_t cap) {
     if (cap <= h->vcap) return GPHIP_OK;
     (void)hipFree(h->dV); (void)hipFree(h->dXsT); (void)hipFree(h->dXsS); (void)hipFree(h->dMean); (void)hipFree(h->dVar);
-    (void)hipFree(h->dPwMeanT); (void)hipFree(h->dPwNugT);
+    (void)hipFree(h->dPwMeanT); (void)hipFree(h->dPwNugT); (void)hipFree(h->dXsS2);
+    h->dXsS2 = nullptr;
     h->dV = h->dXsT = h->dXsS = nullptr;
     h->dMean = h->dVar = h->dPwMeanT = h->dPwNugT = nullptr;
     h->vcap = 0;
     HIPCHK(hipMalloc(&h->dV, (size_t)cap * h->Npad * h->es));
     HIPCHK(hipMalloc(&h->dXsT, (size_t)cap * h->d * h->es));
     HIPCHK(hipMalloc(&h->dXsS, (size_t)cap * h->d * h->es));
+    if (h->nl2 > 0) HIPCHK(hipMalloc(&h->dXsS2, (size_t)cap * h->d * h->es));
     HIPCHK(hipMalloc(&h->dMean, (size_t)cap * 8));
     HIPCHK(hipMalloc(&h->dVar, (size_t)cap * 8));
     HIPCHK(hipMalloc(&h->dPwMeanT, (size_t)cap * 8));
@@ -1095,6 +1153,9 @@ int queue_scale_train(gphip_ctx* h) {
     if (gx > 1024) gx = 1024;
     hipLaunchKernelGGL(k_scale<T>, dim3(gx, 1), dim3(256), 0, h->cs, (const T*)h->dXt, (T*)h->dXs, h->dInvEll, (int)h->d,
                        (int)h->Npad);
+    if (h->nl2 > 0)
+        hipLaunchKernelGGL(k_scale<T>, dim3(gx, 1), dim3(256), 0, h->cs, (const T*)h->dXt, (T*)h->dXs2, h->dInvEll2, (int)h->d,
+                           (int)h->Npad);
     return 0;
 }
 
@@ -1105,7 +1166,11 @@ int queue_cross(gphip_ctx* h, int64_t mc, int64_t mpad, int nslots) {
     const long tot = (long)h->d * mpad;
     hipLaunchKernelGGL(k_scale<T>, dim3((unsigned)((tot + 255) / 256), nslots), dim3(256), 0, h->stream,
                        (const T*)h->dXsT, (T*)h->dXsS, h->dInvEll, (int)h->d, (int)mpad);
+    if (h->nl2 > 0)
+        hipLaunchKernelGGL(k_scale<T>, dim3((unsigned)((tot + 255) / 256), nslots), dim3(256), 0, h->stream,
+                           (const T*)h->dXsT, (T*)h->dXsS2, h->dInvEll2, (int)h->d, (int)mpad);
     KBuildArgs<T> a{};
+    a.ks = h->ks; a.xi2 = (const T*)h->dXsS2; a.xj2 = (const T*)h->dXs2;
     a.out = (T*)h->dV; a.ld = mpad; a.bstride = (long)mpad * h->Npad;
     a.xi = (const T*)h->dXsS; a.xj = (const T*)h->dXs; a.xi_bstride = tot; a.xj_bstride = (long)h->d * h->Npad;
     a.npad_i = (int)mpad; a.npad_j = (int)h->Npad; a.n_i = (int)mc; a.n_j = (int)h->N;
@@ -1194,6 +1259,16 @@ void launch_grad_kt(gphip_ctx* h, const GradArgs<T>& a, dim3 grid) {
 #undef GR_CASE
 }
 
+template <typename T>
+void launch_grad(gphip_ctx* h, GradArgs<T>& a, dim3 grid) {
+    if (h->kt == 0) launch_grad_kt<T, 0>(h, a, grid);
+    else if (h->kt == 1) launch_grad_kt<T, 1>(h, a, grid);
+    else {
+        a.ks = h->ks; a.xs2 = (const T*)h->dXs2;
+        hipLaunchKernelGGL(grad_reduce_general_kernel<T>, grid, dim3(256), (size_t)(4 * a.d + 1) * TB * sizeof(T), h->cs, a);
+    }
+}
+
 // alpha = K^-1 r from the fitted factor (z = L^-1 r sits in the rhs row): one backward pass on a
 // 128-row scratch block whose row 0 is z
 template <typename T>
@@ -1223,8 +1298,7 @@ int queue_grad_chunk(gphip_ctx* h, int64_t c0, int64_t mc, int64_t mpad) {
     a.npad = (int)h->Npad; a.n = (int)h->N; a.c0 = (int)c0; a.mc = (int)mc; a.d = (int)h->d;
     a.slotp = h->dSlotp; a.gacc = h->dGacc;
     const dim3 grid((unsigned)(mpad / TB), (unsigned)h->Nt);
-    if (h->kt == 0) launch_grad_kt<T, 0>(h, a, grid);
-    else launch_grad_kt<T, 1>(h, a, grid);
+    launch_grad<T>(h, a, grid);
     return GPHIP_OK;
 }
 
@@ -1247,8 +1321,7 @@ int queue_grad_potri(gphip_ctx* h) {
     a.npad = (int)npad; a.n = (int)h->N; a.c0 = 0; a.mc = (int)h->N; a.d = (int)h->d; a.tri = 1;
     a.slotp = h->dSlotp; a.gacc = h->dGacc;
     const dim3 grid((unsigned)h->Nt, (unsigned)h->Nt);
-    if (h->kt == 0) launch_grad_kt<T, 0>(h, a, grid);
-    else launch_grad_kt<T, 1>(h, a, grid);
+    launch_grad<T>(h, a, grid);
     return GPHIP_OK;
 }
 
@@ -1295,7 +1368,29 @@ static int create_ctx(const void* X, const void* y, int64_t N, int64_t d, int ke
     if (!X || !y) return GPHIP_ERR_ARG;
     if (N < 1 || d < 1) return GPHIP_ERR_DIM;
     if (d > 32) return GPHIP_ERR_UNSUPPORTED;   // LDS-resident point tiles: 2*d*1 KiB <= 64 KiB
-    if (kernel_id < 0 || kernel_id > GPHIP_KERNEL_NULL) return GPHIP_ERR_ARG;
+    // kernel_id: a plain named kernel, or GPHIP_KERNEL_COMPOSE(term1, op, term2, offset)
+    struct Base { int fam; bool ard; };
+    auto base = [](int id, Base& b) {
+        switch (id) {
+            case GPHIP_KERNEL_SE: b = {0, false}; return true;
+            case GPHIP_KERNEL_SE_ARD: b = {0, true}; return true;
+            case GPHIP_KERNEL_MATERN52: b = {1, false}; return true;
+            case GPHIP_KERNEL_MATERN52_ARD: b = {1, true}; return true;
+            case GPHIP_KERNEL_MATERN32: b = {2, false}; return true;
+            case GPHIP_KERNEL_MATERN32_ARD: b = {2, true}; return true;
+            case GPHIP_KERNEL_RQ: b = {3, false}; return true;
+            case GPHIP_KERNEL_RQ_ARD: b = {3, true}; return true;
+            default: return false;
+        }
+    };
+    const bool composed = kernel_id >= (1 << 24);
+    const int id1 = composed ? (kernel_id & 0xff) : kernel_id, id2 = composed ? ((kernel_id >> 8) & 0xff) : 0;
+    const int op = composed ? ((kernel_id >> 16) & 0xf) : 0, offs = composed ? ((kernel_id >> 20) & 0xf) : 0;
+    Base b1{0, false}, b2{0, false};
+    if (kernel_id != GPHIP_KERNEL_NULL) {
+        if (kernel_id < 0 || !base(id1, b1)) return GPHIP_ERR_ARG;
+        if (op < 0 || op > 2 || offs > 1 || (op != 0 && !base(id2, b2))) return GPHIP_ERR_ARG;
+    }
     if (mean_id != GPHIP_MEAN_ZERO && mean_id != GPHIP_MEAN_CONST) return GPHIP_ERR_ARG;
     if (dtype != 64 && dtype != 32) return GPHIP_ERR_UNSUPPORTED;
     int ndevs = 0;
@@ -1312,10 +1407,20 @@ static int create_ctx(const void* X, const void* y, int64_t N, int64_t d, int ke
     h->R = h->Nt + 1;
     h->slot_elems = h->R * (h->R + 1) / 2 * TS;
     h->kernel_id = kernel_id; h->mean_id = mean_id;
-    h->kt = (kernel_id == GPHIP_KERNEL_MATERN52 || kernel_id == GPHIP_KERNEL_MATERN52_ARD) ? 1 : 0;
-    h->nl = (kernel_id == GPHIP_KERNEL_SE || kernel_id == GPHIP_KERNEL_MATERN52) ? 1
-            : (kernel_id == GPHIP_KERNEL_NULL ? 0 : (int)d);
-    h->p = (kernel_id == GPHIP_KERNEL_NULL ? 1 : h->nl + 2) + (mean_id == GPHIP_MEAN_CONST ? 1 : 0);
+    if (kernel_id == GPHIP_KERNEL_NULL) {
+        h->kt = 0; h->nl = 0;
+        h->p = 1 + (mean_id == GPHIP_MEAN_CONST ? 1 : 0);
+    } else {
+        // SE / Matern-5/2 alone keep their specialised kernels (kt 0 / 1); everything else runs the general form (kt 2)
+        h->ks = KSpec{b1.fam, b2.fam, op, offs};
+        h->kt = (op == 0 && offs == 0 && b1.fam <= 1) ? b1.fam : 2;
+        h->nl = b1.ard ? (int)d : 1;
+        h->nl2 = op != 0 ? (b2.ard ? (int)d : 1) : 0;
+        h->has_a1 = b1.fam == 3;
+        h->has_a2 = op != 0 && b2.fam == 3;
+        h->p = h->nl + (h->has_a1 ? 1 : 0) + 1 + (op != 0 ? h->nl2 + (h->has_a2 ? 1 : 0) + 1 : 0) + offs + 1 +
+               (mean_id == GPHIP_MEAN_CONST ? 1 : 0);
+    }
     const double* Xd = static_cast<const double*>(X);
     const double* yd = static_cast<const double*>(y);
     auto bail = [&](int code) { gphip_destroy(h); return code; };
@@ -1398,6 +1503,7 @@ int gphip_destroy(gphip_handle h) {
     (void)hipFree(h->dXt); (void)hipFree(h->dY); (void)hipFree(h->dExp2);
     (void)hipFree(h->dV); (void)hipFree(h->dXsT); (void)hipFree(h->dXsS); (void)hipFree(h->dMean);
     (void)hipFree(h->dVar); (void)hipFree(h->dAlpha); (void)hipFree(h->dGacc); (void)hipFree(h->dKinv);
+    (void)hipFree(h->dXsS2); (void)hipFree(h->dPwMeanT); (void)hipFree(h->dPwNugT);
     (void)hipFree(h->dNullMu); (void)hipFree(h->dNullOut); (void)hipFree(h->dPart);
     for (auto e : h->pool) (void)hipEventDestroy(e);
     for (auto e : h->sync_events) (void)hipEventDestroy(e);
@@ -1450,7 +1556,8 @@ int gphip_loglik_grad(gphip_handle h, const double* theta, int p, double* out, d
     HIPCHK(hipSetDevice(h->device));
     const int64_t N = h->N, Npad = h->Npad, d = h->d;
     if (!h->dAlpha) HIPCHK(hipMalloc(&h->dAlpha, (size_t)Npad * h->es));
-    if (!h->dGacc) HIPCHK(hipMalloc(&h->dGacc, (size_t)(d + 2) * 8));
+    const size_t ngacc = (size_t)2 * d + 6;             // general form: both terms' length scales, sf, alpha, c, sn
+    if (!h->dGacc) HIPCHK(hipMalloc(&h->dGacc, ngacc * 8));
     // potri route when U (Npad x Npad scratch) and the lower tiles of K^-1 both fit in a quarter of the HBM
     // that is free right now; otherwise K^-1 is streamed in row blocks through forward + backward substitution
     bool potri = h->grad_potri != 0;
@@ -1487,7 +1594,7 @@ int gphip_loglik_grad(gphip_handle h, const double* theta, int p, double* out, d
     h->cs = h->stream;
     rc = DISPATCH(h, queue_alpha, h);
     if (rc) return rc;
-    HIPCHK(hipMemsetAsync(h->dGacc, 0, (size_t)(d + 2) * 8, h->stream));
+    HIPCHK(hipMemsetAsync(h->dGacc, 0, ngacc * 8, h->stream));
     if (potri) {
         rc = DISPATCH(h, queue_grad_potri, h);
         if (rc) return rc;
@@ -1499,32 +1606,44 @@ int gphip_loglik_grad(gphip_handle h, const double* theta, int p, double* out, d
             if (rc) return rc;
         }
     }
-    std::vector<double> gacc((size_t)d + 2), alpha;
+    std::vector<double> gacc(ngacc), alpha;
     HIPCHK(hipMemcpyAsync(gacc.data(), h->dGacc, gacc.size() * 8, hipMemcpyDeviceToHost, h->stream));
     rc = DISPATCH(h, download, h, alpha, h->dAlpha, (size_t)N, h->stream);
     if (rc) return rc;
     HIPCHK(hipGetLastError());
     harvest(h);
-    const double sf = theta[h->nl], sn = theta[h->nl + 1];
-    if (h->nl == 1) {
-        double sum = 0.0;
-        for (int64_t j = 0; j < d; ++j) sum += gacc[(size_t)j];
-        grad[0] = 0.5 * sum / theta[0];                       // even in l: d/dl of f(l^2)
-    } else {
-        for (int64_t j = 0; j < d; ++j) grad[j] = 0.5 * gacc[(size_t)j] / theta[j];
+    // chain rule onto the theta layout [term 1: l.., (alpha), sf] [term 2] [c] sn [mu]  (accumulators: grad_reduce_*)
+    int o = 0;
+    auto lengths = [&](int nl, size_t base) {
+        if (nl == 1) {
+            double sum = 0.0;
+            for (int64_t j = 0; j < d; ++j) sum += gacc[base + (size_t)j];
+            grad[o] = 0.5 * sum / theta[o];                   // even in l: d/dl of f(l^2)
+        } else {
+            for (int64_t j = 0; j < d; ++j) grad[o + j] = 0.5 * gacc[base + (size_t)j] / theta[o + j];
+        }
+        o += nl;
+    };
+    lengths(h->nl, 0);
+    if (h->has_a1) grad[o++] = 0.5 * gacc[(size_t)2 * d + 3];
+    grad[o] = gacc[(size_t)d] / theta[o]; ++o;                // sf1: 1/2 * sum w (dk/dk1) k1 * 2/sf
+    if (h->nl2 > 0) {
+        lengths(h->nl2, (size_t)d + 2);
+        if (h->has_a2) grad[o++] = 0.5 * gacc[(size_t)2 * d + 4];
+        grad[o] = gacc[(size_t)2 * d + 2] / theta[o]; ++o;
     }
-    grad[h->nl] = gacc[(size_t)d] / sf;                       // 1/2 * sum w k * 2/sf
-    grad[h->nl + 1] = gacc[(size_t)d + 1] * sn;               // 1/2 * tr(W) * 2 sn
+    if (h->ks.offset) grad[o++] = 0.5 * gacc[(size_t)2 * d + 5];
+    grad[o] = gacc[(size_t)d + 1] * theta[o]; ++o;            // sn: 1/2 * tr(W) * 2 sn
     if (h->mean_id == GPHIP_MEAN_CONST) {
         double sum = 0.0;
         for (double v : alpha) sum += v;
-        grad[h->nl + 2] = sum;
+        grad[o++] = sum;
     }
     h->fitted = true;                                         // the factor of theta is still resident
     h->theta_fit.assign(theta, theta + p);
     h->logdet_fit = parts[0];
     h->mu_fit = h->hSlotp[2];
-    h->kappa_fit = h->hSlotp[0] + h->hSlotp[1];
+    h->kappa_fit = h->hSlotp[SP_KXX] + h->hSlotp[1];
     return GPHIP_OK;
 }
 
@@ -1564,7 +1683,7 @@ int gphip_fit(gphip_handle h, const double* theta, int p, int* info) {
     h->theta_fit.assign(theta, theta + p);
     h->logdet_fit = parts[0];
     h->mu_fit = h->hSlotp[2];
-    h->kappa_fit = h->hSlotp[0] + h->hSlotp[1];
+    h->kappa_fit = h->hSlotp[SP_KXX] + h->hSlotp[1];
     return GPHIP_OK;
 }
 
@@ -1590,8 +1709,8 @@ int gphip_covariance(gphip_handle h, const double* theta, int p, double* K) {
     if (rc) return rc;
     h->fitted = false;
     if (!stage_theta(h, 0, theta)) return fail(h, GPHIP_ERR_ARG, "non-finite or zero hyper-parameter");
-    HIPCHK(hipMemcpyAsync(h->dInvEll, h->hInvEll, (size_t)h->d * 8, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(h->dSlotp, h->hSlotp, SLOTP * 8, hipMemcpyHostToDevice, h->stream));
+    rc = copy_theta(h, 1);
+    if (rc) return rc;
     h->cs = h->stream;
     DISPATCH(h, queue_build, h, 1);
     // the lower-triangle tiles of the packed workspace (tile (ti, tj) at tile_index(ti, tj, R), column-major inside)
@@ -1626,8 +1745,8 @@ int gphip_cross_covariance(gphip_handle h, const double* theta, int p, const voi
     if (rc) return rc;
     h->fitted = false;
     if (!stage_theta(h, 0, theta)) return fail(h, GPHIP_ERR_ARG, "non-finite or zero hyper-parameter");
-    HIPCHK(hipMemcpyAsync(h->dInvEll, h->hInvEll, (size_t)d * 8, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(h->dSlotp, h->hSlotp, SLOTP * 8, hipMemcpyHostToDevice, h->stream));
+    rc = copy_theta(h, 1);
+    if (rc) return rc;
     h->cs = h->stream;
     DISPATCH(h, queue_scale_train, h);
     const double* X = static_cast<const double*>(Xs);
@@ -1651,7 +1770,7 @@ int gphip_cross_covariance(gphip_handle h, const double* theta, int p, const voi
         for (int64_t j = 0; j < N; ++j)
             for (int64_t t = 0; t < mc; ++t) k[j * M + m0 + t] = v[(size_t)j * mpad + t];
     }
-    for (int64_t t = 0; t < M; ++t) kappa[t] = h->hSlotp[0] + h->hSlotp[1];
+    for (int64_t t = 0; t < M; ++t) kappa[t] = h->hSlotp[SP_KXX] + h->hSlotp[1];
     return GPHIP_OK;
 }
 
@@ -1998,8 +2117,8 @@ int gphip_dist_begin(gphip_handle h, const double* theta, int p, int rank, int w
     h->dist_theta_ok = stage_theta(h, 0, theta, h->pw_nug_host, h->pw_mean_host);
     rc = upload_pw(h, 0, 1);                   // point-dependent nugget / mean of this evaluation, if the caller set them
     if (rc) return rc;
-    HIPCHK(hipMemcpyAsync(h->dInvEll, h->hInvEll, (size_t)h->d * 8, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(h->dSlotp, h->hSlotp, SLOTP * 8, hipMemcpyHostToDevice, h->stream));
+    rc = copy_theta(h, 1);
+    if (rc) return rc;
     HIPCHK(hipMemsetAsync(h->dInfo, 0, 4, h->stream));
     HIPCHK(hipMemsetAsync(h->dPartial, 0, (size_t)h->Nt * 8, h->stream));
     h->cs = h->stream;

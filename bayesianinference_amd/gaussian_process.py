@@ -12,7 +12,11 @@ keys and failure behaviour:
 
 Differences forced by the closed kernel set (SURVEY.md §7 "Arbitrary WL kernels vs named
 kernels"): `kernel` is a named spec ("SE", "SEARD", "Matern52", "Matern52ARD" or None for the
-null kernel BGP:25), the nugget is the constant sigma_n^2 and the mean is None / "Constant";
+null kernel BGP:25).  The nugget and the mean function may be ANY functions of the point, as in
+the reference (`nugget[points[[i]]]` BGP:37, `meanFunction /@ inputData` BGP:300): pass a callable
+f(X[N, d], theta[p]) -> values[N] (vectorised over the points; the hyper-parameters it uses are
+entries of theta) and the host evaluates it per theta and hands the values to the library
+(gphip_*_pw); "Constant" / None keep the forms sigma_n^2 and mu / 0 read from theta.
 `variables` must list the hyper-parameters in the C-ABI order (l.., sigma_f, sigma_n[, mu]).
 All arithmetic runs in the HIP library; nothing here falls back to the CPU.
 """
@@ -34,6 +38,8 @@ _KERNEL_ALIASES = {
     "matern52": "matern52", "matern5/2": "matern52",
     "matern52ard": "matern52_ard", "matern52_ard": "matern52_ard",
     "null": "null", "none": "null",
+    "matern32": "matern32", "matern3/2": "matern32", "matern32ard": "matern32_ard", "matern32_ard": "matern32_ard",
+    "rq": "rq", "rationalquadratic": "rq", "rqard": "rq_ard", "rq_ard": "rq_ard",
 }
 
 # The WL expressions that define each named kernel for the *reference* defineGaussianProcess, so
@@ -44,7 +50,27 @@ WL_KERNEL_EXPRESSIONS = {
     "matern52": "Function[{p, q}, With[{s = Sqrt[Total[(p - q)^2]]/l}, sf^2 (1 + Sqrt[5] s + 5 s^2/3) Exp[-Sqrt[5] s]]]",
     "matern52_ard": "Function[{p, q}, With[{s = Sqrt[Total[((p - q)/{l1, ..., ld})^2]]}, sf^2 (1 + Sqrt[5] s + 5 s^2/3) Exp[-Sqrt[5] s]]]",
     "null": "Function[0]",
+    "matern32": "Function[{p, q}, With[{s = Sqrt[Total[(p - q)^2]]/l}, sf^2 (1 + Sqrt[3] s) Exp[-Sqrt[3] s]]]",
+    "matern32_ard": "Function[{p, q}, With[{s = Sqrt[Total[((p - q)/{l1, ..., ld})^2]]}, sf^2 (1 + Sqrt[3] s) Exp[-Sqrt[3] s]]]",
+    "rq": "Function[{p, q}, sf^2 (1 + Total[(p - q)^2]/(2 alpha l^2))^-alpha]",
+    "rq_ard": "Function[{p, q}, sf^2 (1 + Total[((p - q)/{l1, ..., ld})^2]/(2 alpha))^-alpha]",
 }
+
+
+def wl_kernel_expression(kname: str) -> str:
+    """WL text of a named or composed kernel ('term [(+|*) term] [+const]'): what a user hands to the REFERENCE's
+    defineGaussianProcess so that "same inputs" is defined (each term with its own l / alpha / sf symbols)."""
+    if kname in WL_KERNEL_EXPRESSIONS:
+        return WL_KERNEL_EXPRESSIONS[kname]
+    key, offset = (kname[:-len("+const")], True) if kname.endswith("+const") else (kname, False)
+    for op in ("+", "*"):
+        if op in key:
+            a, b = key.split(op, 1)
+            body = f"({WL_KERNEL_EXPRESSIONS[a]})[p, q] {op} ({WL_KERNEL_EXPRESSIONS[b]})[p, q]"
+            break
+    else:
+        body = f"({WL_KERNEL_EXPRESSIONS[key]})[p, q]"
+    return "Function[{p, q}, " + ("c + " if offset else "") + body + "]"
 WL_NUGGET_EXPRESSION = "Function[sn^2]"
 
 
@@ -166,10 +192,21 @@ def _resolve_kernel(kernel):
     if kernel is None:
         return "null"
     key = str(kernel).lower().replace(" ", "").replace("-", "")
-    if key not in _KERNEL_ALIASES:
-        raise ValueError(f"kernel {kernel!r} is not one of the named kernels {sorted(set(_KERNEL_ALIASES.values()))}; "
-                         "arbitrary pure functions stay on the reference's own path")
-    return _KERNEL_ALIASES[key]
+    if key in _KERNEL_ALIASES:
+        return _KERNEL_ALIASES[key]
+    # composed forms: term [(+|*) term] [+const]  (include/gphip.h GPHIP_KERNEL_COMPOSE)
+    body, offset = (key[:-len("+const")], "+const") if key.endswith("+const") else (key, "")
+    for op in ("+", "*"):
+        if op in body:
+            a, b = body.split(op, 1)
+            if a in _KERNEL_ALIASES and b in _KERNEL_ALIASES and "null" not in (_KERNEL_ALIASES[a], _KERNEL_ALIASES[b]):
+                return _KERNEL_ALIASES[a] + op + _KERNEL_ALIASES[b] + offset
+            break
+    else:
+        if body in _KERNEL_ALIASES and _KERNEL_ALIASES[body] != "null" and offset:
+            return _KERNEL_ALIASES[body] + offset
+    raise ValueError(f"kernel {kernel!r} is not a named kernel {sorted(set(_KERNEL_ALIASES.values()))} or a composed form "
+                     "'term [(+|*) term] [+const]'; arbitrary pure functions stay on the reference's own path")
 
 
 def _log_prior_function(prior, params):
@@ -210,15 +247,33 @@ def random_domain_points(params, count=100, width=100.0, rng=None):
     return width * np.tan(clo + u * (chi - clo))
 
 
-def make_log_likelihood(handle: "_lib.Handle"):
+def _pointwise(fn, P, thetas):
+    """values of a point-dependent nugget / mean function for every theta: [B, len(P)] (None stays None)"""
+    if fn is None:
+        return None
+    rows = []
+    for th in np.atleast_2d(thetas):
+        v = np.asarray(fn(P, th), dtype=np.float64)
+        rows.append(np.broadcast_to(v, (len(P),)) if v.ndim == 0 else v.reshape(len(P)))
+    return np.ascontiguousarray(np.array(rows))
+
+
+def make_log_likelihood(handle: "_lib.Handle", nugget_fn=None, mean_fn=None, X=None):
     """The drop-in closure for "LogLikelihoodFunction" (seam at BGP:249,293-294): theta -> machine
     real, total over the parameter box, $MachineLogZero on numerical failure (BGP:298-304), never an
-    exception for bad theta values (BS:276-298)."""
+    exception for bad theta values (BS:276-298).  nugget_fn / mean_fn: point-dependent nugget[x] / meanFunction[x]
+    (callables f(X, theta) -> values[N], BGP:37, 300), evaluated here on the host for every theta."""
+    pw = nugget_fn is not None or mean_fn is not None
+
     def log_likelihood(theta):
         theta = np.asarray(theta, dtype=np.float64)
-        if theta.ndim == 2:                               # Listable use: B x p -> B (BGP:59)
-            out, info = handle.loglik_batch(theta)
-            return np.where(info == 0, np.clip(out, MACHINE_LOG_ZERO, -MACHINE_LOG_ZERO), MACHINE_LOG_ZERO)
+        if theta.ndim == 2 or pw:                         # Listable use: B x p -> B (BGP:59)
+            if pw:
+                out, info = handle.loglik_batch_pw(theta, _pointwise(mean_fn, X, theta), _pointwise(nugget_fn, X, theta))
+            else:
+                out, info = handle.loglik_batch(theta)
+            res = np.where((info == 0) & np.isfinite(out), np.clip(out, MACHINE_LOG_ZERO, -MACHINE_LOG_ZERO), MACHINE_LOG_ZERO)
+            return res if theta.ndim == 2 else float(res[0])
         ll, info = handle.loglik(theta)
         if info != 0 or not math.isfinite(ll):
             return MACHINE_LOG_ZERO
@@ -246,11 +301,13 @@ def defineGaussianProcess(data, kernel, nugget="Constant", meanFunction=None, va
     if len(X) != len(Y):                                          # BGP:251-253
         return inferenceObject(None)
     if isinstance(nugget, str) and nugget.lower() != "constant":
-        raise ValueError("only the constant nugget Function[sn^2] is supported on the HIP path")
+        raise ValueError('nugget must be "Constant" (Function[sn^2]) or a callable f(X, theta) -> variances[N]')
+    nugget_fn = nugget if callable(nugget) else None
+    mean_fn = meanFunction if callable(meanFunction) else None
     kname = _resolve_kernel(kernel)
-    mean = "zero" if meanFunction in (None, 0, "Zero", "zero") else "const"
+    mean = "zero" if (mean_fn is not None or meanFunction in (None, 0, "Zero", "zero")) else "const"
     if mean == "const" and str(meanFunction).lower() not in ("constant", "const"):
-        raise ValueError("meanFunction must be None/0 or 'Constant' on the HIP path")
+        raise ValueError("meanFunction must be None/0, 'Constant' or a callable f(X, theta) -> means[N]")
     params = [tuple(v) for v in variables]
     if not params or any(len(v) != 3 for v in params):            # paramSpecPattern, BS:19
         return inferenceObject(None)
@@ -277,22 +334,38 @@ def defineGaussianProcess(data, kernel, nugget="Constant", meanFunction=None, va
     user_ll = rules.pop("LogLikelihoodFunction", None)
     branch = "UserFunction" if callable(user_ll) else ("Automatic" if isinstance(user_ll, str) and
                                                        user_ll.lower() == "automatic" else "Default")
-    loglik = user_ll if callable(user_ll) else make_log_likelihood(handle)
+    pointwise = nugget_fn is not None or mean_fn is not None
+    loglik = user_ll if callable(user_ll) else make_log_likelihood(handle, nugget_fn, mean_fn, X)
 
     def log_likelihood_gradient(theta):
         """(value, gradient) -- extension for gradient-based MAP / Laplace routes (LA:177-238 uses
-        NMaximize without gradients); sentinel and NaN gradient on numerical failure."""
+        NMaximize without gradients); sentinel and NaN gradient on numerical failure.  Defined for the constant nugget /
+        mean forms only (the library cannot differentiate a host function of the point)."""
+        if pointwise:
+            return loglik(theta), np.full(len(params), np.nan)
         ll, grad, info = handle.loglik_grad(theta)
         return (ll, grad) if info == 0 else (MACHINE_LOG_ZERO, np.full(len(params), np.nan))
 
     def covariance_function(theta):                               # "CovarianceFunction", BGP:264-271
         K = handle.covariance(theta)                              # Listable: B x p -> B matrices (BGP:59)
+        if nugget_fn is not None:                                 # nugget[points[[i]]] on the diagonal instead of sn^2
+            th2 = np.atleast_2d(np.asarray(theta, dtype=np.float64))
+            nug = _pointwise(nugget_fn, X, th2)
+            Kb = K.reshape((len(th2),) + K.shape[-2:]).copy()
+            for b in range(len(th2)):
+                sn = th2[b, handle.p - (2 if mean == "const" else 1)]      # theta = (l.., sf, sn[, mu])
+                Kb[b][np.diag_indices(len(X))] += nug[b] - sn * sn
+            K = Kb.reshape(K.shape)
         if kname == "null":                                       # covarianceMatrix[.., nullKernel, ..] = nugget /@ points:
             return np.diagonal(K, axis1=-2, axis2=-1).copy()      # the DIAGONAL as a vector (BGP:27)
         return K
 
     def inverse_covariance_function(theta):                       # "InverseCovarianceFunction", BGP:308
-        info = handle.fit(theta)
+        if pointwise:
+            nug, mt = _pointwise(nugget_fn, X, theta), _pointwise(mean_fn, X, theta)
+            info = handle.fit_pw(theta, mt, nug)
+        else:
+            info = handle.fit(theta)
         if info != 0:
             return MACHINE_LOG_ZERO                               # Throw[$MachineLogZero, "MatInv"]
         return {"Inverse": handle.solve, "LogDet": handle.logdet()}
@@ -304,9 +377,9 @@ def defineGaussianProcess(data, kernel, nugget="Constant", meanFunction=None, va
         "KernelName": kname, "MeanName": mean, "LikelihoodBranch": branch,
         "GaussianProcessData": {
             "ModelFunctions": {
-                "KernelFunction": (kname, WL_KERNEL_EXPRESSIONS[kname]),
-                "NuggetFunction": WL_NUGGET_EXPRESSION,
-                "MeanFunction": mean,
+                "KernelFunction": (kname, wl_kernel_expression(kname)),
+                "NuggetFunction": nugget_fn if nugget_fn is not None else WL_NUGGET_EXPRESSION,
+                "MeanFunction": mean_fn if mean_fn is not None else mean,
                 "CovarianceFunction": covariance_function,
                 "InverseCovarianceFunction": inverse_covariance_function,
             },
@@ -372,7 +445,10 @@ def predictFromGaussianProcess(obj_or_examples, pts, kernel=None, theta=None, me
         samples = obj["Samples"]
         points = np.array([s["Point"] for s in samples], dtype=np.float64)
         weights = np.array([s["CrudePosteriorWeight"] for s in samples], dtype=np.float64)
-        return _predict_samples(handle, points, weights, P)
+        mf = obj["GaussianProcessData"]["ModelFunctions"]
+        nugget_fn = mf["NuggetFunction"] if callable(mf["NuggetFunction"]) else None
+        mean_fn = mf["MeanFunction"] if callable(mf["MeanFunction"]) else None
+        return _predict_samples(handle, points, weights, P, nugget_fn, mean_fn, X)
     norm = dataNormalForm(obj_or_examples)
     P = dataNormalForm(pts)
     if norm is None or not isinstance(norm, tuple) or P is None or norm[1].shape[1] != 1:
@@ -407,9 +483,14 @@ def predictiveDistribution(obj, inputs=None, estimate=None):
     return predictFromGaussianProcess(obj, inputs)
 
 
-def _predict_samples(handle, points, weights, P):
-    """One batched pass over all samples (gphip_predict_samples); singular samples -> NaN rows."""
-    mean, var, info = handle.predict_samples(points, P)
+def _predict_samples(handle, points, weights, P, nugget_fn=None, mean_fn=None, X=None):
+    """One batched pass over all samples (gphip_predict_samples); singular samples -> NaN rows.  Point-dependent
+    nugget / mean functions are evaluated per sample at the training AND the test points (BGP:113, 408)."""
+    if nugget_fn is not None or mean_fn is not None:
+        mean, var, info = handle.predict_samples_pw(points, P, _pointwise(mean_fn, X, points), _pointwise(nugget_fn, X, points),
+                                                    _pointwise(mean_fn, P, points), _pointwise(nugget_fn, P, points))
+    else:
+        mean, var, info = handle.predict_samples(points, P)
     bad = info != 0
     mean[bad], var[bad] = np.nan, np.nan
     with np.errstate(invalid="ignore"):

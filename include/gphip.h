@@ -55,6 +55,22 @@ typedef struct gphip_ctx* gphip_handle;
 #define GPHIP_KERNEL_MATERN52 2      /* sf^2 (1+sqrt5 s+5 s^2/3) exp(-sqrt5 s), s=|p-q|/l             */
 #define GPHIP_KERNEL_MATERN52_ARD 3  /* same with s = sqrt(sum ((p_j-q_j)/l_j)^2)                     */
 #define GPHIP_KERNEL_NULL 4          /* Function[0]: K = diag(sn^2) (BGP:25-27,156-159); theta=(sn[,mu]) */
+#define GPHIP_KERNEL_MATERN32 5      /* sf^2 (1 + sqrt3 s) exp(-sqrt3 s), s = |p-q|/l                  */
+#define GPHIP_KERNEL_MATERN32_ARD 6
+#define GPHIP_KERNEL_RQ 7            /* rational quadratic sf^2 (1 + r2/(2 alpha))^-alpha, r2 = |p-q|^2/l^2; theta = (l, alpha, sf, ..) */
+#define GPHIP_KERNEL_RQ_ARD 8        /* same with r2 = sum ((p_j-q_j)/l_j)^2;                  theta = (l_1..l_d, alpha, sf, ..)  */
+/* The reference takes ANY kernel[p, q] (BGP:32); its own worked example is a constant plus a squared exponential,
+ * `#2 + Exp[-(pt1 - pt2)^2/#1^2]` (BGP:16).  Composed forms of the named kernels cover that family:
+ *     k = [c +] k1   |   [c +] k1 + k2   |   [c +] k1 * k2
+ * each term with its own length scales / alpha / sf.  theta layout:
+ *     [term 1: l.., (alpha), sf] [term 2: l.., (alpha), sf] [c] sn [mu]
+ * (c = the constant offset, present when offset = 1).  Anything else stays on the reference's own path (the WL package
+ * falls back to the reference's defineGaussianProcess).  */
+#define GPHIP_OP_NONE 0
+#define GPHIP_OP_SUM 1
+#define GPHIP_OP_PRODUCT 2
+#define GPHIP_KERNEL_COMPOSE(term1, op, term2, offset) \
+    ((term1) | ((term2) << 8) | ((op) << 16) | ((offset) << 20) | (1 << 24))
 #define GPHIP_MEAN_ZERO 0            /* Function[0]  (BGP:168,255)                                    */
 #define GPHIP_MEAN_CONST 1           /* Function[mu], mu = last entry of theta                        */
 

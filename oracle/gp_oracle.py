@@ -35,7 +35,34 @@ import scipy.linalg as sla
 MACHINE_LOG_ZERO = -1.7976931348623157e308
 LOG_TWO_PI = math.log(2.0 * math.pi)          # BGP:182
 
-KERNELS = ("se", "se_ard", "matern52", "matern52_ard", "null")
+KERNELS = ("se", "se_ard", "matern52", "matern52_ard", "null", "matern32", "matern32_ard", "rq", "rq_ard")
+
+
+def parse_kernel(kernel: str):
+    """'term [(+|*) term] [+const]' -> ([term names], op in (None, '+', '*'), has_offset).  The reference takes any
+    kernel[p, q] (BGP:32; its own example is `#2 + Exp[-(pt1-pt2)^2/#1^2]`, BGP:16): sums / products of the named
+    families with an optional additive constant are the composed forms the build covers."""
+    key = kernel.replace(" ", "").lower()
+    offset = key.endswith("+const")
+    if offset:
+        key = key[:-len("+const")]
+    for op in ("+", "*"):
+        if op in key:
+            a, b = key.split(op, 1)
+            terms = [a, b]
+            break
+    else:
+        terms, op = [key], None
+    for t in terms:
+        if t not in KERNELS or (t == "null" and (len(terms) > 1 or offset)):
+            raise ValueError(kernel)
+    return terms, op, offset
+
+
+def _term_params(term: str, d: int) -> int:
+    """hyper-parameters of one term: its length scales, alpha for the rational quadratic, sf"""
+    return (1 if term in ("se", "matern52", "matern32", "rq") else d) + (1 if term.startswith("rq") else 0) + 1
+
 
 
 class MatInvFailure(Exception):
@@ -46,9 +73,9 @@ class MatInvFailure(Exception):
 # Named kernels.  theta layout: (l_1..l_nl, sigma_f, sigma_n [, mu])
 # --------------------------------------------------------------------------------------
 def n_lengthscales(kernel: str, d: int) -> int:
-    if kernel in ("se", "matern52"):
+    if kernel in ("se", "matern52", "matern32", "rq"):
         return 1
-    if kernel in ("se_ard", "matern52_ard"):
+    if kernel in ("se_ard", "matern52_ard", "matern32_ard", "rq_ard"):
         return d
     if kernel == "null":
         return 0
@@ -56,13 +83,42 @@ def n_lengthscales(kernel: str, d: int) -> int:
 
 
 def n_params(kernel: str, d: int, mean: str = "zero") -> int:
-    # null kernel: theta = (sigma_n [, mu])
-    base = 1 if kernel == "null" else n_lengthscales(kernel, d) + 2
+    # null kernel: theta = (sigma_n [, mu]); general: [term 1: l.., (alpha), sf] [term 2 ..] [c] sn [mu]
+    terms, _, offset = parse_kernel(kernel)
+    base = 1 if kernel == "null" else sum(_term_params(t, d) for t in terms) + (1 if offset else 0) + 1
     return base + (1 if mean == "const" else 0)
+
+
+def split_general(kernel: str, d: int, theta, mean: str = "zero"):
+    """theta -> ([(term, ell[d], alpha, sf), ..], op, c, sn, mu) for any kernel of the grammar of parse_kernel."""
+    theta = np.asarray(theta, dtype=np.float64)
+    terms, op, offset = parse_kernel(kernel)
+    out, o = [], 0
+    for t in terms:
+        nl = n_lengthscales(t, d)
+        ell = np.broadcast_to(theta[o:o + nl], (d,)) if nl == 1 else theta[o:o + nl]
+        o += nl
+        alpha = None
+        if t.startswith("rq"):
+            alpha = float(theta[o])
+            o += 1
+        out.append((t, np.asarray(ell, dtype=np.float64), alpha, float(theta[o])))
+        o += 1
+    c = 0.0
+    if offset:
+        c = float(theta[o])
+        o += 1
+    sn = float(theta[o])
+    o += 1
+    mu = float(theta[o]) if mean == "const" else 0.0
+    return out, op, c, sn, mu
 
 
 def split_theta(kernel: str, d: int, theta, mean: str = "zero"):
     theta = np.asarray(theta, dtype=np.float64)
+    if kernel not in ("se", "se_ard", "matern52", "matern52_ard", "null"):      # general form: callers use split_general
+        terms, _, _, sn, mu = split_general(kernel, d, theta, mean)
+        return terms[0][1], terms[0][3], sn, mu
     nl = n_lengthscales(kernel, d)
     if kernel == "null":
         ell, sf, sn = np.ones(1), 0.0, theta[0]
@@ -106,9 +162,31 @@ def _kernel_block(kernel: str, sf: float, A: np.ndarray, B: np.ndarray) -> np.nd
         s = np.sqrt(r2)
         s5 = math.sqrt(5.0) * s
         return (sf * sf) * (1.0 + s5 + (5.0 / 3.0) * r2) * np.exp(-s5)
+    if kernel in ("matern32", "matern32_ard"):
+        s3 = math.sqrt(3.0) * np.sqrt(r2)
+        return (sf * sf) * (1.0 + s3) * np.exp(-s3)
     if kernel == "null":
         return np.zeros_like(r2)
     raise ValueError(kernel)
+
+
+def general_kernel_matrix(kernel: str, theta, A: np.ndarray, B: np.ndarray, mean: str = "zero") -> np.ndarray:
+    """k(a_i, b_j) = [c +] k1 [(+|*) k2] for the composed forms (and the plain families with their own theta layout)."""
+    A = np.atleast_2d(np.asarray(A, dtype=np.float64))
+    B = np.atleast_2d(np.asarray(B, dtype=np.float64))
+    terms, op, c, _, _ = split_general(kernel, A.shape[1], theta, mean)
+    mats = []
+    for t, ell, alpha, sf in terms:
+        if t.startswith("rq"):
+            r2 = np.zeros((A.shape[0], B.shape[0]))
+            for j in range(A.shape[1]):
+                diff = A[:, j][:, None] / ell[j] - B[:, j][None, :] / ell[j]
+                r2 += diff * diff
+            mats.append((sf * sf) * np.power(1.0 + r2 / (2.0 * alpha), -alpha))
+        else:
+            mats.append(kernel_matrix(t, ell, sf, A, B))
+    K = mats[0] if op is None else (mats[0] + mats[1] if op == "+" else mats[0] * mats[1])
+    return K + c
 
 
 def covariance_matrix(kernel: str, theta, X: np.ndarray, mean: str = "zero", nugget_fn=None):
@@ -121,7 +199,10 @@ def covariance_matrix(kernel: str, theta, X: np.ndarray, mean: str = "zero", nug
     nug = np.full(X.shape[0], sn * sn) if nugget_fn is None else np.array([float(nugget_fn(x)) for x in X])
     if kernel == "null":
         return nug
-    K = kernel_matrix(kernel, ell, sf, X, X)
+    if kernel in ("se", "se_ard", "matern52", "matern52_ard"):
+        K = kernel_matrix(kernel, ell, sf, X, X)
+    else:
+        K = general_kernel_matrix(kernel, theta, X, X, mean)
     K[np.diag_indices_from(K)] += nug
     return K
 
@@ -223,6 +304,14 @@ def log_likelihood_grad(kernel: str, theta, X, y, mean: str = "zero") -> np.ndar
     X = np.atleast_2d(np.asarray(X, dtype=np.float64))
     theta = np.asarray(theta, dtype=np.float64)
     n, d = X.shape
+    if kernel not in ("se", "se_ard", "matern52", "matern52_ard"):
+        # general forms: 4th-order central differences of the oracle's own log-likelihood (small N only)
+        grad = np.zeros(len(theta))
+        for i in range(len(theta)):
+            hstep = 1e-3 * max(abs(theta[i]), 0.1)
+            f = lambda t: log_likelihood(kernel, np.concatenate([theta[:i], [theta[i] + t], theta[i + 1:]]), X, y, mean)  # noqa: E731
+            grad[i] = (-f(2 * hstep) + 8 * f(hstep) - 8 * f(-hstep) + f(-2 * hstep)) / (12 * hstep)
+        return grad
     ell, sf, sn, mu = split_theta(kernel, d, theta, mean)
     nl = n_lengthscales(kernel, d)
     K = covariance_matrix(kernel, theta, X, mean)
@@ -260,9 +349,13 @@ def k_and_kappa(kernel: str, theta, X, Xs, mean: str = "zero", nugget_fn=None):
     X = np.atleast_2d(np.asarray(X, dtype=np.float64))
     Xs = np.atleast_2d(np.asarray(Xs, dtype=np.float64))
     ell, sf, sn, _ = split_theta(kernel, X.shape[1], theta, mean)
-    k = kernel_matrix(kernel, ell, sf, X, Xs)
     nug = np.full(Xs.shape[0], sn * sn) if nugget_fn is None else np.array([float(nugget_fn(x)) for x in Xs])
-    kappa = (0.0 if kernel == "null" else sf * sf) + nug
+    if kernel in ("se", "se_ard", "matern52", "matern52_ard", "null"):
+        k = kernel_matrix(kernel, ell, sf, X, Xs)
+        kappa = (0.0 if kernel == "null" else sf * sf) + nug
+    else:
+        k = general_kernel_matrix(kernel, theta, X, Xs, mean)
+        kappa = np.array([general_kernel_matrix(kernel, theta, x[None, :], x[None, :], mean)[0, 0] for x in Xs]) + nug
     return k, kappa
 
 

@@ -167,3 +167,36 @@ def test_covariance_function_listable_and_null_kernel_vector():
     diag = nobj["GaussianProcessData", "ModelFunctions", "CovarianceFunction"]([0.7])
     np.testing.assert_allclose(diag, orc.covariance_matrix("null", [0.7], X), rtol=1e-15)
     assert diag.shape == (90,)
+
+
+def test_define_gaussian_process_with_nugget_and_mean_functions_of_the_point():
+    """The reference takes ANY nugget[x] and meanFunction[x] (BGP:37, 300, 113, 408).  Host mirror: callables
+    f(X, theta) -> values; the object's closure, covariance, inverse and mixture prediction all follow them."""
+    X, y = syn.make_dataset(180, 2)
+    variables = [("l1", 0.2, 5.0), ("l2", 0.2, 5.0), ("sf", 0.3, 3.0), ("sn", 0.05, 1.0)]
+    nugget = lambda P, th: th[3] ** 2 * (1.0 + P[:, 0] ** 2)          # noqa: E731  heteroscedastic noise
+    mean = lambda P, th: 0.2 + 0.5 * P[:, 1]                          # noqa: E731  linear mean
+    obj = gp.defineGaussianProcess((X, y), "SEARD", nugget, mean, variables, "Uniform")
+    assert not obj.failed                                             # the 100-theta smoke sweep ran through gphip_loglik_batch_pw
+    th = np.array([0.8, 1.7, 1.2, 0.3])
+    nf = lambda x: nugget(x[None, :], th)[0]                          # noqa: E731
+    mf = lambda x: mean(x[None, :], th)[0]                            # noqa: E731
+    want = orc.log_likelihood("se_ard", th, X, y, nugget_fn=nf, mean_fn=mf)
+    assert obj["LogLikelihoodFunction"](th) == pytest.approx(want, rel=1e-8)
+    batch = obj["LogLikelihoodFunction"](np.array([th, th * 1.1]))
+    assert batch.shape == (2,) and batch[0] == pytest.approx(want, rel=1e-8)
+    fns = obj["GaussianProcessData", "ModelFunctions"]
+    assert fns["NuggetFunction"] is nugget and fns["MeanFunction"] is mean
+    np.testing.assert_allclose(fns["CovarianceFunction"](th), orc.covariance_matrix("se_ard", th, X, nugget_fn=nf), rtol=1e-12)
+    inv = fns["InverseCovarianceFunction"](th)
+    K = orc.covariance_matrix("se_ard", th, X, nugget_fn=nf)
+    assert inv["LogDet"] == pytest.approx(np.linalg.slogdet(K)[1], rel=1e-9)
+    samples = [{"Point": th, "CrudePosteriorWeight": 0.6}, {"Point": th * 1.2, "CrudePosteriorWeight": 0.4}]
+    Xs = syn.make_test_points(11, 2)
+    res = gp.predictFromGaussianProcess(obj.append({"Samples": samples}), Xs)
+    for s, smp in enumerate(samples):
+        t = np.asarray(smp["Point"])
+        mo, so = orc.predict_internal("se_ard", t, X, y, Xs, nugget_fn=lambda x, t=t: nugget(x[None, :], t)[0],
+                                      mean_fn=lambda x, t=t: mean(x[None, :], t)[0])
+        np.testing.assert_allclose(res["Mean"][s], mo, rtol=1e-7, atol=1e-9)
+        np.testing.assert_allclose(res["StandardDeviation"][s], so, rtol=1e-7)

@@ -35,7 +35,15 @@ def test_kernel_names_and_wl_expressions():
     assert gp._resolve_kernel("Matern-52") == "matern52"
     with pytest.raises(ValueError):
         gp._resolve_kernel(lambda p, q: 0.0)
-    assert set(gp.WL_KERNEL_EXPRESSIONS) == {"se", "se_ard", "matern52", "matern52_ard", "null"}
+    assert set(gp.WL_KERNEL_EXPRESSIONS) == {"se", "se_ard", "matern52", "matern52_ard", "null", "matern32", "matern32_ard",
+                                             "rq", "rq_ard"}
+    # composed forms: term [(+|*) term] [+const] (the reference's own example is a constant plus an SE, BGP:16)
+    assert gp._resolve_kernel("SE + Const") == "se+const" and gp._resolve_kernel("SEARD*RQ") == "se_ard*rq"
+    assert gp._resolve_kernel("Matern32ARD+SE+const") == "matern32_ard+se+const"
+    assert gp.wl_kernel_expression("se+const").startswith("Function[{p, q}, c + (Function[{p, q}, sf^2 Exp[")
+    for bad in ("se+null", "const", "se+", "se*foo"):
+        with pytest.raises(ValueError):
+            gp._resolve_kernel(bad)
 
 
 def test_priors_and_random_domain_points():
