@@ -93,6 +93,7 @@ _SIGNATURES = {
     "gphip_get_profile": (C.c_int, [_h, C.c_int, _dp, _dp, _dp, _dp]),
     "gphip_reset_profile": (C.c_int, [_h]),
     "gphip_sync": (C.c_int, [_h]),
+    "gphip_factor_bytes": (C.c_int, [_h, C.c_int, _dp]),
     "gphip_set_streams": (C.c_int, [_h, C.c_void_p, C.c_void_p]),
     "gphip_dist_num_panels": (C.c_int, [_h, _ip]),
     "gphip_dist_panel_shape": (C.c_int, [_h, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
@@ -395,6 +396,12 @@ class Handle:
 
     def sync(self):
         self._check(self._lib.gphip_sync(self._h))
+
+    def factor_bytes(self, member: int = 0) -> float:
+        """device bytes local rank `member` holds for factor storage right now (workspace + own panels + receive buffers)"""
+        v = C.c_double(0.0)
+        self._check(self._lib.gphip_factor_bytes(self._h, member, C.byref(v)))
+        return v.value
 
     # -- multi-GPU block-cyclic Cholesky steps (driven by dist_cholesky.py) ---------------
     def set_streams(self, main_stream: int, panel_stream: int):

@@ -47,6 +47,11 @@ constexpr long TS = (long)TB * TB + GP_TILE_PAD;
 __host__ __device__ __forceinline__ long tile_index(int ti, int tj, int R) {
     return (long)tj * R - ((long)tj * (tj - 1)) / 2 + (ti - tj);
 }
+// Multi-GPU 1-D block-cyclic layout: slot of tile column tj in the per-panel tables -- outer panel tj / panel for the nt
+// matrix columns, and one extra slot (the number of outer panels) for the rhs column tj == nt, whose only tile is the corner
+__host__ __device__ __forceinline__ int panel_slot(int tj, int nt, int panel) {
+    return tj >= nt ? (nt + panel - 1) / panel : tj / panel;
+}
 constexpr int SLOTP = 16;       // doubles of per-slot scalars: [0] sf2 (term 1), [1] sn2, [2] mu, [3] pivot_tol, [4] bad_theta,
                                 // [5] sf2 of term 2, [6] alpha of term 1, [7] alpha of term 2 (rational quadratic), [8] constant
                                 // offset c, [9] k(x, x) (prior variance without the nugget)
@@ -295,6 +300,9 @@ struct KBuildArgs {
     int own_panel, own_world, own_rank;   // own_world > 0 (multi-GPU 1-D block-cyclic layout): build
                             // only tile columns whose outer panel (tj / own_panel) belongs to own_rank;
                             // the rhs x rhs corner tile belongs to rank 0
+    const long* adj;        // own_world > 0 and the rank keeps ONLY its own panels (compact storage): adj[q] = tiles to add
+                            // to the dense tile index of any tile of outer panel q (index nt_j / .. see panel_slot);
+                            // null: the dense packed layout
 };
 
 // One 128x128 tile per workgroup (4 waves).  Wave w owns 32 output columns; lane owns 2 adjacent
@@ -324,7 +332,8 @@ __global__ __launch_bounds__(256) void kbuild_kernel(KBuildArgs<T> a) {
     // column-major block
     const long ldo = (a.mode == 0) ? (long)TB : a.ld;
     T* out = a.out + (long)slot * a.bstride +
-             ((a.mode == 0) ? tile_index(ti, tj, a.nt_i) * TS : (long)tj * TB * a.ld + (long)ti * TB);
+             ((a.mode == 0) ? (tile_index(ti, tj, a.nt_i) + (a.adj ? a.adj[panel_slot(tj, a.nt_j, a.own_panel)] : 0l)) * TS
+                            : (long)tj * TB * a.ld + (long)ti * TB);
     const int r0 = 2 * lane;
 
     if (a.mode == 0 && ti == a.nt_i - 1) {      // right-hand-side block-row: row 0 = r^T, rest 0
@@ -874,13 +883,13 @@ __global__ __launch_bounds__(256) void potrf128_kernel(T* __restrict__ Abase, lo
 // prediction / gradient paths substitute with 128-blocks, so gphip_fit re-inverts once here.
 template <typename T>
 __global__ __launch_bounds__(256) void trtri128_kernel(const T* __restrict__ Abase, long bstride,
-                                                       T* __restrict__ Winv, int nt) {
+                                                       T* __restrict__ Winv, int nt, int b0 = 0) {
     extern __shared__ double lds_raw[];
     T* Ls = reinterpret_cast<T*>(lds_raw + 2);
     T* dinv = Ls + 36 * 256;
     const int tid = threadIdx.x;
     const int er = tid & 15, ec = tid >> 4;
-    const int b = blockIdx.x, slot = blockIdx.y;
+    const int b = b0 + blockIdx.x, slot = blockIdx.y;           // diagonal blocks b0, b0 + 1, ..
     constexpr long ld = TB;
     const T* Ad = Abase + (long)slot * bstride + tile_index(b, b, nt + 1) * TS;
     for (int bi = 0; bi < 8; ++bi)
@@ -924,6 +933,8 @@ struct GemmArgs {
     // a_k0 / b_k0 = tile column where the operand panel starts.  The base pointer may be shifted so that a panel kept
     // OUTSIDE the workspace (a received panel of the multi-GPU schedule) is addressed with its global tile indices.
     int c_R, a_R, b_R, a_k0, b_k0;
+    const long* c_adj; int c_adj_panel;          // C in a rank's COMPACT own-panel storage (multi-GPU): tiles to add to the dense index
+                                                 // of a tile of outer panel panel_slot(tj, c_R - 1, c_adj_panel); null: dense
     int K;                                       // multiple of GK
     int r0, r1, c0, c1;                          // tile ranges: rows [r0,r1), cols [c0,c1)
     int tri;                                     // 1: keep only tiles with ti >= tj (needs r0 >= c0)
@@ -1133,7 +1144,8 @@ __global__ __launch_bounds__(64 * NWI * NWJ, (NWI * NWJ == 4) ? 2 : 4) void gemm
     // C tile: lane holds i = i0 + y*16 + (lane&15), j = j0 + x*16 + drow(lane>>4, r)
     const long ldc = c_tiled ? (long)TB : g.ldc;
     T* Cg = g.C + (long)slot * g.c_bstride +
-            (c_tiled ? tile_index(ti, tj, g.c_R) * TS : (long)tj * TB * g.ldc + (long)ti * TB) +
+            (c_tiled ? (tile_index(ti, tj, g.c_R) + (g.c_adj ? g.c_adj[panel_slot(tj, g.c_R - 1, g.c_adj_panel)] : 0l)) * TS
+                     : (long)tj * TB * g.ldc + (long)ti * TB) +
             (long)(wj * (16 * FJ)) * ldc + wi * (16 * FI) + (lane & 15);
     const int l4 = lane >> 4;
     const int nk = (g.K - (int)koff) / GK;
@@ -1893,11 +1905,12 @@ __global__ __launch_bounds__(256) void predict_partial_kernel(const T* __restric
     const int j0 = strip * js;
     const int jn = (ncols - j0 < js) ? (ncols - j0) : js;       // columns of this strip (<= 0: nothing to add)
     V += (long)slot * v_bstride + (long)tb * TB + 2 * lane;
-    // z_j = element (Npad, j) of the slot's factor: row 0 of tile (Nt, j / 128) of the packed workspace (zR = Nt + 1)
+    // z_j = element (Npad, j) of the slot's factor: row 0 of tile (Nt, j / 128) of the packed workspace (zR = Nt + 1);
+    // zR = 0: a plain vector (the factor is spread over several devices and z was gathered while its panels streamed by)
     zbase += (long)slot * z_bstride;
     for (int j = tid; j < jn; j += 256) {
         const int gj = j0 + j;
-        zs[j] = (double)zbase[tile_index(zR - 1, gj >> 7, zR) * TS + (long)(gj & 127) * TB];
+        zs[j] = zR > 0 ? (double)zbase[tile_index(zR - 1, gj >> 7, zR) * TS + (long)(gj & 127) * TB] : (double)zbase[gj];
     }
     __syncthreads();
     double d0 = 0.0, d1 = 0.0, n0 = 0.0, n1 = 0.0;
@@ -1960,8 +1973,9 @@ __global__ void predict_finish_kernel(const double* __restrict__ part, int nstri
 // ---------------------------------------------------------------------------------------------
 // row `row` (0..127) of tile row Nt of the packed workspace (z = L^-1 r sits in row 0) -> out[j * ldo], j < npad
 template <typename T>
-__global__ void gather_rhs_row_kernel(const T* __restrict__ Abase, int R, int row, int npad, T* __restrict__ out, long ldo) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void gather_rhs_row_kernel(const T* __restrict__ Abase, int R, int row, int npad, T* __restrict__ out, long ldo,
+                                      int j_first = 0) {
+    const int j = j_first + blockIdx.x * blockDim.x + threadIdx.x;        // columns [j_first, npad)
     if (j < npad) out[(long)j * ldo] = Abase[tile_index(R - 1, j >> 7, R) * TS + (long)(j & 127) * TB + row];
 }
 

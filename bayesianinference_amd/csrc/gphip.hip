@@ -88,6 +88,7 @@ struct gphip_ctx {
     int la_main = 0;                             // 1: look-ahead update LA(k) on the main stream ahead of REST(k) (measured slower: 189.4 vs 186.2 ms)
     int panel_wide = 1;                          // wider outer panels while the trailing matrix is large (queue_factor)
     int thin_tiles = 1;                          // gemm_nt: skip the zero rows of the rhs block-row and the unread upper quadrant of diagonal tiles
+    int debug_fail_alloc = 0;                    // tests: make the n-th device allocation of the next slot (re)allocation fail
     int dataflow_tail = 64;                      // large N: the last <= dataflow_tail tile columns go to the dataflow kernel (0 = off)
     bool fused_eval = false;                     // eval_chunk: the whole evaluation is ONE dataflow launch (build + factor + results)
     bool theta_packed = false;                   // eval_chunk: hyper-parameters travel as kernel arguments (k_scale_theta)
@@ -122,8 +123,22 @@ struct gphip_ctx {
     hipStream_t cstream = nullptr;               // communication stream (panel broadcasts), group members only
     void* packed[3] = {nullptr, nullptr, nullptr};   // rotating packed-panel buffers, group members only
     size_t packed_bytes = 0;
-    double* dScal = nullptr;                     // 4 doubles for the scalar all-reduce (multi-process groups)
+    double* dScal8 = nullptr;                    // 8 doubles for the scalar all-reduces (multi-process groups)
+    int fit_rank = 0, fit_world = 0;             // the layout a distributed fit was made in
     bool in_group_call = false;                  // set on a member while the group handle runs a sharded call on it
+    // Sharded evaluation (gphip_dist_*): where this rank keeps ITS outer panels.  replicate_factor = 0 (default): a
+    // compact buffer holding only the owned panels (+ the corner tile on rank 0) -- memory per rank ~ 1 / world of the
+    // workspace; 1: the dense workspace dA (every received panel is received in place: all ranks end up with all of L).
+    int replicate_factor = 0;
+    void* dOwn = nullptr;                        // typed compact own-panel storage
+    size_t own_bytes = 0;
+    void* dist_base = nullptr;                   // dOwn or dA: base of the storage the current sharded evaluation runs in
+    std::vector<long> dist_adj;                  // [nouter + 1] tiles to add to a dense tile index of panel slot q (owned slots)
+    long* dDistAdj = nullptr;                    // device copy; null while every entry is 0 (dense)
+    int lay_rank = -1, lay_world = 0, lay_panel = 0, lay_full = -1;   // what dist_adj / dOwn were laid out for
+    void* ws_override = nullptr;                 // tl<T>() / queue_panel address this base instead of dA (one owned panel)
+    bool dist_fit = false;                       // the factor of theta_fit is spread over the ranks (owned panels only)
+    void* dZ = nullptr;                          // typed [Npad]: z = L^-1 r gathered while the panels stream by (sharded prediction)
     bool null_fit = false;                       // fitted state of a null-kernel handle (no factor: K = diag(sn^2))
     // Point-dependent nugget / mean of the CURRENT call (gphip_*_pw, BGP:37, 113, 300, 408): host rows [B][N] (training
     // points) and [S][M] (test points), null = the constant forms; device copies per workspace slot / prediction chunk
@@ -135,6 +150,7 @@ struct gphip_ctx {
     bool pw_mean_on = false, pw_nug_on = false;  // queue_build reads the device copies
     double *dPwMeanT = nullptr, *dPwNugT = nullptr;   // [vcap] test-point values of the current prediction chunk
     std::vector<double> null_diag, null_mean_test;    // fitted null kernel with a point-dependent nugget: the diagonal
+    std::vector<double> fit_pw_mean, fit_pw_nug;      // the point-dependent arrays a DISTRIBUTED fit was made with (local refit)
 };
 
 namespace {
@@ -230,6 +246,7 @@ void free_slots(gphip_ctx* h) {
     h->hInfo = nullptr;
     h->slots = 0;
     h->fitted = false;
+    h->dist_fit = false;                       // (a distributed fit keeps its block inverses / scalars in these buffers)
 }
 
 size_t slot_bytes(const gphip_ctx* h) {
@@ -237,43 +254,68 @@ size_t slot_bytes(const gphip_ctx* h) {
            (size_t)h->Nt * 16 + (size_t)(2 * h->Nt + 1) * (2 * h->Nt + 1) * 4 + 4096;
 }
 
-int ensure_slots(gphip_ctx* h, int want) {
-    if (want <= h->slots) return GPHIP_OK;
+// workspace = false (sharded evaluations of a rank that keeps only its own panels): everything a slot needs EXCEPT the
+// workspace matrix itself (scaled inputs, block inverses, scalars, flags)
+int ensure_slots(gphip_ctx* h, int want, bool workspace = true) {
+    if (want <= h->slots && (h->dA || !workspace)) return GPHIP_OK;
     size_t fr = 0, tot = 0;
     HIPCHK(hipMemGetInfo(&fr, &tot));
-    fr += (size_t)h->slots * slot_bytes(h);               // what we are about to give back
-    int fit = (int)((double)fr * 0.85 / (double)slot_bytes(h));
+    const size_t per_slot = slot_bytes(h) - (workspace ? 0 : (size_t)h->slot_elems * h->es);
+    fr += (size_t)h->slots * (slot_bytes(h) - (h->dA ? 0 : (size_t)h->slot_elems * h->es));   // what we are about to give back
+    int fit = (int)((double)fr * 0.85 / (double)per_slot);
     if (fit < 1) return fail(h, GPHIP_ERR_HIP, "not enough device memory for one workspace matrix");
     if (want > fit) want = fit;
     if (want > h->max_slots) want = h->max_slots;
-    if (want <= h->slots) return GPHIP_OK;
+    if (want <= h->slots && (h->dA || !workspace)) return GPHIP_OK;
+    if (want < h->slots) want = h->slots;                 // (adding the workspace to existing small slots)
     free_slots(h);
     const size_t S = (size_t)want;
-    HIPCHK(hipMalloc(&h->dA, S * (size_t)h->slot_elems * h->es));
-    HIPCHK(hipMalloc(&h->dXs, S * h->d * h->Npad * h->es));
-    HIPCHK(hipMalloc(&h->dW, S * h->Nt * TB * TB * h->es));
-    HIPCHK(hipMalloc(&h->dInvEll, S * h->d * 8));
+    // Any failure below rolls back to the consistent ZERO-slot state (everything freed, slots = 0): the handle stays
+    // usable and the next call simply allocates again (scripts/gpu_api_fuzz.py drives this to out-of-memory).
+    hipError_t e = hipSuccess;
+    const char* what = "";
+    auto dev = [&](void** p, size_t bytes, const char* name) {
+        if (e != hipSuccess) return;
+        if (h->debug_fail_alloc > 0 && --h->debug_fail_alloc == 0) { e = hipErrorOutOfMemory; what = name; return; }   // fault injection (tests)
+        if ((e = hipMalloc(p, bytes)) != hipSuccess) what = name;
+    };
+    auto host = [&](void** p, size_t bytes, const char* name) {
+        if (e == hipSuccess && (e = hipHostMalloc(p, bytes)) != hipSuccess) what = name;
+    };
+    const size_t nflags = S * (size_t)(2 * h->Nt + 1) * (size_t)(2 * h->Nt + 1) * 4;
+    if (workspace) dev(&h->dA, S * (size_t)h->slot_elems * h->es, "workspace");
+    dev(&h->dXs, S * h->d * h->Npad * h->es, "scaled inputs");
+    dev(&h->dW, S * h->Nt * TB * TB * h->es, "block inverses");
+    dev((void**)&h->dInvEll, S * h->d * 8, "inverse length scales");
     if (h->nl2 > 0) {                          // second term of a sum / product kernel: its own scaled copy of the inputs
-        HIPCHK(hipMalloc(&h->dXs2, S * h->d * h->Npad * h->es));
-        HIPCHK(hipMalloc(&h->dInvEll2, S * h->d * 8));
-        HIPCHK(hipHostMalloc(&h->hInvEll2, S * h->d * 8));
+        dev(&h->dXs2, S * h->d * h->Npad * h->es, "scaled inputs (term 2)");
+        dev((void**)&h->dInvEll2, S * h->d * 8, "inverse length scales (term 2)");
+        host((void**)&h->hInvEll2, S * h->d * 8, "pinned inverse length scales (term 2)");
     }
-    HIPCHK(hipMalloc(&h->dSlotp, S * SLOTP * 8));
-    HIPCHK(hipMalloc(&h->dPartial, S * 2 * h->Nt * 8));           // per 64-block in the fine dataflow schedule
-    HIPCHK(hipMalloc(&h->dRes, S * 2 * 8));
-    HIPCHK(hipMalloc(&h->dInfo, S * 4));
-    HIPCHK(hipMalloc(&h->dFlags, S * (2 * h->Nt + 1) * (2 * h->Nt + 1) * 4));
+    dev((void**)&h->dSlotp, S * SLOTP * 8, "slot scalars");
+    dev((void**)&h->dPartial, S * 2 * h->Nt * 8, "log-det partials");     // per 64-block in the fine dataflow schedule
+    dev((void**)&h->dRes, S * 2 * 8, "results");
+    dev((void**)&h->dInfo, S * 4, "info words");
+    dev((void**)&h->dFlags, nflags, "dependency flags");
+    dev((void**)&h->dTicket, 16, "ticket counter");
+    host((void**)&h->hInvEll, S * h->d * 8, "pinned inverse length scales");
+    host((void**)&h->hSlotp, S * SLOTP * 8, "pinned slot scalars");
+    host((void**)&h->hRes, S * 2 * 8, "pinned results");
+    host((void**)&h->hInfo, (S + 1) * 4, "pinned info words");            // + the dataflow abort flag
     // ON THE HANDLE'S STREAM: the handle's streams are non-blocking, so a null-stream hipMemset is not ordered before
     // the kernels queued next -- a dataflow task could read a recycled allocation's stale flags (another handle's epoch
     // numbers) or tickets before the clear landed.  Found by scripts/gpu_api_fuzz.py (wrong likelihood / memory fault
     // right after a batch grew the slot count), present since round 1.
-    HIPCHK(hipMemsetAsync(h->dFlags, 0, S * (2 * h->Nt + 1) * (2 * h->Nt + 1) * 4, h->stream));
-    HIPCHK(hipMalloc(&h->dTicket, 16));
-    HIPCHK(hipMemsetAsync(h->dTicket, 0, 16, h->stream));
-    HIPCHK(hipHostMalloc(&h->hInvEll, S * h->d * 8));
-    HIPCHK(hipHostMalloc(&h->hSlotp, S * SLOTP * 8));
-    HIPCHK(hipHostMalloc(&h->hRes, S * 2 * 8));
-    HIPCHK(hipHostMalloc(&h->hInfo, (S + 1) * 4));          // + the dataflow abort flag
+    if (e == hipSuccess && (e = hipMemsetAsync(h->dFlags, 0, nflags, h->stream)) != hipSuccess) what = "flag clear";
+    if (e == hipSuccess && (e = hipMemsetAsync(h->dTicket, 0, 16, h->stream)) != hipSuccess) what = "ticket clear";
+    if (e != hipSuccess) {
+        (void)hipGetLastError();               // (clear the sticky out-of-memory status)
+        free_slots(h);
+        char buf[256];
+        snprintf(buf, sizeof buf, "allocating %d workspace slot(s) failed at '%s': %s", want, what, hipGetErrorString(e));
+        h->err = buf;
+        return GPHIP_ERR_HIP;
+    }
     h->slots = want;
     return GPHIP_OK;
 }
@@ -333,6 +375,7 @@ int queue_build(gphip_ctx* h, int nslots) {
     a.y = (const T*)h->dY; a.slotp = h->dSlotp; a.d = (int)h->d; a.mode = 0; a.exp2tab = h->dExp2;
     a.nt_i = (int)h->Nt + 1; a.nt_j = (int)h->Nt;
     a.own_panel = h->panel; a.own_world = h->dist_world; a.own_rank = h->dist_rank;
+    if (h->dist_world > 0) { a.out = (T*)h->dist_base; a.adj = h->dDistAdj; }     // sharded evaluation: this rank's own storage
     a.pw_nug = h->pw_nug_on ? (const T*)h->dPwNug : nullptr;
     a.pw_mean = h->pw_mean_on ? (const T*)h->dPwMean : nullptr;
     a.pw_bstride = h->Npad;
@@ -349,12 +392,13 @@ int queue_build(gphip_ctx* h, int nslots) {
 template <typename T>
 struct Opnd {
     const T* p; long ld; long bs; int R; int k0;
+    const long* adj = nullptr; int adj_panel = 0;      // C only: compact own-panel storage of a rank (GemmArgs::c_adj)
 };
 template <typename T>
 Opnd<T> cm(const T* p, long ld, long bs) { return Opnd<T>{p, ld, bs, 0, 0}; }
 template <typename T>
 Opnd<T> tl(const gphip_ctx* h, int k0 = 0, bool all_slots = true) {
-    return Opnd<T>{(const T*)h->dA, TB, all_slots ? (long)h->slot_elems : 0l, (int)h->R, k0};
+    return Opnd<T>{(const T*)(h->ws_override ? h->ws_override : h->dA), TB, all_slots ? (long)h->slot_elems : 0l, (int)h->R, k0};
 }
 
 template <typename T>
@@ -372,6 +416,7 @@ void launch_gemm(gphip_ctx* h, int cls, Opnd<T> Co, Opnd<T> Ao, Opnd<T> Bo, int 
     g.thin_row = h->thin_tiles ? thin_row : -1;
     g.skip_upper = (h->thin_tiles && thin_row >= 0 && tri && mode == 0 && !ktri) ? 1 : 0;
     g.C = const_cast<T*>(Co.p); g.ldc = Co.ld; g.c_bstride = Co.bs; g.c_R = Co.R;
+    g.c_adj = Co.adj; g.c_adj_panel = Co.adj_panel;
     g.A = Ao.p; g.lda = Ao.ld; g.a_bstride = Ao.bs; g.a_R = Ao.R; g.a_k0 = Ao.k0;
     g.B = Bo.p; g.ldb = Bo.ld; g.b_bstride = Bo.bs; g.b_R = Bo.R; g.b_k0 = Bo.k0;
     g.K = K; g.r0 = r0; g.r1 = r1; g.c0 = c0; g.c1 = c1; g.tri = tri;
@@ -450,8 +495,8 @@ void launch_gemm(gphip_ctx* h, int cls, Opnd<T> Co, Opnd<T> Ao, Opnd<T> Bo, int 
 
 hipEvent_t sync_event(gphip_ctx* h) {       // untimed events for cross-stream ordering
     if (h->sync_used == h->sync_events.size()) {
-        hipEvent_t e;
-        (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
+        hipEvent_t e = nullptr;
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;   // (recording it then fails loudly)
         h->sync_events.push_back(e);
     }
     return h->sync_events[h->sync_used++];
@@ -465,7 +510,7 @@ template <typename T>
 int queue_panel(gphip_ctx* h, int K0, int nin, int nslots) {
     const int Nt = (int)h->Nt, R = Nt + 1;
     const long bs = h->slot_elems, lrs = (long)Nt * TB * TB;
-    T* A = (T*)h->dA;
+    T* A = (T*)(h->ws_override ? h->ws_override : h->dA);
     T* W = (T*)h->dW;
     // In-panel updates: right-looking (after column b, K = 128 onto every remaining column of the panel: few,
     // wide launches -- shortest chain for one theta) or left-looking (before column b, ONE update of that
@@ -643,12 +688,12 @@ int queue_factor(gphip_ctx* h, int nslots) {
     } else {
         h->sync_used = 0;
         hipEvent_t built = sync_event(h);
-        (void)hipEventRecord(built, h->stream);
-        (void)hipStreamWaitEvent(h->pstream, built, 0);
+        HIPCHK(hipEventRecord(built, h->stream));
+        HIPCHK(hipStreamWaitEvent(h->pstream, built, 0));
         h->cs = h->pstream;
         queue_panel<T>(h, 0, k0(1), nslots);
         hipEvent_t ev_panel = sync_event(h);
-        (void)hipEventRecord(ev_panel, h->pstream);
+        HIPCHK(hipEventRecord(ev_panel, h->pstream));
         hipEvent_t ev_rest = nullptr, ev_rest2 = nullptr;
         // tail: once only `dataflow_tail` tile columns are left the dataflow kernel finishes the job in one
         // launch -- the last panels are chain bound, the regime the dataflow schedule wins
@@ -660,8 +705,8 @@ int queue_factor(gphip_ctx* h, int nslots) {
             hipEvent_t ev_next = nullptr;
             if (k + 1 == kc) {                  // last multi-kernel panel: apply it to everything, then cut over
                 h->cs = h->stream;
-                (void)hipStreamWaitEvent(h->stream, ev_panel, 0);
-                if (ev_rest2) (void)hipStreamWaitEvent(h->stream, ev_rest2, 0);
+                HIPCHK(hipStreamWaitEvent(h->stream, ev_panel, 0));
+                if (ev_rest2) HIPCHK(hipStreamWaitEvent(h->stream, ev_rest2, 0));
                 trailing(k, k0(k + 1), R, 4);
                 const int rem = Nt - k0(kc);                       // tile columns left
                 if constexpr (sizeof(T) == 8) {
@@ -683,45 +728,45 @@ int queue_factor(gphip_ctx* h, int nslots) {
                 // SLOWER (186.2 -> 189.4 ms): run back to back, LA(k) and REST(k) each pay their own partial last wave
                 // of workgroups; run together they fill each other's tails.
                 h->cs = h->stream;
-                (void)hipStreamWaitEvent(h->stream, ev_panel, 0);
+                HIPCHK(hipStreamWaitEvent(h->stream, ev_panel, 0));
                 trailing(k, k0(k + 1), k0(k + 2), 4);                          // LA(k)
                 hipEvent_t ev_la = sync_event(h);
-                (void)hipEventRecord(ev_la, h->stream);
+                HIPCHK(hipEventRecord(ev_la, h->stream));
                 h->cs = h->pstream;
-                (void)hipStreamWaitEvent(h->pstream, ev_la, 0);
+                HIPCHK(hipStreamWaitEvent(h->pstream, ev_la, 0));
                 queue_panel<T>(h, k0(k + 1), k0(k + 2) - k0(k + 1), nslots);    // factor panel k+1
                 ev_next = sync_event(h);
-                (void)hipEventRecord(ev_next, h->pstream);
+                HIPCHK(hipEventRecord(ev_next, h->pstream));
             } else if (k + 1 < nouter) {
                 h->cs = h->pstream;
-                if (ev_rest) (void)hipStreamWaitEvent(h->pstream, ev_rest, 0);
-                if (ev_rest2) (void)hipStreamWaitEvent(h->pstream, ev_rest2, 0);
+                if (ev_rest) HIPCHK(hipStreamWaitEvent(h->pstream, ev_rest, 0));
+                if (ev_rest2) HIPCHK(hipStreamWaitEvent(h->pstream, ev_rest2, 0));
                 trailing(k, k0(k + 1), k0(k + 2), 3);                          // LA(k)
                 queue_panel<T>(h, k0(k + 1), k0(k + 2) - k0(k + 1), nslots);    // factor panel k+1
                 ev_next = sync_event(h);
-                (void)hipEventRecord(ev_next, h->pstream);
+                HIPCHK(hipEventRecord(ev_next, h->pstream));
             }
             if (split && k0(k + 2) % 2 == 0) {
                 h->cs = h->stream2;
-                (void)hipStreamWaitEvent(h->stream2, ev_panel, 0);
+                HIPCHK(hipStreamWaitEvent(h->stream2, ev_panel, 0));
                 trailing_half(k, k0(k + 2), 1);                                // REST(k), odd groups
                 ev_rest2 = sync_event(h);
-                (void)hipEventRecord(ev_rest2, h->stream2);
+                HIPCHK(hipEventRecord(ev_rest2, h->stream2));
                 h->cs = h->stream;
-                (void)hipStreamWaitEvent(h->stream, ev_panel, 0);
+                HIPCHK(hipStreamWaitEvent(h->stream, ev_panel, 0));
                 trailing_half(k, k0(k + 2), 0);                                // REST(k), even groups
             } else {
                 h->cs = h->stream;
-                (void)hipStreamWaitEvent(h->stream, ev_panel, 0);
-                if (ev_rest2) (void)hipStreamWaitEvent(h->stream, ev_rest2, 0);
+                HIPCHK(hipStreamWaitEvent(h->stream, ev_panel, 0));
+                if (ev_rest2) HIPCHK(hipStreamWaitEvent(h->stream, ev_rest2, 0));
                 trailing(k, k0(k + 2), R, 4);                                  // REST(k)
             }
             ev_rest = sync_event(h);
-            (void)hipEventRecord(ev_rest, h->stream);
+            HIPCHK(hipEventRecord(ev_rest, h->stream));
             ev_panel = ev_next;
         }
         h->cs = h->stream;
-        if (ev_rest2) (void)hipStreamWaitEvent(h->stream, ev_rest2, 0);
+        if (ev_rest2) HIPCHK(hipStreamWaitEvent(h->stream, ev_rest2, 0));
     }
     if (tail_k0 >= 0) {
         launch_finalize<T>(h, nslots, tail_k0, Nt, tail_part, tail_n);
@@ -1091,6 +1136,28 @@ int ensure_vbuf(gphip_ctx* h, int64_t cap) {
     return GPHIP_OK;
 }
 
+// One outer panel [k0, k1) of the forward substitution below: solve its tile columns, update the rest of the panel after
+// each, then update everything right of the panel ONCE with K = 128 (k1 - k0).  L is read through tl<T>() -- the dense
+// workspace, or (sharded prediction) whatever buffer currently holds this panel (ws_override).
+template <typename T>
+int queue_forward_panel(gphip_ctx* h, int64_t mpad, int nslots, int k0, int k1, int b_start, bool identity_rows) {
+    const int Nt = (int)h->Nt, Mt = (int)(mpad / TB);
+    const long vs = (long)mpad * h->Npad, lrs = (long)Nt * TB * TB;
+    T *V = (T*)h->dV, *W = (T*)h->dW;
+    auto rows_at = [&](int b) { return identity_rows ? std::min(Mt, b - b_start + 1) : Mt; };
+    for (int b = k0; b < k1; ++b) {
+        launch_gemm<T>(h, 2, cm<T>(V, mpad, vs), cm<T>(V + (long)b * TB * mpad, mpad, vs),
+                       cm<T>(W + (long)b * TB * TB - (long)b * TB, TB, lrs), TB, 0, rows_at(b), b, b + 1, 0, nslots, 1);
+        if (b + 1 < k1)
+            launch_gemm<T>(h, 3, cm<T>(V, mpad, vs), cm<T>(V + (long)b * TB * mpad, mpad, vs), tl<T>(h, b), TB, 0, rows_at(b),
+                           b + 1, k1, 0, nslots);
+    }
+    if (k1 < Nt)
+        launch_gemm<T>(h, 3, cm<T>(V, mpad, vs), cm<T>(V + (long)k0 * TB * mpad, mpad, vs), tl<T>(h, k0), (k1 - k0) * TB, 0,
+                       rows_at(k1 - 1), k1, Nt, 0, nslots);
+    return 0;
+}
+
 // V <- V L^-T for the mpad x Npad row block in dV (right-looking over the 128-tile columns of L):
 // every row of V becomes (L^-1 v)^T.  Panel solves and updates are the same MFMA GEMM kernel.
 template <typename T>
@@ -1104,22 +1171,8 @@ int queue_forward_rows(gphip_ctx* h, int64_t mpad, int nslots, int b_start = 0, 
     // many rows (prediction of thousands of test points, K^-1 for the gradient): every pass over the columns right of a
     // panel reads and writes all of V there, so wider panels pay (cfg 5, M = 10 000: 374 -> 359 ms from 4 to 12 tiles)
     const int Nt = (int)h->Nt, Mt = (int)(mpad / TB), P = (Mt >= 8 && h->panel_wide) ? std::max(h->panel, 12) : h->panel;
-    const long vs = (long)mpad * h->Npad, lrs = (long)Nt * TB * TB;
-    T *V = (T*)h->dV, *W = (T*)h->dW;
-    auto rows_at = [&](int b) { return identity_rows ? std::min(Mt, b - b_start + 1) : Mt; };
-    for (int k0 = b_start; k0 < Nt; k0 += P) {   // b_start > 0: the rows are known to be zero left of tile column b_start
-        const int k1 = (k0 + P < Nt) ? k0 + P : Nt;
-        for (int b = k0; b < k1; ++b) {
-            launch_gemm<T>(h, 2, cm<T>(V, mpad, vs), cm<T>(V + (long)b * TB * mpad, mpad, vs),
-                           cm<T>(W + (long)b * TB * TB - (long)b * TB, TB, lrs), TB, 0, rows_at(b), b, b + 1, 0, nslots, 1);
-            if (b + 1 < k1)
-                launch_gemm<T>(h, 3, cm<T>(V, mpad, vs), cm<T>(V + (long)b * TB * mpad, mpad, vs), tl<T>(h, b), TB, 0, rows_at(b),
-                               b + 1, k1, 0, nslots);
-        }
-        if (k1 < Nt)
-            launch_gemm<T>(h, 3, cm<T>(V, mpad, vs), cm<T>(V + (long)k0 * TB * mpad, mpad, vs), tl<T>(h, k0), (k1 - k0) * TB, 0,
-                           rows_at(k1 - 1), k1, Nt, 0, nslots);
-    }
+    for (int k0 = b_start; k0 < Nt; k0 += P)     // b_start > 0: the rows are known to be zero left of tile column b_start
+        queue_forward_panel<T>(h, mpad, nslots, k0, std::min(k0 + P, Nt), b_start, identity_rows);
     return 0;
 }
 
@@ -1218,7 +1271,8 @@ int queue_predict_reduce(gphip_ctx* h, int64_t mc, int64_t mpad, int nslots) {
         ProfScope ps(h, 6, 4.0 * (double)mpad * h->Npad * nslots, (double)sizeof(T) * mpad * h->Npad * nslots);
         hipLaunchKernelGGL(predict_partial_kernel<T>, dim3((unsigned)Mt, (unsigned)nstrips, (unsigned)nslots), dim3(256),
                            (size_t)js * 8 + 8 * TB * 8, h->stream, (const T*)h->dV, (long)mpad, (long)mpad * h->Npad, (int)h->N,
-                           (const T*)h->dA, (int)h->R, (long)h->slot_elems, js, h->dPart, nstrips);
+                           h->dist_fit ? (const T*)h->dZ : (const T*)h->dA, h->dist_fit ? 0 : (int)h->R, (long)h->slot_elems, js,
+                           h->dPart, nstrips);
         hipLaunchKernelGGL(predict_finish_kernel, dim3((unsigned)((mc + 255) / 256), (unsigned)nslots), dim3(256), 0, h->stream,
                            (const double*)h->dPart, nstrips, (long)mpad, (const double*)h->dSlotp, (int)mc, (long)mpad,
                            h->dMean, h->dVar, h->pw_mean_test ? (const double*)h->dPwMeanT : nullptr,
@@ -1233,15 +1287,20 @@ int queue_dist_update(gphip_ctx* h, const void* packed, long K0, long rows, long
     // the packed panel is the panel's own contiguous range of the tile-major workspace: shifted base, global tile indices
     (void)rows;
     Opnd<T> pk{(const T*)packed - tile_index((int)K0, (int)K0, (int)h->R) * TS, TB, 0, (int)h->R, (int)K0};
-    launch_gemm<T>(h, cls, tl<T>(h, 0, false), pk, pk, (int)cols, c_lo, (int)h->Nt + 1, c_lo, c_hi, 1, 1, 0, 0, (int)h->Nt, groups,
+    // C = this rank's own panels: the dense workspace, or its compact own-panel storage addressed through the adj table
+    Opnd<T> co{(const T*)h->dist_base, TB, 0, (int)h->R, 0};
+    co.adj = h->dDistAdj; co.adj_panel = h->panel;
+    launch_gemm<T>(h, cls, co, pk, pk, (int)cols, c_lo, (int)h->Nt + 1, c_lo, c_hi, 1, 1, 0, 0, (int)h->Nt, groups,
                    grp_stride, h->panel);
     return 0;
 }
 
 template <typename T>
-int queue_finalize(gphip_ctx* h) {
-    hipLaunchKernelGGL(finalize_kernel<T>, dim3(1), dim3(64), 0, h->stream, (const T*)h->dA, (long)h->slot_elems,
-                       (long)(h->slot_elems - TS), h->dPartial, (int)h->Nt, h->dRes);
+int queue_finalize(gphip_ctx* h) {         // sharded evaluation: the corner tile lives in rank 0's storage (slot nouter)
+    const int nouter = (int)((h->Nt + h->panel - 1) / h->panel);
+    const long corner = h->dist_rank == 0 ? (h->dist_adj[(size_t)nouter] + tile_index((int)h->Nt, (int)h->Nt, (int)h->R)) * TS : 0l;
+    hipLaunchKernelGGL(finalize_kernel<T>, dim3(1), dim3(64), 0, h->stream, (const T*)h->dist_base, 0l, corner, h->dPartial,
+                       (int)h->Nt, h->dRes);
     return 0;
 }
 
@@ -1326,6 +1385,70 @@ int queue_grad_potri(gphip_ctx* h) {
 }
 
 void apply_env_options(gphip_ctx* h);        // GPHIP_OPTIONS, defined next to gphip_set_option
+
+// tiles of outer panel k (its contiguous range of the packed layout) and the dense index of its first tile
+long dist_panel_tiles(const gphip_ctx* h, int k) {
+    const int K0 = k * h->panel, K1 = (int)std::min<int64_t>(K0 + h->panel, h->Nt);
+    return tile_index(K1, K1, (int)h->R) - tile_index(K0, K0, (int)h->R);
+}
+long dist_panel_first(const gphip_ctx* h, int k) { return tile_index(k * h->panel, k * h->panel, (int)h->R); }
+
+// Lay out where this rank keeps its panels for (rank, world, panel width): compact own-panel storage, or the dense
+// workspace when the factor is to be replicated.  dist_adj[q] = (local tile offset of slot q) - (its dense tile index).
+int dist_layout(gphip_ctx* h, int rank, int world, bool full) {
+    const int nouter = (int)((h->Nt + h->panel - 1) / h->panel);
+    if (h->lay_rank == rank && h->lay_world == world && h->lay_panel == h->panel && h->lay_full == (int)full &&
+        (full ? h->dA != nullptr : h->dOwn != nullptr)) {
+        h->dist_base = full ? h->dA : h->dOwn;
+        return GPHIP_OK;
+    }
+    h->dist_adj.assign((size_t)nouter + 1, 0);
+    if (full) {
+        int rc = ensure_slots(h, 1, true);
+        if (rc) return rc;
+        (void)hipFree(h->dDistAdj);
+        h->dDistAdj = nullptr;
+        h->dist_base = h->dA;
+    } else {
+        long off = 0;
+        for (int q = 0; q < nouter; ++q)
+            if (q % world == rank) {
+                h->dist_adj[(size_t)q] = off - dist_panel_first(h, q);
+                off += dist_panel_tiles(h, q);
+            }
+        if (rank == 0) {                                    // the rhs x rhs corner tile
+            h->dist_adj[(size_t)nouter] = off - tile_index((int)h->Nt, (int)h->Nt, (int)h->R);
+            off += 1;
+        }
+        if (off < 1) off = 1;                               // (a rank that owns nothing still gets a valid pointer)
+        const size_t need = (size_t)off * TS * h->es;
+        if (need > h->own_bytes) {
+            (void)hipFree(h->dOwn);
+            h->dOwn = nullptr; h->own_bytes = 0;
+            HIPCHK(hipMalloc(&h->dOwn, need));
+            h->own_bytes = need;
+        }
+        if (!h->dDistAdj || h->lay_panel != h->panel) {
+            (void)hipFree(h->dDistAdj);
+            h->dDistAdj = nullptr;
+            HIPCHK(hipMalloc(&h->dDistAdj, ((size_t)nouter + 1) * sizeof(long)));
+        }
+        HIPCHK(hipMemcpyAsync(h->dDistAdj, h->dist_adj.data(), ((size_t)nouter + 1) * sizeof(long), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        h->dist_base = h->dOwn;
+    }
+    h->lay_rank = rank; h->lay_world = world; h->lay_panel = h->panel; h->lay_full = (int)full;
+    return GPHIP_OK;
+}
+
+// base pointer through which the tiles of OWNED outer panel q are addressed with their global (dense) tile indices
+char* dist_panel_base(const gphip_ctx* h, int q) {
+    return static_cast<char*>(h->dist_base) + h->dist_adj[(size_t)q] * TS * (long)h->es;
+}
+// the panel's own contiguous range (what is broadcast)
+char* dist_panel_range(const gphip_ctx* h, int q) {
+    return dist_panel_base(h, q) + dist_panel_first(h, q) * TS * (long)h->es;
+}
 
 }  // namespace
 
@@ -1497,7 +1620,8 @@ int gphip_destroy(gphip_handle h) {
     group_destroy(h);                          // communicators + the other members of a multi-device handle
     (void)hipSetDevice(h->device);
     for (void* pk : h->packed) (void)hipFree(pk);
-    (void)hipFree(h->dScal);
+    (void)hipFree(h->dOwn); (void)hipFree(h->dDistAdj); (void)hipFree(h->dZ);
+    (void)hipFree(h->dScal8);
     if (h->cstream) (void)hipStreamDestroy(h->cstream);
     free_slots(h);
     (void)hipFree(h->dXt); (void)hipFree(h->dY); (void)hipFree(h->dExp2);
@@ -1547,8 +1671,8 @@ int gphip_loglik_grad(gphip_handle h, const double* theta, int p, double* out, d
     }
     std::lock_guard<std::recursive_mutex> lk(h->mu);
     double parts[2] = {0, 0};
-    h->want_w = true;
-    int rc = eval_batch(h, theta, 1, p, out, parts, info);
+    h->want_w = true;                          // (a multi-device handle factors on its first device: the K^-1 contraction needs the whole factor)
+    int rc = eval_batch_local(h, theta, 1, p, out, parts, info);
     h->want_w = false;
     if (rc) return rc;
     for (int i = 0; i < p; ++i) grad[i] = std::nan("");
@@ -1679,6 +1803,10 @@ int gphip_fit(gphip_handle h, const double* theta, int p, int* info) {
     int rc = eval_batch(h, theta, 1, p, &out, parts, info);
     h->want_w = false;
     if (rc) return rc;
+    if (h->dist_fit) {                         // (a later gphip_solve factors locally again: it needs the same K)
+        h->fit_pw_mean.assign(h->pw_mean_host ? h->pw_mean_host : nullptr, h->pw_mean_host ? h->pw_mean_host + h->N : nullptr);
+        h->fit_pw_nug.assign(h->pw_nug_host ? h->pw_nug_host : nullptr, h->pw_nug_host ? h->pw_nug_host + h->N : nullptr);
+    }
     h->fitted = (*info == 0);
     h->theta_fit.assign(theta, theta + p);
     h->logdet_fit = parts[0];
@@ -1797,6 +1925,7 @@ int gphip_covariance_batch(gphip_handle h, const double* Theta, int B, int p, do
 }
 
 static int predict_local(gphip_handle h, const void* Xs, int64_t M, double* mean, double* var);
+static int predict_streamed(gphip_handle h, const void* Xs, int64_t M, double* mean, double* var);
 
 int gphip_predict(gphip_handle h, const void* Xs, int64_t M, double* mean, double* var) {
     if (!h || !Xs || !mean || !var) return fail(h, GPHIP_ERR_ARG, "null argument");
@@ -1810,7 +1939,10 @@ int gphip_predict(gphip_handle h, const void* Xs, int64_t M, double* mean, doubl
         }
         return GPHIP_OK;
     }
-    // multi-device handle whose members all hold the factor (sharded fit): test points shard, no collective
+    // the factor of the fitted theta is spread over the ranks (sharded fit, replicate_factor = 0): its panels are
+    // streamed through every rank once more, each rank substituting ITS test points -- a collective call
+    if (h->dist_fit) return predict_streamed(h, Xs, M, mean, var);
+    // multi-device handle whose members all hold the factor (sharded fit, replicate_factor = 1): test points shard, no collective
     if (h->group && h->group->members.size() > 1 && M >= 2 * TB * (int64_t)h->group->members.size()) {
         gphip_group* g = h->group;
         bool all = true;
@@ -1873,6 +2005,158 @@ static int predict_local(gphip_handle h, const void* Xs, int64_t M, double* mean
         HIPCHK(hipStreamSynchronize(h->stream));
         HIPCHK(hipGetLastError());
         harvest(h);
+    }
+    return GPHIP_OK;
+}
+
+// Prediction from a DISTRIBUTED factor (sharded fit with replicate_factor = 0: every rank holds only its own outer panels).
+// The test points are dealt to the local ranks; then the factor's panels are broadcast once more, in order, through the
+// rotating receive buffers, and every rank runs the forward substitution of ITS test points panel by panel as the panels
+// arrive (the 128-block inverses of received diagonal blocks are rebuilt on arrival, z = L^-1 r is gathered from the rhs
+// tile row of each panel).  Traffic: the factor once per pass (N^2/2 elements received per rank); a pass handles up to
+// ~8 GiB of V per rank.  COLLECTIVE for rank handles in separate processes: every rank calls gphip_predict (each with its
+// own test points, any count >= 1); the number of passes is agreed on with one all-reduce.
+static int predict_streamed(gphip_handle h, const void* Xs, int64_t M, double* mean, double* var) {
+    gphip_group* g = h->group;
+    if (!g) return fail(h, GPHIP_ERR_STATE, "distributed fit without a group");
+    if (g->broken) return fail(h, GPHIP_ERR_STATE, "a collective call failed earlier: this multi-device handle can no longer shard");
+    const int nl = (int)g->members.size(), W = g->world;
+    const double* X = static_cast<const double*>(Xs);
+    const int64_t d = h->d;
+    int nouter = 0;
+    int rc = gphip_dist_num_panels(h, &nouter);
+    if (rc) return rc;
+    for (gphip_ctx* m : g->members)
+        if (!m->dist_fit || m->theta_fit != h->theta_fit || m->lay_panel != m->panel)
+            return fail(h, GPHIP_ERR_STATE, "the distributed factor is gone (another call reused the buffers, or \"panel\" changed): fit again");
+    // test points -> local ranks (contiguous blocks; few points: the first rank alone), chunks of <= ~8 GiB of V
+    std::vector<int64_t> lo((size_t)nl + 1, M);
+    lo[0] = 0;
+    if (nl > 1 && M >= 2 * TB * (int64_t)nl)
+        for (int i = 1; i < nl; ++i) lo[(size_t)i] = M * i / nl;
+    std::vector<int64_t> MC((size_t)nl, TB);
+    double passes = 1.0;
+    for (int i = 0; i < nl; ++i) {
+        gphip_ctx* m = g->members[(size_t)i];
+        const int64_t Mi = lo[(size_t)i + 1] - lo[(size_t)i];
+        if (Mi <= 0) continue;
+        HIPCHK(hipSetDevice(m->device));
+        int64_t mc = (int64_t)((8.0 * (1 << 30)) / ((double)m->Npad * m->es)) / TB * TB;
+        mc = std::max<int64_t>(2048, std::min<int64_t>(mc, 32768));
+        if (Mi < mc) mc = (Mi + TB - 1) / TB * TB;
+        rc = ensure_vbuf(m, mc);
+        while (rc == GPHIP_ERR_HIP && mc > 2048) {
+            (void)hipGetLastError();
+            mc = (mc / 2 + TB - 1) / TB * TB;
+            rc = ensure_vbuf(m, mc);
+        }
+        if (rc) { if (m != h) h->err = m->err; return rc; }
+        if (!m->dZ) HIPCHK(hipMalloc(&m->dZ, (size_t)m->Npad * m->es));
+        MC[(size_t)i] = mc;
+        passes = std::max(passes, (double)((Mi + mc - 1) / mc));
+    }
+    if (nl < W) {                                                      // ranks elsewhere: agree on the number of passes (max)
+        HIPCHK(hipSetDevice(h->device));
+        if (!h->dScal8) HIPCHK(hipMalloc(&h->dScal8, 8 * sizeof(double)));
+        HIPCHK(hipMemcpyAsync(h->dScal8, &passes, 8, hipMemcpyHostToDevice, h->stream));
+        if (rccl().AllReduce(h->dScal8, h->dScal8, 1, NCCL_FLOAT64, NCCL_MAX, g->comms[0], h->stream) != 0) {
+            g->broken = true;
+            return fail(h, GPHIP_ERR_HIP, "ncclAllReduce (passes) failed");
+        }
+        HIPCHK(hipMemcpyAsync(&passes, h->dScal8, 8, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    rc = group_resize_packed(h, g);
+    if (rc) return rc;
+    std::vector<double> xt;
+    const double *pm0 = h->pw_mean_test, *pn0 = h->pw_nug_test;      // (member 0 IS the public handle: keep the call's pointers)
+    struct Restore { gphip_ctx* h; const double *a, *b; ~Restore() { h->pw_mean_test = a; h->pw_nug_test = b; } } restore{h, pm0, pn0};
+    for (int pass = 0; pass < (int)passes; ++pass) {
+        std::vector<int64_t> c0((size_t)nl, 0), mcv((size_t)nl, 0), mpadv((size_t)nl, 0);
+        for (int i = 0; i < nl; ++i) {                                 // k* of this pass's chunk on every rank that has one
+            gphip_ctx* m = g->members[(size_t)i];
+            m->sync_used = 0;
+            const int64_t a = lo[(size_t)i] + (int64_t)pass * MC[(size_t)i], b = std::min(lo[(size_t)i + 1], a + MC[(size_t)i]);
+            if (b <= a) continue;
+            c0[(size_t)i] = a; mcv[(size_t)i] = b - a; mpadv[(size_t)i] = (b - a + TB - 1) / TB * TB;
+            const int64_t mc = b - a, mpad = mpadv[(size_t)i];
+            HIPCHK(hipSetDevice(m->device));
+            m->cs = m->stream;
+            xt.assign((size_t)d * mpad, 0.0);
+            for (int64_t r = 0; r < mc; ++r)
+                for (int64_t j = 0; j < d; ++j) xt[(size_t)j * mpad + r] = X[(a + r) * d + j];
+            rc = DISPATCH(m, upload, m, m->dXsT, xt, m->stream);
+            if (rc) { if (m != h) h->err = m->err; return rc; }
+            m->pw_mean_test = pm0 ? pm0 + a : nullptr;
+            m->pw_nug_test = pn0 ? pn0 + a : nullptr;
+            rc = upload_pw_test(m, 0, 1, 0, mc, mpad);
+            if (rc) { if (m != h) h->err = m->err; return rc; }
+            DISPATCH(m, queue_cross, m, mc, mpad, 1);
+        }
+        std::vector<std::vector<hipEvent_t>> ev_used((size_t)nl, std::vector<hipEvent_t>((size_t)nouter, nullptr));
+        for (int k = 0; k < nouter; ++k) {
+            const int o = k % W;
+            for (int i = 0; i < nl; ++i) {                             // the receive buffer's last reader: panel k-3's substitution
+                gphip_ctx* m = g->members[(size_t)i];
+                HIPCHK(hipSetDevice(m->device));
+                if (k >= 3 && ev_used[(size_t)i][(size_t)k - 3]) HIPCHK(hipStreamWaitEvent(m->cstream, ev_used[(size_t)i][(size_t)k - 3], 0));
+                if (pass == 0 && k < 3) {                              // nothing of an earlier call may still read the buffers
+                    hipEvent_t e = sync_event(m);
+                    HIPCHK(hipEventRecord(e, m->stream));
+                    HIPCHK(hipStreamWaitEvent(m->cstream, e, 0));
+                }
+            }
+            const int c = group_broadcast(h, g, k, (size_t)dist_panel_tiles(h, k) * TS * h->es, o);
+            if (c) { g->broken = true; return c; }
+            const int K0 = k * h->panel, K1 = (int)std::min<int64_t>(K0 + h->panel, h->Nt);
+            for (int i = 0; i < nl; ++i) {
+                gphip_ctx* m = g->members[(size_t)i];
+                if (mcv[(size_t)i] <= 0) continue;
+                HIPCHK(hipSetDevice(m->device));
+                hipEvent_t eb = sync_event(m);
+                HIPCHK(hipEventRecord(eb, m->cstream));
+                HIPCHK(hipStreamWaitEvent(m->stream, eb, 0));
+                const bool mine = o == g->ranks[(size_t)i];
+                // base through which this panel's tiles are addressed with their global indices
+                char* base = mine ? dist_panel_base(m, k)
+                                  : static_cast<char*>(m->packed[k % 3]) - dist_panel_first(m, k) * TS * (long)m->es;
+                m->cs = m->stream;
+                if (m->dtype == 64) {
+                    if (!mine) hipLaunchKernelGGL(trtri128_kernel<double>, dim3((unsigned)(K1 - K0), 1), dim3(256), potrf_lds<double>(),
+                                                  m->stream, (const double*)base, 0l, (double*)m->dW, (int)m->Nt, K0);
+                    if (pass == 0)
+                        hipLaunchKernelGGL(gather_rhs_row_kernel<double>, dim3((unsigned)(((K1 - K0) * TB + 255) / 256)), dim3(256), 0,
+                                           m->stream, (const double*)base, (int)m->R, 0, K1 * TB, (double*)m->dZ, 1l, K0 * TB);
+                } else {
+                    if (!mine) hipLaunchKernelGGL(trtri128_kernel<float>, dim3((unsigned)(K1 - K0), 1), dim3(256), potrf_lds<float>(),
+                                                  m->stream, (const float*)base, 0l, (float*)m->dW, (int)m->Nt, K0);
+                    if (pass == 0)
+                        hipLaunchKernelGGL(gather_rhs_row_kernel<float>, dim3((unsigned)(((K1 - K0) * TB + 255) / 256)), dim3(256), 0,
+                                           m->stream, (const float*)base, (int)m->R, 0, K1 * TB, (float*)m->dZ, 1l, K0 * TB);
+                }
+                m->ws_override = base;
+                DISPATCH(m, queue_forward_panel, m, mpadv[(size_t)i], 1, K0, K1, 0, false);
+                m->ws_override = nullptr;
+                hipEvent_t eu = sync_event(m);
+                HIPCHK(hipEventRecord(eu, m->stream));
+                ev_used[(size_t)i][(size_t)k] = eu;
+            }
+        }
+        for (int i = 0; i < nl; ++i) {
+            gphip_ctx* m = g->members[(size_t)i];
+            HIPCHK(hipSetDevice(m->device));
+            if (mcv[(size_t)i] > 0) {
+                const int64_t mc = mcv[(size_t)i], a = c0[(size_t)i];
+                DISPATCH(m, queue_predict_reduce, m, mc, mpadv[(size_t)i], 1);
+                HIPCHK(hipMemcpyAsync(mean + a, m->dMean, (size_t)mc * 8, hipMemcpyDeviceToHost, m->stream));
+                HIPCHK(hipMemcpyAsync(var + a, m->dVar, (size_t)mc * 8, hipMemcpyDeviceToHost, m->stream));
+            }
+            HIPCHK(hipStreamSynchronize(m->cstream));
+            HIPCHK(hipStreamSynchronize(m->stream));
+            HIPCHK(hipGetLastError());
+            harvest(m);
+            m->pw_mean_test = m->pw_nug_test = nullptr;
+        }
     }
     return GPHIP_OK;
 }
@@ -2030,6 +2314,23 @@ int gphip_solve(gphip_handle h, const double* rhs, int64_t nrhs, double* out) {
     if (nrhs < 1) return fail(h, GPHIP_ERR_DIM, "nrhs < 1");
     std::lock_guard<std::recursive_mutex> lk(h->mu);
     if (!h->fitted) return fail(h, GPHIP_ERR_STATE, "gphip_solve before a successful gphip_fit");
+    if (h->dist_fit) {
+        // the factor is spread over the ranks: "Inverse" is a parity helper for small systems, so the first device simply
+        // factors the fitted theta again on its own (in separate processes: every rank does) and substitutes locally
+        const std::vector<double> th = h->theta_fit;
+        double ll, parts[2];
+        int info = 0;
+        h->want_w = true;
+        const double *pm = h->pw_mean_host, *pn = h->pw_nug_host;
+        h->pw_mean_host = h->fit_pw_mean.empty() ? nullptr : h->fit_pw_mean.data();
+        h->pw_nug_host = h->fit_pw_nug.empty() ? nullptr : h->fit_pw_nug.data();
+        int rc = eval_batch_local(h, th.data(), 1, (int)th.size(), &ll, parts, &info);
+        h->pw_mean_host = pm; h->pw_nug_host = pn;
+        h->want_w = false;
+        if (rc) return rc;
+        if (info != 0) return fail(h, GPHIP_ERR_STATE, "the fitted theta no longer factors");
+        h->fitted = true;                      // now a LOCAL fit of the same theta (logdet_fit / mu_fit / kappa_fit unchanged)
+    }
     if (h->null_fit) {                         // "Inverse" -> Function[Divide[#, matrixDiagonal]]  (BGP:156-159)
         for (int64_t i = 0; i < nrhs * h->N; ++i)
             out[i] = rhs[i] / (h->null_diag.empty() ? h->kappa_fit : h->null_diag[(size_t)(i % h->N)]);
@@ -2110,9 +2411,12 @@ int gphip_dist_begin(gphip_handle h, const double* theta, int p, int rank, int w
     if (h->kernel_id == GPHIP_KERNEL_NULL) return fail(h, GPHIP_ERR_UNSUPPORTED, "null kernel needs no factorisation");
     std::lock_guard<std::recursive_mutex> lk(h->mu);
     HIPCHK(hipSetDevice(h->device));
-    int rc = ensure_slots(h, 1);
+    const bool full = h->replicate_factor != 0;
+    int rc = ensure_slots(h, 1, full);
     if (rc) return rc;
-    h->fitted = false;
+    rc = dist_layout(h, rank, world, full);
+    if (rc) return rc;
+    h->fitted = false; h->dist_fit = false;
     h->dist_rank = rank; h->dist_world = world;
     h->dist_theta_ok = stage_theta(h, 0, theta, h->pw_nug_host, h->pw_mean_host);
     rc = upload_pw(h, 0, 1);                   // point-dependent nugget / mean of this evaluation, if the caller set them
@@ -2127,23 +2431,25 @@ int gphip_dist_begin(gphip_handle h, const double* theta, int p, int rank, int w
     return GPHIP_OK;
 }
 
-// owner of panel k: factor it in place (panel stream) and pack it into `packed`
-// (rows x cols elements, column-major, contiguous) for the broadcast
+// owner of panel k: factor it in place (panel stream).  `packed` (optional): a copy of the panel's range for a host that
+// runs its own collective (dist_cholesky.py); the in-library schedule broadcasts straight from the rank's storage
 int gphip_dist_factor_panel(gphip_handle h, int k, void* packed) {
-    if (!h || !packed) return fail(h, GPHIP_ERR_ARG, "null argument");
+    if (!h) return fail(h, GPHIP_ERR_ARG, "null argument");
     int64_t rows, cols;
     int rc = gphip_dist_panel_shape(h, k, &rows, &cols);
     if (rc) return rc;
     std::lock_guard<std::recursive_mutex> lk(h->mu);
     if (h->dist_world < 1) return fail(h, GPHIP_ERR_STATE, "gphip_dist_factor_panel outside dist_begin/dist_end");
+    if (k % h->dist_world != h->dist_rank) return fail(h, GPHIP_ERR_ARG, "gphip_dist_factor_panel: not the owner of this panel");
     HIPCHK(hipSetDevice(h->device));
     const int64_t K0 = (int64_t)k * h->panel;
-    h->cs = h->pstream;
     const int64_t K1 = (K0 + h->panel < h->Nt) ? K0 + h->panel : h->Nt;
+    h->cs = h->pstream;
+    h->ws_override = dist_panel_base(h, k);
     DISPATCH(h, queue_panel, h, (int)K0, (int)(K1 - K0), 1);
-    const char* src = static_cast<const char*>(h->dA) + (size_t)tile_index((int)K0, (int)K0, (int)h->R) * TS * h->es;
-    if (packed != (void*)src)                  // (a caller may hand the workspace range itself: nothing to pack)
-        HIPCHK(hipMemcpyAsync(packed, src, (size_t)rows * cols * h->es, hipMemcpyDeviceToDevice, h->pstream));
+    h->ws_override = nullptr;
+    if (packed && packed != (void*)dist_panel_range(h, k))
+        HIPCHK(hipMemcpyAsync(packed, dist_panel_range(h, k), (size_t)rows * cols * h->es, hipMemcpyDeviceToDevice, h->pstream));
     h->cs = h->stream;
     return GPHIP_OK;
 }
@@ -2224,6 +2530,7 @@ int* option_slot(gphip_ctx* h, const char* name) {
         {"max_slots", &gphip_ctx::max_slots}, {"shard_min_n", &gphip_ctx::shard_min_n},
         {"thin_tiles", &gphip_ctx::thin_tiles}, {"panel_wide", &gphip_ctx::panel_wide},
         {"la_main", &gphip_ctx::la_main}, {"rest_split", &gphip_ctx::rest_split},
+        {"debug_fail_alloc", &gphip_ctx::debug_fail_alloc}, {"replicate_factor", &gphip_ctx::replicate_factor},
     };
     for (const Entry& e : table)
         if (!strcmp(name, e.name)) return &(h->*(e.field));
@@ -2293,6 +2600,22 @@ int gphip_reset_profile(gphip_handle h) {
     if (!h) return GPHIP_ERR_ARG;
     std::lock_guard<std::recursive_mutex> lk(h->mu);
     for (int c = 0; c < GPHIP_NCLASS; ++c) h->acc_ms[c] = h->acc_n[c] = h->acc_flops[c] = h->acc_bytes[c] = 0;
+    return GPHIP_OK;
+}
+
+// Device memory this handle's rank `member` (0 .. nlocal-1; 0 for a plain handle) holds for factor storage right now:
+// the dense workspace slots + its compact own-panel storage + its receive buffers (diagnostics / tests).
+int gphip_factor_bytes(gphip_handle h, int member, double* bytes) {
+    if (!h || !bytes) return GPHIP_ERR_ARG;
+    std::lock_guard<std::recursive_mutex> lk(h->mu);
+    gphip_ctx* m = h;
+    if (h->group) {
+        if (member < 0 || member >= (int)h->group->members.size()) return fail(h, GPHIP_ERR_ARG, "no such local rank");
+        m = h->group->members[(size_t)member];
+    } else if (member != 0) return fail(h, GPHIP_ERR_ARG, "no such local rank");
+    double b = (m->dA ? (double)m->slots * (double)m->slot_elems * (double)m->es : 0.0) + (double)m->own_bytes;
+    for (void* pk : m->packed) b += pk ? (double)m->packed_bytes : 0.0;
+    *bytes = b;
     return GPHIP_OK;
 }
 

@@ -17,10 +17,10 @@
 namespace gphip {
 
 // the handful of declarations used, with RCCL's ABI (rccl.h: ncclUniqueId is 128 opaque bytes; ncclChar = 0,
-// ncclFloat64 = 8, ncclSum = 0; every call returns ncclResult_t, 0 = ncclSuccess)
+// ncclFloat64 = 8, ncclSum = 0, ncclMax = 2; every call returns ncclResult_t, 0 = ncclSuccess)
 struct NcclUniqueId { char internal[128]; };
 typedef struct ncclComm* nccl_comm_t;
-constexpr int NCCL_CHAR = 0, NCCL_FLOAT64 = 8, NCCL_SUM = 0;
+constexpr int NCCL_CHAR = 0, NCCL_FLOAT64 = 8, NCCL_SUM = 0, NCCL_MAX = 2;
 
 struct RcclApi {
     void* so = nullptr;

@@ -193,7 +193,14 @@ int gphip_logdet(gphip_handle h, double* out);
  *                  of the 128 bordered right-hand-side rows (zero), and the strictly-upper quadrant of diagonal tiles
  *   "max_slots"    cap on concurrently resident batch matrices
  *   "shard_min_n"  multi-device handles: shard ONE factorisation over the devices from this N on (default 16384;
- *                  0 = always, even for a world of one) */
+ *                  0 = always, even for a world of one)
+ *   "replicate_factor"  multi-device handles, sharded evaluations: 0 (default) every rank keeps ONLY its own outer panels
+ *                  (compact storage + three receive buffers: ~1 / world of the workspace per rank); a fit leaves the factor
+ *                  distributed and gphip_predict streams its panels through the ranks once more (a COLLECTIVE call for
+ *                  rank handles in separate processes); 1: every rank keeps the dense workspace and receives panels in
+ *                  place, so that after a fit all ranks hold all of L and prediction needs no further traffic
+ *   "panel", "shard_min_n", "replicate_factor" must have the same value on every rank of a multi-process job (checked by
+ *   one small all-reduce at the start of every sharded evaluation: a mismatch fails the call on ALL ranks). */
 int gphip_set_option(gphip_handle h, const char* name, double value);
 int gphip_get_option(gphip_handle h, const char* name, double* value);
 /* The environment variable GPHIP_OPTIONS="name=value,name=value" presets options for every handle the process
@@ -222,6 +229,10 @@ int gphip_dist_factor_panel(gphip_handle h, int k, void* packed_dev);
 int gphip_dist_update(gphip_handle h, int k, const void* packed_dev, int j_first, int j_last,
                       int on_panel_stream);
 int gphip_dist_end(gphip_handle h, double* logdet_partial, double* quad, int* info);
+
+/* Device memory (bytes) local rank `member` of the handle holds for factor storage right now: dense workspace slots +
+ * compact own-panel storage + receive buffers (diagnostics: a sharded evaluation keeps ~1 / world of the workspace). */
+int gphip_factor_bytes(gphip_handle h, int member, double* bytes);
 
 /* Block until all work queued on the handle's stream is complete. */
 int gphip_sync(gphip_handle h);

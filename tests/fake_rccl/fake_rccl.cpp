@@ -109,15 +109,22 @@ int ncclBroadcast(const void* send, void* recv, size_t count, int dtype, int roo
     pthread_barrier_wait(&comm->seg->bar);          // everyone has read: the segment may be overwritten
     return 0;
 }
-int ncclAllReduce(const void* send, void* recv, size_t count, int dtype, int /*op: sum*/, void* c, hipStream_t st) {
+int ncclAllReduce(const void* send, void* recv, size_t count, int dtype, int op /* 0 sum, 2 max */, void* c, hipStream_t st) {
     Comm* comm = static_cast<Comm*>(c);
-    if (dtype != 8 || count > 8 || comm->nranks > 64) return 3;
+    if (dtype != 8 || count > 8 || comm->nranks > 64 || (op != 0 && op != 2)) return 3;
     double mine[8], tot[8] = {0};
     if (hipMemcpyAsync(mine, send, count * 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return 1;
+    if (!comm->seg) {                               // in-process communicator of one rank
+        if (hipMemcpyAsync(recv, mine, count * 8, hipMemcpyHostToDevice, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return 1;
+        return 0;
+    }
     memcpy(comm->seg->red + 8 * comm->rank, mine, count * 8);
     pthread_barrier_wait(&comm->seg->bar);
     for (int r = 0; r < comm->nranks; ++r)
-        for (size_t i = 0; i < count; ++i) tot[i] += comm->seg->red[8 * r + i];
+        for (size_t i = 0; i < count; ++i) {
+            const double v = comm->seg->red[8 * r + i];
+            tot[i] = (op == 2 && r > 0) ? (v > tot[i] ? v : tot[i]) : (op == 2 ? v : tot[i] + v);
+        }
     pthread_barrier_wait(&comm->seg->bar);
     if (hipMemcpyAsync(recv, tot, count * 8, hipMemcpyHostToDevice, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return 1;
     return 0;

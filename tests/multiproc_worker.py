@@ -25,10 +25,11 @@ def main():
     bad = th.copy()
     bad[0] = np.nan
     res["nan"] = list(h.loglik(bad))
-    res["fit"] = h.fit(th)                               # collective; L replicated by unpack-on-receive
+    res["fit"] = h.fit(th)                               # collective; every rank keeps its own panels of L
     Xs = syn.make_test_points(64, d)
-    lo, hi = 64 * rank // world, 64 * (rank + 1) // world     # each rank predicts ITS shard, no collective
-    mu, var = h.predict(Xs[lo:hi])
+    lo, hi = 64 * rank // world, 64 * (rank + 1) // world     # each rank predicts ITS shard: collective (the factor's panels
+    mu, var = h.predict(Xs[lo:hi])                            # stream through every rank once more)
+    res["bytes"] = h.factor_bytes()
     res["mu"], res["var"], res["shard"] = mu.tolist(), var.tolist(), [lo, hi]
     res["logdet"] = h.logdet()
     res["alpha_head"] = h.solve(y)[:5].tolist()

@@ -5,6 +5,8 @@ schedule, ownership (panel j -> rank j % world), packing, look-ahead ordering, u
 L and the scalar reduction are exactly what runs on 8 GPUs -- only the transport differs (device copies for
 virtual ranks; RCCL, bound with dlopen, once the ordinals are distinct).  The RCCL binding itself is exercised
 at world size 1 through gphip_create_rank (ncclCommInitRank / ncclBroadcast / ncclAllReduce on one GPU)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -63,10 +65,12 @@ def test_sharded_loglik_matches_oracle_and_single_device(n, d, kernel, world, pa
     gd.close(); g.close(); h.close()
 
 
-def test_sharded_fit_replicates_factor_and_predict_shards_test_points():
-    """C3: after a sharded fit EVERY rank holds all of L, z and the block inverses
-    (each received panel is unpacked on arrival -- no extra collective), so test points shard with no further
-    traffic and solve / logdet work on the first device."""
+@pytest.mark.parametrize("replicate", [0, 1])
+def test_sharded_fit_and_predict_shards_test_points(replicate):
+    """C3.  replicate_factor = 1: after a sharded fit EVERY rank holds all of L, z and the block
+    inverses (each panel is received in place in the rank's dense workspace), test points shard with no further traffic.
+    replicate_factor = 0 (default): every rank keeps only ITS panels; prediction streams the factor's panels through the
+    ranks once more, each rank substituting its share of the test points; solve / logdet work on the first device."""
     n, d, world = 2300, 4, 4
     X, y = syn.make_dataset(n, d)
     th = syn.default_theta("matern52_ard", d)
@@ -74,6 +78,7 @@ def test_sharded_fit_replicates_factor_and_predict_shards_test_points():
     g = _lib.Handle(X, y, "matern52_ard", device=[0] * world)
     g.set_option("shard_min_n", 0)
     g.set_option("panel", 2)
+    g.set_option("replicate_factor", replicate)
     assert g.fit(th) == 0
     mu, var = g.predict(Xs)
     mo, so = orc.predict_internal("matern52_ard", th, X, y, Xs)
@@ -169,4 +174,44 @@ def test_gradient_and_cross_covariance_on_a_sharding_group_handle():
     k, kappa = g.cross_covariance(th, X[:6])
     ko, kap = orc.k_and_kappa("se_ard", th, X, X[:6])
     np.testing.assert_allclose(k, ko, rtol=1e-12, atol=1e-300)
+    g.close()
+
+
+def test_sharding_shards_memory(golden_dir):
+    """A rank of a sharding handle keeps only its own block-cyclic panels (+ three receive buffers of one panel each):
+    at N = 32768 with 4 ranks and 128-wide panels each rank holds <= 0.3x the single-handle workspace, while the
+    evaluation reproduces the ORACLE's scalars for this problem (tests/golden/f3_scalars.npz) and the fit + streamed
+    prediction reproduce the single-device handle (the streamed prediction itself is checked against the oracle at
+    N = 2300 above); replicate_factor = 1 trades that for the dense workspace on every rank."""
+    n, d, world = 32768, 8, 4
+    X, y = syn.make_dataset(n, d)
+    th = syn.default_theta("se_ard", d)
+    gold = np.load(os.path.join(golden_dir, "f3_scalars.npz"))
+    row = [i for i in range(len(gold["n"])) if int(gold["n"][i]) == n and str(gold["kernel"][i]) == "se_ard"][0]
+    Xs = syn.make_test_points(600, d)
+    h = _lib.Handle(X, y, "se_ard")
+    assert h.fit(th) == 0
+    single = h.factor_bytes()
+    mu1, var1 = h.predict(Xs)
+    h.close()
+    g = _lib.Handle(X, y, "se_ard", device=[0] * world)
+    g.set_option("shard_min_n", 0)
+    g.set_option("panel", 1)
+    ll, ld, qd, info = g.loglik_parts(th)
+    assert info == 0 and close(ll, float(gold["loglik"][row]), n) and close(ld, float(gold["logdet"][row]), n)
+    assert close(qd, float(gold["quad"][row]), n)
+    assert g.fit(th) == 0
+    mu, var = g.predict(Xs)
+    np.testing.assert_allclose(mu, mu1, rtol=1e-8, atol=1e-9)
+    np.testing.assert_allclose(var, var1, rtol=1e-8, atol=1e-12)
+    per_rank = [g.factor_bytes(i) for i in range(world)]
+    assert max(per_rank) <= 0.3 * single, (per_rank, single)
+    assert sum(per_rank) <= 1.2 * single                 # the factor once + the receive buffers
+    ll2, info = g.loglik(th)                             # the buffers are reused by the next evaluation
+    assert info == 0 and ll2 == ll
+    g.set_option("replicate_factor", 1)
+    assert g.fit(th) == 0
+    assert min(g.factor_bytes(i) for i in range(world)) >= single
+    mu2, _ = g.predict(Xs)
+    np.testing.assert_allclose(mu2, mu1, rtol=1e-8, atol=1e-9)
     g.close()

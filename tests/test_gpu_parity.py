@@ -722,3 +722,37 @@ def test_growing_the_slot_count_mid_handle_is_ordered_before_the_next_launch():
             want = -0.5 * (n * log2pi + 2 * np.log(np.diag(L)).sum() + z @ z)
             assert info[b] == 0 and close(out[b], want, n), (it, n, kernel, b, out[b], want)
         h.close()
+
+
+def test_failed_slot_allocation_rolls_back_and_the_handle_stays_usable():
+    """ensure_slots: a device allocation that fails half way (fault injection through the option "debug_fail_alloc":
+    the n-th allocation of the next slot growth reports out-of-memory) must leave the handle in the consistent zero-slot
+    state -- the failing call returns an error, the next call allocates again and gives the right answer."""
+    n, d = 400, 3
+    X, y = syn.make_dataset(n, d)
+    Th = syn.theta_batch(12, "se_ard", d)
+    Th[:, -1] = np.maximum(Th[:, -1], 0.05)
+    want = [orc.log_likelihood("se_ard", th, X, y) for th in Th]
+    h = _lib.Handle(X, y, "se_ard")
+    ll, info = h.loglik(Th[0])                               # one slot allocated
+    assert info == 0 and close(ll, want[0], n)
+    for nth in (1, 2, 5, 9, 11):                             # fail the workspace itself, a middle buffer, the flags, ..
+        h.set_option("debug_fail_alloc", nth)
+        with pytest.raises(_lib.GphipError) as exc:
+            h.loglik_batch(Th)                               # growth 1 -> 12 slots hits the injected failure
+        assert "failed at" in str(exc.value)
+        out, info = h.loglik_batch(Th)                       # same call again: allocates from the zero-slot state
+        assert np.all(info == 0)
+        for a, b in zip(out, want):
+            assert close(a, b, n)
+        assert h.fit(Th[1]) == 0                             # fitted state works after the re-allocation
+        h.set_option("max_slots", 4)                         # shrink, then force another growth for the next round
+        h.loglik_batch(Th[:2])
+        h.set_option("max_slots", 256)
+        hfree = _lib.Handle(X, y, "se_ard")                  # (keeps the allocator honest between rounds)
+        hfree.close()
+        # drop back to one slot so that the next round grows again
+        h.close()
+        h = _lib.Handle(X, y, "se_ard")
+        h.loglik(Th[0])
+    h.close()
