@@ -93,6 +93,10 @@ _SIGNATURES = {
     "gphip_get_profile": (C.c_int, [_h, C.c_int, _dp, _dp, _dp, _dp]),
     "gphip_reset_profile": (C.c_int, [_h]),
     "gphip_sync": (C.c_int, [_h]),
+    "gphip_ns_default_options": (C.c_int, [C.c_void_p]),
+    "gphip_nested_sampling": (C.c_int, [_h, _dp, _ip, C.c_void_p, C.c_void_p, C.c_void_p, _dp, C.c_int64, _dp, _dp, _dp, _dp,
+                                        C.POINTER(C.c_int64), _dp, C.POINTER(C.c_int64)]),
+    "gphip_ns_crude_weights": (C.c_int, [_dp, _dp, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_int64), _dp, _dp, _dp]),
     "gphip_factor_bytes": (C.c_int, [_h, C.c_int, _dp]),
     "gphip_set_streams": (C.c_int, [_h, C.c_void_p, C.c_void_p]),
     "gphip_dist_num_panels": (C.c_int, [_h, _ip]),
@@ -159,6 +163,30 @@ def comm_unique_id() -> bytes:
 
 def _d(a: np.ndarray):
     return a.ctypes.data_as(_dp)
+
+
+class NsOptions(C.Structure):
+    """gphip_ns_options (include/gphip.h)"""
+    _fields_ = [("pool", C.c_int), ("max_iterations", C.c_int), ("min_iterations", C.c_int), ("mc_steps", C.c_int),
+                ("walkers", C.c_int), ("termination_fraction", C.c_double), ("min_accept", C.c_double),
+                ("max_accept", C.c_double), ("seed", C.c_uint64)]
+
+
+LOGPRIOR_FN = C.CFUNCTYPE(C.c_double, _dp, C.c_int, C.c_void_p)
+
+
+def ns_crude_weights(points, loglik, pool: int):
+    """gphip_ns_crude_weights: (order, logX, crude log weights, log evidence) -- calculateWeightsCrude, BS:818-835."""
+    pts = np.ascontiguousarray(np.atleast_2d(np.asarray(points, dtype=np.float64)))
+    ll = np.ascontiguousarray(np.asarray(loglik, dtype=np.float64))
+    m, p = pts.shape
+    order = np.zeros(m, dtype=np.int64)
+    logx, logw, z = np.zeros(m), np.zeros(m), C.c_double(0.0)
+    rc = load().gphip_ns_crude_weights(_d(pts), _d(ll), m, p, int(pool), order.ctypes.data_as(C.POINTER(C.c_int64)), _d(logx),
+                                       _d(logw), C.byref(z))
+    if rc != OK:
+        raise GphipError(rc, "gphip_ns_crude_weights")
+    return order, logx, logw, z.value
 
 
 class Handle:
@@ -381,6 +409,33 @@ class Handle:
         out = C.c_double(0.0)
         self._check(self._lib.gphip_logdet(self._h, C.byref(out)))
         return out.value
+
+    def nested_sampling(self, box, prior_kind=None, logprior=None, start=None, cap=None, **options):
+        """gphip_nested_sampling: the native batched sampler.  options: pool, max_iterations, min_iterations, mc_steps,
+        walkers, termination_fraction, min_accept, max_accept, seed.  Returns a dict with Points, LogLikelihood,
+        LogPriorPDF, AcceptanceRate (generation order), CrudeLogEvidence, LikelihoodEvaluations, SamplePoolSize."""
+        o = NsOptions()
+        self._check(self._lib.gphip_ns_default_options(C.byref(o)))
+        for k, v in options.items():
+            if not hasattr(o, k):
+                raise GphipError(1, f"unknown sampler option {k!r}")
+            setattr(o, k, v)
+        box = np.ascontiguousarray(np.asarray(box, dtype=np.float64).reshape(self.p, 2))
+        kinds = None if prior_kind is None else np.ascontiguousarray(np.asarray(prior_kind, dtype=np.int32))
+        cb = None
+        if logprior is not None:
+            cb = LOGPRIOR_FN(lambda th, p, _u: float(logprior(np.ctypeslib.as_array(th, shape=(p,)).copy())))
+        st = None if start is None else np.ascontiguousarray(np.asarray(start, dtype=np.float64).reshape(o.pool, self.p))
+        cap = int(cap or (o.pool + max(o.max_iterations, o.min_iterations) + 1))
+        pts, ll, lp, ar = np.zeros((cap, self.p)), np.zeros(cap), np.zeros(cap), np.zeros(cap)
+        ns, ne, z = C.c_int64(0), C.c_int64(0), C.c_double(0.0)
+        self._check(self._lib.gphip_nested_sampling(
+            self._h, _d(box), None if kinds is None else kinds.ctypes.data_as(_ip), C.cast(cb, C.c_void_p) if cb else None, None,
+            C.byref(o), None if st is None else _d(st), cap, _d(pts), _d(ll), _d(lp), _d(ar), C.byref(ns), C.byref(z), C.byref(ne)))
+        m = ns.value
+        return {"Points": pts[:m].copy(), "LogLikelihood": ll[:m].copy(), "LogPriorPDF": lp[:m].copy(),
+                "AcceptanceRate": ar[:m].copy(), "SamplePoolSize": int(o.pool), "GeneratedNestedSamples": m - int(o.pool),
+                "TotalSamples": m, "CrudeLogEvidence": z.value, "LikelihoodEvaluations": ne.value, "Seed": int(o.seed)}
 
     # -- measurement ---------------------------------------------------------------------
     def reset_profile(self):

@@ -130,6 +130,7 @@ struct gphip_ctx {
     // compact buffer holding only the owned panels (+ the corner tile on rank 0) -- memory per rank ~ 1 / world of the
     // workspace; 1: the dense workspace dA (every received panel is received in place: all ranks end up with all of L).
     int replicate_factor = 0;
+    int share_local_panels = 1;                  // virtual ranks on the owner's GPU read a factored panel where the owner keeps it
     void* dOwn = nullptr;                        // typed compact own-panel storage
     size_t own_bytes = 0;
     void* dist_base = nullptr;                   // dOwn or dA: base of the storage the current sharded evaluation runs in
@@ -2118,8 +2119,7 @@ static int predict_streamed(gphip_handle h, const void* Xs, int64_t M, double* m
                 HIPCHK(hipStreamWaitEvent(m->stream, eb, 0));
                 const bool mine = o == g->ranks[(size_t)i];
                 // base through which this panel's tiles are addressed with their global indices
-                char* base = mine ? dist_panel_base(m, k)
-                                  : static_cast<char*>(m->packed[k % 3]) - dist_panel_first(m, k) * TS * (long)m->es;
+                char* base = group_panel_ptr(g, i, k) - dist_panel_first(m, k) * TS * (long)m->es;
                 m->cs = m->stream;
                 if (m->dtype == 64) {
                     if (!mine) hipLaunchKernelGGL(trtri128_kernel<double>, dim3((unsigned)(K1 - K0), 1), dim3(256), potrf_lds<double>(),
@@ -2531,6 +2531,7 @@ int* option_slot(gphip_ctx* h, const char* name) {
         {"thin_tiles", &gphip_ctx::thin_tiles}, {"panel_wide", &gphip_ctx::panel_wide},
         {"la_main", &gphip_ctx::la_main}, {"rest_split", &gphip_ctx::rest_split},
         {"debug_fail_alloc", &gphip_ctx::debug_fail_alloc}, {"replicate_factor", &gphip_ctx::replicate_factor},
+        {"share_local_panels", &gphip_ctx::share_local_panels},
     };
     for (const Entry& e : table)
         if (!strcmp(name, e.name)) return &(h->*(e.field));
@@ -2629,3 +2630,5 @@ int gphip_sync(gphip_handle h) {
 }
 
 }  // extern "C"
+
+#include "gphip_sampler.inc"

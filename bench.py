@@ -247,6 +247,8 @@ def main() -> None:
     ap.add_argument("--no-alone", action="store_true", help="skip the extra look-ahead-off evaluation behind roofline_syrk_alone "
                                                             "(profiling runs: keeps the rocprof launch statistics those of the timed schedule)")
     ap.add_argument("--no-extras", action="store_true", help="skip the short BASELINE.json cfg-4 / cfg-5 measurements")
+    ap.add_argument("--no-strong", action="store_true", help="N>1, mode theta: skip the short strong-scaling series (ONE "
+                                                             "factorisation sharded over all ranks) printed as the `strong` sub-record")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -340,6 +342,38 @@ def main() -> None:
         alone = h.profile()["syrk_trailing"]
         h.set_option("lookahead", 1)
 
+    # N > 1, default (weak, theta-sharded) mode: ALSO a short strong-scaling series -- the split north_star names: ONE
+    # likelihood factored by all ranks together (1-D block-cyclic Cholesky, RCCL panel broadcast, entirely behind the C ABI
+    # through gphip_create_rank).  Outside the timed region of the headline; reported as the `strong` sub-record.
+    strong = None
+    if dist is not None and not sharded and not args.no_strong:
+        try:
+            box = [_lib.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            hs = _lib.Handle(X, y, "se_ard", device=local_rank, rank=rank, world=world, comm_id=box[0])
+            hs.set_option("shard_min_n", 0)
+            jit0 = syn.uniform(syn.STREAM_THETA, 1000, 8 * (d + 2))
+            ths = base[None, :] * (1.0 + 0.05 * (jit0.reshape(8, d + 2) - 0.5))
+            hs.loglik(ths[0]); hs.loglik(ths[1])
+            barrier()
+            t1 = time.perf_counter()
+            sv = [hs.loglik(ths[2 + i]) for i in range(5)]
+            barrier()
+            ds = time.perf_counter() - t1
+            ts = torch.tensor([ds], device="cuda", dtype=torch.float64)
+            dist.all_reduce(ts, op=dist.ReduceOp.MAX)
+            ci = hs.comm_info()
+            strong = {"what": f"ONE evaluation per step factored by all {world} ranks together (1-D block-cyclic Cholesky, one "
+                              "RCCL broadcast of the factored panel per 512-column step, gphip_create_rank)",
+                      "scaling": "strong", "steps": 5, "ms_per_eval": float(ts.item()) / 5 * 1e3,
+                      "evals_per_s": 5 / float(ts.item()), "speedup_vs_one_gpu_weak_step": (dt / args.steps) / (float(ts.item()) / 5),
+                      "cholesky_tflops_total": n ** 3 / 3.0 * 5 / float(ts.item()) / 1e12,
+                      "rccl_ranks": ci["world"], "comm": ci["comm"], "factor_bytes_per_rank": hs.factor_bytes(),
+                      "all_ok": bool(all(v[1] == 0 and np.isfinite(v[0]) for v in sv))}
+            hs.close()
+        except Exception as exc:                                    # never let the extra break the headline
+            strong = {"error": repr(exc)}
+
     if rank == 0:
         syrk = prof["syrk_trailing"]
         achieved = syrk["flops"] / (syrk["ms"] * 1e-3) / 1e12 if syrk["ms"] > 0 else 0.0
@@ -368,6 +402,8 @@ def main() -> None:
         }
         out["roofline"]["note"] = ("timed inside the evaluation, where the SYRK shares the chip with the look-ahead stream; "
                                    "roofline_syrk_alone = the same kernel, one extra evaluation with look-ahead off")
+        if strong is not None:
+            out["strong"] = strong
         if alone is not None:
             out["roofline_syrk_alone"] = _roof(alone, FP64_MFMA_PEAK_TFLOPS, "TFLOP/s",
                                                "gemm_nt_kernel<double, 0, 2, 2, 2>, look-ahead off (outside the timed region)")

@@ -163,6 +163,40 @@ int gphip_cross_covariance(gphip_handle h, const double* theta, int p, const voi
 int gphip_solve(gphip_handle h, const double* rhs, int64_t nrhs, double* out);
 int gphip_logdet(gphip_handle h, double* out);
 
+/* ---- Nested sampling over the hyper-parameters, driven natively.  Restates the reference's
+ * nestedSamplingInternal (BayesianStatistics.wl:859-1040): same live-point bookkeeping, X values (:790-802), trapezoid
+ * weights (:757-771), stop rule (:967-978) and constrained-prior Metropolis move (:707-745) -- but `walkers` chains advance in
+ * lock step so that every Metropolis step is ONE batched likelihood call instead of "MonteCarloSteps" sequential ones.
+ *   box          p x 2 row-major {min, max} per parameter (paramSpecPattern, BS:19)
+ *   prior_kind   per parameter 0 = uniform, 1 = log-uniform over its range (NULL = all uniform); or
+ *   logprior     a "LogPriorPDFFunction" callback (BS:256-274) overriding prior_kind; the box still bounds the walk
+ *   start        pool x p starting points (generateStartingPoints, BS:1046-1068) or NULL = drawn from the built-in prior
+ * Output, in generation order (the pool first, then one sample per iteration), up to `cap` samples: points (cap x p),
+ * loglik, logprior_out, accept_rate (NaN for the pool: Missing["InitialSample"]); *n_samples; *log_evidence = the crude
+ * estimate logSumExp of the crude posterior weights (BS:1019); *n_evals = likelihood evaluations spent.  The statistical
+ * post-processing (evidenceSampling, BS:1158-1291; combineRuns) stays with the host: the WL package hands the samples to
+ * the reference's OWN evidenceSampling. */
+typedef double (*gphip_logprior_fn)(const double* theta, int p, void* user);
+typedef struct {
+    int pool;                      /* "SamplePoolSize", default 100 (BS:833-855) */
+    int max_iterations;            /* "MaxIterations" 10000 */
+    int min_iterations;            /* "MinIterations" 100 */
+    int mc_steps;                  /* "MonteCarloSteps" 200 */
+    int walkers;                   /* chains advanced in lock step, default 32 (1 = the reference's sequential chain) */
+    double termination_fraction;   /* "TerminationFraction" 0.01 */
+    double min_accept, max_accept; /* "MinMaxAcceptanceRate" {0, 1} */
+    uint64_t seed;
+} gphip_ns_options;
+int gphip_ns_default_options(gphip_ns_options* opts);
+int gphip_nested_sampling(gphip_handle h, const double* box, const int* prior_kind, gphip_logprior_fn logprior, void* user,
+                          const gphip_ns_options* opts, const double* start, int64_t cap, double* points, double* loglik,
+                          double* logprior_out, double* accept_rate, int64_t* n_samples, double* log_evidence,
+                          int64_t* n_evals);
+/* calculateWeightsCrude (BS:818-835) for m samples of which `pool` are live: order (sorted by (LogLikelihood, Point)), log X
+ * and crude log posterior weights in that order, and their logSumExp (exported for tests and hosts without the reference). */
+int gphip_ns_crude_weights(const double* points, const double* loglik, int64_t m, int p, int pool, int64_t* order,
+                           double* logx, double* logw, double* log_evidence);
+
 /* Options (tuning knobs; results do not depend on them beyond rounding order):
  *   "panel"        outer panel width in 128-tiles (default 4)
  *   "panel_wide"   0/1 (default 1): single-device schedule uses 2x / 1.5x that width while >= 192 / >= 128 tile columns
@@ -199,6 +233,9 @@ int gphip_logdet(gphip_handle h, double* out);
  *                  distributed and gphip_predict streams its panels through the ranks once more (a COLLECTIVE call for
  *                  rank handles in separate processes); 1: every rank keeps the dense workspace and receives panels in
  *                  place, so that after a fit all ranks hold all of L and prediction needs no further traffic
+ *   "share_local_panels"  0/1 (default 1): ranks that share the owner's GPU (virtual ranks of a 1-GPU box, device-copy
+ *                  communicator) read a factored panel where the owner keeps it instead of copying it; 0 forces the copies
+ *                  through the rotating receive buffers (what distinct GPUs do)
  *   "panel", "shard_min_n", "replicate_factor" must have the same value on every rank of a multi-process job (checked by
  *   one small all-reduce at the start of every sharded evaluation: a mismatch fails the call on ALL ranks). */
 int gphip_set_option(gphip_handle h, const char* name, double value);

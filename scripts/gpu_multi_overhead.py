@@ -31,6 +31,10 @@ g.close()
 for w in (2, 4, 8):
     g = _lib.Handle(X, y, "se_ard", device=[0] * w)
     g.set_option("shard_min_n", 0)
-    dt, r = timeit(g); print(f"N={n} {w} virtual ranks (copies):    {dt*1e3:8.2f} ms  ll={r[0]:.10g}", flush=True)
+    dt, r = timeit(g); print(f"N={n} {w} virtual ranks, panels read in place: {dt*1e3:8.2f} ms  ll={r[0]:.10g}", flush=True)
+    dt, r = timeit(g, fit=True); print(f"N={n}   ... fit (factor stays distributed):  {dt*1e3:8.2f} ms", flush=True)
+    g.set_option("share_local_panels", 0)
+    dt, r = timeit(g); print(f"N={n} {w} virtual ranks, device copies into receive buffers: {dt*1e3:8.2f} ms", flush=True)
+    g.set_option("replicate_factor", 1)
     dt, r = timeit(g, fit=True); print(f"N={n}   ... fit (replicates L x{w}):  {dt*1e3:8.2f} ms", flush=True)
     g.close()

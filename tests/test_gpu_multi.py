@@ -79,6 +79,7 @@ def test_sharded_fit_and_predict_shards_test_points(replicate):
     g.set_option("shard_min_n", 0)
     g.set_option("panel", 2)
     g.set_option("replicate_factor", replicate)
+    g.set_option("share_local_panels", replicate)        # (0: copies through the rotating receive buffers, like distinct GPUs)
     assert g.fit(th) == 0
     mu, var = g.predict(Xs)
     mo, so = orc.predict_internal("matern52_ard", th, X, y, Xs)
@@ -197,6 +198,7 @@ def test_sharding_shards_memory(golden_dir):
     g = _lib.Handle(X, y, "se_ard", device=[0] * world)
     g.set_option("shard_min_n", 0)
     g.set_option("panel", 1)
+    g.set_option("share_local_panels", 0)                # behave like distinct GPUs: every rank receives into its own buffers
     ll, ld, qd, info = g.loglik_parts(th)
     assert info == 0 and close(ll, float(gold["loglik"][row]), n) and close(ld, float(gold["logdet"][row]), n)
     assert close(qd, float(gold["quad"][row]), n)

@@ -108,3 +108,76 @@ def test_min_max_acceptance_rate_window():
     assert abs(res["LogEvidence"]["Mean"] - want) < 4 * res["LogEvidence"]["StandardError"] + 0.25
     out = ns.nestedSampling(obj, SamplePoolSize=20, MonteCarloSteps=2, Walkers=4, Seed=1, MinMaxAcceptanceRate=(2.0, 3.0))
     assert out == "Bad likelihood function"
+
+
+# ---------------------------------------------------------------------------------------------
+# the native driver's deterministic pieces against this module (value for value), and the statistical law of the
+# batched-walker chain (stale candidates re-used after an exact rejection step) over many seeds
+# ---------------------------------------------------------------------------------------------
+def test_native_crude_weights_equal_the_python_restatement():
+    from bayesianinference_amd import _lib
+    rng = np.random.default_rng(5)
+    for m, p, pool in ((50, 2, 20), (300, 3, 100), (7, 1, 3), (2, 1, 1)):
+        pts = rng.random((m, p))
+        ll = rng.standard_normal(m) * 5
+        if m > 6:
+            ll[3] = ll[4]                                 # a tie: broken by the point (BS:822)
+        order, logx, logw, z = _lib.ns_crude_weights(pts, ll, pool)
+        o2, x2, w2 = ns.calculate_weights_crude(pts, ll, pool)
+        assert np.array_equal(order, o2)
+        np.testing.assert_allclose(logx, x2, rtol=0, atol=0)
+        np.testing.assert_allclose(logw, w2, rtol=1e-13, atol=1e-13)
+        assert z == pytest.approx(ns.log_sum_exp(w2), abs=1e-12)
+
+
+def _gaussian_problem():
+    """N(theta; mu, s^2 I) in d = 2 under a uniform prior on [-5, 5]^2: Z = (mass inside the box) / 100, closed form."""
+    mu, s = np.array([0.7, -1.1]), 0.5
+    from scipy.special import erf
+
+    def loglik(th):
+        th = np.atleast_2d(th)
+        return -0.5 * np.sum((th - mu) ** 2, axis=1) / s ** 2 - math.log(2 * math.pi * s ** 2)
+    mass = np.prod([0.5 * (erf((5 - m) / (s * math.sqrt(2))) - erf((-5 - m) / (s * math.sqrt(2)))) for m in mu])
+    params = [("a", -5.0, 5.0), ("b", -5.0, 5.0)]
+    return loglik, (lambda th: -math.log(100.0)), params, math.log(mass) - math.log(100.0)
+
+
+@pytest.mark.parametrize("walkers", [1, 32])
+def test_log_evidence_is_unbiased_over_20_seeds(walkers):
+    """z-scores of log Z over 20 seeds on a closed-form evidence: the lock-step walkers with stale-candidate reuse must
+    not bias the estimate (|mean z| < 0.5 -- a 2.2 sigma band for 20 unit normals) and the quoted standard error must be
+    of the right size (0.5 < sd z < 2)."""
+    loglik, logprior, params, want = _gaussian_problem()
+    zs = []
+    for seed in range(20):
+        rng = np.random.default_rng(1000 + seed)
+        start = -5 + 10 * rng.random((60, 2))
+        res = ns.nested_sampling_internal(loglik, logprior, start, params, SamplePoolSize=60, MonteCarloSteps=25,
+                                          Walkers=walkers, Seed=seed, PostProcessSamplingRuns=60)
+        zs.append((res["LogEvidence"]["Mean"] - want) / res["LogEvidence"]["StandardError"])
+    zs = np.array(zs)
+    assert abs(zs.mean()) < 0.5, zs
+    assert 0.5 < zs.std(ddof=1) < 2.0, zs
+
+
+@pytest.mark.parametrize("walkers", [1, 32])
+def test_prior_mass_shrinks_like_minus_i_over_n(walkers):
+    """The sequential law log X_i = -i/n (BS:790-802): for L = -theta^2 under U[-1, 1] the prior mass above a dead point
+    is X = |theta| exactly, so log X_true(i) + i/n is a sum of i independent errors of sd 1/n.  Over 20 seeds the mean
+    standardised deviation must vanish -- for ONE walker (the reference's chain) and for the batched walkers alike."""
+    n = 50
+    params = [("t", -1.0, 1.0)]
+    devs = []
+    for seed in range(20):
+        rng = np.random.default_rng(77 + seed)
+        start = -1 + 2 * rng.random((n, 1))
+        res = ns.nested_sampling_internal(lambda th: -np.atleast_2d(th)[:, 0] ** 2, lambda th: -math.log(2.0), start, params,
+                                          SamplePoolSize=n, MonteCarloSteps=20, Walkers=walkers, Seed=seed, MinIterations=250,
+                                          MaxIterations=250, PostProcessSamplingRuns=0)
+        ll = np.sort(res["LogLikelihood"])                # dead points in order of deletion, then the live set
+        for i in (50, 100, 200):
+            devs.append((0.5 * math.log(-ll[i - 1]) + i / n) / (math.sqrt(i) / n))
+    devs = np.array(devs).reshape(20, 3)
+    assert np.all(np.abs(devs.mean(axis=0)) < 0.6), devs.mean(axis=0)
+    assert np.all(devs.std(axis=0, ddof=1) < 2.0)
