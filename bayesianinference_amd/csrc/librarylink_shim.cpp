@@ -15,6 +15,7 @@
 // the WL closure stays numeric for every theta (BayesianStatistics.wl:276-298).  Status map: GPHIP_ERR_ARG ->
 // LIBRARY_TYPE_ERROR, GPHIP_ERR_DIM -> LIBRARY_DIMENSION_ERROR, everything else -> LIBRARY_FUNCTION_ERROR; wrong
 // argument count -> LIBRARY_FUNCTION_ERROR; wrong tensor rank -> LIBRARY_RANK_ERROR.
+#include <algorithm>
 #include <limits>
 #include <vector>
 
@@ -23,6 +24,7 @@
 
 static std::vector<gphip_handle> g_handles;
 static std::vector<mint> g_n;              // training-set size per handle
+static std::vector<mint> g_d;              // input dimension per handle (test points must have this many columns)
 
 EXTERN_C DLLEXPORT mint WolframLibrary_getVersion() { return WolframLibraryVersion; }
 EXTERN_C DLLEXPORT int WolframLibrary_initialize(WolframLibraryData) { return LIBRARY_NO_ERROR; }
@@ -30,6 +32,24 @@ EXTERN_C DLLEXPORT void WolframLibrary_uninitialize(WolframLibraryData) {
     for (auto h : g_handles) gphip_destroy(h);
     g_handles.clear();
     g_n.clear();
+    g_d.clear();
+}
+
+// a real tensor of the given rank; 0 = fine, else the LIBRARY_* code to return
+static int want_real(WolframLibraryData lib, MTensor t, mint rank) {
+    if (lib->MTensor_getRank(t) != rank) return LIBRARY_RANK_ERROR;
+    if (lib->MTensor_getType(t) != MType_Real) return LIBRARY_TYPE_ERROR;
+    return 0;
+}
+// optional per-point array: an EMPTY list stands for "the constant form" (null pointer at the C ABI); otherwise a real
+// tensor with exactly `count` elements
+static int optional_values(WolframLibraryData lib, MTensor t, mint count, const double** out) {
+    *out = nullptr;
+    if (lib->MTensor_getFlattenedLength(t) == 0) return 0;
+    if (lib->MTensor_getType(t) != MType_Real) return LIBRARY_TYPE_ERROR;
+    if (lib->MTensor_getFlattenedLength(t) != count) return LIBRARY_DIMENSION_ERROR;
+    *out = lib->MTensor_getRealData(t);
+    return 0;
 }
 
 static gphip_handle lookup(mint id) {
@@ -66,6 +86,7 @@ EXTERN_C DLLEXPORT int gphip_wl_create(WolframLibraryData lib, mint argc, MArgum
     if (rc != GPHIP_OK) return status_to_wl(rc);
     g_handles.push_back(h);
     g_n.push_back(dims[0]);
+    g_d.push_back(dims[1]);
     MArgument_setInteger(res, (mint)g_handles.size() - 1);
     return LIBRARY_NO_ERROR;
 }
@@ -197,10 +218,12 @@ EXTERN_C DLLEXPORT int gphip_wl_logdet(WolframLibraryData, mint argc, MArgument*
 // gphip_wl_predict[h, Xs (M x d)] -> 2 x M {means, variances}
 EXTERN_C DLLEXPORT int gphip_wl_predict(WolframLibraryData lib, mint argc, MArgument* args, MArgument res) {
     if (argc != 2) return LIBRARY_FUNCTION_ERROR;
-    gphip_handle h = lookup(MArgument_getInteger(args[0]));
+    const mint id = MArgument_getInteger(args[0]);
+    gphip_handle h = lookup(id);
     MTensor xs = MArgument_getMTensor(args[1]);
     if (!h) return LIBRARY_FUNCTION_ERROR;
-    if (lib->MTensor_getRank(xs) != 2) return LIBRARY_RANK_ERROR;
+    if (int e = want_real(lib, xs, 2)) return e;
+    if (lib->MTensor_getDimensions(xs)[1] != g_d[(size_t)id]) return LIBRARY_DIMENSION_ERROR;   // the C ABI reads M * d doubles
     const mint M = lib->MTensor_getDimensions(xs)[0];
     MTensor r; mint d[2] = {2, M};
     if (lib->MTensor_new(MType_Real, 2, d, &r)) return LIBRARY_FUNCTION_ERROR;
@@ -215,10 +238,13 @@ EXTERN_C DLLEXPORT int gphip_wl_predict(WolframLibraryData lib, mint argc, MArgu
 // a sample whose K is not positive definite comes back as NaN rows (result value, not an error)
 EXTERN_C DLLEXPORT int gphip_wl_predict_samples(WolframLibraryData lib, mint argc, MArgument* args, MArgument res) {
     if (argc != 3) return LIBRARY_FUNCTION_ERROR;
-    gphip_handle h = lookup(MArgument_getInteger(args[0]));
+    const mint id = MArgument_getInteger(args[0]);
+    gphip_handle h = lookup(id);
     MTensor th = MArgument_getMTensor(args[1]), xs = MArgument_getMTensor(args[2]);
     if (!h) return LIBRARY_FUNCTION_ERROR;
-    if (lib->MTensor_getRank(th) != 2 || lib->MTensor_getRank(xs) != 2) return LIBRARY_RANK_ERROR;
+    if (int e = want_real(lib, th, 2)) return e;
+    if (int e = want_real(lib, xs, 2)) return e;
+    if (lib->MTensor_getDimensions(xs)[1] != g_d[(size_t)id]) return LIBRARY_DIMENSION_ERROR;
     const mint S = lib->MTensor_getDimensions(th)[0], p = lib->MTensor_getDimensions(th)[1];
     const mint M = lib->MTensor_getDimensions(xs)[0];
     MTensor r; mint d[3] = {2, S, M};
@@ -262,7 +288,9 @@ EXTERN_C DLLEXPORT int gphip_wl_cross_covariance(WolframLibraryData lib, mint ar
     gphip_handle h = lookup(id);
     MTensor th = MArgument_getMTensor(args[1]), xs = MArgument_getMTensor(args[2]);
     if (!h) return LIBRARY_FUNCTION_ERROR;
-    if (lib->MTensor_getRank(th) != 1 || lib->MTensor_getRank(xs) != 2) return LIBRARY_RANK_ERROR;
+    if (int e = want_real(lib, th, 1)) return e;
+    if (int e = want_real(lib, xs, 2)) return e;
+    if (lib->MTensor_getDimensions(xs)[1] != g_d[(size_t)id]) return LIBRARY_DIMENSION_ERROR;
     const mint N = g_n[(size_t)id], M = lib->MTensor_getDimensions(xs)[0];
     MTensor r; mint d[2] = {N + 1, M};
     if (lib->MTensor_new(MType_Real, 2, d, &r)) return LIBRARY_FUNCTION_ERROR;
@@ -270,6 +298,143 @@ EXTERN_C DLLEXPORT int gphip_wl_cross_covariance(WolframLibraryData lib, mint ar
     int rc = gphip_cross_covariance(h, lib->MTensor_getRealData(th), (int)lib->MTensor_getDimensions(th)[0],
                                     lib->MTensor_getRealData(xs), M, o, o + N * M);
     if (rc != GPHIP_OK) { lib->MTensor_free(r); return status_to_wl(rc); }
+    MArgument_setMTensor(res, r);
+    return LIBRARY_NO_ERROR;
+}
+
+// gphip_wl_device_count[] -> number of gfx950 devices visible to this process (sub-kernels of parallelNestedSampling
+// pick Mod[$KernelID, count], BayesianStatistics.wl:1349-1357)
+EXTERN_C DLLEXPORT int gphip_wl_device_count(WolframLibraryData, mint argc, MArgument*, MArgument res) {
+    if (argc != 0) return LIBRARY_FUNCTION_ERROR;
+    int n = 0;
+    gphip_device_count(&n);
+    MArgument_setInteger(res, n);
+    return LIBRARY_NO_ERROR;
+}
+
+// ---- point-dependent nugget[x] / meanFunction[x] (BayesianGaussianProcess.wl:37, 113, 171, 300, 408): WL maps the two
+// functions over the points for the theta of the call and passes the VALUES; an empty list = the constant form.
+// gphip_wl_loglik_batch_pw[h, Theta (B x p), meanTrain (B x N | {}), nuggetTrain (B x N | {})] -> B x 2 {{value, info}..}
+EXTERN_C DLLEXPORT int gphip_wl_loglik_batch_pw(WolframLibraryData lib, mint argc, MArgument* args, MArgument res) {
+    if (argc != 4) return LIBRARY_FUNCTION_ERROR;
+    const mint id = MArgument_getInteger(args[0]);
+    gphip_handle h = lookup(id);
+    MTensor th = MArgument_getMTensor(args[1]);
+    if (!h) return LIBRARY_FUNCTION_ERROR;
+    if (int e = want_real(lib, th, 2)) return e;
+    const mint* dims = lib->MTensor_getDimensions(th);
+    const double *mt = nullptr, *nt = nullptr;
+    if (int e = optional_values(lib, MArgument_getMTensor(args[2]), dims[0] * g_n[(size_t)id], &mt)) return e;
+    if (int e = optional_values(lib, MArgument_getMTensor(args[3]), dims[0] * g_n[(size_t)id], &nt)) return e;
+    std::vector<double> out((size_t)dims[0]);
+    std::vector<int> info((size_t)dims[0]);
+    int rc = gphip_loglik_batch_pw(h, lib->MTensor_getRealData(th), (int)dims[0], (int)dims[1], mt, nt, out.data(), info.data());
+    if (rc != GPHIP_OK) return status_to_wl(rc);
+    MTensor r; mint d[2] = {dims[0], 2};
+    if (lib->MTensor_new(MType_Real, 2, d, &r)) return LIBRARY_FUNCTION_ERROR;
+    double* p = lib->MTensor_getRealData(r);
+    for (mint i = 0; i < dims[0]; ++i) { p[2 * i] = info[(size_t)i] == 0 ? out[(size_t)i] : 0.0; p[2 * i + 1] = info[(size_t)i]; }
+    MArgument_setMTensor(res, r);
+    return LIBRARY_NO_ERROR;
+}
+
+// gphip_wl_fit_pw[h, theta, meanTrain (N | {}), nuggetTrain (N | {})] -> info
+EXTERN_C DLLEXPORT int gphip_wl_fit_pw(WolframLibraryData lib, mint argc, MArgument* args, MArgument res) {
+    if (argc != 4) return LIBRARY_FUNCTION_ERROR;
+    const mint id = MArgument_getInteger(args[0]);
+    gphip_handle h = lookup(id);
+    MTensor th = MArgument_getMTensor(args[1]);
+    if (!h) return LIBRARY_FUNCTION_ERROR;
+    if (int e = want_real(lib, th, 1)) return e;
+    const double *mt = nullptr, *nt = nullptr;
+    if (int e = optional_values(lib, MArgument_getMTensor(args[2]), g_n[(size_t)id], &mt)) return e;
+    if (int e = optional_values(lib, MArgument_getMTensor(args[3]), g_n[(size_t)id], &nt)) return e;
+    int info = 0;
+    int rc = gphip_fit_pw(h, lib->MTensor_getRealData(th), (int)lib->MTensor_getDimensions(th)[0], mt, nt, &info);
+    if (rc != GPHIP_OK) return status_to_wl(rc);
+    MArgument_setInteger(res, info);
+    return LIBRARY_NO_ERROR;
+}
+
+// gphip_wl_predict_samples_pw[h, Thetas (S x p), meanTrain (S x N | {}), nuggetTrain (S x N | {}), Xs (M x d),
+//                             meanTest (S x M | {}), nuggetTest (S x M | {})] -> 2 x S x M {means, variances}
+EXTERN_C DLLEXPORT int gphip_wl_predict_samples_pw(WolframLibraryData lib, mint argc, MArgument* args, MArgument res) {
+    if (argc != 7) return LIBRARY_FUNCTION_ERROR;
+    const mint id = MArgument_getInteger(args[0]);
+    gphip_handle h = lookup(id);
+    MTensor th = MArgument_getMTensor(args[1]), xs = MArgument_getMTensor(args[4]);
+    if (!h) return LIBRARY_FUNCTION_ERROR;
+    if (int e = want_real(lib, th, 2)) return e;
+    if (int e = want_real(lib, xs, 2)) return e;
+    if (lib->MTensor_getDimensions(xs)[1] != g_d[(size_t)id]) return LIBRARY_DIMENSION_ERROR;
+    const mint S = lib->MTensor_getDimensions(th)[0], p = lib->MTensor_getDimensions(th)[1];
+    const mint M = lib->MTensor_getDimensions(xs)[0], N = g_n[(size_t)id];
+    const double *mt = nullptr, *nt = nullptr, *ms = nullptr, *nsx = nullptr;
+    if (int e = optional_values(lib, MArgument_getMTensor(args[2]), S * N, &mt)) return e;
+    if (int e = optional_values(lib, MArgument_getMTensor(args[3]), S * N, &nt)) return e;
+    if (int e = optional_values(lib, MArgument_getMTensor(args[5]), S * M, &ms)) return e;
+    if (int e = optional_values(lib, MArgument_getMTensor(args[6]), S * M, &nsx)) return e;
+    MTensor r; mint d[3] = {2, S, M};
+    if (lib->MTensor_new(MType_Real, 3, d, &r)) return LIBRARY_FUNCTION_ERROR;
+    double* out = lib->MTensor_getRealData(r);
+    std::vector<int> info((size_t)S);
+    int rc = gphip_predict_samples_pw(h, lib->MTensor_getRealData(th), (int)S, (int)p, mt, nt, lib->MTensor_getRealData(xs), M, ms,
+                                      nsx, out, out + S * M, info.data());
+    if (rc != GPHIP_OK) { lib->MTensor_free(r); return status_to_wl(rc); }
+    const double nan = std::numeric_limits<double>::quiet_NaN();
+    for (mint s = 0; s < S; ++s)
+        if (info[(size_t)s] != 0)
+            for (mint t = 0; t < M; ++t) out[s * M + t] = out[S * M + s * M + t] = nan;
+    MArgument_setMTensor(res, r);
+    return LIBRARY_NO_ERROR;
+}
+
+// gphip_wl_nested_sampling[h, box (p x 2), priorKinds (p integers: 0 uniform, 1 log-uniform), opts (real vector:
+//   pool, maxIterations, minIterations, mcSteps, walkers, terminationFraction, minAccept, maxAccept, seed),
+//   start (pool x p | {})] -> n x (p + 3): {point.., logLikelihood, logPriorPDF, acceptanceRate (NaN for the pool)} per
+// sample in generation order.  The native driver of nestedSamplingInternal (BayesianStatistics.wl:859-1040); the WL
+// package wraps the rows into the reference's "Samples" association and calls the reference's evidenceSampling on it.
+EXTERN_C DLLEXPORT int gphip_wl_nested_sampling(WolframLibraryData lib, mint argc, MArgument* args, MArgument res) {
+    if (argc != 5) return LIBRARY_FUNCTION_ERROR;
+    gphip_handle h = lookup(MArgument_getInteger(args[0]));
+    MTensor box = MArgument_getMTensor(args[1]), kinds = MArgument_getMTensor(args[2]), ov = MArgument_getMTensor(args[3]),
+            st = MArgument_getMTensor(args[4]);
+    if (!h) return LIBRARY_FUNCTION_ERROR;
+    if (int e = want_real(lib, box, 2)) return e;
+    if (int e = want_real(lib, ov, 1)) return e;
+    if (lib->MTensor_getRank(kinds) != 1) return LIBRARY_RANK_ERROR;
+    if (lib->MTensor_getType(kinds) != MType_Integer) return LIBRARY_TYPE_ERROR;
+    int p = 0;
+    gphip_num_params(h, &p);
+    if (lib->MTensor_getDimensions(box)[0] != p || lib->MTensor_getDimensions(box)[1] != 2 || lib->MTensor_getDimensions(kinds)[0] != p ||
+        lib->MTensor_getDimensions(ov)[0] != 9)
+        return LIBRARY_DIMENSION_ERROR;
+    const double* o = lib->MTensor_getRealData(ov);
+    gphip_ns_options opt;
+    gphip_ns_default_options(&opt);
+    opt.pool = (int)o[0]; opt.max_iterations = (int)o[1]; opt.min_iterations = (int)o[2]; opt.mc_steps = (int)o[3];
+    opt.walkers = (int)o[4]; opt.termination_fraction = o[5]; opt.min_accept = o[6]; opt.max_accept = o[7]; opt.seed = (uint64_t)o[8];
+    if (opt.pool < 2) return LIBRARY_DIMENSION_ERROR;
+    const double* start = nullptr;
+    if (int e = optional_values(lib, st, (mint)opt.pool * p, &start)) return e;
+    std::vector<int> kd((size_t)p);
+    for (int j = 0; j < p; ++j) kd[(size_t)j] = (int)lib->MTensor_getIntegerData(kinds)[j];
+    const int64_t cap = (int64_t)opt.pool + std::max(opt.max_iterations, opt.min_iterations) + 1;
+    std::vector<double> pts((size_t)cap * p), ll((size_t)cap), lp((size_t)cap), ar((size_t)cap);
+    int64_t n = 0, ne = 0;
+    double z = 0.0;
+    int rc = gphip_nested_sampling(h, lib->MTensor_getRealData(box), kd.data(), nullptr, nullptr, &opt, start, cap, pts.data(), ll.data(),
+                                   lp.data(), ar.data(), &n, &z, &ne);
+    if (rc != GPHIP_OK) return status_to_wl(rc);
+    MTensor r; mint d[2] = {(mint)n, (mint)p + 3};
+    if (lib->MTensor_new(MType_Real, 2, d, &r)) return LIBRARY_FUNCTION_ERROR;
+    double* out = lib->MTensor_getRealData(r);
+    for (int64_t i = 0; i < n; ++i) {
+        for (int j = 0; j < p; ++j) out[i * (p + 3) + j] = pts[(size_t)(i * p + j)];
+        out[i * (p + 3) + p] = ll[(size_t)i];
+        out[i * (p + 3) + p + 1] = lp[(size_t)i];
+        out[i * (p + 3) + p + 2] = ar[(size_t)i];
+    }
     MArgument_setMTensor(res, r);
     return LIBRARY_NO_ERROR;
 }

@@ -156,6 +156,7 @@ def nested_sampling_internal(loglik, logprior, starting_points, params, **opts):
     log_evidence, entropy, iteration = MACHINE_LOG_ZERO, 0.0, 1
     cand_pts = np.zeros((0, pts.shape[1]))
     cand_ll = np.zeros(0)
+    cand_rate = np.zeros(0)                                       # acceptance rate of the walker batch a candidate came from
     n_evals = n
     while iteration <= max_it:
         if iteration > 1 and iteration > min_it:                  # stop rule BS:967-978
@@ -167,8 +168,8 @@ def nested_sampling_internal(loglik, logprior, starting_points, params, **opts):
         threshold = ll[best].min()
         cov = 0.5 * (cov + np.atleast_2d(np.cov(pts[best].T)))    # BS:988
         keep = cand_ll > threshold                                # exact rejection of stale candidates
-        cand_pts, cand_ll = cand_pts[keep], cand_ll[keep]
-        factor, rate = 1.0, np.nan
+        cand_pts, cand_ll, cand_rate = cand_pts[keep], cand_ll[keep], cand_rate[keep]
+        factor = 1.0
         rmin, rmax = o["MinMaxAcceptanceRate"]
         while len(cand_ll) == 0:
             steps = int(math.ceil(factor * o["MonteCarloSteps"]))
@@ -178,16 +179,17 @@ def nested_sampling_internal(loglik, logprior, starting_points, params, **opts):
             # BS:990-1004: the chain is re-run with 1.25x the steps until its acceptance rate lies inside
             # "MinMaxAcceptanceRate" (Between[rate, {min, max}], default {0, 1} = always); here the rate is that of
             # the whole walker batch, and a batch outside the window is discarded like the reference's chain
+            cand_rate = np.full(len(cand_ll), rate)
             if not (rmin <= rate <= rmax):
-                cand_pts, cand_ll = cand_pts[:0], cand_ll[:0]
+                cand_pts, cand_ll, cand_rate = cand_pts[:0], cand_ll[:0], cand_rate[:0]
             factor *= 1.25                                        # BS:1003 step inflation on failure
             if factor > 50:
                 return "Bad likelihood function"
         pts = np.vstack([pts, cand_pts[:1]])
         ll = np.append(ll, cand_ll[0])                            # BS:1012 (value carried from the chain)
         lpr = np.append(lpr, logprior(cand_pts[0]))
-        acc_rates.append(rate)
-        cand_pts, cand_ll = cand_pts[1:], cand_ll[1:]
+        acc_rates.append(cand_rate[0])
+        cand_pts, cand_ll, cand_rate = cand_pts[1:], cand_ll[1:], cand_rate[1:]
         order, logx, logw = calculate_weights_crude(pts, ll, n)
         log_evidence = log_sum_exp(logw)                          # BS:1019
         entropy = calculate_entropy(logw, ll[order], log_evidence)

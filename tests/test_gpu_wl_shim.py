@@ -191,3 +191,75 @@ def test_every_shim_entry_point_through_a_fake_wolfram_library_data():
     # its error path; no "Constant" argument was freed
     assert K.lib.drv_live() == live0 and K.lib.drv_const_frees() == 0
     K.lib.WolframLibrary_uninitialize(K.data)
+
+
+def test_new_shim_entry_points_pointwise_kernels_device_count_and_native_sampler():
+    K = Kernel()
+    n, d = 200, 2
+    X, y = syn.make_dataset(n, d)
+    live0 = K.lib.drv_live()
+    rc, ndev = K.call("gphip_wl_device_count", [], "int")
+    assert rc == NO_ERROR and ndev >= 1
+    # a composed kernel through the integer code of GPHIP_KERNEL_COMPOSE: SE-ARD + Matern-3/2 + const
+    kid = _lib.kernel_id("se_ard+matern32+const")
+    rc, h = K.call("gphip_wl_create", [X, y, kid, 0, 64, np.array([0])], "int")
+    assert rc == NO_ERROR
+    th = np.array([0.6, 1.4, 0.8, 1.9, 0.7, 0.05, 0.2])
+    rc, r = K.call("gphip_wl_loglik", [h, th])
+    want = orc.log_likelihood("se_ard+matern32+const", th, X, y)
+    assert rc == NO_ERROR and r[1] == 0 and abs(r[0] - want) <= 1e-8 * max(abs(want), n)
+
+    # test points of the wrong width: LIBRARY_DIMENSION_ERROR, not an out-of-bounds read
+    Xs = syn.make_test_points(9, d)
+    assert K.call("gphip_wl_fit", [h, th], "int") == (NO_ERROR, 0)
+    bad = syn.make_test_points(9, d + 1)
+    assert K.call("gphip_wl_predict", [h, bad])[0] == DIMENSION_ERROR
+    assert K.call("gphip_wl_predict_samples", [h, th[None, :], bad])[0] == DIMENSION_ERROR
+    assert K.call("gphip_wl_cross_covariance", [h, th, bad])[0] == DIMENSION_ERROR
+    assert K.call("gphip_wl_predict", [h, Xs.astype(np.int64)])[0] == TYPE_ERROR
+
+    # point-dependent nugget / mean: values per theta; an empty list = the constant form
+    nf = lambda x: 0.04 * (1.0 + x[0] ** 2)                   # noqa: E731
+    mf = lambda x: 0.1 - 0.3 * x[1]                           # noqa: E731
+    nug = np.array([nf(x) for x in X])
+    mean = np.array([mf(x) for x in X])
+    Th = np.stack([th, th * 1.05])
+    empty = np.zeros(0)
+    rc, r = K.call("gphip_wl_loglik_batch_pw", [h, Th, np.stack([mean, mean]), np.stack([nug, nug])])
+    w0 = orc.log_likelihood("se_ard+matern32+const", Th[0], X, y, nugget_fn=nf, mean_fn=mf)
+    assert rc == NO_ERROR and r.shape == (2, 2) and r[0, 1] == 0 and abs(r[0, 0] - w0) <= 1e-8 * max(abs(w0), n)
+    rc, r = K.call("gphip_wl_loglik_batch_pw", [h, Th, empty, empty])               # both constant: the plain closure
+    assert rc == NO_ERROR and abs(r[0, 0] - want) <= 1e-8 * max(abs(want), n)
+    assert K.call("gphip_wl_loglik_batch_pw", [h, Th, mean, empty])[0] == DIMENSION_ERROR     # B x N expected
+    assert K.call("gphip_wl_fit_pw", [h, th, mean, nug], "int") == (NO_ERROR, 0)
+    Kmat = orc.covariance_matrix("se_ard+matern32+const", th, X, nugget_fn=nf)
+    rc, ld = K.call("gphip_wl_logdet", [h], "real")
+    assert rc == NO_ERROR and abs(ld - np.linalg.slogdet(Kmat)[1]) <= 1e-8 * n
+    nug_s, mean_s = np.array([nf(x) for x in Xs]), np.array([mf(x) for x in Xs])
+    rc, r = K.call("gphip_wl_predict_samples_pw", [h, th[None, :], mean[None, :], nug[None, :], Xs, mean_s[None, :], nug_s[None, :]])
+    mo, so = orc.predict_internal("se_ard+matern32+const", th, X, y, Xs, nugget_fn=nf, mean_fn=mf)
+    assert rc == NO_ERROR and r.shape == (2, 1, 9)
+    np.testing.assert_allclose(r[0, 0], mo, rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(np.sqrt(r[1, 0]), so, rtol=1e-7)
+
+    # the native sampler: rows {point.., loglik, logprior, acceptance rate}; the pool first (acceptance rate NaN)
+    rc, hs = K.call("gphip_wl_create", [X[:64, :1].copy(), y[:64].copy(), 0, 0, 64, np.array([0])], "int")
+    box = np.array([[0.05, 1.5], [0.2, 3.0], [0.03, 0.6]])
+    opts = np.array([30, 120, 20, 10, 8, 0.01, 0.0, 1.0, 3.0])
+    rc, rows = K.call("gphip_wl_nested_sampling", [hs, box, np.zeros(3, np.int64), opts, empty])
+    assert rc == NO_ERROR and rows.ndim == 2 and rows.shape[1] == 6 and rows.shape[0] > 30
+    assert np.all(np.isnan(rows[:30, 5])) and np.all(np.isfinite(rows[30:, 5]))
+    assert np.all((rows[:, :3] >= box[:, 0]) & (rows[:, :3] <= box[:, 1]))
+    ll0, info = _lib.Handle(X[:64, :1], y[:64], "se").loglik(rows[40, :3])
+    assert info == 0 and abs(ll0 - rows[40, 3]) <= 1e-8 * max(abs(ll0), 64)
+    np.testing.assert_allclose(rows[:, 4], -np.sum(np.log(box[:, 1] - box[:, 0])))            # uniform prior density
+    start = rows[:30, :3].copy()
+    rc, rows2 = K.call("gphip_wl_nested_sampling", [hs, box, np.zeros(3, np.int64), opts, start])
+    assert rc == NO_ERROR and np.array_equal(rows2[:30, :3], start)
+    assert K.call("gphip_wl_nested_sampling", [hs, box[:2], np.zeros(3, np.int64), opts, empty])[0] == DIMENSION_ERROR
+    assert K.call("gphip_wl_nested_sampling", [hs, box, np.zeros(3, np.int64), opts[:5], empty])[0] == DIMENSION_ERROR
+
+    for hh in (h, hs):
+        assert K.call("gphip_wl_destroy", [hh], "int") == (NO_ERROR, 0)
+    assert K.lib.drv_live() == live0 and K.lib.drv_const_frees() == 0
+    K.lib.WolframLibrary_uninitialize(K.data)

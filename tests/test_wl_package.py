@@ -20,21 +20,20 @@ def wl_bindings():
     text = re.sub(r"\(\*.*?\*\)", "", text, flags=re.S)
     out = {}
     for m in re.finditer(r'LibraryFunctionLoad\[\$GPHIPLibrary,\s*"(\w+)",\s*\{', text):
-        i, depth, args, cur = m.end(), 1, 0, False
+        i, depth, args, seen = m.end(), 1, 0, False
         while depth:                                   # count top-level elements of the argument list
             ch = text[i]
             if ch in "{[":
                 depth += 1
-                cur = True
+                seen = True
             elif ch in "}]":
                 depth -= 1
             elif ch == "," and depth == 1:
                 args += 1
-                cur = False
             elif not ch.isspace():
-                cur = True
+                seen = True
             i += 1
-        out[m.group(1)] = args + 1
+        out[m.group(1)] = args + 1 if seen else 0      # ({} = no arguments)
     return out
 
 
@@ -47,7 +46,7 @@ def shim_argc():
 
 def test_every_wl_binding_matches_a_shim_entry_point():
     wl, shim = wl_bindings(), shim_argc()
-    assert len(wl) == 13 and set(wl) == set(shim), (sorted(wl), sorted(shim))
+    assert len(wl) == 18 and set(wl) == set(shim), (sorted(wl), sorted(shim))
     assert wl == shim, {k: (wl[k], shim[k]) for k in wl if wl[k] != shim[k]}
 
 
@@ -84,9 +83,27 @@ def test_wl_package_keeps_reference_shapes():
     # of equal specificity is never reached)
     assert re.search(r"DownValues\[predictFromGaussianProcess\]\s*=\s*Prepend\[", text)
     assert re.search(r"DownValues\[predictiveDistribution\]\s*=\s*Join\[\s*\{", text)      # new rules FIRST
-    # brackets balance (the nearest thing to a syntax check available without a Wolfram kernel)
-    code = re.sub(r"\(\*.*?\*\)", "", text, flags=re.S)
-    code = re.sub(r'"(?:[^"\\]|\\.)*"', '""', code)
-    for a, b in ("[]", "{}", "()"):
-        assert code.count(a) == code.count(b), (a, code.count(a), code.count(b))
+    # brackets NEST properly once comments and strings are blanked (the nearest thing to a syntax check available
+    # without a Wolfram kernel; it also catches a "*)" inside a comment, which ends the comment early)
+    def blank(m):
+        return re.sub(r"[^\n]", " ", m.group(0))
+    code = re.sub(r"\(\*.*?\*\)", blank, text, flags=re.S)
+    code = re.sub(r'"(?:[^"\\]|\\.)*"', blank, code)
+    stack, line = [], 1
+    pairs = {")": "(", "]": "[", "}": "{"}
+    for ch in code:
+        if ch == "\n":
+            line += 1
+        elif ch in "([{":
+            stack.append((ch, line))
+        elif ch in ")]}":
+            assert stack and stack[-1][0] == pairs[ch], (ch, line, stack[-1:] )
+            stack.pop()
+    assert not stack, stack[-3:]
     assert code.count("<|") == code.count("|>")
+    # the reference's own argument list, the fall-through for non-native kernels, the device count and the native sampler
+    assert re.search(r"defineGaussianProcessHIP\[\s*dataIn_List.*?kerf_, nugf_, meanf_,", text, flags=re.S)     # BGP:228-234
+    assert "Return @ defineGaussianProcess[dataIn -> dataOut, kerf, nugf, meanf, variables, variablePrior" in text
+    assert "Mod[$KernelID, Max[gpDevices[], 1]]" in text and "Mod[$KernelID, 8]" not in text
+    assert "evidenceSampling[" in text and "gpNested[" in text                                               # BS:1158-1291
+    assert "expressionToFunction[nugf, vars -> paramVector]" in text                                       # BGP:257-262
