@@ -933,6 +933,9 @@ struct GemmArgs {
     // a_k0 / b_k0 = tile column where the operand panel starts.  The base pointer may be shifted so that a panel kept
     // OUTSIDE the workspace (a received panel of the multi-GPU schedule) is addressed with its global tile indices.
     int c_R, a_R, b_R, a_k0, b_k0;
+    int b_lower;                                 // ROLE 2: the J operand is a LOWER-TRIANGULAR 128 x 128 block with explicit zeros above
+                                                 //    the diagonal (W_b = L_bb^-1): B(j, k) = 0 for k > j, so the MFMAs of a 16-column
+                                                 //    group whose columns all lie left of the current k-group are skipped (they add 0)
     const long* c_adj; int c_adj_panel;          // C in a rank's COMPACT own-panel storage (multi-GPU): tiles to add to the dense index
                                                  // of a tile of outer panel panel_slot(tj, c_R - 1, c_adj_panel); null: dense
     int K;                                       // multiple of GK
@@ -1209,22 +1212,36 @@ __global__ __launch_bounds__(64 * NWI * NWJ, (NWI * NWJ == 4) ? 2 : 4) void gemm
 #pragma unroll
         for (int f = 0; f < FJ; ++f) asm volatile("" : "+v"(fj[f]));
     };
-    auto mfma_block = [&](const T* fi, const T* fj, auto nyc) {
+    // kfirst = first k of this k-group (ROLE 2 with a lower-triangular J operand only: see GemmArgs::b_lower)
+    const int jbase = (uw / NWI) * (16 * FJ) + 15;           // last column of this wave's first 16-column group
+    auto mfma_block = [&](const T* fi, const T* fj, auto nyc, int kfirst) {
         constexpr int NY = decltype(nyc)::value;
         T nj[FJ];
 #pragma unroll
         for (int f = 0; f < FJ; ++f) nj[f] = from_zero ? fj[f] : -fj[f];
+        if constexpr (ROLE == 2) {
+            // column group x holds j <= jbase + 16 x: all of its B(j, k) are zero once k > that
+            const int d = g.b_lower ? kfirst - jbase : 0;
+            const int xskip = d > 0 ? (d + 15) >> 4 : 0;
 #pragma unroll
-        for (int x = 0; x < FJ; ++x)
+            for (int x = 0; x < FJ; ++x)
+                if (x >= xskip) {
 #pragma unroll
-            for (int y = 0; y < NY; ++y) acc[x][y] = Num<T>::mfma(nj[x], fi[y], acc[x][y]);
+                    for (int y = 0; y < NY; ++y) acc[x][y] = Num<T>::mfma(nj[x], fi[y], acc[x][y]);
+                }
+        } else {
+#pragma unroll
+            for (int x = 0; x < FJ; ++x)
+#pragma unroll
+                for (int y = 0; y < NY; ++y) acc[x][y] = Num<T>::mfma(nj[x], fi[y], acc[x][y]);
+        }
     };
-    auto compute = [&](int buf) {
+    auto compute = [&](int buf, int kb) {
         T fi[FI], fj[FJ];
 #pragma unroll
         for (int kk = 0; kk < GK / 4; ++kk) {
             load_frags(buf, kk, fi, fj);
-            mfma_block(fi, fj, std::integral_constant<int, FI>{});
+            mfma_block(fi, fj, std::integral_constant<int, FI>{}, kb * GK + 4 * kk);
         }
     };
     if constexpr (NBUF == 2) {
@@ -1255,7 +1272,7 @@ __global__ __launch_bounds__(64 * NWI * NWJ, (NWI * NWJ == 4) ? 2 : 4) void gemm
                         __builtin_amdgcn_sched_barrier(0);
                         load_frags(cur, kk + 1, fa[(kk + 1) & 1], fb[(kk + 1) & 1]);   // ... before these reads
                         __builtin_amdgcn_sched_barrier(0);
-                        mfma_block(fa[kk & 1], fb[kk & 1], nyc);
+                        mfma_block(fa[kk & 1], fb[kk & 1], nyc, kb * GK + 4 * kk);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                     // every read of this stage has landed: once this wave's DMA has too, the barrier both
@@ -1267,7 +1284,7 @@ __global__ __launch_bounds__(64 * NWI * NWJ, (NWI * NWJ == 4) ? 2 : 4) void gemm
                 if (NY > 0) {
                     if (kb + 1 < nk) load_frags(cur ^ 1, 0, fa[0], fb[0]);
                     __builtin_amdgcn_sched_barrier(0);
-                    mfma_block(fa[(NKK - 1) & 1], fb[(NKK - 1) & 1], nyc);
+                    mfma_block(fa[(NKK - 1) & 1], fb[(NKK - 1) & 1], nyc, kb * GK + 4 * (NKK - 1));
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -1300,7 +1317,7 @@ __global__ __launch_bounds__(64 * NWI * NWJ, (NWI * NWJ == 4) ? 2 : 4) void gemm
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                  // stage kb landed for every wave; buffer (kb-1)%4 is free
             if (kb + AHEAD < nk) stage(kb + AHEAD, (kb + AHEAD) % NBUF);
-            compute(kb % NBUF);
+            compute(kb % NBUF, kb);
         }
     }
 

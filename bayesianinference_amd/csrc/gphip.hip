@@ -394,9 +394,17 @@ template <typename T>
 struct Opnd {
     const T* p; long ld; long bs; int R; int k0;
     const long* adj = nullptr; int adj_panel = 0;      // C only: compact own-panel storage of a rank (GemmArgs::c_adj)
+    int lower = 0;                                     // J operand only: lower-triangular block with explicit zeros above (W_b)
 };
 template <typename T>
 Opnd<T> cm(const T* p, long ld, long bs) { return Opnd<T>{p, ld, bs, 0, 0}; }
+// the 128-block inverse W_b = L_bb^-1 (lower triangular, explicit zeros above the diagonal) as the J operand of a solve
+template <typename T>
+Opnd<T> wb(const T* W, int b, long lrs) {
+    Opnd<T> o{W + (long)b * TB * TB - (long)b * TB, TB, lrs, 0, 0};
+    o.lower = 1;
+    return o;
+}
 template <typename T>
 Opnd<T> tl(const gphip_ctx* h, int k0 = 0, bool all_slots = true) {
     return Opnd<T>{(const T*)(h->ws_override ? h->ws_override : h->dA), TB, all_slots ? (long)h->slot_elems : 0l, (int)h->R, k0};
@@ -418,6 +426,7 @@ void launch_gemm(gphip_ctx* h, int cls, Opnd<T> Co, Opnd<T> Ao, Opnd<T> Bo, int 
     g.skip_upper = (h->thin_tiles && thin_row >= 0 && tri && mode == 0 && !ktri) ? 1 : 0;
     g.C = const_cast<T*>(Co.p); g.ldc = Co.ld; g.c_bstride = Co.bs; g.c_R = Co.R;
     g.c_adj = Co.adj; g.c_adj_panel = Co.adj_panel;
+    g.b_lower = Bo.lower;
     g.A = Ao.p; g.lda = Ao.ld; g.a_bstride = Ao.bs; g.a_R = Ao.R; g.a_k0 = Ao.k0;
     g.B = Bo.p; g.ldb = Bo.ld; g.b_bstride = Bo.bs; g.b_R = Bo.R; g.b_k0 = Bo.k0;
     g.K = K; g.r0 = r0; g.r1 = r1; g.c0 = c0; g.c1 = c1; g.tri = tri;
@@ -530,8 +539,7 @@ int queue_panel(gphip_ctx* h, int K0, int nin, int nslots) {
                                h->dPartial, Nt, h->dInfo, h->dSlotp);
         }
         // panel solve X <- X W_b^T for every row tile below the diagonal block (incl. rhs rows)
-        launch_gemm<T>(h, 2, tl<T>(h), tl<T>(h, b), cm<T>(W + (long)b * TB * TB - (long)b * TB, TB, lrs), TB, b + 1, R, b, b + 1,
-                       0, nslots, 1, 0, Nt);
+        launch_gemm<T>(h, 2, tl<T>(h), tl<T>(h, b), wb<T>(W, b, lrs), TB, b + 1, R, b, b + 1, 0, nslots, 1, 0, Nt);
         if (!left && s + 1 < nin)
             launch_gemm<T>(h, 3, tl<T>(h), tl<T>(h, b), tl<T>(h, b), TB, b + 1, R, b + 1, K0 + nin, 1, nslots, 0, 0, Nt);
     }
@@ -1147,8 +1155,8 @@ int queue_forward_panel(gphip_ctx* h, int64_t mpad, int nslots, int k0, int k1, 
     T *V = (T*)h->dV, *W = (T*)h->dW;
     auto rows_at = [&](int b) { return identity_rows ? std::min(Mt, b - b_start + 1) : Mt; };
     for (int b = k0; b < k1; ++b) {
-        launch_gemm<T>(h, 2, cm<T>(V, mpad, vs), cm<T>(V + (long)b * TB * mpad, mpad, vs),
-                       cm<T>(W + (long)b * TB * TB - (long)b * TB, TB, lrs), TB, 0, rows_at(b), b, b + 1, 0, nslots, 1);
+        launch_gemm<T>(h, 2, cm<T>(V, mpad, vs), cm<T>(V + (long)b * TB * mpad, mpad, vs), wb<T>(W, b, lrs), TB, 0, rows_at(b), b,
+                       b + 1, 0, nslots, 1);
         if (b + 1 < k1)
             launch_gemm<T>(h, 3, cm<T>(V, mpad, vs), cm<T>(V + (long)b * TB * mpad, mpad, vs), tl<T>(h, b), TB, 0, rows_at(b),
                            b + 1, k1, 0, nslots);
