@@ -140,6 +140,7 @@ struct gphip_ctx {
     void* ws_override = nullptr;                 // tl<T>() / queue_panel address this base instead of dA (one owned panel)
     bool dist_fit = false;                       // the factor of theta_fit is spread over the ranks (owned panels only)
     void* dZ = nullptr;                          // typed [Npad]: z = L^-1 r gathered while the panels stream by (sharded prediction)
+    bool z_vector = false;                       // the prediction epilogue reads z from dZ (set only inside predict_streamed)
     bool null_fit = false;                       // fitted state of a null-kernel handle (no factor: K = diag(sn^2))
     // Point-dependent nugget / mean of the CURRENT call (gphip_*_pw, BGP:37, 113, 300, 408): host rows [B][N] (training
     // points) and [S][M] (test points), null = the constant forms; device copies per workspace slot / prediction chunk
@@ -246,7 +247,7 @@ void free_slots(gphip_ctx* h) {
     h->hInvEll = h->hSlotp = h->hRes = nullptr;
     h->hInfo = nullptr;
     h->slots = 0;
-    h->fitted = false;
+    h->fitted = false; h->dist_fit = false;
     h->dist_fit = false;                       // (a distributed fit keeps its block inverses / scalars in these buffers)
 }
 
@@ -1050,7 +1051,7 @@ int eval_batch_local(gphip_ctx* h, const double* Theta, int B, int p, double* ou
     if (h->kernel_id == GPHIP_KERNEL_NULL) return null_kernel_batch(h, Theta, B, out, parts, info, nullptr);
     int rc = ensure_slots(h, B);
     if (rc) return rc;
-    h->fitted = false;
+    h->fitted = false; h->dist_fit = false;
     for (int s0 = 0; s0 < B; s0 += h->slots) {
         const int nb = (B - s0 < h->slots) ? (B - s0) : h->slots;
         rc = eval_chunk(h, Theta + (size_t)s0 * p, nb, out + s0, parts ? parts + 2 * s0 : nullptr, info + s0, s0);
@@ -1280,7 +1281,7 @@ int queue_predict_reduce(gphip_ctx* h, int64_t mc, int64_t mpad, int nslots) {
         ProfScope ps(h, 6, 4.0 * (double)mpad * h->Npad * nslots, (double)sizeof(T) * mpad * h->Npad * nslots);
         hipLaunchKernelGGL(predict_partial_kernel<T>, dim3((unsigned)Mt, (unsigned)nstrips, (unsigned)nslots), dim3(256),
                            (size_t)js * 8 + 8 * TB * 8, h->stream, (const T*)h->dV, (long)mpad, (long)mpad * h->Npad, (int)h->N,
-                           h->dist_fit ? (const T*)h->dZ : (const T*)h->dA, h->dist_fit ? 0 : (int)h->R, (long)h->slot_elems, js,
+                           h->z_vector ? (const T*)h->dZ : (const T*)h->dA, h->z_vector ? 0 : (int)h->R, (long)h->slot_elems, js,
                            h->dPart, nstrips);
         hipLaunchKernelGGL(predict_finish_kernel, dim3((unsigned)((mc + 255) / 256), (unsigned)nslots), dim3(256), 0, h->stream,
                            (const double*)h->dPart, nstrips, (long)mpad, (const double*)h->dSlotp, (int)mc, (long)mpad,
@@ -1772,7 +1773,8 @@ int gphip_loglik_grad(gphip_handle h, const double* theta, int p, double* out, d
         for (double v : alpha) sum += v;
         grad[o++] = sum;
     }
-    h->fitted = true;                                         // the factor of theta is still resident
+    h->fitted = true;                                         // the factor of theta is still resident (whole, on this device)
+    h->dist_fit = false;
     h->theta_fit.assign(theta, theta + p);
     h->logdet_fit = parts[0];
     h->mu_fit = h->hSlotp[2];
@@ -1803,6 +1805,7 @@ int gphip_fit(gphip_handle h, const double* theta, int p, int* info) {
             *info = !fin ? GPHIP_INFO_NAN : (pos && std::isfinite(ld) ? GPHIP_INFO_OK : GPHIP_INFO_NOT_SPD);
         }
         h->fitted = h->null_fit = (*info == 0);
+        h->dist_fit = false;
         h->theta_fit.assign(theta, theta + p);
         h->mu_fit = mu;
         h->kappa_fit = sn * sn;
@@ -1844,7 +1847,7 @@ int gphip_covariance(gphip_handle h, const double* theta, int p, double* K) {
     }
     int rc = ensure_slots(h, 1);
     if (rc) return rc;
-    h->fitted = false;
+    h->fitted = false; h->dist_fit = false;
     if (!stage_theta(h, 0, theta)) return fail(h, GPHIP_ERR_ARG, "non-finite or zero hyper-parameter");
     rc = copy_theta(h, 1);
     if (rc) return rc;
@@ -1880,7 +1883,7 @@ int gphip_cross_covariance(gphip_handle h, const double* theta, int p, const voi
     HIPCHK(hipSetDevice(h->device));
     int rc = ensure_slots(h, 1);
     if (rc) return rc;
-    h->fitted = false;
+    h->fitted = false; h->dist_fit = false;
     if (!stage_theta(h, 0, theta)) return fail(h, GPHIP_ERR_ARG, "non-finite or zero hyper-parameter");
     rc = copy_theta(h, 1);
     if (rc) return rc;
@@ -2075,6 +2078,7 @@ static int predict_streamed(gphip_handle h, const void* Xs, int64_t M, double* m
         HIPCHK(hipMemcpyAsync(&passes, h->dScal8, 8, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
     }
+    g->replicate = 0;                                                  // a distributed factor: owned panels + receive buffers
     rc = group_resize_packed(h, g);
     if (rc) return rc;
     std::vector<double> xt;
@@ -2155,7 +2159,9 @@ static int predict_streamed(gphip_handle h, const void* Xs, int64_t M, double* m
             HIPCHK(hipSetDevice(m->device));
             if (mcv[(size_t)i] > 0) {
                 const int64_t mc = mcv[(size_t)i], a = c0[(size_t)i];
+                m->z_vector = true;
                 DISPATCH(m, queue_predict_reduce, m, mc, mpadv[(size_t)i], 1);
+                m->z_vector = false;
                 HIPCHK(hipMemcpyAsync(mean + a, m->dMean, (size_t)mc * 8, hipMemcpyDeviceToHost, m->stream));
                 HIPCHK(hipMemcpyAsync(var + a, m->dVar, (size_t)mc * 8, hipMemcpyDeviceToHost, m->stream));
             }
@@ -2217,7 +2223,7 @@ int gphip_predict_samples(gphip_handle h, const double* Thetas, int S, int p, co
     HIPCHK(hipSetDevice(h->device));
     int rc = ensure_slots(h, S);
     if (rc) return rc;
-    h->fitted = false;
+    h->fitted = false; h->dist_fit = false;
     const double* X = static_cast<const double*>(Xs);
     const int64_t d = h->d;
     std::vector<double> xt, hm, hv, scratch_out(1), scratch_parts;
@@ -2338,6 +2344,7 @@ int gphip_solve(gphip_handle h, const double* rhs, int64_t nrhs, double* out) {
         if (rc) return rc;
         if (info != 0) return fail(h, GPHIP_ERR_STATE, "the fitted theta no longer factors");
         h->fitted = true;                      // now a LOCAL fit of the same theta (logdet_fit / mu_fit / kappa_fit unchanged)
+        h->dist_fit = false;
     }
     if (h->null_fit) {                         // "Inverse" -> Function[Divide[#, matrixDiagonal]]  (BGP:156-159)
         for (int64_t i = 0; i < nrhs * h->N; ++i)

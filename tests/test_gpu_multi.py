@@ -217,3 +217,31 @@ def test_sharding_shards_memory(golden_dir):
     mu2, _ = g.predict(Xs)
     np.testing.assert_allclose(mu2, mu1, rtol=1e-8, atol=1e-9)
     g.close()
+
+
+def test_distributed_fit_state_does_not_leak_into_later_local_calls():
+    """Found by scripts/gpu_api_fuzz.py: after a sharded fit (factor distributed, z gathered into a side vector) a later
+    LOCAL call on a member -- batched mixture prediction, a local fit below shard_min_n -- must not read that stale state."""
+    n, d, world = 129, 1, 2
+    X, y = syn.make_dataset(n, d)
+    Th = syn.theta_batch(4, "matern52_ard", d)
+    Th[:, -1] = np.maximum(Th[:, -1], 0.2)
+    Xs = syn.make_test_points(3, d)
+    g = _lib.Handle(X, y, "matern52_ard", device=[0] * world)
+    g.set_option("shard_min_n", 0)
+    assert g.fit(Th[0]) == 0                              # distributed fit
+    g.predict(Xs)
+    mS, vS, iS = g.predict_samples(Th, Xs)                # samples dealt to the members: local evaluations
+    assert np.all(iS == 0)
+    for s in range(4):
+        mo, so = orc.predict_internal("matern52_ard", Th[s], X, y, Xs)
+        np.testing.assert_allclose(mS[s], mo, rtol=1e-7, atol=1e-9)
+        np.testing.assert_allclose(np.sqrt(vS[s]), so, rtol=1e-7)
+    assert g.fit(Th[1]) == 0                              # distributed again ...
+    g.set_option("shard_min_n", 1 << 30)
+    assert g.fit(Th[2]) == 0                              # ... then a LOCAL fit: prediction must use it, not the stale stream
+    mu, var = g.predict(Xs)
+    mo, so = orc.predict_internal("matern52_ard", Th[2], X, y, Xs)
+    np.testing.assert_allclose(mu, mo, rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(np.sqrt(var), so, rtol=1e-7)
+    g.close()
