@@ -38,3 +38,17 @@ for w in (2, 4, 8):
     g.set_option("replicate_factor", 1)
     dt, r = timeit(g, fit=True); print(f"N={n}   ... fit (replicates L x{w}):  {dt*1e3:8.2f} ms", flush=True)
     g.close()
+
+# the serial owner path with the chip to itself: an evaluation with look-ahead off and uniform 512-wide panels runs the
+# panel kernels (potrf128, panel solves, in-panel GEMMs) alone -- their summed time / 64 steps is what one owner spends per
+# step on the chain of the sharded schedule (plus LA, which look-ahead-off folds into the trailing update)
+h = _lib.Handle(X, y, "se_ard")
+h.set_option("lookahead", 0); h.set_option("panel_wide", 0); h.set_option("dataflow_tail", 0)
+h.loglik(th)
+h.set_option("profile", 2); h.reset_profile(); h.loglik(th)
+pr = h.profile()
+steps = (n // 128 + 3) // 4
+tot = pr["potrf"]["ms"] + pr["trsm"]["ms"] + pr["gemm_panel"]["ms"]
+print(f"owner path, chip to itself: potrf {pr['potrf']['ms']:.2f} + panel solves {pr['trsm']['ms']:.2f} + in-panel GEMMs {pr['gemm_panel']['ms']:.2f} ms"
+      f" = {tot:.2f} ms over {steps} steps = {tot/steps*1e3:.0f} us per 512-column step (trailing SYRK {pr['syrk_trailing']['ms']:.1f} ms)", flush=True)
+h.close()
