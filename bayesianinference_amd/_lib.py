@@ -226,7 +226,12 @@ class Handle:
                                   MEAN_IDS[mean], dtype, devs, nd, C.byref(self._h))
         if rc != OK:
             self._h = None
-            raise GphipError(rc, "gphip_create failed (is a gfx950 GPU visible?)")
+            why = {5: "no gfx950 GPU visible, or a device ordinal that does not exist",
+                   6: "unsupported combination (null kernel on a multi-device handle, d > 32, dtype other than 64 / 32, or no "
+                      "RCCL could be bound for a multi-process handle: set GPHIP_RCCL_PATH)",
+                   1: "bad argument (unknown kernel / mean id, rank outside the world)",
+                   2: "bad shape (N < 1 or d < 1)"}.get(rc, "is a gfx950 GPU visible?")
+            raise GphipError(rc, "gphip_create failed: " + why)
         p = C.c_int(0)
         lib.gphip_num_params(self._h, C.byref(p))
         self.p = p.value

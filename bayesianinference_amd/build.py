@@ -25,6 +25,14 @@ def hipcc_path() -> str:
     raise RuntimeError("hipcc not found: cannot build libgphip.so (ROCm >= 7.0 required)")
 
 
+def rocm_prefix() -> str:
+    """ROCm installation the found hipcc belongs to ($ROCM_PATH, else <hipcc>/../..), not a hard-coded /opt/rocm."""
+    env = os.environ.get("ROCM_PATH")
+    if env and os.path.isdir(env):
+        return env
+    return os.path.dirname(os.path.dirname(os.path.realpath(hipcc_path())))
+
+
 def needs_build() -> bool:
     if not os.path.exists(LIB):
         return True
@@ -85,8 +93,10 @@ def build_fake_rccl(force: bool = False, verbose: bool = False) -> str:
     (gphip_create_rank) run with two ranks on a one-GPU box, where real RCCL refuses two ranks on one device."""
     if not force and os.path.exists(FAKE_RCCL_LIB) and os.path.getmtime(FAKE_RCCL_SRC) <= os.path.getmtime(FAKE_RCCL_LIB):
         return FAKE_RCCL_LIB
+    rocm = rocm_prefix()
     cmd = [hipcc_path(), "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-x", "c++", "-D__HIP_PLATFORM_AMD__",
-           "-I/opt/rocm/include", "-o", FAKE_RCCL_LIB, FAKE_RCCL_SRC, "-L/opt/rocm/lib", "-lamdhip64", "-lpthread", "-lrt"]
+           "-I" + os.path.join(rocm, "include"), "-o", FAKE_RCCL_LIB, FAKE_RCCL_SRC, "-L" + os.path.join(rocm, "lib"),
+           "-lamdhip64", "-lpthread", "-lrt"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     res = subprocess.run(cmd, capture_output=True, text=True)

@@ -15,7 +15,7 @@ from bayesianinference_amd import _lib, synthetic as syn      # noqa: E402
 sizes = [int(a) for a in sys.argv[1:]] or [131072, 160000]
 d = 8
 for n in sizes:
-    rec = {"N": n, "d": d, "dtype": "f64", "factor_GB": round(8e-9 * n * n, 1)}
+    rec = {"N": n, "d": d, "dtype": "f64", "factor_GB": round(8e-9 * n * n / 2, 1)}    # packed lower triangle
     try:
         X, y = syn.make_dataset(n, d)
         th = syn.default_theta("se_ard", d)
