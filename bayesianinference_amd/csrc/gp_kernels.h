@@ -959,6 +959,48 @@ struct GemmArgs {
                                                  //    lower sub-tiles only)
 };
 
+// Position p of the lower triangle of an H x H tile grid enumerated SUPER-TILE by super-tile (8 x 8 tiles; super-tile
+// columns left to right, inside a column the diagonal super-tile first, then downwards; inside a super-tile rows fastest).
+// Column J < H / 8 holds T(J) = 36 + 8 (H - 8 J - 8) tiles, so the prefix P(J) = J (8 H - 28) - 32 J (J - 1) is inverted in
+// closed form; a last column of H % 8 tile columns holds a small triangle.
+__device__ __forceinline__ void blocked_tri_decode(int p, int H, int& u, int& v) {
+    const int Sf = H >> 3;                                   // full 8-wide super-tile columns
+    auto prefix = [&](int J) { return (long)J * (8 * H - 28) - 32l * J * (J - 1); };
+    const double b = 8.0 * H + 4.0;
+    const double disc = b * b - 128.0 * (double)p;
+    int J = (int)((b - __builtin_sqrt(disc > 0.0 ? disc : 0.0)) * (1.0 / 64.0));
+    if (J < 0) J = 0;
+    if (J > Sf) J = Sf;
+    while (J > 0 && prefix(J) > p) --J;
+    while (J < Sf && prefix(J + 1) <= p) ++J;
+    const int q = p - (int)prefix(J);
+    if (J == Sf) {                                           // the ragged last column: a triangle of H % 8 tile columns
+        int uu, vv;
+        tri_decode(q, H & 7, uu, vv);
+        u = 8 * J + uu;
+        v = 8 * J + vv;
+        return;
+    }
+    if (q < 36) {                                            // diagonal super-tile: the lower triangle of 8 x 8
+        int uu, vv;
+        tri_decode(q, 8, uu, vv);
+        u = 8 * J + uu;
+        v = 8 * J + vv;
+        return;
+    }
+    const int below = H - 8 * J - 8, nfull = below >> 3, q2 = q - 36;
+    int grp = q2 >> 6;
+    if (grp < nfull) {
+        const int w = q2 & 63;
+        u = 8 * J + 8 + 8 * grp + (w & 7);
+        v = 8 * J + (w >> 3);
+    } else {                                                 // the last, shorter group of rows
+        const int rl = below & 7, w = q2 - 64 * nfull;
+        u = 8 * J + 8 + 8 * nfull + w % rl;
+        v = 8 * J + w / rl;
+    }
+}
+
 template <typename T>
 __device__ __forceinline__ void gemm_tile_decode(const GemmArgs<T>& g, int t, int r0, int c0, int nrect, int& ti, int& tj) {
     const int H = g.r1 - r0;
@@ -1036,7 +1078,22 @@ __global__ __launch_bounds__(64 * NWI * NWJ, (NWI * NWJ == 4) ? 2 : 4) void gemm
         ntiles = ntc * H - ntc * (ntc - 1) / 2;
         if (bid >= ntiles) return;             // (only the clipped last group can come up short)
     }
-    if (g.super) {
+    if (g.super == 2) {
+        // BALANCED blocked order: the tile list itself is enumerated super-tile by super-tile (8 x 8 tiles: 8 row panels + 8
+        // column panels = 16 operand panels for 64 tiles, instead of 65 for 64 tiles down a column), and every XCD takes a
+        // contiguous, equally long chunk of that list as with the plain swizzle -- whole super-tiles pass through an XCD's
+        // private L2 without the static super-tile-per-XCD split whose unequal loads cost more than the traffic saved.
+        const int H = g.r1 - g.r0;
+        {
+            const int nx = 8, n = ntiles;
+            const int q = n / nx, rem = n % nx, x = bid % nx, o = bid / nx;
+            bid = (x < rem ? x * (q + 1) : rem * (q + 1) + (x - rem) * q) + o;
+        }
+        int u, v;
+        blocked_tri_decode(bid, H, u, v);
+        ti = g.r0 + u;
+        tj = g.r0 + v;
+    } else if (g.super) {
         // Blocks b, b+8, b+16, .. run on XCD b % 8 (observed dispatch rule; speed only).  Give each
         // XCD whole 8x8 super-tiles: its 64 resident workgroups then share 8 row panels and 8
         // column panels through that XCD's private 4 MiB L2 instead of streaming 65 panels.

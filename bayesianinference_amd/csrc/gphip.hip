@@ -77,7 +77,9 @@ struct gphip_ctx {
     double *hInvEll = nullptr, *hSlotp = nullptr, *hRes = nullptr;
     int* hInfo = nullptr;
     // options
-    int panel = 4, profile = 0, swizzle = 1, max_slots = 256, lookahead = 1, supertile = 0;
+    int panel = 4, profile = 0, swizzle = 1, max_slots = 256, lookahead = 1;
+    int supertile = 2;                 // trailing SYRK tile order: 0 column-major chunks per XCD, 1 static 8x8 super-tiles per XCD
+                                       // (measured slower: unequal loads), 2 the tile LIST in 8x8 super-tile order, equal chunks per XCD
     int latency_gemm = 1, latency_tiles = 256;   // launches of <= latency_tiles tiles use the latency GEMM shape
     int dataflow = 1, dataflow_max_nt = 96, dataflow_max_slots = 8;   // single-launch dataflow Cholesky: latency regime only
     int dataflow_fine_nt = 96;                   // ... with 64x64 tiles up to this many 128-tiles (fp64; measured best up to N = 12288)
@@ -445,7 +447,9 @@ void launch_gemm(gphip_ctx* h, int cls, Opnd<T> Co, Opnd<T> Ao, Opnd<T> Bo, int 
     }
     g.swizzle = h->swizzle && g.ntiles >= 64;
     int grid_x = g.ntiles;
-    if (tri && r0 == c0 && W == H && h->supertile && H >= 16 && mode == 0) {   // pure triangle: 8x8 super-tiles
+    if (tri && r0 == c0 && W == H && h->supertile == 2 && H >= 16 && mode == 0 && groups == 1 && nslots == 1) {
+        g.super = 2;                            // the tile list in blocked (8 x 8 super-tile) order, equal chunks per XCD
+    } else if (tri && r0 == c0 && W == H && h->supertile == 1 && H >= 16 && mode == 0) {   // pure triangle: 8x8 super-tiles, static split
         const int S = (H + 7) / 8;
         const int nsuper = (S * (S + 1) / 2 + 7) / 8 * 8;
         g.super = 1;

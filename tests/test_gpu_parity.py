@@ -690,6 +690,12 @@ def test_experimental_schedules_give_the_same_factorisation():
         got = h.loglik_parts(th)
         h.set_option(opt, 0)
         assert got[3] == 0 and all(close(got[k], ref[k], n, 1e-11) for k in range(3)), (opt, got, ref)
+    # tile order of the trailing update (default 2 = blocked list; 0 = column-major list; 1 = static super-tiles): the
+    # order decides WHICH workgroup computes a tile, never how -- results are bit-identical
+    for order in (0, 1, 2):
+        h.set_option("supertile", order)
+        got = h.loglik_parts(th)
+        assert got[3] == 0 and all(got[k] == ref[k] for k in range(3)), (order, got, ref)
     h.close()
 
 
