@@ -300,6 +300,9 @@ struct KBuildArgs {
     int own_panel, own_world, own_rank;   // own_world > 0 (multi-GPU 1-D block-cyclic layout): build
                             // only tile columns whose outer panel (tj / own_panel) belongs to own_rank;
                             // the rhs x rhs corner tile belongs to rank 0
+    int t0;                 // mode 0: first tile (column-major packed index) of this launch -- the build of a look-ahead
+                            // factorisation is split into "tile columns of panel 0" and "the rest" (panel 0 is factored
+                            // under the rest of the build)
     const long* adj;        // own_world > 0 and the rank keeps ONLY its own panels (compact storage): adj[q] = tiles to add
                             // to the dense tile index of any tile of outer panel q (index nt_j / .. see panel_slot);
                             // null: the dense packed layout
@@ -317,7 +320,7 @@ __global__ __launch_bounds__(256) void kbuild_kernel(KBuildArgs<T> a) {
     const int slot = blockIdx.y;
     int ti, tj;
     if (a.mode == 0) {
-        tri_decode(blockIdx.x, a.nt_i, ti, tj);
+        tri_decode(blockIdx.x + a.t0, a.nt_i, ti, tj);
     } else {
         ti = blockIdx.x % a.nt_i;
         tj = blockIdx.x / a.nt_i;

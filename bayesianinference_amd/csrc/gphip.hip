@@ -52,6 +52,8 @@ struct gphip_ctx {
     hipStream_t cs = nullptr;          // stream the launch helpers currently target
     std::vector<hipEvent_t> sync_events;
     size_t sync_used = 0;
+    hipEvent_t ev_built0 = nullptr;              // queue_build -> queue_factor: "the tile columns of panel 0 are built" (split build)
+    int build_overlap = 1;                       // option: factor panel 0 under the rest of the kernel build
     bool own_streams = true;
     int dist_rank = 0, dist_world = 0;  // > 0 between gphip_dist_begin and gphip_dist_end
     bool dist_theta_ok = true;
@@ -102,6 +104,11 @@ struct gphip_ctx {
     // fitted state (slot 0)
     bool fitted = false;
     std::vector<double> theta_fit;
+    // Fit epoch: ws_gen counts the calls that overwrote this context's workspace, fit_gen is ws_gen at the time the
+    // resident factor was made, fit_id the number of the group's sharded fit that made it.  A factor is used only
+    // while fit_gen == ws_gen (and, when test points shard over a group's members, while every member carries the
+    // group's current fit_id) -- so a member's stale factor can never serve a later fit's prediction, whatever theta.
+    unsigned long ws_gen = 0, fit_gen = ~0ul, fit_id = 0;
     double logdet_fit = 0, mu_fit = 0, kappa_fit = 0;
     // prediction / solve scratch
     void *dV = nullptr, *dXsT = nullptr, *dXsS = nullptr;   // typed
@@ -179,6 +186,16 @@ int fail(gphip_ctx* h, int code, const char* msg) {
     return code;
 }
 
+// every call that overwrites the workspace (or frees it) ends the life of the resident factor
+void invalidate_fit(gphip_ctx* h) {
+    h->fitted = false;
+    h->dist_fit = false;
+    ++h->ws_gen;
+}
+// ... and a successful fit stamps the factor with the workspace generation it lives in
+void stamp_fit(gphip_ctx* h);
+bool has_fit(const gphip_ctx* h) { return h->fitted && h->fit_gen == h->ws_gen; }
+
 double pivot_tol_rel(const gphip_ctx* h) {
     return 64.0 * (h->dtype == 64 ? 2.220446049250313e-16 : 1.1920929e-07);
 }
@@ -249,8 +266,7 @@ void free_slots(gphip_ctx* h) {
     h->hInvEll = h->hSlotp = h->hRes = nullptr;
     h->hInfo = nullptr;
     h->slots = 0;
-    h->fitted = false; h->dist_fit = false;
-    h->dist_fit = false;                       // (a distributed fit keeps its block inverses / scalars in these buffers)
+    invalidate_fit(h);                         // (a distributed fit keeps its block inverses / scalars in these buffers too)
 }
 
 size_t slot_bytes(const gphip_ctx* h) {
@@ -352,9 +368,31 @@ void launch_kbuild(gphip_ctx* h, const KBuildArgs<T>& a, dim3 grid) {
         hipLaunchKernelGGL((kbuild_kernel<T, 0, 2>), grid, dim3(256), (size_t)4 * a.d * TB * sizeof(T), h->cs, a);
 }
 
-// queue k_scale + kbuild for nslots slots (theta already staged in dInvEll / dSlotp)
+// Outer panel boundaries of the multi-kernel factorisation.  Far from the end the trailing update is long and hides a wider
+// panel's factorisation behind it, and a wider panel means fewer read-modify-write passes over the trailing matrix (measured,
+// one theta, fp64: N=32768 190.2 -> 187.4 ms, N=49152 621 -> 610 ms; at N <= 16384 the base width is best): twice the base
+// width while >= 192 tile columns remain, 1.5x while >= 128 remain (option "panel_wide", default 1).
+std::vector<int> panel_bounds(const gphip_ctx* h) {
+    const int Nt = (int)h->Nt, P = h->panel;
+    std::vector<int> bnd{0};
+    while (bnd.back() < Nt) {
+        const int rem = Nt - bnd.back();
+        int w = P;
+        if (h->panel_wide) w = rem >= 192 ? 2 * P : (rem >= 128 ? P + P / 2 : P);
+        bnd.push_back(std::min(Nt, bnd.back() + w));
+    }
+    return bnd;
+}
+bool use_dataflow(const gphip_ctx* h, int nslots);
+hipEvent_t sync_event(gphip_ctx* h);
+
+// queue k_scale + kbuild for nslots slots (theta already staged in dInvEll / dSlotp).  for_factor: the look-ahead
+// factorisation follows on this handle's streams -- the build is then split after the tile columns of outer panel 0 and an
+// event tells queue_factor's panel stream that it may start on them while the main stream builds the rest (the build is
+// HBM-store bound, the first panel's factorisation latency / MFMA bound: they overlap almost for free, and nothing else
+// hides panel 0).
 template <typename T>
-int queue_build(gphip_ctx* h, int nslots) {
+int queue_build(gphip_ctx* h, int nslots, bool for_factor = false) {
     const long tot = (long)h->d * h->Npad;
     int gx = (int)((tot + 255) / 256);
     if (gx > 1024) gx = 1024;
@@ -385,6 +423,21 @@ int queue_build(gphip_ctx* h, int nslots) {
     a.pw_bstride = h->Npad;
     const long ntiles = (long)(h->Nt + 1) * (h->Nt + 2) / 2;
     ProfScope ps(h, 0, 0.0, (double)sizeof(T) * nslots * ((double)h->N * (h->N + 1) / 2 + (double)h->N * h->d));
+    h->ev_built0 = nullptr;
+    if (for_factor && h->build_overlap && h->lookahead && h->dist_world == 0 && h->cs == h->stream && !use_dataflow(h, nslots)) {
+        const std::vector<int> bnd = panel_bounds(h);
+        if (bnd.size() >= 3) {                                         // >= 2 outer panels: queue_factor runs the look-ahead schedule
+            const long c = bnd[1], R = h->Nt + 1;
+            const long first = c * R - c * (c - 1) / 2;                // tiles of the tile columns [0, c) (column-major packed order)
+            launch_kbuild<T>(h, a, dim3((unsigned)first, nslots));
+            h->sync_used = 0;
+            h->ev_built0 = sync_event(h);
+            HIPCHK(hipEventRecord(h->ev_built0, h->stream));
+            a.t0 = (int)first;
+            launch_kbuild<T>(h, a, dim3((unsigned)(ntiles - first), nslots));
+            return 0;
+        }
+    }
     launch_kbuild<T>(h, a, dim3((unsigned)ntiles, nslots));
     return 0;
 }
@@ -447,7 +500,7 @@ void launch_gemm(gphip_ctx* h, int cls, Opnd<T> Co, Opnd<T> Ao, Opnd<T> Bo, int 
     }
     g.swizzle = h->swizzle && g.ntiles >= 64;
     int grid_x = g.ntiles;
-    if (tri && r0 == c0 && W == H && h->supertile == 2 && H >= 16 && mode == 0 && groups == 1 && nslots == 1) {
+    if (tri && r0 == c0 && W == H && h->supertile >= 2 && H >= 16 && mode == 0 && groups == 1 && (nslots == 1 || h->supertile == 3)) {
         g.super = 2;                            // the tile list in blocked (8 x 8 super-tile) order, equal chunks per XCD
     } else if (tri && r0 == c0 && W == H && h->supertile == 1 && H >= 16 && mode == 0) {   // pure triangle: 8x8 super-tiles, static split
         const int S = (H + 7) / 8;
@@ -651,18 +704,9 @@ int queue_factor_dataflow(gphip_ctx* h, int nslots) {
 template <typename T>
 int queue_factor(gphip_ctx* h, int nslots) {
     const int Nt = (int)h->Nt, R = Nt + 1;     // R = tile rows incl. the rhs block-row
-    const int P = h->panel;
-    // Outer panel boundaries.  Far from the end the trailing update is long and hides a wider panel's factorisation
-    // behind it, and a wider panel means fewer read-modify-write passes over the trailing matrix (measured, one theta,
-    // fp64: N=32768 190.2 -> 187.4 ms, N=49152 621 -> 610 ms; at N <= 16384 the base width is best): twice the base
-    // width while >= 192 tile columns remain, 1.5x while >= 128 remain (option "panel_wide", default 1).
-    std::vector<int> bnd{0};
-    while (bnd.back() < Nt) {
-        const int rem = Nt - bnd.back();
-        int w = P;
-        if (h->panel_wide) w = rem >= 192 ? 2 * P : (rem >= 128 ? P + P / 2 : P);
-        bnd.push_back(std::min(Nt, bnd.back() + w));
-    }
+    const std::vector<int> bnd = panel_bounds(h);
+    hipEvent_t built0 = h->ev_built0;           // set by a split build: panel 0's tile columns are ready before the rest
+    h->ev_built0 = nullptr;
     const int nouter = (int)bnd.size() - 1;
     auto k0 = [&](int k) { return bnd[(size_t)std::min(k, nouter)]; };
     auto trailing = [&](int k, int c_lo, int c_hi, int cls) {      // apply panel k to tile columns [c_lo,c_hi)
@@ -700,10 +744,10 @@ int queue_factor(gphip_ctx* h, int nslots) {
             trailing(k, k0(k + 1), R, 4);
         }
     } else {
-        h->sync_used = 0;
+        if (!built0) h->sync_used = 0;          // (the split build took the first event of this evaluation)
         hipEvent_t built = sync_event(h);
         HIPCHK(hipEventRecord(built, h->stream));
-        HIPCHK(hipStreamWaitEvent(h->pstream, built, 0));
+        HIPCHK(hipStreamWaitEvent(h->pstream, built0 ? built0 : built, 0));
         h->cs = h->pstream;
         queue_panel<T>(h, 0, k0(1), nslots);
         hipEvent_t ev_panel = sync_event(h);
@@ -753,6 +797,7 @@ int queue_factor(gphip_ctx* h, int nslots) {
                 HIPCHK(hipEventRecord(ev_next, h->pstream));
             } else if (k + 1 < nouter) {
                 h->cs = h->pstream;
+                if (k == 0 && built0) HIPCHK(hipStreamWaitEvent(h->pstream, built, 0));     // LA(0) reads columns the rest of the build writes
                 if (ev_rest) HIPCHK(hipStreamWaitEvent(h->pstream, ev_rest, 0));
                 if (ev_rest2) HIPCHK(hipStreamWaitEvent(h->pstream, ev_rest2, 0));
                 trailing(k, k0(k + 1), k0(k + 2), 3);                          // LA(k)
@@ -762,6 +807,7 @@ int queue_factor(gphip_ctx* h, int nslots) {
             }
             if (split && k0(k + 2) % 2 == 0) {
                 h->cs = h->stream2;
+                if (k == 0 && built0) HIPCHK(hipStreamWaitEvent(h->stream2, built, 0));
                 HIPCHK(hipStreamWaitEvent(h->stream2, ev_panel, 0));
                 trailing_half(k, k0(k + 2), 1);                                // REST(k), odd groups
                 ev_rest2 = sync_event(h);
@@ -1020,7 +1066,7 @@ int eval_chunk(gphip_ctx* h, const double* Theta, int nb, double* out, double* p
     h->cs = h->stream;
     {
         ProfScope ps(h, 5, 0.0, 0.0);
-        if (!h->fused_eval) DISPATCH(h, queue_build, h, nb);
+        if (!h->fused_eval) DISPATCH(h, queue_build, h, nb, true);
         DISPATCH(h, queue_factor, h, nb);
     }
     h->fused_eval = false;
@@ -1055,7 +1101,7 @@ int eval_batch_local(gphip_ctx* h, const double* Theta, int B, int p, double* ou
     if (h->kernel_id == GPHIP_KERNEL_NULL) return null_kernel_batch(h, Theta, B, out, parts, info, nullptr);
     int rc = ensure_slots(h, B);
     if (rc) return rc;
-    h->fitted = false; h->dist_fit = false;
+    invalidate_fit(h);
     for (int s0 = 0; s0 < B; s0 += h->slots) {
         const int nb = (B - s0 < h->slots) ? (B - s0) : h->slots;
         rc = eval_chunk(h, Theta + (size_t)s0 * p, nb, out + s0, parts ? parts + 2 * s0 : nullptr, info + s0, s0);
@@ -1471,6 +1517,16 @@ static int create_ctx(const void* X, const void* y, int64_t N, int64_t d, int ke
 #include "gphip_multi.inc"
 
 namespace {
+// A fit made by ONE context of a multi-device handle (below shard_min_n, gradient, local refit) starts a new fit of the
+// group: the other members' factors (an earlier sharded fit, possibly of the same theta but another nugget / mean
+// array) must not serve its predictions.
+void stamp_fit(gphip_ctx* h) {
+    h->fit_gen = h->ws_gen;
+    if (h->group && !h->in_group_call && !h->group->in_sharded_fit) h->fit_id = ++h->group->fit_id;
+}
+}  // namespace
+
+namespace {
 // every likelihood-type entry point lands here: a plain handle evaluates locally; a group handle shards ONE
 // factorisation over its ranks (N >= shard_min_n) or deals a batch of thetas to its local devices
 int eval_batch(gphip_ctx* h, const double* Theta, int B, int p, double* out, double* parts, int* info) {
@@ -1779,6 +1835,7 @@ int gphip_loglik_grad(gphip_handle h, const double* theta, int p, double* out, d
     }
     h->fitted = true;                                         // the factor of theta is still resident (whole, on this device)
     h->dist_fit = false;
+    stamp_fit(h);
     h->theta_fit.assign(theta, theta + p);
     h->logdet_fit = parts[0];
     h->mu_fit = h->hSlotp[2];
@@ -1810,20 +1867,24 @@ int gphip_fit(gphip_handle h, const double* theta, int p, int* info) {
         }
         h->fitted = h->null_fit = (*info == 0);
         h->dist_fit = false;
+        stamp_fit(h);
         h->theta_fit.assign(theta, theta + p);
         h->mu_fit = mu;
         h->kappa_fit = sn * sn;
         return GPHIP_OK;
     }
     h->want_w = true;                          // the substitutions that follow a fit use the 128-block inverses
+    const unsigned long id_before = h->group ? h->group->fit_id : 0;
     int rc = eval_batch(h, theta, 1, p, &out, parts, info);
     h->want_w = false;
     if (rc) return rc;
+    const bool sharded_fit = h->group && h->group->fit_id != id_before;     // group_eval_run stamped every member itself
     if (h->dist_fit) {                         // (a later gphip_solve factors locally again: it needs the same K)
         h->fit_pw_mean.assign(h->pw_mean_host ? h->pw_mean_host : nullptr, h->pw_mean_host ? h->pw_mean_host + h->N : nullptr);
         h->fit_pw_nug.assign(h->pw_nug_host ? h->pw_nug_host : nullptr, h->pw_nug_host ? h->pw_nug_host + h->N : nullptr);
     }
     h->fitted = (*info == 0);
+    if (!sharded_fit) stamp_fit(h);
     h->theta_fit.assign(theta, theta + p);
     h->logdet_fit = parts[0];
     h->mu_fit = h->hSlotp[2];
@@ -1833,7 +1894,7 @@ int gphip_fit(gphip_handle h, const double* theta, int p, int* info) {
 
 int gphip_logdet(gphip_handle h, double* out) {
     if (!h || !out) return fail(h, GPHIP_ERR_ARG, "null argument");
-    if (!h->fitted) return fail(h, GPHIP_ERR_STATE, "gphip_logdet before a successful gphip_fit");
+    if (!has_fit(h)) return fail(h, GPHIP_ERR_STATE, "gphip_logdet before a successful gphip_fit");
     *out = h->logdet_fit;
     return GPHIP_OK;
 }
@@ -1851,7 +1912,7 @@ int gphip_covariance(gphip_handle h, const double* theta, int p, double* K) {
     }
     int rc = ensure_slots(h, 1);
     if (rc) return rc;
-    h->fitted = false; h->dist_fit = false;
+    invalidate_fit(h);
     if (!stage_theta(h, 0, theta)) return fail(h, GPHIP_ERR_ARG, "non-finite or zero hyper-parameter");
     rc = copy_theta(h, 1);
     if (rc) return rc;
@@ -1887,7 +1948,7 @@ int gphip_cross_covariance(gphip_handle h, const double* theta, int p, const voi
     HIPCHK(hipSetDevice(h->device));
     int rc = ensure_slots(h, 1);
     if (rc) return rc;
-    h->fitted = false; h->dist_fit = false;
+    invalidate_fit(h);
     if (!stage_theta(h, 0, theta)) return fail(h, GPHIP_ERR_ARG, "non-finite or zero hyper-parameter");
     rc = copy_theta(h, 1);
     if (rc) return rc;
@@ -1947,7 +2008,7 @@ int gphip_predict(gphip_handle h, const void* Xs, int64_t M, double* mean, doubl
     if (!h || !Xs || !mean || !var) return fail(h, GPHIP_ERR_ARG, "null argument");
     if (M < 1) return fail(h, GPHIP_ERR_DIM, "M < 1");
     std::lock_guard<std::recursive_mutex> lk(h->mu);
-    if (!h->fitted) return fail(h, GPHIP_ERR_STATE, "gphip_predict before a successful gphip_fit");
+    if (!has_fit(h)) return fail(h, GPHIP_ERR_STATE, "gphip_predict before a successful gphip_fit");
     if (h->null_fit) {                         // null kernel (BGP:63-89): k = 0, kappa = nugget
         for (int64_t t = 0; t < M; ++t) {
             mean[t] = h->pw_mean_test ? h->pw_mean_test[t] : h->mu_fit;
@@ -1962,7 +2023,7 @@ int gphip_predict(gphip_handle h, const void* Xs, int64_t M, double* mean, doubl
     if (h->group && h->group->members.size() > 1 && M >= 2 * TB * (int64_t)h->group->members.size()) {
         gphip_group* g = h->group;
         bool all = true;
-        for (gphip_ctx* m : g->members) all = all && m->fitted && m->theta_fit == h->theta_fit;
+        for (gphip_ctx* m : g->members) all = all && has_fit(m) && m->fit_id == g->fit_id && m->theta_fit == h->theta_fit;
         if (all) {
             const int64_t nl = (int64_t)g->members.size(), d = h->d;
             const double* X = static_cast<const double*>(Xs);
@@ -2043,7 +2104,7 @@ static int predict_streamed(gphip_handle h, const void* Xs, int64_t M, double* m
     int rc = gphip_dist_num_panels(h, &nouter);
     if (rc) return rc;
     for (gphip_ctx* m : g->members)
-        if (!m->dist_fit || m->theta_fit != h->theta_fit || m->lay_panel != m->panel)
+        if (!m->dist_fit || !has_fit(m) || m->fit_id != g->fit_id || m->theta_fit != h->theta_fit || m->lay_panel != m->panel)
             return fail(h, GPHIP_ERR_STATE, "the distributed factor is gone (another call reused the buffers, or \"panel\" changed): fit again");
     // test points -> local ranks (contiguous blocks; few points: the first rank alone), chunks of <= ~8 GiB of V
     std::vector<int64_t> lo((size_t)nl + 1, M);
@@ -2227,7 +2288,7 @@ int gphip_predict_samples(gphip_handle h, const double* Thetas, int S, int p, co
     HIPCHK(hipSetDevice(h->device));
     int rc = ensure_slots(h, S);
     if (rc) return rc;
-    h->fitted = false; h->dist_fit = false;
+    invalidate_fit(h);
     const double* X = static_cast<const double*>(Xs);
     const int64_t d = h->d;
     std::vector<double> xt, hm, hv, scratch_out(1), scratch_parts;
@@ -2331,7 +2392,7 @@ int gphip_solve(gphip_handle h, const double* rhs, int64_t nrhs, double* out) {
     if (!h || !rhs || !out) return fail(h, GPHIP_ERR_ARG, "null argument");
     if (nrhs < 1) return fail(h, GPHIP_ERR_DIM, "nrhs < 1");
     std::lock_guard<std::recursive_mutex> lk(h->mu);
-    if (!h->fitted) return fail(h, GPHIP_ERR_STATE, "gphip_solve before a successful gphip_fit");
+    if (!has_fit(h)) return fail(h, GPHIP_ERR_STATE, "gphip_solve before a successful gphip_fit");
     if (h->dist_fit) {
         // the factor is spread over the ranks: "Inverse" is a parity helper for small systems, so the first device simply
         // factors the fitted theta again on its own (in separate processes: every rank does) and substitutes locally
@@ -2348,6 +2409,7 @@ int gphip_solve(gphip_handle h, const double* rhs, int64_t nrhs, double* out) {
         if (rc) return rc;
         if (info != 0) return fail(h, GPHIP_ERR_STATE, "the fitted theta no longer factors");
         h->fitted = true;                      // now a LOCAL fit of the same theta (logdet_fit / mu_fit / kappa_fit unchanged)
+        stamp_fit(h);
         h->dist_fit = false;
     }
     if (h->null_fit) {                         // "Inverse" -> Function[Divide[#, matrixDiagonal]]  (BGP:156-159)
@@ -2435,7 +2497,7 @@ int gphip_dist_begin(gphip_handle h, const double* theta, int p, int rank, int w
     if (rc) return rc;
     rc = dist_layout(h, rank, world, full);
     if (rc) return rc;
-    h->fitted = false; h->dist_fit = false;
+    invalidate_fit(h);
     h->dist_rank = rank; h->dist_world = world;
     h->dist_theta_ok = stage_theta(h, 0, theta, h->pw_nug_host, h->pw_mean_host);
     rc = upload_pw(h, 0, 1);                   // point-dependent nugget / mean of this evaluation, if the caller set them
@@ -2545,7 +2607,7 @@ int* option_slot(gphip_ctx* h, const char* name) {
         {"dataflow", &gphip_ctx::dataflow}, {"dataflow_max_nt", &gphip_ctx::dataflow_max_nt},
         {"dataflow_max_slots", &gphip_ctx::dataflow_max_slots}, {"dataflow_fine_nt", &gphip_ctx::dataflow_fine_nt},
         {"dataflow_tail", &gphip_ctx::dataflow_tail}, {"grad_potri", &gphip_ctx::grad_potri},
-        {"fused_eval", &gphip_ctx::fuse_option}, {"panel_left", &gphip_ctx::panel_left},
+        {"fused_eval", &gphip_ctx::fuse_option}, {"panel_left", &gphip_ctx::panel_left}, {"build_overlap", &gphip_ctx::build_overlap},
         {"max_slots", &gphip_ctx::max_slots}, {"shard_min_n", &gphip_ctx::shard_min_n},
         {"thin_tiles", &gphip_ctx::thin_tiles}, {"panel_wide", &gphip_ctx::panel_wide},
         {"la_main", &gphip_ctx::la_main}, {"rest_split", &gphip_ctx::rest_split},

@@ -8,7 +8,8 @@ n, B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096, int(sys.argv[2]) if len(
 X, y = syn.make_dataset(n, 8)
 Th = syn.theta_batch(B, "se_ard", 8)
 Th[:, -1] = np.maximum(Th[:, -1], 0.05)
-variants = [{}, {"supertile": 1}, {"xcd_swizzle": 0}, {"lookahead": 0}, {"panel": 8}, {"panel": 8, "lookahead": 0}, {"panel": 6}, {}]
+variants = [dict(kv.split("=") for kv in a.split(",") if kv) for a in sys.argv[3:]] or [{}, {"build_overlap": 0}, {}, {"build_overlap": 0}]
+variants = [{k: int(v) for k, v in o.items()} for o in variants]
 for opts in variants:
     h = _lib.Handle(X, y, "se_ard")
     for k, v in opts.items():

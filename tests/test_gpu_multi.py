@@ -245,3 +245,35 @@ def test_distributed_fit_state_does_not_leak_into_later_local_calls():
     np.testing.assert_allclose(mu, mo, rtol=1e-7, atol=1e-9)
     np.testing.assert_allclose(np.sqrt(var), so, rtol=1e-7)
     g.close()
+
+
+def test_fit_epoch_members_never_serve_an_older_fit():
+    """Fit epoch (a group counts its fits, members carry the number of the fit whose factor they hold): a sharded fit
+    with all of L on every member (replicate_factor = 1), then a LOCAL fit of the SAME theta with another nugget array
+    on the public handle only.  Sharding the test points over the members would now mix two different factors -- the
+    theta comparison alone cannot see that; the epoch does, and the prediction runs on the fresh local factor."""
+    n, d, world = 700, 2, 2
+    X, y = syn.make_dataset(n, d)
+    th = syn.default_theta("se_ard", d)
+    Xs = syn.make_test_points(2 * 128 * world + 40, d)                # enough test points to shard over the members
+    rng = np.random.default_rng(5)
+    nug_a, nug_b = 0.05 + 0.1 * rng.random(n), 0.4 + 0.3 * rng.random(n)
+    g = _lib.Handle(X, y, "se_ard", device=[0] * world)
+    g.set_option("replicate_factor", 1)
+    g.set_option("shard_min_n", 0)
+    assert g.fit_pw(th, None, nug_a) == 0                             # sharded: both members hold L(nug_a)
+    mu_a, var_a = g.predict(Xs)
+    g.set_option("shard_min_n", 1 << 30)
+    assert g.fit_pw(th, None, nug_b) == 0                             # local: member 0 holds L(nug_b), member 1 still L(nug_a)
+    mu_b, var_b = g.predict(Xs)
+    s = _lib.Handle(X, y, "se_ard")
+    assert s.fit_pw(th, None, nug_a) == 0
+    ra = s.predict(Xs)
+    assert s.fit_pw(th, None, nug_b) == 0
+    rb = s.predict(Xs)
+    s.close(); g.close()
+    np.testing.assert_allclose(mu_a, ra[0], rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(var_a, ra[1], rtol=1e-8, atol=1e-11)
+    np.testing.assert_allclose(mu_b, rb[0], rtol=1e-9, atol=1e-11)     # (wrong on the second half of Xs without the epoch)
+    np.testing.assert_allclose(var_b, rb[1], rtol=1e-8, atol=1e-11)
+    assert np.abs(ra[0] - rb[0]).max() > 1e-4                          # the two fits do differ
