@@ -3,7 +3,7 @@
 // Why not -lrccl: a host process may already hold a copy of RCCL (PyTorch-ROCm wheels bundle their own
 // librccl.so next to their own HIP runtime).  Two RCCLs -- or an RCCL linked against a second
 // libamdhip64 -- in one process do not work.  So the library first looks for an RCCL that is ALREADY
-// mapped (RTLD_NOLOAD), then for $GPHIP_RCCL_PATH, then for the system one.  A single-GPU handle never
+// mapped (RTLD_NOLOAD) -- unless $GPHIP_RCCL_PATH names one, which wins --, then for the system one.  A single-GPU handle never
 // touches this file's code; a multi-device handle without any usable RCCL falls back to peer copies
 // (CopyComm in gphip_multi.inc) when all its ranks live in this process, and fails loudly otherwise.
 #pragma once
@@ -44,9 +44,9 @@ inline const RcclApi& rccl() {
         struct Cand { const char* name; int flags; };
         const char* env = getenv("GPHIP_RCCL_PATH");
         const Cand cands[] = {
+            {env, RTLD_NOW},                             // an explicit $GPHIP_RCCL_PATH wins
             {"librccl.so", RTLD_NOW | RTLD_NOLOAD},      // PyTorch's bundled copy, if the host process mapped it
             {"librccl.so.1", RTLD_NOW | RTLD_NOLOAD},
-            {env, RTLD_NOW},
             {"librccl.so.1", RTLD_NOW},
             {"librccl.so", RTLD_NOW},
             {"/opt/rocm/lib/librccl.so.1", RTLD_NOW},

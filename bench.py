@@ -233,7 +233,7 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=32768)
+    ap.add_argument("--n", "--npoints", dest="n", type=int, default=32768)     # (--npoints: torchrun's own parser chokes on an abbreviable "--n")
     ap.add_argument("--d", type=int, default=8)
     ap.add_argument("--panel", type=int, default=0)
     ap.add_argument("--mode", choices=["theta", "cholesky", "cholesky-torch"], default="theta",
@@ -247,6 +247,8 @@ def main() -> None:
     ap.add_argument("--no-alone", action="store_true", help="skip the extra look-ahead-off evaluation behind roofline_syrk_alone "
                                                             "(profiling runs: keeps the rocprof launch statistics those of the timed schedule)")
     ap.add_argument("--no-extras", action="store_true", help="skip the short BASELINE.json cfg-4 / cfg-5 measurements")
+    ap.add_argument("--strong-timeout", type=float, default=180.0, help="seconds the strong-scaling series may take before the "
+                                                                        "record is printed without it")
     ap.add_argument("--no-strong", action="store_true", help="N>1, mode theta: skip the short strong-scaling series (ONE "
                                                              "factorisation sharded over all ranks) printed as the `strong` sub-record")
     args = ap.parse_args()
@@ -262,13 +264,23 @@ def main() -> None:
 
     if not torch.cuda.is_available() or _lib.device_count() < 1:
         raise SystemExit("bench.py needs an MI355X (gfx950): the HIP path has no CPU fallback")
+    # GPHIP_BENCH_BACKEND=gloo (tests only, tests/test_gpu_bench_multirank.py): the multi-rank control flow of this file on
+    # a ONE-GPU box -- every rank on device 0, torch.distributed over gloo, the library's collectives through the
+    # tests-only shared-memory library named by $GPHIP_RCCL_PATH (real RCCL refuses two ranks on one device)
+    backend = os.environ.get("GPHIP_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % torch.cuda.device_count()
+    red_dev = "cuda" if backend == "nccl" else "cpu"
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist_
         dist = dist_
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     n, d = args.n, args.d
     X, y = syn.make_dataset(n, d)                      # every rank regenerates the same data
@@ -324,7 +336,7 @@ def main() -> None:
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        t = torch.tensor([dt], device=red_dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     prof = h.profile()
@@ -342,39 +354,7 @@ def main() -> None:
         alone = h.profile()["syrk_trailing"]
         h.set_option("lookahead", 1)
 
-    # N > 1, default (weak, theta-sharded) mode: ALSO a short strong-scaling series -- the split north_star names: ONE
-    # likelihood factored by all ranks together (1-D block-cyclic Cholesky, RCCL panel broadcast, entirely behind the C ABI
-    # through gphip_create_rank).  Outside the timed region of the headline; reported as the `strong` sub-record.
-    strong = None
-    if dist is not None and not sharded and not args.no_strong:
-        try:
-            box = [_lib.comm_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(box, src=0)
-            hs = _lib.Handle(X, y, "se_ard", device=local_rank, rank=rank, world=world, comm_id=box[0])
-            hs.set_option("shard_min_n", 0)
-            jit0 = syn.uniform(syn.STREAM_THETA, 1000, 8 * (d + 2))
-            ths = base[None, :] * (1.0 + 0.05 * (jit0.reshape(8, d + 2) - 0.5))
-            hs.loglik(ths[0]); hs.loglik(ths[1])
-            barrier()
-            t1 = time.perf_counter()
-            sv = [hs.loglik(ths[2 + i]) for i in range(5)]
-            barrier()
-            ds = time.perf_counter() - t1
-            ts = torch.tensor([ds], device="cuda", dtype=torch.float64)
-            dist.all_reduce(ts, op=dist.ReduceOp.MAX)
-            ci = hs.comm_info()
-            strong = {"what": f"ONE evaluation per step factored by all {world} ranks together (1-D block-cyclic Cholesky, one "
-                              "RCCL broadcast of the factored panel per 512-column step, gphip_create_rank)",
-                      "scaling": "strong", "steps": 5, "ms_per_eval": float(ts.item()) / 5 * 1e3,
-                      "evals_per_s": 5 / float(ts.item()), "speedup_vs_one_gpu_weak_step": (dt / args.steps) / (float(ts.item()) / 5),
-                      "cholesky_tflops_total": n ** 3 / 3.0 * 5 / float(ts.item()) / 1e12,
-                      "rccl_ranks": ci["world"], "comm": ci["comm"], "factor_bytes_per_rank": hs.factor_bytes(),
-                      "all_ok": bool(all(v[1] == 0 and np.isfinite(v[0]) for v in sv))}
-            hs.close()
-        except Exception as exc:                                    # never let the extra break the headline
-            strong = {"error": repr(exc)}
-
-    if rank == 0:
+    def record(strong, alone):
         syrk = prof["syrk_trailing"]
         achieved = syrk["flops"] / (syrk["ms"] * 1e-3) / 1e12 if syrk["ms"] > 0 else 0.0
         evals = args.steps * (1 if sharded else world)
@@ -414,6 +394,59 @@ def main() -> None:
             out["roofline"]["traffic_replayed_from"] = "profiles/" + tr["source"]
             out["roofline"]["traffic_unit"] = "HBM-side bytes per launch (rocprofv3 PMC: 2 x FETCH_SIZE + WRITE_SIZE, KiB -> B)"
             out["roofline"]["algorithmic_bytes_per_launch"] = syrk["bytes"] / max(syrk["launches"], 1)
+        return out
+
+    # N > 1, default (weak, theta-sharded) mode: ALSO a short strong-scaling series -- the split north_star names: ONE
+    # likelihood factored by all ranks together (1-D block-cyclic Cholesky, RCCL panel broadcast, entirely behind the C ABI
+    # through gphip_create_rank).  Outside the timed region of the headline; reported as the `strong` sub-record.
+    strong = None
+    if dist is not None and not sharded and not args.no_strong:
+        # Watchdog: this is the only place where the bench waits inside RCCL collectives of the library (real multi-rank
+        # RCCL has only ever been exercised here).  If one does not return, the headline measured above must not be lost:
+        # after --strong-timeout seconds rank 0 prints the record with the failure noted and every rank leaves.
+        import threading
+
+        def give_up():
+            if rank == 0:
+                rec = record(None, None)
+                rec["strong"] = {"error": f"no result after {args.strong_timeout:.0f} s (a collective call did not return); "
+                                          "the headline above was measured before this series started"}
+                print(json.dumps(rec), flush=True)
+            os._exit(0)
+        dog = threading.Timer(args.strong_timeout + (0.0 if rank == 0 else 5.0), give_up)
+        dog.daemon = True
+        dog.start()
+        try:
+            box = [_lib.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            hs = _lib.Handle(X, y, "se_ard", device=local_rank, rank=rank, world=world, comm_id=box[0])
+            hs.set_option("shard_min_n", 0)
+            jit0 = syn.uniform(syn.STREAM_THETA, 1000, 8 * (d + 2))
+            ths = base[None, :] * (1.0 + 0.05 * (jit0.reshape(8, d + 2) - 0.5))
+            hs.loglik(ths[0]); hs.loglik(ths[1])
+            barrier()
+            t1 = time.perf_counter()
+            sv = [hs.loglik(ths[2 + i]) for i in range(5)]
+            barrier()
+            ds = time.perf_counter() - t1
+            ts = torch.tensor([ds], device=red_dev, dtype=torch.float64)
+            dist.all_reduce(ts, op=dist.ReduceOp.MAX)
+            ci = hs.comm_info()
+            strong = {"what": f"ONE evaluation per step factored by all {world} ranks together (1-D block-cyclic Cholesky, one "
+                              "RCCL broadcast of the factored panel per 512-column step, gphip_create_rank)",
+                      "scaling": "strong", "steps": 5, "ms_per_eval": float(ts.item()) / 5 * 1e3,
+                      "evals_per_s": 5 / float(ts.item()), "speedup_vs_one_gpu_weak_step": (dt / args.steps) / (float(ts.item()) / 5),
+                      "cholesky_tflops_total": n ** 3 / 3.0 * 5 / float(ts.item()) / 1e12,
+                      "rccl_ranks": ci["world"], "comm": ci["comm"], "factor_bytes_per_rank": hs.factor_bytes(),
+                      "all_ok": bool(all(v[1] == 0 and np.isfinite(v[0]) for v in sv))}
+            hs.close()
+        except Exception as exc:                                    # never let the extra break the headline
+            strong = {"error": repr(exc)}
+        dog.cancel()
+
+
+    if rank == 0:
+        out = record(strong, alone)
         if world == 1 and not args.no_extras:
             h.close()                                           # free the 8.7 GB workspace first
             out["other_configs"] = other_configs(local_rank)

@@ -1,0 +1,55 @@
+"""bench.py's multi-rank control flow (launched exactly as the driver launches it: python -m torch.distributed.run,
+one process per rank) on a ONE-GPU box: GPHIP_BENCH_BACKEND=gloo puts every rank on device 0 and torch.distributed on
+gloo, and the library's own collectives (the `strong` sub-record: one factorisation sharded over all ranks through
+gphip_create_rank) go through the tests-only shared-memory collective library, because real RCCL refuses two ranks on
+one device.  Checks the ONE JSON line of rank 0: whole-job value, the strong series, and the watchdog that prints the
+record without the series when a collective does not return."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+from bayesianinference_amd import build
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _run(tmp_name, extra, world=2, timeout=600):
+    fake = build.build_fake_rccl()
+    env = dict(os.environ, GPHIP_BENCH_BACKEND="gloo", GPHIP_RCCL_PATH=fake, FAKE_RCCL_SHM=f"/gphip_bench_{os.getpid()}_{tmp_name}",
+               LD_LIBRARY_PATH="/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "2",
+           "--warmup", "1", "--npoints", "4096"] + extra
+    p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=timeout)
+    assert p.returncode == 0, (p.stdout + p.stderr)[-4000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]                       # rank 0 prints ONE JSON line
+    return json.loads(lines[0])
+
+
+def test_two_ranks_weak_headline_and_strong_series():
+    rec = _run("a", [])
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["steps"] == 2 and rec["warmup"] == 1
+    assert rec["value"] > 0 and abs(rec["value"] - 2 * 2 / (rec["ms_per_step"] * 2 * 1e-3)) < 1e-6 * rec["value"]   # whole job: 2 ranks x 2 steps
+    assert rec["config"]["parallelism"] == "theta-sharded x2" and rec["dtype"] == "f64"
+    st = rec["strong"]
+    assert "error" not in st, st
+    assert st["scaling"] == "strong" and st["rccl_ranks"] == 2 and st["all_ok"] and st["ms_per_eval"] > 0
+    assert "cpu_baseline" not in rec                                # rank 0 at N = 1 only
+
+
+def test_strong_series_watchdog_keeps_the_headline():
+    rec = _run("b", ["--strong-timeout", "0.001"])                 # the series cannot finish in 1 ms: the watchdog speaks
+    assert rec["n_gpus"] == 2 and rec["value"] > 0
+    assert "no result after" in rec["strong"]["error"]
