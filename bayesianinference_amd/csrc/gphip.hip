@@ -53,7 +53,8 @@ struct gphip_ctx {
     std::vector<hipEvent_t> sync_events;
     size_t sync_used = 0;
     hipEvent_t ev_built0 = nullptr;              // queue_build -> queue_factor: "the tile columns of panel 0 are built" (split build)
-    int build_overlap = 1;                       // option: factor panel 0 under the rest of the kernel build
+    int build_overlap = 0;                       // option: factor panel 0 under the rest of the kernel build (measured: -0.1 % per
+                                                 // evaluation, but the build itself slows 4-15 % while it shares the chip: off)
     bool own_streams = true;
     int dist_rank = 0, dist_world = 0;  // > 0 between gphip_dist_begin and gphip_dist_end
     bool dist_theta_ok = true;

@@ -163,6 +163,68 @@ def pmc_traffic(kernel_substr: str = "gemm_nt_kernel<double, 0,"):
     return best
 
 
+def under_profiler() -> bool:
+    return any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
+
+
+def live_pmc_traffic(n: int, d: int, device: int, kernel_substr: str = "gemm_nt_kernel<double, 0,"):
+    """HBM-side bytes per launch of the dominant kernel measured IN THIS RUN: two child processes run the same evaluation
+    (`bench.py --pmc-probe`: this file, no torch) under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` -- one counter
+    per pass, no trace domain next to it, as MI355X_MICROARCH.md (HBM section) prescribes; FETCH_SIZE is doubled (gfx950
+    counts 64 B per 128-B request on wide coalesced reads), both are KiB.  Returns None (and the caller falls back to the
+    committed profiles/ summary) when rocprofv3 is missing, this process is itself being profiled, or a pass fails."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None or under_profiler():
+        return None
+    got = {}
+    t0 = time.perf_counter()
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        tmp = tempfile.mkdtemp(prefix="gphip_pmc_", dir="/tmp")
+        try:
+            env = dict(os.environ, TMPDIR="/tmp", GPHIP_NO_TORCH="1", HIP_VISIBLE_DEVICES=os.environ.get("HIP_VISIBLE_DEVICES", str(device)),
+                       LD_LIBRARY_PATH="/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+            cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", tmp, "-o", "p", "--", sys.executable,
+                   os.path.join(ROOT, "bench.py"), "--pmc-probe", "--npoints", str(n), "--d", str(d)]
+            res = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
+            if res.returncode != 0:
+                return None
+            vals = []
+            for path in glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True):
+                with open(path) as f:
+                    for row in csv.DictReader(f):
+                        if kernel_substr in row["Kernel_Name"] and row["Counter_Name"] == counter:
+                            vals.append(float(row["Counter_Value"]))
+            if not vals:
+                return None
+            got[counter] = (sum(vals) / len(vals), len(vals))
+        except Exception:                                       # never let the counters break the headline
+            return None
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+    return {"bytes_per_launch": (2.0 * got["FETCH_SIZE"][0] + got["WRITE_SIZE"][0]) * 1024.0,
+            "fetch_kib_per_launch": got["FETCH_SIZE"][0], "write_kib_per_launch": got["WRITE_SIZE"][0],
+            "launches": got["FETCH_SIZE"][1], "seconds": round(time.perf_counter() - t0, 1)}
+
+
+def pmc_probe(n: int, d: int) -> None:
+    """Child of live_pmc_traffic: the timed loop's evaluation (same data, same theta stream), twice, nothing else."""
+    from bayesianinference_amd import _lib, synthetic as syn
+    X, y = syn.make_dataset(n, d)
+    h = _lib.Handle(X, y, "se_ard")
+    base = syn.default_theta("se_ard", d)
+    jit = syn.uniform(syn.STREAM_THETA, 1000, 2 * (d + 2))
+    for th in base[None, :] * (1.0 + 0.05 * (jit.reshape(2, d + 2) - 0.5)):
+        ll, info = h.loglik(th)
+        if info != 0:
+            raise SystemExit("pmc probe: evaluation failed")
+    h.close()
+
+
 def other_configs(local_rank: int) -> dict:
     """Short measurements of the other BASELINE.json configs on one GPU (reported next to the headline,
     never part of `value`): cfg 1 / cfg 2 = one theta at a time at N=512 d=1 and N=8192 d=8 (the
@@ -247,6 +309,9 @@ def main() -> None:
     ap.add_argument("--no-alone", action="store_true", help="skip the extra look-ahead-off evaluation behind roofline_syrk_alone "
                                                             "(profiling runs: keeps the rocprof launch statistics those of the timed schedule)")
     ap.add_argument("--no-extras", action="store_true", help="skip the short BASELINE.json cfg-4 / cfg-5 measurements")
+    ap.add_argument("--pmc-probe", action="store_true", help=argparse.SUPPRESS)      # child mode of live_pmc_traffic
+    ap.add_argument("--no-live-pmc", action="store_true", help="do not measure roofline.traffic in this run (two rocprofv3 --pmc "
+                                                               "passes over a child process); replay profiles/ instead")
     ap.add_argument("--strong-timeout", type=float, default=180.0, help="seconds the strong-scaling series may take before the "
                                                                         "record is printed without it")
     ap.add_argument("--no-strong", action="store_true", help="N>1, mode theta: skip the short strong-scaling series (ONE "
@@ -259,6 +324,9 @@ def main() -> None:
     if world != args.gpus and world > 1:
         args.gpus = world
 
+    if args.pmc_probe:
+        pmc_probe(args.n, args.d)
+        return
     import torch
     from bayesianinference_amd import _lib, synthetic as syn
 
@@ -389,7 +457,7 @@ def main() -> None:
                                                "gemm_nt_kernel<double, 0, 2, 2, 2>, look-ahead off (outside the timed region)")
         tr = pmc_traffic()
         if tr is not None:
-            # NOT measured in this run: PMC counters need their own rocprofv3 passes (profiles/); replayed for reference
+            # the committed PMC passes (profiles/); replaced below by counters measured in THIS run when that is possible
             out["roofline"]["traffic"] = tr["bytes_per_launch"]
             out["roofline"]["traffic_replayed_from"] = "profiles/" + tr["source"]
             out["roofline"]["traffic_unit"] = "HBM-side bytes per launch (rocprofv3 PMC: 2 x FETCH_SIZE + WRITE_SIZE, KiB -> B)"
@@ -447,6 +515,18 @@ def main() -> None:
 
     if rank == 0:
         out = record(strong, alone)
+        if world == 1 and not args.no_extras and not args.no_live_pmc and args.mode == "theta":
+            live = live_pmc_traffic(n, d, local_rank)
+            if live is not None:
+                committed = out["roofline"].get("traffic")
+                out["roofline"]["traffic"] = live["bytes_per_launch"]
+                out["roofline"].pop("traffic_replayed_from", None)
+                out["roofline"]["traffic_unit"] = "HBM-side bytes per launch (rocprofv3 PMC: 2 x FETCH_SIZE + WRITE_SIZE, KiB -> B)"
+                out["roofline"]["algorithmic_bytes_per_launch"] = prof["syrk_trailing"]["bytes"] / max(prof["syrk_trailing"]["launches"], 1)
+                out["roofline"]["traffic_source"] = (
+                    f"measured in this run: two child processes of this bench (bench.py --pmc-probe, 2 evaluations each) under "
+                    f"rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, {live['launches']} launches averaged, {live['seconds']} s "
+                    f"outside the timed region; committed profiles/ summary says {committed}")
         if world == 1 and not args.no_extras:
             h.close()                                           # free the 8.7 GB workspace first
             out["other_configs"] = other_configs(local_rank)

@@ -217,10 +217,10 @@ int gphip_ns_crude_weights(const double* points, const double* loglik, int64_t m
  *   "panel_left"   -1 auto / 0 / 1: left-looking in-panel updates (one K = 128 s update per column instead of
  *                  K = 128 updates after every column); auto = for batches of more than "dataflow_max_slots" and
  *                  for panels of >= 8 tiles (the wide early panels of a large factorisation)
- *   "build_overlap" 0/1 (default 1): the look-ahead schedule builds the tile columns of outer panel 0 first and starts
+ *   "build_overlap" 0/1 (default 0): the look-ahead schedule builds the tile columns of outer panel 0 first and starts
  *                  factoring them on the panel stream while the main stream builds the rest of K (measured: the first
- *                  trailing update starts 0.2-0.7 ms earlier; -0.1 % at N = 32768, noise for batches whose build fills
- *                  every CU anyway)
+ *                  trailing update starts 0.2-0.7 ms earlier, -0.1 % at N = 32768, noise for batches whose build fills
+ *                  every CU anyway -- while the build kernel itself runs 4-15 % slower sharing the chip; kept off)
  *   "fused_eval"   0/1 (default 1): a pure likelihood call of <= 8 thetas that qualifies for 64-tile dataflow
  *                  runs as ONE kernel launch (K(theta) tiles built inside the kernel, results written to
  *                  pinned host memory by its last task)

@@ -677,7 +677,8 @@ def test_thin_tiles_skip_only_work_nobody_reads(n, d, dtype, batch):
 
 def test_experimental_schedules_give_the_same_factorisation():
     """Options kept for the record: `la_main` (look-ahead update ahead of the trailing update on the
-    main stream) and `rest_split` (each trailing update as two grouped launches on two streams).  Different launch
+    main stream), `rest_split` (each trailing update as two grouped launches on two streams) and `build_overlap` (panel 0
+    factored under the rest of the kernel build).  Different launch
     structure, same arithmetic per tile: results agree with the default schedule to rounding."""
     n, d = 20000, 4                                      # Nt = 157: wide early panels, look-ahead, dataflow tail
     X, y = syn.make_dataset(n, d)
@@ -685,10 +686,13 @@ def test_experimental_schedules_give_the_same_factorisation():
     h = _lib.Handle(X, y, "se_ard")
     ref = h.loglik_parts(th)
     assert ref[3] == 0
-    for opt in ("la_main", "rest_split"):
+    for opt in ("la_main", "rest_split", "build_overlap"):
         h.set_option(opt, 1)
+        if opt == "rest_split":
+            h.set_option("supertile", 0)                 # (the split launches exist only with the plain tile order)
         got = h.loglik_parts(th)
         h.set_option(opt, 0)
+        h.set_option("supertile", 2)
         assert got[3] == 0 and all(close(got[k], ref[k], n, 1e-11) for k in range(3)), (opt, got, ref)
     # tile order of the trailing update (default 2 = blocked list; 0 = column-major list; 1 = static super-tiles): the
     # order decides WHICH workgroup computes a tile, never how -- results are bit-identical
