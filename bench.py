@@ -262,6 +262,23 @@ def other_configs(local_rank: int) -> dict:
     except Exception as exc:                                    # never let an extra break the headline
         out["cfg4_error"] = repr(exc)
     try:
+        # cfg 4 as BASELINE.json words it: the SAMPLER with 200 live points over (l, sigma_f, sigma_n) on an N=4096 problem --
+        # the native batched driver (gphip_nested_sampling: 200 lock-step walkers x 20 Metropolis steps per round, every
+        # round ONE gphip_loglik_batch of 200 thetas), 150 nested iterations after the 200-point initial sweep
+        X, y = syn.make_dataset(4096, 1)
+        h = _lib.Handle(X, y, "se", device=local_rank)
+        box = [(0.1, 10.0), (0.1, 10.0), (0.01, 1.0)]
+        h.loglik_batch(np.tile(np.array([[1.0, 1.0, 0.1]]), (200, 1)))             # size the 200-slot workspace first
+        t0 = time.perf_counter()
+        res = h.nested_sampling(box, pool=200, walkers=200, mc_steps=20, max_iterations=150, min_iterations=150, seed=1)
+        dt = time.perf_counter() - t0
+        out["cfg4_nested_sampling_200live_n4096_f64"] = {
+            "likelihood_evals_per_s": res["LikelihoodEvaluations"] / dt, "likelihood_evals": int(res["LikelihoodEvaluations"]),
+            "nested_iterations": int(res["GeneratedNestedSamples"]), "seconds": dt, "crude_log_evidence": res["CrudeLogEvidence"]}
+        h.close()
+    except Exception as exc:
+        out["cfg4_ns_error"] = repr(exc)
+    try:
         n, d, m = 65536, 16, 10000
         X, y = syn.make_dataset(n, d)
         th = syn.default_theta("matern52_ard", d, dtype="f32")
