@@ -473,10 +473,11 @@ __global__ __launch_bounds__(256) void kbuild_kernel(KBuildArgs<T> a) {
 // workgroup (look-ahead runs it concurrently with the trailing SYRK), and MFMA fragment reads
 // (lane -> row l&15, k = l>>4) are bank-conflict free.
 // ---------------------------------------------------------------------------------------------
-// developer instrumentation (scripts/micro/potrf_time.hip): phase stamps of workgroup 0, thread 0
+// developer instrumentation (scripts/micro/df_phases.hip): phase stamps of thread 0 of every workgroup
 #ifdef GPHIP_TIMING
-__device__ long long g_stamps[64];
-#define GP_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_stamps[i] = clock64(); } while (0)
+__device__ long long* g_stamp_buf;               // [workgroups of the launch][64] wall-clock (100 MHz) phase stamps; entry 63 of a
+                                                 // dataflow workgroup = its task number
+#define GP_STAMP(i) do { if (threadIdx.x == 0 && g_stamp_buf) g_stamp_buf[(long)blockIdx.x * 64 + (i)] = wall_clock64(); } while (0)
 #else
 #define GP_STAMP(i) do { } while (0)
 #endif
@@ -1517,6 +1518,9 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g, Th
     j = __builtin_amdgcn_readfirstlane(j);                 // (through the vector sqrt: back to the scalar unit)
     const int i = __builtin_amdgcn_readfirstlane(j + (q - (j * R - j * (j - 1) / 2)));
 
+#ifdef GPHIP_TIMING
+    if (threadIdx.x == 0 && g_stamp_buf) g_stamp_buf[(long)blockIdx.x * 64 + 63] = task;
+#endif
     long long* tr = g.trace ? g.trace + (long)task * 8 : nullptr;
     auto stamp = [&](int k) { if (tr && tid == 0) tr[k] = wall_clock64(); };
     stamp(0);

@@ -53,6 +53,7 @@ struct gphip_ctx {
     std::vector<hipEvent_t> sync_events;
     size_t sync_used = 0;
     hipEvent_t ev_built0 = nullptr;              // queue_build -> queue_factor: "the tile columns of panel 0 are built" (split build)
+    int dataflow_lds_kib = -1;                   // LDS request of the 64-tile dataflow kernel (> 80: ONE workgroup per CU); -1 auto, 0 off
     int build_overlap = 0;                       // option: factor panel 0 under the rest of the kernel build (measured: -0.1 % per
                                                  // evaluation, but the build itself slows 4-15 % while it shares the chip: off)
     bool own_streams = true;
@@ -653,7 +654,16 @@ void launch_dataflow(gphip_ctx* h, int nslots, int c0 = 0, double* part = nullpt
         g.hres = h->hRes; g.hinfo = h->hInfo;
         h->hInfo[nslots] = 0;                  // the abort word: only ever SET by the kernel
     }
-    constexpr size_t lds = df_lds_bytes<T, TBX, NST>();
+    size_t lds = df_lds_bytes<T, TBX, NST>();
+    if constexpr (TBX == 64) {
+        // ONE workgroup per CU while the launch is chain bound: the chain's latency-bound potrf / solve waves then never share
+        // a SIMD with another workgroup's back-to-back MFMAs (per-phase stamps, scripts/micro/df_phases.hip: every phase of
+        // potrf64 runs 1.6-1.8x slower next to a co-resident accumulating workgroup).  Measured crossover ~3 500 tasks:
+        // one theta N = 2048-5120 -3..-7 %, N = 6144 -1 %, N >= 7168 +14 % (throughput bound: two per CU);
+        // 2 thetas up to N = 3072, 4 up to 2048, 8 up to 1536.  Occupancy is set through the LDS request (> 80 KiB).
+        const int kib = h->dataflow_lds_kib < 0 ? (tasks <= 3500 ? 84 : 0) : h->dataflow_lds_kib;
+        if ((size_t)kib * 1024 > lds) lds = (size_t)kib * 1024;
+    }
     hipLaunchKernelGGL((chol_dataflow_kernel<T, TBX, OCC, NST, BUILD>), dim3((unsigned)tasks), dim3(256), lds, h->stream, g, tp);
 }
 
@@ -1124,7 +1134,7 @@ int set_func_attrs(gphip_ctx* h) {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>((chol_dataflow_kernel<T, 128, 1, 4>)),
                                hipFuncAttributeMaxDynamicSharedMemorySize, df128x));
     if constexpr (sizeof(T) == 8) {
-        constexpr int df64 = (int)df_lds_bytes<T, 64, 2>();
+        constexpr int df64 = 152 * 1024;       // (room for the one-workgroup-per-CU request, option "dataflow_lds_kib")
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(chol_dataflow_kernel<T, 64, 2>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, df64));
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>((chol_dataflow_kernel<T, 64, 2, 2, true>)),
@@ -2608,7 +2618,7 @@ int* option_slot(gphip_ctx* h, const char* name) {
         {"dataflow", &gphip_ctx::dataflow}, {"dataflow_max_nt", &gphip_ctx::dataflow_max_nt},
         {"dataflow_max_slots", &gphip_ctx::dataflow_max_slots}, {"dataflow_fine_nt", &gphip_ctx::dataflow_fine_nt},
         {"dataflow_tail", &gphip_ctx::dataflow_tail}, {"grad_potri", &gphip_ctx::grad_potri},
-        {"fused_eval", &gphip_ctx::fuse_option}, {"panel_left", &gphip_ctx::panel_left}, {"build_overlap", &gphip_ctx::build_overlap},
+        {"fused_eval", &gphip_ctx::fuse_option}, {"panel_left", &gphip_ctx::panel_left}, {"build_overlap", &gphip_ctx::build_overlap}, {"dataflow_lds_kib", &gphip_ctx::dataflow_lds_kib},
         {"max_slots", &gphip_ctx::max_slots}, {"shard_min_n", &gphip_ctx::shard_min_n},
         {"thin_tiles", &gphip_ctx::thin_tiles}, {"panel_wide", &gphip_ctx::panel_wide},
         {"la_main", &gphip_ctx::la_main}, {"rest_split", &gphip_ctx::rest_split},
