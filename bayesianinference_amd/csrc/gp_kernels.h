@@ -1432,6 +1432,8 @@ struct DfArgs {
     unsigned long long ticket_base;           // value of *ticket before this launch
     int* abort_flag;
     int nd, nslots, epoch;                    // nd = diagonal blocks = Npad / TBX; tile row nd = the rhs rows
+    int* park;                                // 64-tiles, two workgroups per CU: [DF_PARK_SLOTS] counters "a chain task is in its critical
+                                              // section on this CU" (index = XCC / SE / SH / CU id); the neighbour sleeps meanwhile; or null
     long long* trace;                         // developer timing (scripts/micro/df_trace.hip): 8 stamps per task, or null
     // BUILD variant only (one launch per evaluation: tiles built in-kernel, results exported by the corner task)
     const T* xt; const T* yv;                 // unscaled inputs [d][npad], outputs [npad]
@@ -1439,6 +1441,7 @@ struct DfArgs {
     double* hres; int* hinfo;                 // pinned host: {logdet, quad} per slot; info per slot + abort flag
 };
 
+constexpr int DF_PARK_SLOTS = 4096;           // 16 XCC ids x 256 (SE, SH, CU) ids
 constexpr int DF_SPIN_LIMIT = 1 << 22;        // x ~1 us per poll: seconds, never reached by a live schedule
 
 __device__ __forceinline__ void df_wait(const int* f, int epoch, int* abort_flag) {
@@ -1492,6 +1495,7 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g, Th
     constexpr int FI = TBX / 32, FJ = TBX / 32, WT = TBX / 2;   // MFMA tiles per wave, wave tile edge
     extern __shared__ double smem_raw[];
     __shared__ int s_task;
+    __shared__ int s_park;
     T* smem = reinterpret_cast<T*>(smem_raw);
     typedef typename Num<T>::acc_t acc_t;
     constexpr int GK = Num<T>::GK;
@@ -1530,6 +1534,32 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g, Th
 #define GP_DF_PRIO 3
 #endif
     if (GP_DF_PRIO > 0 && (i == j || (TBX == 64 && i == j + 1))) __builtin_amdgcn_s_setprio(GP_DF_PRIO);
+    // Per-phase stamps (scripts/micro/df_phases.hip) show every phase of a diagonal task's potrf / solve running 1.6-1.8x slower
+    // next to a co-resident workgroup's back-to-back MFMAs (and at its stand-alone pace with the CU to itself).  So while a
+    // diagonal task is in its critical section -- dependencies met, nothing but its own work between it and ready(j,j) -- it
+    // raises a counter keyed by its CU, and the neighbour workgroup checks that counter once per slab and sleeps while it is
+    // up.  A task in its own critical section never sleeps, and a critical section needs nobody else: no deadlock.
+    int* parkp = nullptr;
+    bool critical = false;
+    if constexpr (TBX == 64) {
+        if (g.park) {
+            const unsigned hw = __builtin_amdgcn_s_getreg((7 << 11) | (8 << 6) | 4);       // HW_ID[15:8] = SE, SH, CU ids
+            const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);     // XCC_ID[3:0]
+            parkp = g.park + (((xcc & 15) << 8) | (hw & 255));
+        }
+    }
+    auto enter_critical = [&]() {
+        if (parkp && !critical) {
+            critical = true;
+            if (tid == 0) __hip_atomic_fetch_add(parkp, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
+    auto leave_critical = [&]() {
+        if (parkp && critical) {
+            critical = false;
+            if (tid == 0) __hip_atomic_fetch_add(parkp, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
     T* As = g.A + (long)slot * g.bstride;
     int* F = g.flags + (long)slot * g.f_bstride;
     T* Wj = g.W + (long)slot * g.w_bstride + (long)j * TBX * TBX;
@@ -1744,10 +1774,25 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g, Th
             __syncthreads();
             for (int kb = 0; kb < nk; ++kb) {
                 const int cur = kb & 1;
+                // once per slab: does a chain task want this CU to itself?  (the load flies under the slab's first stage)
+                const bool chk = TBX == 64 && parkp != nullptr && !critical && (kb % SPB) == 0;
+                int pk = 0;
+                if (chk && tid == 0) pk = __hip_atomic_load(parkp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (kb + 1 < nk) stage(kb + 1, cur ^ 1);
                 compute(cur);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (chk && tid == 0) s_park = pk;
                 __syncthreads();
+                if (chk && __builtin_expect(s_park != 0, 0)) {
+                    for (int it = 0; it < 2048; ++it) {             // bounded (~ms): a missed wake-up costs time, never a hang
+                        __builtin_amdgcn_s_sleep(48);
+                        __syncthreads();
+                        if (tid == 0) s_park = __hip_atomic_load(parkp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __syncthreads();
+                        if (s_park == 0) break;
+                    }
+                    __syncthreads();
+                }
             }
         }
     };
@@ -1836,6 +1881,7 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g, Th
                 df_wait(F + jm * R + jm, g.epoch, g.abort_flag);          // W_{j-1}
             }
             __syncthreads();
+            enter_critical();                              // from here to ready(j,j) nothing but this workgroup's own work
             stamp(5);
             acc_t accx[FJ][FI];
             zero_c(accx);
@@ -1894,6 +1940,7 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g, Th
             }
             return;
         }
+        enter_critical();                                   // (column 0 has no sub-diagonal solve before it)
         // accumulators -> tile-packed LDS image of the lower triangle, then factor + invert in place
         T* Ls = reinterpret_cast<T*>(smem_raw + 2);
 #pragma unroll
@@ -1912,6 +1959,7 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g, Th
                                         (T)sp[3]);
         stamp(3);
         publish(j, j);
+        leave_critical();
         stamp(4);
         return;
     }

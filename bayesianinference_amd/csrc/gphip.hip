@@ -53,6 +53,7 @@ struct gphip_ctx {
     std::vector<hipEvent_t> sync_events;
     size_t sync_used = 0;
     hipEvent_t ev_built0 = nullptr;              // queue_build -> queue_factor: "the tile columns of panel 0 are built" (split build)
+    int dataflow_park = 1;                       // 64-tile dataflow, two workgroups per CU: park the neighbour of a chain task
     int dataflow_lds_kib = -1;                   // LDS request of the 64-tile dataflow kernel (> 80: ONE workgroup per CU); -1 auto, 0 off
     int build_overlap = 0;                       // option: factor panel 0 under the rest of the kernel build (measured: -0.1 % per
                                                  // evaluation, but the build itself slows 4-15 % while it shares the chip: off)
@@ -319,7 +320,7 @@ int ensure_slots(gphip_ctx* h, int want, bool workspace = true) {
     dev((void**)&h->dRes, S * 2 * 8, "results");
     dev((void**)&h->dInfo, S * 4, "info words");
     dev((void**)&h->dFlags, nflags, "dependency flags");
-    dev((void**)&h->dTicket, 16, "ticket counter");
+    dev((void**)&h->dTicket, 16 + DF_PARK_SLOTS * 4, "ticket counter");        // + the per-CU "chain task here" counters
     host((void**)&h->hInvEll, S * h->d * 8, "pinned inverse length scales");
     host((void**)&h->hSlotp, S * SLOTP * 8, "pinned slot scalars");
     host((void**)&h->hRes, S * 2 * 8, "pinned results");
@@ -329,7 +330,7 @@ int ensure_slots(gphip_ctx* h, int want, bool workspace = true) {
     // numbers) or tickets before the clear landed.  Found by scripts/gpu_api_fuzz.py (wrong likelihood / memory fault
     // right after a batch grew the slot count), present since round 1.
     if (e == hipSuccess && (e = hipMemsetAsync(h->dFlags, 0, nflags, h->stream)) != hipSuccess) what = "flag clear";
-    if (e == hipSuccess && (e = hipMemsetAsync(h->dTicket, 0, 16, h->stream)) != hipSuccess) what = "ticket clear";
+    if (e == hipSuccess && (e = hipMemsetAsync(h->dTicket, 0, 16 + DF_PARK_SLOTS * 4, h->stream)) != hipSuccess) what = "ticket clear";
     if (e != hipSuccess) {
         (void)hipGetLastError();               // (clear the sticky out-of-memory status)
         free_slots(h);
@@ -655,6 +656,7 @@ void launch_dataflow(gphip_ctx* h, int nslots, int c0 = 0, double* part = nullpt
         h->hInfo[nslots] = 0;                  // the abort word: only ever SET by the kernel
     }
     size_t lds = df_lds_bytes<T, TBX, NST>();
+    g.park = nullptr;
     if constexpr (TBX == 64) {
         // ONE workgroup per CU while the launch is chain bound: the chain's latency-bound potrf / solve waves then never share
         // a SIMD with another workgroup's back-to-back MFMAs (per-phase stamps, scripts/micro/df_phases.hip: every phase of
@@ -663,6 +665,8 @@ void launch_dataflow(gphip_ctx* h, int nslots, int c0 = 0, double* part = nullpt
         // 2 thetas up to N = 3072, 4 up to 2048, 8 up to 1536.  Occupancy is set through the LDS request (> 80 KiB).
         const int kib = h->dataflow_lds_kib < 0 ? (tasks <= 3500 ? 84 : 0) : h->dataflow_lds_kib;
         if ((size_t)kib * 1024 > lds) lds = (size_t)kib * 1024;
+        // two workgroups per CU: the neighbour of a diagonal task steps aside while that task is on the chain
+        if (lds <= 80 * 1024 && h->dataflow_park) g.park = reinterpret_cast<int*>(h->dTicket + 2);
     }
     hipLaunchKernelGGL((chol_dataflow_kernel<T, TBX, OCC, NST, BUILD>), dim3((unsigned)tasks), dim3(256), lds, h->stream, g, tp);
 }
@@ -1087,7 +1091,7 @@ int eval_chunk(gphip_ctx* h, const double* Theta, int nb, double* out, double* p
     HIPCHK(hipGetLastError());
     harvest(h);
     if (h->hInfo[nb] != 0) {                   // a dataflow dependency wait hit its spin limit: results are void
-        HIPCHK(hipMemsetAsync(h->dTicket + 1, 0, 8, h->stream));
+        HIPCHK(hipMemsetAsync(h->dTicket + 1, 0, 8 + DF_PARK_SLOTS * 4, h->stream));
         return fail(h, GPHIP_ERR_HIP, "dataflow Cholesky schedule timed out (set option dataflow=0 and report)");
     }
     for (int s = 0; s < nb; ++s) {
@@ -2618,7 +2622,7 @@ int* option_slot(gphip_ctx* h, const char* name) {
         {"dataflow", &gphip_ctx::dataflow}, {"dataflow_max_nt", &gphip_ctx::dataflow_max_nt},
         {"dataflow_max_slots", &gphip_ctx::dataflow_max_slots}, {"dataflow_fine_nt", &gphip_ctx::dataflow_fine_nt},
         {"dataflow_tail", &gphip_ctx::dataflow_tail}, {"grad_potri", &gphip_ctx::grad_potri},
-        {"fused_eval", &gphip_ctx::fuse_option}, {"panel_left", &gphip_ctx::panel_left}, {"build_overlap", &gphip_ctx::build_overlap}, {"dataflow_lds_kib", &gphip_ctx::dataflow_lds_kib},
+        {"fused_eval", &gphip_ctx::fuse_option}, {"panel_left", &gphip_ctx::panel_left}, {"build_overlap", &gphip_ctx::build_overlap}, {"dataflow_lds_kib", &gphip_ctx::dataflow_lds_kib}, {"dataflow_park", &gphip_ctx::dataflow_park},
         {"max_slots", &gphip_ctx::max_slots}, {"shard_min_n", &gphip_ctx::shard_min_n},
         {"thin_tiles", &gphip_ctx::thin_tiles}, {"panel_wide", &gphip_ctx::panel_wide},
         {"la_main", &gphip_ctx::la_main}, {"rest_split", &gphip_ctx::rest_split},

@@ -220,6 +220,8 @@ int gphip_ns_crude_weights(const double* points, const double* loglik, int64_t m
  *   "dataflow_lds_kib" -1 auto (default) / 0 / KiB: LDS request of the 64-tile dataflow kernel; > 80 puts ONE workgroup on a
  *                  CU, which keeps the chain's latency-bound waves off SIMDs busy with another workgroup's MFMAs: auto
  *                  asks for 84 KiB while the launch has <= 3 500 tile tasks (one theta up to N ~ 5 000: -3..-7 %)
+ *   "dataflow_park" 0/1 (default 1): 64-tile dataflow launches with two workgroups per CU -- the workgroup sharing a CU with a
+ *                  diagonal (chain) task sleeps while that task is in its critical section (N = 6144: -9 %, 8192: -1 %)
  *   "build_overlap" 0/1 (default 0): the look-ahead schedule builds the tile columns of outer panel 0 first and starts
  *                  factoring them on the panel stream while the main stream builds the rest of K (measured: the first
  *                  trailing update starts 0.2-0.7 ms earlier, -0.1 % at N = 32768, noise for batches whose build fills

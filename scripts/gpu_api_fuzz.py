@@ -53,13 +53,13 @@ while time.time() < t_end:
         if op == "option":
             name = str(rng.choice(["panel", "dataflow", "lookahead", "thin_tiles", "fused_eval", "dataflow_fine_nt", "panel_wide",
                                    "dataflow_tail", "grad_potri", "max_slots", "latency_gemm", "shard_min_n", "panel_left",
-                                   "replicate_factor", "share_local_panels", "debug_fail_alloc", "supertile", "build_overlap"]))
+                                   "replicate_factor", "share_local_panels", "debug_fail_alloc", "supertile", "build_overlap", "dataflow_park", "dataflow_lds_kib"]))
             if name == "debug_fail_alloc" and rng.random() < 0.7:
                 name = "panel"
             val = {"panel": int(rng.choice([1, 2, 3, 4, 6])), "dataflow_fine_nt": int(rng.choice([0, 96])),
                    "debug_fail_alloc": int(rng.choice([1, 3, 7, 10])),
                    "dataflow_tail": int(rng.choice([0, 7, 64])), "max_slots": int(rng.choice([1, 3, 256])),
-                   "shard_min_n": int(rng.choice([0, 1 << 30])), "panel_left": int(rng.choice([-1, 0, 1])), "supertile": int(rng.choice([0, 1, 2, 3]))}.get(name, int(rng.integers(0, 2)))
+                   "shard_min_n": int(rng.choice([0, 1 << 30])), "panel_left": int(rng.choice([-1, 0, 1])), "supertile": int(rng.choice([0, 1, 2, 3])), "dataflow_lds_kib": int(rng.choice([-1, 0, 84]))}.get(name, int(rng.integers(0, 2)))
             print(f'    {name}={val}', file=log, flush=True)
             if name == "debug_fail_alloc":
                 # fault injection: the next slot (re)allocation fails at its val-th device allocation; the call must
@@ -78,6 +78,9 @@ while time.time() < t_end:
                 continue
             h.set_option(name, val)
             opts[name] = val
+            if name == "panel" and world > 1:
+                fitted = None          # documented: a DISTRIBUTED factor is laid out for the panel width it was made with;
+                                       # prediction after a change of "panel" is refused (GPHIP_ERR_STATE: fit again)
             continue
         if op == "nasty":
             # hyper-parameters the closure must survive (BS:276-298: total over the box, sentinel on failure): NaN, 0,

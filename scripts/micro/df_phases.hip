@@ -1,7 +1,7 @@
 // Per-task timeline of chol_dataflow_kernel<double, 64, 2, 2> on a synthetic SPD matrix in the packed tile-major layout,
 // WITH the phase stamps of the potrf body inside the diagonal tasks (developer tool; wall clock = 100 MHz s_memrealtime).
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -o /tmp/df_phases scripts/micro/df_phases.hip && /tmp/df_phases 64
-// argument = number of 128-tile columns (64 -> N = 8192: the loaded regime; 8 -> N = 1024: the chain alone)
+// arguments: number of 128-tile columns (64 -> N = 8192: the loaded regime; 8 -> N = 1024: the chain alone) [LDS KiB per workgroup]
 #define GPHIP_TIMING 1
 #include "../../bayesianinference_amd/csrc/gp_kernels.h"
 #include <algorithm>
@@ -30,9 +30,10 @@ int main(int argc, char** argv) {
     double sp[SLOTP] = {1.0, 0.1, 0.0, 1e-14};
     hipMemcpy(dS, sp, sizeof sp, hipMemcpyHostToDevice); hipMemset(dI, 0, 4); hipMemset(dF, 0, (size_t)R * R * 4); hipMemset(dT, 0, 16);
     hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_buf), &dSt, sizeof dSt);
-    constexpr size_t lds = df_lds_bytes<double, 64, 2>();
+    size_t lds = df_lds_bytes<double, 64, 2>();
+    if (argc > 2 && (size_t)atoi(argv[2]) * 1024 > lds) lds = (size_t)atoi(argv[2]) * 1024;      // > 80 KiB: one workgroup per CU
     auto kern = chol_dataflow_kernel<double, 64, 2, 2, false>;
-    hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
     std::vector<long long> tr((size_t)ntask * 8), st((size_t)ntask * 64);
     for (int rep = 0; rep < 3; ++rep) {
         hipMemcpy(dA, A.data(), A.size() * 8, hipMemcpyHostToDevice);
