@@ -53,6 +53,7 @@ struct gphip_ctx {
     std::vector<hipEvent_t> sync_events;
     size_t sync_used = 0;
     hipEvent_t ev_built0 = nullptr;              // queue_build -> queue_factor: "the tile columns of panel 0 are built" (split build)
+    int dataflow_occ3 = -1;                      // 64-tile kernel built for three workgroups per CU: -1 auto (>= 8 000 tasks), 0 never, 1 always
     int dataflow_park = 1;                       // 64-tile dataflow, two workgroups per CU: park the neighbour of a chain task
     int dataflow_lds_kib = -1;                   // LDS request of the 64-tile dataflow kernel (> 80: ONE workgroup per CU); -1 auto, 0 off
     int build_overlap = 0;                       // option: factor panel 0 under the rest of the kernel build (measured: -0.1 % per
@@ -683,11 +684,19 @@ int queue_factor_dataflow(gphip_ctx* h, int nslots) {
     h->cs = h->stream;
     if constexpr (sizeof(T) == 8) {
         if (h->Nt <= h->dataflow_fine_nt) {
+            // Throughput-bound launches (>= ~8 000 tile tasks: one theta from N = 8192 on) run the build of the same kernel
+            // that fits THREE workgroups on a CU (166 registers, a few spills): a resident task holds its slot through the
+            // 2-3 column hops it waits for at the end of its life, so more residents = more slots doing work
+            // (N=10240 8.79 -> 8.33 ms, N=12288 14.8 -> 13.85 ms, N=8192 -1.8 %; at N=6144, chain bound, +6 %: not there)
+            const long t64 = (long)(2 * h->Nt + 1) * (2 * h->Nt + 2) / 2 * nslots;
+            const bool occ3 = h->dataflow_occ3 > 0 || (h->dataflow_occ3 < 0 && t64 >= 8000);
             if (h->fused_eval) {               // tiles built in-kernel, results exported by the corner task
-                launch_dataflow<T, 64, 2, 2, true>(h, nslots);
+                if (occ3) launch_dataflow<T, 64, 3, 2, true>(h, nslots);
+                else launch_dataflow<T, 64, 2, 2, true>(h, nslots);
                 return 0;
             }
-            launch_dataflow<T, 64>(h, nslots);
+            if (occ3) launch_dataflow<T, 64, 3>(h, nslots);
+            else launch_dataflow<T, 64>(h, nslots);
             launch_finalize<T>(h, nslots, 2 * (int)h->Nt);
             if (h->want_w)
                 hipLaunchKernelGGL(trtri128_kernel<T>, dim3((unsigned)h->Nt, nslots), dim3(256), potrf_lds<T>(), h->stream,
@@ -786,7 +795,9 @@ int queue_factor(gphip_ctx* h, int nslots) {
                     if (2 * rem <= Nt) {                           // 64-tiles: the faster chain; its 2 rem block partials
                         tail_part = h->dPartial + (long)h->slots * Nt;         // live behind the 128-block list
                         tail_n = 2 * rem;
-                        launch_dataflow<T, 64>(h, nslots, 2 * k0(kc), tail_part, tail_n);
+                        if (h->dataflow_occ3 > 0 || (h->dataflow_occ3 < 0 && (long)(2 * rem + 1) * (2 * rem + 2) / 2 * nslots >= 8000))
+                            launch_dataflow<T, 64, 3>(h, nslots, 2 * k0(kc), tail_part, tail_n);
+                        else launch_dataflow<T, 64>(h, nslots, 2 * k0(kc), tail_part, tail_n);
                         tail_k0 = k0(kc);
                         break;
                     }
@@ -1140,6 +1151,10 @@ int set_func_attrs(gphip_ctx* h) {
     if constexpr (sizeof(T) == 8) {
         constexpr int df64 = 152 * 1024;       // (room for the one-workgroup-per-CU request, option "dataflow_lds_kib")
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(chol_dataflow_kernel<T, 64, 2>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, df64));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(chol_dataflow_kernel<T, 64, 3>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, df64));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>((chol_dataflow_kernel<T, 64, 3, 2, true>)),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, df64));
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>((chol_dataflow_kernel<T, 64, 2, 2, true>)),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, df64));
@@ -2622,7 +2637,7 @@ int* option_slot(gphip_ctx* h, const char* name) {
         {"dataflow", &gphip_ctx::dataflow}, {"dataflow_max_nt", &gphip_ctx::dataflow_max_nt},
         {"dataflow_max_slots", &gphip_ctx::dataflow_max_slots}, {"dataflow_fine_nt", &gphip_ctx::dataflow_fine_nt},
         {"dataflow_tail", &gphip_ctx::dataflow_tail}, {"grad_potri", &gphip_ctx::grad_potri},
-        {"fused_eval", &gphip_ctx::fuse_option}, {"panel_left", &gphip_ctx::panel_left}, {"build_overlap", &gphip_ctx::build_overlap}, {"dataflow_lds_kib", &gphip_ctx::dataflow_lds_kib}, {"dataflow_park", &gphip_ctx::dataflow_park},
+        {"fused_eval", &gphip_ctx::fuse_option}, {"panel_left", &gphip_ctx::panel_left}, {"build_overlap", &gphip_ctx::build_overlap}, {"dataflow_lds_kib", &gphip_ctx::dataflow_lds_kib}, {"dataflow_park", &gphip_ctx::dataflow_park}, {"dataflow_occ3", &gphip_ctx::dataflow_occ3},
         {"max_slots", &gphip_ctx::max_slots}, {"shard_min_n", &gphip_ctx::shard_min_n},
         {"thin_tiles", &gphip_ctx::thin_tiles}, {"panel_wide", &gphip_ctx::panel_wide},
         {"la_main", &gphip_ctx::la_main}, {"rest_split", &gphip_ctx::rest_split},

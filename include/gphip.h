@@ -220,6 +220,8 @@ int gphip_ns_crude_weights(const double* points, const double* loglik, int64_t m
  *   "dataflow_lds_kib" -1 auto (default) / 0 / KiB: LDS request of the 64-tile dataflow kernel; > 80 puts ONE workgroup on a
  *                  CU, which keeps the chain's latency-bound waves off SIMDs busy with another workgroup's MFMAs: auto
  *                  asks for 84 KiB while the launch has <= 3 500 tile tasks (one theta up to N ~ 5 000: -3..-7 %)
+ *   "dataflow_occ3" -1 auto (default) / 0 / 1: the 64-tile dataflow kernel in its three-workgroups-per-CU build (166 registers);
+ *                  auto = launches of >= 8 000 tile tasks, which are throughput bound (N = 12288: -6.5 %)
  *   "dataflow_park" 0/1 (default 1): 64-tile dataflow launches with two workgroups per CU -- the workgroup sharing a CU with a
  *                  diagonal (chain) task sleeps while that task is in its critical section (N = 6144: -9 %, 8192: -1 %)
  *   "build_overlap" 0/1 (default 0): the look-ahead schedule builds the tile columns of outer panel 0 first and starts

@@ -10,7 +10,7 @@ budget = float(sys.argv[2]) if len(sys.argv) > 2 else 60.0
 t_end = time.time() + budget
 cases = evals = bad = 0
 while time.time() < t_end:
-    n = int(rng.choice([70, 129, 300, 640, 1000, 1537, 2048, 3000, 4096, 5000, 6200, 7000]))
+    n = int(rng.choice([70, 129, 300, 640, 1000, 1537, 2048, 3000, 4096, 5000, 6200, 7000, 8200, 9100]))
     d = int(rng.choice([1, 2, 3, 8]))
     kernel = str(rng.choice(["se_ard", "matern52_ard"]))
     B = int(rng.choice([1, 1, 1, 2, 5, 8, 16]))
@@ -23,6 +23,7 @@ while time.time() < t_end:
     h.set_option("dataflow", 1)
     h.set_option("dataflow_lds_kib", int(rng.choice([-1, -1, 0, 84])))      # occupancy rule: auto / two per CU / one per CU
     h.set_option("dataflow_park", int(rng.choice([1, 1, 0])))
+    h.set_option("dataflow_occ3", int(rng.choice([-1, -1, 0, 1])))          # three-per-CU build: auto / never / always
     first = None
     for rep in range(int(rng.integers(3, 12))):
         out, info = h.loglik_batch(Th)
