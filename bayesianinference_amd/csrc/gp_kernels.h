@@ -958,6 +958,12 @@ struct GemmArgs {
                                                  //    from the group's own diagonal to r1; one dense 1-D grid over all groups
     int thin_row;                                // tile row whose rows beyond the first are zero and stay zero (the bordered
                                                  //    right-hand-side block-row of the factorisation: only r^T is real); -1: none
+    // ROLE 4 (= ROLE 1 for the panel-stream updates of the look-ahead schedule; its own symbol because the potrf body costs
+    // registers: 272 -> one such wave per SIMD), fuse_b >= 0: the workgroup that updates diagonal tile
+    // (fuse_b, fuse_b) goes on to FACTOR it (the potrf128 body, same LDS) -- a separate potrf128 launch waits 100-250 us for a
+    // CU slot under the trailing update, this workgroup already has one.  Outputs as potrf128_kernel's.
+    int fuse_b;
+    T* fuse_W; double* fuse_partial; int* fuse_info; const double* fuse_slotp; int fuse_nt;
     int skip_upper;                              // 1: diagonal tiles of a triangular update leave their strictly-upper 64x64
                                                  //    quadrant alone (nothing reads it: potrf128 and the dataflow tail take the
                                                  //    lower sub-tiles only)
@@ -1029,6 +1035,7 @@ template <> __device__ __forceinline__ int lds_off<float>(int k, int row) {
 // ROLE only gives each use its own kernel symbol (separate rows in rocprof summaries):
 // 0 = trailing SYRK (K = panel*128, the dominant kernel), 1 = in-panel GEMM (K = 128),
 // 2 = panel solve X <- X W^T (C = A B^T, A aliases C, one column tile),
+// 4 = ROLE 1 + the workgroup of one diagonal tile goes on to factor it (GemmArgs::fuse_b),
 // 3 = "NN" form for the backward solve: the J operand is read transposed, B(j,k) at
 //     B[k + j*ldb] (k contiguous), through an XOR-swizzled [j][GK] LDS image; g.mode picks
 //     C -= A B (0) or C = A B (1).
@@ -1363,6 +1370,31 @@ __global__ __launch_bounds__(64 * NWI * NWJ, (NWI * NWJ == 4) ? 2 : 4) void gemm
         if (ny == FI) pipeline(std::integral_constant<int, FI>{});
         else if (ny == 1) pipeline(std::integral_constant<int, 1>{});
         else pipeline(std::integral_constant<int, 0>{});
+        if constexpr (ROLE == 4 && NW == 4) {
+            if (g.fuse_b >= 0 && ti == g.fuse_b && tj == g.fuse_b) {
+                // accumulators (= the fully updated diagonal tile) -> tile-packed LDS image of the lower triangle, then the
+                // potrf128 body: L over the tile just stored, W_b, log-det partial, SPD verdict
+                __syncthreads();                               // every wave is done with the stage buffers
+                T* Ls = reinterpret_cast<T*>(smem_raw + 2);
+                if (ny == FI) {
+#pragma unroll
+                    for (int x = 0; x < FJ; ++x)
+#pragma unroll
+                        for (int y = 0; y < FI; ++y) {
+                            const int bi = wi * FI + y, bj = wj * FJ + x;
+                            if (bi >= bj) {
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) Ls[ptile(bi, bj) + Num<T>::drow(l4, r) * 16 + (lane & 15)] = acc[x][y][r];
+                            }
+                        }
+                }
+                __syncthreads();
+                T* Ct = Cg - ((long)(wj * (16 * FJ)) * ldc + wi * (16 * FI) + (lane & 15));        // tile base
+                potrf128_core_call<T, 8>(smem_raw, Ct, ldc, g.fuse_W + ((long)slot * g.fuse_nt + g.fuse_b) * TB * TB,
+                                         g.fuse_partial + (long)slot * g.fuse_nt + g.fuse_b, g.fuse_info + slot,
+                                         (T)g.fuse_slotp[(long)slot * SLOTP + 3]);
+            }
+        }
         return;
     } else {
         // deep pipeline: NBUF-1 stages in flight; every wave issues IPS DMA instructions per stage

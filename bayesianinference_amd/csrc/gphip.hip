@@ -53,6 +53,9 @@ struct gphip_ctx {
     std::vector<hipEvent_t> sync_events;
     size_t sync_used = 0;
     hipEvent_t ev_built0 = nullptr;              // queue_build -> queue_factor: "the tile columns of panel 0 are built" (split build)
+    int fuse_potrf = 1;                          // option: panel-stream updates factor the diagonal tile they have just updated
+    int fuse_b = -1;                             // launch_gemm: request (tile to factor) ...
+    bool fuse_done = false;                      // ... and answer (the launch took it)
     int dataflow_occ3 = -1;                      // 64-tile kernel built for three workgroups per CU: -1 auto (>= 8 000 tasks), 0 never, 1 always
     int dataflow_park = 1;                       // 64-tile dataflow, two workgroups per CU: park the neighbour of a chain task
     int dataflow_lds_kib = -1;                   // LDS request of the 64-tile dataflow kernel (> 80: ONE workgroup per CU); -1 auto, 0 off
@@ -471,6 +474,9 @@ Opnd<T> tl(const gphip_ctx* h, int k0 = 0, bool all_slots = true) {
 }
 
 template <typename T>
+size_t potrf_lds();
+
+template <typename T>
 void launch_gemm(gphip_ctx* h, int cls, Opnd<T> Co, Opnd<T> Ao, Opnd<T> Bo, int K, int r0, int r1, int c0, int c1, int tri,
                  int nslots, int mode = 0, int ktri = 0, int thin_row = -1, int groups = 1, int grp_stride = 0,
                  int grp_width = 0) {
@@ -553,6 +559,18 @@ void launch_gemm(gphip_ctx* h, int cls, Opnd<T> Co, Opnd<T> Ao, Opnd<T> Bo, int 
     // (measured: -8 % per evaluation at N=4096, neutral at 8192, +5 % at 32768 where its 147 KB of LDS keeps
     //  trailing-SYRK workgroups off the CU -- so it is used for small problems only)
     const bool lat = h->latency_gemm && !g.super && h->Nt <= 48 && (long)grid_x * nslots <= h->latency_tiles;
+    // a panel-stream update asked to factor the diagonal tile it updates (queue_panel / queue_factor): 256-thread shape only
+    g.fuse_b = -1;
+    h->fuse_done = false;
+    size_t lds2 = GEMM_LDS;
+    if (h->fuse_b >= 0 && cls == 3 && mode == 0 && !lat && !ktri && groups == 1 && tri && h->fuse_b >= c0 && h->fuse_b < c1 &&
+        h->fuse_b >= r0) {
+        g.fuse_b = h->fuse_b;
+        g.fuse_W = (T*)h->dW; g.fuse_partial = h->dPartial; g.fuse_info = h->dInfo; g.fuse_slotp = h->dSlotp; g.fuse_nt = (int)h->Nt;
+        lds2 = std::max(lds2, potrf_lds<T>());
+        h->fuse_done = true;
+    }
+    h->fuse_b = -1;
 #define GEMM_LAUNCH(ROLE)                                                                                          \
     do {                                                                                                           \
         if (lat) hipLaunchKernelGGL((gemm_nt_kernel<T, ROLE, 4, 4, 4>), grid, dim3(1024), 2 * GEMM_LDS, h->cs, g);  \
@@ -561,6 +579,7 @@ void launch_gemm(gphip_ctx* h, int cls, Opnd<T> Co, Opnd<T> Ao, Opnd<T> Bo, int 
     if (cls == 6) GEMM_LAUNCH(3);
     else if (mode == 1) GEMM_LAUNCH(2);
     else if (cls == 4) GEMM_LAUNCH(0);
+    else if (g.fuse_b >= 0) hipLaunchKernelGGL((gemm_nt_kernel<T, 4, 2, 2, 2>), grid, dim3(256), lds2, h->cs, g);
     else GEMM_LAUNCH(1);
 #undef GEMM_LAUNCH
 }
@@ -579,7 +598,7 @@ size_t potrf_lds() { return 16 + (size_t)PT_LDS_ELEMS * sizeof(T); }
 
 // factor the tile columns [K0, K0+nin) of all slots (diagonal blocks, panel solves, in-panel updates)
 template <typename T>
-int queue_panel(gphip_ctx* h, int K0, int nin, int nslots) {
+int queue_panel(gphip_ctx* h, int K0, int nin, int nslots, bool first_factored = false) {
     const int Nt = (int)h->Nt, R = Nt + 1;
     const long bs = h->slot_elems, lrs = (long)Nt * TB * TB;
     T* A = (T*)(h->ws_override ? h->ws_override : h->dA);
@@ -591,19 +610,30 @@ int queue_panel(gphip_ctx* h, int K0, int nin, int nslots) {
     // auto: batches, and the wide (>= 8-tile) early panels of a large single factorisation (N = 32768: -0.7 %, N = 49152:
     // -0.8 %; with 4-6-tile panels right-looking is 1 % faster)
     const bool left = h->panel_left > 0 || (h->panel_left < 0 && (nslots > h->dataflow_max_slots || nin >= 8));
+    // "fuse_potrf": an update launch that completes diagonal tile (b, b) also factors it (GemmArgs::fuse_b) -- then there is
+    // no potrf128 launch for column b.  first_factored: the caller's look-ahead update already did that for column K0.
+    const bool fuse = h->fuse_potrf && h->dist_world == 0 && !h->ws_override;
+    bool factored = first_factored;
     for (int s = 0; s < nin; ++s) {
         const int b = K0 + s;
-        if (left && s > 0)
+        if (left && s > 0) {
+            if (fuse) h->fuse_b = b;
             launch_gemm<T>(h, 3, tl<T>(h), tl<T>(h, K0), tl<T>(h, K0), s * TB, b, R, b, b + 1, 1, nslots, 0, 0, Nt);
-        {
+            factored = h->fuse_done;
+        }
+        if (!factored) {
             ProfScope ps(h, 1, 2.0 * TB * TB * TB / 3.0 * nslots, 0.0);
             hipLaunchKernelGGL(potrf128_kernel<T>, dim3(nslots), dim3(256), potrf_lds<T>(), h->cs, A, bs, b, W,
                                h->dPartial, Nt, h->dInfo, h->dSlotp);
         }
         // panel solve X <- X W_b^T for every row tile below the diagonal block (incl. rhs rows)
         launch_gemm<T>(h, 2, tl<T>(h), tl<T>(h, b), wb<T>(W, b, lrs), TB, b + 1, R, b, b + 1, 0, nslots, 1, 0, Nt);
-        if (!left && s + 1 < nin)
+        factored = false;
+        if (!left && s + 1 < nin) {
+            if (fuse) h->fuse_b = b + 1;
             launch_gemm<T>(h, 3, tl<T>(h), tl<T>(h, b), tl<T>(h, b), TB, b + 1, R, b + 1, K0 + nin, 1, nslots, 0, 0, Nt);
+            factored = h->fuse_done;
+        }
     }
     return 0;
 }
@@ -826,8 +856,10 @@ int queue_factor(gphip_ctx* h, int nslots) {
                 if (k == 0 && built0) HIPCHK(hipStreamWaitEvent(h->pstream, built, 0));     // LA(0) reads columns the rest of the build writes
                 if (ev_rest) HIPCHK(hipStreamWaitEvent(h->pstream, ev_rest, 0));
                 if (ev_rest2) HIPCHK(hipStreamWaitEvent(h->pstream, ev_rest2, 0));
+                if (h->fuse_potrf && h->dist_world == 0) h->fuse_b = k0(k + 1);  // ... whose first diagonal tile LA(k) also factors
                 trailing(k, k0(k + 1), k0(k + 2), 3);                          // LA(k)
-                queue_panel<T>(h, k0(k + 1), k0(k + 2) - k0(k + 1), nslots);    // factor panel k+1
+                const bool first_factored = h->fuse_done;
+                queue_panel<T>(h, k0(k + 1), k0(k + 2) - k0(k + 1), nslots, first_factored);    // factor panel k+1
                 ev_next = sync_event(h);
                 HIPCHK(hipEventRecord(ev_next, h->pstream));
             }
@@ -1174,6 +1206,8 @@ int set_func_attrs(gphip_ctx* h) {
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * GEMM_LDS)));
     GEMM_ATTR(0) GEMM_ATTR(1) GEMM_ATTR(2) GEMM_ATTR(3)
 #undef GEMM_ATTR
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<T, 4, 2, 2, 2>),     // (+ the fused potrf image)
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max(GEMM_LDS, potrf_lds<T>())));
     return GPHIP_OK;
 }
 
@@ -2637,7 +2671,7 @@ int* option_slot(gphip_ctx* h, const char* name) {
         {"dataflow", &gphip_ctx::dataflow}, {"dataflow_max_nt", &gphip_ctx::dataflow_max_nt},
         {"dataflow_max_slots", &gphip_ctx::dataflow_max_slots}, {"dataflow_fine_nt", &gphip_ctx::dataflow_fine_nt},
         {"dataflow_tail", &gphip_ctx::dataflow_tail}, {"grad_potri", &gphip_ctx::grad_potri},
-        {"fused_eval", &gphip_ctx::fuse_option}, {"panel_left", &gphip_ctx::panel_left}, {"build_overlap", &gphip_ctx::build_overlap}, {"dataflow_lds_kib", &gphip_ctx::dataflow_lds_kib}, {"dataflow_park", &gphip_ctx::dataflow_park}, {"dataflow_occ3", &gphip_ctx::dataflow_occ3},
+        {"fused_eval", &gphip_ctx::fuse_option}, {"panel_left", &gphip_ctx::panel_left}, {"build_overlap", &gphip_ctx::build_overlap}, {"dataflow_lds_kib", &gphip_ctx::dataflow_lds_kib}, {"dataflow_park", &gphip_ctx::dataflow_park}, {"fuse_potrf", &gphip_ctx::fuse_potrf}, {"dataflow_occ3", &gphip_ctx::dataflow_occ3},
         {"max_slots", &gphip_ctx::max_slots}, {"shard_min_n", &gphip_ctx::shard_min_n},
         {"thin_tiles", &gphip_ctx::thin_tiles}, {"panel_wide", &gphip_ctx::panel_wide},
         {"la_main", &gphip_ctx::la_main}, {"rest_split", &gphip_ctx::rest_split},

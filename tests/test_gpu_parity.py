@@ -686,6 +686,10 @@ def test_experimental_schedules_give_the_same_factorisation():
     h = _lib.Handle(X, y, "se_ard")
     ref = h.loglik_parts(th)
     assert ref[3] == 0
+    h.set_option("fuse_potrf", 0)                        # default on: diagonal tiles factored by the update that completes them
+    got = h.loglik_parts(th)
+    h.set_option("fuse_potrf", 1)
+    assert got[3] == 0 and all(got[k] == ref[k] for k in range(3)), ("fuse_potrf", got, ref)   # same arithmetic, same order: bit-identical
     for opt in ("la_main", "rest_split", "build_overlap"):
         h.set_option(opt, 1)
         if opt == "rest_split":
