@@ -612,7 +612,9 @@ int queue_panel(gphip_ctx* h, int K0, int nin, int nslots, bool first_factored =
     const bool left = h->panel_left > 0 || (h->panel_left < 0 && (nslots > h->dataflow_max_slots || nin >= 8));
     // "fuse_potrf": an update launch that completes diagonal tile (b, b) also factors it (GemmArgs::fuse_b) -- then there is
     // no potrf128 launch for column b.  first_factored: the caller's look-ahead update already did that for column K0.
-    const bool fuse = h->fuse_potrf && h->dist_world == 0 && !h->ws_override;
+    // One theta (or a few): the diagonal block is latency-critical.  Batches are throughput bound and the fused kernel's 272
+    // registers halve the resident waves of what are then BIG update launches (200 x N=4096: 86 -> 91 ms): not there.
+    const bool fuse = h->fuse_potrf && nslots <= 8 && h->dist_world == 0 && !h->ws_override;
     bool factored = first_factored;
     for (int s = 0; s < nin; ++s) {
         const int b = K0 + s;
@@ -856,7 +858,7 @@ int queue_factor(gphip_ctx* h, int nslots) {
                 if (k == 0 && built0) HIPCHK(hipStreamWaitEvent(h->pstream, built, 0));     // LA(0) reads columns the rest of the build writes
                 if (ev_rest) HIPCHK(hipStreamWaitEvent(h->pstream, ev_rest, 0));
                 if (ev_rest2) HIPCHK(hipStreamWaitEvent(h->pstream, ev_rest2, 0));
-                if (h->fuse_potrf && h->dist_world == 0) h->fuse_b = k0(k + 1);  // ... whose first diagonal tile LA(k) also factors
+                if (h->fuse_potrf && nslots <= 8 && h->dist_world == 0) h->fuse_b = k0(k + 1);  // ... whose first diagonal tile LA(k) also factors
                 trailing(k, k0(k + 1), k0(k + 2), 3);                          // LA(k)
                 const bool first_factored = h->fuse_done;
                 queue_panel<T>(h, k0(k + 1), k0(k + 2) - k0(k + 1), nslots, first_factored);    // factor panel k+1

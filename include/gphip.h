@@ -220,8 +220,8 @@ int gphip_ns_crude_weights(const double* points, const double* loglik, int64_t m
  *   "dataflow_lds_kib" -1 auto (default) / 0 / KiB: LDS request of the 64-tile dataflow kernel; > 80 puts ONE workgroup on a
  *                  CU, which keeps the chain's latency-bound waves off SIMDs busy with another workgroup's MFMAs: auto
  *                  asks for 84 KiB while the launch has <= 3 500 tile tasks (one theta up to N ~ 5 000: -3..-7 %)
- *   "fuse_potrf"   0/1 (default 1): the panel-stream update that completes a diagonal tile also factors it (no separate
- *                  potrf128 launch, which waits 100-250 us for a CU slot under the trailing update): N = 16384 -3 %
+ *   "fuse_potrf"   0/1 (default 1): calls of <= 8 thetas -- the panel-stream update that completes a diagonal tile also factors
+ *                  it (no separate potrf128 launch, which waits 100-250 us for a CU slot under the trailing update): N = 16384 -3 %
  *   "dataflow_occ3" -1 auto (default) / 0 / 1: the 64-tile dataflow kernel in its three-workgroups-per-CU build (166 registers);
  *                  auto = launches of >= 8 000 tile tasks, which are throughput bound (N = 12288: -6.5 %)
  *   "dataflow_park" 0/1 (default 1): 64-tile dataflow launches with two workgroups per CU -- the workgroup sharing a CU with a
