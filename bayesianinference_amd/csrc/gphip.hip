@@ -614,7 +614,7 @@ int queue_panel(gphip_ctx* h, int K0, int nin, int nslots, bool first_factored =
     // no potrf128 launch for column b.  first_factored: the caller's look-ahead update already did that for column K0.
     // One theta (or a few): the diagonal block is latency-critical.  Batches are throughput bound and the fused kernel's 272
     // registers halve the resident waves of what are then BIG update launches (200 x N=4096: 86 -> 91 ms): not there.
-    const bool fuse = h->fuse_potrf && nslots <= 8 && h->dist_world == 0 && !h->ws_override;
+    const bool fuse = h->fuse_potrf && nslots <= 8;
     bool factored = first_factored;
     for (int s = 0; s < nin; ++s) {
         const int b = K0 + s;
