@@ -206,7 +206,8 @@ int gphip_ns_crude_weights(const double* points, const double* loglik, int64_t m
  *   "supertile"    tile order of the trailing SYRK: 0 column-major list, one contiguous chunk per XCD; 1 whole 8x8 super-tiles
  *                  dealt statically to the XCDs (measured slower: unequal loads); 2 (default) the tile LIST itself in 8x8
  *                  super-tile order, equal contiguous chunks per XCD (16 operand panels per 64 resident tiles instead of 65:
- *                  less cache-to-L2 traffic, SYRK alone 0.849 -> 0.861 of peak)
+ *                  less cache-to-L2 traffic, SYRK alone 0.849 -> 0.861 of peak); 3 = 2, for batches of thetas too (measured: no
+ *                  difference there)
  *   "lookahead"    0/1 factor panel k+1 on a second stream under the trailing update of panel k (default 1)
  *   "latency_gemm" / "latency_tiles"   4x4-wave GEMM shape for launches of <= latency_tiles tiles (small N)
  *   "dataflow"     0/1 single-launch dataflow Cholesky (one workgroup per tile, flags instead of launches)
