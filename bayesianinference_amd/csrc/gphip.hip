@@ -53,6 +53,8 @@ struct gphip_ctx {
     std::vector<hipEvent_t> sync_events;
     size_t sync_used = 0;
     hipEvent_t ev_built0 = nullptr;              // queue_build -> queue_factor: "the tile columns of panel 0 are built" (split build)
+    int bcast_chunks = 1;                        // sharded evaluation: a factored panel is broadcast one tile column at a time
+    std::vector<hipEvent_t>* col_events = nullptr;   // queue_panel: record "tile column final" events here (owner of a sharded panel)
     int fuse_potrf = 1;                          // option: panel-stream updates factor the diagonal tile they have just updated
     int fuse_b = -1;                             // launch_gemm: request (tile to factor) ...
     bool fuse_done = false;                      // ... and answer (the launch took it)
@@ -631,6 +633,11 @@ int queue_panel(gphip_ctx* h, int K0, int nin, int nslots, bool first_factored =
         // panel solve X <- X W_b^T for every row tile below the diagonal block (incl. rhs rows)
         launch_gemm<T>(h, 2, tl<T>(h), tl<T>(h, b), wb<T>(W, b, lrs), TB, b + 1, R, b, b + 1, 0, nslots, 1, 0, Nt);
         factored = false;
+        if (h->col_events) {                   // tile column b is final from here on (later columns only read it)
+            hipEvent_t e = sync_event(h);
+            HIPCHK(hipEventRecord(e, h->cs));
+            h->col_events->push_back(e);
+        }
         if (!left && s + 1 < nin) {
             if (fuse) h->fuse_b = b + 1;
             launch_gemm<T>(h, 3, tl<T>(h), tl<T>(h, b), tl<T>(h, b), TB, b + 1, R, b + 1, K0 + nin, 1, nslots, 0, 0, Nt);
@@ -2673,7 +2680,7 @@ int* option_slot(gphip_ctx* h, const char* name) {
         {"dataflow", &gphip_ctx::dataflow}, {"dataflow_max_nt", &gphip_ctx::dataflow_max_nt},
         {"dataflow_max_slots", &gphip_ctx::dataflow_max_slots}, {"dataflow_fine_nt", &gphip_ctx::dataflow_fine_nt},
         {"dataflow_tail", &gphip_ctx::dataflow_tail}, {"grad_potri", &gphip_ctx::grad_potri},
-        {"fused_eval", &gphip_ctx::fuse_option}, {"panel_left", &gphip_ctx::panel_left}, {"build_overlap", &gphip_ctx::build_overlap}, {"dataflow_lds_kib", &gphip_ctx::dataflow_lds_kib}, {"dataflow_park", &gphip_ctx::dataflow_park}, {"fuse_potrf", &gphip_ctx::fuse_potrf}, {"dataflow_occ3", &gphip_ctx::dataflow_occ3},
+        {"fused_eval", &gphip_ctx::fuse_option}, {"panel_left", &gphip_ctx::panel_left}, {"build_overlap", &gphip_ctx::build_overlap}, {"dataflow_lds_kib", &gphip_ctx::dataflow_lds_kib}, {"dataflow_park", &gphip_ctx::dataflow_park}, {"fuse_potrf", &gphip_ctx::fuse_potrf}, {"bcast_chunks", &gphip_ctx::bcast_chunks}, {"dataflow_occ3", &gphip_ctx::dataflow_occ3},
         {"max_slots", &gphip_ctx::max_slots}, {"shard_min_n", &gphip_ctx::shard_min_n},
         {"thin_tiles", &gphip_ctx::thin_tiles}, {"panel_wide", &gphip_ctx::panel_wide},
         {"la_main", &gphip_ctx::la_main}, {"rest_split", &gphip_ctx::rest_split},

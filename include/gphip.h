@@ -221,6 +221,8 @@ int gphip_ns_crude_weights(const double* points, const double* loglik, int64_t m
  *   "dataflow_lds_kib" -1 auto (default) / 0 / KiB: LDS request of the 64-tile dataflow kernel; > 80 puts ONE workgroup on a
  *                  CU, which keeps the chain's latency-bound waves off SIMDs busy with another workgroup's MFMAs: auto
  *                  asks for 84 KiB while the launch has <= 3 500 tile tasks (one theta up to N ~ 5 000: -3..-7 %)
+ *   "bcast_chunks" 0/1 (default 1): sharded evaluation -- a factored panel is broadcast one tile column at a time, each as soon as
+ *                  it is final, instead of as one message after the whole panel (must agree on all ranks: checked)
  *   "fuse_potrf"   0/1 (default 1): calls of <= 8 thetas -- the panel-stream update that completes a diagonal tile also factors
  *                  it (no separate potrf128 launch, which waits 100-250 us for a CU slot under the trailing update): N = 16384 -3 %
  *   "dataflow_occ3" -1 auto (default) / 0 / 1: the 64-tile dataflow kernel in its three-workgroups-per-CU build (166 registers);

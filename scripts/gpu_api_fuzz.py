@@ -53,7 +53,7 @@ while time.time() < t_end:
         if op == "option":
             name = str(rng.choice(["panel", "dataflow", "lookahead", "thin_tiles", "fused_eval", "dataflow_fine_nt", "panel_wide",
                                    "dataflow_tail", "grad_potri", "max_slots", "latency_gemm", "shard_min_n", "panel_left",
-                                   "replicate_factor", "share_local_panels", "debug_fail_alloc", "supertile", "build_overlap", "dataflow_park", "dataflow_lds_kib", "fuse_potrf"]))
+                                   "replicate_factor", "share_local_panels", "debug_fail_alloc", "supertile", "build_overlap", "dataflow_park", "dataflow_lds_kib", "fuse_potrf", "bcast_chunks"]))
             if name == "debug_fail_alloc" and rng.random() < 0.7:
                 name = "panel"
             val = {"panel": int(rng.choice([1, 2, 3, 4, 6])), "dataflow_fine_nt": int(rng.choice([0, 96])),

@@ -46,6 +46,10 @@ def test_sharded_loglik_matches_oracle_and_single_device(n, d, kernel, world, pa
     # repeated calls reuse events / buffers; a second theta; bit-repeatable
     ll2, *_ = g.loglik_parts(th)
     assert ll2 == ll
+    g.set_option("bcast_chunks", 0)                      # the panel as ONE broadcast instead of one per tile column: same bits
+    ll3, *_ = g.loglik_parts(th)
+    g.set_option("bcast_chunks", 1)
+    assert ll3 == ll
     th2 = th * 1.07
     assert close(g.loglik(th2)[0], h.loglik(th2)[0], n, 1e-10)
     if n < 8:
