@@ -53,6 +53,7 @@ struct gphip_ctx {
     std::vector<hipEvent_t> sync_events;
     size_t sync_used = 0;
     hipEvent_t ev_built0 = nullptr;              // queue_build -> queue_factor: "the tile columns of panel 0 are built" (split build)
+    int dist_first_factored = -1;                // sharded evaluation: outer panel whose first diagonal block the last LA update factored
     int bcast_chunks = 1;                        // sharded evaluation: a factored panel is broadcast one tile column at a time
     std::vector<hipEvent_t>* col_events = nullptr;   // queue_panel: record "tile column final" events here (owner of a sharded panel)
     int fuse_potrf = 1;                          // option: panel-stream updates factor the diagonal tile they have just updated
@@ -2600,7 +2601,9 @@ int gphip_dist_factor_panel(gphip_handle h, int k, void* packed) {
     const int64_t K1 = (K0 + h->panel < h->Nt) ? K0 + h->panel : h->Nt;
     h->cs = h->pstream;
     h->ws_override = dist_panel_base(h, k);
-    DISPATCH(h, queue_panel, h, (int)K0, (int)(K1 - K0), 1);
+    const bool first_factored = h->dist_first_factored == k;       // (by this rank's look-ahead update of the panel)
+    h->dist_first_factored = -1;
+    DISPATCH(h, queue_panel, h, (int)K0, (int)(K1 - K0), 1, first_factored);
     h->ws_override = nullptr;
     if (packed && packed != (void*)dist_panel_range(h, k))
         HIPCHK(hipMemcpyAsync(packed, dist_panel_range(h, k), (size_t)rows * cols * h->es, hipMemcpyDeviceToDevice, h->pstream));
@@ -2632,12 +2635,20 @@ int gphip_dist_update(gphip_handle h, int k, const void* packed, int j_first, in
         if (j % W == h->dist_rank) { if (j0 < 0) j0 = j; ++cnt; }
     const int cls = on_panel_stream ? 3 : 4;
     const bool corner = j_last > nouter && nouter >= jb && h->dist_rank == 0;
+    h->dist_first_factored = -1;
     if (cnt > 0) {
+        // the look-ahead update of the NEXT panel (this rank owns it) also factors that panel's first diagonal block
+        // (fuse_potrf): gphip_dist_factor_panel then starts at the panel solve
+        const bool la_one = on_panel_stream && h->fuse_potrf && je - jb == 1;
         if (W == 1) {            // adjacent panels (and the corner tile right behind them): one triangular launch
+            if (la_one) h->fuse_b = j0 * P;
             DISPATCH(h, queue_dist_update, h, packed, K0, (long)rows, (long)cols, j0 * P,
                      (corner && je == nouter) ? R : std::min(je * P, Nt), cls);
+            if (la_one && h->fuse_done) h->dist_first_factored = j0;
         } else if (cnt == 1) {
+            if (la_one) h->fuse_b = j0 * P;
             DISPATCH(h, queue_dist_update, h, packed, K0, (long)rows, (long)cols, j0 * P, std::min(j0 * P + P, Nt), cls);
+            if (la_one && h->fuse_done) h->dist_first_factored = j0;
         } else {
             DISPATCH(h, queue_dist_update, h, packed, K0, (long)rows, (long)cols, j0 * P, Nt, cls, cnt, W * P);
         }
