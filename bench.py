@@ -189,7 +189,7 @@ def live_pmc_traffic(n: int, d: int, device: int, kernel_substr: str = "gemm_nt_
             env = dict(os.environ, TMPDIR="/tmp", GPHIP_NO_TORCH="1", HIP_VISIBLE_DEVICES=os.environ.get("HIP_VISIBLE_DEVICES", str(device)),
                        LD_LIBRARY_PATH="/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
             cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", tmp, "-o", "p", "--", sys.executable,
-                   os.path.join(ROOT, "bench.py"), "--pmc-probe", "--npoints", str(n), "--d", str(d)]
+                   os.path.join(ROOT, "bench.py"), "--pmc-probe", "--npoints", str(n), "--dim", str(d)]
             res = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
             if res.returncode != 0:
                 return None
@@ -313,7 +313,7 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--n", "--npoints", dest="n", type=int, default=32768)     # (--npoints: torchrun's own parser chokes on an abbreviable "--n")
-    ap.add_argument("--d", type=int, default=8)
+    ap.add_argument("--d", "--dim", dest="d", type=int, default=8)              # (--dim: same reason)
     ap.add_argument("--panel", type=int, default=0)
     ap.add_argument("--mode", choices=["theta", "cholesky", "cholesky-torch"], default="theta",
                     help="N>1 only. theta (default): ranks evaluate disjoint theta, no data-path collective, "
