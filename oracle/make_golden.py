@@ -92,6 +92,18 @@ def f3():
         quad=np.array([r[7] for r in rows]), info=np.array([r[8] for r in rows]))
 
 
+def fcfg5():
+    """BASELINE.json cfg 5 at its own size: Matern-5/2 ARD, N = 65536, d = 16, the fp32 timing theta (sn = 0.3) -- ONE in-place
+    LU of a 34.4 GB matrix (needs ~36 GB of RAM and ~15 min on 8 cores; `--cfg5` regenerates only this file).  Scalars only."""
+    n, d, kernel = 65536, 16, "matern52_ard"
+    X, y = syn.make_dataset(n, d)
+    th = syn.default_theta(kernel, d, dtype="f32")
+    ll, ld, qd, info = orc.log_likelihood(kernel, th, X, y, parts=True)
+    print("CFG5", n, d, kernel, ll, ld, qd, info)
+    np.savez_compressed(os.path.join(OUT, "cfg5_scalars.npz"), n=n, d=d, kernel=kernel, theta=th, xsum=float(X.sum()),
+                        ysum=float(y.sum()), loglik=ll, logdet=ld, quad=qd, info=info)
+
+
 def f4():
     # duplicate rows + zero nugget -> singular; sigma_n = 1e-12 -> hopelessly ill-conditioned
     X, y = syn.make_dataset(64, 2)
@@ -138,6 +150,9 @@ def fhp():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
+    if "--cfg5" in sys.argv:
+        fcfg5()
+        sys.exit(0)
     if "--f3" in sys.argv:
         f3()
         sys.exit(0)
