@@ -770,3 +770,30 @@ def test_failed_slot_allocation_rolls_back_and_the_handle_stays_usable():
         h = _lib.Handle(X, y, "se_ard")
         h.loglik(Th[0])
     h.close()
+
+
+def test_fit_predict_solve_on_the_lookahead_schedule_against_oracle():
+    """Fit -> predict / solve / logdet where the factor comes from the look-ahead schedule (N > 12288, ragged): diagonal
+    blocks factored by the updates that complete them, 64-tile dataflow tail, 128-block inverses rebuilt for the
+    substitutions -- against the oracle's LU at the same size (BGP:396-422, 126-141)."""
+    n, d, m = 16500, 4, 40
+    X, y = syn.make_dataset(n, d)
+    Xs = syn.make_test_points(m, d)
+    th = syn.default_theta("se_ard", d)
+    th[-1] = 0.15
+    mo, so = orc.predict_internal("se_ard", th, X, y, Xs)
+    want = orc.log_likelihood("se_ard", th, X, y, parts=True)
+    for opts in ({}, {"fuse_potrf": 0}, {"dataflow_tail": 0}):
+        h = _lib.Handle(X, y, "se_ard")
+        for k, v in opts.items():
+            h.set_option(k, v)
+        assert h.fit(th) == 0
+        assert close(h.logdet(), want[1], n)
+        mu, var = h.predict(Xs)
+        np.testing.assert_allclose(mu, mo, rtol=1e-7, atol=1e-9, err_msg=str(opts))
+        np.testing.assert_allclose(np.sqrt(var), so, rtol=1e-7, err_msg=str(opts))
+        alpha = h.solve(y)
+        assert close(float(y @ alpha), want[2], n)
+        ll, g, info = h.loglik_grad(th)
+        assert info == 0 and close(ll, want[0], n)
+        h.close()
