@@ -1464,6 +1464,8 @@ struct DfArgs {
     unsigned long long ticket_base;           // value of *ticket before this launch
     int* abort_flag;
     int nd, nslots, epoch;                    // nd = diagonal blocks = Npad / TBX; tile row nd = the rhs rows
+    int role;                                 // 0: this launch runs every task; split launch on CU-masked streams: 1 = the
+                                              // diagonal (chain) tasks on the reserved CUs, 2 = all other tasks on the rest
     int* park;                                // 64-tiles, two workgroups per CU: [DF_PARK_SLOTS] counters "a chain task is in its critical
                                               // section on this CU" (index = XCC / SE / SH / CU id); the neighbour sleeps meanwhile; or null
     long long* trace;                         // developer timing (scripts/micro/df_trace.hip): 8 stamps per task, or null
@@ -1545,14 +1547,21 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g, Th
     const int task = __builtin_amdgcn_readfirstlane(s_task);
     const int R = g.nd + 1;
     const int slot = task % g.nslots, q = task / g.nslots;
-    // q -> (j, i): column-major over the lower triangle, column j starts at off(j) = jR - j(j-1)/2
-    int j = (int)(((double)(2 * R + 1) - sqrt((double)(2 * R + 1) * (2 * R + 1) - 8.0 * q)) * 0.5);
+    // q -> (j, i): column-major over the lower triangle, column j starts at off(j) = jR - j(j-1)/2.
+    // Split launch (g.role, launch_dataflow): role 1 = the diagonal tasks in order (q = j), role 2 = every other task, still
+    // column-major (the strictly lower triangle = a lower triangle of R - 1 rows, shifted down by one).  Each launch hands
+    // out ITS tasks in the global topological order, so the lowest unfinished task of either launch is always resident and
+    // the lowest unfinished task overall has all its dependencies finished: the deadlock argument above carries over.
+    const int Rq = g.role == 2 ? R - 1 : R;
+    int j = (int)(((double)(2 * Rq + 1) - sqrt((double)(2 * Rq + 1) * (2 * Rq + 1) - 8.0 * q)) * 0.5);
     if (j < 0) j = 0;
-    if (j > R - 1) j = R - 1;
-    while (j + 1 < R && (j + 1) * R - (j + 1) * j / 2 <= q) ++j;
-    while (j > 0 && j * R - j * (j - 1) / 2 > q) --j;
+    if (j > Rq - 1) j = Rq - 1;
+    while (j + 1 < Rq && (j + 1) * Rq - (j + 1) * j / 2 <= q) ++j;
+    while (j > 0 && j * Rq - j * (j - 1) / 2 > q) --j;
+    int i = j + (q - (j * Rq - j * (j - 1) / 2)) + (g.role == 2 ? 1 : 0);
+    if (g.role == 1) { j = q; i = q; }
     j = __builtin_amdgcn_readfirstlane(j);                 // (through the vector sqrt: back to the scalar unit)
-    const int i = __builtin_amdgcn_readfirstlane(j + (q - (j * R - j * (j - 1) / 2)));
+    i = __builtin_amdgcn_readfirstlane(i);
 
 #ifdef GPHIP_TIMING
     if (threadIdx.x == 0 && g_stamp_buf) g_stamp_buf[(long)blockIdx.x * 64 + 63] = task;
@@ -1606,7 +1615,7 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g, Th
     T* Ct = tptr(i, j);                                    // tile (i,j)
     // per-slot scalars {sf2, sn2, mu, pivot tol, ..}: from the argument pack (BUILD) or from device memory
     const double* sp = BUILD ? tp.v + g.nslots * g.d + slot * SLOTP : g.slotp + (long)slot * SLOTP;
-    if (BUILD && q == 0 && tid == 0) g.info[slot] = 0;     // task 0 of the slot precedes every potrf of the slot
+    if (BUILD && i == 0 && j == 0 && tid == 0) g.info[slot] = 0;     // task (0,0) of the slot precedes every potrf of the slot
 
     acc_t acc[FJ][FI];
     // D-layout address of this lane's accumulators inside a TBX x TBX tile with leading dimension ldc

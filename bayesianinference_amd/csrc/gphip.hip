@@ -15,6 +15,8 @@
 #include "gp_kernels.h"
 #include "rccl_dyn.h"
 
+#include <hip/hip_ext.h>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -32,6 +34,9 @@ namespace {
 
 constexpr double LOG_TWO_PI = 1.8378770664093454835606594728112;
 constexpr size_t GEMM_LDS = 2 * STAGE_BYTES;
+// dTicket: [0] ticket, [1] abort word, [2 ..] DF_PARK_SLOTS ints of per-CU park counters, then the chain launch's ticket
+constexpr size_t DF_TICKET2 = 2 + DF_PARK_SLOTS * 4 / 8;
+constexpr size_t DF_TICKET_BYTES = (DF_TICKET2 + 2) * 8;
 
 struct ProfRec {
     int cls;
@@ -62,6 +67,13 @@ struct gphip_ctx {
     int dataflow_occ3 = -1;                      // 64-tile kernel built for three workgroups per CU: -1 auto (>= 8 000 tasks), 0 never, 1 always
     int dataflow_park = 1;                       // 64-tile dataflow, two workgroups per CU: park the neighbour of a chain task
     int dataflow_lds_kib = -1;                   // LDS request of the 64-tile dataflow kernel (> 80: ONE workgroup per CU); -1 auto, 0 off
+    // Split dataflow launch (64-tiles): the diagonal (chain) tasks run as their OWN launch on a stream whose CU mask reserves
+    // `df_split` CUs per XCD, every other task on a stream masked to the remaining CUs -- the chain never shares a SIMD, an
+    // LDS or a dispatch slot with the throughput work.  -1 auto (by task count), 0 off.
+    int df_split = 0, df_split_lds_kib = 84, df_split_min_tasks = 5000, df_split_auto = 3;
+    hipStream_t chain_stream = nullptr, bulk_stream = nullptr;
+    int split_streams_for = 0;                   // reserved CUs per XCD the two masked streams were created for
+    unsigned long long ticket_base2 = 0;         // chain launch's own ticket counter (dTicket + DF_TICKET2)
     int build_overlap = 0;                       // option: factor panel 0 under the rest of the kernel build (measured: -0.1 % per
                                                  // evaluation, but the build itself slows 4-15 % while it shares the chip: off)
     bool own_streams = true;
@@ -143,6 +155,9 @@ struct gphip_ctx {
     void* packed[3] = {nullptr, nullptr, nullptr};   // rotating packed-panel buffers, group members only
     size_t packed_bytes = 0;
     double* dScal8 = nullptr;                    // 8 doubles for the scalar all-reduces (multi-process groups)
+    void* drain_buf = nullptr;                   // scratch a draining member broadcasts through (group_drain_buf)
+    size_t drain_bytes = 0;
+    int debug_fail_hip = 0;                      // tests: make the n-th checked HIP call of the next collective sequence fail
     int fit_rank = 0, fit_world = 0;             // the layout a distributed fit was made in
     bool in_group_call = false;                  // set on a member while the group handle runs a sharded call on it
     // Sharded evaluation (gphip_dist_*): where this rank keeps ITS outer panels.  replicate_factor = 0 (default): a
@@ -267,9 +282,10 @@ void free_slots(gphip_ctx* h) {
     h->dPwMean = h->dPwNug = nullptr; h->pw_cap = 0;
     (void)hipFree(h->dXs2); (void)hipFree(h->dInvEll2); (void)hipHostFree(h->hInvEll2);
     h->dXs2 = nullptr; h->dInvEll2 = h->hInvEll2 = nullptr;
-    h->dFlags = nullptr; h->dTicket = nullptr; h->ticket_base = 0;
+    h->dFlags = nullptr; h->dTicket = nullptr; h->ticket_base = 0; h->ticket_base2 = 0;
     (void)hipHostFree(h->hInvEll); (void)hipHostFree(h->hSlotp); (void)hipHostFree(h->hRes);
     (void)hipHostFree(h->hInfo);
+    if (h->dist_base == h->dA) { h->dist_base = nullptr; if (h->lay_full == 1) { h->lay_rank = -1; h->lay_full = -1; } }
     h->dA = h->dXs = h->dW = nullptr;
     h->dInvEll = h->dSlotp = h->dPartial = h->dRes = nullptr;
     h->dInfo = nullptr;
@@ -327,7 +343,7 @@ int ensure_slots(gphip_ctx* h, int want, bool workspace = true) {
     dev((void**)&h->dRes, S * 2 * 8, "results");
     dev((void**)&h->dInfo, S * 4, "info words");
     dev((void**)&h->dFlags, nflags, "dependency flags");
-    dev((void**)&h->dTicket, 16 + DF_PARK_SLOTS * 4, "ticket counter");        // + the per-CU "chain task here" counters
+    dev((void**)&h->dTicket, DF_TICKET_BYTES, "ticket counter");        // + the per-CU "chain task here" counters
     host((void**)&h->hInvEll, S * h->d * 8, "pinned inverse length scales");
     host((void**)&h->hSlotp, S * SLOTP * 8, "pinned slot scalars");
     host((void**)&h->hRes, S * 2 * 8, "pinned results");
@@ -337,7 +353,7 @@ int ensure_slots(gphip_ctx* h, int want, bool workspace = true) {
     // numbers) or tickets before the clear landed.  Found by scripts/gpu_api_fuzz.py (wrong likelihood / memory fault
     // right after a batch grew the slot count), present since round 1.
     if (e == hipSuccess && (e = hipMemsetAsync(h->dFlags, 0, nflags, h->stream)) != hipSuccess) what = "flag clear";
-    if (e == hipSuccess && (e = hipMemsetAsync(h->dTicket, 0, 16 + DF_PARK_SLOTS * 4, h->stream)) != hipSuccess) what = "ticket clear";
+    if (e == hipSuccess && (e = hipMemsetAsync(h->dTicket, 0, DF_TICKET_BYTES, h->stream)) != hipSuccess) what = "ticket clear";
     if (e != hipSuccess) {
         (void)hipGetLastError();               // (clear the sticky out-of-memory status)
         free_slots(h);
@@ -668,6 +684,35 @@ bool use_dataflow(const gphip_ctx* h, int nslots) {
     return tasks < (1l << 30);
 }
 
+// The two CU-masked streams of a split dataflow launch.  Mask bit i of hipExtStreamCreateWithCUMask is CU (i / 8) / 4 of shader
+// engine (i / 8) % 4 of XCD i % 8 on this stack (measured bit by bit: scripts/micro/cumask_map.hip) -- bits x + 8 k, k < res,
+// reserve `res` CUs in EVERY XCD (the workgroup dispatcher deals a grid round-robin over the XCDs, so an uneven mask would make
+// the smallest XCD the pace of the bulk launch).  false = not available (the caller falls back to the single launch).
+bool split_streams(gphip_ctx* h, int res) {
+    if (res > 8) res = 8;
+    if (h->chain_stream && h->split_streams_for == res) return true;
+    int ncu = 0;
+    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess || ncu != 256) return false;
+    if (h->chain_stream) { (void)hipStreamDestroy(h->chain_stream); h->chain_stream = nullptr; }
+    if (h->bulk_stream) { (void)hipStreamDestroy(h->bulk_stream); h->bulk_stream = nullptr; }
+    uint32_t cm[8] = {0, 0, 0, 0, 0, 0, 0, 0}, bm[8];
+    for (int x = 0; x < 8; ++x)
+        for (int k = 0; k < res; ++k) {
+            const int b = x + 8 * k;
+            cm[b / 32] |= 1u << (b % 32);
+        }
+    for (int w = 0; w < 8; ++w) bm[w] = ~cm[w];
+    if (hipExtStreamCreateWithCUMask(&h->chain_stream, 8, cm) != hipSuccess ||
+        hipExtStreamCreateWithCUMask(&h->bulk_stream, 8, bm) != hipSuccess) {
+        (void)hipGetLastError();
+        if (h->chain_stream) { (void)hipStreamDestroy(h->chain_stream); h->chain_stream = nullptr; }
+        h->bulk_stream = nullptr;
+        return false;
+    }
+    h->split_streams_for = res;
+    return true;
+}
+
 // c0 > 0 (128-tiles only): factor the trailing submatrix that starts at tile column c0 -- the tail of the
 // look-ahead schedule, already updated by every earlier panel.  No finalize here.
 template <typename T, int TBX, int OCC = 2, int NST = 2, bool BUILD = false>
@@ -708,6 +753,34 @@ void launch_dataflow(gphip_ctx* h, int nslots, int c0 = 0, double* part = nullpt
         if ((size_t)kib * 1024 > lds) lds = (size_t)kib * 1024;
         // two workgroups per CU: the neighbour of a diagonal task steps aside while that task is on the chain
         if (lds <= 80 * 1024 && h->dataflow_park) g.park = reinterpret_cast<int*>(h->dTicket + 2);
+    }
+    if constexpr (TBX == 64) {
+        const int res = h->df_split >= 0 ? h->df_split : (tasks >= h->df_split_min_tasks && nslots == 1 ? h->df_split_auto : 0);
+        if (res > 0 && R >= 4 && split_streams(h, res)) {
+            // chain launch: diagonal tasks, ONE workgroup per reserved CU (LDS request); bulk launch: everything else
+            hipEvent_t e0 = sync_event(h), e1 = sync_event(h), e2 = sync_event(h);
+            (void)hipEventRecord(e0, h->stream);
+            (void)hipStreamWaitEvent(h->chain_stream, e0, 0);
+            (void)hipStreamWaitEvent(h->bulk_stream, e0, 0);
+            DfArgs<T> gc = g, gb = g;
+            gc.role = 1; gc.park = nullptr;
+            gc.ticket = h->dTicket + DF_TICKET2; gc.ticket_base = h->ticket_base2;
+            const long ctasks = (long)R * nslots;
+            h->ticket_base2 += (unsigned long long)ctasks;
+            gb.role = 2; gb.park = nullptr;
+            h->ticket_base -= (unsigned long long)ctasks;             // (the bulk launch draws tasks - ctasks tickets)
+            size_t clds = df_lds_bytes<T, TBX, NST>();
+            if ((size_t)h->df_split_lds_kib * 1024 > clds) clds = (size_t)h->df_split_lds_kib * 1024;
+            hipLaunchKernelGGL((chol_dataflow_kernel<T, TBX, 2, NST, BUILD>), dim3((unsigned)ctasks), dim3(256), clds, h->chain_stream, gc, tp);
+            const size_t blds = df_lds_bytes<T, TBX, NST>();
+            hipLaunchKernelGGL((chol_dataflow_kernel<T, TBX, OCC, NST, BUILD>), dim3((unsigned)(tasks - ctasks)), dim3(256), blds,
+                               h->bulk_stream, gb, tp);
+            (void)hipEventRecord(e1, h->chain_stream);
+            (void)hipEventRecord(e2, h->bulk_stream);
+            (void)hipStreamWaitEvent(h->stream, e1, 0);
+            (void)hipStreamWaitEvent(h->stream, e2, 0);
+            return;
+        }
     }
     hipLaunchKernelGGL((chol_dataflow_kernel<T, TBX, OCC, NST, BUILD>), dim3((unsigned)tasks), dim3(256), lds, h->stream, g, tp);
 }
@@ -1536,6 +1609,9 @@ int dist_layout(gphip_ctx* h, int rank, int world, bool full) {
         h->dist_base = full ? h->dA : h->dOwn;
         return GPHIP_OK;
     }
+    // any failure below leaves NO layout behind (a draining member must never address panel storage through a stale one)
+    h->lay_rank = -1; h->lay_world = 0; h->lay_full = -1;
+    h->dist_base = nullptr;
     h->dist_adj.assign((size_t)nouter + 1, 0);
     if (full) {
         int rc = ensure_slots(h, 1, true);
@@ -1765,7 +1841,7 @@ int gphip_destroy(gphip_handle h) {
     (void)hipSetDevice(h->device);
     for (void* pk : h->packed) (void)hipFree(pk);
     (void)hipFree(h->dOwn); (void)hipFree(h->dDistAdj); (void)hipFree(h->dZ);
-    (void)hipFree(h->dScal8);
+    (void)hipFree(h->dScal8); (void)hipFree(h->drain_buf);
     if (h->cstream) (void)hipStreamDestroy(h->cstream);
     free_slots(h);
     (void)hipFree(h->dXt); (void)hipFree(h->dY); (void)hipFree(h->dExp2);
@@ -1776,6 +1852,8 @@ int gphip_destroy(gphip_handle h) {
     for (auto e : h->pool) (void)hipEventDestroy(e);
     for (auto e : h->sync_events) (void)hipEventDestroy(e);
     if (h->stream2) { (void)hipStreamSynchronize(h->stream2); (void)hipStreamDestroy(h->stream2); }
+    if (h->chain_stream) (void)hipStreamDestroy(h->chain_stream);
+    if (h->bulk_stream) (void)hipStreamDestroy(h->bulk_stream);
     if (h->own_streams) {
         if (h->pstream) (void)hipStreamDestroy(h->pstream);
         if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -2177,9 +2255,27 @@ static int predict_streamed(gphip_handle h, const void* Xs, int64_t M, double* m
     int nouter = 0;
     int rc = gphip_dist_num_panels(h, &nouter);
     if (rc) return rc;
+    // COLLECTIVE from here on (one all-reduce, then passes x nouter broadcasts that every rank of the job issues): nothing
+    // rank-local returns before the all-reduce -- it carries a "this rank cannot" flag, so all ranks bail out TOGETHER --
+    // and after it a local failure only switches this process to drain mode (the remaining broadcasts still go out, through
+    // a scratch buffer), exactly as in group_eval_run.
+    int failed = GPHIP_OK;
+    std::string failed_why;
+    auto local_fail = [&](int code, const std::string& why) {
+        if (code != GPHIP_OK && failed == GPHIP_OK) { failed = code; failed_why = why; }
+    };
+    auto soft = [&](hipError_t e, const char* what) {
+        if (h->debug_fail_hip > 0 && --h->debug_fail_hip == 0) e = hipErrorUnknown;                  // fault injection (tests)
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            local_fail(GPHIP_ERR_HIP, std::string(what) + " failed in a streamed prediction: " + hipGetErrorString(e));
+        }
+        return e == hipSuccess;
+    };
+#define SOFT(call) soft((call), #call)
     for (gphip_ctx* m : g->members)
         if (!m->dist_fit || !has_fit(m) || m->fit_id != g->fit_id || m->theta_fit != h->theta_fit || m->lay_panel != m->panel)
-            return fail(h, GPHIP_ERR_STATE, "the distributed factor is gone (another call reused the buffers, or \"panel\" changed): fit again");
+            local_fail(GPHIP_ERR_STATE, "the distributed factor is gone (another call reused the buffers, or \"panel\" changed): fit again");
     // test points -> local ranks (contiguous blocks; few points: the first rank alone), chunks of <= ~8 GiB of V
     std::vector<int64_t> lo((size_t)nl + 1, M);
     lo[0] = 0;
@@ -2187,11 +2283,11 @@ static int predict_streamed(gphip_handle h, const void* Xs, int64_t M, double* m
         for (int i = 1; i < nl; ++i) lo[(size_t)i] = M * i / nl;
     std::vector<int64_t> MC((size_t)nl, TB);
     double passes = 1.0;
-    for (int i = 0; i < nl; ++i) {
+    for (int i = 0; i < nl && failed == GPHIP_OK; ++i) {
         gphip_ctx* m = g->members[(size_t)i];
         const int64_t Mi = lo[(size_t)i + 1] - lo[(size_t)i];
         if (Mi <= 0) continue;
-        HIPCHK(hipSetDevice(m->device));
+        if (!SOFT(hipSetDevice(m->device))) break;
         int64_t mc = (int64_t)((8.0 * (1 << 30)) / ((double)m->Npad * m->es)) / TB * TB;
         mc = std::max<int64_t>(2048, std::min<int64_t>(mc, 32768));
         if (Mi < mc) mc = (Mi + TB - 1) / TB * TB;
@@ -2201,73 +2297,89 @@ static int predict_streamed(gphip_handle h, const void* Xs, int64_t M, double* m
             mc = (mc / 2 + TB - 1) / TB * TB;
             rc = ensure_vbuf(m, mc);
         }
-        if (rc) { if (m != h) h->err = m->err; return rc; }
-        if (!m->dZ) HIPCHK(hipMalloc(&m->dZ, (size_t)m->Npad * m->es));
+        if (rc) { local_fail(rc, m->err); break; }
+        if (!m->dZ && !SOFT(hipMalloc(&m->dZ, (size_t)m->Npad * m->es))) break;
         MC[(size_t)i] = mc;
         passes = std::max(passes, (double)((Mi + mc - 1) / mc));
     }
-    if (nl < W) {                                                      // ranks elsewhere: agree on the number of passes (max)
-        HIPCHK(hipSetDevice(h->device));
-        if (!h->dScal8) HIPCHK(hipMalloc(&h->dScal8, 8 * sizeof(double)));
-        HIPCHK(hipMemcpyAsync(h->dScal8, &passes, 8, hipMemcpyHostToDevice, h->stream));
-        if (rccl().AllReduce(h->dScal8, h->dScal8, 1, NCCL_FLOAT64, NCCL_MAX, g->comms[0], h->stream) != 0) {
+    g->replicate = 0;                                                  // a distributed factor: owned panels + receive buffers
+    if (failed == GPHIP_OK) {
+        rc = group_resize_packed(h, g);
+        if (rc) local_fail(rc, h->err);
+    }
+    if (nl < W) {                                  // ranks elsewhere: agree on the number of passes (max) AND on "everybody can"
+        double v[2] = {passes, failed != GPHIP_OK ? 1.0 : 0.0};
+        (void)hipSetDevice(h->device);
+        if (!h->dScal8) { g->broken = true; return fail(h, GPHIP_ERR_HIP, "scalar buffer of the multi-device handle is missing"); }
+        if (hipMemcpyAsync(h->dScal8, v, sizeof v, hipMemcpyHostToDevice, h->stream) != hipSuccess) {
+            (void)hipGetLastError();
+            local_fail(GPHIP_ERR_HIP, "uploading the pass count of a streamed prediction failed");
+            (void)hipMemsetAsync(h->dScal8, 0x7f, sizeof v, h->stream);            // 1.4e306 in both entries: reads as "a rank cannot"
+        }
+        if (rccl().AllReduce(h->dScal8, h->dScal8, 2, NCCL_FLOAT64, NCCL_MAX, g->comms[0], h->stream) != 0) {
             g->broken = true;
             return fail(h, GPHIP_ERR_HIP, "ncclAllReduce (passes) failed");
         }
-        HIPCHK(hipMemcpyAsync(&passes, h->dScal8, 8, hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(hipStreamSynchronize(h->stream));
+        if (hipMemcpyAsync(v, h->dScal8, sizeof v, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+            hipStreamSynchronize(h->stream) != hipSuccess) {
+            (void)hipGetLastError();
+            g->broken = true;                      // this rank cannot learn what its peers are about to do
+            return fail(h, GPHIP_ERR_HIP, "reading back the pass count of a streamed prediction failed");
+        }
+        if (!(v[1] == 0.0)) {                      // some rank cannot: NO rank issues a broadcast
+            h->err = failed != GPHIP_OK ? failed_why : std::string("another rank of the job could not prepare this streamed prediction");
+            return failed != GPHIP_OK ? failed : GPHIP_ERR_HIP;
+        }
+        passes = v[0];
+    } else if (failed != GPHIP_OK) {
+        h->err = failed_why;
+        return failed;
     }
-    g->replicate = 0;                                                  // a distributed factor: owned panels + receive buffers
-    rc = group_resize_packed(h, g);
-    if (rc) return rc;
     std::vector<double> xt;
     const double *pm0 = h->pw_mean_test, *pn0 = h->pw_nug_test;      // (member 0 IS the public handle: keep the call's pointers)
     struct Restore { gphip_ctx* h; const double *a, *b; ~Restore() { h->pw_mean_test = a; h->pw_nug_test = b; } } restore{h, pm0, pn0};
+    auto member_fail = [&](gphip_ctx* m, int code) { if (code) local_fail(code, m->err); };
     for (int pass = 0; pass < (int)passes; ++pass) {
         std::vector<int64_t> c0((size_t)nl, 0), mcv((size_t)nl, 0), mpadv((size_t)nl, 0);
-        for (int i = 0; i < nl; ++i) {                                 // k* of this pass's chunk on every rank that has one
+        for (int i = 0; i < nl && failed == GPHIP_OK; ++i) {           // k* of this pass's chunk on every rank that has one
             gphip_ctx* m = g->members[(size_t)i];
             m->sync_used = 0;
             const int64_t a = lo[(size_t)i] + (int64_t)pass * MC[(size_t)i], b = std::min(lo[(size_t)i + 1], a + MC[(size_t)i]);
             if (b <= a) continue;
             c0[(size_t)i] = a; mcv[(size_t)i] = b - a; mpadv[(size_t)i] = (b - a + TB - 1) / TB * TB;
             const int64_t mc = b - a, mpad = mpadv[(size_t)i];
-            HIPCHK(hipSetDevice(m->device));
+            if (!SOFT(hipSetDevice(m->device))) break;
             m->cs = m->stream;
             xt.assign((size_t)d * mpad, 0.0);
             for (int64_t r = 0; r < mc; ++r)
                 for (int64_t j = 0; j < d; ++j) xt[(size_t)j * mpad + r] = X[(a + r) * d + j];
-            rc = DISPATCH(m, upload, m, m->dXsT, xt, m->stream);
-            if (rc) { if (m != h) h->err = m->err; return rc; }
+            member_fail(m, DISPATCH(m, upload, m, m->dXsT, xt, m->stream));
             m->pw_mean_test = pm0 ? pm0 + a : nullptr;
             m->pw_nug_test = pn0 ? pn0 + a : nullptr;
-            rc = upload_pw_test(m, 0, 1, 0, mc, mpad);
-            if (rc) { if (m != h) h->err = m->err; return rc; }
-            DISPATCH(m, queue_cross, m, mc, mpad, 1);
+            if (failed == GPHIP_OK) member_fail(m, upload_pw_test(m, 0, 1, 0, mc, mpad));
+            if (failed == GPHIP_OK) DISPATCH(m, queue_cross, m, mc, mpad, 1);
         }
         std::vector<std::vector<hipEvent_t>> ev_used((size_t)nl, std::vector<hipEvent_t>((size_t)nouter, nullptr));
         for (int k = 0; k < nouter; ++k) {
             const int o = k % W;
-            for (int i = 0; i < nl; ++i) {                             // the receive buffer's last reader: panel k-3's substitution
+            for (int i = 0; i < nl && failed == GPHIP_OK; ++i) {       // the receive buffer's last reader: panel k-3's substitution
                 gphip_ctx* m = g->members[(size_t)i];
-                HIPCHK(hipSetDevice(m->device));
-                if (k >= 3 && ev_used[(size_t)i][(size_t)k - 3]) HIPCHK(hipStreamWaitEvent(m->cstream, ev_used[(size_t)i][(size_t)k - 3], 0));
+                SOFT(hipSetDevice(m->device));
+                if (k >= 3 && ev_used[(size_t)i][(size_t)k - 3]) SOFT(hipStreamWaitEvent(m->cstream, ev_used[(size_t)i][(size_t)k - 3], 0));
                 if (pass == 0 && k < 3) {                              // nothing of an earlier call may still read the buffers
                     hipEvent_t e = sync_event(m);
-                    HIPCHK(hipEventRecord(e, m->stream));
-                    HIPCHK(hipStreamWaitEvent(m->cstream, e, 0));
+                    if (SOFT(hipEventRecord(e, m->stream))) SOFT(hipStreamWaitEvent(m->cstream, e, 0));
                 }
             }
-            const int c = group_broadcast(h, g, k, (size_t)dist_panel_tiles(h, k) * TS * h->es, o);
+            const int c = group_broadcast(h, g, k, (size_t)dist_panel_tiles(h, k) * TS * h->es, o, 0, failed != GPHIP_OK);
             if (c) { g->broken = true; return c; }
             const int K0 = k * h->panel, K1 = (int)std::min<int64_t>(K0 + h->panel, h->Nt);
-            for (int i = 0; i < nl; ++i) {
+            for (int i = 0; i < nl && failed == GPHIP_OK; ++i) {
                 gphip_ctx* m = g->members[(size_t)i];
                 if (mcv[(size_t)i] <= 0) continue;
-                HIPCHK(hipSetDevice(m->device));
+                SOFT(hipSetDevice(m->device));
                 hipEvent_t eb = sync_event(m);
-                HIPCHK(hipEventRecord(eb, m->cstream));
-                HIPCHK(hipStreamWaitEvent(m->stream, eb, 0));
+                if (!SOFT(hipEventRecord(eb, m->cstream)) || !SOFT(hipStreamWaitEvent(m->stream, eb, 0))) break;
                 const bool mine = o == g->ranks[(size_t)i];
                 // base through which this panel's tiles are addressed with their global indices
                 char* base = group_panel_ptr(g, i, k) - dist_panel_first(m, k) * TS * (long)m->es;
@@ -2289,27 +2401,31 @@ static int predict_streamed(gphip_handle h, const void* Xs, int64_t M, double* m
                 DISPATCH(m, queue_forward_panel, m, mpadv[(size_t)i], 1, K0, K1, 0, false);
                 m->ws_override = nullptr;
                 hipEvent_t eu = sync_event(m);
-                HIPCHK(hipEventRecord(eu, m->stream));
-                ev_used[(size_t)i][(size_t)k] = eu;
+                if (SOFT(hipEventRecord(eu, m->stream))) ev_used[(size_t)i][(size_t)k] = eu;
             }
         }
         for (int i = 0; i < nl; ++i) {
             gphip_ctx* m = g->members[(size_t)i];
-            HIPCHK(hipSetDevice(m->device));
-            if (mcv[(size_t)i] > 0) {
+            (void)hipSetDevice(m->device);
+            if (mcv[(size_t)i] > 0 && failed == GPHIP_OK) {
                 const int64_t mc = mcv[(size_t)i], a = c0[(size_t)i];
                 m->z_vector = true;
                 DISPATCH(m, queue_predict_reduce, m, mc, mpadv[(size_t)i], 1);
                 m->z_vector = false;
-                HIPCHK(hipMemcpyAsync(mean + a, m->dMean, (size_t)mc * 8, hipMemcpyDeviceToHost, m->stream));
-                HIPCHK(hipMemcpyAsync(var + a, m->dVar, (size_t)mc * 8, hipMemcpyDeviceToHost, m->stream));
+                SOFT(hipMemcpyAsync(mean + a, m->dMean, (size_t)mc * 8, hipMemcpyDeviceToHost, m->stream));
+                SOFT(hipMemcpyAsync(var + a, m->dVar, (size_t)mc * 8, hipMemcpyDeviceToHost, m->stream));
             }
-            HIPCHK(hipStreamSynchronize(m->cstream));
-            HIPCHK(hipStreamSynchronize(m->stream));
-            HIPCHK(hipGetLastError());
+            SOFT(hipStreamSynchronize(m->cstream));
+            SOFT(hipStreamSynchronize(m->stream));
+            SOFT(hipGetLastError());
             harvest(m);
             m->pw_mean_test = m->pw_nug_test = nullptr;
         }
+    }
+#undef SOFT
+    if (failed != GPHIP_OK) {
+        h->err = failed_why;
+        return failed;
     }
     return GPHIP_OK;
 }
@@ -2573,6 +2689,7 @@ int gphip_dist_begin(gphip_handle h, const double* theta, int p, int rank, int w
     if (rc) return rc;
     invalidate_fit(h);
     h->dist_rank = rank; h->dist_world = world;
+    h->dist_first_factored = -1;
     h->dist_theta_ok = stage_theta(h, 0, theta, h->pw_nug_host, h->pw_mean_host);
     rc = upload_pw(h, 0, 1);                   // point-dependent nugget / mean of this evaluation, if the caller set them
     if (rc) return rc;
@@ -2635,7 +2752,8 @@ int gphip_dist_update(gphip_handle h, int k, const void* packed, int j_first, in
         if (j % W == h->dist_rank) { if (j0 < 0) j0 = j; ++cnt; }
     const int cls = on_panel_stream ? 3 : 4;
     const bool corner = j_last > nouter && nouter >= jb && h->dist_rank == 0;
-    h->dist_first_factored = -1;
+    // (dist_first_factored stays set until gphip_dist_factor_panel consumes it: the look-ahead update is the LAST update of
+    //  its panel, so a main-stream update issued between LA(k) and the factorisation of panel k + 1 cannot invalidate it)
     if (cnt > 0) {
         // the look-ahead update of the NEXT panel (this rank owns it) also factors that panel's first diagonal block
         // (fuse_potrf): gphip_dist_factor_panel then starts at the panel solve
@@ -2691,11 +2809,11 @@ int* option_slot(gphip_ctx* h, const char* name) {
         {"dataflow", &gphip_ctx::dataflow}, {"dataflow_max_nt", &gphip_ctx::dataflow_max_nt},
         {"dataflow_max_slots", &gphip_ctx::dataflow_max_slots}, {"dataflow_fine_nt", &gphip_ctx::dataflow_fine_nt},
         {"dataflow_tail", &gphip_ctx::dataflow_tail}, {"grad_potri", &gphip_ctx::grad_potri},
-        {"fused_eval", &gphip_ctx::fuse_option}, {"panel_left", &gphip_ctx::panel_left}, {"build_overlap", &gphip_ctx::build_overlap}, {"dataflow_lds_kib", &gphip_ctx::dataflow_lds_kib}, {"dataflow_park", &gphip_ctx::dataflow_park}, {"fuse_potrf", &gphip_ctx::fuse_potrf}, {"bcast_chunks", &gphip_ctx::bcast_chunks}, {"dataflow_occ3", &gphip_ctx::dataflow_occ3},
+        {"fused_eval", &gphip_ctx::fuse_option}, {"panel_left", &gphip_ctx::panel_left}, {"build_overlap", &gphip_ctx::build_overlap}, {"dataflow_lds_kib", &gphip_ctx::dataflow_lds_kib}, {"dataflow_park", &gphip_ctx::dataflow_park}, {"fuse_potrf", &gphip_ctx::fuse_potrf}, {"bcast_chunks", &gphip_ctx::bcast_chunks}, {"dataflow_occ3", &gphip_ctx::dataflow_occ3}, {"df_split", &gphip_ctx::df_split}, {"df_split_lds_kib", &gphip_ctx::df_split_lds_kib}, {"df_split_min_tasks", &gphip_ctx::df_split_min_tasks}, {"df_split_auto", &gphip_ctx::df_split_auto},
         {"max_slots", &gphip_ctx::max_slots}, {"shard_min_n", &gphip_ctx::shard_min_n},
         {"thin_tiles", &gphip_ctx::thin_tiles}, {"panel_wide", &gphip_ctx::panel_wide},
         {"la_main", &gphip_ctx::la_main}, {"rest_split", &gphip_ctx::rest_split},
-        {"debug_fail_alloc", &gphip_ctx::debug_fail_alloc}, {"replicate_factor", &gphip_ctx::replicate_factor},
+        {"debug_fail_alloc", &gphip_ctx::debug_fail_alloc}, {"debug_fail_hip", &gphip_ctx::debug_fail_hip}, {"replicate_factor", &gphip_ctx::replicate_factor},
         {"share_local_panels", &gphip_ctx::share_local_panels},
     };
     for (const Entry& e : table)

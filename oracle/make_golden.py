@@ -94,14 +94,27 @@ def f3():
 
 def fcfg5():
     """BASELINE.json cfg 5 at its own size: Matern-5/2 ARD, N = 65536, d = 16, the fp32 timing theta (sn = 0.3) -- ONE in-place
-    LU of a 34.4 GB matrix (needs ~36 GB of RAM and ~15 min on 8 cores; `--cfg5` regenerates only this file).  Scalars only."""
-    n, d, kernel = 65536, 16, "matern52_ard"
+    LU of a 34.4 GB matrix (needs ~36 GB of RAM and ~15-40 min on 8 cores; `--cfg5` regenerates only this file).  The three
+    scalars AND, from the same factorisation, the prediction (BGP:396-422: mu*, sigma*) at the first 64 of cfg 5's 10 000 test
+    points -- the steps of gp_oracle.predict_internal with the LU shared instead of redone."""
+    n, d, kernel, m = 65536, 16, "matern52_ard", 64
     X, y = syn.make_dataset(n, d)
+    Xs = syn.make_test_points(10000, d)[:m]
     th = syn.default_theta(kernel, d, dtype="f32")
-    ll, ld, qd, info = orc.log_likelihood(kernel, th, X, y, parts=True)
-    print("CFG5", n, d, kernel, ll, ld, qd, info)
+    r = orc.residual(kernel, th, X, y)
+    K = orc.covariance_matrix(kernel, th, X)
+    solve, ld = orc.matrix_inverse_and_det(K.T, overwrite=True)      # (symmetric bit for bit: the transpose view is column-major)
+    del K
+    alpha = solve(r)
+    qd = float(r @ alpha)
+    ll = orc.gp_log_likelihood_from_parts(r, solve, ld)
+    k, kappa = orc.k_and_kappa(kernel, th, X, Xs)
+    mu = alpha @ k                                                    # mean function 0 (BGP:407-412)
+    with np.errstate(invalid="ignore"):
+        sd = np.sqrt(kappa - np.sum(k * solve(k), axis=0))            # BGP:414-417
+    print("CFG5", n, d, kernel, ll, ld, qd, mu[:3], sd[:3])
     np.savez_compressed(os.path.join(OUT, "cfg5_scalars.npz"), n=n, d=d, kernel=kernel, theta=th, xsum=float(X.sum()),
-                        ysum=float(y.sum()), loglik=ll, logdet=ld, quad=qd, info=info)
+                        ysum=float(y.sum()), loglik=ll, logdet=ld, quad=qd, info=0, Xs=Xs, mu=mu, sd=sd)
 
 
 def f4():

@@ -92,3 +92,39 @@ def test_single_process_grouped_rccl_path(tmp_path):
     mo, so = orc.predict_internal(kernel, th, X, y, syn.make_test_points(700, d))
     np.testing.assert_allclose(res["mu"], mo, rtol=1e-7, atol=1e-9)
     np.testing.assert_allclose(np.sqrt(res["var"]), so, rtol=1e-7)
+
+
+@pytest.mark.parametrize("fault,world,fault_rank,arg", [("alloc", 2, 1, 1), ("alloc", 2, 0, 1), ("hip", 3, 1, 7), ("hip", 3, 2, 1),
+                                                         ("hip", 2, 0, 25), ("predict", 2, 1, 0), ("predict", 3, 0, 0)])
+def test_rank_local_failure_never_leaves_peers_in_a_collective(tmp_path, fault, world, fault_rank, arg):
+    """Fault injection on ONE rank of a multi-process job (tests/multiproc_fault_worker.py): a failed slot allocation in
+    gphip_dist_begin on a handle that has no layout yet (replicate_factor = 1, share_local_panels = 0), the n-th HIP call of
+    the schedule itself (event record / stream wait) failing, a rank whose distributed factor is gone at prediction time.
+    Every rank must come back from the call -- with an error -- and the next collective call must work on all of them."""
+    n, d, kernel, panel = 900, 3, "se_ard", 2
+    fake = build.build_fake_rccl()
+    env = dict(os.environ, GPHIP_NO_TORCH="1", GPHIP_RCCL_PATH=fake, FAKE_RCCL_SHM=f"/gphip_fault_{os.getpid()}_{fault}_{fault_rank}",
+               LD_LIBRARY_PATH="/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+    outs = [str(tmp_path / f"rank{r}.json") for r in range(world)]
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "multiproc_fault_worker.py"), str(r), str(world),
+                               outs[r], str(n), str(d), kernel, str(panel), fault, str(fault_rank), str(arg)], env=env, cwd=ROOT,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    logs = []
+    for p in procs:
+        try:
+            logs.append(p.communicate(timeout=240)[0])
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            pytest.fail("a rank hung: a local failure left its peers blocked in a collective")
+    assert all(p.returncode == 0 for p in procs), "\n".join(logs)[-3000:]
+    res = [json.load(open(o)) for o in outs]
+    X, y = syn.make_dataset(n, d)
+    want = orc.log_likelihood(kernel, syn.default_theta(kernel, d), X, y, parts=True)
+    for r in res:
+        assert not r["faulted"]["ok"], r                               # EVERY rank reports the failure, from the same call
+        assert r["faulted"]["status"] in (3, 4), r
+        assert r["after"]["ok"], r                                     # ... and the job carries on
+        ll, ld, qd, info = r["after"]["value"]
+        assert info == 0 and close(ll, want[0], n) and close(ld, want[1], n) and close(qd, want[2], n)
+    assert any("another rank" in r["faulted"]["msg"] or "disagree" in r["faulted"]["msg"] for r in res if r["rank"] != fault_rank) or world == 1
