@@ -117,6 +117,33 @@ __device__ __forceinline__ double exp_tab(double w, const double* __restrict__ t
     const int ki = __double2loint(t);
     return __builtin_ldexp(tab[ki & (EXP_TAB - 1)] * p, ki >> 9);
 }
+// The same table with the argument ALREADY in table units (round 4: the kernel build is fp64-VALU bound on a chip that runs it
+// at a low shader clock, so every instruction of the inner loop shows):   sf2 exp(-u ln2/512) = sf2 2^(-u/512),  u >= 0.
+//   t  = MAGIC - u            (k = -rint(u) lands in the low mantissa bits)
+//   r' = -u - k               EXACT (|r'| <= 1/2: the difference of two doubles that agree in their leading bits) -- no Cody-Waite
+//                             split, no multiplication by ln2/512: that factor sits in the polynomial's coefficients
+//   sf2 2^(-u/512) = 2^(k >> 9) * TAB[k & 511] * (1 + c1 r' + c2 r'^2 + c3 r'^3 + c4 r'^4),   c_n = (ln2/512)^n / n!
+// 10 fp64 VALU instructions instead of 12 (+ the same 3 integer ones).  For the squared exponential the caller scales the
+// point coordinates by sqrt(512 / (2 ln2)) once per tile, so that the accumulated squared distance IS u.
+constexpr double EXP_U_PER_ARG = 738.6598609351493;          // 512 / ln 2: u = EXP_U_PER_ARG * (the exponent's magnitude)
+constexpr double EXP_COORD_SCALE_SE = 19.217958540583197;    // sqrt(512 / (2 ln 2)): coordinates -> sum of squares = u of exp(-r2/2)
+__device__ __forceinline__ double exp_tab_u(double u, const double* __restrict__ tab) {
+    constexpr double MAGIC = 6755399441055744.0;             // 1.5 * 2^52
+    constexpr double C1 = 1.3538030870311431e-03;            // ln2 / 512
+    constexpr double C2 = 9.163913992275265e-07;             // C1^2 / 2
+    constexpr double C3 = 4.1353783506767136e-10;           // C1^3 / 6
+    constexpr double C4 = 1.399621994296973e-13;             // C1^4 / 24
+    u = fmin(u, 1.0e6);                                      // 2^-1953 = 0 in fp64: keeps k inside the int range
+    const double t = MAGIC - u;
+    const double kd = t - MAGIC;                             // -rint(u), exact
+    const double r = -kd - u;                                // exact
+    double p = __builtin_fma(C4, r, C3);
+    p = __builtin_fma(p, r, C2);
+    p = __builtin_fma(p, r, C1);
+    p = __builtin_fma(p, r, 1.0);
+    const int ki = __double2loint(t);
+    return __builtin_ldexp(tab[ki & (EXP_TAB - 1)] * p, ki >> 9);
+}
 
 // Per-type numerics and MFMA shape
 template <typename T> struct Num;
@@ -365,9 +392,15 @@ __global__ __launch_bounds__(256) void kbuild_kernel(KBuildArgs<T> a) {
     double* etab = lds_raw + ((D > 0) ? D : 2 * d) * TB;
     if (sizeof(T) == 8 && KT != 2)
         for (int idx = tid; idx < EXP_TAB; idx += 256) etab[idx] = sp[0] * a.exp2tab[idx];
+    // fp64 squared exponential: coordinates in units in which the squared distance IS the exp table's argument (exp_tab_u)
+    constexpr bool USCALE = sizeof(T) == 8 && KT == 0 && D > 0;
+    // fp32 fast path below: sum of squares = r2 log2(e) / 2 (SE) or 5 r2 (Matern-5/2)
+    constexpr bool F32FAST = sizeof(T) == 4 && D > 0 && KT != 2;
+    constexpr float CS32 = KT == 0 ? 0.84932180028801904f /* sqrt(log2(e) / 2) */ : 2.2360679774997896f /* sqrt 5 */;
+    const T cscale = USCALE ? (T)EXP_COORD_SCALE_SE : (F32FAST ? (T)CS32 : (T)1);
     for (int idx = tid; idx < d * TB; idx += 256) {
         const int dd = idx >> 7, c = idx & 127;
-        xjs[idx] = xjg[(long)dd * a.npad_j + c];
+        xjs[idx] = (USCALE || F32FAST) ? xjg[(long)dd * a.npad_j + c] * cscale : xjg[(long)dd * a.npad_j + c];
         if (D == 0) xis[idx] = xig[(long)dd * a.npad_i + c];
         if (KT == 2 && two) {
             xjs2[idx] = a.xj2[(long)slot * a.xj_bstride + (long)tj * TB + (long)dd * a.npad_j + c];
@@ -379,15 +412,75 @@ __global__ __launch_bounds__(256) void kbuild_kernel(KBuildArgs<T> a) {
 #pragma unroll
         for (int dd = 0; dd < D; ++dd) {
             const pair_t v = *reinterpret_cast<const pair_t*>(xig + (long)dd * a.npad_i + r0);
-            xa[dd] = v.x;
-            xb[dd] = v.y;
+            xa[dd] = USCALE ? v.x * cscale : v.x;
+            xb[dd] = USCALE ? v.y * cscale : v.y;
         }
     }
     __syncthreads();
 
-    const int gi = ti * TB + r0;
     const bool edge = (a.mode == 0) ? (ti == tj || (ti + 1) * TB > a.n_i)
                                     : ((ti + 1) * TB > a.n_i || (tj + 1) * TB > a.n_j);
+    if constexpr (F32FAST) {
+        // fp32 (round 4; the build is VALU bound -- 16 dimensions, a square root and an exponential per 4-byte entry): a lane
+        // owns FOUR adjacent rows of one column, a half-wave one column, so every store is a 16-byte dwordx4, every J-side LDS
+        // broadcast serves four entries and the whole distance loop is v_pk_add_f32 / v_pk_fma_f32 on row pairs.  The
+        // coordinates are rescaled once per tile so that the accumulated sum of squares is directly what the kernel function
+        // needs: SE  sf2 2^(-acc) (one v_exp_f32, its negation is an input modifier);  Matern-5/2  acc = 5 r2,
+        // s5 = acc * rsq(acc) (v_rsq_f32, 1 ulp; the IEEE sqrtf expansion was 14 instructions per entry),
+        // sf2 (1 + s5 + acc / 3) 2^(-s5 log2 e).
+        constexpr float CS = CS32;
+        const int half = lane >> 5, r4 = 4 * (lane & 31);
+        typedef float v2f __attribute__((ext_vector_type(2)));     // row pairs: v_pk_add_f32 / v_pk_fma_f32
+        v2f xr[D][2];
+#pragma unroll
+        for (int dd = 0; dd < D; ++dd) {
+            const f4 v = *reinterpret_cast<const f4*>(xig + (long)dd * a.npad_i + r4);
+            xr[dd][0] = (v2f){v[0] * CS, v[1] * CS};
+            xr[dd][1] = (v2f){v[2] * CS, v[3] * CS};
+        }
+        const int gi4 = ti * TB + r4;
+        for (int jj = 2 * wave + half; jj < TB; jj += 8) {
+            v2f acc2[2] = {(v2f){0.f, 0.f}, (v2f){0.f, 0.f}};
+#pragma unroll
+            for (int dd = 0; dd < D; ++dd) {
+                const float xj1 = xjs[dd * TB + jj];
+                const v2f xjv = (v2f){xj1, xj1};
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const v2f dl = xr[dd][r] - xjv;
+                    acc2[r] = __builtin_elementwise_fma(dl, dl, acc2[r]);
+                }
+            }
+            const float acc[4] = {acc2[0][0], acc2[0][1], acc2[1][0], acc2[1][1]};
+            f4 v;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (KT == 0) {
+                    v[r] = sf2 * __builtin_amdgcn_exp2f(-acc[r]);
+                } else {
+                    const float q = fmaxf(acc[r], 1e-30f);
+                    const float s5 = q * __builtin_amdgcn_rsqf(q);
+                    v[r] = sf2 * (1.0f + s5 + q * (1.0f / 3.0f)) * __builtin_amdgcn_exp2f(s5 * -1.4426950408889634f);
+                }
+            }
+            if (edge) {
+                const int gj = tj * TB + jj;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int gi = gi4 + r;
+                    if (a.mode == 0) {
+                        if (gi == gj) v[r] += a.pw_nug ? a.pw_nug[(long)slot * a.pw_bstride + gj] : sn2;
+                        if (gj >= a.n_j || gi >= a.n_i) v[r] = (gi == gj) ? 1.f : 0.f;          // identity pad
+                    } else if (gj >= a.n_j || gi >= a.n_i) {
+                        v[r] = 0.f;
+                    }
+                }
+            }
+            *reinterpret_cast<f4*>(out + (long)jj * ldo + r4) = v;
+        }
+        return;
+    }
+    const int gi = ti * TB + r0;
     // columns of the tile dealt round-robin to the four waves: at any moment the workgroup writes four ADJACENT 1 KiB
     // column segments (one contiguous 4 KiB of the tile)
     for (int jj = wave; jj < TB; jj += 4) {
@@ -422,12 +515,17 @@ __global__ __launch_bounds__(256) void kbuild_kernel(KBuildArgs<T> a) {
             vb = kgeneral<T>(a.ks, rb, rb2, sp);
         } else if constexpr (sizeof(T) == 8) {
             if (KT == 0) {
-                va = exp_tab<true>(ra, etab);
-                vb = exp_tab<true>(rb, etab);
+                if constexpr (USCALE) {
+                    va = exp_tab_u(ra, etab);
+                    vb = exp_tab_u(rb, etab);
+                } else {
+                    va = exp_tab<true>(ra, etab);
+                    vb = exp_tab<true>(rb, etab);
+                }
             } else {
                 const double sa = __builtin_sqrt(5.0 * ra), sb = __builtin_sqrt(5.0 * rb);
-                va = (1.0 + sa + (5.0 / 3.0) * ra) * exp_tab<false>(sa, etab);
-                vb = (1.0 + sb + (5.0 / 3.0) * rb) * exp_tab<false>(sb, etab);
+                va = (1.0 + sa + (5.0 / 3.0) * ra) * exp_tab_u(sa * EXP_U_PER_ARG, etab);
+                vb = (1.0 + sb + (5.0 / 3.0) * rb) * exp_tab_u(sb * EXP_U_PER_ARG, etab);
             }
         } else {
             va = kfun<KT, T>(ra, sf2);

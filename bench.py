@@ -76,16 +76,24 @@ def cpu_baseline(n_full: int, d: int, max_full_s: float = 600.0) -> dict:
     th = syn.default_theta("se_ard", d)
     Xw, yw = syn.make_dataset(512, d)
     orc.log_likelihood("se_ard", th, Xw, yw)                   # warm the BLAS threads
+    # The kernel-matrix build of the oracle is numpy element-wise code: serial unless its row blocks go to a thread pool
+    # (round 3 timed it serial: 23 of the 39 s at N = 32768).  Same arithmetic, bit-identical matrix.
+    build_threads = max(1, min(threads, 32))
 
     def timed(n, nthreads):
         """(build s, LU factor + solve + formula s, log-likelihood) of ONE whole evaluation, oracle functions only (the
         same calls orc.log_likelihood makes, split so that the two phases can be reported separately)."""
         X, y = syn.make_dataset(n, d)
+        orc.BUILD_THREADS = build_threads
+        try:
+            with limited(1):                                     # (the pool's workers are the parallelism of the build)
+                t0 = time.perf_counter()
+                r = orc.residual("se_ard", th, X, y)
+                K = orc.covariance_matrix("se_ard", th, X)
+                t1 = time.perf_counter()
+        finally:
+            orc.BUILD_THREADS = 1
         with limited(nthreads):
-            t0 = time.perf_counter()
-            r = orc.residual("se_ard", th, X, y)
-            K = orc.covariance_matrix("se_ard", th, X)
-            t1 = time.perf_counter()
             big = K.size > orc._BLOCK_ELEMS                      # large N: LU in place (K is symmetric bit for bit)
             solve, logdet = orc.matrix_inverse_and_det(K.T if big else K, overwrite=big)
             del K
@@ -93,10 +101,20 @@ def cpu_baseline(n_full: int, d: int, max_full_s: float = 600.0) -> dict:
             t2 = time.perf_counter()
         return t1 - t0, t2 - t1, ll
 
-    # LAPACK on very many threads can be slower than on fewer: pick the best of a short ladder at N = 4096
-    ladder = sorted({t for t in (16, 32, 64, threads) if t <= threads})
-    probe = {t: timed(4096, t) for t in ladder}
-    threads = min(probe, key=lambda t: probe[t][0] + probe[t][1])
+    # LAPACK on very many threads can be slower than on fewer: pick the LU's thread count on a short ladder AT N = 8192
+    # (round 3 chose it at N = 4096, where 16 threads won; the measured sizes are 4-8x larger)
+    ladder = sorted({t for t in (16, 32, 64, 128, threads) if t <= threads})
+    Xl, yl = syn.make_dataset(8192, d)
+    Kl = orc.covariance_matrix("se_ard", th, Xl)
+    probe = {}
+    for t in ladder:
+        with limited(t):
+            Kc = Kl.copy()
+            t0 = time.perf_counter()
+            sla.lu_factor(Kc, overwrite_a=True, check_finite=False)
+            probe[t] = time.perf_counter() - t0
+    del Kl, Kc
+    threads = min(probe, key=probe.get)
     measured = {}
     for n in (8192, 16384):
         if n < n_full:
@@ -110,8 +128,8 @@ def cpu_baseline(n_full: int, d: int, max_full_s: float = 600.0) -> dict:
         tb, tf, ll = timed(n_full, threads)
         measured[n_full] = (tb, tf, ll)
         est = tb + tf
-        how = (f"MEASURED: one whole evaluation at N={n_full} ({threads} threads): build {tb:.2f} s, LU+solve {tf:.2f} s "
-               f"= {est:.1f} s/eval")
+        how = (f"MEASURED: one whole evaluation at N={n_full} (build on a {build_threads}-thread pool {tb:.2f} s, LU+solve on "
+               f"{threads} LAPACK threads {tf:.2f} s = {est:.1f} s/eval)")
     else:
         est = predicted
         how = (f"N={n_full} NOT measured (the N={n_ref} sample predicts {predicted:.0f} s > {max_full_s:.0f} s): scaled from the "
@@ -130,7 +148,9 @@ def cpu_baseline(n_full: int, d: int, max_full_s: float = 600.0) -> dict:
         for _ in range(5):
             orc.log_likelihood("se", th1, X1, y1)
         t_cfg1 = (time.perf_counter() - t0) / 5
-    return {"value": 1.0 / est, "unit": "evals/s", "cores": int(threads), "kind": "port",
+    return {"value": 1.0 / est, "unit": "evals/s", "cores": int(max(threads, build_threads)), "kind": "port",
+            "threads": {"lu": int(threads), "build_pool": int(build_threads),
+                        "lu_ladder_s_at_N8192": {str(k): round(v, 3) for k, v in sorted(probe.items())}},
             "sample": "CPU oracle (numpy build + scipy dgetrf/dgetrs LU restatement of BGP:29-43,130-141,181-199; not "
                       f"Mathematica), d={d}, whole evaluations. " + how,
             "measured": {f"N{n}": {"build_s": round(v[0], 3), "lu_solve_s": round(v[1], 3), "loglik": v[2]}
@@ -167,12 +187,10 @@ def under_profiler() -> bool:
     return any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
 
 
-def live_pmc_traffic(n: int, d: int, device: int, kernel_substr: str = "gemm_nt_kernel<double, 0,"):
-    """HBM-side bytes per launch of the dominant kernel measured IN THIS RUN: two child processes run the same evaluation
-    (`bench.py --pmc-probe`: this file, no torch) under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` -- one counter
-    per pass, no trace domain next to it, as MI355X_MICROARCH.md (HBM section) prescribes; FETCH_SIZE is doubled (gfx950
-    counts 64 B per 128-B request on wide coalesced reads), both are KiB.  Returns None (and the caller falls back to the
-    committed profiles/ summary) when rocprofv3 is missing, this process is itself being profiled, or a pass fails."""
+def _pmc_pass(counters, n: int, d: int, device: int):
+    """One child process (`bench.py --pmc-probe`: this file, no torch, two evaluations) under `rocprofv3 --pmc <counters>` --
+    counters only, no trace domain next to them, as MI355X_MICROARCH.md prescribes.  Returns the rows of the counter CSV, or
+    None when rocprofv3 is missing, this process is itself being profiled, or the pass fails."""
     import csv
     import glob
     import shutil
@@ -181,34 +199,73 @@ def live_pmc_traffic(n: int, d: int, device: int, kernel_substr: str = "gemm_nt_
     exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
     if exe is None or under_profiler():
         return None
+    tmp = tempfile.mkdtemp(prefix="gphip_pmc_", dir="/tmp")
+    try:
+        env = dict(os.environ, TMPDIR="/tmp", GPHIP_NO_TORCH="1", HIP_VISIBLE_DEVICES=os.environ.get("HIP_VISIBLE_DEVICES", str(device)),
+                   LD_LIBRARY_PATH="/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+        cmd = [exe, "--pmc"] + list(counters) + ["--output-format", "csv", "-d", tmp, "-o", "p", "--", sys.executable,
+               os.path.join(ROOT, "bench.py"), "--pmc-probe", "--npoints", str(n), "--dim", str(d)]
+        res = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
+        if res.returncode != 0:
+            return None
+        rows = []
+        for path in glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True):
+            with open(path) as f:
+                rows.extend(csv.DictReader(f))
+        return rows
+    except Exception:                                           # never let the counters break the headline
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def live_pmc_traffic(n: int, d: int, device: int, kernel_substr: str = "gemm_nt_kernel<double, 0,"):
+    """HBM-side bytes per launch of the dominant kernel measured IN THIS RUN: two passes (FETCH_SIZE, WRITE_SIZE: the TCC
+    block cannot hold both); FETCH_SIZE is doubled (gfx950 counts 64 B per 128-B request on wide coalesced reads), both are
+    KiB.  Returns None (and the caller falls back to the committed profiles/ summary) when a pass is not possible."""
     got = {}
     t0 = time.perf_counter()
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-        tmp = tempfile.mkdtemp(prefix="gphip_pmc_", dir="/tmp")
-        try:
-            env = dict(os.environ, TMPDIR="/tmp", GPHIP_NO_TORCH="1", HIP_VISIBLE_DEVICES=os.environ.get("HIP_VISIBLE_DEVICES", str(device)),
-                       LD_LIBRARY_PATH="/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
-            cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", tmp, "-o", "p", "--", sys.executable,
-                   os.path.join(ROOT, "bench.py"), "--pmc-probe", "--npoints", str(n), "--dim", str(d)]
-            res = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
-            if res.returncode != 0:
-                return None
-            vals = []
-            for path in glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True):
-                with open(path) as f:
-                    for row in csv.DictReader(f):
-                        if kernel_substr in row["Kernel_Name"] and row["Counter_Name"] == counter:
-                            vals.append(float(row["Counter_Value"]))
-            if not vals:
-                return None
-            got[counter] = (sum(vals) / len(vals), len(vals))
-        except Exception:                                       # never let the counters break the headline
+        rows = _pmc_pass([counter], n, d, device)
+        if rows is None:
             return None
-        finally:
-            shutil.rmtree(tmp, ignore_errors=True)
+        vals = [float(r["Counter_Value"]) for r in rows if kernel_substr in r["Kernel_Name"] and r["Counter_Name"] == counter]
+        if not vals:
+            return None
+        got[counter] = (sum(vals) / len(vals), len(vals))
     return {"bytes_per_launch": (2.0 * got["FETCH_SIZE"][0] + got["WRITE_SIZE"][0]) * 1024.0,
             "fetch_kib_per_launch": got["FETCH_SIZE"][0], "write_kib_per_launch": got["WRITE_SIZE"][0],
             "launches": got["FETCH_SIZE"][1], "seconds": round(time.perf_counter() - t0, 1)}
+
+
+def live_kbuild_clock(n: int, d: int, device: int, kernel_substr: str = "kbuild_kernel<double"):
+    """What the kernel build's HBM fraction depends on besides the code: the SHADER CLOCK it runs at.  The build is co-limited
+    by fp64 VALU issue and the HBM store rate (profiles/r03_kbuild_pmc.md), so its time moves with the clock the box sustains.
+    One more PMC pass of the probe: SQ_BUSY_CYCLES (summed over the 32 shader engines) / 32 / launch duration = shader
+    clock; SQ_INSTS_VALU x 4 cycles (fp64: 16 lanes per SIMD per clock) / (1024 SIMDs x cycles) = fp64-VALU-busy fraction.
+    The probe's first build launch is the process's first large kernel ("cold": clocks still high after idle), the second
+    follows ~0.2 s of MFMA work -- the situation of every launch inside the timed loop."""
+    rows = _pmc_pass(["SQ_BUSY_CYCLES", "SQ_INSTS_VALU"], n, d, device)
+    if rows is None:
+        return None
+    per = {}
+    for r in rows:
+        if kernel_substr in r["Kernel_Name"]:
+            e = per.setdefault(r["Dispatch_Id"], {"start": float(r["Start_Timestamp"]), "end": float(r["End_Timestamp"])})
+            e[r["Counter_Name"]] = float(r["Counter_Value"])
+    launches = [v for _, v in sorted(per.items(), key=lambda kv: kv[1]["start"]) if "SQ_BUSY_CYCLES" in v and "SQ_INSTS_VALU" in v]
+    if not launches:
+        return None
+    alg = 8.0 * (n * (n + 1) / 2 + n * d)
+    out = []
+    for v in launches:
+        ns = max(v["end"] - v["start"], 1.0)
+        cyc = v["SQ_BUSY_CYCLES"] / 32.0
+        out.append({"ms": ns * 1e-6, "shader_clock_ghz": cyc / ns, "fp64_valu_busy": v["SQ_INSTS_VALU"] * 4.0 / (1024.0 * cyc),
+                    "hbm_frac": alg / (ns * 1e-9) / 1e9 / HBM_PEAK_GBS})
+    return {"cold_first_launch": out[0], "after_mfma_work": out[-1], "launches": len(out),
+            "note": "one rocprofv3 --pmc SQ_BUSY_CYCLES SQ_INSTS_VALU pass over bench.py --pmc-probe (outside the timed region; "
+                    "profiled passes run at slightly lower clocks than the timed loop)"}
 
 
 def pmc_probe(n: int, d: int) -> None:
@@ -485,19 +542,29 @@ def main() -> None:
     # likelihood factored by all ranks together (1-D block-cyclic Cholesky, RCCL panel broadcast, entirely behind the C ABI
     # through gphip_create_rank).  Outside the timed region of the headline; reported as the `strong` sub-record.
     strong = None
+    strong_failed = False
     if dist is not None and not sharded and not args.no_strong:
         # Watchdog: this is the only place where the bench waits inside RCCL collectives of the library (real multi-rank
         # RCCL has only ever been exercised here).  If one does not return, the headline measured above must not be lost:
-        # after --strong-timeout seconds rank 0 prints the record with the failure noted and every rank leaves.
+        # after --strong-timeout seconds rank 0 prints the record with the failure noted and every rank leaves -- with a
+        # NON-ZERO exit code (a hung collective is a failure of the run, not a success).  Exactly one record is printed:
+        # the main thread and the watchdog both take `emit_lock` and check `emitted` before they print.
         import threading
+        emit_lock = threading.Lock()
+        emitted = [False]
 
         def give_up():
-            if rank == 0:
-                rec = record(None, None)
-                rec["strong"] = {"error": f"no result after {args.strong_timeout:.0f} s (a collective call did not return); "
-                                          "the headline above was measured before this series started"}
-                print(json.dumps(rec), flush=True)
-            os._exit(0)
+            with emit_lock:
+                if emitted[0]:
+                    return                                     # the series finished while the timer fired
+                emitted[0] = True
+                if rank == 0:
+                    rec = record(None, None)
+                    rec["strong"] = {"error": f"no result after {args.strong_timeout:.0f} s (a collective call did not return); "
+                                              "the headline above was measured before this series started"}
+                    rec["strong_speedup"] = rec["strong_ms_per_eval"] = rec["rccl_ranks"] = None
+                    print(json.dumps(rec), flush=True)
+                os._exit(3)
         dog = threading.Timer(args.strong_timeout + (0.0 if rank == 0 else 5.0), give_up)
         dog.daemon = True
         dog.start()
@@ -518,20 +585,32 @@ def main() -> None:
             dist.all_reduce(ts, op=dist.ReduceOp.MAX)
             ci = hs.comm_info()
             strong = {"what": f"ONE evaluation per step factored by all {world} ranks together (1-D block-cyclic Cholesky, one "
-                              "RCCL broadcast of the factored panel per 512-column step, gphip_create_rank)",
+                              "RCCL broadcast per tile column of the factored panel, gphip_create_rank)",
                       "scaling": "strong", "steps": 5, "ms_per_eval": float(ts.item()) / 5 * 1e3,
                       "evals_per_s": 5 / float(ts.item()), "speedup_vs_one_gpu_weak_step": (dt / args.steps) / (float(ts.item()) / 5),
                       "cholesky_tflops_total": n ** 3 / 3.0 * 5 / float(ts.item()) / 1e12,
                       "rccl_ranks": ci["world"], "comm": ci["comm"], "factor_bytes_per_rank": hs.factor_bytes(),
                       "all_ok": bool(all(v[1] == 0 and np.isfinite(v[0]) for v in sv))}
+            strong_failed = not strong["all_ok"]
             hs.close()
         except Exception as exc:                                    # never let the extra break the headline
             strong = {"error": repr(exc)}
+            strong_failed = True
         dog.cancel()
-
+        with emit_lock:
+            if emitted[0]:                                          # the watchdog got there first and is ending the process
+                time.sleep(60)
+            emitted[0] = True
 
     if rank == 0:
         out = record(strong, alone)
+        if world > 1 and not sharded:
+            # the split north_star names, next to the weak (theta-sharded) `value`: top-level so that a reader of the line
+            # does not mistake the by-construction weak number for it
+            ok = strong is not None and "error" not in strong
+            out["strong_speedup"] = strong["speedup_vs_one_gpu_weak_step"] if ok else None
+            out["strong_ms_per_eval"] = strong["ms_per_eval"] if ok else None
+            out["rccl_ranks"] = strong["rccl_ranks"] if ok else None
         if world == 1 and not args.no_extras and not args.no_live_pmc and args.mode == "theta":
             live = live_pmc_traffic(n, d, local_rank)
             if live is not None:
@@ -544,6 +623,31 @@ def main() -> None:
                     f"measured in this run: two child processes of this bench (bench.py --pmc-probe, 2 evaluations each) under "
                     f"rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, {live['launches']} launches averaged, {live['seconds']} s "
                     f"outside the timed region; committed profiles/ summary says {committed}")
+        if world == 1 and not args.no_extras and out.get("roofline_kbuild"):
+            # The build is a pure streaming WRITE of 4.3 GB: what the same box does with the plainest possible store stream of
+            # the same size (the runtime's own fill kernel behind Tensor.zero_()), measured here with HIP events, is the
+            # ceiling it runs against on THIS box -- the 8 TB/s of `peak` is the read-side headline figure.
+            try:
+                nbytes = int(out["roofline_kbuild"]["algorithmic_per_launch"])
+                buf = torch.empty(nbytes, dtype=torch.uint8, device=f"cuda:{local_rank}")
+                buf.zero_()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                best = 1e30
+                for _ in range(4):
+                    e0.record(); buf.zero_(); e1.record(); e1.synchronize()
+                    best = min(best, e0.elapsed_time(e1))
+                del buf
+                gbs = nbytes / (best * 1e-3) / 1e9
+                out["roofline_kbuild"]["store_ceiling"] = {
+                    "what": "fill kernel (Tensor.zero_) over the same number of bytes on this box, best of 4, HIP events",
+                    "achieved": gbs, "unit": "GB/s", "frac_of_peak": gbs / HBM_PEAK_GBS,
+                    "kbuild_frac_of_store_ceiling": out["roofline_kbuild"]["achieved"] / gbs}
+            except Exception as exc:                                # never let an extra break the headline
+                out["roofline_kbuild"]["store_ceiling"] = {"error": repr(exc)}
+        if world == 1 and not args.no_extras and not args.no_live_pmc and args.mode == "theta" and out.get("roofline_kbuild"):
+            clk = live_kbuild_clock(n, d, local_rank)
+            if clk is not None:
+                out["roofline_kbuild"]["clock_probe"] = clk
         if world == 1 and not args.no_extras:
             h.close()                                           # free the 8.7 GB workspace first
             out["other_configs"] = other_configs(local_rank)
@@ -553,6 +657,8 @@ def main() -> None:
     h.close()
     if dist is not None:
         dist.destroy_process_group()
+    if strong_failed:
+        sys.exit(3)                                                 # the record is out; the strong series failed: not a success
 
 
 if __name__ == "__main__":

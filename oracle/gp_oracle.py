@@ -136,11 +136,22 @@ def kernel_matrix(kernel: str, ell, sf: float, A: np.ndarray, B: np.ndarray) -> 
     differences (no |a|^2+|b|^2-2ab expansion: cancellation would cost the 1e-8 parity)."""
     A = np.asarray(A, dtype=np.float64) / ell
     B = np.asarray(B, dtype=np.float64) / ell
-    if A.shape[0] * B.shape[0] > _BLOCK_ELEMS:
+    if A.shape[0] * B.shape[0] > _BLOCK_ELEMS or (BUILD_THREADS > 1 and A.shape[0] >= 512):
         # large problems (golden scalars at N = 16384 / 32768, the bench's CPU baseline): the same arithmetic,
         # element for element, in row blocks so that the temporaries stay small next to the result
         out = np.empty((A.shape[0], B.shape[0]))
         step = max(1, _BLOCK_ELEMS // B.shape[0])
+        if BUILD_THREADS > 1:
+            # bench.py's cpu_baseline only: the row blocks on a thread pool (numpy's element-wise loops release the GIL).
+            # Every element goes through the same operations in the same order -- the matrix is bit-identical.
+            from concurrent.futures import ThreadPoolExecutor
+            step = max(1, min(step, -(-A.shape[0] // (4 * BUILD_THREADS))))
+
+            def block(i0):
+                out[i0:i0 + step] = _kernel_block(kernel, sf, A[i0:i0 + step], B)
+            with ThreadPoolExecutor(BUILD_THREADS) as pool:
+                list(pool.map(block, range(0, A.shape[0], step)))
+            return out
         for i0 in range(0, A.shape[0], step):
             out[i0:i0 + step] = _kernel_block(kernel, sf, A[i0:i0 + step], B)
         return out
@@ -148,6 +159,7 @@ def kernel_matrix(kernel: str, ell, sf: float, A: np.ndarray, B: np.ndarray) -> 
 
 
 _BLOCK_ELEMS = 1 << 26          # 512 MiB of fp64 per temporary
+BUILD_THREADS = 1               # > 1: kernel_matrix's row blocks run on a thread pool (set by bench.py's CPU baseline only)
 
 
 def _kernel_block(kernel: str, sf: float, A: np.ndarray, B: np.ndarray) -> np.ndarray:

@@ -24,7 +24,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run(tmp_name, extra, world=2, timeout=600):
+def _run(tmp_name, extra, world=2, timeout=600, want_rc=0):
     fake = build.build_fake_rccl()
     env = dict(os.environ, GPHIP_BENCH_BACKEND="gloo", GPHIP_RCCL_PATH=fake, FAKE_RCCL_SHM=f"/gphip_bench_{os.getpid()}_{tmp_name}",
                LD_LIBRARY_PATH="/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
@@ -32,7 +32,7 @@ def _run(tmp_name, extra, world=2, timeout=600):
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "2",
            "--warmup", "1", "--npoints", "4096"] + extra
     p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=timeout)
-    assert p.returncode == 0, (p.stdout + p.stderr)[-4000:]
+    assert (p.returncode == 0) == (want_rc == 0), (p.stdout + p.stderr)[-4000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, p.stdout[-2000:]                       # rank 0 prints ONE JSON line
     return json.loads(lines[0])
@@ -46,10 +46,14 @@ def test_two_ranks_weak_headline_and_strong_series():
     st = rec["strong"]
     assert "error" not in st, st
     assert st["scaling"] == "strong" and st["rccl_ranks"] == 2 and st["all_ok"] and st["ms_per_eval"] > 0
+    # the split north_star names is also readable at the top level, next to the weak headline
+    assert rec["rccl_ranks"] == 2 and rec["strong_ms_per_eval"] == st["ms_per_eval"] and rec["strong_speedup"] > 0
     assert "cpu_baseline" not in rec                                # rank 0 at N = 1 only
 
 
 def test_strong_series_watchdog_keeps_the_headline():
-    rec = _run("b", ["--strong-timeout", "0.001"])                 # the series cannot finish in 1 ms: the watchdog speaks
+    # the series cannot finish in 1 ms: the watchdog prints the ONE record and the job ends with a NON-ZERO exit code (a hung
+    # collective is not a success)
+    rec = _run("b", ["--strong-timeout", "0.001"], want_rc=3)
     assert rec["n_gpus"] == 2 and rec["value"] > 0
-    assert "no result after" in rec["strong"]["error"]
+    assert "no result after" in rec["strong"]["error"] and rec["strong_speedup"] is None
