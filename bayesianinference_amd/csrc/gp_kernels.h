@@ -1525,6 +1525,143 @@ __global__ __launch_bounds__(64 * NWI * NWJ, (NWI * NWJ == 4) ? 2 : 4) void gemm
 }
 
 // ---------------------------------------------------------------------------------------------
+// panel_rows: everything an outer panel [K0, K0 + nin) does to ONE tile row below its diagonal block, in one workgroup
+// (batches of thetas, round 4).  The multi-kernel panel factorisation touches every tile of the panel twice per column step
+// -- in-panel update (read C, read the row's earlier X tiles, write C), then the solve (read C, write X): 22 tile transfers
+// per row of a 4-column panel at K = 128 per pass, i.e. ~8 flop per HBM byte, and a batch of 200 thetas does not fit any
+// cache: those launches ran at 25-30 TFLOP/s, 45 % of a batch's time for 23 % of its flops.  Here the diagonal block of the
+// panel (its L tiles and W_b = L_bb^-1) is factored first for all slots (small launches), and then one workgroup per
+// (row tile, slot) walks the columns b = 0 .. nin - 1:
+//     acc = C(i, b);   acc -= sum_{a < b} X(i, a) L(b, a)^T     (one pipelined pass over the b slabs)
+//     pre-solve tile -> memory (it has to become an MFMA operand);   X(i, b) = pre W_b^T;   X(i, b) -> memory
+// Each C tile is read from HBM once and each X tile written once (4 + 4 transfers per row instead of 22); the earlier X tiles
+// of the row and the pre-solve tile come back through the L2 this workgroup has just written them to, L and W of the
+// diagonal block are shared by every row of the slot.  Same arithmetic in the same order as the launches it replaces
+// (left-looking in-panel update with K = 128 b, then the explicit-inverse solve): results are bit-identical.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+struct PanelRowsArgs {
+    T* A; long bstride;            // packed tile-major workspace (slot 0), elements between slots
+    int R;                         // tile rows of the workspace
+    int K0, nin;                   // the panel's tile columns
+    const T* W; long w_bstride;    // W_b blocks: [slot][tile column][128 x 128]
+    int r_first;                   // first tile row of this launch (K0 + nin); blockIdx.x counts rows from there
+};
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void panel_rows_kernel(PanelRowsArgs<T> g) {
+    constexpr int FI = 4, FJ = 4, WT = 64;
+    extern __shared__ double smem_raw[];
+    T* smem = reinterpret_cast<T*>(smem_raw);
+    typedef typename Num<T>::acc_t acc_t;
+    constexpr int GK = Num<T>::GK;
+    constexpr int STAGE = STAGE_BYTES / (int)sizeof(T);
+    constexpr int JOFF = STAGE / 2;
+    constexpr bool F64 = sizeof(T) == 8;
+    constexpr int SPB = TB / GK;                            // LDS stages per 128-wide slab
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wi = wave & 1, wj = wave >> 1;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int uw = __builtin_amdgcn_readfirstlane(wave);
+    const int slot = blockIdx.y, ti = g.r_first + blockIdx.x;
+    T* As = g.A + (long)slot * g.bstride;
+    const T* Ws = g.W + (long)slot * g.w_bstride;
+    auto tptr = [&](int ti_, int tj_) -> T* { return As + tile_index(ti_, tj_, g.R) * TS; };
+    acc_t acc[FJ][FI];
+    auto c_ptr = [&](T* base) { return base + (long)(wj * WT) * TB + wi * WT + l15; };
+    auto load_c = [&](const T* base) {
+        const T* cp = c_ptr(const_cast<T*>(base));
+#pragma unroll
+        for (int x = 0; x < FJ; ++x)
+#pragma unroll
+            for (int y = 0; y < FI; ++y)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[x][y][r] = cp[(long)(x * 16 + Num<T>::drow(l4, r)) * TB + y * 16];
+    };
+    // write-through (agent scope) stores: the tile is re-read by this workgroup's own LDS-DMA a moment later
+    auto store_c = [&](T* base) {
+        T* cp0 = c_ptr(base);
+#pragma unroll
+        for (int x = 0; x < FJ; ++x)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                T* cp = cp0 + (long)(x * 16 + Num<T>::drow(l4, r)) * TB;
+#pragma unroll
+                for (int y = 0; y < FI; ++y) __hip_atomic_store(cp + y * 16, acc[x][y][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+    };
+    // acc (+/-)= I J^T over nslab 128-wide slabs: slab s reads I from tile (ti, K0 + s) and J from Jtile(s) (column-major,
+    // leading dimension 128 both).  LDS-DMA double buffer as in gemm_nt.
+    auto run = [&](int nslab, bool negate, auto itile, auto jtile) {
+        const int nk = nslab * SPB;
+        auto stage = [&](int kb, int st) {
+            T* Is = smem + st * STAGE;
+            T* Js = Is + JOFF;
+            const int sl = kb / SPB;
+            const long o = (long)(kb % SPB) * GK * TB;
+            const T* Ig = itile(sl) + o;
+            const T* Jg = jtile(sl) + o;
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) {
+                const int qq = uw + 4 * s2;
+                if (F64) {
+                    __builtin_amdgcn_global_load_lds((glb_void*)(Ig + (long)qq * TB + 2 * lane), (lds_void*)(Is + qq * LDT), 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds((glb_void*)(Jg + (long)qq * TB + 2 * lane), (lds_void*)(Js + qq * LDT), 16, 0, 0);
+                } else {
+                    const long kcol = 4 * (qq >> 1) + (qq & 1) + 2 * (lane >> 5);
+                    const int row = 4 * (lane & 31);
+                    __builtin_amdgcn_global_load_lds((glb_void*)(Ig + kcol * TB + row), (lds_void*)(Is + qq * LDP), 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds((glb_void*)(Jg + kcol * TB + row), (lds_void*)(Js + qq * LDP), 16, 0, 0);
+                }
+            }
+        };
+        stage(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int kb = 0; kb < nk; ++kb) {
+            const int cur = kb & 1;
+            if (kb + 1 < nk) stage(kb + 1, cur ^ 1);
+            const T* Is = smem + cur * STAGE + wi * WT + l15;
+            const T* Js = smem + cur * STAGE + JOFF + wj * WT + l15;
+#pragma unroll
+            for (int kk = 0; kk < GK / 4; ++kk) {
+                const int k = 4 * kk + l4;
+                T fi[FI], fj[FJ];
+#pragma unroll
+                for (int f = 0; f < FI; ++f) fi[f] = Is[lds_off<T>(k, f * 16)];
+#pragma unroll
+                for (int f = 0; f < FJ; ++f) fj[f] = negate ? -Js[lds_off<T>(k, f * 16)] : Js[lds_off<T>(k, f * 16)];
+#pragma unroll
+                for (int x = 0; x < FJ; ++x)
+#pragma unroll
+                    for (int y = 0; y < FI; ++y) acc[x][y] = Num<T>::mfma(fj[x], fi[y], acc[x][y]);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    };
+    for (int b = 0; b < g.nin; ++b) {
+        T* Cb = tptr(ti, g.K0 + b);
+        if (b > 0) {
+            load_c(Cb);
+            run(b, true, [&](int s) { return (const T*)tptr(ti, g.K0 + s); }, [&](int s) { return (const T*)tptr(g.K0 + b, g.K0 + s); });
+            store_c(Cb);                                    // the pre-solve tile
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+#pragma unroll
+        for (int x = 0; x < FJ; ++x)
+#pragma unroll
+            for (int y = 0; y < FI; ++y) acc[x][y] = (acc_t){0, 0, 0, 0};
+        const T* Wb = Ws + (long)(g.K0 + b) * TB * TB;
+        run(1, false, [&](int) { return (const T*)Cb; }, [&](int) { return Wb; });
+        store_c(Cb);                                        // X(i, b)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // chol_dataflow: the whole bordered Cholesky of small / mid problems in ONE launch.
 //
 // The multi-kernel schedule above is bound, below N ~ 8k, by the serial chain of dependent launches
@@ -2129,7 +2266,7 @@ __global__ void finalize_kernel(const T* __restrict__ Abase, long bstride, long 
                                 const double* __restrict__ partial, int nt, double* __restrict__ res,
                                 const int* __restrict__ info = nullptr, const int* __restrict__ abort_flag = nullptr,
                                 double* __restrict__ hres = nullptr, int* __restrict__ hinfo = nullptr,
-                                int pstride = 0, const double* __restrict__ partial2 = nullptr, int n2 = 0) {
+                                int pstride = 0, const double* __restrict__ partial2 = nullptr, int n2 = 0, int abort_at = -1) {
     // partial: nt entries per slot at stride pstride (0 = nt); partial2 (optional): n2 more entries per slot,
     // stride n2 -- the 64-blocks of a dataflow tail that followed a multi-kernel bulk
     const int slot = blockIdx.x;
@@ -2146,7 +2283,7 @@ __global__ void finalize_kernel(const T* __restrict__ Abase, long bstride, long 
             hres[slot * 2 + 0] = logdet;
             hres[slot * 2 + 1] = quad;
             hinfo[slot] = info[slot];
-            if (slot == 0) hinfo[gridDim.x] = *abort_flag;
+            if (slot == 0) hinfo[abort_at >= 0 ? abort_at : (int)gridDim.x] = *abort_flag;   // (abort_at: this launch covers a slot sub-range)
         }
     }
 }

@@ -74,6 +74,15 @@ struct gphip_ctx {
     hipStream_t chain_stream = nullptr, bulk_stream = nullptr;
     int split_streams_for = 0;                   // reserved CUs per XCD the two masked streams were created for
     unsigned long long ticket_base2 = 0;         // chain launch's own ticket counter (dTicket + DF_TICKET2)
+    // Phase-shifted batch groups (eval_chunk): a large theta batch is cut into `batch_groups` slot ranges, each factored on its
+    // own (main, panel) stream pair and started one phase after the previous one, so that a group's kernel build / outer
+    // panel 0 / last panels -- latency-shaped, nothing of its own to hide behind -- run under another group's trailing SYRKs.
+    int batch_groups = 1, batch_group_min = 48;   // 1 = off (measured: no gain, the batch is throughput bound), -1 auto, n groups
+    int panel_rows = 0;                           // (measured: bit-identical, 2 % slower -- off) batches: rows below a panel's diagonal block handled by panel_rows_kernel
+    std::vector<hipStream_t> grp_streams;         // [2 g], [2 g + 1] = main / panel stream of group g >= 1
+    std::vector<hipEvent_t> grp_events;           // dedicated events (the sync_events pool is recycled inside queue_factor)
+    hipEvent_t* stagger_out = nullptr;            // queue_factor: record "outer panel 0 is factored" here (panel stream)
+    int final_abort_at = -1;                      // launch_finalize: where (relative to hInfo) the abort word goes when the launch covers a slot sub-range
     int build_overlap = 0;                       // option: factor panel 0 under the rest of the kernel build (measured: -0.1 % per
                                                  // evaluation, but the build itself slows 4-15 % while it shares the chip: off)
     bool own_streams = true;
@@ -635,6 +644,30 @@ int queue_panel(gphip_ctx* h, int K0, int nin, int nslots, bool first_factored =
     // registers halve the resident waves of what are then BIG update launches (200 x N=4096: 86 -> 91 ms): not there.
     const bool fuse = h->fuse_potrf && nslots <= 8;
     bool factored = first_factored;
+    // Batches (option "panel_rows", default on): the diagonal block of the panel first -- the same launches restricted to its
+    // own tile rows -- then ONE launch in which a workgroup takes a whole tile row below it through all nin columns
+    // (panel_rows_kernel: each C tile read once, each X tile written once; bit-identical results).
+    if (h->panel_rows && left && nslots > h->dataflow_max_slots && !h->col_events && !first_factored && K0 + nin <= Nt) {
+        const int rend = K0 + nin;
+        for (int s = 0; s < nin; ++s) {
+            const int b = K0 + s;
+            if (s > 0) launch_gemm<T>(h, 3, tl<T>(h), tl<T>(h, K0), tl<T>(h, K0), s * TB, b, rend, b, b + 1, 1, nslots, 0, 0, Nt);
+            {
+                ProfScope ps(h, 1, 2.0 * TB * TB * TB / 3.0 * nslots, 0.0);
+                hipLaunchKernelGGL(potrf128_kernel<T>, dim3(nslots), dim3(256), potrf_lds<T>(), h->cs, A, bs, b, W,
+                                   h->dPartial, Nt, h->dInfo, h->dSlotp);
+            }
+            if (b + 1 < rend)
+                launch_gemm<T>(h, 2, tl<T>(h), tl<T>(h, b), wb<T>(W, b, lrs), TB, b + 1, rend, b, b + 1, 0, nslots, 1, 0, Nt);
+        }
+        PanelRowsArgs<T> pr{};
+        pr.A = A; pr.bstride = bs; pr.R = R; pr.K0 = K0; pr.nin = nin; pr.W = W; pr.w_bstride = lrs; pr.r_first = rend;
+        const int rows = R - rend;                                     // (>= 1: the rhs tile row)
+        const double prods = (double)nin * (nin + 1) / 2.0;            // K = 128 products per row: nin solves + nin (nin - 1) / 2 updates
+        ProfScope ps(h, 3, 2.0 * TB * TB * TB * prods * rows * nslots, (double)sizeof(T) * 2.0 * TB * TB * nin * rows * nslots);
+        hipLaunchKernelGGL(panel_rows_kernel<T>, dim3((unsigned)rows, (unsigned)nslots), dim3(256), GEMM_LDS, h->cs, pr);
+        return 0;
+    }
     for (int s = 0; s < nin; ++s) {
         const int b = K0 + s;
         if (left && s > 0) {
@@ -719,6 +752,7 @@ template <typename T, int TBX, int OCC = 2, int NST = 2, bool BUILD = false>
 void launch_dataflow(gphip_ctx* h, int nslots, int c0 = 0, double* part = nullptr, long pstride = 0) {
     const int nd = (int)(h->Npad / TBX) - c0, R = nd + 1;
     const long tasks = (long)R * (R + 1) / 2 * nslots;
+    if (getenv("GPHIP_DEBUG")) fprintf(stderr, "gphip debug: launch_dataflow TBX=%d nslots=%d c0=%d tasks=%ld\n", TBX, nslots, c0, tasks);
     DfArgs<T> g{};
     g.A = (T*)h->dA; g.bstride = h->slot_elems; g.R128 = (int)h->R; g.c0 = c0;
     g.W = (T*)h->dW + (long)c0 * TBX * TBX; g.w_bstride = (long)h->Nt * TB * TB;
@@ -789,7 +823,7 @@ template <typename T>
 void launch_finalize(gphip_ctx* h, int nslots, int nparts, int pstride = 0, const double* part2 = nullptr, int n2 = 0) {
     hipLaunchKernelGGL(finalize_kernel<T>, dim3(nslots), dim3(64), 0, h->stream, (const T*)h->dA, (long)h->slot_elems,
                        (long)(h->slot_elems - TS), h->dPartial, nparts, h->dRes, (const int*)h->dInfo,
-                       (const int*)reinterpret_cast<int*>(h->dTicket + 1), h->hRes, h->hInfo, pstride, part2, n2);
+                       (const int*)reinterpret_cast<int*>(h->dTicket + 1), h->hRes, h->hInfo, pstride, part2, n2, h->final_abort_at);
 }
 
 template <typename T>
@@ -881,7 +915,7 @@ int queue_factor(gphip_ctx* h, int nslots) {
             trailing(k, k0(k + 1), R, 4);
         }
     } else {
-        if (!built0) h->sync_used = 0;          // (the split build took the first event of this evaluation)
+        if (!built0 && !h->stagger_out) h->sync_used = 0;   // (the split build took the first event of this evaluation; batch groups: one pool for all groups)
         hipEvent_t built = sync_event(h);
         HIPCHK(hipEventRecord(built, h->stream));
         HIPCHK(hipStreamWaitEvent(h->pstream, built0 ? built0 : built, 0));
@@ -889,6 +923,7 @@ int queue_factor(gphip_ctx* h, int nslots) {
         queue_panel<T>(h, 0, k0(1), nslots);
         hipEvent_t ev_panel = sync_event(h);
         HIPCHK(hipEventRecord(ev_panel, h->pstream));
+        if (h->stagger_out) HIPCHK(hipEventRecord(*h->stagger_out, h->pstream));   // the next batch group may start its build now
         hipEvent_t ev_rest = nullptr, ev_rest2 = nullptr;
         // tail: once only `dataflow_tail` tile columns are left the dataflow kernel finishes the job in one
         // launch -- the last panels are chain bound, the regime the dataflow schedule wins
@@ -904,6 +939,7 @@ int queue_factor(gphip_ctx* h, int nslots) {
                 if (ev_rest2) HIPCHK(hipStreamWaitEvent(h->stream, ev_rest2, 0));
                 trailing(k, k0(k + 1), R, 4);
                 const int rem = Nt - k0(kc);                       // tile columns left
+                if (rem == 0) break;                               // (no tail: this was the last panel -- batches, or dataflow_tail off)
                 if constexpr (sizeof(T) == 8) {
                     if (2 * rem <= Nt) {                           // 64-tiles: the faster chain; its 2 rem block partials
                         tail_part = h->dPartial + (long)h->slots * Nt;         // live behind the 128-block list
@@ -1182,6 +1218,99 @@ int null_kernel_batch(gphip_ctx* h, const double* Theta, int B, double* out, dou
     return GPHIP_OK;
 }
 
+// ---- phase-shifted batch groups -------------------------------------------------------------------------------------
+// Every per-slot array of the context addressed from slot s0 on (the launch helpers index slots from the context's base
+// pointers, blockIdx.y = slot): a group of a batch is then queued with the ordinary single-range code.
+struct SlotShift {
+    gphip_ctx* h;
+    void *dA, *dXs, *dXs2, *dW, *dPwMean, *dPwNug;
+    double *dInvEll, *dInvEll2, *dSlotp, *dPartial, *dRes, *hRes;
+    int *dInfo, *hInfo;
+    hipStream_t stream, pstream;
+    SlotShift(gphip_ctx* h_, int s0, hipStream_t ms, hipStream_t ps) : h(h_) {
+        dA = h->dA; dXs = h->dXs; dXs2 = h->dXs2; dW = h->dW; dPwMean = h->dPwMean; dPwNug = h->dPwNug;
+        dInvEll = h->dInvEll; dInvEll2 = h->dInvEll2; dSlotp = h->dSlotp; dPartial = h->dPartial; dRes = h->dRes; hRes = h->hRes;
+        dInfo = h->dInfo; hInfo = h->hInfo; stream = h->stream; pstream = h->pstream;
+        auto sh = [&](void* p, size_t bytes_per_slot) -> void* { return p ? static_cast<char*>(p) + (size_t)s0 * bytes_per_slot : nullptr; };
+        h->dA = sh(dA, (size_t)h->slot_elems * h->es);
+        h->dXs = sh(dXs, (size_t)h->d * h->Npad * h->es);
+        h->dXs2 = sh(dXs2, (size_t)h->d * h->Npad * h->es);
+        h->dW = sh(dW, (size_t)h->Nt * TB * TB * h->es);
+        h->dPwMean = sh(dPwMean, (size_t)h->Npad * h->es);
+        h->dPwNug = sh(dPwNug, (size_t)h->Npad * h->es);
+        h->dInvEll = (double*)sh(dInvEll, (size_t)h->d * 8);
+        h->dInvEll2 = (double*)sh(dInvEll2, (size_t)h->d * 8);
+        h->dSlotp = (double*)sh(dSlotp, (size_t)SLOTP * 8);
+        h->dPartial = (double*)sh(dPartial, (size_t)h->Nt * 8);
+        h->dRes = (double*)sh(dRes, 16);
+        h->hRes = (double*)sh(hRes, 16);
+        h->dInfo = (int*)sh(dInfo, 4);
+        h->hInfo = (int*)sh(hInfo, 4);
+        h->stream = ms; h->pstream = ps; h->cs = ms;
+    }
+    ~SlotShift() {
+        h->dA = dA; h->dXs = dXs; h->dXs2 = dXs2; h->dW = dW; h->dPwMean = dPwMean; h->dPwNug = dPwNug;
+        h->dInvEll = dInvEll; h->dInvEll2 = dInvEll2; h->dSlotp = dSlotp; h->dPartial = dPartial; h->dRes = dRes; h->hRes = hRes;
+        h->dInfo = dInfo; h->hInfo = hInfo; h->stream = stream; h->pstream = pstream; h->cs = stream;
+    }
+};
+
+// how many groups for a batch of nb thetas: only the throughput-bound multi-kernel look-ahead schedule has exposed phases
+// worth hiding (a dataflow launch is one kernel; a sharded evaluation has its own schedule)
+int batch_group_count(const gphip_ctx* h, int nb) {
+    if (h->batch_groups == 0 || h->batch_groups == 1) return 1;
+    if (h->fused_eval || h->theta_packed || !h->lookahead || h->dist_world > 0 || use_dataflow(h, nb)) return 1;
+    if ((int)((h->Nt + h->panel - 1) / h->panel) < 3) return 1;                    // needs a few outer panels to pipeline
+    int G = h->batch_groups > 0 ? h->batch_groups : (nb >= 4 * h->batch_group_min ? 3 : 2);
+    while (G > 1 && nb / G < h->batch_group_min) --G;
+    // the dataflow kernels share ONE ticket counter / flag array per context: concurrent groups must never reach the dataflow
+    // tail of the look-ahead schedule (taken by calls of <= dataflow_max_slots thetas)
+    while (G > 1 && h->dataflow && nb / G <= h->dataflow_max_slots) --G;
+    if (G > 1 && use_dataflow(h, (nb + G - 1) / G)) return 1;                      // (the groups must run the same schedule)
+    return G;
+}
+
+int queue_batch_groups(gphip_ctx* h, int nb, int G) {
+    while ((int)h->grp_streams.size() < 2 * G) {                                    // (entries 0, 1 stay null: group 0 runs on the handle's own pair)
+        hipStream_t st = nullptr;
+        if (h->grp_streams.size() >= 2) {
+            int least = 0, greatest = 0;
+            (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+            HIPCHK(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, (h->grp_streams.size() & 1) ? greatest : least));
+        }
+        h->grp_streams.push_back(st);
+    }
+    while ((int)h->grp_events.size() < 2 * G + 1) {
+        hipEvent_t e = nullptr;
+        HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        h->grp_events.push_back(e);
+    }
+    hipStream_t main0 = h->stream, panel0 = h->pstream;
+    hipEvent_t ready = h->grp_events[(size_t)2 * G];
+    h->sync_used = 0;
+    HIPCHK(hipEventRecord(ready, main0));                                           // thetas uploaded, info words cleared
+    ProfScope ps(h, 5, 0.0, 0.0);
+    for (int g = 0; g < G; ++g) {
+        const int s0 = (int)((long)nb * g / G), s1 = (int)((long)nb * (g + 1) / G);
+        hipStream_t ms = g == 0 ? main0 : h->grp_streams[(size_t)2 * g], pst = g == 0 ? panel0 : h->grp_streams[(size_t)2 * g + 1];
+        SlotShift shift(h, s0, ms, pst);
+        if (g > 0) {
+            HIPCHK(hipStreamWaitEvent(ms, ready, 0));
+            HIPCHK(hipStreamWaitEvent(ms, h->grp_events[(size_t)2 * (g - 1)], 0));  // previous group: outer panel 0 factored
+        }
+        h->stagger_out = &h->grp_events[(size_t)2 * g];
+        h->final_abort_at = nb - s0;
+        int rc = DISPATCH(h, queue_build, h, s1 - s0, true);
+        if (rc == 0) rc = DISPATCH(h, queue_factor, h, s1 - s0);
+        h->stagger_out = nullptr;
+        h->final_abort_at = -1;
+        if (rc) return rc;
+        if (g > 0) HIPCHK(hipEventRecord(h->grp_events[(size_t)2 * g + 1], ms));     // group finished (its finalize is queued)
+    }
+    for (int g = 1; g < G; ++g) HIPCHK(hipStreamWaitEvent(main0, h->grp_events[(size_t)2 * g + 1], 0));
+    return GPHIP_OK;
+}
+
 // s0: index of the chunk's first theta within the call (rows of the call's point-dependent nugget / mean arrays)
 int eval_chunk(gphip_ctx* h, const double* Theta, int nb, double* out, double* parts, int* info, int s0 = 0) {
     std::vector<char> okv(nb);
@@ -1205,7 +1334,11 @@ int eval_chunk(gphip_ctx* h, const double* Theta, int nb, double* out, double* p
     h->fused_eval = h->fuse_option && h->theta_packed && h->kt != 2 && h->dtype == 64 && !h->want_w && h->profile < 2 &&
                     !h->pw_mean_on && !h->pw_nug_on && use_dataflow(h, nb) && h->Nt <= h->dataflow_fine_nt;
     h->cs = h->stream;
-    {
+    const int G = batch_group_count(h, nb);
+    if (G > 1) {
+        const int rc = queue_batch_groups(h, nb, G);
+        if (rc) return rc;
+    } else {
         ProfScope ps(h, 5, 0.0, 0.0);
         if (!h->fused_eval) DISPATCH(h, queue_build, h, nb, true);
         DISPATCH(h, queue_factor, h, nb);
@@ -1216,6 +1349,11 @@ int eval_chunk(gphip_ctx* h, const double* Theta, int nb, double* out, double* p
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipGetLastError());
     harvest(h);
+    if (h->hInfo[nb] != 0 && getenv("GPHIP_DEBUG")) {
+        fprintf(stderr, "gphip debug: nb=%d G=%d hInfo[nb]=%d slots=%d; hInfo[0..]:", nb, G, h->hInfo[nb], h->slots);
+        for (int i = 0; i <= nb && i < 80; ++i) fprintf(stderr, " %d", h->hInfo[i]);
+        fprintf(stderr, "\n");
+    }
     if (h->hInfo[nb] != 0) {                   // a dataflow dependency wait hit its spin limit: results are void
         HIPCHK(hipMemsetAsync(h->dTicket + 1, 0, 8 + DF_PARK_SLOTS * 4, h->stream));
         return fail(h, GPHIP_ERR_HIP, "dataflow Cholesky schedule timed out (set option dataflow=0 and report)");
@@ -1276,6 +1414,8 @@ int set_func_attrs(gphip_ctx* h) {
     }
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trtri128_kernel<T>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)potrf_lds<T>()));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(panel_rows_kernel<T>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS));
     if (h->kt == 2) {                          // general covariance form: both terms' row and column points in LDS
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>((kbuild_kernel<T, 0, 2>)),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * h->d * TB * sizeof(T))));
@@ -1852,6 +1992,8 @@ int gphip_destroy(gphip_handle h) {
     for (auto e : h->pool) (void)hipEventDestroy(e);
     for (auto e : h->sync_events) (void)hipEventDestroy(e);
     if (h->stream2) { (void)hipStreamSynchronize(h->stream2); (void)hipStreamDestroy(h->stream2); }
+    for (hipStream_t st : h->grp_streams) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+    for (hipEvent_t e : h->grp_events) (void)hipEventDestroy(e);
     if (h->chain_stream) (void)hipStreamDestroy(h->chain_stream);
     if (h->bulk_stream) (void)hipStreamDestroy(h->bulk_stream);
     if (h->own_streams) {
@@ -2809,7 +2951,7 @@ int* option_slot(gphip_ctx* h, const char* name) {
         {"dataflow", &gphip_ctx::dataflow}, {"dataflow_max_nt", &gphip_ctx::dataflow_max_nt},
         {"dataflow_max_slots", &gphip_ctx::dataflow_max_slots}, {"dataflow_fine_nt", &gphip_ctx::dataflow_fine_nt},
         {"dataflow_tail", &gphip_ctx::dataflow_tail}, {"grad_potri", &gphip_ctx::grad_potri},
-        {"fused_eval", &gphip_ctx::fuse_option}, {"panel_left", &gphip_ctx::panel_left}, {"build_overlap", &gphip_ctx::build_overlap}, {"dataflow_lds_kib", &gphip_ctx::dataflow_lds_kib}, {"dataflow_park", &gphip_ctx::dataflow_park}, {"fuse_potrf", &gphip_ctx::fuse_potrf}, {"bcast_chunks", &gphip_ctx::bcast_chunks}, {"dataflow_occ3", &gphip_ctx::dataflow_occ3}, {"df_split", &gphip_ctx::df_split}, {"df_split_lds_kib", &gphip_ctx::df_split_lds_kib}, {"df_split_min_tasks", &gphip_ctx::df_split_min_tasks}, {"df_split_auto", &gphip_ctx::df_split_auto},
+        {"fused_eval", &gphip_ctx::fuse_option}, {"panel_left", &gphip_ctx::panel_left}, {"build_overlap", &gphip_ctx::build_overlap}, {"dataflow_lds_kib", &gphip_ctx::dataflow_lds_kib}, {"dataflow_park", &gphip_ctx::dataflow_park}, {"fuse_potrf", &gphip_ctx::fuse_potrf}, {"bcast_chunks", &gphip_ctx::bcast_chunks}, {"dataflow_occ3", &gphip_ctx::dataflow_occ3}, {"batch_groups", &gphip_ctx::batch_groups}, {"panel_rows", &gphip_ctx::panel_rows}, {"batch_group_min", &gphip_ctx::batch_group_min}, {"df_split", &gphip_ctx::df_split}, {"df_split_lds_kib", &gphip_ctx::df_split_lds_kib}, {"df_split_min_tasks", &gphip_ctx::df_split_min_tasks}, {"df_split_auto", &gphip_ctx::df_split_auto},
         {"max_slots", &gphip_ctx::max_slots}, {"shard_min_n", &gphip_ctx::shard_min_n},
         {"thin_tiles", &gphip_ctx::thin_tiles}, {"panel_wide", &gphip_ctx::panel_wide},
         {"la_main", &gphip_ctx::la_main}, {"rest_split", &gphip_ctx::rest_split},

@@ -120,6 +120,15 @@ def test_cfg5_matern52_n65536_d16_fp32_predict_10k_against_fp64_path():
         assert close(qd64, float(gold["quad"]), n, 1e-8)
         assert close(ll32, float(gold["loglik"]), n, 1e-3) and close(ld32, float(gold["logdet"]), n, 1e-3)
         assert close(qd32, float(gold["quad"]), n, 1e-3)
+        # ... and the PREDICTION (BGP:396-422) at cfg 5's own size: the oracle's mu*, sigma* from the same LU at the first 64 of
+        # the 10 000 test points -- fp64 HIP at 1e-7, fp32 HIP at the stated 1e-3 (round 3 compared HIP with HIP here)
+        if "mu" in gold.files:
+            k = len(gold["mu"])
+            np.testing.assert_allclose(gold["Xs"], Xs[:k])
+            np.testing.assert_allclose(mu64[:k], gold["mu"], rtol=1e-7, atol=1e-9)
+            np.testing.assert_allclose(np.sqrt(var64[:k]), gold["sd"], rtol=1e-7)
+            np.testing.assert_allclose(mu32[:k], gold["mu"], rtol=1e-3, atol=1e-3)
+            np.testing.assert_allclose(np.sqrt(var32[:k]), gold["sd"], rtol=1e-3)
     # stated fp32 tolerance: 1e-3 relative
     assert abs(ld32 - ld64) <= 1e-3 * max(abs(ld64), n)
     assert abs(qd32 - qd64) <= 1e-3 * max(abs(qd64), n)
