@@ -17,6 +17,7 @@
 // argument count -> LIBRARY_FUNCTION_ERROR; wrong tensor rank -> LIBRARY_RANK_ERROR.
 #include <algorithm>
 #include <limits>
+#include <cmath>
 #include <vector>
 
 #include "WolframLibrary.h"
@@ -424,6 +425,85 @@ EXTERN_C DLLEXPORT int gphip_wl_nested_sampling(WolframLibraryData lib, mint arg
     int64_t n = 0, ne = 0;
     double z = 0.0;
     int rc = gphip_nested_sampling(h, lib->MTensor_getRealData(box), kd.data(), nullptr, nullptr, &opt, start, cap, pts.data(), ll.data(),
+                                   lp.data(), ar.data(), &n, &z, &ne);
+    if (rc != GPHIP_OK) return status_to_wl(rc);
+    MTensor r; mint d[2] = {(mint)n, (mint)p + 3};
+    if (lib->MTensor_new(MType_Real, 2, d, &r)) return LIBRARY_FUNCTION_ERROR;
+    double* out = lib->MTensor_getRealData(r);
+    for (int64_t i = 0; i < n; ++i) {
+        for (int j = 0; j < p; ++j) out[i * (p + 3) + j] = pts[(size_t)(i * p + j)];
+        out[i * (p + 3) + p] = ll[(size_t)i];
+        out[i * (p + 3) + p + 1] = lp[(size_t)i];
+        out[i * (p + 3) + p + 2] = ar[(size_t)i];
+    }
+    MArgument_setMTensor(res, r);
+    return LIBRARY_NO_ERROR;
+}
+
+// ---- any SEPARABLE prior for the native sampler (BayesianStatistics.wl:256-274: "LogPriorPDFFunction" of a
+// ProductDistribution of univariate distributions -- Normal, LogNormal, Gamma, .. -- is the sum of the factors' log densities).
+// The WL package tabulates each factor's log density on a uniform grid over the parameter's {min, max} (paramSpecPattern,
+// BS:19) and draws the starting pool itself (RandomVariate[prior, pool], BS:1046-1068); the library's C ABI takes the prior
+// as its gphip_logprior_fn callback -- implemented HERE by interpolating the tables (4-point Lagrange, error O(h^4)).
+namespace {
+struct TabPrior { int p; mint m; const double* box; const double* tab; };
+double tab_logprior(const double* th, int p, void* user) {
+    const TabPrior* t = static_cast<const TabPrior*>(user);
+    double s = 0.0;
+    for (int j = 0; j < p; ++j) {
+        const double lo = t->box[2 * j], hi = t->box[2 * j + 1];
+        const double u = (th[j] - lo) / (hi - lo) * (double)(t->m - 1);
+        mint i = (mint)std::floor(u);
+        if (i < 1) i = 1;
+        if (i > t->m - 3) i = t->m - 3;
+        const double x = u - (double)i;                       // nodes at -1, 0, 1, 2 relative to i
+        const double* f = t->tab + (size_t)j * t->m + (i - 1);
+        auto zero = [](double v) { return !(v > -1e290); };      // -1e300 (or NaN / -inf) marks a zero of the density
+        if (zero(f[0]) || zero(f[1]) || zero(f[2]) || zero(f[3])) {
+            // next to a zero of the density (log = -inf): no polynomial through it -- the nearer node decides
+            const double v = f[1 + (x > 0.5 ? 1 : 0)];
+            if (zero(v)) return -INFINITY;
+            s += v;
+            continue;
+        }
+        s += -x * (x - 1.0) * (x - 2.0) / 6.0 * f[0] + (x + 1.0) * (x - 1.0) * (x - 2.0) / 2.0 * f[1] -
+             (x + 1.0) * x * (x - 2.0) / 2.0 * f[2] + (x + 1.0) * x * (x - 1.0) / 6.0 * f[3];
+    }
+    return s;
+}
+}  // namespace
+
+// gphip_wl_nested_sampling_tab[h, box (p x 2), logPriorTables (p x m, m >= 4: log density of factor j at the m grid nodes of
+//   [min_j, max_j]), opts (as gphip_wl_nested_sampling), start (pool x p, REQUIRED: drawn from the prior by the caller)]
+//   -> n x (p + 3) rows as gphip_wl_nested_sampling
+EXTERN_C DLLEXPORT int gphip_wl_nested_sampling_tab(WolframLibraryData lib, mint argc, MArgument* args, MArgument res) {
+    if (argc != 5) return LIBRARY_FUNCTION_ERROR;
+    gphip_handle h = lookup(MArgument_getInteger(args[0]));
+    MTensor box = MArgument_getMTensor(args[1]), tab = MArgument_getMTensor(args[2]), ov = MArgument_getMTensor(args[3]),
+            st = MArgument_getMTensor(args[4]);
+    if (!h) return LIBRARY_FUNCTION_ERROR;
+    if (int e = want_real(lib, box, 2)) return e;
+    if (int e = want_real(lib, tab, 2)) return e;
+    if (int e = want_real(lib, ov, 1)) return e;
+    if (int e = want_real(lib, st, 2)) return e;
+    int p = 0;
+    gphip_num_params(h, &p);
+    const mint m = lib->MTensor_getDimensions(tab)[1];
+    if (lib->MTensor_getDimensions(box)[0] != p || lib->MTensor_getDimensions(box)[1] != 2 || lib->MTensor_getDimensions(tab)[0] != p ||
+        m < 4 || lib->MTensor_getDimensions(ov)[0] != 9 || lib->MTensor_getDimensions(st)[1] != p)
+        return LIBRARY_DIMENSION_ERROR;
+    const double* o = lib->MTensor_getRealData(ov);
+    gphip_ns_options opt;
+    gphip_ns_default_options(&opt);
+    opt.pool = (int)lib->MTensor_getDimensions(st)[0]; opt.max_iterations = (int)o[1]; opt.min_iterations = (int)o[2]; opt.mc_steps = (int)o[3];
+    opt.walkers = (int)o[4]; opt.termination_fraction = o[5]; opt.min_accept = o[6]; opt.max_accept = o[7]; opt.seed = (uint64_t)o[8];
+    if (opt.pool < 2) return LIBRARY_DIMENSION_ERROR;
+    TabPrior tp{p, m, lib->MTensor_getRealData(box), lib->MTensor_getRealData(tab)};
+    const int64_t cap = (int64_t)opt.pool + std::max(opt.max_iterations, opt.min_iterations) + 1;
+    std::vector<double> pts((size_t)cap * p), ll((size_t)cap), lp((size_t)cap), ar((size_t)cap);
+    int64_t n = 0, ne = 0;
+    double z = 0.0;
+    int rc = gphip_nested_sampling(h, tp.box, nullptr, tab_logprior, &tp, &opt, lib->MTensor_getRealData(st), cap, pts.data(), ll.data(),
                                    lp.data(), ar.data(), &n, &z, &ne);
     if (rc != GPHIP_OK) return status_to_wl(rc);
     MTensor r; mint d[2] = {(mint)n, (mint)p + 3};

@@ -20,7 +20,7 @@
 BeginPackage["GPHIP`", {"BayesianUtilities`", "BayesianStatistics`", "BayesianGaussianProcess`"}]
 
 defineGaussianProcessHIP::usage = "defineGaussianProcessHIP[X -> Y, kernel, nugget, meanFunction, variables, prior, opts] has the argument list of defineGaussianProcess (BayesianGaussianProcess.wl:228-234) and builds the same inferenceObject with the log-likelihood evaluated on the GPU. kernel: a named kernel \"SE\", \"SEARD\", \"Matern52\", \"Matern52ARD\", \"Matern32\", \"Matern32ARD\", \"RQ\", \"RQARD\", a composed form \"term + term\", \"term * term\", optionally followed by \" + Const\" (e.g. \"SE + Const\"), or None (null kernel); ANY OTHER kernel expression falls through to the reference's own defineGaussianProcess. nugget: \"Constant\" (Function[sn^2]) or any expression / function of the point in the parameter symbols (evaluated on the host per theta, the values go to the GPU). meanFunction: None, \"Constant\" or any expression / function of the point. variables in the library's order: {term 1: l.., (alpha), sf}, {term 2 ..}, {c}, {sn}, {mu}. The short form defineGaussianProcessHIP[X -> Y, kernelName, variables, prior, opts] takes the constant nugget and \"ConstantMean\" -> False | True. Options: \"Precision\" -> \"Double\" | \"Single\", \"Devices\" -> Automatic | {0, 1, ..}, \"LibraryOptions\" -> {\"panel\" -> 4, ..}.";
-nestedSamplingHIP::usage = "nestedSamplingHIP[obj, opts] runs the native batched nested-sampling driver of the library (lock-step walkers: one batched likelihood call per Metropolis step) on a HIP-backed GP object whose prior is a product of UniformDistribution's (or \"PriorKinds\" -> {0 | 1 ..}, 1 = log-uniform over the parameter's range) and returns the object joined with the result, in the shape nestedSampling returns (the reference's own evidenceSampling post-processes the samples). Takes the options of nestedSampling plus \"Walkers\" -> 32 and \"Seed\" -> 0. Other priors: use nestedSampling[obj], which drives the same GPU closure one theta at a time.";
+nestedSamplingHIP::usage = "nestedSamplingHIP[obj, opts] runs the native batched nested-sampling driver of the library (lock-step walkers: one batched likelihood call per Metropolis step) on a HIP-backed GP object whose prior is a product of UniformDistribution's (or \"PriorKinds\" -> {0 | 1 ..}, 1 = log-uniform over the parameter's range) or ANY product of univariate distributions (its factors' log densities travel as tables, the starting pool is drawn from the prior here) and returns the object joined with the result, in the shape nestedSampling returns (the reference's own evidenceSampling post-processes the samples). Takes the options of nestedSampling plus \"Walkers\" -> 32 and \"Seed\" -> 0. Joint (non-separable) priors fall through to nestedSampling[obj], which drives the same GPU closure one theta at a time.";
 defineGaussianProcessHIP::nonnative = "Kernel `1` is not one of the named or composed kernels of the library: it runs on the reference's own path, which needs the nugget and the mean function as expressions in the parameter symbols (not \"Constant\").";
 hipKernelFunction::usage = "hipKernelFunction[kernelName, d] gives theta |-> Function[{p, q}, ..], the exact WL form of the named kernel (what one would hand to the reference's defineGaussianProcess for the same model).";
 $GPHIPLibrary::usage = "Path of the LibraryLink shim (libgphip_wl).";
@@ -93,6 +93,8 @@ gpPredictSPW := gpPredictSPW = LibraryFunctionLoad[$GPHIPLibrary, "gphip_wl_pred
 	 {Real, _, "Constant"}, {Real, _, "Constant"}}, {Real, 3}];
 gpNested   := gpNested   = LibraryFunctionLoad[$GPHIPLibrary, "gphip_wl_nested_sampling",
 	{Integer, {Real, 2, "Constant"}, {Integer, 1, "Constant"}, {Real, 1, "Constant"}, {Real, _, "Constant"}}, {Real, 2}];
+gpNestedTab := gpNestedTab = LibraryFunctionLoad[$GPHIPLibrary, "gphip_wl_nested_sampling_tab",
+	{Integer, {Real, 2, "Constant"}, {Real, 2, "Constant"}, {Real, 1, "Constant"}, {Real, 2, "Constant"}}, {Real, 2}];
 
 (* value -> machine real; info != 0 or a LibraryFunctionError -> $MachineLogZero, exactly what
    Catch[..., "MatInv"] yields in the reference closure (BayesianGaussianProcess.wl:298-304). *)
@@ -321,26 +323,56 @@ Options[nestedSamplingHIP] = Join[Options[nestedSampling], {"Walkers" -> 32, "Se
 uniformPriorQ[prior_, p_] := MatchQ[prior, "Uniform" | _UniformDistribution |
 	ProductDistribution[(_UniformDistribution | {_UniformDistribution, _Integer})..]];
 
+(* Any SEPARABLE prior (a ProductDistribution of univariate distributions -- or one univariate distribution for one
+   parameter): its "LogPriorPDFFunction" (BayesianStatistics.wl:256-274) is the sum of the factors' log densities, which travel
+   to the native driver as tables on a uniform grid over each parameter's {min, max}; zeros of a density become -1.*^300 (read
+   as -Infinity by the shim).  $Failed for anything else (joint distributions): those runs stay with nestedSampling. *)
+priorFactors[ProductDistribution[d__], p_] := With[{f = Flatten[Replace[{d}, {dist_, n_Integer} :> ConstantArray[dist, n], {1}]]},
+	If[Length[f] === p && AllTrue[f, UnivariateDistributionQ], f, $Failed]];
+priorFactors[d_?UnivariateDistributionQ, 1] := {d};
+priorFactors[__] := $Failed;
+priorTables[factors_List, params_, m_Integer] := MapThread[
+	Function[{dist, spec},
+		Clip[Replace[N @ Log @ PDF[dist, N @ Subdivide[spec[[2]], spec[[3]], m - 1]], Except[_Real] -> -1.*^300, {1}], {-1.*^300, 1.*^300}]],
+	{factors, params}];
+(* the starting pool: draws from the prior that fall inside the parameter ranges (generateStartingPoints, BS:1046-1068) *)
+priorPool[prior_, params_, pool_Integer] := Module[{pts = {}, draw, tries = 0},
+	While[Length[pts] < pool && tries++ < 50,
+		draw = RandomVariate[prior, 2 pool];
+		If[VectorQ[draw], draw = List /@ draw];
+		pts = Join[pts, Select[draw, And @@ Thread[params[[All, 2]] <= # <= params[[All, 3]]]&]]
+	];
+	If[Length[pts] >= pool, N @ pts[[;; pool]], $Failed]
+];
+
 nestedSamplingHIP[inferenceObject[assoc_?AssociationQ], opts : OptionsPattern[]] /;
 	KeyExistsQ[Lookup[assoc, "GaussianProcessData", <||>], "HIPHandle"] := Module[{
 	h = assoc["GaussianProcessData", "HIPHandle"],
-	params = assoc["Parameters"], p, pool, kinds, start, rows, samples, result,
+	params = assoc["Parameters"], p, pool, kinds, factors, nsOpts, start, rows, samples, result,
 	pwFlags = Lookup[assoc["GaussianProcessData"], "PointwiseFunctions", {False, False}]
 },
 	p = Length[params];
 	kinds = Replace[OptionValue["PriorKinds"], Automatic :> If[uniformPriorQ[assoc["PriorDistribution"], p], ConstantArray[0, p], $Failed]];
-	(* point-dependent nugget / mean functions live in this kernel process, and so do priors outside the built-in
-	   family: those runs go through the reference's own driver with the GPU closure *)
-	If[ kinds === $Failed || Or @@ pwFlags,
+	factors = If[kinds === $Failed, priorFactors[assoc["PriorDistribution"], p], $Failed];
+	(* point-dependent nugget / mean functions live in this kernel process, and so do NON-separable priors: those runs go
+	   through the reference's own driver with the GPU closure *)
+	If[ (kinds === $Failed && factors === $Failed) || Or @@ pwFlags,
 		Return @ nestedSampling[inferenceObject[assoc], Sequence @@ FilterRules[{opts}, Options[nestedSampling]]]
 	];
 	start = Replace[OptionValue["StartingPoints"], Except[_?(MatrixQ[#, NumericQ]&)] :> Lookup[assoc, "StartingPoints", {}]];
 	pool = If[MatrixQ[start], Length[start], OptionValue["SamplePoolSize"]];
 	touch[h];
-	rows = gpNested[h, N @ params[[All, {2, 3}]], kinds,
-		N @ {pool, OptionValue["MaxIterations"], OptionValue["MinIterations"], OptionValue["MonteCarloSteps"], OptionValue["Walkers"],
-			OptionValue["TerminationFraction"], Sequence @@ OptionValue["MinMaxAcceptanceRate"], OptionValue["Seed"]},
-		If[MatrixQ[start], N @ start, {}]];
+	nsOpts = N @ {pool, OptionValue["MaxIterations"], OptionValue["MinIterations"], OptionValue["MonteCarloSteps"], OptionValue["Walkers"],
+		OptionValue["TerminationFraction"], Sequence @@ OptionValue["MinMaxAcceptanceRate"], OptionValue["Seed"]};
+	rows = If[ kinds =!= $Failed,
+		gpNested[h, N @ params[[All, {2, 3}]], kinds, nsOpts, If[MatrixQ[start], N @ start, {}]],
+		(* separable prior: tabulated factors, pool drawn here from the prior itself *)
+		If[!MatrixQ[start], start = priorPool[assoc["PriorDistribution"], params, pool]];
+		If[ start === $Failed,
+			Return @ nestedSampling[inferenceObject[assoc], Sequence @@ FilterRules[{opts}, Options[nestedSampling]]]
+		];
+		gpNestedTab[h, N @ params[[All, {2, 3}]], priorTables[factors, params, 2049], nsOpts, N @ start]
+	];
 	If[ !MatrixQ[rows], Return["Bad likelihood function"]];     (* BayesianStatistics.wl:917-921 *)
 	samples = Association @ MapIndexed[
 		Function[{row, index},

@@ -263,3 +263,68 @@ def test_new_shim_entry_points_pointwise_kernels_device_count_and_native_sampler
         assert K.call("gphip_wl_destroy", [hh], "int") == (NO_ERROR, 0)
     assert K.lib.drv_live() == live0 and K.lib.drv_const_frees() == 0
     K.lib.WolframLibrary_uninitialize(K.data)
+
+
+def test_native_sampler_with_a_tabulated_normal_prior_matches_quadrature_over_20_seeds():
+    """nestedSamplingHIP for a NON-uniform (separable) prior: gphip_wl_nested_sampling_tab takes each factor's log density as a
+    table over the parameter's range (what GPHIP.wl sends for a ProductDistribution of univariate distributions) and a
+    starting pool drawn from the prior.  Null kernel + constant mean: log L(sn, mu) is analytic, so the evidence under
+    sn ~ U[0.4, 2], mu ~ N(0.2, 0.5) truncated to [-1, 1.5] is a smooth 2-D integral (midpoint rule, 1200 x 1200)."""
+    import math
+    from bayesianinference_amd import nested_sampling as ns
+    K = Kernel()
+    rng = np.random.default_rng(3)
+    n = 40
+    X = rng.random((n, 1))
+    y = 0.3 + 0.8 * rng.standard_normal(n)
+    box = np.array([[0.4, 2.0], [-1.0, 1.5]])
+    m0, s0 = 0.2, 0.5
+    from scipy.stats import norm
+    mass = norm.cdf(box[1, 1], m0, s0) - norm.cdf(box[1, 0], m0, s0)
+
+    def logprior(sn, mu):                                    # the density the TABLES describe (normalised on the box)
+        return -math.log(box[0, 1] - box[0, 0]) + norm.logpdf(mu, m0, s0) - math.log(mass)
+
+    g = 1200
+    sn = box[0, 0] + (np.arange(g) + 0.5) * (box[0, 1] - box[0, 0]) / g
+    mu = box[1, 0] + (np.arange(g) + 0.5) * (box[1, 1] - box[1, 0]) / g
+    s1, s2 = y.sum(), (y * y).sum()
+    quad = (s2 - 2 * mu[None, :] * s1 + n * mu[None, :] ** 2) / sn[:, None] ** 2
+    ll = -0.5 * (n * math.log(2 * math.pi) + 2 * n * np.log(sn)[:, None] + quad)
+    lp = -math.log(box[0, 1] - box[0, 0]) + norm.logpdf(mu, m0, s0)[None, :] - math.log(mass)
+    cell = (box[0, 1] - box[0, 0]) / g * (box[1, 1] - box[1, 0]) / g
+    want = ns.log_sum_exp((ll + lp).ravel()) + math.log(cell)
+    nodes = 513
+    tab = np.stack([np.full(nodes, -math.log(box[0, 1] - box[0, 0])),
+                    norm.logpdf(np.linspace(box[1, 0], box[1, 1], nodes), m0, s0) - math.log(mass)])
+    rc, hs = K.call("gphip_wl_create", [X, y, 4, 1, 64, np.array([0])], "int")          # null kernel, constant mean
+    assert rc == NO_ERROR
+    pool, zs = 60, []
+    for seed in range(20):
+        r = np.random.default_rng(100 + seed)
+        start = np.empty((pool, 2))
+        start[:, 0] = r.uniform(box[0, 0], box[0, 1], pool)
+        k = 0
+        while k < pool:                                       # truncated normal by rejection (RandomVariate + Select in GPHIP.wl)
+            v = r.normal(m0, s0)
+            if box[1, 0] <= v <= box[1, 1]:
+                start[k, 1] = v
+                k += 1
+        opts = np.array([pool, 10000, 100, 25, 32, 0.01, 0.0, 1.0, float(seed)])
+        rc, rows = K.call("gphip_wl_nested_sampling_tab", [hs, box, tab, opts, start])
+        assert rc == NO_ERROR and rows.shape[1] == 5 and rows.shape[0] > pool
+        np.testing.assert_array_equal(rows[:pool, :2], start)
+        i = pool + 7                                          # the recorded prior density IS the tabulated one (interpolated)
+        assert abs(rows[i, 3] - logprior(rows[i, 0], rows[i, 1])) < 1e-8
+        res = {"Points": rows[:, :2], "LogLikelihood": rows[:, 2], "LogPriorPDF": rows[:, 3], "AcceptanceRate": rows[:, 4],
+               "SamplePoolSize": pool, "GeneratedNestedSamples": len(rows) - pool, "TotalSamples": len(rows)}
+        out = ns.evidence_sampling(res, ["sn", "mu"], pool, np.random.default_rng(seed))
+        zs.append((out["LogEvidence"]["Mean"] - want) / out["LogEvidence"]["StandardError"])
+    zs = np.array(zs)
+    assert abs(zs.mean()) < 0.5 and np.all(np.abs(zs) < 4.0), zs
+    assert 0.5 < zs.std(ddof=1) < 2.0, zs
+    # argument checks: table row count, too few nodes, missing pool
+    assert K.call("gphip_wl_nested_sampling_tab", [hs, box, tab[:1], opts, start])[0] == DIMENSION_ERROR
+    assert K.call("gphip_wl_nested_sampling_tab", [hs, box, tab[:, :3], opts, start])[0] == DIMENSION_ERROR
+    assert K.call("gphip_wl_nested_sampling_tab", [hs, box, tab, opts, start[:, :1]])[0] == DIMENSION_ERROR
+    assert K.call("gphip_wl_destroy", [hs], "int") == (NO_ERROR, 0)
