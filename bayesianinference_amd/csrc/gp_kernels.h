@@ -393,7 +393,13 @@ __global__ __launch_bounds__(256) void kbuild_kernel(KBuildArgs<T> a) {
     if (sizeof(T) == 8 && KT != 2)
         for (int idx = tid; idx < EXP_TAB; idx += 256) etab[idx] = sp[0] * a.exp2tab[idx];
     // fp64 squared exponential: coordinates in units in which the squared distance IS the exp table's argument (exp_tab_u)
-    constexpr bool USCALE = sizeof(T) == 8 && KT == 0 && D > 0;
+    // (GP_KBUILD_USCALE: round-4 experiment, off.  10 instead of 12 fp64 instructions per exponential bought 1 % on the boxes
+    //  measured -- the build is not purely VALU bound there -- and the different rounding moved the SPD verdict of the
+    //  multi-kernel schedule inside the sentinel band of tests/test_gpu_sentinel_band.py (cond 7e13): not worth it.)
+#ifndef GP_KBUILD_USCALE
+#define GP_KBUILD_USCALE 0
+#endif
+    constexpr bool USCALE = GP_KBUILD_USCALE && sizeof(T) == 8 && KT == 0 && D > 0;
     // fp32 fast path below: sum of squares = r2 log2(e) / 2 (SE) or 5 r2 (Matern-5/2)
     constexpr bool F32FAST = sizeof(T) == 4 && D > 0 && KT != 2;
     constexpr float CS32 = KT == 0 ? 0.84932180028801904f /* sqrt(log2(e) / 2) */ : 2.2360679774997896f /* sqrt 5 */;
@@ -524,8 +530,8 @@ __global__ __launch_bounds__(256) void kbuild_kernel(KBuildArgs<T> a) {
                 }
             } else {
                 const double sa = __builtin_sqrt(5.0 * ra), sb = __builtin_sqrt(5.0 * rb);
-                va = (1.0 + sa + (5.0 / 3.0) * ra) * exp_tab_u(sa * EXP_U_PER_ARG, etab);
-                vb = (1.0 + sb + (5.0 / 3.0) * rb) * exp_tab_u(sb * EXP_U_PER_ARG, etab);
+                va = (1.0 + sa + (5.0 / 3.0) * ra) * exp_tab<false>(sa, etab);
+                vb = (1.0 + sb + (5.0 / 3.0) * rb) * exp_tab<false>(sb, etab);
             }
         } else {
             va = kfun<KT, T>(ra, sf2);
@@ -1699,6 +1705,7 @@ struct DfArgs {
     unsigned long long ticket_base;           // value of *ticket before this launch
     int* abort_flag;
     int nd, nslots, epoch;                    // nd = diagonal blocks = Npad / TBX; tile row nd = the rhs rows
+    int cw;                                   // split launch: tiles per column (from the diagonal down) that belong to the chain launch
     int role;                                 // 0: this launch runs every task; split launch on CU-masked streams: 1 = the
                                               // diagonal (chain) tasks on the reserved CUs, 2 = all other tasks on the rest
     int* park;                                // 64-tiles, two workgroups per CU: [DF_PARK_SLOTS] counters "a chain task is in its critical
@@ -1787,14 +1794,25 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g, Th
     // column-major (the strictly lower triangle = a lower triangle of R - 1 rows, shifted down by one).  Each launch hands
     // out ITS tasks in the global topological order, so the lowest unfinished task of either launch is always resident and
     // the lowest unfinished task overall has all its dependencies finished: the deadlock argument above carries over.
-    const int Rq = g.role == 2 ? R - 1 : R;
+    // (chain width cw = g.cw >= 1: the chain launch takes the cw tiles of every column nearest the diagonal -- the diagonal
+    //  task, the sub-diagonal one that feeds it, ..; its last cw - 1 columns are shorter)
+    const int cw = g.role ? g.cw : 0;
+    const int Rq = g.role == 2 ? R - cw : R;
     int j = (int)(((double)(2 * Rq + 1) - sqrt((double)(2 * Rq + 1) * (2 * Rq + 1) - 8.0 * q)) * 0.5);
     if (j < 0) j = 0;
     if (j > Rq - 1) j = Rq - 1;
     while (j + 1 < Rq && (j + 1) * Rq - (j + 1) * j / 2 <= q) ++j;
     while (j > 0 && j * Rq - j * (j - 1) / 2 > q) --j;
-    int i = j + (q - (j * Rq - j * (j - 1) / 2)) + (g.role == 2 ? 1 : 0);
-    if (g.role == 1) { j = q; i = q; }
+    int i = j + (q - (j * Rq - j * (j - 1) / 2)) + (g.role == 2 ? cw : 0);
+    if (g.role == 1) {
+        const int full = R - cw + 1;                       // columns 0 .. full - 1 have cw chain tiles each
+        if (q < full * cw) { j = q / cw; i = j + q % cw; }
+        else {                                              // the short columns at the end: a cw - 1 triangle
+            int rest = q - full * cw, jj = full, len = cw - 1;
+            while (rest >= len) { rest -= len; ++jj; --len; }
+            j = jj; i = jj + rest;
+        }
+    }
     j = __builtin_amdgcn_readfirstlane(j);                 // (through the vector sqrt: back to the scalar unit)
     i = __builtin_amdgcn_readfirstlane(i);
 

@@ -70,7 +70,7 @@ struct gphip_ctx {
     // Split dataflow launch (64-tiles): the diagonal (chain) tasks run as their OWN launch on a stream whose CU mask reserves
     // `df_split` CUs per XCD, every other task on a stream masked to the remaining CUs -- the chain never shares a SIMD, an
     // LDS or a dispatch slot with the throughput work.  -1 auto (by task count), 0 off.
-    int df_split = 0, df_split_lds_kib = 84, df_split_min_tasks = 5000, df_split_auto = 3;
+    int df_split = 0, df_split_lds_kib = 84, df_split_min_tasks = 5000, df_split_auto = 3, df_split_width = 1;
     hipStream_t chain_stream = nullptr, bulk_stream = nullptr;
     int split_streams_for = 0;                   // reserved CUs per XCD the two masked streams were created for
     unsigned long long ticket_base2 = 0;         // chain launch's own ticket counter (dTicket + DF_TICKET2)
@@ -799,7 +799,11 @@ void launch_dataflow(gphip_ctx* h, int nslots, int c0 = 0, double* part = nullpt
             DfArgs<T> gc = g, gb = g;
             gc.role = 1; gc.park = nullptr;
             gc.ticket = h->dTicket + DF_TICKET2; gc.ticket_base = h->ticket_base2;
-            const long ctasks = (long)R * nslots;
+            int cw = h->df_split_width < 1 ? 1 : h->df_split_width;
+            if (cw > R - 1) cw = R - 1;
+            gc.cw = gb.cw = cw;
+            // chain tiles: cw per column for the first R - cw + 1 columns, then cw - 1, .., 1
+            const long ctasks = ((long)(R - cw + 1) * cw + (long)cw * (cw - 1) / 2) * nslots;
             h->ticket_base2 += (unsigned long long)ctasks;
             gb.role = 2; gb.park = nullptr;
             h->ticket_base -= (unsigned long long)ctasks;             // (the bulk launch draws tasks - ctasks tickets)
@@ -2951,7 +2955,7 @@ int* option_slot(gphip_ctx* h, const char* name) {
         {"dataflow", &gphip_ctx::dataflow}, {"dataflow_max_nt", &gphip_ctx::dataflow_max_nt},
         {"dataflow_max_slots", &gphip_ctx::dataflow_max_slots}, {"dataflow_fine_nt", &gphip_ctx::dataflow_fine_nt},
         {"dataflow_tail", &gphip_ctx::dataflow_tail}, {"grad_potri", &gphip_ctx::grad_potri},
-        {"fused_eval", &gphip_ctx::fuse_option}, {"panel_left", &gphip_ctx::panel_left}, {"build_overlap", &gphip_ctx::build_overlap}, {"dataflow_lds_kib", &gphip_ctx::dataflow_lds_kib}, {"dataflow_park", &gphip_ctx::dataflow_park}, {"fuse_potrf", &gphip_ctx::fuse_potrf}, {"bcast_chunks", &gphip_ctx::bcast_chunks}, {"dataflow_occ3", &gphip_ctx::dataflow_occ3}, {"batch_groups", &gphip_ctx::batch_groups}, {"panel_rows", &gphip_ctx::panel_rows}, {"batch_group_min", &gphip_ctx::batch_group_min}, {"df_split", &gphip_ctx::df_split}, {"df_split_lds_kib", &gphip_ctx::df_split_lds_kib}, {"df_split_min_tasks", &gphip_ctx::df_split_min_tasks}, {"df_split_auto", &gphip_ctx::df_split_auto},
+        {"fused_eval", &gphip_ctx::fuse_option}, {"panel_left", &gphip_ctx::panel_left}, {"build_overlap", &gphip_ctx::build_overlap}, {"dataflow_lds_kib", &gphip_ctx::dataflow_lds_kib}, {"dataflow_park", &gphip_ctx::dataflow_park}, {"fuse_potrf", &gphip_ctx::fuse_potrf}, {"bcast_chunks", &gphip_ctx::bcast_chunks}, {"dataflow_occ3", &gphip_ctx::dataflow_occ3}, {"batch_groups", &gphip_ctx::batch_groups}, {"panel_rows", &gphip_ctx::panel_rows}, {"batch_group_min", &gphip_ctx::batch_group_min}, {"df_split", &gphip_ctx::df_split}, {"df_split_lds_kib", &gphip_ctx::df_split_lds_kib}, {"df_split_min_tasks", &gphip_ctx::df_split_min_tasks}, {"df_split_auto", &gphip_ctx::df_split_auto}, {"df_split_width", &gphip_ctx::df_split_width},
         {"max_slots", &gphip_ctx::max_slots}, {"shard_min_n", &gphip_ctx::shard_min_n},
         {"thin_tiles", &gphip_ctx::thin_tiles}, {"panel_wide", &gphip_ctx::panel_wide},
         {"la_main", &gphip_ctx::la_main}, {"rest_split", &gphip_ctx::rest_split},

@@ -1,27 +1,25 @@
-"""Split dataflow launch (option df_split = reserved CUs per XCD for the diagonal chain tasks) vs the single launch:
-ms per single-theta evaluation, results must be bit-identical.  Usage: gpu_df_split.py [N ...]"""
+"""Split dataflow launch (option df_split = reserved CUs per XCD for the chain tasks, df_split_width = tiles per column, from the
+diagonal down, that count as chain tasks) vs the single launch: ms per single-theta evaluation, results must be bit-identical.
+Usage: gpu_df_split.py [N ...]"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from bayesianinference_amd import _lib, synthetic as syn
 
-sizes = [int(a) for a in sys.argv[1:]] or [4096, 6144, 8192, 10240, 12288, 16384]
+sizes = [int(a) for a in sys.argv[1:]] or [4096, 6144, 8192, 10240, 12288]
 variants = [("single", {"df_split": 0})]
-for res in (1, 2, 3, 4, 6):
-    variants.append((f"res{res}", {"df_split": res, "df_split_lds_kib": 84}))
-variants.append(("res3/2wg", {"df_split": 3, "df_split_lds_kib": 0}))
-variants.append(("res2/2wg", {"df_split": 2, "df_split_lds_kib": 0}))
+for cw in (2, 3, 4):
+    for res, kib in ((2, 84), (3, 84), (4, 84), (3, 0), (4, 0), (6, 0)):
+        variants.append((f"w{cw}r{res}{'x2' if kib == 0 else ''}", {"df_split": res, "df_split_lds_kib": kib, "df_split_width": cw}))
 for n in sizes:
     d, kernel = 8, "se_ard"
     X, y = syn.make_dataset(n, d)
     h = _lib.Handle(X, y, kernel)
-    if n > 12288:
-        h.set_option("dataflow_max_nt", 256); h.set_option("dataflow_fine_nt", 256)
     th = syn.default_theta(kernel, d)
     ref = None
-    row = [f"N={n:5d}"]
     for rnd in range(2):
+        row = [f"N={n:5d}"]
         for name, opts in variants:
             for k, v in opts.items():
                 h.set_option(k, v)
@@ -38,7 +36,6 @@ for n in sizes:
             if ref is None:
                 ref = ll
             flag = "" if ll == ref else f" DIFF {ll - ref:.3e}"
-            row.append(f"{name}: {dt*1e3:7.3f}{flag}")
+            row.append(f"{name}: {dt*1e3:6.3f}{flag}")
         print(" | ".join(row), flush=True)
-        row = [f"N={n:5d}"]
     h.close()
