@@ -72,6 +72,12 @@ struct gphip_ctx {
     // LDS or a dispatch slot with the throughput work.  -1 auto (by task count), 0 off.
     int df_split = 0, df_split_lds_kib = 84, df_split_min_tasks = 5000, df_split_auto = 3, df_split_width = 1;
     hipStream_t chain_stream = nullptr, bulk_stream = nullptr;
+    // Look-ahead schedule, mid sizes: the trailing updates REST(k) run on a stream whose CU mask leaves `rest_mask` CUs per XCD
+    // free, so that the latency-shaped kernels of the panel stream (fused potrf, panel solves, in-panel updates) find a CU
+    // at once instead of waiting for a trailing-update workgroup to retire.  0 off, -1 auto.
+    int rest_mask = 0, rest_mask_max_nt = 192;
+    hipStream_t rest_stream = nullptr;
+    int rest_stream_for = 0;
     int split_streams_for = 0;                   // reserved CUs per XCD the two masked streams were created for
     unsigned long long ticket_base2 = 0;         // chain launch's own ticket counter (dTicket + DF_TICKET2)
     // Phase-shifted batch groups (eval_chunk): a large theta batch is cut into `batch_groups` slot ranges, each factored on its
@@ -746,6 +752,25 @@ bool split_streams(gphip_ctx* h, int res) {
     return true;
 }
 
+// the trailing updates' stream: every CU except `res` per XCD (mask layout: see split_streams)
+hipStream_t masked_rest_stream(gphip_ctx* h, int res) {
+    if (res > 8) res = 8;
+    if (h->rest_stream && h->rest_stream_for == res) return h->rest_stream;
+    int ncu = 0;
+    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess || ncu != 256) return nullptr;
+    if (h->rest_stream) { (void)hipStreamDestroy(h->rest_stream); h->rest_stream = nullptr; }
+    uint32_t m[8];
+    for (int w = 0; w < 8; ++w) m[w] = 0xffffffffu;
+    for (int x = 0; x < 8; ++x)
+        for (int k = 0; k < res; ++k) {
+            const int b = x + 8 * k;
+            m[b / 32] &= ~(1u << (b % 32));
+        }
+    if (hipExtStreamCreateWithCUMask(&h->rest_stream, 8, m) != hipSuccess) { (void)hipGetLastError(); h->rest_stream = nullptr; return nullptr; }
+    h->rest_stream_for = res;
+    return h->rest_stream;
+}
+
 // c0 > 0 (128-tiles only): factor the trailing submatrix that starts at tile column c0 -- the tail of the
 // look-ahead schedule, already updated by every earlier panel.  No finalize here.
 template <typename T, int TBX, int OCC = 2, int NST = 2, bool BUILD = false>
@@ -923,6 +948,15 @@ int queue_factor(gphip_ctx* h, int nslots) {
         hipEvent_t built = sync_event(h);
         HIPCHK(hipEventRecord(built, h->stream));
         HIPCHK(hipStreamWaitEvent(h->pstream, built0 ? built0 : built, 0));
+        // the trailing updates' stream (CU-masked for mid sizes, see gphip_ctx::rest_mask)
+        hipStream_t rs = h->stream;
+        {
+            const int res = h->rest_mask >= 0 ? h->rest_mask : 0;
+            if (res > 0 && nslots == 1 && !split && Nt <= h->rest_mask_max_nt && h->dist_world == 0) {
+                hipStream_t m = masked_rest_stream(h, res);
+                if (m) { rs = m; HIPCHK(hipStreamWaitEvent(rs, built, 0)); }
+            }
+        }
         h->cs = h->pstream;
         queue_panel<T>(h, 0, k0(1), nslots);
         hipEvent_t ev_panel = sync_event(h);
@@ -940,6 +974,7 @@ int queue_factor(gphip_ctx* h, int nslots) {
             if (k + 1 == kc) {                  // last multi-kernel panel: apply it to everything, then cut over
                 h->cs = h->stream;
                 HIPCHK(hipStreamWaitEvent(h->stream, ev_panel, 0));
+                if (rs != h->stream && ev_rest) HIPCHK(hipStreamWaitEvent(h->stream, ev_rest, 0));
                 if (ev_rest2) HIPCHK(hipStreamWaitEvent(h->stream, ev_rest2, 0));
                 trailing(k, k0(k + 1), R, 4);
                 const int rem = Nt - k0(kc);                       // tile columns left
@@ -997,17 +1032,18 @@ int queue_factor(gphip_ctx* h, int nslots) {
                 HIPCHK(hipStreamWaitEvent(h->stream, ev_panel, 0));
                 trailing_half(k, k0(k + 2), 0);                                // REST(k), even groups
             } else {
-                h->cs = h->stream;
-                HIPCHK(hipStreamWaitEvent(h->stream, ev_panel, 0));
-                if (ev_rest2) HIPCHK(hipStreamWaitEvent(h->stream, ev_rest2, 0));
+                h->cs = rs;
+                HIPCHK(hipStreamWaitEvent(rs, ev_panel, 0));
+                if (ev_rest2) HIPCHK(hipStreamWaitEvent(rs, ev_rest2, 0));
                 trailing(k, k0(k + 2), R, 4);                                  // REST(k)
             }
             ev_rest = sync_event(h);
-            HIPCHK(hipEventRecord(ev_rest, h->stream));
+            HIPCHK(hipEventRecord(ev_rest, split && k0(k + 2) % 2 == 0 ? h->stream : rs));
             ev_panel = ev_next;
         }
         h->cs = h->stream;
         if (ev_rest2) HIPCHK(hipStreamWaitEvent(h->stream, ev_rest2, 0));
+        if (rs != h->stream && ev_rest) HIPCHK(hipStreamWaitEvent(h->stream, ev_rest, 0));
     }
     if (tail_k0 >= 0) {
         launch_finalize<T>(h, nslots, tail_k0, Nt, tail_part, tail_n);
@@ -1999,6 +2035,7 @@ int gphip_destroy(gphip_handle h) {
     for (hipStream_t st : h->grp_streams) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
     for (hipEvent_t e : h->grp_events) (void)hipEventDestroy(e);
     if (h->chain_stream) (void)hipStreamDestroy(h->chain_stream);
+    if (h->rest_stream) (void)hipStreamDestroy(h->rest_stream);
     if (h->bulk_stream) (void)hipStreamDestroy(h->bulk_stream);
     if (h->own_streams) {
         if (h->pstream) (void)hipStreamDestroy(h->pstream);
@@ -2955,7 +2992,7 @@ int* option_slot(gphip_ctx* h, const char* name) {
         {"dataflow", &gphip_ctx::dataflow}, {"dataflow_max_nt", &gphip_ctx::dataflow_max_nt},
         {"dataflow_max_slots", &gphip_ctx::dataflow_max_slots}, {"dataflow_fine_nt", &gphip_ctx::dataflow_fine_nt},
         {"dataflow_tail", &gphip_ctx::dataflow_tail}, {"grad_potri", &gphip_ctx::grad_potri},
-        {"fused_eval", &gphip_ctx::fuse_option}, {"panel_left", &gphip_ctx::panel_left}, {"build_overlap", &gphip_ctx::build_overlap}, {"dataflow_lds_kib", &gphip_ctx::dataflow_lds_kib}, {"dataflow_park", &gphip_ctx::dataflow_park}, {"fuse_potrf", &gphip_ctx::fuse_potrf}, {"bcast_chunks", &gphip_ctx::bcast_chunks}, {"dataflow_occ3", &gphip_ctx::dataflow_occ3}, {"batch_groups", &gphip_ctx::batch_groups}, {"panel_rows", &gphip_ctx::panel_rows}, {"batch_group_min", &gphip_ctx::batch_group_min}, {"df_split", &gphip_ctx::df_split}, {"df_split_lds_kib", &gphip_ctx::df_split_lds_kib}, {"df_split_min_tasks", &gphip_ctx::df_split_min_tasks}, {"df_split_auto", &gphip_ctx::df_split_auto}, {"df_split_width", &gphip_ctx::df_split_width},
+        {"fused_eval", &gphip_ctx::fuse_option}, {"panel_left", &gphip_ctx::panel_left}, {"build_overlap", &gphip_ctx::build_overlap}, {"dataflow_lds_kib", &gphip_ctx::dataflow_lds_kib}, {"dataflow_park", &gphip_ctx::dataflow_park}, {"fuse_potrf", &gphip_ctx::fuse_potrf}, {"bcast_chunks", &gphip_ctx::bcast_chunks}, {"dataflow_occ3", &gphip_ctx::dataflow_occ3}, {"batch_groups", &gphip_ctx::batch_groups}, {"panel_rows", &gphip_ctx::panel_rows}, {"batch_group_min", &gphip_ctx::batch_group_min}, {"df_split", &gphip_ctx::df_split}, {"df_split_lds_kib", &gphip_ctx::df_split_lds_kib}, {"df_split_min_tasks", &gphip_ctx::df_split_min_tasks}, {"rest_mask", &gphip_ctx::rest_mask}, {"rest_mask_max_nt", &gphip_ctx::rest_mask_max_nt}, {"df_split_auto", &gphip_ctx::df_split_auto}, {"df_split_width", &gphip_ctx::df_split_width},
         {"max_slots", &gphip_ctx::max_slots}, {"shard_min_n", &gphip_ctx::shard_min_n},
         {"thin_tiles", &gphip_ctx::thin_tiles}, {"panel_wide", &gphip_ctx::panel_wide},
         {"la_main", &gphip_ctx::la_main}, {"rest_split", &gphip_ctx::rest_split},
