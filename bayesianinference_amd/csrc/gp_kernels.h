@@ -97,6 +97,7 @@ __device__ __forceinline__ float exp_nonpos(float x) { return __expf(fmaxf(x, -1
 //   sf2 exp = 2^(k >> 9) * TAB[k & 511] * (1 + r + r^2/2 + r^3/6 + r^4/24)      truncation r^5/120 < 1.3e-18
 // TAB[j] = sf2 2^(j/512) lives in LDS (4 KiB, filled per workgroup from a 512-entry device table of 2^(j/512)).
 // 15 VALU instructions instead of 23; <= 2.5 ulp.
+constexpr int KB_LDS_MAXD = 32;     // generic-d kernel build / gradient reduction: point tiles are staged in LDS up to this many dimensions
 constexpr int EXP_TAB = 512;
 template <bool HALF>
 __device__ __forceinline__ double exp_tab(double w, const double* __restrict__ tab) {
@@ -388,8 +389,14 @@ __global__ __launch_bounds__(256) void kbuild_kernel(KBuildArgs<T> a) {
     T* xjs2 = lds + 2 * d * TB;
     T* xis2 = lds + 3 * d * TB;
     const bool two = KT == 2 && a.ks.op != 0;
+    // Input dimensions beyond KB_LDS_MAXD (generic-d instantiations only): the point tiles no longer fit in LDS next to a
+    // second workgroup, so the inner loop reads the scaled coordinates straight from global memory (the J-side value is one
+    // wave-uniform 8-byte load per dimension and column, the I-side pair a coalesced 16-byte load; both tiles stay L1 / L2
+    // resident).  Slower per entry, but the reference takes points of ANY dimension (BGP:29-43) and for such d the
+    // factorisation dominates anyway.
+    const bool glb = D == 0 && d > KB_LDS_MAXD;
     // fp64: sf2 2^(j/512) table behind the point tiles (see exp_tab)
-    double* etab = lds_raw + ((D > 0) ? D : 2 * d) * TB;
+    double* etab = lds_raw + (glb ? 0 : ((D > 0) ? D : 2 * d) * TB);
     if (sizeof(T) == 8 && KT != 2)
         for (int idx = tid; idx < EXP_TAB; idx += 256) etab[idx] = sp[0] * a.exp2tab[idx];
     // fp64 squared exponential: coordinates in units in which the squared distance IS the exp table's argument (exp_tab_u)
@@ -404,7 +411,7 @@ __global__ __launch_bounds__(256) void kbuild_kernel(KBuildArgs<T> a) {
     constexpr bool F32FAST = sizeof(T) == 4 && D > 0 && KT != 2;
     constexpr float CS32 = KT == 0 ? 0.84932180028801904f /* sqrt(log2(e) / 2) */ : 2.2360679774997896f /* sqrt 5 */;
     const T cscale = USCALE ? (T)EXP_COORD_SCALE_SE : (F32FAST ? (T)CS32 : (T)1);
-    for (int idx = tid; idx < d * TB; idx += 256) {
+    for (int idx = tid; idx < (glb ? 0 : d * TB); idx += 256) {
         const int dd = idx >> 7, c = idx & 127;
         xjs[idx] = (USCALE || F32FAST) ? xjg[(long)dd * a.npad_j + c] * cscale : xjg[(long)dd * a.npad_j + c];
         if (D == 0) xis[idx] = xig[(long)dd * a.npad_i + c];
@@ -499,10 +506,18 @@ __global__ __launch_bounds__(256) void kbuild_kernel(KBuildArgs<T> a) {
                 ra = Num<T>::fma_(da, da, ra);
                 rb = Num<T>::fma_(db, db, rb);
             }
-        } else {
+        } else if (!glb) {
             for (int dd = 0; dd < d; ++dd) {
                 const T xjv = xjs[dd * TB + jj];
                 const T da = xis[dd * TB + r0] - xjv, db = xis[dd * TB + r0 + 1] - xjv;
+                ra = Num<T>::fma_(da, da, ra);
+                rb = Num<T>::fma_(db, db, rb);
+            }
+        } else {
+            for (int dd = 0; dd < d; ++dd) {
+                const T xjv = xjg[(long)dd * a.npad_j + jj];
+                const pair_t xi = *reinterpret_cast<const pair_t*>(xig + (long)dd * a.npad_i + r0);
+                const T da = xi.x - xjv, db = xi.y - xjv;
                 ra = Num<T>::fma_(da, da, ra);
                 rb = Num<T>::fma_(db, db, rb);
             }
@@ -510,13 +525,24 @@ __global__ __launch_bounds__(256) void kbuild_kernel(KBuildArgs<T> a) {
         T va, vb;
         if constexpr (KT == 2) {
             T ra2 = (T)0, rb2 = (T)0;
-            if (two)
+            if (two && !glb)
                 for (int dd = 0; dd < d; ++dd) {
                     const T xjv = xjs2[dd * TB + jj];
                     const T da = xis2[dd * TB + r0] - xjv, db = xis2[dd * TB + r0 + 1] - xjv;
                     ra2 = Num<T>::fma_(da, da, ra2);
                     rb2 = Num<T>::fma_(db, db, rb2);
                 }
+            if (two && glb) {
+                const T* xj2g = a.xj2 + (long)slot * a.xj_bstride + (long)tj * TB;
+                const T* xi2g = a.xi2 + (long)slot * a.xi_bstride + (long)ti * TB;
+                for (int dd = 0; dd < d; ++dd) {
+                    const T xjv = xj2g[(long)dd * a.npad_j + jj];
+                    const pair_t xi = *reinterpret_cast<const pair_t*>(xi2g + (long)dd * a.npad_i + r0);
+                    const T da = xi.x - xjv, db = xi.y - xjv;
+                    ra2 = Num<T>::fma_(da, da, ra2);
+                    rb2 = Num<T>::fma_(db, db, rb2);
+                }
+            }
             va = kgeneral<T>(a.ks, ra, ra2, sp);
             vb = kgeneral<T>(a.ks, rb, rb2, sp);
         } else if constexpr (sizeof(T) == 8) {

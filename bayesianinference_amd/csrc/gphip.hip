@@ -60,6 +60,7 @@ struct gphip_ctx {
     hipEvent_t ev_built0 = nullptr;              // queue_build -> queue_factor: "the tile columns of panel 0 are built" (split build)
     int dist_first_factored = -1;                // sharded evaluation: outer panel whose first diagonal block the last LA update factored
     int bcast_chunks = 1;                        // sharded evaluation: a factored panel is broadcast one tile column at a time
+    int bcast_two_hop = 0;                       // sharded evaluation over RCCL, world > 2: every broadcast as scatter (send / recv) + in-place all-gather
     std::vector<hipEvent_t>* col_events = nullptr;   // queue_panel: record "tile column final" events here (owner of a sharded panel)
     int fuse_potrf = 1;                          // option: panel-stream updates factor the diagonal tile they have just updated
     int fuse_b = -1;                             // launch_gemm: request (tile to factor) ...
@@ -396,7 +397,7 @@ void launch_kbuild_kt(gphip_ctx* h, const KBuildArgs<T>& a, dim3 grid) {
         KB_CASE(1) KB_CASE(2) KB_CASE(3) KB_CASE(4) KB_CASE(5) KB_CASE(6) KB_CASE(7) KB_CASE(8)
         KB_CASE(16)
         default:
-            hipLaunchKernelGGL((kbuild_kernel<T, 0, KT>), grid, dim3(256), (size_t)2 * d * TB * sizeof(T) + etab, h->cs, a);
+            hipLaunchKernelGGL((kbuild_kernel<T, 0, KT>), grid, dim3(256), (d > KB_LDS_MAXD ? 0 : (size_t)2 * d * TB * sizeof(T)) + etab, h->cs, a);
     }
 #undef KB_CASE
 }
@@ -406,7 +407,7 @@ void launch_kbuild(gphip_ctx* h, const KBuildArgs<T>& a, dim3 grid) {
     if (h->kt == 0) launch_kbuild_kt<T, 0>(h, a, grid);
     else if (h->kt == 1) launch_kbuild_kt<T, 1>(h, a, grid);
     else        // general form: row and column points of both terms in LDS
-        hipLaunchKernelGGL((kbuild_kernel<T, 0, 2>), grid, dim3(256), (size_t)4 * a.d * TB * sizeof(T), h->cs, a);
+        hipLaunchKernelGGL((kbuild_kernel<T, 0, 2>), grid, dim3(256), a.d > KB_LDS_MAXD ? 64 : (size_t)4 * a.d * TB * sizeof(T), h->cs, a);
 }
 
 // Outer panel boundaries of the multi-kernel factorisation.  Far from the end the trailing update is long and hides a wider
@@ -1456,7 +1457,7 @@ int set_func_attrs(gphip_ctx* h) {
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)potrf_lds<T>()));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(panel_rows_kernel<T>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS));
-    if (h->kt == 2) {                          // general covariance form: both terms' row and column points in LDS
+    if (h->kt == 2 && h->d <= KB_LDS_MAXD) {   // general covariance form: both terms' row and column points in LDS
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>((kbuild_kernel<T, 0, 2>)),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * h->d * TB * sizeof(T))));
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(grad_reduce_general_kernel<T>),
@@ -1890,7 +1891,7 @@ static int create_ctx(const void* X, const void* y, int64_t N, int64_t d, int ke
     *out = nullptr;
     if (!X || !y) return GPHIP_ERR_ARG;
     if (N < 1 || d < 1) return GPHIP_ERR_DIM;
-    if (d > 32) return GPHIP_ERR_UNSUPPORTED;   // LDS-resident point tiles: 2*d*1 KiB <= 64 KiB
+    // (d > KB_LDS_MAXD = 32: the kernel build reads the point tiles from global memory instead of LDS; gradients stay limited)
     // kernel_id: a plain named kernel, or GPHIP_KERNEL_COMPOSE(term1, op, term2, offset)
     struct Base { int fam; bool ard; };
     auto base = [](int id, Base& b) {
@@ -2075,6 +2076,9 @@ int gphip_loglik_grad(gphip_handle h, const double* theta, int p, double* out, d
         return null_kernel_batch(h, theta, 1, out, nullptr, info, grad);
     }
     std::lock_guard<std::recursive_mutex> lk(h->mu);
+    // the gradient reductions keep (d + 1) point tiles (general form: 4 d + 1) in LDS: beyond KB_LDS_MAXD dimensions only the
+    // likelihood / fit / prediction paths are implemented (they read the points from global memory instead)
+    if (h->d > KB_LDS_MAXD) return fail(h, GPHIP_ERR_UNSUPPORTED, "gphip_loglik_grad supports input dimensions up to 32");
     double parts[2] = {0, 0};
     h->want_w = true;                          // (a multi-device handle factors on its first device: the K^-1 contraction needs the whole factor)
     int rc = eval_batch_local(h, theta, 1, p, out, parts, info);
@@ -2486,6 +2490,7 @@ static int predict_streamed(gphip_handle h, const void* Xs, int64_t M, double* m
         passes = std::max(passes, (double)((Mi + mc - 1) / mc));
     }
     g->replicate = 0;                                                  // a distributed factor: owned panels + receive buffers
+    g->two_hop = false;                                                // (whole panels, plain broadcasts: no agreement check precedes this call)
     if (failed == GPHIP_OK) {
         rc = group_resize_packed(h, g);
         if (rc) local_fail(rc, h->err);
@@ -2992,7 +2997,7 @@ int* option_slot(gphip_ctx* h, const char* name) {
         {"dataflow", &gphip_ctx::dataflow}, {"dataflow_max_nt", &gphip_ctx::dataflow_max_nt},
         {"dataflow_max_slots", &gphip_ctx::dataflow_max_slots}, {"dataflow_fine_nt", &gphip_ctx::dataflow_fine_nt},
         {"dataflow_tail", &gphip_ctx::dataflow_tail}, {"grad_potri", &gphip_ctx::grad_potri},
-        {"fused_eval", &gphip_ctx::fuse_option}, {"panel_left", &gphip_ctx::panel_left}, {"build_overlap", &gphip_ctx::build_overlap}, {"dataflow_lds_kib", &gphip_ctx::dataflow_lds_kib}, {"dataflow_park", &gphip_ctx::dataflow_park}, {"fuse_potrf", &gphip_ctx::fuse_potrf}, {"bcast_chunks", &gphip_ctx::bcast_chunks}, {"dataflow_occ3", &gphip_ctx::dataflow_occ3}, {"batch_groups", &gphip_ctx::batch_groups}, {"panel_rows", &gphip_ctx::panel_rows}, {"batch_group_min", &gphip_ctx::batch_group_min}, {"df_split", &gphip_ctx::df_split}, {"df_split_lds_kib", &gphip_ctx::df_split_lds_kib}, {"df_split_min_tasks", &gphip_ctx::df_split_min_tasks}, {"rest_mask", &gphip_ctx::rest_mask}, {"rest_mask_max_nt", &gphip_ctx::rest_mask_max_nt}, {"df_split_auto", &gphip_ctx::df_split_auto}, {"df_split_width", &gphip_ctx::df_split_width},
+        {"fused_eval", &gphip_ctx::fuse_option}, {"panel_left", &gphip_ctx::panel_left}, {"build_overlap", &gphip_ctx::build_overlap}, {"dataflow_lds_kib", &gphip_ctx::dataflow_lds_kib}, {"dataflow_park", &gphip_ctx::dataflow_park}, {"fuse_potrf", &gphip_ctx::fuse_potrf}, {"bcast_chunks", &gphip_ctx::bcast_chunks}, {"bcast_two_hop", &gphip_ctx::bcast_two_hop}, {"dataflow_occ3", &gphip_ctx::dataflow_occ3}, {"batch_groups", &gphip_ctx::batch_groups}, {"panel_rows", &gphip_ctx::panel_rows}, {"batch_group_min", &gphip_ctx::batch_group_min}, {"df_split", &gphip_ctx::df_split}, {"df_split_lds_kib", &gphip_ctx::df_split_lds_kib}, {"df_split_min_tasks", &gphip_ctx::df_split_min_tasks}, {"rest_mask", &gphip_ctx::rest_mask}, {"rest_mask_max_nt", &gphip_ctx::rest_mask_max_nt}, {"df_split_auto", &gphip_ctx::df_split_auto}, {"df_split_width", &gphip_ctx::df_split_width},
         {"max_slots", &gphip_ctx::max_slots}, {"shard_min_n", &gphip_ctx::shard_min_n},
         {"thin_tiles", &gphip_ctx::thin_tiles}, {"panel_wide", &gphip_ctx::panel_wide},
         {"la_main", &gphip_ctx::la_main}, {"rest_split", &gphip_ctx::rest_split},

@@ -31,6 +31,11 @@ struct RcclApi {
     int (*CommDestroy)(nccl_comm_t) = nullptr;
     int (*Broadcast)(const void*, void*, size_t, int, int, nccl_comm_t, hipStream_t) = nullptr;
     int (*AllReduce)(const void*, void*, size_t, int, int, nccl_comm_t, hipStream_t) = nullptr;
+    // optional (the two-hop panel broadcast: scatter by grouped send / recv, then an in-place all-gather)
+    int (*Send)(const void*, size_t, int, int, nccl_comm_t, hipStream_t) = nullptr;
+    int (*Recv)(void*, size_t, int, int, nccl_comm_t, hipStream_t) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, nccl_comm_t, hipStream_t) = nullptr;
+    bool two_hop_ok() const { return Send && Recv && AllGather; }
     int (*GroupStart)() = nullptr;
     int (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
@@ -65,6 +70,9 @@ inline const RcclApi& rccl() {
             GP_SYM(CommDestroy, "ncclCommDestroy");
             GP_SYM(Broadcast, "ncclBroadcast");
             GP_SYM(AllReduce, "ncclAllReduce");
+            GP_SYM(Send, "ncclSend");
+            GP_SYM(Recv, "ncclRecv");
+            GP_SYM(AllGather, "ncclAllGather");
             GP_SYM(GroupStart, "ncclGroupStart");
             GP_SYM(GroupEnd, "ncclGroupEnd");
             GP_SYM(GetErrorString, "ncclGetErrorString");

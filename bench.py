@@ -592,6 +592,21 @@ def main() -> None:
                       "rccl_ranks": ci["world"], "comm": ci["comm"], "factor_bytes_per_rank": hs.factor_bytes(),
                       "all_ok": bool(all(v[1] == 0 and np.isfinite(v[0]) for v in sv))}
             strong_failed = not strong["all_ok"]
+            if world > 2:
+                # the same five evaluations with every panel broadcast as scatter + in-place all-gather (option
+                # "bcast_two_hop": all links of the xGMI mesh carry 1 / world of a message at once instead of one ring)
+                hs.set_option("bcast_two_hop", 1)
+                hs.loglik(ths[0])
+                barrier()
+                t2 = time.perf_counter()
+                sv2 = [hs.loglik(ths[2 + i]) for i in range(5)]
+                barrier()
+                ts2 = torch.tensor([time.perf_counter() - t2], device=red_dev, dtype=torch.float64)
+                dist.all_reduce(ts2, op=dist.ReduceOp.MAX)
+                strong["two_hop_ms_per_eval"] = float(ts2.item()) / 5 * 1e3
+                strong["two_hop_speedup_vs_one_gpu_weak_step"] = (dt / args.steps) / (float(ts2.item()) / 5)
+                strong["two_hop_identical_results"] = bool(all(a[0] == b[0] and a[1] == b[1] for a, b in zip(sv, sv2)))
+                strong_failed = strong_failed or not strong["two_hop_identical_results"]
             hs.close()
         except Exception as exc:                                    # never let the extra break the headline
             strong = {"error": repr(exc)}

@@ -32,7 +32,8 @@ struct Segment {
     char data[CAP];
 };
 struct Comm { int rank, nranks; Segment* seg; };
-struct Op { const void* send; void* recv; size_t bytes; int root; Comm* comm; hipStream_t st; };
+// kind: 0 broadcast (in-process mode only), 1 send (peer = root field), 2 recv (peer = root field), 3 all-gather (in-process mode)
+struct Op { const void* send; void* recv; size_t bytes; int root; Comm* comm; hipStream_t st; int kind; };
 int g_depth = 0;
 Op g_ops[64];
 int g_nops = 0;
@@ -92,7 +93,7 @@ int ncclBroadcast(const void* send, void* recv, size_t count, int dtype, int roo
     const size_t bytes = count * type_size(dtype);
     if (!comm->seg) {                               // in-process communicator: executed at ncclGroupEnd
         if (g_depth < 1 || g_nops >= 64) return 4;
-        g_ops[g_nops++] = Op{send, recv, bytes, root, comm, st};
+        g_ops[g_nops++] = Op{send, recv, bytes, root, comm, st, 0};
         return 0;
     }
     if (bytes > CAP) return 3;
@@ -129,10 +130,97 @@ int ncclAllReduce(const void* send, void* recv, size_t count, int dtype, int op 
     if (hipMemcpyAsync(recv, tot, count * 8, hipMemcpyHostToDevice, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return 1;
     return 0;
 }
+// ---- the three calls of the library's two-hop panel broadcast.  Point-to-point calls are only meaningful inside a group
+// (as in NCCL); they are recorded and executed at ncclGroupEnd.  Multi-process mode implements exactly the pattern the
+// library issues -- ONE rank sends equal pieces to all the others, every other rank receives one piece from it -- as a
+// collective step over the shared segment (piece for rank r at r * bytes).
+int ncclSend(const void* send, size_t count, int dtype, int peer, void* c, hipStream_t st) {
+    if (g_depth < 1 || g_nops >= 64) return 4;
+    g_ops[g_nops++] = Op{send, nullptr, count * type_size(dtype), peer, static_cast<Comm*>(c), st, 1};
+    return 0;
+}
+int ncclRecv(void* recv, size_t count, int dtype, int peer, void* c, hipStream_t st) {
+    if (g_depth < 1 || g_nops >= 64) return 4;
+    g_ops[g_nops++] = Op{nullptr, recv, count * type_size(dtype), peer, static_cast<Comm*>(c), st, 2};
+    return 0;
+}
+int ncclAllGather(const void* send, void* recv, size_t count, int dtype, void* c, hipStream_t st) {
+    Comm* comm = static_cast<Comm*>(c);
+    const size_t bytes = count * type_size(dtype);
+    if (!comm->seg) {                               // in-process communicator: executed at ncclGroupEnd
+        if (g_depth < 1 || g_nops >= 64) return 4;
+        g_ops[g_nops++] = Op{send, recv, bytes, -1, comm, st, 3};
+        return 0;
+    }
+    if (bytes * (size_t)comm->nranks > CAP) return 3;
+    if (hipMemcpyAsync(comm->seg->data + (size_t)comm->rank * bytes, send, bytes, hipMemcpyDeviceToHost, st) != hipSuccess) return 1;
+    if (hipStreamSynchronize(st) != hipSuccess) return 1;
+    pthread_barrier_wait(&comm->seg->bar);
+    for (int r = 0; r < comm->nranks; ++r) {
+        char* dst = static_cast<char*>(recv) + (size_t)r * bytes;
+        if (r == comm->rank && dst == send) continue;   // in place
+        if (hipMemcpyAsync(dst, comm->seg->data + (size_t)r * bytes, bytes, hipMemcpyHostToDevice, st) != hipSuccess) return 1;
+    }
+    if (hipStreamSynchronize(st) != hipSuccess) return 1;
+    pthread_barrier_wait(&comm->seg->bar);
+    return 0;
+}
 int ncclGroupStart() { ++g_depth; return 0; }
 int ncclGroupEnd() {
     if (--g_depth > 0) return 0;
     int rc = 0;
+    // point-to-point operations recorded in this group
+    bool p2p = false, gather = false;
+    for (int i = 0; i < g_nops; ++i) { p2p = p2p || g_ops[i].kind == 1 || g_ops[i].kind == 2; gather = gather || g_ops[i].kind == 3; }
+    if (p2p) {
+        Comm* c0 = g_ops[0].comm;
+        if (c0->seg) {
+            // multi-process: this rank either sends (pieces to everybody else) or receives its one piece
+            for (int i = 0; i < g_nops && rc == 0; ++i) {
+                const Op& o = g_ops[i];
+                if (o.kind != 1) continue;
+                if (o.bytes * (size_t)o.comm->nranks > CAP) { rc = 3; break; }
+                if (hipMemcpyAsync(o.comm->seg->data + (size_t)o.root * o.bytes, o.send, o.bytes, hipMemcpyDeviceToHost, o.st) != hipSuccess) rc = 1;
+            }
+            for (int i = 0; i < g_nops && rc == 0; ++i)
+                if (g_ops[i].kind == 1 && hipStreamSynchronize(g_ops[i].st) != hipSuccess) rc = 1;
+            pthread_barrier_wait(&c0->seg->bar);
+            for (int i = 0; i < g_nops && rc == 0; ++i) {
+                const Op& o = g_ops[i];
+                if (o.kind != 2) continue;
+                if (hipMemcpyAsync(o.recv, o.comm->seg->data + (size_t)o.comm->rank * o.bytes, o.bytes, hipMemcpyHostToDevice, o.st) != hipSuccess ||
+                    hipStreamSynchronize(o.st) != hipSuccess) rc = 1;
+            }
+            pthread_barrier_wait(&c0->seg->bar);
+        } else {
+            // in-process: match every recv (on rank b, from peer a) with the send (on rank a, to peer b)
+            for (int i = 0; i < g_nops && rc == 0; ++i) {
+                const Op& r = g_ops[i];
+                if (r.kind != 2) continue;
+                const Op* sd = nullptr;
+                for (int j = 0; j < g_nops; ++j)
+                    if (g_ops[j].kind == 1 && g_ops[j].comm->rank == r.root && g_ops[j].root == r.comm->rank) sd = &g_ops[j];
+                if (!sd || sd->bytes != r.bytes) { rc = 4; break; }
+                if (hipStreamSynchronize(sd->st) != hipSuccess ||
+                    hipMemcpyAsync(r.recv, sd->send, r.bytes, hipMemcpyDeviceToDevice, r.st) != hipSuccess) rc = 1;
+            }
+        }
+        g_nops = 0;
+        return rc;
+    }
+    if (gather) {                                   // in-process all-gather: every rank's piece to every other rank's buffer
+        for (int i = 0; i < g_nops && rc == 0; ++i)
+            if (hipStreamSynchronize(g_ops[i].st) != hipSuccess) rc = 1;
+        for (int d = 0; d < g_nops && rc == 0; ++d)
+            for (int sI = 0; sI < g_nops && rc == 0; ++sI) {
+                const Op &dst = g_ops[d], &src = g_ops[sI];
+                char* to = static_cast<char*>(dst.recv) + (size_t)src.comm->rank * src.bytes;
+                if (to == src.send) continue;
+                if (hipMemcpyAsync(to, src.send, src.bytes, hipMemcpyDeviceToDevice, dst.st) != hipSuccess) rc = 1;
+            }
+        g_nops = 0;
+        return rc;
+    }
     const Op* src = nullptr;
     for (int i = 0; i < g_nops; ++i)
         if (g_ops[i].comm->rank == g_ops[i].root) src = &g_ops[i];

@@ -25,12 +25,17 @@ def close(a, b, n, rtol=1e-8):
     return abs(a - b) <= rtol * max(abs(b), float(n))
 
 
-@pytest.mark.parametrize("n,d,kernel,panel,world", [(1500, 3, "se_ard", 2, 2), (900, 2, "matern52_ard", 1, 3),
-                                                    (100, 2, "se_ard", 4, 2)])     # last: rank 1 owns no panel at all
-def test_rank_handles_in_separate_processes(tmp_path, n, d, kernel, panel, world):
+@pytest.mark.parametrize("n,d,kernel,panel,world,two_hop", [
+    (1500, 3, "se_ard", 2, 2, 0), (900, 2, "matern52_ard", 1, 3, 0),
+    (100, 2, "se_ard", 4, 2, 0),                 # rank 1 owns no panel at all
+    (900, 2, "matern52_ard", 1, 3, 1),           # every panel broadcast as scatter (send / recv) + in-place all-gather
+    (1300, 3, "se_ard", 2, 4, 1)])
+def test_rank_handles_in_separate_processes(tmp_path, n, d, kernel, panel, world, two_hop):
     fake = build.build_fake_rccl()
-    env = dict(os.environ, GPHIP_NO_TORCH="1", GPHIP_RCCL_PATH=fake, FAKE_RCCL_SHM=f"/gphip_fake_{os.getpid()}_{n}",
+    env = dict(os.environ, GPHIP_NO_TORCH="1", GPHIP_RCCL_PATH=fake, FAKE_RCCL_SHM=f"/gphip_fake_{os.getpid()}_{n}_{two_hop}",
                LD_LIBRARY_PATH="/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+    if two_hop:
+        env["GPHIP_OPTIONS"] = "bcast_two_hop=1"     # (every rank of the job: the setting is part of the agreement check)
     outs = [str(tmp_path / f"rank{r}.json") for r in range(world)]
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "multiproc_worker.py"), str(r), str(world),
                                outs[r], str(n), str(d), kernel, str(panel)], env=env, cwd=ROOT,
@@ -67,7 +72,8 @@ def test_rank_handles_in_separate_processes(tmp_path, n, d, kernel, panel, world
     assert all(r["parts"] == res[0]["parts"] for r in res)
 
 
-def test_single_process_grouped_rccl_path(tmp_path):
+@pytest.mark.parametrize("two_hop", [0, 1])
+def test_single_process_grouped_rccl_path(tmp_path, two_hop):
     """gphip_create(.., devices, ndev > 1) with RCCL: ncclCommInitAll, one communicator per local rank, the panel
     broadcast as ncclGroupStart / per-rank ncclBroadcast / ncclGroupEnd issued by ONE host thread.  Real RCCL needs
     distinct devices, so on a one-GPU box the run binds the tests-only collective library (in-process mode) and
@@ -76,6 +82,8 @@ def test_single_process_grouped_rccl_path(tmp_path):
     fake = build.build_fake_rccl()
     env = dict(os.environ, GPHIP_NO_TORCH="1", GPHIP_RCCL_PATH=fake, GPHIP_COMM="rccl",
                LD_LIBRARY_PATH="/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+    if two_hop:
+        env["GPHIP_OPTIONS"] = "bcast_two_hop=1"
     out = str(tmp_path / "inproc.json")
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "inproc_worker.py"), out, str(n), str(d), kernel,
                         str(world), str(panel)], env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)

@@ -457,7 +457,7 @@ def test_predict_samples_batched_equals_per_sample():
 
 def test_edge_shapes_and_chunking():
     """Ragged / extreme shapes: M = 1 test point, more right-hand sides than one 2048-row chunk,
-    d = 32 (largest supported, generic-d kernel), batch larger than the slot cap, d > 32 rejected."""
+    d = 32 (largest LDS-staged dimension of the generic-d kernel), d > 32 (global-memory point tiles), batch larger than the slot cap."""
     X, y = syn.make_dataset(150, 32)
     th = syn.default_theta("se_ard", 32)
     th[:32] = 3.0
@@ -469,9 +469,28 @@ def test_edge_shapes_and_chunking():
     mo, so = orc.predict_internal("se_ard", th, X, y, X[:1])
     assert mu.shape == (1,) and close(mu[0], mo[0], 1, 1e-7) and close(np.sqrt(var[0]), so[0], 1, 1e-7)
     h.close()
-    with pytest.raises(_lib.GphipError) as e:
-        _lib.Handle(np.zeros((10, 33)), np.zeros(10), "se_ard")
-    assert e.value.status == 6
+    # d > 32 (round 4): the kernel build reads the point tiles from global memory instead of LDS -- any dimension, as the
+    # reference's covarianceMatrix takes (BGP:29-43); named, composed and fp32 kernels, covariance / likelihood / prediction
+    for dd, kern, dtype in ((33, "se_ard", 64), (100, "matern52_ard", 64), (40, "se_ard+matern32_ard+const", 64), (48, "se_ard", 32)):
+        X, y = syn.make_dataset(300, dd)
+        th = syn.default_theta(kern, dd) if "+" not in kern else np.concatenate([np.full(dd, 4.0), [1.0], np.full(dd, 6.0), [0.7], [0.2], [0.3]])
+        if "+" not in kern:
+            th[:dd] = 4.0
+        h = _lib.Handle(X, y, kern, dtype=dtype)
+        tol = 1e-8 if dtype == 64 else 1e-3
+        np.testing.assert_allclose(h.covariance(th), orc.covariance_matrix(kern, th, X), rtol=1e-12 if dtype == 64 else 1e-5, atol=1e-14 if dtype == 64 else 1e-6)
+        ll, info = h.loglik(th)
+        assert info == 0 and close(ll, orc.log_likelihood(kern, th, X, y), 300, tol), (dd, kern, ll)
+        assert h.fit(th) == 0
+        Xs = syn.make_test_points(9, dd)
+        mu, var = h.predict(Xs)
+        mo, so = orc.predict_internal(kern, th, X, y, Xs)
+        np.testing.assert_allclose(mu, mo, rtol=1e-7 if dtype == 64 else 2e-3, atol=1e-9 if dtype == 64 else 2e-3)
+        np.testing.assert_allclose(np.sqrt(var), so, rtol=1e-7 if dtype == 64 else 2e-3)
+        with pytest.raises(_lib.GphipError) as e:
+            h.loglik_grad(th)
+        assert e.value.status == 6                               # gradients: d <= 32
+        h.close()
     # nrhs = 2100 > 2048 -> two chunks through gphip_solve
     X, y = syn.make_dataset(130, 2)
     th = np.array([0.8, 1.2, 1.0, 0.3])
