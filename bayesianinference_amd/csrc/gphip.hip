@@ -121,6 +121,7 @@ struct gphip_ctx {
     int supertile = 2;                 // trailing SYRK tile order: 0 column-major chunks per XCD, 1 static 8x8 super-tiles per XCD
                                        // (measured slower: unequal loads), 2 the tile LIST in 8x8 super-tile order, equal chunks per XCD
     int latency_gemm = 1, latency_tiles = 256;   // launches of <= latency_tiles tiles use the latency GEMM shape
+    int latency_max_nt = 48;                     // ... for problems of at most this many tile columns (beyond: its 147 KB of LDS evicts trailing-SYRK workgroups)
     int dataflow = 1, dataflow_max_nt = 96, dataflow_max_slots = 8;   // single-launch dataflow Cholesky: latency regime only
     int dataflow_fine_nt = 96;                   // ... with 64x64 tiles up to this many 128-tiles (fp64; measured best up to N = 12288)
     int panel_left = -1;                         // in-panel updates left-looking: -1 auto (batches), 0 never, 1 always
@@ -593,7 +594,7 @@ void launch_gemm(gphip_ctx* h, int cls, Opnd<T> Co, Opnd<T> Ao, Opnd<T> Bo, int 
     // tile per CU, 4x4 waves / 4 LDS stages with counted DMA waits (latency)
     // (measured: -8 % per evaluation at N=4096, neutral at 8192, +5 % at 32768 where its 147 KB of LDS keeps
     //  trailing-SYRK workgroups off the CU -- so it is used for small problems only)
-    const bool lat = h->latency_gemm && !g.super && h->Nt <= 48 && (long)grid_x * nslots <= h->latency_tiles;
+    const bool lat = h->latency_gemm && !g.super && h->Nt <= h->latency_max_nt && (long)grid_x * nslots <= h->latency_tiles;
     // a panel-stream update asked to factor the diagonal tile it updates (queue_panel / queue_factor): 256-thread shape only
     g.fuse_b = -1;
     h->fuse_done = false;
@@ -2993,7 +2994,7 @@ int* option_slot(gphip_ctx* h, const char* name) {
     static const Entry table[] = {
         {"panel", &gphip_ctx::panel}, {"profile", &gphip_ctx::profile}, {"xcd_swizzle", &gphip_ctx::swizzle},
         {"lookahead", &gphip_ctx::lookahead}, {"supertile", &gphip_ctx::supertile},
-        {"latency_gemm", &gphip_ctx::latency_gemm}, {"latency_tiles", &gphip_ctx::latency_tiles},
+        {"latency_gemm", &gphip_ctx::latency_gemm}, {"latency_tiles", &gphip_ctx::latency_tiles}, {"latency_max_nt", &gphip_ctx::latency_max_nt},
         {"dataflow", &gphip_ctx::dataflow}, {"dataflow_max_nt", &gphip_ctx::dataflow_max_nt},
         {"dataflow_max_slots", &gphip_ctx::dataflow_max_slots}, {"dataflow_fine_nt", &gphip_ctx::dataflow_fine_nt},
         {"dataflow_tail", &gphip_ctx::dataflow_tail}, {"grad_potri", &gphip_ctx::grad_potri},

@@ -255,8 +255,21 @@ int gphip_ns_crude_weights(const double* points, const double* loglik, int64_t m
  *   "share_local_panels"  0/1 (default 1): ranks that share the owner's GPU (virtual ranks of a 1-GPU box, device-copy
  *                  communicator) read a factored panel where the owner keeps it instead of copying it; 0 forces the copies
  *                  through the rotating receive buffers (what distinct GPUs do)
- *   "panel", "shard_min_n", "replicate_factor" must have the same value on every rank of a multi-process job (checked by
- *   one small all-reduce at the start of every sharded evaluation: a mismatch fails the call on ALL ranks). */
+ *   "bcast_two_hop"  0/1 (default 0): sharded evaluation over RCCL with more than two ranks -- every panel message goes out as
+ *                  scatter (the owner sends piece r to rank r: grouped ncclSend / ncclRecv) + in-place ncclAllGather instead of one
+ *                  ncclBroadcast, so that all links of the xGMI mesh carry 1 / world of the message at once (never measured on
+ *                  real multi-GPU hardware; results are bit-identical; must agree on all ranks: checked)
+ *   Round-4 experiments, all bit-identical to the default and all measured SLOWER on one MI355X (kept off):
+ *   "df_split" r / "df_split_width" w / "df_split_lds_kib": the 64-tile dataflow launch split over two CU-masked streams --
+ *                  the w tiles of every column nearest the diagonal as their own launch on r reserved CUs per XCD;
+ *   "rest_mask" r: look-ahead schedule, the trailing updates on a stream whose CU mask leaves r CUs per XCD to the panel stream;
+ *   "batch_groups" g / "batch_group_min": a large theta batch as g phase-shifted slot groups on their own stream pairs;
+ *   "panel_rows"   batches: the rows below a panel's diagonal block handled by one fused row-panel kernel.
+ *   "debug_fail_alloc" / "debug_fail_hip" n: tests only -- the n-th device allocation of the next slot allocation / the n-th checked
+ *                  HIP call of the next collective sequence fails (fault injection of the multi-process tests).
+ *   "panel", "shard_min_n", "replicate_factor", "bcast_chunks", "bcast_two_hop" must have the same value on every rank of a
+ *   multi-process job (checked by one small all-reduce at the start of every sharded evaluation: a mismatch fails the call on ALL
+ *   ranks). */
 int gphip_set_option(gphip_handle h, const char* name, double value);
 int gphip_get_option(gphip_handle h, const char* name, double* value);
 /* The environment variable GPHIP_OPTIONS="name=value,name=value" presets options for every handle the process

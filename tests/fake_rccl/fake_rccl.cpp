@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 #include <pthread.h>
 #include <sys/mman.h>
+#include <sys/stat.h>
 #include <unistd.h>
 
 #include <atomic>
@@ -56,6 +57,14 @@ int ncclCommInitRank(void** comm, int nranks, FakeId, int rank) {
     } else {
         for (int i = 0; i < 20000 && fd < 0; ++i) { fd = shm_open(name, O_RDWR, 0600); if (fd < 0) usleep(1000); }
         if (fd < 0) return 2;
+        // rank 0 creates the object and THEN sizes it: touching a page of a still-empty object is a SIGBUS (seen once as a
+        // "hung" test on a cold box: this rank died, rank 0 waited at the barrier) -- wait until it has its full size
+        struct stat sb;
+        for (int i = 0; i < 20000; ++i) {
+            if (fstat(fd, &sb) == 0 && (size_t)sb.st_size >= sizeof(Segment)) break;
+            usleep(1000);
+        }
+        if (fstat(fd, &sb) != 0 || (size_t)sb.st_size < sizeof(Segment)) { close(fd); return 2; }
     }
     void* p = mmap(nullptr, sizeof(Segment), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
     close(fd);
