@@ -1731,6 +1731,8 @@ struct DfArgs {
     unsigned long long ticket_base;           // value of *ticket before this launch
     int* abort_flag;
     int nd, nslots, epoch;                    // nd = diagonal blocks = Npad / TBX; tile row nd = the rhs rows
+    int ncols;                                // tile columns this launch factors (0 = all): a launch restricted to the columns of ONE outer
+                                              // panel of the sharded schedule contains no diagonal task for the column behind its last one
     int cw;                                   // split launch: tiles per column (from the diagonal down) that belong to the chain launch
     int role;                                 // 0: this launch runs every task; split launch on CU-masked streams: 1 = the
                                               // diagonal (chain) tasks on the reserved CUs, 2 = all other tasks on the rest
@@ -2132,7 +2134,7 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g, Th
     // last slab straight from LDS -- one flag hop per column on the chain instead of two.
     constexpr bool FUSE = TBX == 64;
     const bool diagx = FUSE && i == j && j >= 1 && j < g.nd;     // solves (j,j-1) itself
-    const bool accp = FUSE && i == j + 1 && i < g.nd;            // tile (j+1,j): accumulate only
+    const bool accp = FUSE && i == j + 1 && i < g.nd && (g.ncols <= 0 || i < g.ncols);   // tile (j+1,j): accumulate only (its solver, diagonal task j+1, must be part of this launch)
     const int jacc = diagx ? j - 1 : j;                          // slabs taken from memory
 
     // ---- accumulate the updates of all earlier columns

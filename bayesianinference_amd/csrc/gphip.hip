@@ -60,6 +60,9 @@ struct gphip_ctx {
     hipEvent_t ev_built0 = nullptr;              // queue_build -> queue_factor: "the tile columns of panel 0 are built" (split build)
     int dist_first_factored = -1;                // sharded evaluation: outer panel whose first diagonal block the last LA update factored
     int bcast_chunks = 1;                        // sharded evaluation: a factored panel is broadcast one tile column at a time
+    int dist_panel_df = 0;                       // sharded evaluation, fp64: the owner factors its outer panel as ONE 64-tile dataflow launch
+                                                 // (latency-shaped owner path: flags instead of 3 launches per tile column)
+    bool dist_df_active = false;                 // the current sharded evaluation runs with dataflow panels (64-block partials / inverses)
     int bcast_two_hop = 0;                       // sharded evaluation over RCCL, world > 2: every broadcast as scatter (send / recv) + in-place all-gather
     std::vector<hipEvent_t>* col_events = nullptr;   // queue_panel: record "tile column final" events here (owner of a sharded panel)
     int fuse_potrf = 1;                          // option: panel-stream updates factor the diagonal tile they have just updated
@@ -776,12 +779,13 @@ hipStream_t masked_rest_stream(gphip_ctx* h, int res) {
 // c0 > 0 (128-tiles only): factor the trailing submatrix that starts at tile column c0 -- the tail of the
 // look-ahead schedule, already updated by every earlier panel.  No finalize here.
 template <typename T, int TBX, int OCC = 2, int NST = 2, bool BUILD = false>
-void launch_dataflow(gphip_ctx* h, int nslots, int c0 = 0, double* part = nullptr, long pstride = 0) {
+void launch_dataflow(gphip_ctx* h, int nslots, int c0 = 0, double* part = nullptr, long pstride = 0, int ncols = 0) {
     const int nd = (int)(h->Npad / TBX) - c0, R = nd + 1;
-    const long tasks = (long)R * (R + 1) / 2 * nslots;
-    if (getenv("GPHIP_DEBUG")) fprintf(stderr, "gphip debug: launch_dataflow TBX=%d nslots=%d c0=%d tasks=%ld\n", TBX, nslots, c0, tasks);
+    // ncols > 0: only the first ncols tile columns (an outer panel of the sharded schedule) -- a prefix of the column-major task list
+    const long tasks = (ncols > 0 && ncols < R ? (long)ncols * R - (long)ncols * (ncols - 1) / 2 : (long)R * (R + 1) / 2) * nslots;
     DfArgs<T> g{};
-    g.A = (T*)h->dA; g.bstride = h->slot_elems; g.R128 = (int)h->R; g.c0 = c0;
+    g.A = (T*)(h->ws_override ? h->ws_override : h->dA); g.bstride = h->slot_elems; g.R128 = (int)h->R; g.c0 = c0;
+    g.ncols = (ncols > 0 && ncols < R) ? ncols : 0;
     g.W = (T*)h->dW + (long)c0 * TBX * TBX; g.w_bstride = (long)h->Nt * TB * TB;
     g.partial = h->dPartial + c0; g.p_bstride = h->Npad / TBX;
     if (part) { g.partial = part; g.p_bstride = pstride; }       // (a 64-tile tail keeps its own list of blocks)
@@ -817,7 +821,7 @@ void launch_dataflow(gphip_ctx* h, int nslots, int c0 = 0, double* part = nullpt
     }
     if constexpr (TBX == 64) {
         const int res = h->df_split >= 0 ? h->df_split : (tasks >= h->df_split_min_tasks && nslots == 1 ? h->df_split_auto : 0);
-        if (res > 0 && R >= 4 && split_streams(h, res)) {
+        if (res > 0 && R >= 4 && g.ncols == 0 && split_streams(h, res)) {
             // chain launch: diagonal tasks, ONE workgroup per reserved CU (LDS request); bulk launch: everything else
             hipEvent_t e0 = sync_event(h), e1 = sync_event(h), e2 = sync_event(h);
             (void)hipEventRecord(e0, h->stream);
@@ -1688,8 +1692,9 @@ template <typename T>
 int queue_finalize(gphip_ctx* h) {         // sharded evaluation: the corner tile lives in rank 0's storage (slot nouter)
     const int nouter = (int)((h->Nt + h->panel - 1) / h->panel);
     const long corner = h->dist_rank == 0 ? (h->dist_adj[(size_t)nouter] + tile_index((int)h->Nt, (int)h->Nt, (int)h->R)) * TS : 0l;
+    // (dataflow panels: log-det partials per 64-block, 2 Nt entries; un-owned entries stay zero either way)
     hipLaunchKernelGGL(finalize_kernel<T>, dim3(1), dim3(64), 0, h->stream, (const T*)h->dist_base, 0l, corner, h->dPartial,
-                       (int)h->Nt, h->dRes);
+                       (int)(h->dist_df_active ? 2 * h->Nt : h->Nt), h->dRes);
     return 0;
 }
 
@@ -2885,7 +2890,8 @@ int gphip_dist_begin(gphip_handle h, const double* theta, int p, int rank, int w
     rc = copy_theta(h, 1);
     if (rc) return rc;
     HIPCHK(hipMemsetAsync(h->dInfo, 0, 4, h->stream));
-    HIPCHK(hipMemsetAsync(h->dPartial, 0, (size_t)h->Nt * 8, h->stream));
+    h->dist_df_active = h->dist_panel_df != 0 && h->dtype == 64 && h->dataflow != 0;
+    HIPCHK(hipMemsetAsync(h->dPartial, 0, (size_t)2 * h->Nt * 8, h->stream));
     h->cs = h->stream;
     DISPATCH(h, queue_build, h, 1);
     h->pw_mean_on = h->pw_nug_on = false;
@@ -2909,7 +2915,17 @@ int gphip_dist_factor_panel(gphip_handle h, int k, void* packed) {
     h->ws_override = dist_panel_base(h, k);
     const bool first_factored = h->dist_first_factored == k;       // (by this rank's look-ahead update of the panel)
     h->dist_first_factored = -1;
-    DISPATCH(h, queue_panel, h, (int)K0, (int)(K1 - K0), 1, first_factored);
+    if (h->dist_df_active) {
+        // Latency-shaped owner path (round 4): the whole panel -- its 2 nin 64-wide tile columns over all rows below -- as ONE
+        // dataflow launch on the panel stream: the chain is 2 nin flag hops (~22 us each) instead of 3 dependent launches per
+        // 128-wide column.  Meant for an owner whose chip is mostly idle (its share of the trailing update is 1 / world).
+        hipStream_t keep = h->stream;
+        h->stream = h->pstream;
+        launch_dataflow<double, 64>(h, 1, 2 * (int)K0, nullptr, 0, 2 * (int)(K1 - K0));
+        h->stream = keep;
+    } else {
+        DISPATCH(h, queue_panel, h, (int)K0, (int)(K1 - K0), 1, first_factored);
+    }
     h->ws_override = nullptr;
     if (packed && packed != (void*)dist_panel_range(h, k))
         HIPCHK(hipMemcpyAsync(packed, dist_panel_range(h, k), (size_t)rows * cols * h->es, hipMemcpyDeviceToDevice, h->pstream));
@@ -2946,7 +2962,7 @@ int gphip_dist_update(gphip_handle h, int k, const void* packed, int j_first, in
     if (cnt > 0) {
         // the look-ahead update of the NEXT panel (this rank owns it) also factors that panel's first diagonal block
         // (fuse_potrf): gphip_dist_factor_panel then starts at the panel solve
-        const bool la_one = on_panel_stream && h->fuse_potrf && je - jb == 1;
+        const bool la_one = on_panel_stream && h->fuse_potrf && je - jb == 1 && !h->dist_df_active;
         if (W == 1) {            // adjacent panels (and the corner tile right behind them): one triangular launch
             if (la_one) h->fuse_b = j0 * P;
             DISPATCH(h, queue_dist_update, h, packed, K0, (long)rows, (long)cols, j0 * P,
@@ -2977,9 +2993,16 @@ int gphip_dist_end(gphip_handle h, double* logdet_partial, double* quad, int* in
     HIPCHK(hipMemcpyAsync(h->hRes, h->dRes, 16, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipMemcpyAsync(h->hInfo, h->dInfo, 4, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->pstream));
+    if (h->dist_df_active)                     // dataflow panels: did a dependency wait hit its spin limit?
+        HIPCHK(hipMemcpyAsync(h->hInfo + 1, reinterpret_cast<int*>(h->dTicket + 1), 4, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipGetLastError());
     harvest(h);
+    if (h->dist_df_active && h->hInfo[1] != 0) {
+        HIPCHK(hipMemsetAsync(h->dTicket + 1, 0, 8 + DF_PARK_SLOTS * 4, h->stream));
+        h->dist_world = 0; h->dist_rank = 0;
+        return fail(h, GPHIP_ERR_HIP, "dataflow panel schedule timed out (set option dist_panel_df=0 and report)");
+    }
     *logdet_partial = h->hRes[0];
     *quad = (h->dist_rank == 0) ? h->hRes[1] : 0.0;
     *info = h->dist_theta_ok ? h->hInfo[0] : GPHIP_INFO_NAN;
@@ -2998,7 +3021,7 @@ int* option_slot(gphip_ctx* h, const char* name) {
         {"dataflow", &gphip_ctx::dataflow}, {"dataflow_max_nt", &gphip_ctx::dataflow_max_nt},
         {"dataflow_max_slots", &gphip_ctx::dataflow_max_slots}, {"dataflow_fine_nt", &gphip_ctx::dataflow_fine_nt},
         {"dataflow_tail", &gphip_ctx::dataflow_tail}, {"grad_potri", &gphip_ctx::grad_potri},
-        {"fused_eval", &gphip_ctx::fuse_option}, {"panel_left", &gphip_ctx::panel_left}, {"build_overlap", &gphip_ctx::build_overlap}, {"dataflow_lds_kib", &gphip_ctx::dataflow_lds_kib}, {"dataflow_park", &gphip_ctx::dataflow_park}, {"fuse_potrf", &gphip_ctx::fuse_potrf}, {"bcast_chunks", &gphip_ctx::bcast_chunks}, {"bcast_two_hop", &gphip_ctx::bcast_two_hop}, {"dataflow_occ3", &gphip_ctx::dataflow_occ3}, {"batch_groups", &gphip_ctx::batch_groups}, {"panel_rows", &gphip_ctx::panel_rows}, {"batch_group_min", &gphip_ctx::batch_group_min}, {"df_split", &gphip_ctx::df_split}, {"df_split_lds_kib", &gphip_ctx::df_split_lds_kib}, {"df_split_min_tasks", &gphip_ctx::df_split_min_tasks}, {"rest_mask", &gphip_ctx::rest_mask}, {"rest_mask_max_nt", &gphip_ctx::rest_mask_max_nt}, {"df_split_auto", &gphip_ctx::df_split_auto}, {"df_split_width", &gphip_ctx::df_split_width},
+        {"fused_eval", &gphip_ctx::fuse_option}, {"panel_left", &gphip_ctx::panel_left}, {"build_overlap", &gphip_ctx::build_overlap}, {"dataflow_lds_kib", &gphip_ctx::dataflow_lds_kib}, {"dataflow_park", &gphip_ctx::dataflow_park}, {"fuse_potrf", &gphip_ctx::fuse_potrf}, {"bcast_chunks", &gphip_ctx::bcast_chunks}, {"bcast_two_hop", &gphip_ctx::bcast_two_hop}, {"dist_panel_df", &gphip_ctx::dist_panel_df}, {"dataflow_occ3", &gphip_ctx::dataflow_occ3}, {"batch_groups", &gphip_ctx::batch_groups}, {"panel_rows", &gphip_ctx::panel_rows}, {"batch_group_min", &gphip_ctx::batch_group_min}, {"df_split", &gphip_ctx::df_split}, {"df_split_lds_kib", &gphip_ctx::df_split_lds_kib}, {"df_split_min_tasks", &gphip_ctx::df_split_min_tasks}, {"rest_mask", &gphip_ctx::rest_mask}, {"rest_mask_max_nt", &gphip_ctx::rest_mask_max_nt}, {"df_split_auto", &gphip_ctx::df_split_auto}, {"df_split_width", &gphip_ctx::df_split_width},
         {"max_slots", &gphip_ctx::max_slots}, {"shard_min_n", &gphip_ctx::shard_min_n},
         {"thin_tiles", &gphip_ctx::thin_tiles}, {"panel_wide", &gphip_ctx::panel_wide},
         {"la_main", &gphip_ctx::la_main}, {"rest_split", &gphip_ctx::rest_split},

@@ -69,6 +69,45 @@ def test_sharded_loglik_matches_oracle_and_single_device(n, d, kernel, world, pa
     gd.close(); g.close(); h.close()
 
 
+@pytest.mark.parametrize("n,d,kernel,world,panel", [(1500, 3, "se_ard", 2, 2), (1500, 3, "matern52_ard", 3, 1), (8192, 8, "se_ard", 8, 4),
+                                                    (100, 2, "se_ard", 3, 4), (1300, 4, "matern52", 5, 3)])
+def test_sharded_loglik_with_dataflow_panels(n, d, kernel, world, panel):
+    """Option dist_panel_df (round 4, the latency-shaped owner path): the owner factors its outer panel as ONE 64-tile dataflow
+    launch restricted to the panel's columns instead of three launches per tile column.  Same factorisation up to the summation
+    order inside 64-blocks: oracle / single-device values at the usual bars, bit-repeatable, verdicts through the reduction, a
+    sharded fit (block inverses rebuilt) and the streamed prediction."""
+    X, y = syn.make_dataset(n, d)
+    th = syn.default_theta(kernel, d)
+    g = _lib.Handle(X, y, kernel, device=[0] * world)
+    g.set_option("panel", panel)
+    g.set_option("shard_min_n", 0)
+    g.set_option("dist_panel_df", 1)
+    ll, ld, qd, inf = g.loglik_parts(th)
+    assert inf == 0
+    h = _lib.Handle(X, y, kernel)
+    l1, ld1, qd1, _ = h.loglik_parts(th)
+    assert close(ll, l1, n, 1e-10) and close(ld, ld1, n, 1e-10) and close(qd, qd1, n, 1e-9)
+    if n <= 2000:
+        want = orc.log_likelihood(kernel, th, X, y, parts=True)
+        assert close(ll, want[0], n) and close(ld, want[1], n) and close(qd, want[2], n)
+    assert g.loglik_parts(th)[0] == ll                   # bit-repeatable
+    g.set_option("share_local_panels", 0)                # copies through the receive buffers, like distinct GPUs
+    assert close(g.loglik(th * 1.07)[0], h.loglik(th * 1.07)[0], n, 1e-10)
+    bad = th.copy()
+    bad[0] = np.nan
+    assert g.loglik(bad)[1] == _lib.INFO_NAN and g.loglik(th)[1] == 0
+    if n >= 1000 and n <= 2000:
+        Xs = syn.make_test_points(300, d)
+        mo, so = orc.predict_internal(kernel, th, X, y, Xs)
+        for replicate in (0, 1):
+            g.set_option("replicate_factor", replicate)
+            assert g.fit(th) == 0
+            mu, var = g.predict(Xs)
+            np.testing.assert_allclose(mu, mo, rtol=1e-7, atol=1e-9)
+            np.testing.assert_allclose(np.sqrt(var), so, rtol=1e-7)
+    g.close(); h.close()
+
+
 @pytest.mark.parametrize("replicate", [0, 1])
 def test_sharded_fit_and_predict_shards_test_points(replicate):
     """C3.  replicate_factor = 1: after a sharded fit EVERY rank holds all of L, z and the block
