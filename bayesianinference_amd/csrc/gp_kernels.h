@@ -2121,6 +2121,20 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g, Th
     auto run_k = [&](acc_t (&A)[FJ][FI], const T* Ig0, long ldi, const T* Jg0, long ldj, int nk, bool negate) {
         run_k_impl(std::false_type{}, A, Ig0, ldi, Jg0, ldj, nk, negate, 0, 0);
     };
+    // Publishing a tile whose ONLY payload is store_c's write-through (sc1) stores needs no L2 write-back at all: the stores
+    // are at the device-coherent level once this wave's vmcnt has drained, the barrier collects all waves, then the flag goes
+    // out (MI355X_MICROARCH.md, "sc1 payload -> vmcnt(0) -> sc1 flag").  Saves the buffer_wbl2 / buffer_inv pair that every
+    // thread of the workgroup issued per publish (microseconds under load, twice per column on the chain).  GP_DF_LIGHT_PUBLISH=0
+    // restores the full fence everywhere.  The diagonal task's publish keeps it: potrf's L, W, log-det and info stores are plain.
+#ifndef GP_DF_LIGHT_PUBLISH
+#define GP_DF_LIGHT_PUBLISH 1
+#endif
+    auto publish_wt = [&](int fi_, int fj_) {
+        if (GP_DF_LIGHT_PUBLISH) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else __threadfence();
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(F + fi_ * R + fj_, g.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
     auto publish = [&](int fi_, int fj_) {                  // everything this workgroup stored is visible first
         __threadfence();
         __syncthreads();
@@ -2191,7 +2205,7 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g, Th
     if constexpr (FUSE) {
         if (accp) {                                         // hand the pre-solve tile (j+1,j) to the diagonal task
             if (BUILD || j > 0) store_c(acc, Ct, LDA);
-            publish(j, i);                                  // "pre" flag lives in the unused upper slot (j, j+1)
+            publish_wt(j, i);                               // "pre" flag lives in the unused upper slot (j, j+1)
             stamp(4);
             return;
         }
@@ -2219,7 +2233,7 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g, Th
                         const int c = wj * WT + x * 16 + Num<T>::drow(l4, r), irow = wi * WT + y * 16 + l15;
                         smem[(c >> 4) * JOFF + df_lds_off<T, TBX>(c & 15, irow)] = accx[x][y][r];
                     }
-            publish(j, jm);                                 // (its barrier also orders the LDS image)
+            publish_wt(j, jm);                              // (its barrier also orders the LDS image)
             stamp(7);
 #pragma unroll
             for (int st = 0; st < TBX / GK; ++st)
@@ -2300,7 +2314,7 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g, Th
     run_k(acc, Ct, LDA, Wj, TBX, SPB, false);
     stamp(3);
     store_c(acc, Ct, LDA);
-    publish(i, j);
+    publish_wt(i, j);
     stamp(4);
 }
 
