@@ -624,6 +624,13 @@ __device__ __forceinline__ double fast_rsqrt(double x) {
 
 constexpr int PT_LDS_ELEMS = 36 * 256 + TB;     // tiles + dinv[128]  (+ 2 doubles of reduction scratch)
 
+// global store of the potrf core: plain, or write-through at agent scope (WT: the dataflow kernel's diagonal task, whose
+// results are then published without an L2 write-back fence)
+template <bool WT, typename T>
+__device__ __forceinline__ void gst(T* p, T v) {
+    if constexpr (WT) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
 __device__ __forceinline__ int ptile(int bi, int bj) { return ((bi * (bi + 1) / 2) + bj) << 8; }
 
 // Block column PB of W = L^-1 (rows q = PB+1..7), computed by ONE wave with no barriers:
@@ -631,7 +638,7 @@ __device__ __forceinline__ int ptile(int bi, int bj) { return ((bi * (bi + 1) / 
 // L tiles and the diagonal inverses W_rr are read from LDS; the W[r][PB] this wave has already
 // produced stay in registers in the MFMA D layout, which is exactly the B-operand layout of the
 // next product (Num<T>::kidx), and go straight to the Winv workspace.
-template <typename T, int PB, int NB = 8>
+template <typename T, int PB, int NB = 8, bool WT = false>
 __device__ __forceinline__ void inv_block_column(const T* __restrict__ Ls, T* __restrict__ Wg, int l15, int l4) {
     typedef typename Num<T>::acc_t acc_t;
     constexpr int NQ = NB - 1 - PB;
@@ -667,7 +674,7 @@ __device__ __forceinline__ void inv_block_column(const T* __restrict__ Ls, T* __
         }
         w[qq] = out;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) Wg[(PB * 16 + l15) * (16 * NB) + q * 16 + Num<T>::drow(l4, r)] = out[r];
+        for (int r = 0; r < 4; ++r) gst<WT>(Wg + (PB * 16 + l15) * (16 * NB) + q * 16 + Num<T>::drow(l4, r), (T)out[r]);
     }
 }
 
@@ -717,7 +724,7 @@ __device__ __forceinline__ void potrf_update(T* __restrict__ Ls, int p, int t, i
 // image): (i) the NB 16x16 diagonal inverses, (ii) the off-diagonal blocks column by column on the
 // MFMA, (iii) W (with an explicit zero upper triangle) to Wg, leading dimension 16 NB.
 // dinv[c] = 1 / L_cc.  All 256 threads; ends without a barrier.
-template <typename T, int NB>
+template <typename T, int NB, bool WT = false>
 __device__ __forceinline__ void tri_inverse_lds(T* __restrict__ Ls, const T* __restrict__ dinv, T* __restrict__ Wg) {
     constexpr int NE = 16 * NB;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -753,21 +760,21 @@ __device__ __forceinline__ void tri_inverse_lds(T* __restrict__ Ls, const T* __r
         const int uw = __builtin_amdgcn_readfirstlane(wave);
         if constexpr (NB == 8) {
             if (uw == 0) {
-                inv_block_column<T, 0, 8>(Ls, Wg, l15, l4);
+                inv_block_column<T, 0, 8, WT>(Ls, Wg, l15, l4);
             } else if (uw == 1) {
-                inv_block_column<T, 1, 8>(Ls, Wg, l15, l4);
-                inv_block_column<T, 6, 8>(Ls, Wg, l15, l4);
+                inv_block_column<T, 1, 8, WT>(Ls, Wg, l15, l4);
+                inv_block_column<T, 6, 8, WT>(Ls, Wg, l15, l4);
             } else if (uw == 2) {
-                inv_block_column<T, 2, 8>(Ls, Wg, l15, l4);
-                inv_block_column<T, 5, 8>(Ls, Wg, l15, l4);
+                inv_block_column<T, 2, 8, WT>(Ls, Wg, l15, l4);
+                inv_block_column<T, 5, 8, WT>(Ls, Wg, l15, l4);
             } else {
-                inv_block_column<T, 3, 8>(Ls, Wg, l15, l4);
-                inv_block_column<T, 4, 8>(Ls, Wg, l15, l4);
+                inv_block_column<T, 3, 8, WT>(Ls, Wg, l15, l4);
+                inv_block_column<T, 4, 8, WT>(Ls, Wg, l15, l4);
             }
         } else {
-            if (uw == 0) inv_block_column<T, 0, 4>(Ls, Wg, l15, l4);
-            else if (uw == 1) inv_block_column<T, 1, 4>(Ls, Wg, l15, l4);
-            else if (uw == 2) inv_block_column<T, 2, 4>(Ls, Wg, l15, l4);
+            if (uw == 0) inv_block_column<T, 0, 4, WT>(Ls, Wg, l15, l4);
+            else if (uw == 1) inv_block_column<T, 1, 4, WT>(Ls, Wg, l15, l4);
+            else if (uw == 2) inv_block_column<T, 2, 4, WT>(Ls, Wg, l15, l4);
         }
     }
     GP_STAMP(33);
@@ -776,7 +783,7 @@ __device__ __forceinline__ void tri_inverse_lds(T* __restrict__ Ls, const T* __r
         for (int bj = bi; bj < NB; ++bj) {
             T v = (T)0;
             if (bi == bj && er >= ec) v = Ls[ptile(bi, bj) + tid];
-            Wg[(bj * 16 + ec) * NE + bi * 16 + er] = v;
+            gst<WT>(Wg + (bj * 16 + ec) * NE + bi * 16 + er, v);
         }
 }
 
@@ -785,7 +792,7 @@ __device__ __forceinline__ void tri_inverse_lds(T* __restrict__ Ls, const T* __r
 // multi-kernel schedule) or 4 (64x64, the fine-grained dataflow schedule).  Writes L to Ad (global,
 // leading dimension ld), W = L^-1 to Wg (leading dimension 16 NB, explicit zero upper triangle),
 // sum log L_jj to *logdet_out and 1 to *info_out on a bad pivot.
-template <typename T, int NB = 8>
+template <typename T, int NB = 8, bool WT = false>
 __device__ __forceinline__ void potrf128_core(double* __restrict__ lds_raw, T* __restrict__ Ad, long ld,
                                               T* __restrict__ Wg, double* __restrict__ logdet_out,
                                               int* __restrict__ info_out, T tol) {
@@ -967,7 +974,7 @@ __device__ __forceinline__ void potrf128_core(double* __restrict__ lds_raw, T* _
     // L back to HBM (lower-triangle tiles; diagonal tiles whole, their upper part is never read)
     for (int bi = 0; bi < NB; ++bi)
         for (int bj = 0; bj <= bi; ++bj)
-            Ad[(long)(bj * 16 + ec) * ld + bi * 16 + er] = Ls[ptile(bi, bj) + tid];
+            gst<WT>(Ad + (long)(bj * 16 + ec) * ld + bi * 16 + er, Ls[ptile(bi, bj) + tid]);
     {   // sum log L_jj = -sum log dinv_j  (always accumulated in fp64)
         double lg = 0.0;
         if (tid < NE) lg = -log((double)dinv[tid]);
@@ -976,20 +983,20 @@ __device__ __forceinline__ void potrf128_core(double* __restrict__ lds_raw, T* _
     }
 
     GP_STAMP(31);
-    tri_inverse_lds<T, NB>(Ls, dinv, Wg);
+    tri_inverse_lds<T, NB, WT>(Ls, dinv, Wg);
     GP_STAMP(34);
     if (tid == 0) {
-        *logdet_out = red[0] + red[1];
-        if (bad) *info_out = 1;
+        gst<WT>(logdet_out, red[0] + red[1]);
+        if (bad) gst<WT>(info_out, 1);
     }
 }
 
 // Out-of-line copy for chol_dataflow_kernel: keeps the factorisation's register allocation apart from
 // the accumulator-heavy MFMA loops of that kernel (inlined, the allocator spills accumulators there).
-template <typename T, int NB>
+template <typename T, int NB, bool WT = false>
 __device__ __noinline__ void potrf128_core_call(double* lds_raw, T* Ad, long ld, T* Wg, double* logdet_out,
                                                 int* info_out, T tol) {
-    potrf128_core<T, NB>(lds_raw, Ad, ld, Wg, logdet_out, info_out, tol);
+    potrf128_core<T, NB, WT>(lds_raw, Ad, ld, Wg, logdet_out, info_out, tol);
 }
 template <typename T>
 __global__ __launch_bounds__(256) void potrf128_kernel(T* __restrict__ Abase, long bstride, int b,
@@ -1745,6 +1752,13 @@ struct DfArgs {
     double* hres; int* hinfo;                 // pinned host: {logdet, quad} per slot; info per slot + abort flag
 };
 
+#ifndef GP_DF_DMA_AUX
+#define GP_DF_DMA_AUX 16           // cache-policy bits of the dataflow kernel's LDS-DMA operand loads: 16 = sc1 (served by L2 / fabric,
+#endif                             // never by the CU's L1), 0 = default policy (then GP_DF_ACQUIRE must be 1)
+#ifndef GP_DF_ACQUIRE
+#define GP_DF_ACQUIRE 0            // 1 = agent-scope acquire (buffer_inv sc1) after every dependency wait
+#endif
+static_assert(GP_DF_ACQUIRE || GP_DF_DMA_AUX == 16, "plain operand loads need the acquire after a dependency wait");
 constexpr int DF_PARK_SLOTS = 4096;           // 16 XCC ids x 256 (SE, SH, CU) ids
 constexpr int DF_SPIN_LIMIT = 1 << 22;        // x ~1 us per poll: seconds, never reached by a live schedule
 
@@ -1762,7 +1776,12 @@ __device__ __forceinline__ void df_wait(const int* f, int epoch, int* abort_flag
             }
         }
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    // No agent-scope acquire (L1 invalidate) here since round 4: every tile another workgroup produced inside this launch is
+    // stored write-through (sc1) and read back by LDS-DMA loads that carry the sc1 policy bit themselves (GP_DF_DMA_AUX: they
+    // are served by the L2 / fabric, never by this CU's L1) -- MI355X_MICROARCH.md: "sc1 loads may replace the acquire only
+    // when the producer stored sc1".  With PLAIN operand loads the acquire is indispensable (measured: -DGP_DF_DMA_AUX=0
+    // -DGP_DF_ACQUIRE=0 gives wrong likelihoods within seconds of scripts/gpu_df_soak.py).  -2 % at N = 2048-8192.
+    if (GP_DF_ACQUIRE) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 }
 
 // LDS image of one staged operand tile of the dataflow kernel.  TBX = 128: the gemm_nt image.
@@ -2021,16 +2040,16 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g, Th
                     if (F64) {
                         const long kcol = qq;
                         __builtin_amdgcn_global_load_lds((glb_void*)(Ig + kcol * ldi + 2 * lane),
-                                                         (lds_void*)(Is + qq * LDT), 16, 0, 0);
+                                                         (lds_void*)(Is + qq * LDT), 16, 0, GP_DF_DMA_AUX);
                         __builtin_amdgcn_global_load_lds((glb_void*)(Jg + kcol * ldj + 2 * lane),
-                                                         (lds_void*)(Js + qq * LDT), 16, 0, 0);
+                                                         (lds_void*)(Js + qq * LDT), 16, 0, GP_DF_DMA_AUX);
                     } else {
                         const long kcol = 4 * (qq >> 1) + (qq & 1) + 2 * (lane >> 5);
                         const int row = 4 * (lane & 31);
                         __builtin_amdgcn_global_load_lds((glb_void*)(Ig + kcol * ldi + row),
-                                                         (lds_void*)(Is + qq * LDP), 16, 0, 0);
+                                                         (lds_void*)(Is + qq * LDP), 16, 0, GP_DF_DMA_AUX);
                         __builtin_amdgcn_global_load_lds((glb_void*)(Jg + kcol * ldj + row),
-                                                         (lds_void*)(Js + qq * LDP), 16, 0, 0);
+                                                         (lds_void*)(Js + qq * LDP), 16, 0, GP_DF_DMA_AUX);
                     }
                 }
             } else {
@@ -2040,9 +2059,9 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g, Th
                     const long kcol = 4 * (qq >> 1) + (qq & 1) + 2 * (lane >> 5);
                     const int row = 2 * (lane & 31);
                     __builtin_amdgcn_global_load_lds((glb_void*)(Ig + kcol * ldi + row),
-                                                     (lds_void*)(Is + qq * LD64), 16, 0, 0);
+                                                     (lds_void*)(Is + qq * LD64), 16, 0, GP_DF_DMA_AUX);
                     __builtin_amdgcn_global_load_lds((glb_void*)(Jg + kcol * ldj + row),
-                                                     (lds_void*)(Js + qq * LD64), 16, 0, 0);
+                                                     (lds_void*)(Js + qq * LD64), 16, 0, GP_DF_DMA_AUX);
                 }
             }
         };
@@ -2177,7 +2196,7 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g, Th
         }
         __syncthreads();
         known = __builtin_amdgcn_readfirstlane(s_task);
-        if (known > 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if (known > 0 && GP_DF_ACQUIRE) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     int b0 = 0;
     if constexpr (TBX == 64) {
@@ -2262,6 +2281,7 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g, Th
             if constexpr (BUILD) {
                 // this task depends (transitively) on every other task of the slot: everything is final
                 if (wave == 0) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");        // (plain loads of other workgroups' partials below)
                     double sum = 0.0;
                     for (int b2 = lane; b2 < g.nd; b2 += 64) sum += g.partial[(long)slot * g.p_bstride + b2];
                     for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off);
@@ -2291,10 +2311,15 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g, Th
             }
         __syncthreads();
         stamp(2);
-        potrf128_core_call<T, TBX / 16>(smem_raw, Ct, LDA, Wj, g.partial + (long)slot * g.p_bstride + j, g.info + slot,
-                                        (T)sp[3]);
+        // (GP_DF_WT_POTRF: potrf's L, W, log-det and info stores write-through too, so that this publish needs no fence either)
+#ifndef GP_DF_WT_POTRF
+#define GP_DF_WT_POTRF 1
+#endif
+        potrf128_core_call<T, TBX / 16, GP_DF_WT_POTRF != 0>(smem_raw, Ct, LDA, Wj, g.partial + (long)slot * g.p_bstride + j, g.info + slot,
+                                                              (T)sp[3]);
         stamp(3);
-        publish(j, j);
+        if (GP_DF_WT_POTRF) publish_wt(j, j);
+        else publish(j, j);
         leave_critical();
         stamp(4);
         return;

@@ -814,7 +814,7 @@ void launch_dataflow(gphip_ctx* h, int nslots, int c0 = 0, double* part = nullpt
         // potrf64 runs 1.6-1.8x slower next to a co-resident accumulating workgroup).  Measured crossover ~3 500 tasks:
         // one theta N = 2048-5120 -3..-7 %, N = 6144 -1 %, N >= 7168 +14 % (throughput bound: two per CU);
         // 2 thetas up to N = 3072, 4 up to 2048, 8 up to 1536.  Occupancy is set through the LDS request (> 80 KiB).
-        const int kib = h->dataflow_lds_kib < 0 ? (tasks <= 3500 ? 84 : 0) : h->dataflow_lds_kib;
+        const int kib = h->dataflow_lds_kib < 0 ? (tasks <= 2700 ? 84 : 0) : h->dataflow_lds_kib;   // (round 4, after the fence changes: N=4096 1/CU 1.34 vs 1.36, N=5120 1.83 vs 1.72 two per CU)
         if ((size_t)kib * 1024 > lds) lds = (size_t)kib * 1024;
         // two workgroups per CU: the neighbour of a diagonal task steps aside while that task is on the chain
         if (lds <= 80 * 1024 && h->dataflow_park) g.park = reinterpret_cast<int*>(h->dTicket + 2);
@@ -871,7 +871,7 @@ int queue_factor_dataflow(gphip_ctx* h, int nslots) {
             // 2-3 column hops it waits for at the end of its life, so more residents = more slots doing work
             // (N=10240 8.79 -> 8.33 ms, N=12288 14.8 -> 13.85 ms, N=8192 -1.8 %; at N=6144, chain bound, +6 %: not there)
             const long t64 = (long)(2 * h->Nt + 1) * (2 * h->Nt + 2) / 2 * nslots;
-            const bool occ3 = h->dataflow_occ3 > 0 || (h->dataflow_occ3 < 0 && t64 >= 8000);
+            const bool occ3 = h->dataflow_occ3 > 0 || (h->dataflow_occ3 < 0 && t64 >= 6000);      // (round 4 re-tune: N=7168 3.07 vs 3.14 ms, N=6144 a tie)
             if (h->fused_eval) {               // tiles built in-kernel, results exported by the corner task
                 if (occ3) launch_dataflow<T, 64, 3, 2, true>(h, nslots);
                 else launch_dataflow<T, 64, 2, 2, true>(h, nslots);
@@ -989,7 +989,7 @@ int queue_factor(gphip_ctx* h, int nslots) {
                     if (2 * rem <= Nt) {                           // 64-tiles: the faster chain; its 2 rem block partials
                         tail_part = h->dPartial + (long)h->slots * Nt;         // live behind the 128-block list
                         tail_n = 2 * rem;
-                        if (h->dataflow_occ3 > 0 || (h->dataflow_occ3 < 0 && (long)(2 * rem + 1) * (2 * rem + 2) / 2 * nslots >= 8000))
+                        if (h->dataflow_occ3 > 0 || (h->dataflow_occ3 < 0 && (long)(2 * rem + 1) * (2 * rem + 2) / 2 * nslots >= 6000))
                             launch_dataflow<T, 64, 3>(h, nslots, 2 * k0(kc), tail_part, tail_n);
                         else launch_dataflow<T, 64>(h, nslots, 2 * k0(kc), tail_part, tail_n);
                         tail_k0 = k0(kc);
