@@ -1767,7 +1767,10 @@ __device__ __forceinline__ void df_wait(const int* f, int epoch, int* abort_flag
     // "unlikely": keeps the register allocator from treating this poll loop as hotter than the MFMA
     // loop it sits in (it would spill accumulators around it)
     while (__builtin_expect(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch, 0)) {
-        __builtin_amdgcn_s_sleep(8);                        // (a longer back-off for long waits was measured: no gain)
+#ifndef GP_DF_POLL_SLEEP
+#define GP_DF_POLL_SLEEP 8
+#endif
+        __builtin_amdgcn_s_sleep(GP_DF_POLL_SLEEP);         // (a longer back-off for long waits was measured: no gain)
         if ((++spins & 63) == 0) {
             if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
             if (spins > DF_SPIN_LIMIT) {
@@ -1915,7 +1918,9 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g, Th
     T* Ct = tptr(i, j);                                    // tile (i,j)
     // per-slot scalars {sf2, sn2, mu, pivot tol, ..}: from the argument pack (BUILD) or from device memory
     const double* sp = BUILD ? tp.v + g.nslots * g.d + slot * SLOTP : g.slotp + (long)slot * SLOTP;
-    if (BUILD && i == 0 && j == 0 && tid == 0) g.info[slot] = 0;     // task (0,0) of the slot precedes every potrf of the slot
+    // task (0,0) of the slot precedes every potrf of the slot.  WRITE-THROUGH: no publish of this kernel flushes plain stores any
+    // more (round 4), and the corner task reads the word from another XCD (found by scripts/gpu_api_fuzz.py: garbage info words)
+    if (BUILD && i == 0 && j == 0 && tid == 0) __hip_atomic_store(g.info + slot, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
     acc_t acc[FJ][FI];
     // D-layout address of this lane's accumulators inside a TBX x TBX tile with leading dimension ldc
@@ -1993,6 +1998,10 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g, Th
                     A[x][y][r] = v;
                 }
     };
+    // (Round 4, measured and removed: 16-byte write-through stores -- lane pairs swapping one value each by DPP so that every
+    //  store is a dwordx4 sc1 through inline asm -- are bit-identical and change nothing: N=4096 1.352 vs 1.339 ms, N=8192 4.32 vs
+    //  4.30.  The tile stores are not what a hop waits for.  Lesson kept: a VMEM store of more than 8 bytes issued from inline asm
+    //  needs its own s_nop before the data registers are rewritten, the compiler's hazard recogniser cannot see it.)
     auto store_c = [&](acc_t (&A)[FJ][FI], T* base, long ldc) {
         T* cp0 = c_ptr(base, ldc);
 #pragma unroll
