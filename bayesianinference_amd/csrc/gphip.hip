@@ -972,9 +972,12 @@ int queue_factor(gphip_ctx* h, int nslots) {
         // tail: once only `dataflow_tail` tile columns are left the dataflow kernel finishes the job in one
         // launch -- the last panels are chain bound, the regime the dataflow schedule wins
         int kc = nouter;
+        // (round-4 re-tune: just above the single-launch range a 48-column tail wins -- N=14336: 18.9 vs 19.9 ms with 64 --, from
+        //  N=16384 on 64 does: 26.0 vs 26.8)
+        const int tail_cols = (h->dataflow_tail == 64 && Nt < 124) ? 48 : h->dataflow_tail;
         if (h->dataflow && h->dataflow_tail > 0 && nslots <= h->dataflow_max_slots && h->dist_world == 0)
             for (int k = 1; k < nouter; ++k)
-                if (Nt - k0(k) <= h->dataflow_tail && Nt - k0(k) <= h->dataflow_max_nt) { kc = k; break; }
+                if (Nt - k0(k) <= tail_cols && Nt - k0(k) <= h->dataflow_max_nt) { kc = k; break; }
         for (int k = 0; k < nouter; ++k) {
             hipEvent_t ev_next = nullptr;
             if (k + 1 == kc) {                  // last multi-kernel panel: apply it to everything, then cut over
