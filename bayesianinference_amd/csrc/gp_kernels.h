@@ -1740,6 +1740,10 @@ struct DfArgs {
     int nd, nslots, epoch;                    // nd = diagonal blocks = Npad / TBX; tile row nd = the rhs rows
     int ncols;                                // tile columns this launch factors (0 = all): a launch restricted to the columns of ONE outer
                                               // panel of the sharded schedule contains no diagonal task for the column behind its last one
+    int nprev; long task0; const T* Aprev;    // sharded schedule, fused look-ahead: the first nprev tile columns of the submatrix are a
+                                              // FINISHED outer panel (operands only, read through Aprev -- the owner's receive buffer,
+                                              // addressed with the same global tile indices); task numbering starts at task0 = the
+                                              // first task of column nprev.  The launch applies that panel to its own columns itself.
     int cw;                                   // split launch: tiles per column (from the diagonal down) that belong to the chain launch
     int role;                                 // 0: this launch runs every task; split launch on CU-masked streams: 1 = the
                                               // diagonal (chain) tasks on the reserved CUs, 2 = all other tasks on the rest
@@ -1838,7 +1842,7 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g, Th
     __syncthreads();
     const int task = __builtin_amdgcn_readfirstlane(s_task);
     const int R = g.nd + 1;
-    const int slot = task % g.nslots, q = task / g.nslots;
+    const int slot = task % g.nslots, q = task / g.nslots + (int)g.task0;
     // q -> (j, i): column-major over the lower triangle, column j starts at off(j) = jR - j(j-1)/2.
     // Split launch (g.role, launch_dataflow): role 1 = the diagonal tasks in order (q = j), role 2 = every other task, still
     // column-major (the strictly lower triangle = a lower triangle of R - 1 rows, shifted down by one).  Each launch hands
@@ -1911,8 +1915,9 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g, Th
     // either way (a 64-tile is a quadrant of its 128-tile)
     auto tptr = [&](int ti_, int tj_) -> T* {
         const int gi = ti_ + g.c0, gj = tj_ + g.c0;
-        if constexpr (TBX == 128) return As + tile_index(gi, gj, g.R128) * TS;
-        else return As + tile_index(gi >> 1, gj >> 1, g.R128) * TS + (long)(gj & 1) * 64 * TB + (gi & 1) * 64;
+        T* base = tj_ < g.nprev ? const_cast<T*>(g.Aprev) : As;        // (nprev = 0 outside the sharded schedule)
+        if constexpr (TBX == 128) return base + tile_index(gi, gj, g.R128) * TS;
+        else return base + tile_index(gi >> 1, gj >> 1, g.R128) * TS + (long)(gj & 1) * 64 * TB + (gi & 1) * 64;
     };
     constexpr long LDA = TB;
     T* Ct = tptr(i, j);                                    // tile (i,j)
@@ -2175,7 +2180,7 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g, Th
     // (whose owner only accumulates it and hands the pre-solve tile over through memory) and applies that
     // last slab straight from LDS -- one flag hop per column on the chain instead of two.
     constexpr bool FUSE = TBX == 64;
-    const bool diagx = FUSE && i == j && j >= 1 && j < g.nd;     // solves (j,j-1) itself
+    const bool diagx = FUSE && i == j && j > g.nprev && j < g.nd;   // solves (j,j-1) itself (not a finished panel's tile)
     const bool accp = FUSE && i == j + 1 && i < g.nd && (g.ncols <= 0 || i < g.ncols);   // tile (j+1,j): accumulate only (its solver, diagonal task j+1, must be part of this launch)
     const int jacc = diagx ? j - 1 : j;                          // slabs taken from memory
 
@@ -2186,14 +2191,15 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g, Th
     // dependent ~1 us flag load (and an L2 invalidate) per slab -- more than a 64-wide slab's MFMA work --
     // so wave 0 peeks at all of them in parallel ONCE, and the leading run of finished columns is taken
     // without further polls (one acquire for the lot).
-    int known = 0;
+    int known = g.nprev;                                   // (a finished outer panel's columns need no flags)
     if (jacc > 1) {
         if (wave == 0) {
             int run = 0;
             for (int c0 = 0; c0 < jacc; c0 += 64) {
                 const int c = c0 + lane;
                 bool ready = false;
-                if (c < jacc)
+                if (c < g.nprev) ready = true;
+                else if (c < jacc)
                     ready = __hip_atomic_load(F + i * R + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == g.epoch &&
                             __hip_atomic_load(F + j * R + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == g.epoch;
                 const unsigned long long miss = ~__ballot(ready);

@@ -60,9 +60,13 @@ struct gphip_ctx {
     hipEvent_t ev_built0 = nullptr;              // queue_build -> queue_factor: "the tile columns of panel 0 are built" (split build)
     int dist_first_factored = -1;                // sharded evaluation: outer panel whose first diagonal block the last LA update factored
     int bcast_chunks = 1;                        // sharded evaluation: a factored panel is broadcast one tile column at a time
+    const void* df_prev_ptr = nullptr; int df_prev_k = -2;   // dist_panel_df = 2: where the previous outer panel lies (gphip_dist_update's deferred look-ahead step)
+    int panel_df = -1;                           // one-GPU look-ahead schedule, one theta, fp64: every outer panel as ONE fused dataflow launch
     int dist_panel_df = 0;                       // sharded evaluation, fp64: the owner factors its outer panel as ONE 64-tile dataflow launch
+                                                 // (1), which also applies the look-ahead update (2); -1 = 2 when world > 1, else 0
                                                  // (latency-shaped owner path: flags instead of 3 launches per tile column)
     bool dist_df_active = false;                 // the current sharded evaluation runs with dataflow panels (64-block partials / inverses)
+    int dist_df_mode = 0;                        // .. and which form (dist_panel_df resolved: 0, 1, 2)
     int bcast_two_hop = 0;                       // sharded evaluation over RCCL, world > 2: every broadcast as scatter (send / recv) + in-place all-gather
     std::vector<hipEvent_t>* col_events = nullptr;   // queue_panel: record "tile column final" events here (owner of a sharded panel)
     int fuse_potrf = 1;                          // option: panel-stream updates factor the diagonal tile they have just updated
@@ -713,7 +717,21 @@ int queue_panel(gphip_ctx* h, int K0, int nin, int nslots, bool first_factored =
 // 64x64 tiles (fp64, Nt <= dataflow_fine_nt) halve the serial chain per column once more; they leave
 // inverses of 64-blocks in dW, so callers that substitute afterwards (h->want_w) get the 128-block
 // inverses rebuilt by trtri128.
+// Option "panel_df" of the look-ahead schedule (queue_factor): one theta, fp64 -- every outer panel (look-ahead update by the
+// panel before it + its own factorisation) is ONE fused 64-tile dataflow launch.  -1 = by size: a few such panels, their
+// trailing updates on the 128-tile GEMM, in front of an 80-column dataflow tail beat both the single launch and the
+// multi-kernel panels for N = 11k-15k (round 4, profiles/r04_panel_df_sweep.txt: N=12288 13.2 -> 12.1 ms, 13312 15.7 -> 15.0,
+// 14336 18.9 -> 18.4; no gain at N <= 10240, a loss from N = 16384 on, where the panel launches starve behind the
+// trailing update's one-workgroup-per-CU GEMM).
+bool panel_df_on(const gphip_ctx* h, int nslots) {
+    if (h->dtype != 64 || nslots != 1 || !h->dataflow || !h->lookahead || h->dist_world > 0 || h->la_main || h->rest_split) return false;
+    if ((h->Nt + h->panel - 1) / h->panel < 2) return false;
+    if (h->panel_df >= 0) return h->panel_df != 0;
+    return h->Nt >= 88 && h->Nt <= 120;
+}
+
 bool use_dataflow(const gphip_ctx* h, int nslots) {
+    if (panel_df_on(h, nslots)) return false;
     // measured: wins 1.05-2.3x for one theta up to N = 12288, ties at 8-16 slots, loses 2x at 200 slots
     // (there the multi-kernel schedule's big launches are throughput bound, not latency bound)
     if (!h->dataflow || h->dist_world > 0 || h->Nt > h->dataflow_max_nt) return false;
@@ -779,11 +797,15 @@ hipStream_t masked_rest_stream(gphip_ctx* h, int res) {
 // c0 > 0 (128-tiles only): factor the trailing submatrix that starts at tile column c0 -- the tail of the
 // look-ahead schedule, already updated by every earlier panel.  No finalize here.
 template <typename T, int TBX, int OCC = 2, int NST = 2, bool BUILD = false>
-void launch_dataflow(gphip_ctx* h, int nslots, int c0 = 0, double* part = nullptr, long pstride = 0, int ncols = 0) {
+void launch_dataflow(gphip_ctx* h, int nslots, int c0 = 0, double* part = nullptr, long pstride = 0, int ncols = 0, int nprev = 0,
+                     const void* aprev = nullptr) {
     const int nd = (int)(h->Npad / TBX) - c0, R = nd + 1;
     // ncols > 0: only the first ncols tile columns (an outer panel of the sharded schedule) -- a prefix of the column-major task list
-    const long tasks = (ncols > 0 && ncols < R ? (long)ncols * R - (long)ncols * (ncols - 1) / 2 : (long)R * (R + 1) / 2) * nslots;
+    // nprev > 0: .. of which the first nprev are a finished panel read through aprev (no tasks of their own)
+    const long task0 = (long)nprev * R - (long)nprev * (nprev - 1) / 2;
+    const long tasks = ((ncols > 0 && ncols < R ? (long)ncols * R - (long)ncols * (ncols - 1) / 2 : (long)R * (R + 1) / 2) - task0) * nslots;
     DfArgs<T> g{};
+    g.nprev = nprev; g.task0 = task0; g.Aprev = (const T*)aprev;
     g.A = (T*)(h->ws_override ? h->ws_override : h->dA); g.bstride = h->slot_elems; g.R128 = (int)h->R; g.c0 = c0;
     g.ncols = (ncols > 0 && ncols < R) ? ncols : 0;
     g.W = (T*)h->dW + (long)c0 * TBX * TBX; g.w_bstride = (long)h->Nt * TB * TB;
@@ -943,6 +965,20 @@ int queue_factor(gphip_ctx* h, int nslots) {
     if (use_dataflow(h, nslots)) return queue_factor_dataflow<T>(h, nslots);
     double* tail_part = nullptr;               // a 64-tile dataflow tail keeps its block partials here
     int tail_n = 0, tail_k0 = -1;
+    // Option "panel_df" (one theta, fp64): every outer panel -- the look-ahead update by the panel before it AND its own
+    // factorisation -- is ONE 64-tile dataflow launch on the panel stream (the sharded schedule's dist_panel_df = 2 form).
+    // All log-det partials are then per 64-block (dPartial[0 .. 2 Nt), the tail's too).
+    bool pdf = false;
+    if constexpr (sizeof(T) == 8) pdf = panel_df_on(h, nslots) && nouter >= 2 && !split;
+    auto df_panel = [&](int kp, int kprev) {
+        if constexpr (sizeof(T) == 8) {
+            hipStream_t keep = h->stream;
+            h->stream = h->pstream;
+            const int c0 = 2 * (kprev >= 0 ? k0(kprev) : k0(kp));
+            launch_dataflow<T, 64>(h, 1, c0, nullptr, 0, 2 * k0(kp + 1) - c0, kprev >= 0 ? 2 * (k0(kp) - k0(kprev)) : 0, h->dA);
+            h->stream = keep;
+        }
+    };
     if (!h->lookahead || nouter < 2) {
         h->cs = h->stream;
         for (int k = 0; k < nouter; ++k) {
@@ -964,7 +1000,8 @@ int queue_factor(gphip_ctx* h, int nslots) {
             }
         }
         h->cs = h->pstream;
-        queue_panel<T>(h, 0, k0(1), nslots);
+        if (pdf) df_panel(0, -1);
+        else queue_panel<T>(h, 0, k0(1), nslots);
         hipEvent_t ev_panel = sync_event(h);
         HIPCHK(hipEventRecord(ev_panel, h->pstream));
         if (h->stagger_out) HIPCHK(hipEventRecord(*h->stagger_out, h->pstream));   // the next batch group may start its build now
@@ -974,7 +1011,7 @@ int queue_factor(gphip_ctx* h, int nslots) {
         int kc = nouter;
         // (round-4 re-tune: just above the single-launch range a 48-column tail wins -- N=14336: 18.9 vs 19.9 ms with 64 --, from
         //  N=16384 on 64 does: 26.0 vs 26.8)
-        const int tail_cols = (h->dataflow_tail == 64 && Nt < 124) ? 48 : h->dataflow_tail;
+        const int tail_cols = h->dataflow_tail != 64 ? h->dataflow_tail : (pdf ? 80 : (Nt < 124 ? 48 : 64));
         if (h->dataflow && h->dataflow_tail > 0 && nslots <= h->dataflow_max_slots && h->dist_world == 0)
             for (int k = 1; k < nouter; ++k)
                 if (Nt - k0(k) <= tail_cols && Nt - k0(k) <= h->dataflow_max_nt) { kc = k; break; }
@@ -989,9 +1026,10 @@ int queue_factor(gphip_ctx* h, int nslots) {
                 const int rem = Nt - k0(kc);                       // tile columns left
                 if (rem == 0) break;                               // (no tail: this was the last panel -- batches, or dataflow_tail off)
                 if constexpr (sizeof(T) == 8) {
-                    if (2 * rem <= Nt) {                           // 64-tiles: the faster chain; its 2 rem block partials
+                    if (2 * rem <= Nt || pdf) {                    // 64-tiles: the faster chain; its 2 rem block partials
                         tail_part = h->dPartial + (long)h->slots * Nt;         // live behind the 128-block list
                         tail_n = 2 * rem;
+                        if (pdf) { tail_part = nullptr; tail_n = 0; }          // (panel_df: one list of 64-blocks for everything)
                         if (h->dataflow_occ3 > 0 || (h->dataflow_occ3 < 0 && (long)(2 * rem + 1) * (2 * rem + 2) / 2 * nslots >= 6000))
                             launch_dataflow<T, 64, 3>(h, nslots, 2 * k0(kc), tail_part, tail_n);
                         else launch_dataflow<T, 64>(h, nslots, 2 * k0(kc), tail_part, tail_n);
@@ -1023,10 +1061,14 @@ int queue_factor(gphip_ctx* h, int nslots) {
                 if (k == 0 && built0) HIPCHK(hipStreamWaitEvent(h->pstream, built, 0));     // LA(0) reads columns the rest of the build writes
                 if (ev_rest) HIPCHK(hipStreamWaitEvent(h->pstream, ev_rest, 0));
                 if (ev_rest2) HIPCHK(hipStreamWaitEvent(h->pstream, ev_rest2, 0));
-                if (h->fuse_potrf && nslots <= 8 && h->dist_world == 0) h->fuse_b = k0(k + 1);  // ... whose first diagonal tile LA(k) also factors
-                trailing(k, k0(k + 1), k0(k + 2), 3);                          // LA(k)
-                const bool first_factored = h->fuse_done;
-                queue_panel<T>(h, k0(k + 1), k0(k + 2) - k0(k + 1), nslots, first_factored);    // factor panel k+1
+                if (pdf) {
+                    df_panel(k + 1, k);                                        // LA(k) + factor panel k+1, one launch
+                } else {
+                    if (h->fuse_potrf && nslots <= 8 && h->dist_world == 0) h->fuse_b = k0(k + 1);  // ... whose first diagonal tile LA(k) also factors
+                    trailing(k, k0(k + 1), k0(k + 2), 3);                          // LA(k)
+                    const bool first_factored = h->fuse_done;
+                    queue_panel<T>(h, k0(k + 1), k0(k + 2) - k0(k + 1), nslots, first_factored);    // factor panel k+1
+                }
                 ev_next = sync_event(h);
                 HIPCHK(hipEventRecord(ev_next, h->pstream));
             }
@@ -1054,7 +1096,12 @@ int queue_factor(gphip_ctx* h, int nslots) {
         if (ev_rest2) HIPCHK(hipStreamWaitEvent(h->stream, ev_rest2, 0));
         if (rs != h->stream && ev_rest) HIPCHK(hipStreamWaitEvent(h->stream, ev_rest, 0));
     }
-    if (tail_k0 >= 0) {
+    if (pdf) {
+        launch_finalize<T>(h, nslots, 2 * Nt);
+        if (h->want_w)                             // 64-block inverses everywhere: rebuild the 128-blocks
+            hipLaunchKernelGGL(trtri128_kernel<T>, dim3((unsigned)Nt, nslots), dim3(256), potrf_lds<T>(), h->stream,
+                               (const T*)h->dA, (long)h->slot_elems, (T*)h->dW, Nt);
+    } else if (tail_k0 >= 0) {
         launch_finalize<T>(h, nslots, tail_k0, Nt, tail_part, tail_n);
         if (h->want_w)                             // the tail left 64-block inverses over part of dW: rebuild the 128-blocks
             hipLaunchKernelGGL(trtri128_kernel<T>, dim3((unsigned)Nt, nslots), dim3(256), potrf_lds<T>(), h->stream,
@@ -2893,7 +2940,9 @@ int gphip_dist_begin(gphip_handle h, const double* theta, int p, int rank, int w
     rc = copy_theta(h, 1);
     if (rc) return rc;
     HIPCHK(hipMemsetAsync(h->dInfo, 0, 4, h->stream));
-    h->dist_df_active = h->dist_panel_df != 0 && h->dtype == 64 && h->dataflow != 0;
+    h->dist_df_mode = (h->dtype == 64 && h->dataflow != 0) ? (h->dist_panel_df < 0 ? (world > 1 ? 2 : 0) : h->dist_panel_df) : 0;
+    h->dist_df_active = h->dist_df_mode != 0;
+    h->df_prev_ptr = nullptr; h->df_prev_k = -2;
     HIPCHK(hipMemsetAsync(h->dPartial, 0, (size_t)2 * h->Nt * 8, h->stream));
     h->cs = h->stream;
     DISPATCH(h, queue_build, h, 1);
@@ -2922,9 +2971,19 @@ int gphip_dist_factor_panel(gphip_handle h, int k, void* packed) {
         // Latency-shaped owner path (round 4): the whole panel -- its 2 nin 64-wide tile columns over all rows below -- as ONE
         // dataflow launch on the panel stream: the chain is 2 nin flag hops (~22 us each) instead of 3 dependent launches per
         // 128-wide column.  Meant for an owner whose chip is mostly idle (its share of the trailing update is 1 / world).
+        // dist_panel_df = 2: the look-ahead update of this panel by panel k - 1 rides in the SAME launch
+        // (the tasks read panel k - 1 from where the broadcast put it, as 2 P more slabs): the update's MFMA work then fills
+        // the chip around the panel's serial chain instead of preceding it.
         hipStream_t keep = h->stream;
         h->stream = h->pstream;
-        launch_dataflow<double, 64>(h, 1, 2 * (int)K0, nullptr, 0, 2 * (int)(K1 - K0));
+        if (h->df_prev_ptr && h->df_prev_k == k - 1 && k >= 1) {
+            const int64_t Kp = K0 - h->panel;
+            const char* pbase = static_cast<const char*>(h->df_prev_ptr) - dist_panel_first(h, k - 1) * TS * (long)h->es;
+            launch_dataflow<double, 64>(h, 1, 2 * (int)Kp, nullptr, 0, 2 * (int)(K1 - Kp), 2 * (int)(K0 - Kp), pbase);
+        } else {
+            launch_dataflow<double, 64>(h, 1, 2 * (int)K0, nullptr, 0, 2 * (int)(K1 - K0));
+        }
+        h->df_prev_ptr = nullptr; h->df_prev_k = -2;
         h->stream = keep;
     } else {
         DISPATCH(h, queue_panel, h, (int)K0, (int)(K1 - K0), 1, first_factored);
@@ -2960,6 +3019,14 @@ int gphip_dist_update(gphip_handle h, int k, const void* packed, int j_first, in
         if (j % W == h->dist_rank) { if (j0 < 0) j0 = j; ++cnt; }
     const int cls = on_panel_stream ? 3 : 4;
     const bool corner = j_last > nouter && nouter >= jb && h->dist_rank == 0;
+    if (on_panel_stream && h->dist_df_mode >= 2 && cnt == 1 && j0 == k + 1 && je - jb == 1 && !corner) {
+        // dist_panel_df = 2: the look-ahead update of panel k + 1 is DEFERRED into that panel's dataflow launch
+        // (gphip_dist_factor_panel), which reads panel k from `packed` -- the caller keeps it alive until then, as both the
+        // in-library schedule (three rotating receive buffers) and dist_cholesky.py do.
+        h->df_prev_ptr = packed; h->df_prev_k = k;
+        h->cs = h->stream;
+        return GPHIP_OK;
+    }
     // (dist_first_factored stays set until gphip_dist_factor_panel consumes it: the look-ahead update is the LAST update of
     //  its panel, so a main-stream update issued between LA(k) and the factorisation of panel k + 1 cannot invalidate it)
     if (cnt > 0) {
@@ -3024,7 +3091,7 @@ int* option_slot(gphip_ctx* h, const char* name) {
         {"dataflow", &gphip_ctx::dataflow}, {"dataflow_max_nt", &gphip_ctx::dataflow_max_nt},
         {"dataflow_max_slots", &gphip_ctx::dataflow_max_slots}, {"dataflow_fine_nt", &gphip_ctx::dataflow_fine_nt},
         {"dataflow_tail", &gphip_ctx::dataflow_tail}, {"grad_potri", &gphip_ctx::grad_potri},
-        {"fused_eval", &gphip_ctx::fuse_option}, {"panel_left", &gphip_ctx::panel_left}, {"build_overlap", &gphip_ctx::build_overlap}, {"dataflow_lds_kib", &gphip_ctx::dataflow_lds_kib}, {"dataflow_park", &gphip_ctx::dataflow_park}, {"fuse_potrf", &gphip_ctx::fuse_potrf}, {"bcast_chunks", &gphip_ctx::bcast_chunks}, {"bcast_two_hop", &gphip_ctx::bcast_two_hop}, {"dist_panel_df", &gphip_ctx::dist_panel_df}, {"dataflow_occ3", &gphip_ctx::dataflow_occ3}, {"batch_groups", &gphip_ctx::batch_groups}, {"panel_rows", &gphip_ctx::panel_rows}, {"batch_group_min", &gphip_ctx::batch_group_min}, {"df_split", &gphip_ctx::df_split}, {"df_split_lds_kib", &gphip_ctx::df_split_lds_kib}, {"df_split_min_tasks", &gphip_ctx::df_split_min_tasks}, {"rest_mask", &gphip_ctx::rest_mask}, {"rest_mask_max_nt", &gphip_ctx::rest_mask_max_nt}, {"df_split_auto", &gphip_ctx::df_split_auto}, {"df_split_width", &gphip_ctx::df_split_width},
+        {"fused_eval", &gphip_ctx::fuse_option}, {"panel_left", &gphip_ctx::panel_left}, {"build_overlap", &gphip_ctx::build_overlap}, {"dataflow_lds_kib", &gphip_ctx::dataflow_lds_kib}, {"dataflow_park", &gphip_ctx::dataflow_park}, {"fuse_potrf", &gphip_ctx::fuse_potrf}, {"bcast_chunks", &gphip_ctx::bcast_chunks}, {"bcast_two_hop", &gphip_ctx::bcast_two_hop}, {"dist_panel_df", &gphip_ctx::dist_panel_df}, {"panel_df", &gphip_ctx::panel_df}, {"dataflow_occ3", &gphip_ctx::dataflow_occ3}, {"batch_groups", &gphip_ctx::batch_groups}, {"panel_rows", &gphip_ctx::panel_rows}, {"batch_group_min", &gphip_ctx::batch_group_min}, {"df_split", &gphip_ctx::df_split}, {"df_split_lds_kib", &gphip_ctx::df_split_lds_kib}, {"df_split_min_tasks", &gphip_ctx::df_split_min_tasks}, {"rest_mask", &gphip_ctx::rest_mask}, {"rest_mask_max_nt", &gphip_ctx::rest_mask_max_nt}, {"df_split_auto", &gphip_ctx::df_split_auto}, {"df_split_width", &gphip_ctx::df_split_width},
         {"max_slots", &gphip_ctx::max_slots}, {"shard_min_n", &gphip_ctx::shard_min_n},
         {"thin_tiles", &gphip_ctx::thin_tiles}, {"panel_wide", &gphip_ctx::panel_wide},
         {"la_main", &gphip_ctx::la_main}, {"rest_split", &gphip_ctx::rest_split},

@@ -592,10 +592,20 @@ def main() -> None:
                       "rccl_ranks": ci["world"], "comm": ci["comm"], "factor_bytes_per_rank": hs.factor_bytes(),
                       "all_ok": bool(all(v[1] == 0 and np.isfinite(v[0]) for v in sv))}
             strong_failed = not strong["all_ok"]
+            # The same five evaluations under the schedule options that only a real multi-GPU node can rank (none is measurable
+            # on the one-GPU boxes this code was developed on): "bcast_two_hop" = every panel broadcast as scatter + in-place
+            # all-gather (all links of the xGMI mesh carry 1 / world of a message at once instead of one ring; world > 2);
+            # "dist_panel_df" = 2: the owner factors its panel AND applies the look-ahead update in ONE dataflow launch
+            # (profiles/r04c_owner_path.txt: owner chain 31.8 -> 26.4 ms with the chip to itself).  Results must agree: bit for
+            # bit between broadcast forms, to 1e-10 relative between panel schedules (summation order inside 64-blocks).
+            variants = [("dist_panel_df", {"dist_panel_df": 2})]
             if world > 2:
-                # the same five evaluations with every panel broadcast as scatter + in-place all-gather (option
-                # "bcast_two_hop": all links of the xGMI mesh carry 1 / world of a message at once instead of one ring)
-                hs.set_option("bcast_two_hop", 1)
+                variants = [("two_hop", {"bcast_two_hop": 1})] + variants + [("two_hop_dist_panel_df", {"bcast_two_hop": 1, "dist_panel_df": 2})]
+            strong["variants"] = {}
+            best = ("default", strong["ms_per_eval"])
+            for vname, opts in variants:
+                for k_, v_ in {"bcast_two_hop": 0, "dist_panel_df": 0, **opts}.items():
+                    hs.set_option(k_, v_)
                 hs.loglik(ths[0])
                 barrier()
                 t2 = time.perf_counter()
@@ -603,10 +613,19 @@ def main() -> None:
                 barrier()
                 ts2 = torch.tensor([time.perf_counter() - t2], device=red_dev, dtype=torch.float64)
                 dist.all_reduce(ts2, op=dist.ReduceOp.MAX)
-                strong["two_hop_ms_per_eval"] = float(ts2.item()) / 5 * 1e3
-                strong["two_hop_speedup_vs_one_gpu_weak_step"] = (dt / args.steps) / (float(ts2.item()) / 5)
-                strong["two_hop_identical_results"] = bool(all(a[0] == b[0] and a[1] == b[1] for a, b in zip(sv, sv2)))
-                strong_failed = strong_failed or not strong["two_hop_identical_results"]
+                exact = "dist_panel_df" not in opts
+                same = bool(all(a[1] == b[1] and (a[0] == b[0] if exact else abs(a[0] - b[0]) <= 1e-10 * abs(a[0])) for a, b in zip(sv, sv2)))
+                ms2 = float(ts2.item()) / 5 * 1e3
+                strong["variants"][vname] = {"options": opts, "ms_per_eval": ms2, "speedup_vs_one_gpu_weak_step": (dt / args.steps) / (ms2 / 1e3),
+                                             "same_results": same}
+                strong_failed = strong_failed or not same
+                if ms2 < best[1]:
+                    best = (vname, ms2)
+            strong["best_variant"] = best[0]
+            if "two_hop" in strong["variants"]:                    # (round-3 field names, kept for readers of older lines)
+                strong["two_hop_ms_per_eval"] = strong["variants"]["two_hop"]["ms_per_eval"]
+                strong["two_hop_speedup_vs_one_gpu_weak_step"] = strong["variants"]["two_hop"]["speedup_vs_one_gpu_weak_step"]
+                strong["two_hop_identical_results"] = strong["variants"]["two_hop"]["same_results"]
             hs.close()
         except Exception as exc:                                    # never let the extra break the headline
             strong = {"error": repr(exc)}

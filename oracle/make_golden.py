@@ -5,7 +5,7 @@ The reference (Wolfram Language) cannot run here, so these vectors come from the
 has been pinned by closed forms, the MVN second formulation and mpmath (tests/test_oracle.py).
 Fixtures (SURVEY.md §8c): F1 cfg-1 (N=512,d=1,SE); F2 N=256,d=8 SE-ARD + Matern-5/2-ARD;
 F3 scalars only for N=2048 ... 49152 (data regenerated from the seeded generator, checksummed; the N >= 16384 rows are
-one in-place LU each: minutes of CPU, `--f3` regenerates only this file);
+one in-place LU each: minutes of CPU, `--f3` regenerates only this file; `--f3b`: the N = 11k-15k companion);
 F4 sentinel cases; HP mpmath 50-digit values for N=24/32/48 and 30-digit values for cfg 1 itself (N=512, d=1).
 """
 from __future__ import annotations
@@ -69,14 +69,8 @@ def f2():
                         thetas=thetas, kernel="matern52", mean="const", **res)
 
 
-def f3():
+def _f3_rows(sizes, fname):
     rows = []
-    # N = 16384 / 32768 / 49152: the sizes at which the look-ahead / wide-panel / dataflow-tail schedule of the HIP path
-    # is active (N = 32768 is the BASELINE metric's own size): LU in place, 8.6 GB / 19.3 GB of matrix, minutes of CPU
-    sizes = [(2048, "se_ard"), (4096, "se_ard"), (8192, "se_ard"), (2048, "matern52_ard"), (16384, "se_ard"),
-             (32768, "se_ard"), (16384, "matern52_ard")]
-    if os.environ.get("GOLDEN_F3_HUGE") == "1":
-        sizes.append((49152, "se_ard"))
     for n, kernel in sizes:
         X, y = syn.make_dataset(n, 8)
         th = syn.default_theta(kernel, 8)
@@ -84,12 +78,28 @@ def f3():
         rows.append((n, 8, kernel, float(X.sum()), float(y.sum()), ll, ld, qd, info))
         print("F3", rows[-1])
     np.savez_compressed(
-        os.path.join(OUT, "f3_scalars.npz"),
+        os.path.join(OUT, fname),
         n=np.array([r[0] for r in rows]), d=np.array([r[1] for r in rows]),
         kernel=np.array([r[2] for r in rows]),
         xsum=np.array([r[3] for r in rows]), ysum=np.array([r[4] for r in rows]),
         loglik=np.array([r[5] for r in rows]), logdet=np.array([r[6] for r in rows]),
         quad=np.array([r[7] for r in rows]), info=np.array([r[8] for r in rows]))
+
+
+def f3():
+    # N = 16384 / 32768 / 49152: the sizes at which the look-ahead / wide-panel / dataflow-tail schedule of the HIP path
+    # is active (N = 32768 is the BASELINE metric's own size): LU in place, 8.6 GB / 19.3 GB of matrix, minutes of CPU
+    sizes = [(2048, "se_ard"), (4096, "se_ard"), (8192, "se_ard"), (2048, "matern52_ard"), (16384, "se_ard"),
+             (32768, "se_ard"), (16384, "matern52_ard")]
+    if os.environ.get("GOLDEN_F3_HUGE") == "1":
+        sizes.append((49152, "se_ard"))
+    _f3_rows(sizes, "f3_scalars.npz")
+
+
+def f3b():
+    # N = 11k-15k: the range in which the HIP path runs fused dataflow panels in front of an 80-column dataflow tail
+    # (option panel_df, by size; round 4) -- its own file so that the minutes-long f3 need not be regenerated
+    _f3_rows([(12288, "se_ard"), (13440, "matern52_ard"), (11300, "se_ard")], "f3b_scalars.npz")
 
 
 def fcfg5():
@@ -169,5 +179,8 @@ if __name__ == "__main__":
     if "--f3" in sys.argv:
         f3()
         sys.exit(0)
-    f1(), f2(), f4(), fhp(), f3()
+    if "--f3b" in sys.argv:
+        f3b()
+        sys.exit(0)
+    f1(), f2(), f4(), fhp(), f3(), f3b()
     print("golden fixtures written to", OUT)

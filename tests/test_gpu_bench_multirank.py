@@ -48,6 +48,9 @@ def test_two_ranks_weak_headline_and_strong_series():
     assert st["scaling"] == "strong" and st["rccl_ranks"] == 2 and st["all_ok"] and st["ms_per_eval"] > 0
     # the split north_star names is also readable at the top level, next to the weak headline
     assert rec["rccl_ranks"] == 2 and rec["strong_ms_per_eval"] == st["ms_per_eval"] and rec["strong_speedup"] > 0
+    # the schedule variants only a multi-GPU node can rank are timed beside the default and must agree with it
+    v = st["variants"]["dist_panel_df"]
+    assert v["same_results"] and v["ms_per_eval"] > 0 and st["best_variant"] in ("default", "dist_panel_df")
     assert "cpu_baseline" not in rec                                # rank 0 at N = 1 only
 
 

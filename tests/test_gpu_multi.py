@@ -69,19 +69,21 @@ def test_sharded_loglik_matches_oracle_and_single_device(n, d, kernel, world, pa
     gd.close(); g.close(); h.close()
 
 
+@pytest.mark.parametrize("mode", [1, 2])
 @pytest.mark.parametrize("n,d,kernel,world,panel", [(1500, 3, "se_ard", 2, 2), (1500, 3, "matern52_ard", 3, 1), (8192, 8, "se_ard", 8, 4),
-                                                    (100, 2, "se_ard", 3, 4), (1300, 4, "matern52", 5, 3)])
-def test_sharded_loglik_with_dataflow_panels(n, d, kernel, world, panel):
+                                                    (100, 2, "se_ard", 3, 4), (1300, 4, "matern52", 5, 3), (2100, 2, "se_ard", 2, 4)])
+def test_sharded_loglik_with_dataflow_panels(n, d, kernel, world, panel, mode):
     """Option dist_panel_df (round 4, the latency-shaped owner path): the owner factors its outer panel as ONE 64-tile dataflow
     launch restricted to the panel's columns instead of three launches per tile column.  Same factorisation up to the summation
     order inside 64-blocks: oracle / single-device values at the usual bars, bit-repeatable, verdicts through the reduction, a
-    sharded fit (block inverses rebuilt) and the streamed prediction."""
+    sharded fit (block inverses rebuilt) and the streamed prediction.  mode 2: the look-ahead update of the panel rides in the
+    same launch (the previous panel, read from the receive buffer, is 2 P more slabs of every task)."""
     X, y = syn.make_dataset(n, d)
     th = syn.default_theta(kernel, d)
     g = _lib.Handle(X, y, kernel, device=[0] * world)
     g.set_option("panel", panel)
     g.set_option("shard_min_n", 0)
-    g.set_option("dist_panel_df", 1)
+    g.set_option("dist_panel_df", mode)
     ll, ld, qd, inf = g.loglik_parts(th)
     assert inf == 0
     h = _lib.Handle(X, y, kernel)

@@ -97,8 +97,9 @@ def test_cfg1_against_mpmath_pin(golden_dir):
         h.close()
 
 
-def test_f3_scalars_medium_sizes(golden_dir):
-    g = np.load(os.path.join(golden_dir, "f3_scalars.npz"))
+@pytest.mark.parametrize("fname", ["f3_scalars.npz", "f3b_scalars.npz"])
+def test_f3_scalars_medium_sizes(golden_dir, fname):
+    g = np.load(os.path.join(golden_dir, fname))
     for i in range(len(g["n"])):
         n, d, kernel = int(g["n"][i]), int(g["d"][i]), str(g["kernel"][i])
         X, y = syn.make_dataset(n, d)
@@ -107,7 +108,10 @@ def test_f3_scalars_medium_sizes(golden_dir):
         # N >= 16384 runs the schedule that earns the headline number (look-ahead, wide early panels with left-looking
         # in-panel updates, 64-tile dataflow tail): each of its switches is also turned off in turn, every variant against
         # the ORACLE's scalars (LU, oracle/make_golden.py f3) at the 1e-8 bar -- not HIP against HIP
-        variants = [{}] if n < 16384 else [{}, {"panel_wide": 0}, {"lookahead": 0}, {"dataflow_tail": 0}]
+        # N = 11k-15k (f3b): fused dataflow panels + an 80-column dataflow tail by default (option panel_df = -1), against the
+        # single launch / multi-kernel panels it replaced and against other tail widths
+        variants = [{}] if n < 11000 else [{}, {"panel_wide": 0}, {"lookahead": 0}, {"dataflow_tail": 0}, {"panel_df": 1 if n >= 16384 else 0},
+                                           {"panel_df": 1, "dataflow_tail": 48, "panel": 2}]
         for opts in variants:
             for k, v in opts.items():
                 h.set_option(k, v)
@@ -116,8 +120,48 @@ def test_f3_scalars_medium_sizes(golden_dir):
             assert close(ld, float(g["logdet"][i]), n) and close(qd, float(g["quad"][i]), n), (n, kernel, opts)
             assert close(ll, float(g["loglik"][i]), n), (n, kernel, opts)
             for k in opts:
-                h.set_option(k, {"panel_wide": 1, "lookahead": 1, "dataflow_tail": 64}[k])
+                h.set_option(k, {"panel_wide": 1, "lookahead": 1, "dataflow_tail": 64, "panel_df": -1, "panel": 4}[k])
         h.close()
+
+
+@pytest.mark.parametrize("n,d,kernel,opts", [(2100, 3, "se_ard", {"panel": 4, "dataflow_tail": 8}), (1500, 2, "matern52_ard", {"panel": 2, "dataflow_tail": 0}),
+                                             (3000, 5, "se_ard", {"panel": 3, "dataflow_tail": 9, "panel_wide": 0}), (700, 1, "se", {"panel": 1, "dataflow_tail": 2})])
+def test_panel_df_fused_dataflow_panels(n, d, kernel, opts):
+    """Option panel_df (round 4): every outer panel of the look-ahead schedule -- the look-ahead update by the panel before it
+    and its own factorisation -- as ONE 64-tile dataflow launch whose tasks read the finished panel as extra slabs.  Forced on at
+    small N with odd panel widths / ragged last panels / with and without a dataflow tail: oracle scalars and predictions, the
+    gradient (needs the 128-block inverses rebuilt from the 64-block ones), verdicts, and the default schedule as a cross-check."""
+    X, y = syn.make_dataset(n, d)
+    th = syn.default_theta(kernel, d)
+    h = _lib.Handle(X, y, kernel)
+    ref = h.loglik_parts(th)
+    gref = h.loglik_grad(th)
+    h.set_option("panel_df", 1)
+    for k, v in opts.items():
+        h.set_option(k, v)
+    ll, ld, qd, info = h.loglik_parts(th)
+    assert info == 0
+    want = orc.log_likelihood(kernel, th, X, y, parts=True)
+    assert close(ll, want[0], n) and close(ld, want[1], n) and close(qd, want[2], n)
+    assert close(ll, ref[0], n, 1e-11) and close(ld, ref[1], n, 1e-11)
+    assert h.loglik_parts(th)[0] == ll                                   # bit-repeatable
+    Xs = syn.make_test_points(50, d)
+    assert h.fit(th) == 0
+    mu, var = h.predict(Xs)
+    mo, so = orc.predict_internal(kernel, th, X, y, Xs)
+    np.testing.assert_allclose(mu, mo, rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(np.sqrt(var), so, rtol=1e-7)
+    gl = h.loglik_grad(th)
+    assert gl[2] == 0 and close(gl[0], gref[0], n, 1e-11)
+    np.testing.assert_allclose(gl[1], gref[1], rtol=1e-8, atol=1e-8 * np.abs(gref[1]).max())
+    bad = th.copy(); bad[-1] = 0.0
+    Xd = X.copy(); Xd[n // 2] = Xd[3]
+    hd = _lib.Handle(Xd, y, kernel)
+    hd.set_option("panel_df", 1)
+    for k, v in opts.items():
+        hd.set_option(k, v)
+    assert hd.loglik(bad)[1] == _lib.INFO_NOT_SPD and hd.loglik(np.full_like(th, np.nan))[1] == _lib.INFO_NAN and hd.loglik(th)[1] == 0
+    hd.close(); h.close()
 
 
 def test_closed_forms_and_edge_sizes():
