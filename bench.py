@@ -263,9 +263,21 @@ def live_kbuild_clock(n: int, d: int, device: int, kernel_substr: str = "kbuild_
         cyc = v["SQ_BUSY_CYCLES"] / 32.0
         out.append({"ms": ns * 1e-6, "shader_clock_ghz": cyc / ns, "fp64_valu_busy": v["SQ_INSTS_VALU"] * 4.0 / (1024.0 * cyc),
                     "hbm_frac": alg / (ns * 1e-9) / 1e9 / HBM_PEAK_GBS})
-    return {"cold_first_launch": out[0], "after_mfma_work": out[-1], "launches": len(out),
-            "note": "one rocprofv3 --pmc SQ_BUSY_CYCLES SQ_INSTS_VALU pass over bench.py --pmc-probe (outside the timed region; "
-                    "profiled passes run at slightly lower clocks than the timed loop)"}
+    res = {"cold_first_launch": out[0], "after_mfma_work": out[-1], "launches": len(out),
+           "note": "one rocprofv3 --pmc SQ_BUSY_CYCLES SQ_INSTS_VALU pass over bench.py --pmc-probe (outside the timed region; "
+                   "profiled passes run at slightly lower clocks than the timed loop)"}
+    # the same pass saw every trailing-SYRK launch of the two evaluations: the shader clock the MFMA-bound kernel sustains (the
+    # 78.6 TFLOP/s peak assumes 2.4 GHz; a power-limited chip holds less under back-to-back fp64 MFMAs)
+    sy = {}
+    for r in rows:
+        if "gemm_nt_kernel<double, 0," in r["Kernel_Name"] and r["Counter_Name"] == "SQ_BUSY_CYCLES":
+            e = sy.setdefault(r["Dispatch_Id"], {"ns": float(r["End_Timestamp"]) - float(r["Start_Timestamp"]), "cyc": 0.0})
+            e["cyc"] += float(r["Counter_Value"]) / 32.0
+    big = [e for e in sy.values() if e["ns"] > 1e6]                  # launches of >= 1 ms: the bulk of the factorisation
+    if big:
+        ns, cyc = sum(e["ns"] for e in big), sum(e["cyc"] for e in big)
+        res["syrk"] = {"launches": len(big), "shader_clock_ghz": cyc / ns, "fp64_mfma_peak_at_that_clock_tflops": FP64_MFMA_PEAK_TFLOPS * (cyc / ns) / 2.4}
+    return res
 
 
 def pmc_probe(n: int, d: int) -> None:
@@ -681,7 +693,21 @@ def main() -> None:
         if world == 1 and not args.no_extras and not args.no_live_pmc and args.mode == "theta" and out.get("roofline_kbuild"):
             clk = live_kbuild_clock(n, d, local_rank)
             if clk is not None:
+                syc = clk.pop("syrk", None)
                 out["roofline_kbuild"]["clock_probe"] = clk
+                # the same kernel in the probe's PMC pass, where launches run one at a time with idle gaps between them (the
+                # clocks recover): `frac` above is the build right behind 180 ms of fp64 MFMA work, at whatever clock the
+                # power-limited chip still holds then
+                out["roofline_kbuild"]["frac_in_pmc_probe"] = clk["after_mfma_work"]["hbm_frac"]
+                if syc is not None:
+                    # (the profiled pass serialises kernels: this is the SYRK alone, to be read next to roofline_syrk_alone)
+                    syc["note"] = ("shader clock over the trailing-SYRK launches of the PMC probe (SQ_BUSY_CYCLES / 32 shader engines / "
+                                   "duration); frac_at_clock = TFLOP/s / (78.6 x clock / 2.4 GHz)")
+                    pk = syc["fp64_mfma_peak_at_that_clock_tflops"]
+                    syc["roofline_frac_at_clock"] = out["roofline"]["achieved"] / pk
+                    if out.get("roofline_syrk_alone"):
+                        syc["syrk_alone_frac_at_clock"] = out["roofline_syrk_alone"]["achieved"] / pk
+                    out["roofline"]["clock_probe"] = syc
         if world == 1 and not args.no_extras:
             h.close()                                           # free the 8.7 GB workspace first
             out["other_configs"] = other_configs(local_rank)

@@ -220,13 +220,13 @@ int gphip_ns_crude_weights(const double* points, const double* loglik, int64_t m
  *                  for panels of >= 8 tiles (the wide early panels of a large factorisation)
  *   "dataflow_lds_kib" -1 auto (default) / 0 / KiB: LDS request of the 64-tile dataflow kernel; > 80 puts ONE workgroup on a
  *                  CU, which keeps the chain's latency-bound waves off SIMDs busy with another workgroup's MFMAs: auto
- *                  asks for 84 KiB while the launch has <= 3 500 tile tasks (one theta up to N ~ 5 000: -3..-7 %)
+ *                  asks for 84 KiB while the launch has <= 2 700 tile tasks (one theta up to N ~ 4 600: -2..-7 %)
  *   "bcast_chunks" 0/1 (default 1): sharded evaluation -- a factored panel is broadcast one tile column at a time, each as soon as
  *                  it is final, instead of as one message after the whole panel (must agree on all ranks: checked)
  *   "fuse_potrf"   0/1 (default 1): calls of <= 8 thetas -- the panel-stream update that completes a diagonal tile also factors
  *                  it (no separate potrf128 launch, which waits 100-250 us for a CU slot under the trailing update): N = 16384 -3 %
  *   "dataflow_occ3" -1 auto (default) / 0 / 1: the 64-tile dataflow kernel in its three-workgroups-per-CU build (166 registers);
- *                  auto = launches of >= 8 000 tile tasks, which are throughput bound (N = 12288: -6.5 %)
+ *                  auto = launches of >= 6 000 tile tasks, which are throughput bound (N = 12288: -6.5 %)
  *   "dataflow_park" 0/1 (default 1): 64-tile dataflow launches with two workgroups per CU -- the workgroup sharing a CU with a
  *                  diagonal (chain) task sleeps while that task is in its critical section (N = 6144: -9 %, 8192: -1 %)
  *   "build_overlap" 0/1 (default 0): the look-ahead schedule builds the tile columns of outer panel 0 first and starts
@@ -259,6 +259,14 @@ int gphip_ns_crude_weights(const double* points, const double* loglik, int64_t m
  *                  scatter (the owner sends piece r to rank r: grouped ncclSend / ncclRecv) + in-place ncclAllGather instead of one
  *                  ncclBroadcast, so that all links of the xGMI mesh carry 1 / world of the message at once (never measured on
  *                  real multi-GPU hardware; results are bit-identical; must agree on all ranks: checked)
+ *   "panel_df"     -1 by size (default) / 0 / 1: one theta, fp64, look-ahead schedule -- every outer panel (the look-ahead update by
+ *                  the panel before it + its own factorisation) is ONE 64-tile dataflow launch whose tasks read the finished panel as
+ *                  extra slabs; by size = 88 <= Nt <= 120 (N = 11k-15k: -2..-8 %, with an 80-column dataflow tail behind the panels)
+ *   "dist_panel_df" 0 (default) / 1 / 2: sharded evaluation, fp64 -- the owner factors its outer panel as ONE 64-tile dataflow launch
+ *                  (1), which also applies the look-ahead update, reading the previous panel from the receive buffer (2): the owner's
+ *                  chain of kernels 31.8 -> 26.4 ms per N = 32768 evaluation with the chip to itself, but a panel is then final only
+ *                  when its launch ends, so "bcast_chunks" cannot overlap its columns with the factorisation any more (which side
+ *                  wins depends on the link bandwidth: bench.py --gpus N times both).  Rank-local: need not agree across ranks.
  *   Round-4 experiments, all bit-identical to the default and all measured SLOWER on one MI355X (kept off):
  *   "df_split" r / "df_split_width" w / "df_split_lds_kib": the 64-tile dataflow launch split over two CU-masked streams --
  *                  the w tiles of every column nearest the diagonal as their own launch on r reserved CUs per XCD;
