@@ -61,6 +61,8 @@ struct gphip_ctx {
     int dist_first_factored = -1;                // sharded evaluation: outer panel whose first diagonal block the last LA update factored
     int bcast_chunks = 1;                        // sharded evaluation: a factored panel is broadcast one tile column at a time
     const void* df_prev_ptr = nullptr; int df_prev_k = -2;   // dist_panel_df = 2: where the previous outer panel lies (gphip_dist_update's deferred look-ahead step)
+    int dist_df_occ3_tasks = 1 << 30;            // dist_panel_df = 2: fused panel launches of at least this many tile tasks run three workgroups per CU
+    int df_panel_one_wg_tasks = 600;             // sharded schedule, dataflow panels: one workgroup per CU up to this many tile tasks
     int panel_df = -1;                           // one-GPU look-ahead schedule, one theta, fp64: every outer panel as ONE fused dataflow launch
     int dist_panel_df = 0;                       // sharded evaluation, fp64: the owner factors its outer panel as ONE 64-tile dataflow launch
                                                  // (1), which also applies the look-ahead update (2); -1 = 2 when world > 1, else 0
@@ -727,7 +729,7 @@ bool panel_df_on(const gphip_ctx* h, int nslots) {
     if (h->dtype != 64 || nslots != 1 || !h->dataflow || !h->lookahead || h->dist_world > 0 || h->la_main || h->rest_split) return false;
     if ((h->Nt + h->panel - 1) / h->panel < 2) return false;
     if (h->panel_df >= 0) return h->panel_df != 0;
-    return h->Nt >= 88 && h->Nt <= 120;
+    return h->Nt >= 92 && h->Nt <= 120;
 }
 
 bool use_dataflow(const gphip_ctx* h, int nslots) {
@@ -836,7 +838,10 @@ void launch_dataflow(gphip_ctx* h, int nslots, int c0 = 0, double* part = nullpt
         // potrf64 runs 1.6-1.8x slower next to a co-resident accumulating workgroup).  Measured crossover ~3 500 tasks:
         // one theta N = 2048-5120 -3..-7 %, N = 6144 -1 %, N >= 7168 +14 % (throughput bound: two per CU);
         // 2 thetas up to N = 3072, 4 up to 2048, 8 up to 1536.  Occupancy is set through the LDS request (> 80 KiB).
-        const int kib = h->dataflow_lds_kib < 0 ? (tasks <= 2700 ? 84 : 0) : h->dataflow_lds_kib;   // (round 4, after the fence changes: N=4096 1/CU 1.34 vs 1.36, N=5120 1.83 vs 1.72 two per CU)
+        // (an owner's panel launch of the sharded schedule, chip to itself, has many rows per chain hop: throughput bound down to
+        //  far fewer tasks -- owner chain 26.2 -> 22.6 ms at N=32768; under the one-GPU schedule's trailing update no difference)
+        const long one_wg_tasks = (g.ncols > 0 && h->dist_world > 0) ? h->df_panel_one_wg_tasks : 2700;
+        const int kib = h->dataflow_lds_kib < 0 ? (tasks <= one_wg_tasks ? 84 : 0) : h->dataflow_lds_kib;   // (round 4, after the fence changes: N=4096 1/CU 1.34 vs 1.36, N=5120 1.83 vs 1.72 two per CU)
         if ((size_t)kib * 1024 > lds) lds = (size_t)kib * 1024;
         // two workgroups per CU: the neighbour of a diagonal task steps aside while that task is on the chain
         if (lds <= 80 * 1024 && h->dataflow_park) g.park = reinterpret_cast<int*>(h->dTicket + 2);
@@ -2979,7 +2984,12 @@ int gphip_dist_factor_panel(gphip_handle h, int k, void* packed) {
         if (h->df_prev_ptr && h->df_prev_k == k - 1 && k >= 1) {
             const int64_t Kp = K0 - h->panel;
             const char* pbase = static_cast<const char*>(h->df_prev_ptr) - dist_panel_first(h, k - 1) * TS * (long)h->es;
-            launch_dataflow<double, 64>(h, 1, 2 * (int)Kp, nullptr, 0, 2 * (int)(K1 - Kp), 2 * (int)(K0 - Kp), pbase);
+            // (three workgroups per CU once the launch is throughput bound: the early, tall panels)
+            const long ptasks = (long)2 * (K1 - K0) * (2 * (h->Nt - K0) + 1);
+            if (h->dataflow_occ3 > 0 || (h->dataflow_occ3 < 0 && ptasks >= h->dist_df_occ3_tasks))
+                launch_dataflow<double, 64, 3>(h, 1, 2 * (int)Kp, nullptr, 0, 2 * (int)(K1 - Kp), 2 * (int)(K0 - Kp), pbase);
+            else
+                launch_dataflow<double, 64>(h, 1, 2 * (int)Kp, nullptr, 0, 2 * (int)(K1 - Kp), 2 * (int)(K0 - Kp), pbase);
         } else {
             launch_dataflow<double, 64>(h, 1, 2 * (int)K0, nullptr, 0, 2 * (int)(K1 - K0));
         }
@@ -3091,7 +3101,7 @@ int* option_slot(gphip_ctx* h, const char* name) {
         {"dataflow", &gphip_ctx::dataflow}, {"dataflow_max_nt", &gphip_ctx::dataflow_max_nt},
         {"dataflow_max_slots", &gphip_ctx::dataflow_max_slots}, {"dataflow_fine_nt", &gphip_ctx::dataflow_fine_nt},
         {"dataflow_tail", &gphip_ctx::dataflow_tail}, {"grad_potri", &gphip_ctx::grad_potri},
-        {"fused_eval", &gphip_ctx::fuse_option}, {"panel_left", &gphip_ctx::panel_left}, {"build_overlap", &gphip_ctx::build_overlap}, {"dataflow_lds_kib", &gphip_ctx::dataflow_lds_kib}, {"dataflow_park", &gphip_ctx::dataflow_park}, {"fuse_potrf", &gphip_ctx::fuse_potrf}, {"bcast_chunks", &gphip_ctx::bcast_chunks}, {"bcast_two_hop", &gphip_ctx::bcast_two_hop}, {"dist_panel_df", &gphip_ctx::dist_panel_df}, {"panel_df", &gphip_ctx::panel_df}, {"dataflow_occ3", &gphip_ctx::dataflow_occ3}, {"batch_groups", &gphip_ctx::batch_groups}, {"panel_rows", &gphip_ctx::panel_rows}, {"batch_group_min", &gphip_ctx::batch_group_min}, {"df_split", &gphip_ctx::df_split}, {"df_split_lds_kib", &gphip_ctx::df_split_lds_kib}, {"df_split_min_tasks", &gphip_ctx::df_split_min_tasks}, {"rest_mask", &gphip_ctx::rest_mask}, {"rest_mask_max_nt", &gphip_ctx::rest_mask_max_nt}, {"df_split_auto", &gphip_ctx::df_split_auto}, {"df_split_width", &gphip_ctx::df_split_width},
+        {"fused_eval", &gphip_ctx::fuse_option}, {"panel_left", &gphip_ctx::panel_left}, {"build_overlap", &gphip_ctx::build_overlap}, {"dataflow_lds_kib", &gphip_ctx::dataflow_lds_kib}, {"dataflow_park", &gphip_ctx::dataflow_park}, {"fuse_potrf", &gphip_ctx::fuse_potrf}, {"bcast_chunks", &gphip_ctx::bcast_chunks}, {"bcast_two_hop", &gphip_ctx::bcast_two_hop}, {"dist_panel_df", &gphip_ctx::dist_panel_df}, {"panel_df", &gphip_ctx::panel_df}, {"df_panel_one_wg_tasks", &gphip_ctx::df_panel_one_wg_tasks}, {"dist_df_occ3_tasks", &gphip_ctx::dist_df_occ3_tasks}, {"dataflow_occ3", &gphip_ctx::dataflow_occ3}, {"batch_groups", &gphip_ctx::batch_groups}, {"panel_rows", &gphip_ctx::panel_rows}, {"batch_group_min", &gphip_ctx::batch_group_min}, {"df_split", &gphip_ctx::df_split}, {"df_split_lds_kib", &gphip_ctx::df_split_lds_kib}, {"df_split_min_tasks", &gphip_ctx::df_split_min_tasks}, {"rest_mask", &gphip_ctx::rest_mask}, {"rest_mask_max_nt", &gphip_ctx::rest_mask_max_nt}, {"df_split_auto", &gphip_ctx::df_split_auto}, {"df_split_width", &gphip_ctx::df_split_width},
         {"max_slots", &gphip_ctx::max_slots}, {"shard_min_n", &gphip_ctx::shard_min_n},
         {"thin_tiles", &gphip_ctx::thin_tiles}, {"panel_wide", &gphip_ctx::panel_wide},
         {"la_main", &gphip_ctx::la_main}, {"rest_split", &gphip_ctx::rest_split},

@@ -608,7 +608,7 @@ def main() -> None:
             # on the one-GPU boxes this code was developed on): "bcast_two_hop" = every panel broadcast as scatter + in-place
             # all-gather (all links of the xGMI mesh carry 1 / world of a message at once instead of one ring; world > 2);
             # "dist_panel_df" = 2: the owner factors its panel AND applies the look-ahead update in ONE dataflow launch
-            # (profiles/r04c_owner_path.txt: owner chain 31.8 -> 26.4 ms with the chip to itself).  Results must agree: bit for
+            # (profiles/r04d_owner_path.txt: owner chain 31.8 -> 22.6 ms of kernels with the chip to itself).  Results must agree: bit for
             # bit between broadcast forms, to 1e-10 relative between panel schedules (summation order inside 64-blocks).
             variants = [("dist_panel_df", {"dist_panel_df": 2})]
             if world > 2:

@@ -261,10 +261,10 @@ int gphip_ns_crude_weights(const double* points, const double* loglik, int64_t m
  *                  real multi-GPU hardware; results are bit-identical; must agree on all ranks: checked)
  *   "panel_df"     -1 by size (default) / 0 / 1: one theta, fp64, look-ahead schedule -- every outer panel (the look-ahead update by
  *                  the panel before it + its own factorisation) is ONE 64-tile dataflow launch whose tasks read the finished panel as
- *                  extra slabs; by size = 88 <= Nt <= 120 (N = 11k-15k: -2..-8 %, with an 80-column dataflow tail behind the panels)
+ *                  extra slabs; by size = 92 <= Nt <= 120 (N = 11k-15k: -2..-8 %, with an 80-column dataflow tail behind the panels)
  *   "dist_panel_df" 0 (default) / 1 / 2: sharded evaluation, fp64 -- the owner factors its outer panel as ONE 64-tile dataflow launch
  *                  (1), which also applies the look-ahead update, reading the previous panel from the receive buffer (2): the owner's
- *                  chain of kernels 31.8 -> 26.4 ms per N = 32768 evaluation with the chip to itself, but a panel is then final only
+ *                  chain of kernels 31.8 -> 22.6 ms per N = 32768 evaluation with the chip to itself, but a panel is then final only
  *                  when its launch ends, so "bcast_chunks" cannot overlap its columns with the factorisation any more (which side
  *                  wins depends on the link bandwidth: bench.py --gpus N times both).  Rank-local: need not agree across ranks.
  *   Round-4 experiments, all bit-identical to the default and all measured SLOWER on one MI355X (kept off):

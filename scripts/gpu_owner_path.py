@@ -15,6 +15,9 @@ th = syn.default_theta("se_ard", 8)
 h = _lib.Handle(X, y, "se_ard")
 if len(sys.argv) > 2:
     h.set_option("panel", int(sys.argv[2]))
+for a in sys.argv[3:]:
+    k, v = a.split("=")
+    h.set_option(k, int(v))
 ref = _lib.Handle(X, y, "se_ard").loglik_parts(th)
 sync = torch.cuda.synchronize
 for df, fuse in ((0, 1), (0, 0), (1, 0), (2, 0)):
@@ -30,14 +33,18 @@ for df, fuse in ((0, 1), (0, 0), (1, 0), (2, 0)):
         buf = torch.empty(rows * 8, dtype=torch.uint8, device="cuda")
         sync()
         tf = tl = tr = 0.0
+        per = []
         for k in range(nouter):
             t0 = time.perf_counter(); h.dist_factor_panel(k, buf); sync(); tf += time.perf_counter() - t0
+            per.append((time.perf_counter() - t0) * 1e6)
             if k + 1 < nouter:
                 t0 = time.perf_counter(); h.dist_update(k, buf, k + 1, k + 2, True); sync(); tl += time.perf_counter() - t0
             t0 = time.perf_counter(); h.dist_update(k, buf, k + 2 if k + 1 < nouter else k + 1, nouter + 1, False); sync(); tr += time.perf_counter() - t0
         ld, qd, info = h.dist_end()
     pr = h.profile()
     h.set_option("profile", 0)
+    if os.environ.get("OWNER_PATH_PER_PANEL"):
+        print("   us per panel factorisation (host clock, incl. one synchronisation): " + " ".join(f"{v:.0f}" for v in per[::4]), flush=True)
     ev = pr["potrf"]["ms"] + pr["trsm"]["ms"] + pr["gemm_panel"]["ms"]
     print(f"   event-timed kernels of the chain (no host time): {ev:6.2f} ms   " +
           " ".join(f"{k}={v['ms']:.2f}/{int(v['launches'])}" for k, v in pr.items() if v["launches"]), flush=True)
