@@ -66,6 +66,9 @@ _h = C.c_void_p
 _SIGNATURES = {
     "gphip_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int,
                                _ip, C.c_int, C.POINTER(_h)]),
+    "gphip_create_custom": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                      C.POINTER(_h)]),
+    "gphip_create_error": (C.c_char_p, []),
     "gphip_comm_unique_id": (C.c_int, [C.c_void_p]),
     "gphip_create_rank": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int,
                                     C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(_h)]),
@@ -191,15 +194,34 @@ def ns_crude_weights(points, loglik, pool: int):
     return order, logx, logw, z.value
 
 
+class CustomKernel:
+    """ANY covariance function k(x, x'; p) for the device (the reference takes any `kernel @@ points[[{i,j}]]`, BGP:29-33):
+    `body` = C++ statements in X(k), Y(k) (coordinates of the two points), P(k) (hyper-parameters), D (dimension), T (the
+    arithmetic type) that `return` the covariance without the nugget -- see gphip_create_custom in include/gphip.h;
+    theta of such a handle = [p_0 .. p_{nparams-1}, sn (, mu)].  `fn(A, B, p)` (optional) = the same function in numpy on
+    broadcastable point arrays [.., d] -- what the CPU oracle evaluates in the tests."""
+
+    def __init__(self, body: str, nparams: int, fn=None, name: str = "custom"):
+        self.body, self.nparams, self.fn, self.name = str(body), int(nparams), fn, name
+
+    def __repr__(self):
+        return f"CustomKernel({self.name!r}, nparams={self.nparams})"
+
+
 class Handle:
     """Owns one gphip_handle: training data resident on the device (gphip_create .. gphip_destroy)."""
 
-    def __init__(self, X, y, kernel: str = "se_ard", mean: str = "zero", dtype: int = 64, device=None,
+    def __init__(self, X, y, kernel="se_ard", mean: str = "zero", dtype: int = 64, device=None,
                  rank=None, world=None, comm_id: bytes | None = None):
         """device: None (current device), one ordinal, or a LIST of ordinals = one multi-device handle in this
         process (a repeated ordinal = virtual ranks sharing a GPU).  rank/world/comm_id: this process is one
-        rank of a multi-process job (gphip_create_rank; comm_id from comm_unique_id() of rank 0)."""
+        rank of a multi-process job (gphip_create_rank; comm_id from comm_unique_id() of rank 0).
+        kernel: a name of the grammar of kernel_id(), or a CustomKernel (ANY covariance function, given as the source text of
+        its body: compiled at run time into the library's kernel build, gphip_create_custom)."""
         lib = load()
+        if isinstance(kernel, CustomKernel):
+            self._init_custom(lib, X, y, kernel, mean, dtype, device)
+            return
         X = np.ascontiguousarray(np.atleast_2d(np.asarray(X, dtype=np.float64)))
         y = np.ascontiguousarray(np.asarray(y, dtype=np.float64).ravel())
         if X.shape[0] != y.shape[0]:
@@ -232,6 +254,28 @@ class Handle:
                    1: "bad argument (unknown kernel / mean id, rank outside the world)",
                    2: "bad shape (N < 1 or d < 1)"}.get(rc, "is a gfx950 GPU visible?")
             raise GphipError(rc, "gphip_create failed: " + why)
+        p = C.c_int(0)
+        lib.gphip_num_params(self._h, C.byref(p))
+        self.p = p.value
+
+    def _init_custom(self, lib, X, y, kernel, mean, dtype, device):
+        X = np.ascontiguousarray(np.atleast_2d(np.asarray(X, dtype=np.float64)))
+        y = np.ascontiguousarray(np.asarray(y, dtype=np.float64).ravel())
+        if X.shape[0] != y.shape[0]:
+            raise GphipError(2, "Input and output data are not of same length")     # BGP:251-253
+        if mean not in MEAN_IDS:
+            raise GphipError(1, f"unknown mean {mean!r}")
+        if isinstance(device, (list, tuple)):
+            raise GphipError(6, "a run-time compiled covariance function runs on single-device handles only")
+        self.N, self.d = X.shape
+        self.kernel, self.mean, self.dtype = kernel, mean, int(dtype)
+        self._lib = lib
+        self._h = _h()
+        rc = lib.gphip_create_custom(X.ctypes.data, y.ctypes.data, self.N, self.d, kernel.body.encode(), int(kernel.nparams),
+                                     MEAN_IDS[mean], dtype, -1 if device is None else int(device), C.byref(self._h))
+        if rc != OK:
+            self._h = None
+            raise GphipError(rc, "gphip_create_custom failed: " + (lib.gphip_create_error() or b"").decode())
         p = C.c_int(0)
         lib.gphip_num_params(self._h, C.byref(p))
         self.p = p.value

@@ -32,6 +32,9 @@
 
 #include <type_traits>
 
+// [rtc-begin]  From here to [rtc-end] the text is ALSO compiled at run time (hiprtc, csrc/rtc_dyn.h) for handles created with
+// gphip_create_custom: the same kernel build, instantiated with KT = 3 around a covariance function the caller supplied as
+// source text (GP_CUSTOM_KERNEL).  Keep the region self-contained: no std:: headers, nothing declared outside it.
 namespace gphip {
 
 constexpr int TB = 128;         // tile edge
@@ -334,7 +337,24 @@ struct KBuildArgs {
     const long* adj;        // own_world > 0 and the rank keeps ONLY its own panels (compact storage): adj[q] = tiles to add
                             // to the dense tile index of any tile of outer panel q (index nt_j / .. see panel_slot);
                             // null: the dense packed layout
+    const double* cp; int ncp;   // KT = 3 (run-time compiled covariance function): its hyper-parameters, [slot][ncp]
 };
+
+// KT = 3: the covariance function is source text the caller handed to gphip_create_custom (the reference takes ANY
+// `kernel @@ points[[{i,j}]]`, BGP:29-33), compiled at run time into this header's kernel build.  X / Y are accessors of the
+// two points' coordinates (LDS tiles or, beyond KB_LDS_MAXD dimensions, global memory), Pp the function's hyper-parameters.
+template <typename T>
+struct PointRef {
+    const T* base; long stride;
+    __device__ __forceinline__ T operator()(int k) const { return base[(long)k * stride]; }
+};
+#ifdef GP_CUSTOM_KERNEL
+template <typename T>
+__device__ T gphip_custom_k(PointRef<T> X, PointRef<T> Y, const double* __restrict__ Pp, int D);      // defined by the generated source
+#else
+template <typename T>
+__device__ __forceinline__ T gphip_custom_k(PointRef<T>, PointRef<T>, const double*, int) { return (T)0; }   // never instantiated offline
+#endif
 
 // One 128x128 tile per workgroup (4 waves).  Wave w owns 32 output columns; lane owns 2 adjacent
 // rows (fp64: every store is a 16-byte dwordx4 and a wave writes one full 1 KiB column segment).
@@ -397,7 +417,7 @@ __global__ __launch_bounds__(256) void kbuild_kernel(KBuildArgs<T> a) {
     const bool glb = D == 0 && d > KB_LDS_MAXD;
     // fp64: sf2 2^(j/512) table behind the point tiles (see exp_tab)
     double* etab = lds_raw + (glb ? 0 : ((D > 0) ? D : 2 * d) * TB);
-    if (sizeof(T) == 8 && KT != 2)
+    if (sizeof(T) == 8 && KT < 2)
         for (int idx = tid; idx < EXP_TAB; idx += 256) etab[idx] = sp[0] * a.exp2tab[idx];
     // fp64 squared exponential: coordinates in units in which the squared distance IS the exp table's argument (exp_tab_u)
     // (GP_KBUILD_USCALE: round-4 experiment, off.  10 instead of 12 fp64 instructions per exponential bought 1 % on the boxes
@@ -408,7 +428,7 @@ __global__ __launch_bounds__(256) void kbuild_kernel(KBuildArgs<T> a) {
 #endif
     constexpr bool USCALE = GP_KBUILD_USCALE && sizeof(T) == 8 && KT == 0 && D > 0;
     // fp32 fast path below: sum of squares = r2 log2(e) / 2 (SE) or 5 r2 (Matern-5/2)
-    constexpr bool F32FAST = sizeof(T) == 4 && D > 0 && KT != 2;
+    constexpr bool F32FAST = sizeof(T) == 4 && D > 0 && KT < 2;
     constexpr float CS32 = KT == 0 ? 0.84932180028801904f /* sqrt(log2(e) / 2) */ : 2.2360679774997896f /* sqrt 5 */;
     const T cscale = USCALE ? (T)EXP_COORD_SCALE_SE : (F32FAST ? (T)CS32 : (T)1);
     for (int idx = tid; idx < (glb ? 0 : d * TB); idx += 256) {
@@ -498,7 +518,9 @@ __global__ __launch_bounds__(256) void kbuild_kernel(KBuildArgs<T> a) {
     // column segments (one contiguous 4 KiB of the tile)
     for (int jj = wave; jj < TB; jj += 4) {
         T ra = (T)0, rb = (T)0;
-        if (D > 0) {
+        if constexpr (KT == 3) {
+            // (the caller's function sees the points themselves, not a distance)
+        } else if (D > 0) {
 #pragma unroll
             for (int dd = 0; dd < D; ++dd) {
                 const T xjv = xjs[dd * TB + jj];
@@ -523,7 +545,14 @@ __global__ __launch_bounds__(256) void kbuild_kernel(KBuildArgs<T> a) {
             }
         }
         T va, vb;
-        if constexpr (KT == 2) {
+        if constexpr (KT == 3) {
+            const double* cp = a.cp + (long)slot * a.ncp;
+            const PointRef<T> Yj{glb ? xjg + jj : xjs + jj, glb ? (long)a.npad_j : (long)TB};
+            const PointRef<T> Xa{glb ? xig + r0 : xis + r0, glb ? (long)a.npad_i : (long)TB};
+            const PointRef<T> Xb{Xa.base + 1, Xa.stride};
+            va = gphip_custom_k<T>(Xa, Yj, cp, d);
+            vb = gphip_custom_k<T>(Xb, Yj, cp, d);
+        } else if constexpr (KT == 2) {
             T ra2 = (T)0, rb2 = (T)0;
             if (two && !glb)
                 for (int dd = 0; dd < d; ++dd) {
@@ -584,6 +613,55 @@ __global__ __launch_bounds__(256) void kbuild_kernel(KBuildArgs<T> a) {
         *reinterpret_cast<pair_t*>(out + (long)jj * ldo + r0) = v;
     }
 }
+
+#ifdef GP_CUSTOM_KERNEL
+// k(x_i, x_i) of the points [d][npad] under the slot's hyper-parameters -> out[slot][ostride] (fp64): the prior variance at
+// the test points (BGP:110-115 kappa; a function of the point for a non-stationary covariance function)
+template <typename T>
+__global__ void custom_diag_kernel(const T* __restrict__ x, long x_bstride, int npad, int n, int d, const double* __restrict__ cp,
+                                   int ncp, double* __restrict__ out, long ostride) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, slot = blockIdx.y;
+    if (i >= n) return;
+    const PointRef<T> X{x + (long)slot * x_bstride + i, (long)npad};
+    out[(long)slot * ostride + i] = (double)gphip_custom_k<T>(X, X, cp + (long)slot * ncp, d);
+}
+// Per slot: the largest prior variance over the training points scales the pivot tolerance of the factorisation (the
+// named kernels know k(x, x) = sf^2 on the host; here only the device can evaluate the function).  The host left the
+// relative tolerance in sp[3] and the nugget's scale in sp[SP_SF2B]; one workgroup per slot.
+template <typename T>
+__global__ __launch_bounds__(256) void custom_prep_kernel(const T* __restrict__ x, int npad, int n, int d, const double* __restrict__ cp,
+                                                          int ncp, double* __restrict__ slotp) {
+    __shared__ double red[256];
+    const int slot = blockIdx.x;
+    double m = 0.0;
+    bool bad = false;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const PointRef<T> X{x + i, (long)npad};
+        const double v = (double)gphip_custom_k<T>(X, X, cp + (long)slot * ncp, d);
+        if (!(fabs(v) <= 1.0e300)) bad = true;
+        m = fmax(m, fabs(v));
+    }
+    red[threadIdx.x] = bad ? __builtin_nan("") : m;
+    __syncthreads();
+    for (int s2 = 128; s2 > 0; s2 >>= 1) {
+        if (threadIdx.x < s2) {
+            const double o = red[threadIdx.x + s2], mine = red[threadIdx.x];
+            red[threadIdx.x] = (o != o || mine != mine) ? __builtin_nan("") : fmax(o, mine);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        double* sp = slotp + (long)slot * SLOTP;
+        double kmax = red[0];
+        if (kmax != kmax) { kmax = 1.0; sp[4] = 1.0; }         // (NaN / inf prior variance: the evaluation's verdict will be NaN)
+        sp[0] = kmax; sp[SP_KXX] = kmax;
+        sp[3] = sp[3] * (kmax + sp[SP_SF2B]);
+    }
+}
+#endif
+}  // namespace gphip
+// [rtc-end]
+namespace gphip {
 
 // ---------------------------------------------------------------------------------------------
 // potrf128: Cholesky of one 128x128 diagonal block AND its triangular inverse, in LDS.
@@ -2453,7 +2531,9 @@ __global__ __launch_bounds__(256) void predict_partial_kernel(const T* __restric
 // pw_mean / pw_nug (optional, [slot][out_bstride]): m(x*_t) and nugget(x*_t) evaluated by the host (BGP:113, 408).
 __global__ void predict_finish_kernel(const double* __restrict__ part, int nstrips, long mpad, const double* __restrict__ slotp,
                                       int m, long out_bstride, double* __restrict__ mean, double* __restrict__ var,
-                                      const double* __restrict__ pw_mean = nullptr, const double* __restrict__ pw_nug = nullptr) {
+                                      const double* __restrict__ pw_mean = nullptr, const double* __restrict__ pw_nug = nullptr,
+                                      const double* __restrict__ pw_kxx = nullptr) {
+    // pw_kxx (optional, [slot][out_bstride]): k(x*_t, x*_t) per test point (run-time compiled covariance functions need not be stationary)
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int slot = blockIdx.y;
     if (t >= m) return;
@@ -2465,7 +2545,7 @@ __global__ void predict_finish_kernel(const double* __restrict__ part, int nstri
     }
     const long o = (long)slot * out_bstride + t;
     mean[o] = (pw_mean ? pw_mean[o] : sp[2]) + dot;
-    var[o] = sp[SP_KXX] + (pw_nug ? pw_nug[o] : sp[1]) - nrm;            // kappa = k(x*, x*) + nugget (BGP:110-115)
+    var[o] = (pw_kxx ? pw_kxx[o] : sp[SP_KXX]) + (pw_nug ? pw_nug[o] : sp[1]) - nrm;            // kappa = k(x*, x*) + nugget (BGP:110-115)
 }
 
 // ---------------------------------------------------------------------------------------------

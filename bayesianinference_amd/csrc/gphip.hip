@@ -14,6 +14,7 @@
 // Device arithmetic is fp64 (dtype 64) or fp32 (dtype 32); the ABI is fp64 either way.
 #include "gp_kernels.h"
 #include "rccl_dyn.h"
+#include "rtc_dyn.h"
 
 #include <hip/hip_ext.h>
 
@@ -63,6 +64,11 @@ struct gphip_ctx {
     const void* df_prev_ptr = nullptr; int df_prev_k = -2;   // dist_panel_df = 2: where the previous outer panel lies (gphip_dist_update's deferred look-ahead step)
     int dist_df_occ3_tasks = 1 << 30;            // dist_panel_df = 2: fused panel launches of at least this many tile tasks run three workgroups per CU
     int df_panel_one_wg_tasks = 600;             // sharded schedule, dataflow panels: one workgroup per CU up to this many tile tasks
+    // covariance function supplied as source text (gphip_create_custom): compiled at run time into the kernel build
+    bool custom = false; int ncp = 0;            // ncp = its hyper-parameters p_0 .. p_{ncp-1}
+    hipModule_t cmod = nullptr; hipFunction_t f_cbuild = nullptr, f_cdiag = nullptr, f_cprep = nullptr;
+    double *dCustomP = nullptr, *hCustomP = nullptr;   // [slot][ncp]
+    double* dKss = nullptr; size_t kss_cap = 0;  // k(x*, x*) of the current test points, [slot][mpad]
     int panel_df = -1;                           // one-GPU look-ahead schedule, one theta, fp64: every outer panel as ONE fused dataflow launch
     int dist_panel_df = 0;                       // sharded evaluation, fp64: the owner factors its outer panel as ONE 64-tile dataflow launch
                                                  // (1), which also applies the look-ahead update (2); -1 = 2 when world > 1, else 0
@@ -308,6 +314,8 @@ void free_slots(gphip_ctx* h) {
     h->dPwMean = h->dPwNug = nullptr; h->pw_cap = 0;
     (void)hipFree(h->dXs2); (void)hipFree(h->dInvEll2); (void)hipHostFree(h->hInvEll2);
     h->dXs2 = nullptr; h->dInvEll2 = h->hInvEll2 = nullptr;
+    (void)hipFree(h->dCustomP); (void)hipHostFree(h->hCustomP);
+    h->dCustomP = h->hCustomP = nullptr;
     h->dFlags = nullptr; h->dTicket = nullptr; h->ticket_base = 0; h->ticket_base2 = 0;
     (void)hipHostFree(h->hInvEll); (void)hipHostFree(h->hSlotp); (void)hipHostFree(h->hRes);
     (void)hipHostFree(h->hInfo);
@@ -372,6 +380,10 @@ int ensure_slots(gphip_ctx* h, int want, bool workspace = true) {
     dev((void**)&h->dTicket, DF_TICKET_BYTES, "ticket counter");        // + the per-CU "chain task here" counters
     host((void**)&h->hInvEll, S * h->d * 8, "pinned inverse length scales");
     host((void**)&h->hSlotp, S * SLOTP * 8, "pinned slot scalars");
+    if (h->custom) {
+        dev((void**)&h->dCustomP, S * (size_t)std::max(h->ncp, 1) * 8, "covariance-function parameters");
+        host((void**)&h->hCustomP, S * (size_t)std::max(h->ncp, 1) * 8, "pinned covariance-function parameters");
+    }
     host((void**)&h->hRes, S * 2 * 8, "pinned results");
     host((void**)&h->hInfo, (S + 1) * 4, "pinned info words");            // + the dataflow abort flag
     // ON THE HANDLE'S STREAM: the handle's streams are non-blocking, so a null-stream hipMemset is not ordered before
@@ -413,7 +425,16 @@ void launch_kbuild_kt(gphip_ctx* h, const KBuildArgs<T>& a, dim3 grid) {
 }
 
 template <typename T>
-void launch_kbuild(gphip_ctx* h, const KBuildArgs<T>& a, dim3 grid) {
+void launch_kbuild(gphip_ctx* h, const KBuildArgs<T>& a0, dim3 grid) {
+    if (h->custom) {                               // the run-time compiled instantiation kbuild_kernel<T, 0, 3>
+        KBuildArgs<T> a = a0;
+        a.cp = h->dCustomP; a.ncp = std::max(h->ncp, 1);
+        void* params[] = {&a};
+        const size_t lds = a.d > KB_LDS_MAXD ? 64 : (size_t)2 * a.d * TB * sizeof(T);
+        (void)hipModuleLaunchKernel(h->f_cbuild, grid.x, grid.y, grid.z, 256, 1, 1, (unsigned)lds, h->cs, params, nullptr);
+        return;
+    }
+    const KBuildArgs<T>& a = a0;
     if (h->kt == 0) launch_kbuild_kt<T, 0>(h, a, grid);
     else if (h->kt == 1) launch_kbuild_kt<T, 1>(h, a, grid);
     else        // general form: row and column points of both terms in LDS
@@ -461,6 +482,14 @@ int queue_build(gphip_ctx* h, int nslots, bool for_factor = false) {
     if (h->nl2 > 0)
         hipLaunchKernelGGL(k_scale<T>, dim3(gx, nslots), dim3(256), 0, h->cs, (const T*)h->dXt, (T*)h->dXs2, h->dInvEll2,
                            (int)h->d, (int)h->Npad);
+    if (h->custom) {                               // prior variance scale -> pivot tolerance, per slot (device: only it can evaluate k)
+        const void* x = h->dXt;
+        int npad = (int)h->Npad, n = (int)h->N, d = (int)h->d, ncp = std::max(h->ncp, 1);
+        const double* cp = h->dCustomP;
+        double* sp = h->dSlotp;
+        void* params[] = {&x, &npad, &n, &d, &cp, &ncp, &sp};
+        (void)hipModuleLaunchKernel(h->f_cprep, (unsigned)nslots, 1, 1, 256, 1, 1, 0, h->cs, params, nullptr);
+    }
     KBuildArgs<T> a{};
     a.ks = h->ks; a.xi2 = a.xj2 = (const T*)h->dXs2;
     a.out = (T*)h->dA; a.ld = TB; a.bstride = h->slot_elems;
@@ -1122,6 +1151,8 @@ int copy_theta(gphip_ctx* h, int nb) {
     HIPCHK(hipMemcpyAsync(h->dInvEll, h->hInvEll, (size_t)nb * h->d * 8, hipMemcpyHostToDevice, h->stream));
     if (h->nl2 > 0) HIPCHK(hipMemcpyAsync(h->dInvEll2, h->hInvEll2, (size_t)nb * h->d * 8, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->dSlotp, h->hSlotp, (size_t)nb * SLOTP * 8, hipMemcpyHostToDevice, h->stream));
+    if (h->custom && h->ncp > 0)
+        HIPCHK(hipMemcpyAsync(h->dCustomP, h->hCustomP, (size_t)nb * h->ncp * 8, hipMemcpyHostToDevice, h->stream));
     return GPHIP_OK;
 }
 
@@ -1133,6 +1164,32 @@ bool stage_theta(gphip_ctx* h, int slot, const double* th, const double* nug_row
     bool ok = true;
     for (int i = 0; i < h->p; ++i)
         if (!std::isfinite(th[i])) ok = false;
+    if (h->custom) {
+        // theta = [p_0 .. p_{ncp-1}] sn [mu]: the function's own parameters go to the device as they are (the points are
+        // NOT rescaled: inverse length scales of one); k(x, x), which scales the pivot tolerance, is evaluated on the
+        // device (custom_prep_kernel) -- it finds the relative tolerance in sp[3] and the nugget's scale in sp[SP_SF2B]
+        for (int j = 0; j < h->d; ++j) ie[j] = 1.0;
+        double* cp = h->hCustomP + (size_t)slot * std::max(h->ncp, 1);
+        for (int k = 0; k < h->ncp; ++k) cp[k] = ok ? th[k] : 1.0;
+        double sn = ok ? th[h->ncp] : 1.0;
+        const double mu = (ok && h->mean_id == GPHIP_MEAN_CONST) ? th[h->ncp + 1] : 0.0;
+        double nug_scale = sn * sn;
+        if (nug_row) {
+            nug_scale = 0.0;
+            for (int64_t i = 0; i < h->N; ++i) {
+                if (!std::isfinite(nug_row[i])) ok = false;
+                nug_scale = std::max(nug_scale, std::fabs(nug_row[i]));
+            }
+        }
+        if (mean_row)
+            for (int64_t i = 0; i < h->N; ++i)
+                if (!std::isfinite(mean_row[i])) ok = false;
+        if (!ok || !std::isfinite(nug_scale)) { ok = false; nug_scale = 1.0; sn = 1.0; }
+        for (int k = 0; k < SLOTP; ++k) sp[k] = 0.0;
+        sp[0] = 1.0; sp[1] = sn * sn; sp[2] = mu; sp[3] = pivot_tol_rel(h); sp[SP_SF2B] = nug_scale; sp[SP_KXX] = 1.0;
+        sp[4] = ok ? 0.0 : 1.0;
+        return ok;
+    }
     // theta = [term 1: l.., (alpha), sf] [term 2: l.., (alpha), sf] [c] sn [mu]; only |l| matters (l enters squared)
     int o = 0;
     auto lengths = [&](int nl, double* dst) {
@@ -1715,6 +1772,25 @@ int queue_predict_reduce(gphip_ctx* h, int64_t mc, int64_t mpad, int nslots) {
         HIPCHK(hipMalloc(&h->dPart, need));
         h->part_cap = need;
     }
+    const double* kss = nullptr;
+    if (h->custom) {                               // k(x*, x*) is a function of the test point for a general covariance function
+        const size_t want = (size_t)nslots * mpad * 8;
+        if (want > h->kss_cap) {
+            (void)hipFree(h->dKss);
+            h->dKss = nullptr; h->kss_cap = 0;
+            HIPCHK(hipMalloc(&h->dKss, want));
+            h->kss_cap = want;
+        }
+        const void* x = h->dXsT;                   // the (unscaled) test points [d][mpad], shared by the slots
+        long xbs = 0, ostride = (long)mpad;
+        int npad = (int)mpad, n = (int)mc, d = (int)h->d, ncp = std::max(h->ncp, 1);
+        const double* cp = h->dCustomP;
+        double* out = h->dKss;
+        void* params[] = {&x, &xbs, &npad, &n, &d, &cp, &ncp, &out, &ostride};
+        HIPCHK(hipModuleLaunchKernel(h->f_cdiag, (unsigned)((mc + 255) / 256), (unsigned)nslots, 1, 256, 1, 1, 0, h->stream, params,
+                                     nullptr));
+        kss = h->dKss;
+    }
     {
         ProfScope ps(h, 6, 4.0 * (double)mpad * h->Npad * nslots, (double)sizeof(T) * mpad * h->Npad * nslots);
         hipLaunchKernelGGL(predict_partial_kernel<T>, dim3((unsigned)Mt, (unsigned)nstrips, (unsigned)nslots), dim3(256),
@@ -1724,7 +1800,7 @@ int queue_predict_reduce(gphip_ctx* h, int64_t mc, int64_t mpad, int nslots) {
         hipLaunchKernelGGL(predict_finish_kernel, dim3((unsigned)((mc + 255) / 256), (unsigned)nslots), dim3(256), 0, h->stream,
                            (const double*)h->dPart, nstrips, (long)mpad, (const double*)h->dSlotp, (int)mc, (long)mpad,
                            h->dMean, h->dVar, h->pw_mean_test ? (const double*)h->dPwMeanT : nullptr,
-                           h->pw_nug_test ? (const double*)h->dPwNugT : nullptr);
+                           h->pw_nug_test ? (const double*)h->dPwNugT : nullptr, kss);
     }
     return 0;
 }
@@ -1905,7 +1981,7 @@ char* dist_panel_range(const gphip_ctx* h, int q) {
 }  // namespace
 
 static int create_ctx(const void* X, const void* y, int64_t N, int64_t d, int kernel_id, int mean_id, int dtype, int device,
-                      gphip_handle* out);
+                      gphip_handle* out, const char* custom_body = nullptr, int ncp = 0, std::string* why = nullptr);
 #include "gphip_multi.inc"
 
 namespace {
@@ -1947,10 +2023,12 @@ const char* gphip_last_error(gphip_handle h) { return h ? h->err.c_str() : "null
 
 // one plain context on one device: data upload, streams, kernel attributes
 static int create_ctx(const void* X, const void* y, int64_t N, int64_t d, int kernel_id, int mean_id, int dtype,
-                      int device /* < 0: current */, gphip_handle* out) {
+                      int device /* < 0: current */, gphip_handle* out, const char* custom_body, int ncp, std::string* why) {
     if (!out) return GPHIP_ERR_ARG;
     *out = nullptr;
     if (!X || !y) return GPHIP_ERR_ARG;
+    if (custom_body) kernel_id = GPHIP_KERNEL_CUSTOM;
+    else if (kernel_id == GPHIP_KERNEL_CUSTOM) return GPHIP_ERR_ARG;      // (only gphip_create_custom makes such a handle)
     if (N < 1 || d < 1) return GPHIP_ERR_DIM;
     // (d > KB_LDS_MAXD = 32: the kernel build reads the point tiles from global memory instead of LDS; gradients stay limited)
     // kernel_id: a plain named kernel, or GPHIP_KERNEL_COMPOSE(term1, op, term2, offset)
@@ -1972,7 +2050,7 @@ static int create_ctx(const void* X, const void* y, int64_t N, int64_t d, int ke
     const int id1 = composed ? (kernel_id & 0xff) : kernel_id, id2 = composed ? ((kernel_id >> 8) & 0xff) : 0;
     const int op = composed ? ((kernel_id >> 16) & 0xf) : 0, offs = composed ? ((kernel_id >> 20) & 0xf) : 0;
     Base b1{0, false}, b2{0, false};
-    if (kernel_id != GPHIP_KERNEL_NULL) {
+    if (kernel_id != GPHIP_KERNEL_NULL && !custom_body) {
         if (kernel_id < 0 || !base(id1, b1)) return GPHIP_ERR_ARG;
         if (op < 0 || op > 2 || offs > 1 || (op != 0 && !base(id2, b2))) return GPHIP_ERR_ARG;
     }
@@ -1995,6 +2073,12 @@ static int create_ctx(const void* X, const void* y, int64_t N, int64_t d, int ke
     if (kernel_id == GPHIP_KERNEL_NULL) {
         h->kt = 0; h->nl = 0;
         h->p = 1 + (mean_id == GPHIP_MEAN_CONST ? 1 : 0);
+    } else if (custom_body) {
+        // a covariance function given as source text: the general-form code paths (kt 2) around a kernel build compiled below
+        h->custom = true; h->ncp = ncp;
+        h->ks = KSpec{4, 0, 0, 0};
+        h->kt = 2; h->nl = (int)d; h->nl2 = 0;
+        h->p = ncp + 1 + (mean_id == GPHIP_MEAN_CONST ? 1 : 0);
     } else {
         // SE / Matern-5/2 alone keep their specialised kernels (kt 0 / 1); everything else runs the general form (kt 2)
         h->ks = KSpec{b1.fam, b2.fam, op, offs};
@@ -2034,9 +2118,43 @@ static int create_ctx(const void* X, const void* y, int64_t N, int64_t d, int ke
     if (DISPATCH(h, upload, h, h->dXt, xt, h->stream) != GPHIP_OK) return bail(GPHIP_ERR_HIP);
     if (DISPATCH(h, upload, h, h->dY, yp, h->stream) != GPHIP_OK) return bail(GPHIP_ERR_HIP);
     if (DISPATCH(h, set_func_attrs, h) != GPHIP_OK) return bail(GPHIP_ERR_HIP);
+    if (custom_body) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, h->device) != hipSuccess) return bail(GPHIP_ERR_HIP);
+        std::string arch = prop.gcnArchName;                   // "gfx950:sramecc+:xnack-" -> "gfx950"
+        arch = arch.substr(0, arch.find(':'));
+        RtcResult r;
+        std::string msg;
+        if (!rtc_compile_custom(custom_body, dtype, arch.c_str(), r, msg)) {
+            if (why) *why = msg;
+            return bail(rtc().ok() ? GPHIP_ERR_ARG : GPHIP_ERR_UNSUPPORTED);
+        }
+        if (hipModuleLoadData(&h->cmod, r.code.data()) != hipSuccess ||
+            hipModuleGetFunction(&h->f_cbuild, h->cmod, r.build.c_str()) != hipSuccess ||
+            hipModuleGetFunction(&h->f_cdiag, h->cmod, r.diag.c_str()) != hipSuccess ||
+            hipModuleGetFunction(&h->f_cprep, h->cmod, r.prep.c_str()) != hipSuccess) {
+            if (why) *why = "loading the compiled covariance function failed";
+            return bail(GPHIP_ERR_HIP);
+        }
+    }
     apply_env_options(h);
     *out = h;
     return GPHIP_OK;
+}
+
+namespace {
+thread_local std::string g_create_error;
+}
+/* why the last gphip_create_custom of this thread failed (compiler log of the covariance function, ..) */
+const char* gphip_create_error(void) { return g_create_error.c_str(); }
+
+int gphip_create_custom(const void* X, const void* y, int64_t N, int64_t d, const char* body, int nparams, int mean_id,
+                        int dtype, int device, gphip_handle* out) {
+    g_create_error.clear();
+    if (!out) return GPHIP_ERR_ARG;
+    *out = nullptr;
+    if (!body || !*body || nparams < 0 || nparams > 4096) { g_create_error = "null / empty function body or bad parameter count"; return GPHIP_ERR_ARG; }
+    return create_ctx(X, y, N, d, GPHIP_KERNEL_CUSTOM, mean_id, dtype, device, out, body, nparams, &g_create_error);
 }
 
 // devices/ndev: NULL/0 = the current device; one ordinal = that device; several = a multi-device handle
@@ -2084,6 +2202,8 @@ int gphip_destroy(gphip_handle h) {
     for (void* pk : h->packed) (void)hipFree(pk);
     (void)hipFree(h->dOwn); (void)hipFree(h->dDistAdj); (void)hipFree(h->dZ);
     (void)hipFree(h->dScal8); (void)hipFree(h->drain_buf);
+    (void)hipFree(h->dKss);
+    if (h->cmod) (void)hipModuleUnload(h->cmod);
     if (h->cstream) (void)hipStreamDestroy(h->cstream);
     free_slots(h);
     (void)hipFree(h->dXt); (void)hipFree(h->dY); (void)hipFree(h->dExp2);
@@ -2137,6 +2257,7 @@ int gphip_loglik_grad(gphip_handle h, const double* theta, int p, double* out, d
         return null_kernel_batch(h, theta, 1, out, nullptr, info, grad);
     }
     std::lock_guard<std::recursive_mutex> lk(h->mu);
+    if (h->custom) return fail(h, GPHIP_ERR_UNSUPPORTED, "gphip_loglik_grad: no analytic gradient for a run-time compiled covariance function");
     // the gradient reductions keep (d + 1) point tiles (general form: 4 d + 1) in LDS: beyond KB_LDS_MAXD dimensions only the
     // likelihood / fit / prediction paths are implemented (they read the points from global memory instead)
     if (h->d > KB_LDS_MAXD) return fail(h, GPHIP_ERR_UNSUPPORTED, "gphip_loglik_grad supports input dimensions up to 32");

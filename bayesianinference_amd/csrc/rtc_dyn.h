@@ -1,0 +1,164 @@
+// rtc_dyn.h -- hiprtc bound at run time (dlopen), for handles whose covariance function arrives as source text
+// (gphip_create_custom).  The reference evaluates ANY `kernel @@ points[[{i,j}]]` (BGP:29-33); the named kernels of this
+// library are compiled offline, everything else is compiled here, once per handle, into the SAME kernel build: the
+// [rtc-begin] .. [rtc-end] region of gp_kernels.h is read back from the source tree next to the library
+// (<lib dir>/../csrc/gp_kernels.h, or $GPHIP_SRC_DIR), prefixed with GP_CUSTOM_KERNEL and followed by the caller's function.
+// libgphip.so carries no link-time dependency on hiprtc; a process that never creates such a handle never loads it.
+#pragma once
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+#include <fstream>
+#include <mutex>
+#include <sstream>
+#include <string>
+#include <vector>
+
+namespace gphip {
+
+struct RtcApi {
+    void* so = nullptr;
+    typedef struct _hiprtcProgram* prog_t;
+    int (*CreateProgram)(prog_t*, const char*, const char*, int, const char* const*, const char* const*) = nullptr;
+    int (*DestroyProgram)(prog_t*) = nullptr;
+    int (*AddNameExpression)(prog_t, const char*) = nullptr;
+    int (*CompileProgram)(prog_t, int, const char* const*) = nullptr;
+    int (*GetProgramLogSize)(prog_t, size_t*) = nullptr;
+    int (*GetProgramLog)(prog_t, char*) = nullptr;
+    int (*GetLoweredName)(prog_t, const char*, const char**) = nullptr;
+    int (*GetCodeSize)(prog_t, size_t*) = nullptr;
+    int (*GetCode)(prog_t, char*) = nullptr;
+    bool ok() const { return so != nullptr; }
+};
+
+inline const RtcApi& rtc() {
+    static RtcApi api;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char* env = getenv("GPHIP_HIPRTC_PATH");
+        const char* cands[] = {env, "libhiprtc.so", "libhiprtc.so.7", "/opt/rocm/lib/libhiprtc.so"};
+        for (const char* c : cands) {
+            if (!c || !*c) continue;
+            void* so = dlopen(c, RTLD_NOW);
+            if (!so) continue;
+            RtcApi a;
+            a.so = so;
+#define GP_SYM(field, sym) a.field = reinterpret_cast<decltype(a.field)>(dlsym(so, sym))
+            GP_SYM(CreateProgram, "hiprtcCreateProgram");
+            GP_SYM(DestroyProgram, "hiprtcDestroyProgram");
+            GP_SYM(AddNameExpression, "hiprtcAddNameExpression");
+            GP_SYM(CompileProgram, "hiprtcCompileProgram");
+            GP_SYM(GetProgramLogSize, "hiprtcGetProgramLogSize");
+            GP_SYM(GetProgramLog, "hiprtcGetProgramLog");
+            GP_SYM(GetLoweredName, "hiprtcGetLoweredName");
+            GP_SYM(GetCodeSize, "hiprtcGetCodeSize");
+            GP_SYM(GetCode, "hiprtcGetCode");
+#undef GP_SYM
+            if (a.CreateProgram && a.DestroyProgram && a.AddNameExpression && a.CompileProgram && a.GetProgramLogSize &&
+                a.GetProgramLog && a.GetLoweredName && a.GetCodeSize && a.GetCode) {
+                api = a;
+                return;
+            }
+            dlclose(so);
+        }
+    });
+    return api;
+}
+
+// the [rtc-begin] .. [rtc-end] region of gp_kernels.h, from the source tree the library was built from
+inline bool rtc_kernel_source(std::string& region, std::string& why) {
+    std::vector<std::string> dirs;
+    if (const char* env = getenv("GPHIP_SRC_DIR")) dirs.push_back(env);
+    Dl_info info;
+    if (dladdr(reinterpret_cast<const void*>(&rtc_kernel_source), &info) && info.dli_fname) {
+        std::string lib = info.dli_fname;
+        const size_t slash = lib.rfind('/');
+        const std::string dir = slash == std::string::npos ? "." : lib.substr(0, slash);
+        dirs.push_back(dir + "/../csrc");
+        dirs.push_back(dir);
+    }
+    for (const std::string& d : dirs) {
+        std::ifstream f(d + "/gp_kernels.h");
+        if (!f) continue;
+        std::stringstream ss;
+        ss << f.rdbuf();
+        const std::string text = ss.str();
+        const size_t b = text.find("// [rtc-begin]"), e = text.find("// [rtc-end]");
+        if (b == std::string::npos || e == std::string::npos || e < b) continue;
+        region = text.substr(b, e - b);
+        return true;
+    }
+    why = "gp_kernels.h (with its [rtc-begin] / [rtc-end] region) not found next to the library; set GPHIP_SRC_DIR to the csrc directory";
+    return false;
+}
+
+struct RtcResult {
+    std::vector<char> code;                      // the code object for hipModuleLoadData
+    std::string build, diag, prep;               // lowered names of the three kernels
+};
+
+// body: the statements of   template <typename T> T k(X, Y, P, D)   -- X(k) / Y(k) coordinate k of the two points, P(k)
+// hyper-parameter k, D the input dimension, T the handle's arithmetic type; must `return` the covariance.
+inline bool rtc_compile_custom(const std::string& body, int dtype, const char* arch, RtcResult& out, std::string& why) {
+    const RtcApi& api = rtc();
+    if (!api.ok()) { why = "hiprtc could not be loaded (libhiprtc.so; set GPHIP_HIPRTC_PATH)"; return false; }
+    std::string region;
+    if (!rtc_kernel_source(region, why)) return false;
+    std::string src = "#define GP_CUSTOM_KERNEL 1\n" + region;
+    // names a Mathematica CForm of the function uses (GPHIP.wl translates a pure-function kernel that way)
+    src += "\nnamespace gphip {\n"
+           "template <typename A, typename B> __device__ __forceinline__ auto Power(A a, B b) -> decltype(a * 1.0f) { return pow(a, (decltype(a * 1.0f))b); }\n"
+           "template <typename A> __device__ __forceinline__ A Sqrt(A a) { return sqrt(a); }\n"
+           "template <typename A> __device__ __forceinline__ A Exp(A a) { return exp(a); }\n"
+           "template <typename A> __device__ __forceinline__ A Log(A a) { return log(a); }\n"
+           "template <typename A> __device__ __forceinline__ A Abs(A a) { return fabs(a); }\n"
+           "template <typename A> __device__ __forceinline__ A Sin(A a) { return sin(a); }\n"
+           "template <typename A> __device__ __forceinline__ A Cos(A a) { return cos(a); }\n"
+           "template <typename A> __device__ __forceinline__ A Tanh(A a) { return tanh(a); }\n"
+           "constexpr double Pi = 3.14159265358979323846, E = 2.71828182845904523536;\n"
+           "template <typename T>\n"
+           "__device__ T gphip_custom_k(PointRef<T> X, PointRef<T> Y, const double* __restrict__ Pp, int D) {\n"
+           "#define P(k) ((T)Pp[(k)])\n";
+    src += body;
+    src += "\n#undef P\n}\n}  // namespace gphip\n";
+    const std::string ty = dtype == 64 ? "double" : "float";
+    const std::string n_build = "gphip::kbuild_kernel<" + ty + ", 0, 3>", n_diag = "gphip::custom_diag_kernel<" + ty + ">",
+                      n_prep = "gphip::custom_prep_kernel<" + ty + ">";
+    RtcApi::prog_t prog = nullptr;
+    if (api.CreateProgram(&prog, src.c_str(), "gphip_custom_kernel.hip", 0, nullptr, nullptr) != 0) {
+        why = "hiprtcCreateProgram failed";
+        return false;
+    }
+    api.AddNameExpression(prog, n_build.c_str());
+    api.AddNameExpression(prog, n_diag.c_str());
+    api.AddNameExpression(prog, n_prep.c_str());
+    const std::string archopt = std::string("--offload-arch=") + arch;
+    const char* opts[] = {archopt.c_str(), "-O3", "-std=c++17"};
+    const int rc = api.CompileProgram(prog, 3, opts);
+    if (rc != 0) {
+        size_t n = 0;
+        api.GetProgramLogSize(prog, &n);
+        std::string log(n, '\0');
+        if (n) api.GetProgramLog(prog, &log[0]);
+        why = "the covariance function does not compile:\n" + log;
+        api.DestroyProgram(&prog);
+        return false;
+    }
+    const char* low = nullptr;
+    bool ok = true;
+    ok = ok && api.GetLoweredName(prog, n_build.c_str(), &low) == 0 && low; if (ok) out.build = low;
+    ok = ok && api.GetLoweredName(prog, n_diag.c_str(), &low) == 0 && low;  if (ok) out.diag = low;
+    ok = ok && api.GetLoweredName(prog, n_prep.c_str(), &low) == 0 && low;  if (ok) out.prep = low;
+    size_t sz = 0;
+    ok = ok && api.GetCodeSize(prog, &sz) == 0 && sz > 0;
+    if (ok) {
+        out.code.resize(sz);
+        ok = api.GetCode(prog, out.code.data()) == 0;
+    }
+    api.DestroyProgram(&prog);
+    if (!ok) why = "hiprtc produced no code object";
+    return ok;
+}
+
+}  // namespace gphip

@@ -191,6 +191,8 @@ def takePosteriorFraction(obj, frac: float):
 def _resolve_kernel(kernel):
     if kernel is None:
         return "null"
+    if isinstance(kernel, _lib.CustomKernel):                     # ANY covariance function, as source text (gphip_create_custom)
+        return kernel
     key = str(kernel).lower().replace(" ", "").replace("-", "")
     if key in _KERNEL_ALIASES:
         return _KERNEL_ALIASES[key]
@@ -206,7 +208,8 @@ def _resolve_kernel(kernel):
         if body in _KERNEL_ALIASES and _KERNEL_ALIASES[body] != "null" and offset:
             return _KERNEL_ALIASES[body] + offset
     raise ValueError(f"kernel {kernel!r} is not a named kernel {sorted(set(_KERNEL_ALIASES.values()))} or a composed form "
-                     "'term [(+|*) term] [+const]'; arbitrary pure functions stay on the reference's own path")
+                     "'term [(+|*) term] [+const]'; hand any other covariance function over as a _lib.CustomKernel (the source "
+                     "text of its body, compiled at run time into the device kernel build)")
 
 
 def _log_prior_function(prior, params):
@@ -356,7 +359,7 @@ def defineGaussianProcess(data, kernel, nugget="Constant", meanFunction=None, va
                 sn = th2[b, handle.p - (2 if mean == "const" else 1)]      # theta = (l.., sf, sn[, mu])
                 Kb[b][np.diag_indices(len(X))] += nug[b] - sn * sn
             K = Kb.reshape(K.shape)
-        if kname == "null":                                       # covarianceMatrix[.., nullKernel, ..] = nugget /@ points:
+        if isinstance(kname, str) and kname == "null":            # covarianceMatrix[.., nullKernel, ..] = nugget /@ points:
             return np.diagonal(K, axis1=-2, axis2=-1).copy()      # the DIAGONAL as a vector (BGP:27)
         return K
 
@@ -377,7 +380,8 @@ def defineGaussianProcess(data, kernel, nugget="Constant", meanFunction=None, va
         "KernelName": kname, "MeanName": mean, "LikelihoodBranch": branch,
         "GaussianProcessData": {
             "ModelFunctions": {
-                "KernelFunction": (kname, wl_kernel_expression(kname)),
+                "KernelFunction": ((kname.name, kname.body) if isinstance(kname, _lib.CustomKernel)
+                                   else (kname, wl_kernel_expression(kname))),
                 "NuggetFunction": nugget_fn if nugget_fn is not None else WL_NUGGET_EXPRESSION,
                 "MeanFunction": mean_fn if mean_fn is not None else mean,
                 "CovarianceFunction": covariance_function,
@@ -571,10 +575,15 @@ def mixture_plot_moments(pred: Mapping):
 def save_gaussian_process(obj, path: str, theta=None):
     """Writes data, kernel/mean names, parameter specs, samples (if any) and an optional fitted theta."""
     X, Y = obj["Data"]
-    payload = {"X": X, "Y": Y, "kernel": obj["KernelName"], "mean": obj["MeanName"],
+    kern = obj["KernelName"]
+    custom = isinstance(kern, _lib.CustomKernel)
+    payload = {"X": X, "Y": Y, "kernel": "custom:" + kern.name if custom else kern, "mean": obj["MeanName"],
                "param_names": np.array([p[0] for p in obj["Parameters"]]),
                "param_lo": np.array([p[1] for p in obj["Parameters"]], dtype=np.float64),
                "param_hi": np.array([p[2] for p in obj["Parameters"]], dtype=np.float64)}
+    if custom:                                                    # the function travels as its source text
+        payload["kernel_body"] = kern.body
+        payload["kernel_nparams"] = kern.nparams
     if "Samples" in obj:
         payload["sample_points"] = np.array([smp["Point"] for smp in obj["Samples"]], dtype=np.float64)
         payload["sample_logw"] = np.array([smp["CrudeLogPosteriorWeight"] for smp in obj["Samples"]])
@@ -589,6 +598,8 @@ def load_gaussian_process(path: str, variablePrior="Uniform", **rules):
     z = np.load(path, allow_pickle=False)
     params = [(str(n), float(a), float(b)) for n, a, b in zip(z["param_names"], z["param_lo"], z["param_hi"])]
     kernel = None if str(z["kernel"]) == "null" else str(z["kernel"])
+    if "kernel_body" in z:
+        kernel = _lib.CustomKernel(str(z["kernel_body"]), int(z["kernel_nparams"]), name=str(z["kernel"])[len("custom:"):])
     mean = "Constant" if str(z["mean"]) == "const" else None
     obj = defineGaussianProcess((z["X"], z["Y"]), kernel, "Constant", mean, params, variablePrior, **rules)
     if obj.failed:

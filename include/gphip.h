@@ -71,6 +71,25 @@ typedef struct gphip_ctx* gphip_handle;
 #define GPHIP_OP_PRODUCT 2
 #define GPHIP_KERNEL_COMPOSE(term1, op, term2, offset) \
     ((term1) | ((term2) << 8) | ((op) << 16) | ((offset) << 20) | (1 << 24))
+/* ANY other covariance function: source text compiled at run time (hiprtc) into the library's own kernel build.
+ * `body` = the statements of
+ *     template <typename T> T k(X, Y, P, D) { <body> }
+ * where X(k) / Y(k) are coordinate k (0-based) of the two points, P(k) the function's k-th hyper-parameter, D the input
+ * dimension and T the handle's arithmetic type (double / float); it must `return` the covariance WITHOUT the nugget.  Device
+ * math (exp, sqrt, pow, fabs, sin, ..) and the names Mathematica's CForm emits (Power, Sqrt, Exp, Log, Abs, Sin, Cos, Tanh, Pi, E)
+ * are available.  Example, SE-ARD:  "T s = 0; for (int k = 0; k < D; ++k) { T u = (X(k) - Y(k)) / P(k); s += u * u; }
+ * return P(D) * P(D) * exp((T)-0.5 * s);"  with nparams = d + 1.
+ * theta layout of such a handle:  [p_0 .. p_{nparams-1}] sn [mu].  The function may be non-stationary: the prior variance
+ * k(x, x) is evaluated per point on the device (prediction variance, pivot tolerance of the factorisation).
+ * Likelihoods, batches, fits, predictions, posterior-sample mixtures, covariance exports and the native sampler work as for the
+ * named kernels; gphip_loglik_grad returns GPHIP_ERR_UNSUPPORTED; single-device handles only.  Replaces the reference's
+ * `kernel @@ points[[{i,j}]]` for an arbitrary pure function (BGP:29-33, cross form BGP:100-109).
+ * Errors: GPHIP_ERR_ARG = the body does not compile (gphip_create_error() returns the compiler's log),
+ * GPHIP_ERR_UNSUPPORTED = no hiprtc / the library's kernel source is not next to it (see csrc/rtc_dyn.h). */
+#define GPHIP_KERNEL_CUSTOM 100
+int gphip_create_custom(const void* X, const void* y, int64_t N, int64_t d, const char* body, int nparams, int mean_id,
+                        int dtype, int device /* < 0: current */, gphip_handle* out);
+const char* gphip_create_error(void);
 #define GPHIP_MEAN_ZERO 0            /* Function[0]  (BGP:168,255)                                    */
 #define GPHIP_MEAN_CONST 1           /* Function[mu], mu = last entry of theta                        */
 

@@ -82,7 +82,27 @@ def n_lengthscales(kernel: str, d: int) -> int:
     raise ValueError(kernel)
 
 
+def is_custom(kernel) -> bool:
+    """A covariance function given as a Python function instead of a name: any object with `fn(A, B, p)` (numpy, broadcasting
+    over point arrays [.., d]) and `nparams`; theta = [p_0 .. p_{nparams-1}, sn (, mu)].  Stands for the reference's arbitrary
+    `kernel @@ points[[{i,j}]]` (BGP:29-33, 100-109)."""
+    return hasattr(kernel, "fn") and hasattr(kernel, "nparams") and not isinstance(kernel, str)
+
+
+def custom_kernel_matrix(kernel, theta, A: np.ndarray, B: np.ndarray) -> np.ndarray:
+    A = np.atleast_2d(np.asarray(A, dtype=np.float64))
+    B = np.atleast_2d(np.asarray(B, dtype=np.float64))
+    p = np.asarray(theta, dtype=np.float64)[:kernel.nparams]
+    rows = max(1, _BLOCK_ELEMS // max(1, B.shape[0] * A.shape[1]))
+    out = np.empty((A.shape[0], B.shape[0]))
+    for r0 in range(0, A.shape[0], rows):
+        out[r0:r0 + rows] = kernel.fn(A[r0:r0 + rows, None, :], B[None, :, :], p)
+    return out
+
+
 def n_params(kernel: str, d: int, mean: str = "zero") -> int:
+    if is_custom(kernel):
+        return kernel.nparams + 1 + (1 if mean == "const" else 0)
     # null kernel: theta = (sigma_n [, mu]); general: [term 1: l.., (alpha), sf] [term 2 ..] [c] sn [mu]
     terms, _, offset = parse_kernel(kernel)
     base = 1 if kernel == "null" else sum(_term_params(t, d) for t in terms) + (1 if offset else 0) + 1
@@ -116,6 +136,9 @@ def split_general(kernel: str, d: int, theta, mean: str = "zero"):
 
 def split_theta(kernel: str, d: int, theta, mean: str = "zero"):
     theta = np.asarray(theta, dtype=np.float64)
+    if is_custom(kernel):
+        m = kernel.nparams
+        return np.ones(d), 1.0, float(theta[m]), (float(theta[m + 1]) if mean == "const" else 0.0)
     if kernel not in ("se", "se_ard", "matern52", "matern52_ard", "null"):      # general form: callers use split_general
         terms, _, _, sn, mu = split_general(kernel, d, theta, mean)
         return terms[0][1], terms[0][3], sn, mu
@@ -209,6 +232,10 @@ def covariance_matrix(kernel: str, theta, X: np.ndarray, mean: str = "zero", nug
     X = np.atleast_2d(np.asarray(X, dtype=np.float64))
     ell, sf, sn, _ = split_theta(kernel, X.shape[1], theta, mean)
     nug = np.full(X.shape[0], sn * sn) if nugget_fn is None else np.array([float(nugget_fn(x)) for x in X])
+    if is_custom(kernel):
+        K = custom_kernel_matrix(kernel, theta, X, X)
+        K[np.diag_indices_from(K)] += nug
+        return K
     if kernel == "null":
         return nug
     if kernel in ("se", "se_ard", "matern52", "matern52_ard"):
@@ -362,6 +389,9 @@ def k_and_kappa(kernel: str, theta, X, Xs, mean: str = "zero", nugget_fn=None):
     Xs = np.atleast_2d(np.asarray(Xs, dtype=np.float64))
     ell, sf, sn, _ = split_theta(kernel, X.shape[1], theta, mean)
     nug = np.full(Xs.shape[0], sn * sn) if nugget_fn is None else np.array([float(nugget_fn(x)) for x in Xs])
+    if is_custom(kernel):
+        p = np.asarray(theta, dtype=np.float64)[:kernel.nparams]
+        return custom_kernel_matrix(kernel, theta, X, Xs), np.asarray(kernel.fn(Xs, Xs, p), dtype=np.float64) + nug
     if kernel in ("se", "se_ard", "matern52", "matern52_ard", "null"):
         k = kernel_matrix(kernel, ell, sf, X, Xs)
         kappa = (0.0 if kernel == "null" else sf * sf) + nug

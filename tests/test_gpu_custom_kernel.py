@@ -1,0 +1,161 @@
+"""ANY covariance function on the device (gphip_create_custom): the reference evaluates an arbitrary pure function
+`kernel @@ points[[{i,j}]]` (BGP:29-33; cross form BGP:100-109; kappa BGP:110-115).  The caller's function arrives as source
+text, is compiled at run time (hiprtc) into the library's own kernel build, and everything downstream -- factorisation,
+log-likelihood, prediction, posterior-sample mixtures -- is the same code as for the named kernels.  Parity: against the CPU
+oracle evaluating the same function in numpy (1e-8 fp64, 1e-3 fp32), and against the named-kernel handle where one exists."""
+import numpy as np
+import pytest
+
+from bayesianinference_amd import _lib, synthetic as syn
+from oracle import gp_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+SE_ARD_BODY = "T s = 0; for (int k = 0; k < D; ++k) { const T u = (X(k) - Y(k)) / P(k); s += u * u; } return P(D) * P(D) * exp((T)-0.5 * s);"
+
+
+def se_ard_fn(A, B, p):
+    d = A.shape[-1]
+    return p[d] ** 2 * np.exp(-0.5 * (((A - B) / p[:d]) ** 2).sum(-1))
+
+
+# non-stationary: squared exponential x (1 + c x_0 x'_0)  -- k(x, x) depends on the point
+NONSTAT_BODY = ("T s = 0; for (int k = 0; k < D; ++k) { const T u = X(k) - Y(k); s += u * u; } "
+                "return P(1) * P(1) * exp((T)-0.5 * s / (P(0) * P(0))) * ((T)1 + P(2) * P(2) * X(0) * Y(0));")
+
+
+def nonstat_fn(A, B, p):
+    return p[1] ** 2 * np.exp(-0.5 * ((A - B) ** 2).sum(-1) / p[0] ** 2) * (1.0 + p[2] ** 2 * A[..., 0] * B[..., 0])
+
+
+# periodic (MacKay), the way Mathematica's CForm would print it for d = 1
+PERIODIC_BODY = "return Power(P(2),2)*Exp((-2*Power(Sin((Pi*(X(0) - Y(0)))/P(1)),2))/Power(P(0),2));"
+
+
+def periodic_fn(A, B, p):
+    return p[2] ** 2 * np.exp(-2.0 * np.sin(np.pi * (A[..., 0] - B[..., 0]) / p[1]) ** 2 / p[0] ** 2)
+
+
+def close(a, b, n, tol=1e-8):
+    return abs(a - b) <= tol * max(1.0, abs(b), n)
+
+
+@pytest.mark.parametrize("n,d", [(700, 3), (300, 8), (1500, 2), (260, 40)])
+def test_se_ard_as_source_text_matches_named_kernel_and_oracle(n, d):
+    X, y = syn.make_dataset(n, d)
+    Xs = syn.make_test_points(100, d)
+    th = syn.default_theta("se_ard", d)
+    ck = _lib.CustomKernel(SE_ARD_BODY, d + 1, fn=se_ard_fn)
+    h = _lib.Handle(X, y, ck)
+    ref = _lib.Handle(X, y, "se_ard")
+    assert h.p == d + 2
+    ll, ld, qd, info = h.loglik_parts(th)
+    l0, ld0, qd0, _ = ref.loglik_parts(th)
+    assert info == 0 and close(ll, l0, n, 1e-10) and close(ld, ld0, n, 1e-10) and close(qd, qd0, n, 1e-9)
+    want = orc.log_likelihood(ck, th, X, y, parts=True)
+    assert close(ll, want[0], n) and close(ld, want[1], n) and close(qd, want[2], n)
+    assert h.fit(th) == 0 and ref.fit(th) == 0
+    mu, var = h.predict(Xs)
+    mu0, var0 = ref.predict(Xs)
+    np.testing.assert_allclose(mu, mu0, rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(var, var0, rtol=1e-7, atol=1e-12)
+    # batch of thetas, each slot with its own parameters
+    Th = np.array([th * (1.0 + 0.03 * k) for k in range(5)])
+    lb, ib = h.loglik_batch(Th)
+    lb0, _ = ref.loglik_batch(Th)
+    assert (ib == 0).all()
+    np.testing.assert_allclose(lb, lb0, rtol=1e-10, atol=1e-8)
+    h.close(); ref.close()
+
+
+@pytest.mark.parametrize("body,fn,npar,d,theta", [
+    (NONSTAT_BODY, nonstat_fn, 3, 2, [0.9, 1.2, 0.7, 0.15]),
+    (NONSTAT_BODY, nonstat_fn, 3, 5, [1.6, 0.8, 0.4, 0.2]),
+    (PERIODIC_BODY, periodic_fn, 3, 1, [1.1, 2.3, 1.4, 0.1]),
+])
+def test_arbitrary_covariance_functions_against_the_oracle(body, fn, npar, d, theta):
+    n = 900
+    X, y = syn.make_dataset(n, d)
+    Xs = syn.make_test_points(150, d)
+    th = np.array(theta)
+    ck = _lib.CustomKernel(body, npar, fn=fn)
+    h = _lib.Handle(X, y, ck)
+    ll, ld, qd, info = h.loglik_parts(th)
+    want = orc.log_likelihood(ck, th, X, y, parts=True)
+    assert info == 0 and want[3] == 0
+    assert close(ll, want[0], n) and close(ld, want[1], n) and close(qd, want[2], n)
+    assert h.fit(th) == 0
+    mu, var = h.predict(Xs)
+    mo, so = orc.predict_internal(ck, th, X, y, Xs)
+    np.testing.assert_allclose(mu, mo, rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(np.sqrt(var), so, rtol=1e-7)       # (k(x*, x*) is a function of the test point here)
+    # the covariance matrix itself, entry by entry
+    K = h.covariance(th)
+    np.testing.assert_allclose(K, orc.covariance_matrix(ck, th, X), rtol=1e-12, atol=1e-14)
+    # constant mean, fp32, verdicts
+    hc = _lib.Handle(X, y, ck, mean="const")
+    thc = np.append(th, 0.2)
+    assert close(hc.loglik(thc)[0], orc.log_likelihood(ck, thc, X, y, "const"), n)
+    h32 = _lib.Handle(X, y, ck, dtype=32)
+    l32, i32 = h32.loglik(th)
+    assert i32 == 0 and abs(l32 - want[0]) <= 1e-3 * max(1.0, abs(want[0]), n)
+    bad = th.copy(); bad[0] = np.nan
+    assert h.loglik(bad)[1] == _lib.INFO_NAN and h.loglik(th)[1] == 0
+    Xd = X.copy(); Xd[n // 2] = Xd[3]
+    hd = _lib.Handle(Xd, y, ck)
+    zero_nug = th.copy(); zero_nug[-1] = 0.0
+    assert hd.loglik(zero_nug)[1] == _lib.INFO_NOT_SPD and hd.loglik(th)[1] == 0
+    with pytest.raises(_lib.GphipError) as e:
+        h.loglik_grad(th)
+    assert e.value.status == 6
+    for x in (h, hc, h32, hd):
+        x.close()
+
+
+def test_posterior_sample_mixture_and_errors():
+    n, d = 400, 2
+    X, y = syn.make_dataset(n, d)
+    Xs = syn.make_test_points(40, d)
+    ck = _lib.CustomKernel(NONSTAT_BODY, 3, fn=nonstat_fn)
+    h = _lib.Handle(X, y, ck)
+    samples = np.array([[0.9, 1.2, 0.7, 0.15], [1.0, 1.1, 0.5, 0.2], [0.8, 1.3, 0.9, 0.12]])
+    mu, var, info = h.predict_samples(samples, Xs)
+    assert (info == 0).all()
+    for s in range(3):
+        mo, so = orc.predict_internal(ck, samples[s], X, y, Xs)
+        np.testing.assert_allclose(mu[s], mo, rtol=1e-7, atol=1e-9)
+        np.testing.assert_allclose(np.sqrt(var[s]), so, rtol=1e-7)
+    h.close()
+    with pytest.raises(_lib.GphipError) as e:            # the compiler's log comes back with the error
+        _lib.Handle(X, y, _lib.CustomKernel("return P(0) * no_such_symbol;", 1))
+    assert e.value.status == 1 and "no_such_symbol" in str(e.value)
+    with pytest.raises(_lib.GphipError):
+        _lib.Handle(X, y, ck, device=[0, 0])
+
+
+def test_host_mirror_object_with_a_function_valued_kernel(tmp_path):
+    """defineGaussianProcess / predictFromGaussianProcess / persistence with a CustomKernel: the object a reference user builds
+    with an arbitrary `kernel` pure function (BGP:228-330), its closure against the oracle, the saved file carrying the source text."""
+    from bayesianinference_amd import gaussian_process as gp
+    X, y = syn.make_dataset(300, 2)
+    ck = _lib.CustomKernel(NONSTAT_BODY, 3, fn=nonstat_fn, name="se_times_linear")
+    variables = [("l", 0.2, 5.0), ("sf", 0.2, 5.0), ("c", 0.0, 2.0), ("sn", 0.02, 1.0)]
+    obj = gp.defineGaussianProcess((X, y), ck, variables=variables)
+    assert not obj.failed and obj["GaussianProcessData"]["ModelFunctions"]["KernelFunction"] == ("se_times_linear", NONSTAT_BODY)
+    th = np.array([0.9, 1.2, 0.7, 0.15])
+    assert obj["LogLikelihoodFunction"](th) == pytest.approx(orc.log_likelihood(ck, th, X, y), rel=1e-8)
+    K = obj["GaussianProcessData"]["ModelFunctions"]["CovarianceFunction"](th)
+    np.testing.assert_allclose(K, orc.covariance_matrix(ck, th, X), rtol=1e-12, atol=1e-14)
+    pts = syn.make_test_points(9, 2)
+    samples = [{"Point": th, "CrudePosteriorWeight": 1.0, "CrudeLogPosteriorWeight": 0.0}]
+    a = gp.predictFromGaussianProcess(obj.append({"Samples": samples}), pts)
+    mo, so = orc.predict_internal(ck, th, X, y, pts)
+    np.testing.assert_allclose(a["Mean"][0], mo, rtol=1e-7, atol=1e-9)
+    path = str(tmp_path / "gp_custom.npz")
+    gp.save_gaussian_process(obj.append({"Samples": samples}), path, theta=th)
+    obj2, th2 = gp.load_gaussian_process(path)
+    assert not obj2.failed and obj2["KernelName"].body == NONSTAT_BODY and obj2["KernelName"].nparams == 3
+    b = gp.predictFromGaussianProcess(obj2, pts)
+    np.testing.assert_allclose(a["Mean"], b["Mean"], rtol=1e-12)
+    with pytest.raises(ValueError):                      # wrong number of variables for the function's parameter count
+        gp.defineGaussianProcess((X, y), ck, variables=variables[:3])
