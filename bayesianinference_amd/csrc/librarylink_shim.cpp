@@ -92,6 +92,32 @@ EXTERN_C DLLEXPORT int gphip_wl_create(WolframLibraryData lib, mint argc, MArgum
     return LIBRARY_NO_ERROR;
 }
 
+// gphip_wl_create_custom[X (N x d), y (N), body (C statements of the covariance function, see gphip_create_custom), nparams,
+// meanId, dtype, device] -> handle id.  ANY `kernel @@ points[[{i,j}]]` of the reference (BGP:29-33): GPHIP.wl prints the pure
+// function with CForm and hands the text over; the library compiles it at run time into its own kernel build.  A body that
+// does not compile returns LIBRARY_FUNCTION_ERROR (the package then falls back to the reference's own path).
+EXTERN_C DLLEXPORT int gphip_wl_create_custom(WolframLibraryData lib, mint argc, MArgument* args, MArgument res) {
+    if (argc != 7) return LIBRARY_FUNCTION_ERROR;
+    MTensor X = MArgument_getMTensor(args[0]), y = MArgument_getMTensor(args[1]);
+    if (lib->MTensor_getRank(X) != 2 || lib->MTensor_getRank(y) != 1) return LIBRARY_RANK_ERROR;
+    if (lib->MTensor_getType(X) != MType_Real || lib->MTensor_getType(y) != MType_Real) return LIBRARY_TYPE_ERROR;
+    const mint* dims = lib->MTensor_getDimensions(X);
+    if (lib->MTensor_getDimensions(y)[0] != dims[0]) return LIBRARY_DIMENSION_ERROR;
+    char* body = MArgument_getUTF8String(args[2]);
+    gphip_handle h = nullptr;
+    const int rc = gphip_create_custom(lib->MTensor_getRealData(X), lib->MTensor_getRealData(y), dims[0], dims[1], body,
+                                       (int)MArgument_getInteger(args[3]), (int)MArgument_getInteger(args[4]),
+                                       (int)MArgument_getInteger(args[5]), (int)MArgument_getInteger(args[6]), &h);
+    lib->UTF8String_disown(body);
+    if (rc == GPHIP_ERR_ARG) return LIBRARY_FUNCTION_ERROR;          // the body does not compile (gphip_create_error() has the log)
+    if (rc != GPHIP_OK) return status_to_wl(rc);
+    g_handles.push_back(h);
+    g_n.push_back(dims[0]);
+    g_d.push_back(dims[1]);
+    MArgument_setInteger(res, (mint)g_handles.size() - 1);
+    return LIBRARY_NO_ERROR;
+}
+
 // gphip_wl_set_option[h, name, value] -> 0
 EXTERN_C DLLEXPORT int gphip_wl_set_option(WolframLibraryData lib, mint argc, MArgument* args, MArgument res) {
     if (argc != 3) return LIBRARY_FUNCTION_ERROR;

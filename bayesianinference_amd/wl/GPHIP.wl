@@ -61,6 +61,8 @@ nuggetIndex[{t1_, op_, t2_, offset_}, d_] := termParams[t1, d] + If[op === 0, 0,
 (* ---- LibraryLink bindings (argument lists are checked against the shim by tests/test_wl_package.py) ---- *)
 gpCreate   := gpCreate   = LibraryFunctionLoad[$GPHIPLibrary, "gphip_wl_create",
 	{{Real, 2, "Constant"}, {Real, 1, "Constant"}, Integer, Integer, Integer, {Integer, 1, "Constant"}}, Integer];
+gpCreateCustom := gpCreateCustom = LibraryFunctionLoad[$GPHIPLibrary, "gphip_wl_create_custom",
+	{{Real, 2, "Constant"}, {Real, 1, "Constant"}, "UTF8String", Integer, Integer, Integer, Integer}, Integer];
 gpSetOpt   := gpSetOpt   = LibraryFunctionLoad[$GPHIPLibrary, "gphip_wl_set_option", {Integer, "UTF8String", Real}, Integer];
 gpLogLik   := gpLogLik   = LibraryFunctionLoad[$GPHIPLibrary, "gphip_wl_loglik",
 	{Integer, {Real, 1, "Constant"}}, {Real, 1}];        (* {value, info} *)
@@ -163,6 +165,30 @@ ensureFit[h_, theta_, fit_] := If[ Lookup[$fitted, h, None] === theta,
 	]
 ];
 
+(* ---- an arbitrary kernel as C text.  The kernel expression (in the parameter symbols) is applied to two symbolic points;
+   the result must be free of anything CForm cannot print as elementary arithmetic.  Coordinates become X(k) / Y(k), the
+   parameter symbols P(k) in the order of `variables` (k from 0): the argument convention of gphip_create_custom.  The
+   library's theta for such a handle is {p.., sn}: the reference's nugget arrives as values per point, so the sn slot is a
+   dummy 1. appended by customLift. ---- *)
+customKernelSpec[kerf_, vars_List, d_Integer] := Module[{xs, ys, expr, str},
+	xs = Array[gphipXc, d, 0]; ys = Array[gphipYc, d, 0];
+	expr = Quiet @ Check[kerf[xs, ys], $Failed];
+	If[ expr === $Failed || !FreeQ[expr, _Function | _Slot | _Piecewise | _If | _Which | _List | _Dot], Return[$Failed]];
+	expr = N[expr] /. Thread[vars -> Array[gphipPc, Length[vars], 0]];
+	(* anything left that is neither a coordinate / parameter accessor nor a System` function cannot be printed as C *)
+	If[ Cases[expr, sym_Symbol /; !MemberQ[{gphipXc, gphipYc, gphipPc}, sym] && Context[sym] =!= "System`", {0, Infinity}, Heads -> True] =!= {},
+		Return[$Failed]];
+	str = StringReplace[ToString[CForm[expr]], {"gphipXc" -> "X", "gphipYc" -> "Y", "gphipPc" -> "P"}];
+	{"Custom", "return " <> str <> ";", kerf, Length[vars], vars}
+];
+customSpecQ[spec_] := MatchQ[spec, {"Custom", _String, _, _Integer, _List}];
+customLift[spec_][theta_] := If[ customSpecQ[spec],
+	If[MatrixQ[theta], ArrayFlatten[{{theta, ConstantArray[1., {Length[theta], 1}]}}], Join[theta, {1.}]],
+	theta
+];
+hipKernelFunction[{"Custom", _, kerf_, _, vars_}, d_] := Function[theta, kerf /. Thread[vars -> theta]];
+hipNuggetFunction[{"Custom", __}, d_] := Function[theta, Function[1.]];       (* the dummy sn^2 the library puts on the diagonal *)
+
 Options[defineGaussianProcessHIP] = {"ConstantMean" -> False, "Precision" -> "Double", "Devices" -> Automatic, "LibraryOptions" -> {}};
 
 constantQ[f_] := MatchQ[f, "Constant" | Automatic];
@@ -182,11 +208,22 @@ defineGaussianProcessHIP[
 	own = "ConstantMean" | "Precision" | "Devices" | "LibraryOptions"
 },
 	If[ spec === $Failed,
-		(* not a native kernel: the reference path, with the reference's meaning of every argument (so the nugget and the
-		   mean must be given the reference's way too, not through the "Constant" shorthands of the named kernels) *)
+		(* not a named kernel: the reference's meaning of every argument (so the nugget and the mean must be given the
+		   reference's way too, not through the "Constant" shorthands of the named kernels) *)
 		If[ StringQ[nugf] || nugf === Automatic || StringQ[meanf],
 			Message[defineGaussianProcessHIP::nonnative, kerf];
 			Return[inferenceObject[$Failed]]
+		];
+		(* ANY pure function of two points in the parameter symbols (BGP:29-33): printed with CForm and compiled by the
+		   library at run time into its own kernel build (gphip_create_custom).  Only when that is not possible -- the
+		   expression does not reduce to elementary functions of the coordinates, or the text does not compile -- does the
+		   object fall through to the reference's interpreted path *)
+		With[{custom = customKernelSpec[kerf, variables[[All, 1]], Dimensions[dataIn][[2]]]},
+			If[ custom =!= $Failed,
+				With[{obj = Quiet @ Check[hipGaussianProcess[dataIn -> dataOut, custom, nugf, meanf, variables, variablePrior, rest], $Failed]},
+					If[ obj =!= $Failed && !MatchQ[obj, inferenceObject[$Failed]], Return[obj]]
+				]
+			]
 		];
 		Return @ defineGaussianProcess[dataIn -> dataOut, kerf, nugf, meanf, variables, variablePrior,
 			Sequence @@ FilterRules[{rest}, Except[own]]]
@@ -220,7 +257,10 @@ hipGaussianProcess[dataIn_ -> dataOut_, spec_, nugf_, meanf_, variables_, variab
 	devices = Replace[Lookup[{rest}, "Devices", Automatic], {Automatic :> {Mod[$KernelID, Max[gpDevices[], 1]]}, i_Integer :> {i}}],
 	own = "ConstantMean" | "Precision" | "Devices" | "LibraryOptions"
 },
-	h = gpCreate[inputData, N @ Flatten[dataOut], kernelCode[spec], Boole[constMean], dtype, devices];
+	h = If[ customSpecQ[spec],
+		gpCreateCustom[inputData, N @ Flatten[dataOut], spec[[2]], spec[[4]], 0, dtype, First[devices]],
+		gpCreate[inputData, N @ Flatten[dataOut], kernelCode[spec], Boole[constMean], dtype, devices]
+	];
 	If[ !IntegerQ[h] || h < 0, Return[inferenceObject[$Failed]]];
 	KeyValueMap[gpSetOpt[h, #1, N[#2]]&, Association @ Lookup[{rest}, "LibraryOptions", {}]];
 	(* theta |-> function of the point, exactly as the reference builds them (expressionToFunction, BGP:257-262) *)
@@ -233,14 +273,14 @@ hipGaussianProcess[dataIn_ -> dataOut_, spec_, nugf_, meanf_, variables_, variab
 		touch[h];
 		Which[
 			pw, With[{ths = If[MatrixQ[theta], N @ theta, {N @ theta}]},
-				With[{res = toLogLik /@ gpLogLikBPW[h, ths, values[mean, meanPW, ths, inputData], values[nugget, nugPW, ths, inputData]]},
+				With[{res = toLogLik /@ gpLogLikBPW[h, customLift[spec][ths], values[mean, meanPW, ths, inputData], values[nugget, nugPW, ths, inputData]]},
 					If[MatrixQ[theta], res, First[res]]]],
 			MatrixQ[theta], toLogLik /@ gpLogLikB[h, N @ theta],
 			True, toLogLik @ gpLogLik[h, N @ theta]
 		]
 	];
 	fit = If[ pw,
-		Function[th, gpFitPW[h, th, Flatten @ values[mean, meanPW, {th}, inputData], Flatten @ values[nugget, nugPW, {th}, inputData]]],
+		Function[th, gpFitPW[h, customLift[spec][th], Flatten @ values[mean, meanPW, {th}, inputData], Flatten @ values[nugget, nugPW, {th}, inputData]]],
 		Function[th, gpFit[h, th]]
 	];
 	(* matrixInverseAndDet[covarianceFunction[theta]] (BayesianGaussianProcess.wl:130-141, 308): an Association with
@@ -266,12 +306,13 @@ hipGaussianProcess[dataIn_ -> dataOut_, spec_, nugf_, meanf_, variables_, variab
 				"MeanFunction" -> mean,
 				(* the library builds K with the constant sn^2 on the diagonal; a point-dependent nugget replaces it here *)
 				"CovarianceFunction" -> Function[theta, touch[h];
-					With[{K = gpCov[h, N @ theta]},
+					With[{K = gpCov[h, customLift[spec][N @ theta]]},
 						If[nugPW, K + DiagonalMatrix[(nugget[theta] /@ inputData) - hipNuggetFunction[spec, d][theta][]], K]]],
 				"InverseCovarianceFunction" -> invCov
 			|>,
 			"KernelName" -> spec,
 			"PointwiseFunctions" -> {meanPW, nugPW},
+			"ThetaLift" -> customLift[spec],                       (* identity for the named kernels *)
 			"HIPHandle" -> h
 		|>,
 		Sequence @@ FilterRules[{rest}, Except[own]],
@@ -300,7 +341,7 @@ hipPredict[result_, pts_List] := Module[{
 	   is singular comes back as NaN rows.  Point-dependent nugget / mean functions are evaluated per sample at the
 	   training AND the test points (BGP:113, 408) *)
 	perSample = With[{mv = If[ Or @@ pwFlags,
-			gpPredictSPW[h, thetas, vals[mf["MeanFunction"], pwFlags[[1]], train], vals[mf["NuggetFunction"], pwFlags[[2]], train],
+			gpPredictSPW[h, Lookup[result["GaussianProcessData"], "ThetaLift", Identity][thetas], vals[mf["MeanFunction"], pwFlags[[1]], train], vals[mf["NuggetFunction"], pwFlags[[2]], train],
 				N @ points, vals[mf["MeanFunction"], pwFlags[[1]], points], vals[mf["NuggetFunction"], pwFlags[[2]], points]],
 			gpPredictS[h, thetas, N @ points]
 		]},

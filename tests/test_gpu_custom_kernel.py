@@ -159,3 +159,19 @@ def test_host_mirror_object_with_a_function_valued_kernel(tmp_path):
     np.testing.assert_allclose(a["Mean"], b["Mean"], rtol=1e-12)
     with pytest.raises(ValueError):                      # wrong number of variables for the function's parameter count
         gp.defineGaussianProcess((X, y), ck, variables=variables[:3])
+
+
+def test_native_sampler_runs_on_a_function_valued_kernel():
+    """gphip_nested_sampling drives batched likelihood calls of the handle: with SE-ARD given as source text it must reproduce,
+    draw for draw (same seed), the run on the named-kernel handle."""
+    X, y = syn.make_dataset(96, 1)
+    ck = _lib.CustomKernel(SE_ARD_BODY, 2, fn=se_ard_fn)
+    box = np.array([[0.05, 1.5], [0.2, 3.0], [0.03, 0.6]])
+    opts = dict(pool=30, max_iterations=150, min_iterations=20, mc_steps=8, walkers=8, seed=7)
+    h, ref = _lib.Handle(X, y, ck), _lib.Handle(X, y, "se_ard")
+    a, b = h.nested_sampling(box, **opts), ref.nested_sampling(box, **opts)
+    assert a["TotalSamples"] == b["TotalSamples"] and np.isfinite(a["CrudeLogEvidence"])
+    np.testing.assert_allclose(a["Points"], b["Points"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(a["LogLikelihood"], b["LogLikelihood"], rtol=1e-9, atol=1e-8)
+    assert abs(a["CrudeLogEvidence"] - b["CrudeLogEvidence"]) < 1e-6
+    h.close(); ref.close()

@@ -328,3 +328,38 @@ def test_native_sampler_with_a_tabulated_normal_prior_matches_quadrature_over_20
     assert K.call("gphip_wl_nested_sampling_tab", [hs, box, tab[:, :3], opts, start])[0] == DIMENSION_ERROR
     assert K.call("gphip_wl_nested_sampling_tab", [hs, box, tab, opts, start[:, :1]])[0] == DIMENSION_ERROR
     assert K.call("gphip_wl_destroy", [hs], "int") == (NO_ERROR, 0)
+
+
+def test_create_custom_through_the_shim_the_way_gphip_wl_drives_it():
+    """gphip_wl_create_custom with a CForm-style body, then exactly GPHIP.wl's calling pattern for an arbitrary kernel: theta is
+    the reference's parameter vector plus a dummy sigma_n slot, nugget and mean arrive as VALUES per point (the reference's
+    expressions evaluated on the host)."""
+    K = Kernel()
+    n, d = 220, 2
+    X, y = syn.make_dataset(n, d)
+    live0, dis0 = K.lib.drv_live(), K.lib.drv_disowned()
+    # Function[{p, q}, sf^2 Exp[-(p - q).(p - q)/(2 l^2)] (1 + c^2 p[[1]] q[[1]])] printed by CForm over {l, sf, c, sn}
+    body = ("return (Power(P(1),2)*(1 + Power(P(2),2)*X(0)*Y(0)))/"
+            "Power(E,(Power(X(0) - Y(0),2) + Power(X(1) - Y(1),2))/(2.*Power(P(0),2)));")
+    fn = lambda A, B, p: p[1] ** 2 * np.exp(-0.5 * ((A - B) ** 2).sum(-1) / p[0] ** 2) * (1.0 + p[2] ** 2 * A[..., 0] * B[..., 0])  # noqa: E731
+    ck = _lib.CustomKernel(body, 4, fn=fn)                     # all FOUR reference parameters are P(k); sn = P(3) is used by the nugget only
+    rc, h = K.call("gphip_wl_create_custom", [X, y, body, 4, 0, 64, 0], "int")
+    assert rc == NO_ERROR and K.lib.drv_disowned() == dis0 + 1
+    theta = np.array([0.9, 1.2, 0.7, 0.15])
+    lifted = np.append(theta, 1.0)[None, :]                    # GPHIP.wl: Join[theta, {1.}]
+    nug = np.full((1, n), theta[3] ** 2)
+    rc, r = K.call("gphip_wl_loglik_batch_pw", [h, lifted, np.zeros(0), nug])
+    want = orc.log_likelihood(ck, np.append(theta, theta[3]), X, y)
+    assert rc == NO_ERROR and r[0, 1] == 0 and abs(r[0, 0] - want) <= 1e-8 * max(abs(want), n)
+    Xs = syn.make_test_points(7, d)
+    rc, r = K.call("gphip_wl_predict_samples_pw", [h, lifted, np.zeros(0), nug, Xs, np.zeros(0), np.full((1, 7), theta[3] ** 2)])
+    mo, so = orc.predict_internal(ck, np.append(theta, theta[3]), X, y, Xs)
+    assert rc == NO_ERROR
+    np.testing.assert_allclose(r[0, 0], mo, rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(np.sqrt(r[1, 0]), so, rtol=1e-7)
+    assert K.call("gphip_wl_destroy", [h], "int") == (NO_ERROR, 0)
+    # a body that does not compile: an error code (GPHIP.wl then falls back to the reference's own path), nothing leaked
+    assert K.call("gphip_wl_create_custom", [X, y, "return Undefined(P(0));", 1, 0, 64, 0], "int")[0] == FUNCTION_ERROR
+    assert K.call("gphip_wl_create_custom", [X, y[:-1], body, 4, 0, 64, 0], "int")[0] == DIMENSION_ERROR
+    assert K.lib.drv_live() == live0 and K.lib.drv_const_frees() == 0
+    K.lib.WolframLibrary_uninitialize(K.data)
