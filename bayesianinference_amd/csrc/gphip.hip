@@ -2257,7 +2257,28 @@ int gphip_loglik_grad(gphip_handle h, const double* theta, int p, double* out, d
         return null_kernel_batch(h, theta, 1, out, nullptr, info, grad);
     }
     std::lock_guard<std::recursive_mutex> lk(h->mu);
-    if (h->custom) return fail(h, GPHIP_ERR_UNSUPPORTED, "gphip_loglik_grad: no analytic gradient for a run-time compiled covariance function");
+    if (h->custom) {
+        // a run-time compiled covariance function has no analytic derivative here: central differences of the likelihood, all
+        // 2 p + 1 points as ONE batched evaluation (step 1e-4 max(|theta_k|, 1e-2): ~1e-7 relative on the gradient)
+        if (p != h->p) return fail(h, GPHIP_ERR_DIM, "theta has the wrong length");
+        const int B = 2 * p + 1;
+        std::vector<double> Th((size_t)B * p), ll((size_t)B, 0.0), step((size_t)p);
+        std::vector<int> inf((size_t)B, 0);
+        for (int r = 0; r < B; ++r) memcpy(&Th[(size_t)r * p], theta, (size_t)p * 8);
+        for (int k = 0; k < p; ++k) {
+            step[(size_t)k] = 1e-4 * std::max(std::fabs(theta[k]), 1e-2);
+            Th[(size_t)(1 + 2 * k) * p + k] += step[(size_t)k];
+            Th[(size_t)(2 + 2 * k) * p + k] -= step[(size_t)k];
+        }
+        const int rc = eval_batch(h, Th.data(), B, p, ll.data(), nullptr, inf.data());
+        if (rc) return rc;
+        *out = ll[0];
+        *info = inf[0];
+        for (int k = 0; k < p; ++k)
+            grad[k] = (inf[0] == 0 && inf[(size_t)1 + 2 * k] == 0 && inf[(size_t)2 + 2 * k] == 0)
+                          ? (ll[(size_t)1 + 2 * k] - ll[(size_t)2 + 2 * k]) / (2.0 * step[(size_t)k]) : std::nan("");
+        return GPHIP_OK;
+    }
     // the gradient reductions keep (d + 1) point tiles (general form: 4 d + 1) in LDS: beyond KB_LDS_MAXD dimensions only the
     // likelihood / fit / prediction paths are implemented (they read the points from global memory instead)
     if (h->d > KB_LDS_MAXD) return fail(h, GPHIP_ERR_UNSUPPORTED, "gphip_loglik_grad supports input dimensions up to 32");

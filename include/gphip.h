@@ -82,7 +82,8 @@ typedef struct gphip_ctx* gphip_handle;
  * theta layout of such a handle:  [p_0 .. p_{nparams-1}] sn [mu].  The function may be non-stationary: the prior variance
  * k(x, x) is evaluated per point on the device (prediction variance, pivot tolerance of the factorisation).
  * Likelihoods, batches, fits, predictions, posterior-sample mixtures, covariance exports and the native sampler work as for the
- * named kernels; gphip_loglik_grad returns GPHIP_ERR_UNSUPPORTED; single-device handles only.  Replaces the reference's
+ * named kernels; gphip_loglik_grad returns central differences of the likelihood (2 p + 1 points in one batched evaluation,
+ * ~1e-7 relative) instead of the analytic gradient; single-device handles only.  Replaces the reference's
  * `kernel @@ points[[{i,j}]]` for an arbitrary pure function (BGP:29-33, cross form BGP:100-109).
  * Errors: GPHIP_ERR_ARG = the body does not compile (gphip_create_error() returns the compiler's log),
  * GPHIP_ERR_UNSUPPORTED = no hiprtc / the library's kernel source is not next to it (see csrc/rtc_dyn.h). */
