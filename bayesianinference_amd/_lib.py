@@ -68,6 +68,10 @@ _SIGNATURES = {
                                _ip, C.c_int, C.POINTER(_h)]),
     "gphip_create_custom": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                       C.POINTER(_h)]),
+    "gphip_create_custom_devices": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_char_p, C.c_int, C.c_int, C.c_int, _ip, C.c_int,
+                                              C.POINTER(_h)]),
+    "gphip_create_custom_rank": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                           C.c_int, C.c_int, C.c_void_p, C.POINTER(_h)]),
     "gphip_create_error": (C.c_char_p, []),
     "gphip_comm_unique_id": (C.c_int, [C.c_void_p]),
     "gphip_create_rank": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int,
@@ -220,7 +224,7 @@ class Handle:
         its body: compiled at run time into the library's kernel build, gphip_create_custom)."""
         lib = load()
         if isinstance(kernel, CustomKernel):
-            self._init_custom(lib, X, y, kernel, mean, dtype, device)
+            self._init_custom(lib, X, y, kernel, mean, dtype, device, rank, world, comm_id)
             return
         X = np.ascontiguousarray(np.atleast_2d(np.asarray(X, dtype=np.float64)))
         y = np.ascontiguousarray(np.asarray(y, dtype=np.float64).ravel())
@@ -258,21 +262,28 @@ class Handle:
         lib.gphip_num_params(self._h, C.byref(p))
         self.p = p.value
 
-    def _init_custom(self, lib, X, y, kernel, mean, dtype, device):
+    def _init_custom(self, lib, X, y, kernel, mean, dtype, device, rank=None, world=None, comm_id=None):
         X = np.ascontiguousarray(np.atleast_2d(np.asarray(X, dtype=np.float64)))
         y = np.ascontiguousarray(np.asarray(y, dtype=np.float64).ravel())
         if X.shape[0] != y.shape[0]:
             raise GphipError(2, "Input and output data are not of same length")     # BGP:251-253
         if mean not in MEAN_IDS:
             raise GphipError(1, f"unknown mean {mean!r}")
-        if isinstance(device, (list, tuple)):
-            raise GphipError(6, "a run-time compiled covariance function runs on single-device handles only")
         self.N, self.d = X.shape
         self.kernel, self.mean, self.dtype = kernel, mean, int(dtype)
         self._lib = lib
         self._h = _h()
-        rc = lib.gphip_create_custom(X.ctypes.data, y.ctypes.data, self.N, self.d, kernel.body.encode(), int(kernel.nparams),
-                                     MEAN_IDS[mean], dtype, -1 if device is None else int(device), C.byref(self._h))
+        lst = [] if device is None else ([int(v) for v in device] if isinstance(device, (list, tuple)) else [int(device)])
+        devs = (C.c_int * max(len(lst), 1))(*lst) if lst else None
+        if comm_id is not None:
+            if rank is None or world is None or len(comm_id) != COMM_ID_BYTES:
+                raise GphipError(1, "rank, world and a 128-byte comm_id go together")
+            rc = lib.gphip_create_custom_rank(X.ctypes.data, y.ctypes.data, self.N, self.d, kernel.body.encode(), int(kernel.nparams),
+                                              MEAN_IDS[mean], dtype, lst[0] if lst else -1, int(rank), int(world),
+                                              C.c_char_p(comm_id), C.byref(self._h))
+        else:
+            rc = lib.gphip_create_custom_devices(X.ctypes.data, y.ctypes.data, self.N, self.d, kernel.body.encode(), int(kernel.nparams),
+                                                 MEAN_IDS[mean], dtype, devs, len(lst), C.byref(self._h))
         if rc != OK:
             self._h = None
             raise GphipError(rc, "gphip_create_custom failed: " + (lib.gphip_create_error() or b"").decode())

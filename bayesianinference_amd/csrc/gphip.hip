@@ -1982,6 +1982,13 @@ char* dist_panel_range(const gphip_ctx* h, int q) {
 
 static int create_ctx(const void* X, const void* y, int64_t N, int64_t d, int kernel_id, int mean_id, int dtype, int device,
                       gphip_handle* out, const char* custom_body = nullptr, int ncp = 0, std::string* why = nullptr);
+namespace {
+// the covariance function of the gphip_create_custom* call in progress on this thread: every context the call creates (one per
+// local device of a multi-device handle) compiles it for itself
+thread_local const char* g_pending_body = nullptr;
+thread_local int g_pending_ncp = 0;
+thread_local std::string g_create_error;
+}
 #include "gphip_multi.inc"
 
 namespace {
@@ -2027,8 +2034,11 @@ static int create_ctx(const void* X, const void* y, int64_t N, int64_t d, int ke
     if (!out) return GPHIP_ERR_ARG;
     *out = nullptr;
     if (!X || !y) return GPHIP_ERR_ARG;
+    if (!custom_body && kernel_id == GPHIP_KERNEL_CUSTOM && g_pending_body) {
+        custom_body = g_pending_body; ncp = g_pending_ncp; why = &g_create_error;
+    }
     if (custom_body) kernel_id = GPHIP_KERNEL_CUSTOM;
-    else if (kernel_id == GPHIP_KERNEL_CUSTOM) return GPHIP_ERR_ARG;      // (only gphip_create_custom makes such a handle)
+    else if (kernel_id == GPHIP_KERNEL_CUSTOM) return GPHIP_ERR_ARG;      // (only gphip_create_custom* make such a handle)
     if (N < 1 || d < 1) return GPHIP_ERR_DIM;
     // (d > KB_LDS_MAXD = 32: the kernel build reads the point tiles from global memory instead of LDS; gradients stay limited)
     // kernel_id: a plain named kernel, or GPHIP_KERNEL_COMPOSE(term1, op, term2, offset)
@@ -2142,19 +2152,48 @@ static int create_ctx(const void* X, const void* y, int64_t N, int64_t d, int ke
     return GPHIP_OK;
 }
 
-namespace {
-thread_local std::string g_create_error;
-}
-/* why the last gphip_create_custom of this thread failed (compiler log of the covariance function, ..) */
+/* why the last gphip_create_custom* of this thread failed (compiler log of the covariance function, ..) */
 const char* gphip_create_error(void) { return g_create_error.c_str(); }
 
-int gphip_create_custom(const void* X, const void* y, int64_t N, int64_t d, const char* body, int nparams, int mean_id,
-                        int dtype, int device, gphip_handle* out) {
+static int group_create(const void* X, const void* y, int64_t N, int64_t d, int kernel_id, int mean_id, int dtype,
+                        const int* devices, const int* ranks, int nlocal, int world, const void* id128, gphip_handle* out);
+
+int gphip_create_custom_devices(const void* X, const void* y, int64_t N, int64_t d, const char* body, int nparams, int mean_id,
+                                int dtype, const int* devices, int ndev, gphip_handle* out) {
     g_create_error.clear();
     if (!out) return GPHIP_ERR_ARG;
     *out = nullptr;
     if (!body || !*body || nparams < 0 || nparams > 4096) { g_create_error = "null / empty function body or bad parameter count"; return GPHIP_ERR_ARG; }
-    return create_ctx(X, y, N, d, GPHIP_KERNEL_CUSTOM, mean_id, dtype, device, out, body, nparams, &g_create_error);
+    if (ndev < 0 || (ndev > 0 && !devices)) return GPHIP_ERR_ARG;
+    g_pending_body = body; g_pending_ncp = nparams;
+    int rc;
+    if (ndev <= 1) {
+        rc = create_ctx(X, y, N, d, GPHIP_KERNEL_CUSTOM, mean_id, dtype, ndev == 1 ? devices[0] : -1, out);
+    } else {
+        std::vector<int> ranks((size_t)ndev);
+        for (int i = 0; i < ndev; ++i) ranks[(size_t)i] = i;
+        rc = group_create(X, y, N, d, GPHIP_KERNEL_CUSTOM, mean_id, dtype, devices, ranks.data(), ndev, ndev, nullptr, out);
+    }
+    g_pending_body = nullptr; g_pending_ncp = 0;
+    return rc;
+}
+
+int gphip_create_custom(const void* X, const void* y, int64_t N, int64_t d, const char* body, int nparams, int mean_id,
+                        int dtype, int device, gphip_handle* out) {
+    return gphip_create_custom_devices(X, y, N, d, body, nparams, mean_id, dtype, &device, device < 0 ? 0 : 1, out);
+}
+
+int gphip_create_custom_rank(const void* X, const void* y, int64_t N, int64_t d, const char* body, int nparams, int mean_id,
+                             int dtype, int device, int rank, int world, const void* id128, gphip_handle* out) {
+    g_create_error.clear();
+    if (!out) return GPHIP_ERR_ARG;
+    *out = nullptr;
+    if (!body || !*body || nparams < 0 || nparams > 4096) { g_create_error = "null / empty function body or bad parameter count"; return GPHIP_ERR_ARG; }
+    if (world < 1 || rank < 0 || rank >= world || !id128) return GPHIP_ERR_ARG;
+    g_pending_body = body; g_pending_ncp = nparams;
+    const int rc = group_create(X, y, N, d, GPHIP_KERNEL_CUSTOM, mean_id, dtype, &device, &rank, 1, world, id128, out);
+    g_pending_body = nullptr; g_pending_ncp = 0;
+    return rc;
 }
 
 // devices/ndev: NULL/0 = the current device; one ordinal = that device; several = a multi-device handle

@@ -83,13 +83,19 @@ typedef struct gphip_ctx* gphip_handle;
  * k(x, x) is evaluated per point on the device (prediction variance, pivot tolerance of the factorisation).
  * Likelihoods, batches, fits, predictions, posterior-sample mixtures, covariance exports and the native sampler work as for the
  * named kernels; gphip_loglik_grad returns central differences of the likelihood (2 p + 1 points in one batched evaluation,
- * ~1e-7 relative) instead of the analytic gradient; single-device handles only.  Replaces the reference's
+ * ~1e-7 relative) instead of the analytic gradient.  Replaces the reference's
  * `kernel @@ points[[{i,j}]]` for an arbitrary pure function (BGP:29-33, cross form BGP:100-109).
  * Errors: GPHIP_ERR_ARG = the body does not compile (gphip_create_error() returns the compiler's log),
  * GPHIP_ERR_UNSUPPORTED = no hiprtc / the library's kernel source is not next to it (see csrc/rtc_dyn.h). */
 #define GPHIP_KERNEL_CUSTOM 100
 int gphip_create_custom(const void* X, const void* y, int64_t N, int64_t d, const char* body, int nparams, int mean_id,
                         int dtype, int device /* < 0: current */, gphip_handle* out);
+/* the same with a device list (several ordinals = ONE multi-device handle, see gphip_create) / as one rank of a multi-process
+ * job (see gphip_create_rank): every local context compiles the function for itself */
+int gphip_create_custom_devices(const void* X, const void* y, int64_t N, int64_t d, const char* body, int nparams, int mean_id,
+                                int dtype, const int* devices, int ndev, gphip_handle* out);
+int gphip_create_custom_rank(const void* X, const void* y, int64_t N, int64_t d, const char* body, int nparams, int mean_id,
+                             int dtype, int device, int rank, int world, const void* id128, gphip_handle* out);
 const char* gphip_create_error(void);
 #define GPHIP_MEAN_ZERO 0            /* Function[0]  (BGP:168,255)                                    */
 #define GPHIP_MEAN_CONST 1           /* Function[mu], mu = last entry of theta                        */

@@ -135,8 +135,36 @@ def test_posterior_sample_mixture_and_errors():
     with pytest.raises(_lib.GphipError) as e:            # the compiler's log comes back with the error
         _lib.Handle(X, y, _lib.CustomKernel("return P(0) * no_such_symbol;", 1))
     assert e.value.status == 1 and "no_such_symbol" in str(e.value)
-    with pytest.raises(_lib.GphipError):
-        _lib.Handle(X, y, ck, device=[0, 0])
+
+
+@pytest.mark.parametrize("world,panel", [(2, 2), (3, 1)])
+def test_function_valued_kernel_on_a_multi_device_handle(world, panel):
+    """A device list makes ONE multi-device handle (virtual ranks on the one GPU here): every member compiles the function for
+    itself; a sharded evaluation builds each rank's own panels with it, a sharded fit predicts with per-point prior variances."""
+    n, d = 1300, 2
+    X, y = syn.make_dataset(n, d)
+    Xs = syn.make_test_points(60, d)
+    th = np.array([0.9, 1.2, 0.7, 0.15])
+    ck = _lib.CustomKernel(NONSTAT_BODY, 3, fn=nonstat_fn)
+    g = _lib.Handle(X, y, ck, device=[0] * world)
+    g.set_option("shard_min_n", 0)
+    g.set_option("panel", panel)
+    ll, ld, qd, info = g.loglik_parts(th)
+    want = orc.log_likelihood(ck, th, X, y, parts=True)
+    assert info == 0 and close(ll, want[0], n) and close(ld, want[1], n) and close(qd, want[2], n)
+    mo, so = orc.predict_internal(ck, th, X, y, Xs)
+    for replicate in (0, 1):
+        g.set_option("replicate_factor", replicate)
+        assert g.fit(th) == 0
+        mu, var = g.predict(Xs)
+        np.testing.assert_allclose(mu, mo, rtol=1e-7, atol=1e-9)
+        np.testing.assert_allclose(np.sqrt(var), so, rtol=1e-7)
+    Th = np.array([th * (1.0 + 0.02 * k) for k in range(5)])         # thetas dealt to the members
+    lb, ib = g.loglik_batch(Th)
+    assert (ib == 0).all()
+    for k in range(5):
+        assert close(lb[k], orc.log_likelihood(ck, Th[k], X, y), n)
+    g.close()
 
 
 def test_host_mirror_object_with_a_function_valued_kernel(tmp_path):
