@@ -121,6 +121,18 @@ def test_f3_scalars_medium_sizes(golden_dir, fname):
             assert close(ll, float(g["loglik"][i]), n), (n, kernel, opts)
             for k in opts:
                 h.set_option(k, {"panel_wide": 1, "lookahead": 1, "dataflow_tail": 64, "panel_df": -1, "panel": 4}[k])
+        if 11000 <= n < 16000:
+            # the fit of the default schedule of this range (fused dataflow panels: 64-block inverses everywhere, rebuilt into
+            # 128-block ones for the substitutions) predicts like the fit of the multi-kernel / single-launch schedule
+            Xs = syn.make_test_points(40, d)
+            th = syn.default_theta(kernel, d)
+            assert h.fit(th) == 0
+            mu, var = h.predict(Xs)
+            h.set_option("panel_df", 0)
+            assert h.fit(th) == 0
+            mu0, var0 = h.predict(Xs)
+            np.testing.assert_allclose(mu, mu0, rtol=1e-9, atol=1e-11)
+            np.testing.assert_allclose(var, var0, rtol=1e-8, atol=1e-13)
         h.close()
 
 
