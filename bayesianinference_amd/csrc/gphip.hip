@@ -1753,6 +1753,25 @@ int upload_pw_test(gphip_ctx* h, int s0, int nb, int64_t m0, int64_t mc, int64_t
     return GPHIP_OK;
 }
 
+// run-time compiled covariance function: k(x*_t, x*_t) of the test points in dXsT for every slot -> dKss[slot][mpad] (fp64)
+int queue_custom_kss(gphip_ctx* h, int64_t mc, int64_t mpad, int nslots) {
+    const size_t want = (size_t)nslots * mpad * 8;
+    if (want > h->kss_cap) {
+        (void)hipFree(h->dKss);
+        h->dKss = nullptr; h->kss_cap = 0;
+        HIPCHK(hipMalloc(&h->dKss, want));
+        h->kss_cap = want;
+    }
+    const void* x = h->dXsT;                       // the (unscaled) test points [d][mpad], shared by the slots
+    long xbs = 0, ostride = (long)mpad;
+    int npad = (int)mpad, n = (int)mc, d = (int)h->d, ncp = std::max(h->ncp, 1);
+    const double* cp = h->dCustomP;
+    double* out = h->dKss;
+    void* params[] = {&x, &xbs, &npad, &n, &d, &cp, &ncp, &out, &ostride};
+    HIPCHK(hipModuleLaunchKernel(h->f_cdiag, (unsigned)((mc + 255) / 256), (unsigned)nslots, 1, 256, 1, 1, 0, h->stream, params, nullptr));
+    return GPHIP_OK;
+}
+
 // mu*, var* from V and z: V streamed once (HBM bound) -- strips of columns x 128 test points per workgroup,
 // then the strips are added in order.  Profile class 6: bytes = V once.
 template <typename T>
@@ -1774,21 +1793,8 @@ int queue_predict_reduce(gphip_ctx* h, int64_t mc, int64_t mpad, int nslots) {
     }
     const double* kss = nullptr;
     if (h->custom) {                               // k(x*, x*) is a function of the test point for a general covariance function
-        const size_t want = (size_t)nslots * mpad * 8;
-        if (want > h->kss_cap) {
-            (void)hipFree(h->dKss);
-            h->dKss = nullptr; h->kss_cap = 0;
-            HIPCHK(hipMalloc(&h->dKss, want));
-            h->kss_cap = want;
-        }
-        const void* x = h->dXsT;                   // the (unscaled) test points [d][mpad], shared by the slots
-        long xbs = 0, ostride = (long)mpad;
-        int npad = (int)mpad, n = (int)mc, d = (int)h->d, ncp = std::max(h->ncp, 1);
-        const double* cp = h->dCustomP;
-        double* out = h->dKss;
-        void* params[] = {&x, &xbs, &npad, &n, &d, &cp, &ncp, &out, &ostride};
-        HIPCHK(hipModuleLaunchKernel(h->f_cdiag, (unsigned)((mc + 255) / 256), (unsigned)nslots, 1, 256, 1, 1, 0, h->stream, params,
-                                     nullptr));
+        const int rc = queue_custom_kss(h, mc, mpad, nslots);
+        if (rc) return rc;
         kss = h->dKss;
     }
     {
@@ -2555,8 +2561,16 @@ int gphip_cross_covariance(gphip_handle h, const double* theta, int p, const voi
         harvest(h);
         for (int64_t j = 0; j < N; ++j)
             for (int64_t t = 0; t < mc; ++t) k[j * M + m0 + t] = v[(size_t)j * mpad + t];
+        if (h->custom) {                           // kappa_t = k(x*_t, x*_t) + nugget: a function of the point (device)
+            rc = queue_custom_kss(h, mc, mpad, 1);
+            if (rc) return rc;
+            HIPCHK(hipMemcpyAsync(kappa + m0, h->dKss, (size_t)mc * 8, hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(hipStreamSynchronize(h->stream));
+            for (int64_t t = 0; t < mc; ++t) kappa[m0 + t] += h->hSlotp[1];
+        }
     }
-    for (int64_t t = 0; t < M; ++t) kappa[t] = h->hSlotp[SP_KXX] + h->hSlotp[1];
+    if (!h->custom)
+        for (int64_t t = 0; t < M; ++t) kappa[t] = h->hSlotp[SP_KXX] + h->hSlotp[1];
     return GPHIP_OK;
 }
 

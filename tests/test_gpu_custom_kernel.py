@@ -89,9 +89,13 @@ def test_arbitrary_covariance_functions_against_the_oracle(body, fn, npar, d, th
     mo, so = orc.predict_internal(ck, th, X, y, Xs)
     np.testing.assert_allclose(mu, mo, rtol=1e-7, atol=1e-9)
     np.testing.assert_allclose(np.sqrt(var), so, rtol=1e-7)       # (k(x*, x*) is a function of the test point here)
-    # the covariance matrix itself, entry by entry
+    # the covariance matrix itself, entry by entry; the cross form with kappa = k(x*, x*) + nugget (BGP:100-115)
     K = h.covariance(th)
     np.testing.assert_allclose(K, orc.covariance_matrix(ck, th, X), rtol=1e-12, atol=1e-14)
+    kx, kap = h.cross_covariance(th, Xs)
+    ko, kapo = orc.k_and_kappa(ck, th, X, Xs)
+    np.testing.assert_allclose(kx, ko, rtol=1e-12, atol=1e-14)
+    np.testing.assert_allclose(kap, kapo, rtol=1e-12)
     # constant mean, fp32, verdicts
     hc = _lib.Handle(X, y, ck, mean="const")
     thc = np.append(th, 0.2)
