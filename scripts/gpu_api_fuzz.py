@@ -35,11 +35,14 @@ while time.time() < t_end:
     mean = str(rng.choice(["zero", "const"]))
     world = int(rng.choice([1, 1, 2, 3, 4]))
     X, y = syn.make_dataset(n, d, seed=int(rng.integers(1 << 30)))
-    h = _lib.Handle(X, y, kernel, mean, dtype=dtype, device=([0] * world if world > 1 else None))
+    as_text = kernel == "se_ard" and rng.random() < 0.4   # the same function handed over as source text (gphip_create_custom)
+    kobj = _lib.CustomKernel("T s = 0; for (int k = 0; k < D; ++k) { const T u = (X(k) - Y(k)) / P(k); s += u * u; } "
+                             "return P(D) * P(D) * exp((T)-0.5 * s);", d + 1) if as_text else kernel
+    h = _lib.Handle(X, y, kobj, mean, dtype=dtype, device=([0] * world if world > 1 else None))
     if world > 1:
         h.set_option("shard_min_n", int(rng.choice([0, 1 << 30])))
     nh += 1
-    print(f'HANDLE n={n} d={d} {kernel} {mean} world={world} dtype={dtype}', file=log, flush=True)
+    print(f'HANDLE n={n} d={d} {kernel}{" (as source text)" if as_text else ""} {mean} world={world} dtype={dtype}', file=log, flush=True)
     def rand_theta():
         th = syn.default_theta(kernel, d) * (0.6 + 0.8 * rng.random(len(syn.default_theta(kernel, d))))
         th[-1] = 0.1 + 0.4 * rng.random()
