@@ -37,6 +37,9 @@
 // source text (GP_CUSTOM_KERNEL).  Keep the region self-contained: no std:: headers, nothing declared outside it.
 namespace gphip {
 
+// Bumped whenever a struct or constant the run-time compiled copy of this region shares with the offline library changes
+// (KBuildArgs, SLOTP, the tile layout): rtc_dyn.h refuses a source tree whose value differs from the library's own.
+#define GP_RTC_ABI 1
 constexpr int TB = 128;         // tile edge
 // Elements between consecutive tiles of the packed workspace: 128 x 128 plus a pad.  Without the pad every tile starts on
 // a 128 KiB (fp64) boundary and the workgroups of a launch, which walk their operand tiles in lock step, all touch the

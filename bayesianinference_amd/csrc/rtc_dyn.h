@@ -8,6 +8,8 @@
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
+#include "gp_kernels.h"
+
 #include <cstdlib>
 #include <fstream>
 #include <mutex>
@@ -87,9 +89,17 @@ inline bool rtc_kernel_source(std::string& region, std::string& why) {
         const size_t b = text.find("// [rtc-begin]"), e = text.find("// [rtc-end]");
         if (b == std::string::npos || e == std::string::npos || e < b) continue;
         region = text.substr(b, e - b);
+        // the text must describe the same structs the library was compiled with
+        const std::string tag = "#define GP_RTC_ABI ";
+        const size_t t = region.find(tag);
+        if (t == std::string::npos || atoi(region.c_str() + t + tag.size()) != GP_RTC_ABI) {
+            why = d + "/gp_kernels.h does not match this build of the library (GP_RTC_ABI differs): rebuild, or point GPHIP_SRC_DIR at the matching sources";
+            return false;
+        }
         return true;
     }
-    why = "gp_kernels.h (with its [rtc-begin] / [rtc-end] region) not found next to the library; set GPHIP_SRC_DIR to the csrc directory";
+    if (why.empty())
+        why = "gp_kernels.h (with its [rtc-begin] / [rtc-end] region) not found next to the library; set GPHIP_SRC_DIR to the csrc directory";
     return false;
 }
 
