@@ -1881,8 +1881,14 @@ template <typename T, int TBX> __device__ __forceinline__ int df_lds_off(int k, 
     if constexpr (TBX == 128) return lds_off<T>(k, row);
     else return ((k >> 2) * 2 + (k & 1)) * LD64 + ((k >> 1) & 1) * 64 + row;
 }
+// k-columns per LDS stage of the 64-tile kernel (GP_DF_GK64: 16 = one quarter of a slab, the gemm_nt stage depth; 32 = half a
+// slab: half as many DMA-wait + barrier points per MFMA, 72 KiB of LDS per workgroup -- still two per CU)
+#ifndef GP_DF_GK64
+#define GP_DF_GK64 16
+#endif
+template <typename T, int TBX> constexpr int df_stage_k() { return TBX == 128 ? Num<T>::GK : GP_DF_GK64; }
 template <typename T, int TBX> constexpr int df_stage_elems() {
-    return TBX == 128 ? STAGE_BYTES / (int)sizeof(T) : 2 * 8 * LD64;
+    return TBX == 128 ? STAGE_BYTES / (int)sizeof(T) : 2 * (GP_DF_GK64 / 2) * LD64;
 }
 // NST = LDS stages of the slab pipeline: 2 (double buffer), or 4 with counted DMA waits for a workgroup that
 // has the CU to itself (fp64 128-tiles) while the schedule is chain bound: its on-chain products have no
@@ -1909,7 +1915,7 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g, Th
     __shared__ int s_park;
     T* smem = reinterpret_cast<T*>(smem_raw);
     typedef typename Num<T>::acc_t acc_t;
-    constexpr int GK = Num<T>::GK;
+    constexpr int GK = df_stage_k<T, TBX>();
     constexpr int STAGE = df_stage_elems<T, TBX>();
     constexpr int JOFF = STAGE / 2;
     constexpr bool F64 = sizeof(T) == 8;
@@ -2149,8 +2155,8 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g, Th
                 }
             } else {
 #pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) {
-                    const int qq = uw + 4 * s2;           // 8 instructions per operand tile
+                for (int s2 = 0; s2 < GK / 8; ++s2) {
+                    const int qq = uw + 4 * s2;           // GK / 2 instructions per operand tile
                     const long kcol = 4 * (qq >> 1) + (qq & 1) + 2 * (lane >> 5);
                     const int row = 2 * (lane & 31);
                     __builtin_amdgcn_global_load_lds((glb_void*)(Ig + kcol * ldi + row),
@@ -2338,7 +2344,8 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g, Th
             zero_c(accx);
             run_k(accx, Xt, LDA, g.W + (long)slot * g.w_bstride + (long)jm * TBX * TBX, TBX, SPB, false);
             store_c(accx, Xt, LDA);                        // X(j,j-1): the column below waits for it
-            // X -> four LDS stage images [k][row] (both MFMA operands of X X^T read the same image)
+            // X -> four 16-column LDS images [k][row] (both MFMA operands of X X^T read the same image)
+            constexpr int XIMG = 8 * LD64;
 #pragma unroll
             for (int x = 0; x < FJ; ++x)
 #pragma unroll
@@ -2346,15 +2353,15 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g, Th
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int c = wj * WT + x * 16 + Num<T>::drow(l4, r), irow = wi * WT + y * 16 + l15;
-                        smem[(c >> 4) * JOFF + df_lds_off<T, TBX>(c & 15, irow)] = accx[x][y][r];
+                        smem[(c >> 4) * XIMG + df_lds_off<T, TBX>(c & 15, irow)] = accx[x][y][r];
                     }
             publish_wt(j, jm);                              // (its barrier also orders the LDS image)
             stamp(7);
 #pragma unroll
-            for (int st = 0; st < TBX / GK; ++st)
+            for (int st = 0; st < TBX / 16; ++st)
 #pragma unroll
-                for (int kk = 0; kk < GK / 4; ++kk) {
-                    const T* Im = smem + st * JOFF + l15;
+                for (int kk = 0; kk < 4; ++kk) {
+                    const T* Im = smem + st * XIMG + l15;
                     const int kq = 4 * kk + l4;
                     T fi[FI], fj[FJ];
 #pragma unroll
