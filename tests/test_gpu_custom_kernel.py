@@ -213,3 +213,31 @@ def test_native_sampler_runs_on_a_function_valued_kernel():
     np.testing.assert_allclose(a["LogLikelihood"], b["LogLikelihood"], rtol=1e-9, atol=1e-8)
     assert abs(a["CrudeLogEvidence"] - b["CrudeLogEvidence"]) < 1e-6
     h.close(); ref.close()
+
+
+def test_function_valued_kernel_under_every_factorisation_schedule():
+    """N = 6000: the single dataflow launch (default), the multi-kernel look-ahead schedule with its dataflow tail (dataflow
+    launch off for the whole matrix), fused dataflow panels, and a 3-rank sharded evaluation -- all around the run-time compiled
+    kernel build, all against the oracle evaluating the same non-stationary function."""
+    n, d = 6000, 3
+    X, y = syn.make_dataset(n, d)
+    th = np.array([0.8, 1.1, 0.6, 0.12])
+    ck = _lib.CustomKernel(NONSTAT_BODY, 3, fn=nonstat_fn)
+    want = orc.log_likelihood(ck, th, X, y, parts=True)
+    assert want[3] == 0
+    h = _lib.Handle(X, y, ck)
+    for opts in ({}, {"dataflow_max_nt": 16}, {"dataflow_max_nt": 16, "panel_df": 1, "dataflow_tail": 16}, {"lookahead": 0, "dataflow": 0}):
+        for k, v in opts.items():
+            h.set_option(k, v)
+        ll, ld, qd, info = h.loglik_parts(th)
+        assert info == 0 and close(ll, want[0], n) and close(ld, want[1], n) and close(qd, want[2], n), opts
+        for k in opts:
+            h.set_option(k, {"dataflow_max_nt": 96, "panel_df": -1, "dataflow_tail": 64, "lookahead": 1, "dataflow": 1}[k])
+    h.close()
+    g = _lib.Handle(X, y, ck, device=[0, 0, 0])
+    g.set_option("shard_min_n", 0)
+    for mode in (0, 2):
+        g.set_option("dist_panel_df", mode)
+        ll, ld, qd, info = g.loglik_parts(th)
+        assert info == 0 and close(ll, want[0], n) and close(ld, want[1], n) and close(qd, want[2], n), mode
+    g.close()
