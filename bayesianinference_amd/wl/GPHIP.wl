@@ -170,15 +170,21 @@ ensureFit[h_, theta_, fit_] := If[ Lookup[$fitted, h, None] === theta,
    parameter symbols P(k) in the order of `variables` (k from 0): the argument convention of gphip_create_custom.  The
    library's theta for such a handle is {p.., sn}: the reference's nugget arrives as values per point, so the sn slot is a
    dummy 1. appended by customLift. ---- *)
-customKernelSpec[kerf_, vars_List, d_Integer] := Module[{xs, ys, expr, str},
-	xs = Array[gphipXc, d, 0]; ys = Array[gphipYc, d, 0];
+customKernelSpec[kerf_, vars_List, d_Integer] := Module[{xs, ys, ps, expr, str},
+	(* plain symbols gphipXc0, gphipXc1, .. stand for the coordinates (N[] would turn an index argument into a real) *)
+	xs = Table[Symbol["GPHIP`Private`gphipXc" <> ToString[k]], {k, 0, d - 1}];
+	ys = Table[Symbol["GPHIP`Private`gphipYc" <> ToString[k]], {k, 0, d - 1}];
+	ps = Table[Symbol["GPHIP`Private`gphipPc" <> ToString[k]], {k, 0, Length[vars] - 1}];
 	expr = Quiet @ Check[kerf[xs, ys], $Failed];
 	If[ expr === $Failed || !FreeQ[expr, _Function | _Slot | _Piecewise | _If | _Which | _List | _Dot], Return[$Failed]];
-	expr = N[expr] /. Thread[vars -> Array[gphipPc, Length[vars], 0]];
-	(* anything left that is neither a coordinate / parameter accessor nor a System` function cannot be printed as C *)
-	If[ Cases[expr, sym_Symbol /; !MemberQ[{gphipXc, gphipYc, gphipPc}, sym] && Context[sym] =!= "System`", {0, Infinity}, Heads -> True] =!= {},
+	expr = N[expr /. Thread[vars -> ps]];
+	(* anything left that is neither a coordinate / parameter stand-in nor a System` function cannot be printed as C *)
+	If[ Cases[expr, sym_Symbol /; !MemberQ[Join[xs, ys, ps], sym] && Context[sym] =!= "System`", {0, Infinity}, Heads -> True] =!= {},
 		Return[$Failed]];
-	str = StringReplace[ToString[CForm[expr]], {"gphipXc" -> "X", "gphipYc" -> "Y", "gphipPc" -> "P"}];
+	(* (a symbol of a context that is not on $ContextPath prints with its context: GPHIP_Private_gphipXc0) *)
+	str = StringReplace[ToString[CForm[expr]], {
+		RegularExpression["[A-Za-z0-9_`]*gphipXc(\\d+)"] -> "X($1)", RegularExpression["[A-Za-z0-9_`]*gphipYc(\\d+)"] -> "Y($1)",
+		RegularExpression["[A-Za-z0-9_`]*gphipPc(\\d+)"] -> "P($1)"}];
 	{"Custom", "return " <> str <> ";", kerf, Length[vars], vars}
 ];
 customSpecQ[spec_] := MatchQ[spec, {"Custom", _String, _, _Integer, _List}];
