@@ -126,6 +126,14 @@ inline bool rtc_compile_custom(const std::string& body, int dtype, const char* a
            "template <typename A> __device__ __forceinline__ A Sin(A a) { return sin(a); }\n"
            "template <typename A> __device__ __forceinline__ A Cos(A a) { return cos(a); }\n"
            "template <typename A> __device__ __forceinline__ A Tanh(A a) { return tanh(a); }\n"
+           "template <typename A> __device__ __forceinline__ A Sinh(A a) { return sinh(a); }\n"
+           "template <typename A> __device__ __forceinline__ A Cosh(A a) { return cosh(a); }\n"
+           "template <typename A> __device__ __forceinline__ A Tan(A a) { return tan(a); }\n"
+           "template <typename A> __device__ __forceinline__ A ArcTan(A a) { return atan(a); }\n"
+           "template <typename A> __device__ __forceinline__ A Erf(A a) { return erf(a); }\n"
+           "template <typename A> __device__ __forceinline__ A Erfc(A a) { return erfc(a); }\n"
+           "template <typename A, typename B> __device__ __forceinline__ auto Min(A a, B b) -> decltype(a + b) { return a < b ? a : b; }\n"
+           "template <typename A, typename B> __device__ __forceinline__ auto Max(A a, B b) -> decltype(a + b) { return a > b ? a : b; }\n"
            "constexpr double Pi = 3.14159265358979323846, E = 2.71828182845904523536;\n"
            "template <typename T>\n"
            "__device__ T gphip_custom_k(PointRef<T> X, PointRef<T> Y, const double* __restrict__ Pp, int D) {\n"

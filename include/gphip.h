@@ -76,7 +76,7 @@ typedef struct gphip_ctx* gphip_handle;
  *     template <typename T> T k(X, Y, P, D) { <body> }
  * where X(k) / Y(k) are coordinate k (0-based) of the two points, P(k) the function's k-th hyper-parameter, D the input
  * dimension and T the handle's arithmetic type (double / float); it must `return` the covariance WITHOUT the nugget.  Device
- * math (exp, sqrt, pow, fabs, sin, ..) and the names Mathematica's CForm emits (Power, Sqrt, Exp, Log, Abs, Sin, Cos, Tanh, Pi, E)
+ * math (exp, sqrt, pow, fabs, sin, ..) and the names Mathematica's CForm emits (Power, Sqrt, Exp, Log, Abs, Sin, Cos, Tan, ArcTan, Sinh, Cosh, Tanh, Erf, Erfc, Min, Max, Pi, E)
  * are available.  Example, SE-ARD:  "T s = 0; for (int k = 0; k < D; ++k) { T u = (X(k) - Y(k)) / P(k); s += u * u; }
  * return P(D) * P(D) * exp((T)-0.5 * s);"  with nparams = d + 1.
  * theta layout of such a handle:  [p_0 .. p_{nparams-1}] sn [mu].  The function may be non-stationary: the prior variance

@@ -241,3 +241,17 @@ def test_function_valued_kernel_under_every_factorisation_schedule():
         ll, ld, qd, info = g.loglik_parts(th)
         assert info == 0 and close(ll, want[0], n) and close(ld, want[1], n) and close(qd, want[2], n), mode
     g.close()
+
+
+def test_cform_names_available_to_a_function_body():
+    """Every name Mathematica's CForm can emit for an elementary kernel expression resolves inside the generated source."""
+    X, y = syn.make_dataset(200, 1)
+    body = ("const T r = Abs(X(0) - Y(0)); "
+            "return Power(P(0),2) * Exp(-r) * (1 + Tanh(Min(r, 2.0)) * 0) * Max(Cos(0 * r), 0.5) + 0 * (Sin(r) + Tan(r) + ArcTan(r) + "
+            "Sinh(r) + Cosh(r) + Erf(r) + Erfc(r) + Log(1 + r) + Sqrt(r) + Pi + E);")
+    ck = _lib.CustomKernel(body, 1, fn=lambda A, B, p: p[0] ** 2 * np.exp(-np.abs(A[..., 0] - B[..., 0])))
+    h = _lib.Handle(X, y, ck)
+    th = np.array([1.3, 0.2])
+    ll, info = h.loglik(th)
+    assert info == 0 and close(ll, orc.log_likelihood(ck, th, X, y), 200)
+    h.close()
