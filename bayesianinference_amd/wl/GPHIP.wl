@@ -21,7 +21,7 @@ BeginPackage["GPHIP`", {"BayesianUtilities`", "BayesianStatistics`", "BayesianGa
 
 defineGaussianProcessHIP::usage = "defineGaussianProcessHIP[X -> Y, kernel, nugget, meanFunction, variables, prior, opts] has the argument list of defineGaussianProcess (BayesianGaussianProcess.wl:228-234) and builds the same inferenceObject with the log-likelihood evaluated on the GPU. kernel: a named kernel \"SE\", \"SEARD\", \"Matern52\", \"Matern52ARD\", \"Matern32\", \"Matern32ARD\", \"RQ\", \"RQARD\", a composed form \"term + term\", \"term * term\", optionally followed by \" + Const\" (e.g. \"SE + Const\"), or None (null kernel); ANY OTHER kernel expression falls through to the reference's own defineGaussianProcess. nugget: \"Constant\" (Function[sn^2]) or any expression / function of the point in the parameter symbols (evaluated on the host per theta, the values go to the GPU). meanFunction: None, \"Constant\" or any expression / function of the point. variables in the library's order: {term 1: l.., (alpha), sf}, {term 2 ..}, {c}, {sn}, {mu}. The short form defineGaussianProcessHIP[X -> Y, kernelName, variables, prior, opts] takes the constant nugget and \"ConstantMean\" -> False | True. Options: \"Precision\" -> \"Double\" | \"Single\", \"Devices\" -> Automatic | {0, 1, ..}, \"LibraryOptions\" -> {\"panel\" -> 4, ..}.";
 nestedSamplingHIP::usage = "nestedSamplingHIP[obj, opts] runs the native batched nested-sampling driver of the library (lock-step walkers: one batched likelihood call per Metropolis step) on a HIP-backed GP object whose prior is a product of UniformDistribution's (or \"PriorKinds\" -> {0 | 1 ..}, 1 = log-uniform over the parameter's range) or ANY product of univariate distributions (its factors' log densities travel as tables, the starting pool is drawn from the prior here) and returns the object joined with the result, in the shape nestedSampling returns (the reference's own evidenceSampling post-processes the samples). Takes the options of nestedSampling plus \"Walkers\" -> 32 and \"Seed\" -> 0. Joint (non-separable) priors fall through to nestedSampling[obj], which drives the same GPU closure one theta at a time.";
-defineGaussianProcessHIP::nonnative = "Kernel `1` is not one of the named or composed kernels of the library: it runs on the reference's own path, which needs the nugget and the mean function as expressions in the parameter symbols (not \"Constant\").";
+defineGaussianProcessHIP::nonnative = "Kernel `1` is not one of the named or composed kernels of the library: give the nugget and the mean function as expressions in the parameter symbols (not \"Constant\"); the kernel is then compiled for the device from its CForm, or runs on the reference's own path if it cannot be printed as C.";
 hipKernelFunction::usage = "hipKernelFunction[kernelName, d] gives theta |-> Function[{p, q}, ..], the exact WL form of the named kernel (what one would hand to the reference's defineGaussianProcess for the same model).";
 $GPHIPLibrary::usage = "Path of the LibraryLink shim (libgphip_wl).";
 
