@@ -39,7 +39,7 @@ namespace gphip {
 
 // Bumped whenever a struct or constant the run-time compiled copy of this region shares with the offline library changes
 // (KBuildArgs, SLOTP, the tile layout): rtc_dyn.h refuses a source tree whose value differs from the library's own.
-#define GP_RTC_ABI 1
+#define GP_RTC_ABI 2
 constexpr int TB = 128;         // tile edge
 // Elements between consecutive tiles of the packed workspace: 128 x 128 plus a pad.  Without the pad every tile starts on
 // a 128 KiB (fp64) boundary and the workgroups of a launch, which walk their operand tiles in lock step, all touch the
@@ -60,7 +60,8 @@ __host__ __device__ __forceinline__ int panel_slot(int tj, int nt, int panel) {
 }
 constexpr int SLOTP = 16;       // doubles of per-slot scalars: [0] sf2 (term 1), [1] sn2, [2] mu, [3] pivot_tol, [4] bad_theta,
                                 // [5] sf2 of term 2, [6] alpha of term 1, [7] alpha of term 2 (rational quadratic), [8] constant
-                                // offset c, [9] k(x, x) (prior variance without the nugget)
+                                // offset c, [9] k(x, x) (prior variance without the nugget), [10] != 0: the slot's kernel matrix is
+                                // built by kbuild_mfma_kernel (distance cross term on the matrix pipe), not by kbuild_kernel
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 typedef float f4 __attribute__((ext_vector_type(4)));
@@ -218,7 +219,7 @@ struct KSpec {
     int op;             // 0: one term, 1: k1 + k2, 2: k1 * k2
     int offset;         // 1: + c
 };
-constexpr int SP_SF2B = 5, SP_ALPHA1 = 6, SP_ALPHA2 = 7, SP_OFFSET = 8, SP_KXX = 9;
+constexpr int SP_SF2B = 5, SP_ALPHA1 = 6, SP_ALPHA2 = 7, SP_OFFSET = 8, SP_KXX = 9, SP_MFMA = 10;
 
 // g_fam(r2) and  -2 dg/dr2  (the factor the length-scale derivative needs: dk/dl_j = sf2 (-2 dg/dr2) u_j^2 / l_j) and dg/dalpha
 template <typename T>
@@ -341,6 +342,7 @@ struct KBuildArgs {
                             // to the dense tile index of any tile of outer panel q (index nt_j / .. see panel_slot);
                             // null: the dense packed layout
     const double* cp; int ncp;   // KT = 3 (run-time compiled covariance function): its hyper-parameters, [slot][ncp]
+    int mfma_skip;          // 1: slots whose scalar [SP_MFMA] is set belong to kbuild_mfma_kernel's launch -- leave them alone
 };
 
 // KT = 3: the covariance function is source text the caller handed to gphip_create_custom (the reference takes ANY
@@ -381,6 +383,7 @@ __global__ __launch_bounds__(256) void kbuild_kernel(KBuildArgs<T> a) {
         if (owner != a.own_rank) return;
     }
     const double* sp = a.slotp + (long)slot * SLOTP;
+    if (a.mfma_skip && sp[SP_MFMA] != 0.0) return;
     const T sf2 = (T)sp[0], sn2 = (T)sp[1], mu = (T)sp[2];
     // mode 0 writes one whole tile of the packed workspace (128 KiB contiguous in fp64); mode 1 a tile of a
     // column-major block
@@ -665,6 +668,208 @@ __global__ __launch_bounds__(256) void custom_prep_kernel(const T* __restrict__ 
 }  // namespace gphip
 // [rtc-end]
 namespace gphip {
+
+// ---------------------------------------------------------------------------------------------
+// kbuild_mfma_kernel: the tiles of kbuild_kernel (K1 / K7, BGP:29-43 and BGP:100-109) for the two named stationary
+// kernels, with the distance loop moved from the vector ALU to the matrix pipe.
+//
+// kbuild_kernel spends 2 fp64 VALU instructions per input dimension and entry on sum ((p_k - q_k) / l_k)^2 and ~12 more
+// on the exponential: at d = 8 the kernel is fp64-VALU bound (0.73 - 0.84 busy, MFMA pipe idle) and its time follows the
+// shader clock instead of the HBM store rate.  Here
+//     u(i, j) = |a_i|^2 + |b_j|^2 - 2 a_i . b_j,        a = s (x - c) / l  (points centred on c and scaled)
+// is ONE accumulator initialisation (a VALU add) plus ceil(d / 4) v_mfma_*_16x16x4 per 16 x 16 entries: the J-side
+// operand carries -2 b, the I-side operand a, the norms come from the same rounded coordinates.  s is chosen per
+// kernel family so that u is directly the argument the epilogue needs (fp64 SE: the exponent in units of ln2 / 512,
+// see exp_tab_u; Matern-5/2: 5 r^2; fp32 SE: r^2 log2(e) / 2).  Cost per entry is then independent of d.
+//
+// Accuracy: the rounding error of u is ~eps (|a|^2 + |b|^2) instead of ~eps r^2.  The host therefore (1) centres the
+// points on the mid-range of the training inputs, (2) bounds sum_k (halfrange_k / l_k)^2 for every theta and hands a
+// slot to this kernel only below a threshold (gphip.hip kbuild_mfma_ok; above it kbuild_kernel builds the slot as
+// before -- slot scalar SP_MFMA says which).  At the headline configuration (x in [-1, 1)^8, l = 1) the bound is 8 and
+// the two forms are equally accurate.  Rows / columns of duplicated points stay bit-identical (same inputs, same
+// operation sequence), so an exactly singular K stays exactly singular.
+//
+// One 128 x 128 tile per workgroup (4 waves).  MFMA m <-> tile column j, n <-> tile row i: a lane (c = l & 15,
+// g = l >> 4) ends up with NQ = 16 / sizeof(T) ADJACENT rows i0 + NQ c .. (one MFMA per row offset q) of the columns
+// j0 + drow(g, r), r = 0..3 -- every store is 16 bytes and 16 lanes cover 256 contiguous bytes of a column.  A wave
+// owns 32 columns (two 16-column blocks) and walks the tile's rows in blocks of 16 NQ.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+struct KBuildMArgs {
+    KBuildArgs<T> b;          // tile bookkeeping exactly as kbuild_kernel's (xi / xj / xi2 / xj2 / cp unused)
+    const T* xri;             // RAW (unscaled) row points [d][npad_i]
+    const T* xrj;             // RAW column points [d][npad_j]
+    const double* inv_ell;    // [slot][d]
+    const double* centre;     // [d]
+};
+constexpr int KM_LDP = 144;   // LDS row stride (elements) of the operand tiles: the four k rows a wave reads at once fall
+                              // on disjoint banks (144 * 8 B = 288 dwords = 32 mod 64; 144 * 4 B = 16 mod 32)
+template <typename T, int KS> __host__ __device__ constexpr size_t kbuild_mfma_lds(int d) {
+    const int kr = KS > 0 ? 4 * KS : 4 * ((d + 3) / 4);
+    return ((size_t)2 * kr * KM_LDP + 2 * TB) * sizeof(T) + (sizeof(T) == 8 ? (size_t)EXP_TAB * 8 : 0);
+}
+template <typename T, int KT> struct KmScale;
+template <> struct KmScale<double, 0> { static constexpr double v = EXP_COORD_SCALE_SE; };       // u = table units of exp(-r2 / 2)
+template <> struct KmScale<double, 1> { static constexpr double v = 2.2360679774997896; };        // u = 5 r2
+template <> struct KmScale<float, 0> { static constexpr double v = 0.84932180028801904; };        // u = r2 log2(e) / 2
+template <> struct KmScale<float, 1> { static constexpr double v = 2.2360679774997896; };
+
+// the entry from its accumulator u >= 0 (cancellation may leave u a few ulp of the norms below zero: clamped)
+template <int KT>
+__device__ __forceinline__ double km_value(double u, double, const double* __restrict__ tab) {
+    if (KT == 0) {
+        // (no clamp: u = -1e-10 table units gives t = MAGIC, k = 0, r = -u and the entry sf2 (1 + 1e-13) -- harmless, and
+        //  two fp64 instructions per entry saved)
+        constexpr double MAGIC = 6755399441055744.0;             // 1.5 * 2^52 (exp_tab_u without its upper clamp: the host's
+        constexpr double C1 = 1.3538030870311431e-03;            // bound on the norms keeps u far inside the int range)
+        constexpr double C2 = 9.163913992275265e-07;
+        constexpr double C3 = 4.1353783506767136e-10;
+        constexpr double C4 = 1.399621994296973e-13;
+        const double t = MAGIC - u;
+        const double kd = t - MAGIC;
+        const double r = -kd - u;
+        double p = __builtin_fma(C4, r, C3);
+        p = __builtin_fma(p, r, C2);
+        p = __builtin_fma(p, r, C1);
+        p = __builtin_fma(p, r, 1.0);
+        const int ki = __double2loint(t);
+        return __builtin_ldexp(tab[ki & (EXP_TAB - 1)] * p, ki >> 9);
+    } else {
+        asm("v_max_f64 %0, %1, 0" : "=v"(u) : "v"(u));            // (fmax() costs a canonicalising second v_max_f64)
+        const double sa = __builtin_sqrt(u);
+        return (1.0 + sa + (1.0 / 3.0) * u) * exp_tab<false>(sa, tab);
+    }
+}
+template <int KT>
+__device__ __forceinline__ float km_value(float u, float sf2, const double*) {
+    if (KT == 0) {
+        return sf2 * __builtin_amdgcn_exp2f(-fmaxf(u, 0.f));
+    } else {
+        const float q = fmaxf(u, 1e-30f);
+        const float s5 = q * __builtin_amdgcn_rsqf(q);
+        return sf2 * (1.0f + s5 + q * (1.0f / 3.0f)) * __builtin_amdgcn_exp2f(s5 * -1.4426950408889634f);
+    }
+}
+
+template <typename T, int KS, int KT>
+__global__ __launch_bounds__(256, 2) void kbuild_mfma_kernel(KBuildMArgs<T> m) {
+    const KBuildArgs<T>& a = m.b;
+    constexpr int NQ = 16 / (int)sizeof(T);         // adjacent rows per lane (one 16-byte store)
+    constexpr int IBR = 16 * NQ;                    // rows per row block
+    constexpr int NIB = TB / IBR;
+    typedef T vec_t __attribute__((ext_vector_type(NQ)));
+    typedef typename Num<T>::acc_t acc_t;
+    typedef typename Num<T>::pair_t pair_t;
+    extern __shared__ double lds_raw[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int slot = blockIdx.y;
+    int ti, tj;
+    if (a.mode == 0) {
+        tri_decode(blockIdx.x + a.t0, a.nt_i, ti, tj);
+    } else {
+        ti = blockIdx.x % a.nt_i;
+        tj = blockIdx.x / a.nt_i;
+    }
+    if (a.own_world > 0) {
+        const int owner = (tj == a.nt_j) ? 0 : (tj / a.own_panel) % a.own_world;
+        if (owner != a.own_rank) return;
+    }
+    const double* sp = a.slotp + (long)slot * SLOTP;
+    if (sp[SP_MFMA] == 0.0) return;                 // (kbuild_kernel's slot)
+    const T sf2 = (T)sp[0], sn2 = (T)sp[1], mu = (T)sp[2];
+    const long ldo = (a.mode == 0) ? (long)TB : a.ld;
+    T* out = a.out + (long)slot * a.bstride +
+             ((a.mode == 0) ? (tile_index(ti, tj, a.nt_i) + (a.adj ? a.adj[panel_slot(tj, a.nt_j, a.own_panel)] : 0l)) * TS
+                            : (long)tj * TB * a.ld + (long)ti * TB);
+    if (a.mode == 0 && ti == a.nt_i - 1) {          // right-hand-side block-row: row 0 = r^T, rest 0 (as kbuild_kernel)
+        const int r0 = 2 * lane;
+        for (int jj = wave * 32; jj < wave * 32 + 32; ++jj) {
+            const int gj = tj * TB + jj;
+            pair_t v;
+            v.x = (T)0;
+            v.y = (T)0;
+            if (lane == 0 && tj < a.nt_j && gj < a.n_j)
+                v.x = a.y[gj] - (a.pw_mean ? a.pw_mean[(long)slot * a.pw_bstride + gj] : mu);
+            *reinterpret_cast<pair_t*>(out + (long)jj * ldo + r0) = v;
+        }
+        return;
+    }
+    const int d = a.d;
+    const int ks = KS > 0 ? KS : (d + 3) / 4, kr = 4 * ks;
+    T* xjs = reinterpret_cast<T*>(lds_raw);         // [kr][KM_LDP]  -2 b
+    T* xis = xjs + kr * KM_LDP;                     // [kr][KM_LDP]  a
+    T* nrm = xis + kr * KM_LDP;                     // [2][TB]  |b|^2, |a|^2
+    const double* etab = reinterpret_cast<const double*>(nrm + 2 * TB);
+    if (sizeof(T) == 8) {
+        double* et = const_cast<double*>(etab);
+        for (int idx = tid; idx < EXP_TAB; idx += 256) et[idx] = sp[0] * a.exp2tab[idx];
+    }
+    {   // one thread per point of the two tiles: centre, scale, round to T, norm of the ROUNDED coordinates
+        const int side = tid >> 7, p = tid & 127;
+        const T* src = side ? m.xri + (long)ti * TB + p : m.xrj + (long)tj * TB + p;
+        const long np = side ? a.npad_i : a.npad_j;
+        T* dst = (side ? xis : xjs) + p;
+        const double* ie = m.inv_ell + (long)slot * d;
+        const double cs = KmScale<T, KT>::v;
+        double n2 = 0.0;
+        for (int dd = 0; dd < d; ++dd) {
+            const T v = (T)(((double)src[(long)dd * np] - m.centre[dd]) * (ie[dd] * cs));
+            n2 = __builtin_fma((double)v, (double)v, n2);
+            dst[dd * KM_LDP] = side ? v : (T)-2 * v;
+        }
+        for (int dd = d; dd < kr; ++dd) dst[dd * KM_LDP] = (T)0;
+        nrm[side * TB + p] = (T)n2;
+    }
+    __syncthreads();
+
+    const int c = lane & 15, g = lane >> 4;
+    const bool edge = (a.mode == 0) ? (ti == tj || (ti + 1) * TB > a.n_i)
+                                    : ((ti + 1) * TB > a.n_i || (tj + 1) * TB > a.n_j);
+    // 2 column blocks x NIB row blocks per wave, one rolled loop: the operands of a step are re-read from LDS (a handful
+    // of ds_read per ~100 VALU instructions), which keeps the kernel at ~64 registers -- several workgroups per CU, whose
+    // MFMA and VALU phases overlap -- and the code small
+#pragma unroll 1
+    for (int step = 0; step < 2 * NIB; ++step) {
+        const int j0 = (2 * wave + step / NIB) * 16, i0 = (step % NIB) * IBR + NQ * c;
+        const vec_t nai = *reinterpret_cast<const vec_t*>(nrm + TB + i0);
+        acc_t acc[NQ];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const T nbj = nrm[j0 + Num<T>::drow(g, r)];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) acc[q][r] = nai[q] + nbj;
+        }
+#pragma unroll
+        for (int s = 0; s < (KS > 0 ? KS : ks); ++s) {
+            const T av = xjs[(4 * s + g) * KM_LDP + j0 + c];
+            const vec_t bv = *reinterpret_cast<const vec_t*>(xis + (4 * s + g) * KM_LDP + i0);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) acc[q] = Num<T>::mfma(av, bv[q], acc[q]);
+        }
+        const int gi0 = ti * TB + i0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int jc = j0 + Num<T>::drow(g, r);
+            vec_t v;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) v[q] = km_value<KT>(acc[q][r], sf2, etab);
+            if (edge) {
+                const int gj = tj * TB + jc;
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    const int gi = gi0 + q;
+                    if (a.mode == 0) {
+                        if (gi == gj) v[q] += a.pw_nug ? a.pw_nug[(long)slot * a.pw_bstride + gj] : sn2;
+                        if (gj >= a.n_j || gi >= a.n_i) v[q] = (gi == gj) ? (T)1 : (T)0;      // identity pad
+                    } else if (gj >= a.n_j || gi >= a.n_i) {
+                        v[q] = (T)0;
+                    }
+                }
+            }
+            *reinterpret_cast<vec_t*>(out + (long)jc * ldo + i0) = v;
+        }
+    }
+}
 
 // ---------------------------------------------------------------------------------------------
 // potrf128: Cholesky of one 128x128 diagonal block AND its triangular inverse, in LDS.
@@ -2454,7 +2659,7 @@ __global__ void finalize_kernel(const T* __restrict__ Abase, long bstride, long 
                                 const double* __restrict__ partial, int nt, double* __restrict__ res,
                                 const int* __restrict__ info = nullptr, const int* __restrict__ abort_flag = nullptr,
                                 double* __restrict__ hres = nullptr, int* __restrict__ hinfo = nullptr,
-                                int pstride = 0, const double* __restrict__ partial2 = nullptr, int n2 = 0, int abort_at = -1) {
+                                int pstride = 0, const double* __restrict__ partial2 = nullptr, int n2 = 0) {
     // partial: nt entries per slot at stride pstride (0 = nt); partial2 (optional): n2 more entries per slot,
     // stride n2 -- the 64-blocks of a dataflow tail that followed a multi-kernel bulk
     const int slot = blockIdx.x;
@@ -2471,7 +2676,7 @@ __global__ void finalize_kernel(const T* __restrict__ Abase, long bstride, long 
             hres[slot * 2 + 0] = logdet;
             hres[slot * 2 + 1] = quad;
             hinfo[slot] = info[slot];
-            if (slot == 0) hinfo[abort_at >= 0 ? abort_at : (int)gridDim.x] = *abort_flag;   // (abort_at: this launch covers a slot sub-range)
+            if (slot == 0) hinfo[(int)gridDim.x] = *abort_flag;
         }
     }
 }

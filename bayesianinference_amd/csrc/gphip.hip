@@ -96,15 +96,7 @@ struct gphip_ctx {
     int rest_stream_for = 0;
     int split_streams_for = 0;                   // reserved CUs per XCD the two masked streams were created for
     unsigned long long ticket_base2 = 0;         // chain launch's own ticket counter (dTicket + DF_TICKET2)
-    // Phase-shifted batch groups (eval_chunk): a large theta batch is cut into `batch_groups` slot ranges, each factored on its
-    // own (main, panel) stream pair and started one phase after the previous one, so that a group's kernel build / outer
-    // panel 0 / last panels -- latency-shaped, nothing of its own to hide behind -- run under another group's trailing SYRKs.
-    int batch_groups = 1, batch_group_min = 48;   // 1 = off (measured: no gain, the batch is throughput bound), -1 auto, n groups
     int panel_rows = 0;                           // (measured: bit-identical, 2 % slower -- off) batches: rows below a panel's diagonal block handled by panel_rows_kernel
-    std::vector<hipStream_t> grp_streams;         // [2 g], [2 g + 1] = main / panel stream of group g >= 1
-    std::vector<hipEvent_t> grp_events;           // dedicated events (the sync_events pool is recycled inside queue_factor)
-    hipEvent_t* stagger_out = nullptr;            // queue_factor: record "outer panel 0 is factored" here (panel stream)
-    int final_abort_at = -1;                      // launch_finalize: where (relative to hInfo) the abort word goes when the launch covers a slot sub-range
     int build_overlap = 0;                       // option: factor panel 0 under the rest of the kernel build (measured: -0.1 % per
                                                  // evaluation, but the build itself slows 4-15 % while it shares the chip: off)
     bool own_streams = true;
@@ -124,6 +116,14 @@ struct gphip_ctx {
     int null_cap = 0;
     void *dXt = nullptr, *dY = nullptr;                     // typed: [d][Npad], [Npad]
     double* dExp2 = nullptr;                                // [EXP_TAB] 2^(j/512): the kernel build's exp table
+    // Kernel build with the distance cross term on the matrix pipe (kbuild_mfma_kernel): mid-range and half range of the
+    // training inputs per dimension.  A theta's slot goes to that kernel while sum_k (half_k / l_k)^2 <= kbuild_mfma_bound
+    // (fp32: / 8) -- the rounding error of its squared distances grows with that sum (gp_kernels.h); above it, and for every
+    // other covariance form, kbuild_kernel builds the slot.  Option kbuild_mfma: 0 never, 1 by the bound, 2 always (tests).
+    double* dCentre = nullptr;                              // [d]
+    std::vector<double> x_centre, x_half;
+    int kbuild_mfma = 1, kbuild_mfma_bound = 512;
+    double test_ratio = 0.0;                                // current test points: largest |x* - centre| / half range over the dimensions
     // batch workspace
     int slots = 0;
     void *dA = nullptr, *dXs = nullptr, *dW = nullptr;      // typed
@@ -424,8 +424,41 @@ void launch_kbuild_kt(gphip_ctx* h, const KBuildArgs<T>& a, dim3 grid) {
 #undef KB_CASE
 }
 
+template <typename T, int KT>
+void launch_kbuild_mfma_kt(gphip_ctx* h, const KBuildMArgs<T>& m, dim3 grid) {
+    const int d = m.b.d;
+#define KM_CASE(KS)                                                                                                  \
+    case KS:                                                                                                         \
+        hipLaunchKernelGGL((kbuild_mfma_kernel<T, KS, KT>), grid, dim3(256), (kbuild_mfma_lds<T, KS>(d)), h->cs, m); \
+        break;
+    switch ((d + 3) / 4) {
+        KM_CASE(1) KM_CASE(2) KM_CASE(3) KM_CASE(4)
+        default:
+            hipLaunchKernelGGL((kbuild_mfma_kernel<T, 0, KT>), grid, dim3(256), (kbuild_mfma_lds<T, 0>(d)), h->cs, m);
+    }
+#undef KM_CASE
+}
+
+// xri / xrj: the RAW (unscaled) row / column points kbuild_mfma_kernel scales itself; null = this build has no such form
+// (the direct kernel builds every slot)
 template <typename T>
-void launch_kbuild(gphip_ctx* h, const KBuildArgs<T>& a0, dim3 grid) {
+void launch_kbuild(gphip_ctx* h, const KBuildArgs<T>& a0, dim3 grid, const T* xri = nullptr, const T* xrj = nullptr) {
+    if (!h->custom && h->kt <= 1 && xri && xrj) {
+        int nm = 0;                                // slots of this launch the staged thetas hand to the matrix-pipe build
+        for (unsigned s2 = 0; s2 < grid.y; ++s2) nm += h->hSlotp[(size_t)s2 * SLOTP + SP_MFMA] != 0.0;
+        if (nm > 0) {
+            KBuildMArgs<T> m{};
+            m.b = a0; m.xri = xri; m.xrj = xrj; m.inv_ell = h->dInvEll; m.centre = h->dCentre;
+            if (h->kt == 0) launch_kbuild_mfma_kt<T, 0>(h, m, grid);
+            else launch_kbuild_mfma_kt<T, 1>(h, m, grid);
+            if (nm == (int)grid.y) return;
+        }
+        KBuildArgs<T> a = a0;
+        a.mfma_skip = nm > 0;
+        if (h->kt == 0) launch_kbuild_kt<T, 0>(h, a, grid);
+        else launch_kbuild_kt<T, 1>(h, a, grid);
+        return;
+    }
     if (h->custom) {                               // the run-time compiled instantiation kbuild_kernel<T, 0, 3>
         KBuildArgs<T> a = a0;
         a.cp = h->dCustomP; a.ncp = std::max(h->ncp, 1);
@@ -510,16 +543,16 @@ int queue_build(gphip_ctx* h, int nslots, bool for_factor = false) {
         if (bnd.size() >= 3) {                                         // >= 2 outer panels: queue_factor runs the look-ahead schedule
             const long c = bnd[1], R = h->Nt + 1;
             const long first = c * R - c * (c - 1) / 2;                // tiles of the tile columns [0, c) (column-major packed order)
-            launch_kbuild<T>(h, a, dim3((unsigned)first, nslots));
+            launch_kbuild<T>(h, a, dim3((unsigned)first, nslots), (const T*)h->dXt, (const T*)h->dXt);
             h->sync_used = 0;
             h->ev_built0 = sync_event(h);
             HIPCHK(hipEventRecord(h->ev_built0, h->stream));
             a.t0 = (int)first;
-            launch_kbuild<T>(h, a, dim3((unsigned)(ntiles - first), nslots));
+            launch_kbuild<T>(h, a, dim3((unsigned)(ntiles - first), nslots), (const T*)h->dXt, (const T*)h->dXt);
             return 0;
         }
     }
-    launch_kbuild<T>(h, a, dim3((unsigned)ntiles, nslots));
+    launch_kbuild<T>(h, a, dim3((unsigned)ntiles, nslots), (const T*)h->dXt, (const T*)h->dXt);
     return 0;
 }
 
@@ -914,7 +947,7 @@ template <typename T>
 void launch_finalize(gphip_ctx* h, int nslots, int nparts, int pstride = 0, const double* part2 = nullptr, int n2 = 0) {
     hipLaunchKernelGGL(finalize_kernel<T>, dim3(nslots), dim3(64), 0, h->stream, (const T*)h->dA, (long)h->slot_elems,
                        (long)(h->slot_elems - TS), h->dPartial, nparts, h->dRes, (const int*)h->dInfo,
-                       (const int*)reinterpret_cast<int*>(h->dTicket + 1), h->hRes, h->hInfo, pstride, part2, n2, h->final_abort_at);
+                       (const int*)reinterpret_cast<int*>(h->dTicket + 1), h->hRes, h->hInfo, pstride, part2, n2);
 }
 
 template <typename T>
@@ -1020,7 +1053,7 @@ int queue_factor(gphip_ctx* h, int nslots) {
             trailing(k, k0(k + 1), R, 4);
         }
     } else {
-        if (!built0 && !h->stagger_out) h->sync_used = 0;   // (the split build took the first event of this evaluation; batch groups: one pool for all groups)
+        if (!built0) h->sync_used = 0;          // (the split build took the first event of this evaluation)
         hipEvent_t built = sync_event(h);
         HIPCHK(hipEventRecord(built, h->stream));
         HIPCHK(hipStreamWaitEvent(h->pstream, built0 ? built0 : built, 0));
@@ -1038,7 +1071,6 @@ int queue_factor(gphip_ctx* h, int nslots) {
         else queue_panel<T>(h, 0, k0(1), nslots);
         hipEvent_t ev_panel = sync_event(h);
         HIPCHK(hipEventRecord(ev_panel, h->pstream));
-        if (h->stagger_out) HIPCHK(hipEventRecord(*h->stagger_out, h->pstream));   // the next batch group may start its build now
         hipEvent_t ev_rest = nullptr, ev_rest2 = nullptr;
         // tail: once only `dataflow_tail` tile columns are left the dataflow kernel finishes the job in one
         // launch -- the last panels are chain bound, the regime the dataflow schedule wins
@@ -1188,7 +1220,7 @@ bool stage_theta(gphip_ctx* h, int slot, const double* th, const double* nug_row
         for (int k = 0; k < SLOTP; ++k) sp[k] = 0.0;
         sp[0] = 1.0; sp[1] = sn * sn; sp[2] = mu; sp[3] = pivot_tol_rel(h); sp[SP_SF2B] = nug_scale; sp[SP_KXX] = 1.0;
         sp[4] = ok ? 0.0 : 1.0;
-        return ok;
+        return ok;                                 // (sp[SP_MFMA] = 0: cleared above)
     }
     // theta = [term 1: l.., (alpha), sf] [term 2: l.., (alpha), sf] [c] sn [mu]; only |l| matters (l enters squared)
     int o = 0;
@@ -1235,6 +1267,14 @@ bool stage_theta(gphip_ctx* h, int slot, const double* th, const double* nug_row
         sp[0] = sp[1] = sp[SP_KXX] = 1.0; sp[SP_SF2B] = 0.0; sp[SP_OFFSET] = 0.0; sp[3] = 1e-14;
     }
     sp[4] = ok ? 0.0 : 1.0;
+    // which kernel builds this slot's K (see gphip_ctx::kbuild_mfma)
+    sp[SP_MFMA] = 0.0;
+    if (h->kbuild_mfma && h->kt <= 1 && h->nl2 == 0 && h->d <= KB_LDS_MAXD && h->dCentre && ok) {
+        double bound = 0.0;
+        for (int j = 0; j < h->d; ++j) bound += (h->x_half[(size_t)j] * ie[j]) * (h->x_half[(size_t)j] * ie[j]);
+        const double lim = h->dtype == 64 ? (double)h->kbuild_mfma_bound : (double)h->kbuild_mfma_bound / 8.0;
+        if (h->kbuild_mfma >= 2 || bound <= lim) sp[SP_MFMA] = 1.0;
+    }
     return ok;
 }
 
@@ -1376,99 +1416,6 @@ int null_kernel_batch(gphip_ctx* h, const double* Theta, int B, double* out, dou
     return GPHIP_OK;
 }
 
-// ---- phase-shifted batch groups -------------------------------------------------------------------------------------
-// Every per-slot array of the context addressed from slot s0 on (the launch helpers index slots from the context's base
-// pointers, blockIdx.y = slot): a group of a batch is then queued with the ordinary single-range code.
-struct SlotShift {
-    gphip_ctx* h;
-    void *dA, *dXs, *dXs2, *dW, *dPwMean, *dPwNug;
-    double *dInvEll, *dInvEll2, *dSlotp, *dPartial, *dRes, *hRes;
-    int *dInfo, *hInfo;
-    hipStream_t stream, pstream;
-    SlotShift(gphip_ctx* h_, int s0, hipStream_t ms, hipStream_t ps) : h(h_) {
-        dA = h->dA; dXs = h->dXs; dXs2 = h->dXs2; dW = h->dW; dPwMean = h->dPwMean; dPwNug = h->dPwNug;
-        dInvEll = h->dInvEll; dInvEll2 = h->dInvEll2; dSlotp = h->dSlotp; dPartial = h->dPartial; dRes = h->dRes; hRes = h->hRes;
-        dInfo = h->dInfo; hInfo = h->hInfo; stream = h->stream; pstream = h->pstream;
-        auto sh = [&](void* p, size_t bytes_per_slot) -> void* { return p ? static_cast<char*>(p) + (size_t)s0 * bytes_per_slot : nullptr; };
-        h->dA = sh(dA, (size_t)h->slot_elems * h->es);
-        h->dXs = sh(dXs, (size_t)h->d * h->Npad * h->es);
-        h->dXs2 = sh(dXs2, (size_t)h->d * h->Npad * h->es);
-        h->dW = sh(dW, (size_t)h->Nt * TB * TB * h->es);
-        h->dPwMean = sh(dPwMean, (size_t)h->Npad * h->es);
-        h->dPwNug = sh(dPwNug, (size_t)h->Npad * h->es);
-        h->dInvEll = (double*)sh(dInvEll, (size_t)h->d * 8);
-        h->dInvEll2 = (double*)sh(dInvEll2, (size_t)h->d * 8);
-        h->dSlotp = (double*)sh(dSlotp, (size_t)SLOTP * 8);
-        h->dPartial = (double*)sh(dPartial, (size_t)h->Nt * 8);
-        h->dRes = (double*)sh(dRes, 16);
-        h->hRes = (double*)sh(hRes, 16);
-        h->dInfo = (int*)sh(dInfo, 4);
-        h->hInfo = (int*)sh(hInfo, 4);
-        h->stream = ms; h->pstream = ps; h->cs = ms;
-    }
-    ~SlotShift() {
-        h->dA = dA; h->dXs = dXs; h->dXs2 = dXs2; h->dW = dW; h->dPwMean = dPwMean; h->dPwNug = dPwNug;
-        h->dInvEll = dInvEll; h->dInvEll2 = dInvEll2; h->dSlotp = dSlotp; h->dPartial = dPartial; h->dRes = dRes; h->hRes = hRes;
-        h->dInfo = dInfo; h->hInfo = hInfo; h->stream = stream; h->pstream = pstream; h->cs = stream;
-    }
-};
-
-// how many groups for a batch of nb thetas: only the throughput-bound multi-kernel look-ahead schedule has exposed phases
-// worth hiding (a dataflow launch is one kernel; a sharded evaluation has its own schedule)
-int batch_group_count(const gphip_ctx* h, int nb) {
-    if (h->batch_groups == 0 || h->batch_groups == 1) return 1;
-    if (h->fused_eval || h->theta_packed || !h->lookahead || h->dist_world > 0 || use_dataflow(h, nb)) return 1;
-    if ((int)((h->Nt + h->panel - 1) / h->panel) < 3) return 1;                    // needs a few outer panels to pipeline
-    int G = h->batch_groups > 0 ? h->batch_groups : (nb >= 4 * h->batch_group_min ? 3 : 2);
-    while (G > 1 && nb / G < h->batch_group_min) --G;
-    // the dataflow kernels share ONE ticket counter / flag array per context: concurrent groups must never reach the dataflow
-    // tail of the look-ahead schedule (taken by calls of <= dataflow_max_slots thetas)
-    while (G > 1 && h->dataflow && nb / G <= h->dataflow_max_slots) --G;
-    if (G > 1 && use_dataflow(h, (nb + G - 1) / G)) return 1;                      // (the groups must run the same schedule)
-    return G;
-}
-
-int queue_batch_groups(gphip_ctx* h, int nb, int G) {
-    while ((int)h->grp_streams.size() < 2 * G) {                                    // (entries 0, 1 stay null: group 0 runs on the handle's own pair)
-        hipStream_t st = nullptr;
-        if (h->grp_streams.size() >= 2) {
-            int least = 0, greatest = 0;
-            (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-            HIPCHK(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, (h->grp_streams.size() & 1) ? greatest : least));
-        }
-        h->grp_streams.push_back(st);
-    }
-    while ((int)h->grp_events.size() < 2 * G + 1) {
-        hipEvent_t e = nullptr;
-        HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        h->grp_events.push_back(e);
-    }
-    hipStream_t main0 = h->stream, panel0 = h->pstream;
-    hipEvent_t ready = h->grp_events[(size_t)2 * G];
-    h->sync_used = 0;
-    HIPCHK(hipEventRecord(ready, main0));                                           // thetas uploaded, info words cleared
-    ProfScope ps(h, 5, 0.0, 0.0);
-    for (int g = 0; g < G; ++g) {
-        const int s0 = (int)((long)nb * g / G), s1 = (int)((long)nb * (g + 1) / G);
-        hipStream_t ms = g == 0 ? main0 : h->grp_streams[(size_t)2 * g], pst = g == 0 ? panel0 : h->grp_streams[(size_t)2 * g + 1];
-        SlotShift shift(h, s0, ms, pst);
-        if (g > 0) {
-            HIPCHK(hipStreamWaitEvent(ms, ready, 0));
-            HIPCHK(hipStreamWaitEvent(ms, h->grp_events[(size_t)2 * (g - 1)], 0));  // previous group: outer panel 0 factored
-        }
-        h->stagger_out = &h->grp_events[(size_t)2 * g];
-        h->final_abort_at = nb - s0;
-        int rc = DISPATCH(h, queue_build, h, s1 - s0, true);
-        if (rc == 0) rc = DISPATCH(h, queue_factor, h, s1 - s0);
-        h->stagger_out = nullptr;
-        h->final_abort_at = -1;
-        if (rc) return rc;
-        if (g > 0) HIPCHK(hipEventRecord(h->grp_events[(size_t)2 * g + 1], ms));     // group finished (its finalize is queued)
-    }
-    for (int g = 1; g < G; ++g) HIPCHK(hipStreamWaitEvent(main0, h->grp_events[(size_t)2 * g + 1], 0));
-    return GPHIP_OK;
-}
-
 // s0: index of the chunk's first theta within the call (rows of the call's point-dependent nugget / mean arrays)
 int eval_chunk(gphip_ctx* h, const double* Theta, int nb, double* out, double* parts, int* info, int s0 = 0) {
     std::vector<char> okv(nb);
@@ -1492,11 +1439,7 @@ int eval_chunk(gphip_ctx* h, const double* Theta, int nb, double* out, double* p
     h->fused_eval = h->fuse_option && h->theta_packed && h->kt != 2 && h->dtype == 64 && !h->want_w && h->profile < 2 &&
                     !h->pw_mean_on && !h->pw_nug_on && use_dataflow(h, nb) && h->Nt <= h->dataflow_fine_nt;
     h->cs = h->stream;
-    const int G = batch_group_count(h, nb);
-    if (G > 1) {
-        const int rc = queue_batch_groups(h, nb, G);
-        if (rc) return rc;
-    } else {
+    {
         ProfScope ps(h, 5, 0.0, 0.0);
         if (!h->fused_eval) DISPATCH(h, queue_build, h, nb, true);
         DISPATCH(h, queue_factor, h, nb);
@@ -1508,7 +1451,7 @@ int eval_chunk(gphip_ctx* h, const double* Theta, int nb, double* out, double* p
     HIPCHK(hipGetLastError());
     harvest(h);
     if (h->hInfo[nb] != 0 && getenv("GPHIP_DEBUG")) {
-        fprintf(stderr, "gphip debug: nb=%d G=%d hInfo[nb]=%d slots=%d; hInfo[0..]:", nb, G, h->hInfo[nb], h->slots);
+        fprintf(stderr, "gphip debug: nb=%d hInfo[nb]=%d slots=%d; hInfo[0..]:", nb, h->hInfo[nb], h->slots);
         for (int i = 0; i <= nb && i < 80; ++i) fprintf(stderr, " %d", h->hInfo[i]);
         fprintf(stderr, "\n");
     }
@@ -1717,6 +1660,20 @@ int queue_scale_train(gphip_ctx* h) {
     return 0;
 }
 
+// the test points about to be uploaded ([d][mpad], mc of them): how far outside the training inputs' range do they lie?
+void note_test_range(gphip_ctx* h, const std::vector<double>& xt, int64_t mc, int64_t mpad) {
+    double r = 0.0;
+    if (h->dCentre)
+        for (int64_t j = 0; j < h->d; ++j) {
+            const double c = h->x_centre[(size_t)j], half = h->x_half[(size_t)j];
+            for (int64_t i = 0; i < mc; ++i) {
+                const double dev = std::fabs(xt[(size_t)j * mpad + i] - c);
+                if (dev > 0.0) r = std::max(r, half > 0.0 ? dev / half : HUGE_VAL);
+            }
+        }
+    h->test_ratio = r;
+}
+
 // V(t, j) = k_theta_s(x*_t, x_j) for every slot s: the (unscaled) test points in dXsT are scaled by
 // each slot's 1/l into dXsS[slot]
 template <typename T>
@@ -1734,7 +1691,9 @@ int queue_cross(gphip_ctx* h, int64_t mc, int64_t mpad, int nslots) {
     a.npad_i = (int)mpad; a.npad_j = (int)h->Npad; a.n_i = (int)mc; a.n_j = (int)h->N;
     a.y = nullptr; a.slotp = h->dSlotp; a.d = (int)h->d; a.mode = 1; a.nt_i = (int)(mpad / TB); a.nt_j = (int)h->Nt;
     a.exp2tab = h->dExp2;
-    launch_kbuild<T>(h, a, dim3((unsigned)((mpad / TB) * h->Nt), nslots));
+    // (test points far outside the training inputs' range would void the bound the slots' SP_MFMA verdicts rest on)
+    const bool far = !(h->test_ratio <= 2.0);
+    launch_kbuild<T>(h, a, dim3((unsigned)((mpad / TB) * h->Nt), nslots), far ? nullptr : (const T*)h->dXsT, (const T*)h->dXt);
     return 0;
 }
 
@@ -2133,6 +2092,28 @@ static int create_ctx(const void* X, const void* y, int64_t N, int64_t d, int ke
     }
     if (DISPATCH(h, upload, h, h->dXt, xt, h->stream) != GPHIP_OK) return bail(GPHIP_ERR_HIP);
     if (DISPATCH(h, upload, h, h->dY, yp, h->stream) != GPHIP_OK) return bail(GPHIP_ERR_HIP);
+    if (kernel_id != GPHIP_KERNEL_NULL && !custom_body && h->kt <= 1) {
+        // mid-range / half range of the inputs AS THE DEVICE HOLDS THEM (fp32 handles: rounded to float)
+        h->x_centre.assign((size_t)d, 0.0); h->x_half.assign((size_t)d, 0.0);
+        bool finite = true;
+        for (int64_t j = 0; j < d; ++j) {
+            double lo = 0.0, hi = 0.0;
+            for (int64_t i = 0; i < N; ++i) {
+                const double v = dtype == 64 ? xt[(size_t)j * h->Npad + i] : (double)(float)xt[(size_t)j * h->Npad + i];
+                if (i == 0 || v < lo) lo = v;
+                if (i == 0 || v > hi) hi = v;
+                if (!std::isfinite(v)) finite = false;
+            }
+            double c = 0.5 * lo + 0.5 * hi;
+            if (dtype == 32) c = (double)(float)c;
+            h->x_centre[(size_t)j] = c;
+            h->x_half[(size_t)j] = std::max(hi - c, c - lo);
+        }
+        if (finite) {
+            if (hipMalloc(&h->dCentre, (size_t)d * 8) != hipSuccess) return bail(GPHIP_ERR_HIP);
+            if (hipMemcpy(h->dCentre, h->x_centre.data(), (size_t)d * 8, hipMemcpyHostToDevice) != hipSuccess) return bail(GPHIP_ERR_HIP);
+        }
+    }
     if (DISPATCH(h, set_func_attrs, h) != GPHIP_OK) return bail(GPHIP_ERR_HIP);
     if (custom_body) {
         hipDeviceProp_t prop;
@@ -2251,7 +2232,7 @@ int gphip_destroy(gphip_handle h) {
     if (h->cmod) (void)hipModuleUnload(h->cmod);
     if (h->cstream) (void)hipStreamDestroy(h->cstream);
     free_slots(h);
-    (void)hipFree(h->dXt); (void)hipFree(h->dY); (void)hipFree(h->dExp2);
+    (void)hipFree(h->dXt); (void)hipFree(h->dY); (void)hipFree(h->dExp2); (void)hipFree(h->dCentre);
     (void)hipFree(h->dV); (void)hipFree(h->dXsT); (void)hipFree(h->dXsS); (void)hipFree(h->dMean);
     (void)hipFree(h->dVar); (void)hipFree(h->dAlpha); (void)hipFree(h->dGacc); (void)hipFree(h->dKinv);
     (void)hipFree(h->dXsS2); (void)hipFree(h->dPwMeanT); (void)hipFree(h->dPwNugT);
@@ -2259,8 +2240,6 @@ int gphip_destroy(gphip_handle h) {
     for (auto e : h->pool) (void)hipEventDestroy(e);
     for (auto e : h->sync_events) (void)hipEventDestroy(e);
     if (h->stream2) { (void)hipStreamSynchronize(h->stream2); (void)hipStreamDestroy(h->stream2); }
-    for (hipStream_t st : h->grp_streams) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
-    for (hipEvent_t e : h->grp_events) (void)hipEventDestroy(e);
     if (h->chain_stream) (void)hipStreamDestroy(h->chain_stream);
     if (h->rest_stream) (void)hipStreamDestroy(h->rest_stream);
     if (h->bulk_stream) (void)hipStreamDestroy(h->bulk_stream);
@@ -2552,6 +2531,7 @@ int gphip_cross_covariance(gphip_handle h, const double* theta, int p, const voi
         xt.assign((size_t)d * mpad, 0.0);
         for (int64_t i = 0; i < mc; ++i)
             for (int64_t j = 0; j < d; ++j) xt[(size_t)j * mpad + i] = X[(m0 + i) * d + j];
+        note_test_range(h, xt, mc, mpad);
         rc = DISPATCH(h, upload, h, h->dXsT, xt, h->stream);
         if (rc) return rc;
         DISPATCH(h, queue_cross, h, mc, mpad, 1);
@@ -2665,6 +2645,7 @@ static int predict_local(gphip_handle h, const void* Xs, int64_t M, double* mean
         xt.assign((size_t)d * mpad, 0.0);
         for (int64_t i = 0; i < mc; ++i)
             for (int64_t j = 0; j < d; ++j) xt[(size_t)j * mpad + i] = X[(m0 + i) * d + j];
+        note_test_range(h, xt, mc, mpad);
         rc = DISPATCH(h, upload, h, h->dXsT, xt, h->stream);
         if (rc) return rc;
         rc = upload_pw_test(h, 0, 1, m0, mc, mpad);
@@ -2797,6 +2778,7 @@ static int predict_streamed(gphip_handle h, const void* Xs, int64_t M, double* m
             xt.assign((size_t)d * mpad, 0.0);
             for (int64_t r = 0; r < mc; ++r)
                 for (int64_t j = 0; j < d; ++j) xt[(size_t)j * mpad + r] = X[(a + r) * d + j];
+            note_test_range(m, xt, mc, mpad);
             member_fail(m, DISPATCH(m, upload, m, m->dXsT, xt, m->stream));
             m->pw_mean_test = pm0 ? pm0 + a : nullptr;
             m->pw_nug_test = pn0 ? pn0 + a : nullptr;
@@ -2947,7 +2929,8 @@ int gphip_predict_samples(gphip_handle h, const double* Thetas, int S, int p, co
             xt.assign((size_t)d * mpad, 0.0);
             for (int64_t i = 0; i < mc; ++i)
                 for (int64_t j = 0; j < d; ++j) xt[(size_t)j * mpad + i] = X[(m0 + i) * d + j];
-            rc = DISPATCH(h, upload, h, h->dXsT, xt, h->stream);
+            note_test_range(h, xt, mc, mpad);
+        rc = DISPATCH(h, upload, h, h->dXsT, xt, h->stream);
             if (rc) return rc;
             rc = upload_pw_test(h, s0, nb, m0, mc, mpad);
             if (rc) return rc;
@@ -3296,12 +3279,13 @@ int* option_slot(gphip_ctx* h, const char* name) {
         {"dataflow", &gphip_ctx::dataflow}, {"dataflow_max_nt", &gphip_ctx::dataflow_max_nt},
         {"dataflow_max_slots", &gphip_ctx::dataflow_max_slots}, {"dataflow_fine_nt", &gphip_ctx::dataflow_fine_nt},
         {"dataflow_tail", &gphip_ctx::dataflow_tail}, {"grad_potri", &gphip_ctx::grad_potri},
-        {"fused_eval", &gphip_ctx::fuse_option}, {"panel_left", &gphip_ctx::panel_left}, {"build_overlap", &gphip_ctx::build_overlap}, {"dataflow_lds_kib", &gphip_ctx::dataflow_lds_kib}, {"dataflow_park", &gphip_ctx::dataflow_park}, {"fuse_potrf", &gphip_ctx::fuse_potrf}, {"bcast_chunks", &gphip_ctx::bcast_chunks}, {"bcast_two_hop", &gphip_ctx::bcast_two_hop}, {"dist_panel_df", &gphip_ctx::dist_panel_df}, {"panel_df", &gphip_ctx::panel_df}, {"df_panel_one_wg_tasks", &gphip_ctx::df_panel_one_wg_tasks}, {"dist_df_occ3_tasks", &gphip_ctx::dist_df_occ3_tasks}, {"dataflow_occ3", &gphip_ctx::dataflow_occ3}, {"batch_groups", &gphip_ctx::batch_groups}, {"panel_rows", &gphip_ctx::panel_rows}, {"batch_group_min", &gphip_ctx::batch_group_min}, {"df_split", &gphip_ctx::df_split}, {"df_split_lds_kib", &gphip_ctx::df_split_lds_kib}, {"df_split_min_tasks", &gphip_ctx::df_split_min_tasks}, {"rest_mask", &gphip_ctx::rest_mask}, {"rest_mask_max_nt", &gphip_ctx::rest_mask_max_nt}, {"df_split_auto", &gphip_ctx::df_split_auto}, {"df_split_width", &gphip_ctx::df_split_width},
+        {"fused_eval", &gphip_ctx::fuse_option}, {"panel_left", &gphip_ctx::panel_left}, {"build_overlap", &gphip_ctx::build_overlap}, {"dataflow_lds_kib", &gphip_ctx::dataflow_lds_kib}, {"dataflow_park", &gphip_ctx::dataflow_park}, {"fuse_potrf", &gphip_ctx::fuse_potrf}, {"bcast_chunks", &gphip_ctx::bcast_chunks}, {"bcast_two_hop", &gphip_ctx::bcast_two_hop}, {"dist_panel_df", &gphip_ctx::dist_panel_df}, {"panel_df", &gphip_ctx::panel_df}, {"df_panel_one_wg_tasks", &gphip_ctx::df_panel_one_wg_tasks}, {"dist_df_occ3_tasks", &gphip_ctx::dist_df_occ3_tasks}, {"dataflow_occ3", &gphip_ctx::dataflow_occ3}, {"panel_rows", &gphip_ctx::panel_rows}, {"df_split", &gphip_ctx::df_split}, {"df_split_lds_kib", &gphip_ctx::df_split_lds_kib}, {"df_split_min_tasks", &gphip_ctx::df_split_min_tasks}, {"rest_mask", &gphip_ctx::rest_mask}, {"rest_mask_max_nt", &gphip_ctx::rest_mask_max_nt}, {"df_split_auto", &gphip_ctx::df_split_auto}, {"df_split_width", &gphip_ctx::df_split_width},
         {"max_slots", &gphip_ctx::max_slots}, {"shard_min_n", &gphip_ctx::shard_min_n},
         {"thin_tiles", &gphip_ctx::thin_tiles}, {"panel_wide", &gphip_ctx::panel_wide},
         {"la_main", &gphip_ctx::la_main}, {"rest_split", &gphip_ctx::rest_split},
         {"debug_fail_alloc", &gphip_ctx::debug_fail_alloc}, {"debug_fail_hip", &gphip_ctx::debug_fail_hip}, {"replicate_factor", &gphip_ctx::replicate_factor},
         {"share_local_panels", &gphip_ctx::share_local_panels},
+        {"kbuild_mfma", &gphip_ctx::kbuild_mfma}, {"kbuild_mfma_bound", &gphip_ctx::kbuild_mfma_bound},
     };
     for (const Entry& e : table)
         if (!strcmp(name, e.name)) return &(h->*(e.field));

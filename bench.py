@@ -238,9 +238,11 @@ def live_pmc_traffic(n: int, d: int, device: int, kernel_substr: str = "gemm_nt_
             "launches": got["FETCH_SIZE"][1], "seconds": round(time.perf_counter() - t0, 1)}
 
 
-def live_kbuild_clock(n: int, d: int, device: int, kernel_substr: str = "kbuild_kernel<double"):
-    """What the kernel build's HBM fraction depends on besides the code: the SHADER CLOCK it runs at.  The build is co-limited
-    by fp64 VALU issue and the HBM store rate (profiles/r03_kbuild_pmc.md), so its time moves with the clock the box sustains.
+def live_kbuild_clock(n: int, d: int, device: int, kernel_substr: str = "kbuild_mfma_kernel<double"):
+    """What the kernel build's HBM fraction depends on besides the code: the SHADER CLOCK it runs at.  Up to round 4 the build
+    was co-limited by fp64 VALU issue and the HBM store rate (profiles/r03_kbuild_pmc.md), so its time moved with the clock the
+    box sustains; since round 5 the distance loop runs on the matrix pipe (kbuild_mfma_kernel) and the VALU share is what this
+    probe shows.
     One more PMC pass of the probe: SQ_BUSY_CYCLES (summed over the 32 shader engines) / 32 / launch duration = shader
     clock; SQ_INSTS_VALU x 4 cycles (fp64: 16 lanes per SIMD per clock) / (1024 SIMDs x cycles) = fp64-VALU-busy fraction.
     The probe's first build launch is the process's first large kernel ("cold": clocks still high after idle), the second
@@ -367,7 +369,7 @@ def other_configs(local_rank: int) -> dict:
             "finite": bool(np.all(np.isfinite(mu)) and np.all(var > 0)),
             "roofline_syrk_f32": _roof(prof["syrk_trailing"], FP32_MFMA_PEAK_TFLOPS, "TFLOP/s",
                                        "gemm_nt_kernel<float, 0, 2, 2, 2> (trailing SYRK, v_mfma_f32_16x16x4_f32)"),
-            "roofline_kbuild_f32": _roof(prof["kbuild"], HBM_PEAK_GBS, "GB/s", "kbuild_kernel<float, 16, 1> (Matern-5/2, d=16)"),
+            "roofline_kbuild_f32": _roof(prof["kbuild"], HBM_PEAK_GBS, "GB/s", "kbuild_mfma_kernel<float, 4, 1> (Matern-5/2, d=16; cross term of the squared distances on v_mfma_f32_16x16x4_f32)"),
             "roofline_predict_epilogue_f32": _roof(prof["predict_epilogue"], HBM_PEAK_GBS, "GB/s",
                                                    "predict_partial_kernel<float> + predict_finish_kernel (V streamed once)")}
         h.close()
@@ -532,7 +534,7 @@ def main() -> None:
             "cholesky_frac_of_fp64_mfma_peak": chol_flops * args.steps / dt / 1e12 / (world if sharded else 1) / FP64_MFMA_PEAK_TFLOPS,
             # second target of north_star: >= 60 % of the HBM roofline on the kernel-matrix build, measured in THIS run
             "roofline_kbuild": _roof(prof["kbuild"], HBM_PEAK_GBS, "GB/s",
-                                     "kbuild_kernel<double, 8, 0> (SE-ARD d=8; bytes = 8 [N(N+1)/2 + N d])"),
+                                     "kbuild_mfma_kernel<double, 2, 0> (SE-ARD d=8, cross term of the squared distances on v_mfma_f64_16x16x4_f64; bytes = 8 [N(N+1)/2 + N d])"),
         }
         out["roofline"]["note"] = ("timed inside the evaluation, where the SYRK shares the chip with the look-ahead stream; "
                                    "roofline_syrk_alone = the same kernel, one extra evaluation with look-ahead off")

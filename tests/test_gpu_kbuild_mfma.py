@@ -1,0 +1,159 @@
+"""The kernel-matrix build with the cross term of the squared distances on the matrix pipe (kbuild_mfma_kernel, option
+kbuild_mfma: 0 never / 1 by the host's accuracy bound / 2 always) against the oracle's K (BGP:29-43) and k* (BGP:100-109)
+and against the direct form (kbuild_kernel): entries, the per-slot routing of a batch, the sentinel verdict, fp32."""
+import numpy as np
+import pytest
+
+from bayesianinference_amd import _lib, synthetic as syn
+from oracle import gp_oracle as orc
+
+pytestmark = pytest.mark.gpu
+EPS = 2.220446049250313e-16
+
+
+def _theta(kernel, d, scale):
+    th = syn.default_theta(kernel, d)
+    nl = d if kernel.endswith("_ard") else 1
+    th[:nl] *= scale
+    return th, nl
+
+
+@pytest.mark.parametrize("kernel,d,n,scale", [("se_ard", 8, 300, 1.0), ("se_ard", 8, 300, 0.2), ("matern52_ard", 5, 257, 0.5),
+                                              ("se", 1, 200, 1.0), ("se_ard", 13, 140, 1.0), ("matern52", 2, 128, 1.0),
+                                              ("se_ard", 27, 150, 3.0)])
+def test_entries_match_oracle_off_centre_inputs(kernel, d, n, scale):
+    """Inputs away from the origin (x in [4, 6)^d): without the centring the norms would be ~25 d / l^2 instead of <= d / l^2
+    and the bound below would not hold.  Mode 1 must hold the 1e-12 entry bar of test_covariance_matches_oracle; mode 2 (forced) the bound
+    4 eps sum (half_k / l_k)^2 the host's verdict rests on."""
+    X, y = syn.make_dataset(n, d)
+    X = X + 5.0
+    th, nl = _theta(kernel, d, scale)
+    Ko = orc.covariance_matrix(kernel, th, X)
+    Xs = syn.make_test_points(150, d) + 5.0
+    ko = orc.k_and_kappa(kernel, th, X, Xs)[0]
+    h = _lib.Handle(X, y, kernel)
+    bound = float(np.sum((np.ptp(X, axis=0) / 2 / th[:nl]) ** 2)) if nl == d else float(np.sum((np.ptp(X, axis=0) / 2) ** 2) / th[0] ** 2)
+    got = {}
+    for mode in (0, 1, 2):
+        h.set_option("kbuild_mfma", mode)
+        K = h.covariance(th)
+        k, kappa = h.cross_covariance(th, Xs)
+        got[mode] = (K, k)
+        tol = 1e-12 if mode < 2 else max(1e-12, 8 * EPS * bound)
+        np.testing.assert_allclose(K, Ko, rtol=tol, atol=1e-300, err_msg=f"mode {mode}")
+        np.testing.assert_allclose(k, ko, rtol=tol, atol=1e-300, err_msg=f"cross, mode {mode}")
+        assert np.array_equal(K, K.T)
+    if bound <= 512:
+        assert not np.array_equal(got[0][0], got[1][0])        # (mode 1 really took the other kernel)
+        assert np.array_equal(got[1][0], got[2][0])
+    h.close()
+
+
+def test_bound_sends_short_length_scales_to_the_direct_kernel():
+    X, y = syn.make_dataset(300, 4)
+    h = _lib.Handle(X, y, "se_ard")
+    th, nl = _theta("se_ard", 4, 0.02)                           # sum (1 / 0.02)^2 = 10 000 > 512
+    h.set_option("kbuild_mfma", 0)
+    K0 = h.covariance(th)
+    h.set_option("kbuild_mfma", 1)
+    K1 = h.covariance(th)
+    assert np.array_equal(K0, K1)
+    h.set_option("kbuild_mfma_bound", 20000)
+    K2 = h.covariance(th)
+    assert not np.array_equal(K0, K2)
+    np.testing.assert_allclose(K2, K0, rtol=1e-10, atol=1e-300)
+    h.close()
+
+
+def test_mixed_batch_routes_slots_individually():
+    n, d, B = 1100, 8, 24
+    X, y = syn.make_dataset(n, d)
+    rng = np.random.default_rng(3)
+    Th = np.tile(syn.default_theta("se_ard", d), (B, 1))
+    Th[:, :d] *= np.exp(rng.uniform(np.log(0.03), np.log(3.0), size=(B, d)))
+    under = ((1.0 / Th[:, :d]) ** 2).sum(axis=1) <= 512
+    assert 3 <= under.sum() <= B - 3
+    h = _lib.Handle(X, y, "se_ard")
+    res = {}
+    for mode in (0, 1, 2):
+        h.set_option("kbuild_mfma", mode)
+        res[mode] = h.loglik_batch(Th)
+    h.close()
+    for mode in (1, 2):
+        assert np.array_equal(res[0][1], res[mode][1])
+        np.testing.assert_allclose(res[mode][0], res[0][0], rtol=1e-10)
+    want = np.array([orc.log_likelihood("se_ard", th, X, y) for th in Th[:6]])
+    np.testing.assert_allclose(res[1][0][:6], want, rtol=1e-8)
+    # the slots above the bound were built by the direct kernel: bit-identical to the all-direct batch
+    assert np.array_equal(res[1][0][~under], res[0][0][~under])
+
+
+def test_far_test_points_fall_back_to_the_direct_cross_build():
+    X, y = syn.make_dataset(256, 3)
+    th = syn.default_theta("se_ard", 3)
+    h = _lib.Handle(X, y, "se_ard")
+    near = syn.make_test_points(130, 3)
+    far = near * 50.0
+    h.set_option("kbuild_mfma", 0)
+    k0n, _ = h.cross_covariance(th, near)
+    k0f, _ = h.cross_covariance(th, far)
+    h.set_option("kbuild_mfma", 1)
+    k1n, _ = h.cross_covariance(th, near)
+    k1f, _ = h.cross_covariance(th, far)
+    h.close()
+    assert np.array_equal(k0f, k1f)
+    assert not np.array_equal(k0n, k1n)
+    np.testing.assert_allclose(k1n, k0n, rtol=1e-12, atol=1e-300)
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_duplicated_row_stays_exactly_singular(mode):
+    """F4-style sentinel case: an exactly duplicated input and a vanishing nugget.  Rows of duplicated points are
+    bit-identical in the MFMA form too (same inputs, same operation sequence), so the verdict is the direct form's."""
+    X, y = syn.make_dataset(300, 3)
+    X[150] = X[7]
+    h = _lib.Handle(X, y, "se_ard")
+    h.set_option("kbuild_mfma", mode)
+    K = h.covariance(np.array([1.0, 1.0, 1.0, 1.0, 1e-9]))
+    assert np.array_equal(K[150, np.arange(300) != 150][np.arange(299) != 7], K[7, np.arange(300) != 7][np.arange(299) != 149])
+    for df in (0, 1):
+        h.set_option("dataflow", df)
+        ll, info = h.loglik(np.array([1.0, 1.0, 1.0, 1.0, 1e-9]))
+        assert info != 0
+        ll, info = h.loglik(np.array([1.0, 1.0, 1.0, 1.0, 1e-2]))
+        assert info == 0
+        assert abs(ll - orc.log_likelihood("se_ard", np.array([1.0, 1.0, 1.0, 1.0, 1e-2]), X, y)) <= 1e-8 * 300
+    h.close()
+
+
+@pytest.mark.parametrize("kernel,d", [("matern52_ard", 16), ("se_ard", 16), ("se_ard", 3)])
+def test_fp32_entries(kernel, d):
+    X, y = syn.make_dataset(400, d)
+    th = syn.default_theta(kernel, d, dtype="f32")
+    Ko = orc.covariance_matrix(kernel, th, X.astype(np.float32).astype(np.float64))
+    h = _lib.Handle(X, y, kernel, dtype=32)
+    for mode in (0, 1):
+        h.set_option("kbuild_mfma", mode)
+        K = h.covariance(th)
+        assert np.abs(K - Ko).max() <= (2e-6 if mode == 0 else 6e-6), mode
+    ll1, info = h.loglik(th)
+    h.set_option("kbuild_mfma", 0)
+    ll0, info0 = h.loglik(th)
+    h.close()
+    assert info == 0 and info0 == 0 and abs(ll1 - ll0) <= 1e-4 * abs(ll0)
+
+
+@pytest.mark.parametrize("n,opts", [(3000, {}), (3000, {"dataflow": 0}), (9000, {})])
+def test_loglik_multi_tile_sizes(n, opts):
+    d = 8
+    X, y = syn.make_dataset(n, d)
+    th = syn.default_theta("se_ard", d)
+    want = orc.log_likelihood("se_ard", th, X, y)
+    h = _lib.Handle(X, y, "se_ard")
+    for k, v in opts.items():
+        h.set_option(k, v)
+    for mode in (2, 0):
+        h.set_option("kbuild_mfma", mode)
+        ll, info = h.loglik(th)
+        assert info == 0 and abs(ll - want) <= 1e-9 * abs(want), (mode, ll, want)
+    h.close()
