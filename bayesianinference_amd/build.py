@@ -13,7 +13,7 @@ import sys
 PKG = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(PKG, "csrc", "gphip.hip")
 DEPS = [SRC, os.path.join(PKG, "csrc", "gp_kernels.h"), os.path.join(PKG, "csrc", "gphip_multi.inc"),
-        os.path.join(PKG, "csrc", "gphip_sampler.inc"),
+        os.path.join(PKG, "csrc", "gphip_sampler.inc"), os.path.join(PKG, "csrc", "rtc_dyn.h"),
         os.path.join(PKG, "csrc", "rccl_dyn.h"), os.path.join(os.path.dirname(PKG), "include", "gphip.h")]
 LIB = os.path.join(PKG, "lib", "libgphip.so")
 
@@ -47,7 +47,8 @@ def build(force: bool = False, verbose: bool = False, out: str | None = None) ->
     target = out or LIB
     os.makedirs(os.path.dirname(target), exist_ok=True)
     cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-Wall", "-Wno-unused-function", "-o", target, SRC, "-ldl", "-lpthread"]
+           "-Wall", "-Wno-unused-function", "-I" + os.path.join(PKG, "csrc"),      # (-I: rtc_dyn.h embeds gp_kernels.h with .incbin)
+           "-o", target, SRC, "-ldl", "-lpthread"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     res = subprocess.run(cmd, capture_output=True, text=True)
@@ -67,7 +68,7 @@ def build_wl_stub(force: bool = False, verbose: bool = False) -> str:
     the tests-only stand-in tests/wl_stub/WolframLibrary.h, together with the fake WolframLibraryData driver, linked
     to the in-tree libgphip.so.  (A production build uses the real header of a Wolfram installation, INTEGRATION.md.)"""
     srcs = [WL_SHIM, os.path.join(WL_STUB_DIR, "shim_driver.cpp")]
-    deps = srcs + [os.path.join(WL_STUB_DIR, "WolframLibrary.h"), os.path.join(ROOT, "include", "gphip.h"), LIB]
+    deps = srcs + [os.path.join(WL_STUB_DIR, "WolframLibrary.h"), os.path.join(ROOT, "include", "gphip.h"), LIB]   # (srcs[0] = librarylink_shim.cpp)
     if not force and os.path.exists(WL_STUB_LIB) and all(os.path.getmtime(p) <= os.path.getmtime(WL_STUB_LIB) for p in deps):
         return WL_STUB_LIB
     cxx = shutil.which("g++") or shutil.which("c++")

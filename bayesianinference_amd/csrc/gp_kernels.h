@@ -710,34 +710,43 @@ template <typename T, int KS> __host__ __device__ constexpr size_t kbuild_mfma_l
 }
 template <typename T, int KT> struct KmScale;
 template <> struct KmScale<double, 0> { static constexpr double v = EXP_COORD_SCALE_SE; };       // u = table units of exp(-r2 / 2)
-template <> struct KmScale<double, 1> { static constexpr double v = 2.2360679774997896; };        // u = 5 r2
+template <> struct KmScale<double, 1> { static constexpr double v = 2.2360679774997896 * EXP_U_PER_ARG; };   // u = (sqrt(5) r 512 / ln2)^2: sqrt(u) in table units
 template <> struct KmScale<float, 0> { static constexpr double v = 0.84932180028801904; };        // u = r2 log2(e) / 2
 template <> struct KmScale<float, 1> { static constexpr double v = 2.2360679774997896; };
 
 // the entry from its accumulator u >= 0 (cancellation may leave u a few ulp of the norms below zero: clamped)
+// sf2 2^(-w / 512) for w >= 0 in table units (exp_tab_u without its upper clamp: the host's bound on the norms keeps w far
+// inside the int range; w = -1e-10 gives t = MAGIC, k = 0, r = -w and the factor 1 + 1e-13 -- harmless)
+__device__ __forceinline__ double km_exp_u(double w, const double* __restrict__ tab) {
+    constexpr double MAGIC = 6755399441055744.0;             // 1.5 * 2^52
+    constexpr double C1 = 1.3538030870311431e-03;            // ln2 / 512
+    constexpr double C2 = 9.163913992275265e-07;             // C1^2 / 2
+    constexpr double C3 = 4.1353783506767136e-10;            // C1^3 / 6
+    constexpr double C4 = 1.399621994296973e-13;             // C1^4 / 24
+    const double t = MAGIC - w;
+    const double kd = t - MAGIC;
+    const double r = -kd - w;
+    double p = __builtin_fma(C4, r, C3);
+    p = __builtin_fma(p, r, C2);
+    p = __builtin_fma(p, r, C1);
+    p = __builtin_fma(p, r, 1.0);
+    const int ki = __double2loint(t);
+    return __builtin_ldexp(tab[ki & (EXP_TAB - 1)] * p, ki >> 9);
+}
 template <int KT>
 __device__ __forceinline__ double km_value(double u, double, const double* __restrict__ tab) {
     if (KT == 0) {
-        // (no clamp: u = -1e-10 table units gives t = MAGIC, k = 0, r = -u and the entry sf2 (1 + 1e-13) -- harmless, and
-        //  two fp64 instructions per entry saved)
-        constexpr double MAGIC = 6755399441055744.0;             // 1.5 * 2^52 (exp_tab_u without its upper clamp: the host's
-        constexpr double C1 = 1.3538030870311431e-03;            // bound on the norms keeps u far inside the int range)
-        constexpr double C2 = 9.163913992275265e-07;
-        constexpr double C3 = 4.1353783506767136e-10;
-        constexpr double C4 = 1.399621994296973e-13;
-        const double t = MAGIC - u;
-        const double kd = t - MAGIC;
-        const double r = -kd - u;
-        double p = __builtin_fma(C4, r, C3);
-        p = __builtin_fma(p, r, C2);
-        p = __builtin_fma(p, r, C1);
-        p = __builtin_fma(p, r, 1.0);
-        const int ki = __double2loint(t);
-        return __builtin_ldexp(tab[ki & (EXP_TAB - 1)] * p, ki >> 9);
+        return km_exp_u(u, tab);                                  // (no clamp of u: two fp64 instructions per entry saved)
     } else {
-        asm("v_max_f64 %0, %1, 0" : "=v"(u) : "v"(u));            // (fmax() costs a canonicalising second v_max_f64)
-        const double sa = __builtin_sqrt(u);
-        return (1.0 + sa + (1.0 / 3.0) * u) * exp_tab<false>(sa, tab);
+        // Matern-5/2 with s5 = sqrt(5) r in table units: w = sqrt(u) by the hardware's reciprocal square root seed and one
+        // Newton step (relative error ~4e-15; the IEEE sqrt expansion was 15 instructions), s5 = w ln2 / 512
+        asm("v_max_f64 %0, %1, %2" : "=v"(u) : "v"(u), "v"(1.0e-200));   // (fmax() costs a canonicalising second v_max_f64)
+        const double y = __builtin_amdgcn_rsq(u);
+        const double e = __builtin_fma(-u * y, y, 1.0);
+        const double w = u * __builtin_fma(0.5 * y, e, y);
+        constexpr double A1 = 1.3538030870311431e-03;            // s5 = A1 w
+        constexpr double A2 = 6.109275994850177e-07;             // s5^2 / 3 = A2 u
+        return __builtin_fma(A2, u, __builtin_fma(A1, w, 1.0)) * km_exp_u(w, tab);
     }
 }
 template <int KT>

@@ -2120,16 +2120,16 @@ static int create_ctx(const void* X, const void* y, int64_t N, int64_t d, int ke
         if (hipGetDeviceProperties(&prop, h->device) != hipSuccess) return bail(GPHIP_ERR_HIP);
         std::string arch = prop.gcnArchName;                   // "gfx950:sramecc+:xnack-" -> "gfx950"
         arch = arch.substr(0, arch.find(':'));
-        RtcResult r;
         std::string msg;
-        if (!rtc_compile_custom(custom_body, dtype, arch.c_str(), r, msg)) {
+        const std::shared_ptr<const RtcResult> r = rtc_compile_custom(custom_body, dtype, arch.c_str(), msg);
+        if (!r) {
             if (why) *why = msg;
             return bail(rtc().ok() ? GPHIP_ERR_ARG : GPHIP_ERR_UNSUPPORTED);
         }
-        if (hipModuleLoadData(&h->cmod, r.code.data()) != hipSuccess ||
-            hipModuleGetFunction(&h->f_cbuild, h->cmod, r.build.c_str()) != hipSuccess ||
-            hipModuleGetFunction(&h->f_cdiag, h->cmod, r.diag.c_str()) != hipSuccess ||
-            hipModuleGetFunction(&h->f_cprep, h->cmod, r.prep.c_str()) != hipSuccess) {
+        if (hipModuleLoadData(&h->cmod, r->code.data()) != hipSuccess ||
+            hipModuleGetFunction(&h->f_cbuild, h->cmod, r->build.c_str()) != hipSuccess ||
+            hipModuleGetFunction(&h->f_cdiag, h->cmod, r->diag.c_str()) != hipSuccess ||
+            hipModuleGetFunction(&h->f_cprep, h->cmod, r->prep.c_str()) != hipSuccess) {
             if (why) *why = "loading the compiled covariance function failed";
             return bail(GPHIP_ERR_HIP);
         }
@@ -2141,6 +2141,23 @@ static int create_ctx(const void* X, const void* y, int64_t N, int64_t d, int ke
 
 /* why the last gphip_create_custom* of this thread failed (compiler log of the covariance function, ..) */
 const char* gphip_create_error(void) { return g_create_error.c_str(); }
+
+/* Compiles a covariance function exactly as gphip_create_custom would, without a handle and without a device (hiprtc
+ * cross-compiles): a caller can validate user input early, a deployment can check that the library found hiprtc and carries
+ * its kernel text, and the code object lands in the per-process cache the next gphip_create_custom of the same function hits. */
+int gphip_custom_compile(const char* body, int dtype, const char* arch, int* cache_hit) {
+    g_create_error.clear();
+    if (!body || !*body || (dtype != 64 && dtype != 32)) { g_create_error = "null / empty function body or bad dtype"; return GPHIP_ERR_ARG; }
+    bool hit = false;
+    std::string msg;
+    const std::shared_ptr<const RtcResult> r = rtc_compile_custom(body, dtype, (arch && *arch) ? arch : "gfx950", msg, &hit);
+    if (cache_hit) *cache_hit = hit ? 1 : 0;
+    if (!r) {
+        g_create_error = msg;
+        return rtc().ok() ? GPHIP_ERR_ARG : GPHIP_ERR_UNSUPPORTED;
+    }
+    return GPHIP_OK;
+}
 
 static int group_create(const void* X, const void* y, int64_t N, int64_t d, int kernel_id, int mean_id, int dtype,
                         const int* devices, const int* ranks, int nlocal, int world, const void* id128, gphip_handle* out);

@@ -1,8 +1,11 @@
 // rtc_dyn.h -- hiprtc bound at run time (dlopen), for handles whose covariance function arrives as source text
 // (gphip_create_custom).  The reference evaluates ANY `kernel @@ points[[{i,j}]]` (BGP:29-33); the named kernels of this
-// library are compiled offline, everything else is compiled here, once per handle, into the SAME kernel build: the
-// [rtc-begin] .. [rtc-end] region of gp_kernels.h is read back from the source tree next to the library
-// (<lib dir>/../csrc/gp_kernels.h, or $GPHIP_SRC_DIR), prefixed with GP_CUSTOM_KERNEL and followed by the caller's function.
+// library are compiled offline, everything else is compiled here into the SAME kernel build: the text of gp_kernels.h is
+// EMBEDDED in the library at build time (.incbin below -- a libgphip.so copied anywhere can create such handles, and the text
+// can never describe other structs than the ones the library was compiled with), its [rtc-begin] .. [rtc-end] region is
+// prefixed with GP_CUSTOM_KERNEL and followed by the caller's function.  $GPHIP_SRC_DIR (a directory holding a gp_kernels.h)
+// overrides the embedded text for development; it must carry the library's GP_RTC_ABI.  Code objects are cached per process
+// by (function text, type, architecture): a second handle with the same function costs a hash lookup, not a compilation.
 // libgphip.so carries no link-time dependency on hiprtc; a process that never creates such a handle never loads it.
 #pragma once
 #include <dlfcn.h>
@@ -12,10 +15,24 @@
 
 #include <cstdlib>
 #include <fstream>
+#include <map>
+#include <memory>
 #include <mutex>
 #include <sstream>
 #include <string>
 #include <vector>
+
+// the text of gp_kernels.h, as compiled (the build passes -I <csrc>; host pass only)
+#if !defined(__HIP_DEVICE_COMPILE__)
+__asm__(".pushsection .rodata\n"
+        ".hidden gphip_rtc_embedded_src\n"
+        ".global gphip_rtc_embedded_src\n"
+        "gphip_rtc_embedded_src:\n"
+        ".incbin \"gp_kernels.h\"\n"
+        ".byte 0\n"
+        ".popsection\n");
+#endif
+extern "C" const char gphip_rtc_embedded_src[];
 
 namespace gphip {
 
@@ -68,39 +85,30 @@ inline const RtcApi& rtc() {
     return api;
 }
 
-// the [rtc-begin] .. [rtc-end] region of gp_kernels.h, from the source tree the library was built from
+// the [rtc-begin] .. [rtc-end] region of gp_kernels.h: the embedded text, or $GPHIP_SRC_DIR/gp_kernels.h (developer override)
 inline bool rtc_kernel_source(std::string& region, std::string& why) {
-    std::vector<std::string> dirs;
-    if (const char* env = getenv("GPHIP_SRC_DIR")) dirs.push_back(env);
-    Dl_info info;
-    if (dladdr(reinterpret_cast<const void*>(&rtc_kernel_source), &info) && info.dli_fname) {
-        std::string lib = info.dli_fname;
-        const size_t slash = lib.rfind('/');
-        const std::string dir = slash == std::string::npos ? "." : lib.substr(0, slash);
-        dirs.push_back(dir + "/../csrc");
-        dirs.push_back(dir);
-    }
-    for (const std::string& d : dirs) {
-        std::ifstream f(d + "/gp_kernels.h");
-        if (!f) continue;
+    std::string text, where = "the text embedded in the library";
+    if (const char* env = getenv("GPHIP_SRC_DIR")) {
+        where = std::string(env) + "/gp_kernels.h";
+        std::ifstream f(where);
+        if (!f) { why = where + " (GPHIP_SRC_DIR) cannot be read"; return false; }
         std::stringstream ss;
         ss << f.rdbuf();
-        const std::string text = ss.str();
-        const size_t b = text.find("// [rtc-begin]"), e = text.find("// [rtc-end]");
-        if (b == std::string::npos || e == std::string::npos || e < b) continue;
-        region = text.substr(b, e - b);
-        // the text must describe the same structs the library was compiled with
-        const std::string tag = "#define GP_RTC_ABI ";
-        const size_t t = region.find(tag);
-        if (t == std::string::npos || atoi(region.c_str() + t + tag.size()) != GP_RTC_ABI) {
-            why = d + "/gp_kernels.h does not match this build of the library (GP_RTC_ABI differs): rebuild, or point GPHIP_SRC_DIR at the matching sources";
-            return false;
-        }
-        return true;
+        text = ss.str();
+    } else {
+        text = gphip_rtc_embedded_src;
     }
-    if (why.empty())
-        why = "gp_kernels.h (with its [rtc-begin] / [rtc-end] region) not found next to the library; set GPHIP_SRC_DIR to the csrc directory";
-    return false;
+    const size_t b = text.find("// [rtc-begin]"), e = text.find("// [rtc-end]");
+    if (b == std::string::npos || e == std::string::npos || e < b) { why = where + " has no [rtc-begin] / [rtc-end] region"; return false; }
+    region = text.substr(b, e - b);
+    // the text must describe the same structs the library was compiled with
+    const std::string tag = "#define GP_RTC_ABI ";
+    const size_t t = region.find(tag);
+    if (t == std::string::npos || atoi(region.c_str() + t + tag.size()) != GP_RTC_ABI) {
+        why = where + " does not match this build of the library (GP_RTC_ABI differs): rebuild, or unset GPHIP_SRC_DIR";
+        return false;
+    }
+    return true;
 }
 
 struct RtcResult {
@@ -110,7 +118,7 @@ struct RtcResult {
 
 // body: the statements of   template <typename T> T k(X, Y, P, D)   -- X(k) / Y(k) coordinate k of the two points, P(k)
 // hyper-parameter k, D the input dimension, T the handle's arithmetic type; must `return` the covariance.
-inline bool rtc_compile_custom(const std::string& body, int dtype, const char* arch, RtcResult& out, std::string& why) {
+inline bool rtc_compile_uncached(const std::string& body, int dtype, const char* arch, RtcResult& out, std::string& why) {
     const RtcApi& api = rtc();
     if (!api.ok()) { why = "hiprtc could not be loaded (libhiprtc.so; set GPHIP_HIPRTC_PATH)"; return false; }
     std::string region;
@@ -177,6 +185,23 @@ inline bool rtc_compile_custom(const std::string& body, int dtype, const char* a
     api.DestroyProgram(&prog);
     if (!ok) why = "hiprtc produced no code object";
     return ok;
+}
+
+// per-process cache of code objects, keyed by everything the compilation depends on (the kernel text is fixed per process)
+inline std::shared_ptr<const RtcResult> rtc_compile_custom(const std::string& body, int dtype, const char* arch, std::string& why,
+                                                            bool* cache_hit = nullptr) {
+    static std::mutex mu;
+    static std::map<std::string, std::shared_ptr<const RtcResult>> cache;
+    const char* dev = getenv("GPHIP_SRC_DIR");
+    const std::string key = std::string(arch) + "|" + std::to_string(dtype) + "|" + (dev ? dev : "") + "|" + body;
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = cache.find(key);
+    if (cache_hit) *cache_hit = it != cache.end();
+    if (it != cache.end()) return it->second;
+    auto r = std::make_shared<RtcResult>();
+    if (!rtc_compile_uncached(body, dtype, arch, *r, why)) return nullptr;
+    cache.emplace(key, r);
+    return r;
 }
 
 }  // namespace gphip

@@ -86,7 +86,7 @@ typedef struct gphip_ctx* gphip_handle;
  * ~1e-7 relative) instead of the analytic gradient.  Replaces the reference's
  * `kernel @@ points[[{i,j}]]` for an arbitrary pure function (BGP:29-33, cross form BGP:100-109).
  * Errors: GPHIP_ERR_ARG = the body does not compile (gphip_create_error() returns the compiler's log),
- * GPHIP_ERR_UNSUPPORTED = no hiprtc / the library's kernel source is not next to it (see csrc/rtc_dyn.h). */
+ * GPHIP_ERR_UNSUPPORTED = no hiprtc (see csrc/rtc_dyn.h; $GPHIP_HIPRTC_PATH names the library explicitly). */
 #define GPHIP_KERNEL_CUSTOM 100
 int gphip_create_custom(const void* X, const void* y, int64_t N, int64_t d, const char* body, int nparams, int mean_id,
                         int dtype, int device /* < 0: current */, gphip_handle* out);
@@ -97,6 +97,12 @@ int gphip_create_custom_devices(const void* X, const void* y, int64_t N, int64_t
 int gphip_create_custom_rank(const void* X, const void* y, int64_t N, int64_t d, const char* body, int nparams, int mean_id,
                              int dtype, int device, int rank, int world, const void* id128, gphip_handle* out);
 const char* gphip_create_error(void);
+/* Compile `body` exactly as gphip_create_custom would -- no handle, no device needed (hiprtc cross-compiles for `arch`, null =
+ * "gfx950").  Validates user input early; proves that a deployed libgphip.so finds hiprtc and carries its own kernel text (the
+ * text of csrc/gp_kernels.h is embedded in the library at build time; $GPHIP_SRC_DIR overrides it for development); and warms
+ * the per-process code-object cache (key: body, dtype, arch) that later gphip_create_custom* calls hit.  *cache_hit = 1 when
+ * the code object was already there.  Errors as gphip_create_custom (gphip_create_error() = the compiler's log). */
+int gphip_custom_compile(const char* body, int dtype, const char* arch, int* cache_hit);
 #define GPHIP_MEAN_ZERO 0            /* Function[0]  (BGP:168,255)                                    */
 #define GPHIP_MEAN_CONST 1           /* Function[mu], mu = last entry of theta                        */
 

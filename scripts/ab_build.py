@@ -12,7 +12,7 @@ def one(spec):
     src = SRC
     if flags.startswith("src="):
         src, flags = flags[4:], ""
-    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o",
+    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-I" + os.path.dirname(SRC), "-o",
            os.path.join(OUT, f"libgphip_{name}.so"), src, "-ldl", "-lpthread"] + [f for f in flags.split(",") if f]
     r = subprocess.run(cmd, capture_output=True, text=True)
     return name, r.returncode, r.stderr[-500:]

@@ -4,7 +4,7 @@ import os, re, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "bayesianinference_amd", "csrc", "gphip.hip")
 with tempfile.TemporaryDirectory() as td:
-    res = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+    res = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-I" + os.path.join(ROOT, "bayesianinference_amd", "csrc"),
                           "-Rpass-analysis=kernel-resource-usage", "-o", os.path.join(td, "x.so"), src, "-ldl", "-lpthread"],
                          capture_output=True, text=True)
 txt = res.stderr

@@ -1,9 +1,10 @@
 """Covariance functions given as source text (gphip_create_custom): what can be checked WITHOUT a GPU.
 (1) The oracle's function-valued kernel path against its own named kernels (so that the GPU parity tests of
     tests/test_gpu_custom_kernel.py compare against something pinned).
-(2) The [rtc-begin] .. [rtc-end] region of csrc/gp_kernels.h -- the text the library compiles at run time around the caller's
-    function -- still compiles on its own under hiprtc for gfx950, in both arithmetic types, with loop-style and CForm-style
-    bodies; and a broken body is reported with the compiler's log.  hiprtc needs no GPU."""
+(2) The [rtc-begin] .. [rtc-end] region of csrc/gp_kernels.h -- the text the library embeds and compiles at run time around
+    the caller's function -- compiles under hiprtc for gfx950 through the library's own compile step (gphip_custom_compile), in
+    both arithmetic types, with loop-style and CForm-style bodies; a broken body is reported with the compiler's log; the
+    library alone (no source tree) is enough, and the code-object cache works.  hiprtc needs no GPU."""
 import ctypes as C
 import os
 
@@ -50,46 +51,24 @@ def _hiprtc():
     return None
 
 
-def _compile(rtc, body, ty):
-    src = open(os.path.join(ROOT, "bayesianinference_amd", "csrc", "gp_kernels.h")).read()
-    region = src[src.index("// [rtc-begin]"):src.index("// [rtc-end]")]
-    full = ("#define GP_CUSTOM_KERNEL 1\n" + region + "\nnamespace gphip {\n"
-            "template <typename A, typename B> __device__ auto Power(A a, B b) -> decltype(a * 1.0f) { return pow(a, (decltype(a * 1.0f))b); }\n"
-            "template <typename A> __device__ A Exp(A a) { return exp(a); }\n"
-            "template <typename T> __device__ T gphip_custom_k(PointRef<T> X, PointRef<T> Y, const double* __restrict__ Pp, int D) {\n"
-            "#define P(k) ((T)Pp[(k)])\n" + body + "\n#undef P\n}\n}\n")
-    prog = C.c_void_p()
-    assert rtc.hiprtcCreateProgram(C.byref(prog), full.encode(), b"t.hip", 0, None, None) == 0
-    names = [f"gphip::kbuild_kernel<{ty}, 0, 3>".encode(), f"gphip::custom_diag_kernel<{ty}>".encode(),
-             f"gphip::custom_prep_kernel<{ty}>".encode()]
-    for n in names:
-        rtc.hiprtcAddNameExpression(prog, n)
-    opts = (C.c_char_p * 3)(b"--offload-arch=gfx950", b"-O3", b"-std=c++17")
-    rc = rtc.hiprtcCompileProgram(prog, 3, opts)
-    n = C.c_size_t()
-    rtc.hiprtcGetProgramLogSize(prog, C.byref(n))
-    log = C.create_string_buffer(max(n.value, 1))
-    rtc.hiprtcGetProgramLog(prog, log)
-    size = C.c_size_t(0)
-    if rc == 0:
-        rtc.hiprtcGetCodeSize(prog, C.byref(size))
-        for nm in names:
-            low = C.c_char_p()
-            assert rtc.hiprtcGetLoweredName(prog, nm, C.byref(low)) == 0 and low.value
-    rtc.hiprtcDestroyProgram(C.byref(prog))
-    return rc, log.value.decode(errors="replace"), size.value
+def _compile(body, dtype):
+    """through the library's own compile step (its prelude, its embedded kernel text)"""
+    lib = _lib.load()
+    hit = C.c_int(0)
+    rc = lib.gphip_custom_compile(body.encode(), dtype, b"gfx950", C.byref(hit))
+    return rc, (lib.gphip_create_error() or b"").decode(errors="replace")
 
 
-@pytest.mark.parametrize("ty", ["double", "float"])
-def test_kernel_build_region_compiles_on_its_own_under_hiprtc(ty):
-    rtc = _hiprtc()
-    if rtc is None:
+@pytest.mark.parametrize("dtype", [64, 32])
+def test_kernel_build_region_compiles_under_hiprtc(dtype):
+    if _hiprtc() is None:
         pytest.skip("no libhiprtc.so on this machine")
-    for body in (SE_ARD_BODY, "return Power(P(1),2)*Exp(-0.5*Power((X(0)-Y(0))/P(0),2));"):
-        rc, log, size = _compile(rtc, body, ty)
-        assert rc == 0 and size > 1000, log
-    rc, log, _ = _compile(rtc, "return P(0) * undeclared_symbol;", ty)
-    assert rc != 0 and "undeclared_symbol" in log
+    for body in (SE_ARD_BODY, "return Power(P(1),2)*Exp(-0.5*Power((X(0)-Y(0))/P(0),2));",
+                 "return Min(P(0), 2) * Cos(Pi * Abs(X(0) - Y(0))) + Max(0, Tanh(X(1) * Y(1))) + Erf(P(1)) * Sqrt(1 + Power(X(0) - Y(0), 2));"):
+        rc, log = _compile(body, dtype)
+        assert rc == 0, log
+    rc, log = _compile("return P(0) * undeclared_symbol;", dtype)
+    assert rc == 1 and "undeclared_symbol" in log
 
 
 def test_rtc_region_has_no_host_only_dependencies():
@@ -97,3 +76,47 @@ def test_rtc_region_has_no_host_only_dependencies():
     region = src[src.index("// [rtc-begin]"):src.index("// [rtc-end]")]
     body = "\n".join(ln for ln in region.splitlines() if not ln.lstrip().startswith("//"))
     assert "#include" not in body and "std::" not in body
+
+
+def test_library_alone_compiles_custom_functions_and_caches_them(tmp_path):
+    """Deployment: a libgphip.so copied WITHOUT its source tree still compiles a covariance function (the kernel text is
+    embedded at build time), through the library's own prelude (gphip_custom_compile = the compile step of
+    gphip_create_custom; hiprtc needs no GPU); the second request for the same function is a cache hit in < 5 ms; a broken
+    body comes back with the compiler's log; GPHIP_SRC_DIR pointing at a tree with another GP_RTC_ABI is refused."""
+    import shutil
+    import subprocess
+    import sys
+    import textwrap
+    if _hiprtc() is None:
+        pytest.skip("no libhiprtc.so on this machine")
+    lib = tmp_path / "elsewhere" / "libgphip.so"
+    lib.parent.mkdir()
+    shutil.copy(_lib.LIB_PATH, lib)
+    code = textwrap.dedent(f"""
+        import ctypes as C, time, os
+        L = C.CDLL({str(lib)!r})
+        L.gphip_custom_compile.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.POINTER(C.c_int)]
+        L.gphip_create_error.restype = C.c_char_p
+        body = {SE_ARD_BODY!r}.encode()
+        hit = C.c_int(-1)
+        t0 = time.perf_counter(); rc = L.gphip_custom_compile(body, 64, None, C.byref(hit)); t1 = time.perf_counter()
+        assert rc == 0 and hit.value == 0, (rc, hit.value, L.gphip_create_error())
+        t2 = time.perf_counter(); rc = L.gphip_custom_compile(body, 64, b"gfx950", C.byref(hit)); t3 = time.perf_counter()
+        assert rc == 0 and hit.value == 1 and t3 - t2 < 5e-3, (rc, hit.value, t3 - t2)
+        rc = L.gphip_custom_compile(body, 32, None, C.byref(hit))
+        assert rc == 0 and hit.value == 0                           # (another arithmetic type: another code object)
+        rc = L.gphip_custom_compile(b"return P(0) * undeclared_symbol;", 64, None, C.byref(hit))
+        assert rc == 1 and b"undeclared_symbol" in L.gphip_create_error()
+        os.environ["GPHIP_SRC_DIR"] = {str(tmp_path / "stale")!r}
+        rc = L.gphip_custom_compile(body + b" ", 64, None, C.byref(hit))
+        assert rc != 0 and b"GP_RTC_ABI" in L.gphip_create_error(), L.gphip_create_error()
+        print("first compile %.2f s, cached %.2e s" % (t1 - t0, t3 - t2))
+    """)
+    stale = tmp_path / "stale"
+    stale.mkdir()
+    src = open(os.path.join(ROOT, "bayesianinference_amd", "csrc", "gp_kernels.h")).read()
+    import re
+    (stale / "gp_kernels.h").write_text(re.sub(r"#define GP_RTC_ABI \d+", "#define GP_RTC_ABI 9999", src))
+    env = {k: v for k, v in os.environ.items() if k != "GPHIP_SRC_DIR"}
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=str(tmp_path), env=env, timeout=300)
+    assert res.returncode == 0, res.stdout + res.stderr
