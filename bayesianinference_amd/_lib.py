@@ -73,7 +73,7 @@ _SIGNATURES = {
     "gphip_create_custom_rank": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                            C.c_int, C.c_int, C.c_void_p, C.POINTER(_h)]),
     "gphip_create_error": (C.c_char_p, []),
-    "gphip_custom_compile": (C.c_int, [C.c_char_p, C.c_int, C.c_char_p, _ip]),
+    "gphip_custom_compile": (C.c_int, [C.c_char_p, C.c_int, C.c_char_p, C.c_int, _ip]),
     "gphip_comm_unique_id": (C.c_int, [C.c_void_p]),
     "gphip_create_rank": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int,
                                     C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(_h)]),

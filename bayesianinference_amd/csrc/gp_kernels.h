@@ -39,7 +39,7 @@ namespace gphip {
 
 // Bumped whenever a struct or constant the run-time compiled copy of this region shares with the offline library changes
 // (KBuildArgs, SLOTP, the tile layout): rtc_dyn.h refuses a source tree whose value differs from the library's own.
-#define GP_RTC_ABI 2
+#define GP_RTC_ABI 3
 constexpr int TB = 128;         // tile edge
 // Elements between consecutive tiles of the packed workspace: 128 x 128 plus a pad.  Without the pad every tile starts on
 // a 128 KiB (fp64) boundary and the workgroups of a launch, which walk their operand tiles in lock step, all touch the
@@ -353,12 +353,13 @@ struct PointRef {
     const T* base; long stride;
     __device__ __forceinline__ T operator()(int k) const { return base[(long)k * stride]; }
 };
+// T: the arithmetic type the body computes in -- S itself for the kernel build, Dual<S, NP> (gp_dual.h) for the gradient
 #ifdef GP_CUSTOM_KERNEL
-template <typename T>
-__device__ T gphip_custom_k(PointRef<T> X, PointRef<T> Y, const double* __restrict__ Pp, int D);      // defined by the generated source
+template <typename T, typename S>
+__device__ T gphip_custom_k(PointRef<S> X, PointRef<S> Y, const double* __restrict__ Pp, int D);      // defined by the generated source
 #else
-template <typename T>
-__device__ __forceinline__ T gphip_custom_k(PointRef<T>, PointRef<T>, const double*, int) { return (T)0; }   // never instantiated offline
+template <typename T, typename S>
+__device__ __forceinline__ T gphip_custom_k(PointRef<S>, PointRef<S>, const double*, int) { return (T)0; }   // never instantiated offline
 #endif
 
 // One 128x128 tile per workgroup (4 waves).  Wave w owns 32 output columns; lane owns 2 adjacent
@@ -556,8 +557,8 @@ __global__ __launch_bounds__(256) void kbuild_kernel(KBuildArgs<T> a) {
             const PointRef<T> Yj{glb ? xjg + jj : xjs + jj, glb ? (long)a.npad_j : (long)TB};
             const PointRef<T> Xa{glb ? xig + r0 : xis + r0, glb ? (long)a.npad_i : (long)TB};
             const PointRef<T> Xb{Xa.base + 1, Xa.stride};
-            va = gphip_custom_k<T>(Xa, Yj, cp, d);
-            vb = gphip_custom_k<T>(Xb, Yj, cp, d);
+            va = gphip_custom_k<T, T>(Xa, Yj, cp, d);
+            vb = gphip_custom_k<T, T>(Xb, Yj, cp, d);
         } else if constexpr (KT == 2) {
             T ra2 = (T)0, rb2 = (T)0;
             if (two && !glb)
@@ -629,7 +630,7 @@ __global__ void custom_diag_kernel(const T* __restrict__ x, long x_bstride, int 
     const int i = blockIdx.x * blockDim.x + threadIdx.x, slot = blockIdx.y;
     if (i >= n) return;
     const PointRef<T> X{x + (long)slot * x_bstride + i, (long)npad};
-    out[(long)slot * ostride + i] = (double)gphip_custom_k<T>(X, X, cp + (long)slot * ncp, d);
+    out[(long)slot * ostride + i] = (double)gphip_custom_k<T, T>(X, X, cp + (long)slot * ncp, d);
 }
 // Per slot: the largest prior variance over the training points scales the pivot tolerance of the factorisation (the
 // named kernels know k(x, x) = sf^2 on the host; here only the device can evaluate the function).  The host left the
@@ -643,7 +644,7 @@ __global__ __launch_bounds__(256) void custom_prep_kernel(const T* __restrict__ 
     bool bad = false;
     for (int i = threadIdx.x; i < n; i += 256) {
         const PointRef<T> X{x + i, (long)npad};
-        const double v = (double)gphip_custom_k<T>(X, X, cp + (long)slot * ncp, d);
+        const double v = (double)gphip_custom_k<T, T>(X, X, cp + (long)slot * ncp, d);
         if (!(fabs(v) <= 1.0e300)) bad = true;
         m = fmax(m, fabs(v));
     }
@@ -663,6 +664,74 @@ __global__ __launch_bounds__(256) void custom_prep_kernel(const T* __restrict__ 
         sp[0] = kmax; sp[SP_KXX] = kmax;
         sp[3] = sp[3] * (kmax + sp[SP_SF2B]);
     }
+}
+#endif
+
+// arguments of the gradient reductions (grad_reduce_*_kernel below the region; custom_grad_kernel here)
+template <typename T>
+struct GradArgs {
+    const T* Kinv; long ldv;        // row block: Kinv(t, j) at Kinv[j*ldv + t], t = row c0+t of K^-1
+    const T* alpha;                 // [npad]
+    const T* xs;                    // scaled inputs [d][npad]
+    int npad, n, c0, mc, d;
+    int tri;                        // 1: Kinv holds the lower triangle only (tile rows >= tile columns): skip the
+                                    //    upper tiles and count the strictly lower ones twice (everything is symmetric)
+    const double* slotp;
+    double* gacc;                   // [d + 2]; general form: [2 d + 6], see grad_reduce_general_kernel
+    const T* xs2;                   // general form: inputs scaled by the second term's length scales (or null)
+    KSpec ks;
+};
+
+#if defined(GP_CUSTOM_KERNEL) && defined(GP_CUSTOM_GRAD)
+// Gradient reduction for a run-time compiled covariance function: the caller's text instantiated with the forward-mode type
+// Dual<T, GP_NCP> (gp_dual.h), so that every entry comes with its derivatives in the function's GP_NCP hyper-parameters:
+//   gacc[m]      += w (dk/dp_m)(x_g, x_j),  m < ncp        -> dl/dp_m = 1/2 gacc[m]
+//   gacc[ncp]    += w_gg                                    -> dl/dsn  = gacc[ncp] sn
+// with w = wt (alpha_g alpha_j - Kinv_gj) exactly as grad_reduce_kernel.  One 128 x 128 tile per workgroup, thread = one
+// row x 64 columns; the column points sit in LDS up to KB_LDS_MAXD dimensions, beyond that both points come from global memory.
+template <typename T>
+__global__ __launch_bounds__(256) void custom_grad_kernel(GradArgs<T> a, const double* __restrict__ cp, int ncp) {
+    extern __shared__ double lds_raw[];
+    typedef Dual<T, GP_NCP> dual_t;
+    const int d = a.d;
+    const bool glb = d > KB_LDS_MAXD;
+    T* xjs = reinterpret_cast<T*>(lds_raw);      // [d][128] column points (when they fit), then alpha_j [128]
+    T* aj = xjs + (glb ? 0 : d * TB);
+    const int tid = threadIdx.x, row = tid & 127, half = tid >> 7;
+    const int ti = blockIdx.x, tj = blockIdx.y;
+    if (a.tri && tj > ti) return;
+    const double wt = (a.tri && tj < ti) ? 2.0 : 1.0;
+    const int t = ti * TB + row, g = a.c0 + t;
+    for (int idx = tid; idx < (glb ? 0 : d * TB); idx += 256) xjs[idx] = a.xs[(long)(idx >> 7) * a.npad + tj * TB + (idx & 127)];
+    if (tid < TB) aj[tid] = a.alpha[tj * TB + tid];
+    double acc[GP_NCP];
+#pragma unroll
+    for (int m = 0; m < GP_NCP; ++m) acc[m] = 0.0;
+    double acc_dg = 0.0;
+    const T ag = (t < a.mc) ? a.alpha[g] : (T)0;
+    __syncthreads();
+    if (t < a.mc && g < a.n) {
+        const PointRef<T> Xg{a.xs + g, (long)a.npad};
+        for (int jj = half * 64; jj < half * 64 + 64; ++jj) {
+            const int j = tj * TB + jj;
+            if (j >= a.n) break;
+            const PointRef<T> Yj{glb ? a.xs + j : xjs + jj, glb ? (long)a.npad : (long)TB};
+            const dual_t k = gphip_custom_k<dual_t, T>(Xg, Yj, cp, d);
+            const double w = wt * ((double)ag * (double)aj[jj] - (double)a.Kinv[(long)j * a.ldv + t]);
+#pragma unroll
+            for (int m = 0; m < GP_NCP; ++m) acc[m] = __builtin_fma(w, (double)k.g[m], acc[m]);
+            if (j == g) acc_dg += w;
+        }
+    }
+    const int lane = tid & 63;
+#pragma unroll
+    for (int m = 0; m < GP_NCP; ++m) {
+        double v = acc[m];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+        if (lane == 0 && m < ncp) atomicAdd(a.gacc + m, v);
+    }
+    for (int off = 32; off > 0; off >>= 1) acc_dg += __shfl_down(acc_dg, off);
+    if (lane == 0) atomicAdd(a.gacc + ncp, acc_dg);
 }
 #endif
 }  // namespace gphip
@@ -2797,19 +2866,6 @@ __global__ void identity_rows_kernel(T* __restrict__ V, long ldv, int npad, int 
     }
 }
 
-template <typename T>
-struct GradArgs {
-    const T* Kinv; long ldv;        // row block: Kinv(t, j) at Kinv[j*ldv + t], t = row c0+t of K^-1
-    const T* alpha;                 // [npad]
-    const T* xs;                    // scaled inputs [d][npad]
-    int npad, n, c0, mc, d;
-    int tri;                        // 1: Kinv holds the lower triangle only (tile rows >= tile columns): skip the
-                                    //    upper tiles and count the strictly lower ones twice (everything is symmetric)
-    const double* slotp;
-    double* gacc;                   // [d + 2]; general form: [2 d + 6], see grad_reduce_general_kernel
-    const T* xs2;                   // general form: inputs scaled by the second term's length scales (or null)
-    KSpec ks;
-};
 
 // One 128 (rows of the block) x 128 (columns) tile per workgroup; thread = one row, 64 columns.
 template <typename T, int D, int KT>

@@ -67,6 +67,13 @@ struct gphip_ctx {
     // covariance function supplied as source text (gphip_create_custom): compiled at run time into the kernel build
     bool custom = false; int ncp = 0;            // ncp = its hyper-parameters p_0 .. p_{ncp-1}
     hipModule_t cmod = nullptr; hipFunction_t f_cbuild = nullptr, f_cdiag = nullptr, f_cprep = nullptr;
+    // its gradient: the same text instantiated with forward-mode dual numbers (gp_dual.h), compiled at the first
+    // gphip_loglik_grad (cgrad_state 0 = not tried yet, 1 = loaded, -1 = the text does not compile that way: differences)
+    std::string custom_body, arch;
+    hipModule_t cgmod = nullptr; hipFunction_t f_cgrad = nullptr;
+    int cgrad_state = 0;
+    int custom_grad = 1;                         // option: 0 = always central differences of the likelihood
+    int grad_analytic = 0;                       // read-only: the last gphip_loglik_grad used the one-factorisation route
     double *dCustomP = nullptr, *hCustomP = nullptr;   // [slot][ncp]
     double* dKss = nullptr; size_t kss_cap = 0;  // k(x*, x*) of the current test points, [slot][mpad]
     int panel_df = -1;                           // one-GPU look-ahead schedule, one theta, fp64: every outer panel as ONE fused dataflow launch
@@ -1810,6 +1817,14 @@ void launch_grad_kt(gphip_ctx* h, const GradArgs<T>& a, dim3 grid) {
 
 template <typename T>
 void launch_grad(gphip_ctx* h, GradArgs<T>& a, dim3 grid) {
+    if (h->custom) {                               // the run-time compiled custom_grad_kernel<T> (dual-number instantiation)
+        const double* cp = h->dCustomP;
+        int ncp = h->ncp;
+        void* params[] = {&a, &cp, &ncp};
+        const size_t lds = (size_t)((a.d > KB_LDS_MAXD ? 0 : a.d) + 1) * TB * sizeof(T);
+        (void)hipModuleLaunchKernel(h->f_cgrad, grid.x, grid.y, grid.z, 256, 1, 1, (unsigned)lds, h->cs, params, nullptr);
+        return;
+    }
     if (h->kt == 0) launch_grad_kt<T, 0>(h, a, grid);
     else if (h->kt == 1) launch_grad_kt<T, 1>(h, a, grid);
     else {
@@ -2121,6 +2136,7 @@ static int create_ctx(const void* X, const void* y, int64_t N, int64_t d, int ke
         std::string arch = prop.gcnArchName;                   // "gfx950:sramecc+:xnack-" -> "gfx950"
         arch = arch.substr(0, arch.find(':'));
         std::string msg;
+        h->custom_body = custom_body; h->arch = arch;
         const std::shared_ptr<const RtcResult> r = rtc_compile_custom(custom_body, dtype, arch.c_str(), msg);
         if (!r) {
             if (why) *why = msg;
@@ -2145,12 +2161,13 @@ const char* gphip_create_error(void) { return g_create_error.c_str(); }
 /* Compiles a covariance function exactly as gphip_create_custom would, without a handle and without a device (hiprtc
  * cross-compiles): a caller can validate user input early, a deployment can check that the library found hiprtc and carries
  * its kernel text, and the code object lands in the per-process cache the next gphip_create_custom of the same function hits. */
-int gphip_custom_compile(const char* body, int dtype, const char* arch, int* cache_hit) {
+int gphip_custom_compile(const char* body, int dtype, const char* arch, int grad_nparams, int* cache_hit) {
     g_create_error.clear();
     if (!body || !*body || (dtype != 64 && dtype != 32)) { g_create_error = "null / empty function body or bad dtype"; return GPHIP_ERR_ARG; }
     bool hit = false;
     std::string msg;
-    const std::shared_ptr<const RtcResult> r = rtc_compile_custom(body, dtype, (arch && *arch) ? arch : "gfx950", msg, &hit);
+    if (grad_nparams == 0 || grad_nparams > 32) { g_create_error = "the gradient program takes 1 .. 32 hyper-parameters"; return GPHIP_ERR_ARG; }
+    const std::shared_ptr<const RtcResult> r = rtc_compile_custom(body, dtype, (arch && *arch) ? arch : "gfx950", msg, &hit, grad_nparams < 0 ? -1 : grad_nparams);
     if (cache_hit) *cache_hit = hit ? 1 : 0;
     if (!r) {
         g_create_error = msg;
@@ -2250,6 +2267,7 @@ int gphip_destroy(gphip_handle h) {
     if (h->cstream) (void)hipStreamDestroy(h->cstream);
     free_slots(h);
     (void)hipFree(h->dXt); (void)hipFree(h->dY); (void)hipFree(h->dExp2); (void)hipFree(h->dCentre);
+    if (h->cgmod) (void)hipModuleUnload(h->cgmod);
     (void)hipFree(h->dV); (void)hipFree(h->dXsT); (void)hipFree(h->dXsS); (void)hipFree(h->dMean);
     (void)hipFree(h->dVar); (void)hipFree(h->dAlpha); (void)hipFree(h->dGacc); (void)hipFree(h->dKinv);
     (void)hipFree(h->dXsS2); (void)hipFree(h->dPwMeanT); (void)hipFree(h->dPwNugT);
@@ -2299,15 +2317,35 @@ int gphip_loglik_grad(gphip_handle h, const double* theta, int p, double* out, d
     }
     std::lock_guard<std::recursive_mutex> lk(h->mu);
     if (h->custom) {
-        // a run-time compiled covariance function has no analytic derivative here: central differences of the likelihood, all
-        // 2 p + 1 points as ONE batched evaluation (step 1e-4 max(|theta_k|, 1e-2): ~1e-7 relative on the gradient)
         if (p != h->p) return fail(h, GPHIP_ERR_DIM, "theta has the wrong length");
+        // One factorisation: the function's text instantiated with forward-mode dual numbers inside the gradient reduction
+        // (custom_grad_kernel), compiled on first use.  A body that does not compile that way (a math function gp_dual.h
+        // does not differentiate, intermediates of a fixed scalar type, ..) keeps the difference route below.
+        constexpr int CGRAD_MAX_NCP = 32;
+        if (h->cgrad_state == 0 && h->custom_grad && h->ncp >= 1 && h->ncp <= CGRAD_MAX_NCP) {
+            std::string msg;
+            const std::shared_ptr<const RtcResult> r = rtc_compile_custom(h->custom_body, h->dtype, h->arch.c_str(), msg, nullptr, h->ncp);
+            h->cgrad_state = -1;
+            HIPCHK(hipSetDevice(h->device));
+            if (r && hipModuleLoadData(&h->cgmod, r->code.data()) == hipSuccess &&
+                hipModuleGetFunction(&h->f_cgrad, h->cgmod, r->grad.c_str()) == hipSuccess)
+                h->cgrad_state = 1;
+            else
+                (void)hipGetLastError();
+        }
+    }
+    h->grad_analytic = 0;
+    if (h->custom && !(h->custom_grad && h->cgrad_state == 1)) {
+        // central differences of the likelihood, all 2 p + 1 points as ONE batched evaluation.  Step eps^(1/3) max(|theta_k|,
+        // 1e-2) in the handle's arithmetic (fp64 6e-6, fp32 5e-3): the truncation error (h^2 / 6 times the third derivative)
+        // and the rounding error eps_ll |ll| / h balance there; expect ~1e-6 relative in fp64 at moderate N, ~1e-2 in fp32.
         const int B = 2 * p + 1;
         std::vector<double> Th((size_t)B * p), ll((size_t)B, 0.0), step((size_t)p);
         std::vector<int> inf((size_t)B, 0);
         for (int r = 0; r < B; ++r) memcpy(&Th[(size_t)r * p], theta, (size_t)p * 8);
+        const double rel = h->dtype == 64 ? 6.0e-6 : 5.0e-3;
         for (int k = 0; k < p; ++k) {
-            step[(size_t)k] = 1e-4 * std::max(std::fabs(theta[k]), 1e-2);
+            step[(size_t)k] = rel * std::max(std::fabs(theta[k]), 1e-2);
             Th[(size_t)(1 + 2 * k) * p + k] += step[(size_t)k];
             Th[(size_t)(2 + 2 * k) * p + k] -= step[(size_t)k];
         }
@@ -2322,7 +2360,7 @@ int gphip_loglik_grad(gphip_handle h, const double* theta, int p, double* out, d
     }
     // the gradient reductions keep (d + 1) point tiles (general form: 4 d + 1) in LDS: beyond KB_LDS_MAXD dimensions only the
     // likelihood / fit / prediction paths are implemented (they read the points from global memory instead)
-    if (h->d > KB_LDS_MAXD) return fail(h, GPHIP_ERR_UNSUPPORTED, "gphip_loglik_grad supports input dimensions up to 32");
+    if (!h->custom && h->d > KB_LDS_MAXD) return fail(h, GPHIP_ERR_UNSUPPORTED, "gphip_loglik_grad supports input dimensions up to 32");
     double parts[2] = {0, 0};
     h->want_w = true;                          // (a multi-device handle factors on its first device: the K^-1 contraction needs the whole factor)
     int rc = eval_batch_local(h, theta, 1, p, out, parts, info);
@@ -2333,7 +2371,8 @@ int gphip_loglik_grad(gphip_handle h, const double* theta, int p, double* out, d
     HIPCHK(hipSetDevice(h->device));
     const int64_t N = h->N, Npad = h->Npad, d = h->d;
     if (!h->dAlpha) HIPCHK(hipMalloc(&h->dAlpha, (size_t)Npad * h->es));
-    const size_t ngacc = (size_t)2 * d + 6;             // general form: both terms' length scales, sf, alpha, c, sn
+    // general form: both terms' length scales, sf, alpha, c, sn; run-time compiled function: its ncp parameters, sn
+    const size_t ngacc = std::max((size_t)2 * d + 6, (size_t)h->ncp + 1);
     if (!h->dGacc) HIPCHK(hipMalloc(&h->dGacc, ngacc * 8));
     // potri route when U (Npad x Npad scratch) and the lower tiles of K^-1 both fit in a quarter of the HBM
     // that is free right now; otherwise K^-1 is streamed in row blocks through forward + backward substitution
@@ -2389,6 +2428,25 @@ int gphip_loglik_grad(gphip_handle h, const double* theta, int p, double* out, d
     if (rc) return rc;
     HIPCHK(hipGetLastError());
     harvest(h);
+    h->grad_analytic = 1;
+    if (h->custom) {
+        // theta = [p_0 .. p_{ncp-1}] sn [mu]  (accumulators: custom_grad_kernel)
+        for (int m = 0; m < h->ncp; ++m) grad[m] = 0.5 * gacc[(size_t)m];
+        grad[h->ncp] = gacc[(size_t)h->ncp] * theta[h->ncp];
+        if (h->mean_id == GPHIP_MEAN_CONST) {
+            double sum = 0.0;
+            for (double v : alpha) sum += v;
+            grad[h->ncp + 1] = sum;
+        }
+        h->fitted = true;
+        h->dist_fit = false;
+        stamp_fit(h);
+        h->theta_fit.assign(theta, theta + p);
+        h->logdet_fit = parts[0];
+        h->mu_fit = h->hSlotp[2];
+        h->kappa_fit = h->hSlotp[SP_KXX] + h->hSlotp[1];
+        return GPHIP_OK;
+    }
     // chain rule onto the theta layout [term 1: l.., (alpha), sf] [term 2] [c] sn [mu]  (accumulators: grad_reduce_*)
     int o = 0;
     auto lengths = [&](int nl, size_t base) {
@@ -3303,6 +3361,7 @@ int* option_slot(gphip_ctx* h, const char* name) {
         {"debug_fail_alloc", &gphip_ctx::debug_fail_alloc}, {"debug_fail_hip", &gphip_ctx::debug_fail_hip}, {"replicate_factor", &gphip_ctx::replicate_factor},
         {"share_local_panels", &gphip_ctx::share_local_panels},
         {"kbuild_mfma", &gphip_ctx::kbuild_mfma}, {"kbuild_mfma_bound", &gphip_ctx::kbuild_mfma_bound},
+        {"custom_grad", &gphip_ctx::custom_grad}, {"grad_analytic", &gphip_ctx::grad_analytic},
     };
     for (const Entry& e : table)
         if (!strcmp(name, e.name)) return &(h->*(e.field));

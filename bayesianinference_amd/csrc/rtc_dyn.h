@@ -20,6 +20,7 @@
 #include <mutex>
 #include <sstream>
 #include <string>
+#include <utility>
 #include <vector>
 
 // the text of gp_kernels.h, as compiled (the build passes -I <csrc>; host pass only)
@@ -30,9 +31,15 @@ __asm__(".pushsection .rodata\n"
         "gphip_rtc_embedded_src:\n"
         ".incbin \"gp_kernels.h\"\n"
         ".byte 0\n"
+        ".hidden gphip_rtc_embedded_dual\n"
+        ".global gphip_rtc_embedded_dual\n"
+        "gphip_rtc_embedded_dual:\n"
+        ".incbin \"gp_dual.h\"\n"
+        ".byte 0\n"
         ".popsection\n");
 #endif
 extern "C" const char gphip_rtc_embedded_src[];
+extern "C" const char gphip_rtc_embedded_dual[];       // gp_dual.h: the forward-mode type the gradient instantiates the function with
 
 namespace gphip {
 
@@ -86,17 +93,20 @@ inline const RtcApi& rtc() {
 }
 
 // the [rtc-begin] .. [rtc-end] region of gp_kernels.h: the embedded text, or $GPHIP_SRC_DIR/gp_kernels.h (developer override)
-inline bool rtc_kernel_source(std::string& region, std::string& why) {
+inline bool rtc_kernel_source(std::string& region, std::string& dual, std::string& why) {
     std::string text, where = "the text embedded in the library";
     if (const char* env = getenv("GPHIP_SRC_DIR")) {
         where = std::string(env) + "/gp_kernels.h";
-        std::ifstream f(where);
-        if (!f) { why = where + " (GPHIP_SRC_DIR) cannot be read"; return false; }
-        std::stringstream ss;
+        std::ifstream f(where), f2(std::string(env) + "/gp_dual.h");
+        if (!f || !f2) { why = where + " / gp_dual.h (GPHIP_SRC_DIR) cannot be read"; return false; }
+        std::stringstream ss, s2;
         ss << f.rdbuf();
+        s2 << f2.rdbuf();
         text = ss.str();
+        dual = s2.str();
     } else {
         text = gphip_rtc_embedded_src;
+        dual = gphip_rtc_embedded_dual;
     }
     const size_t b = text.find("// [rtc-begin]"), e = text.find("// [rtc-end]");
     if (b == std::string::npos || e == std::string::npos || e < b) { why = where + " has no [rtc-begin] / [rtc-end] region"; return false; }
@@ -113,20 +123,26 @@ inline bool rtc_kernel_source(std::string& region, std::string& why) {
 
 struct RtcResult {
     std::vector<char> code;                      // the code object for hipModuleLoadData
-    std::string build, diag, prep;               // lowered names of the three kernels
+    std::string build, diag, prep;               // lowered names of the three kernels of the value program ...
+    std::string grad;                            // ... or of the gradient program's one kernel (custom_grad_kernel)
 };
 
 // body: the statements of   template <typename T> T k(X, Y, P, D)   -- X(k) / Y(k) coordinate k of the two points, P(k)
-// hyper-parameter k, D the input dimension, T the handle's arithmetic type; must `return` the covariance.
-inline bool rtc_compile_uncached(const std::string& body, int dtype, const char* arch, RtcResult& out, std::string& why) {
+// hyper-parameter k (of type T), D the input dimension, T the arithmetic type; must `return` the covariance.
+// grad_ncp < 0: the value program (kernel build, k(x, x) kernels).  grad_ncp >= 1: the gradient program -- the same text
+// instantiated with T = Dual<S, grad_ncp> inside custom_grad_kernel (intermediates that depend on P must be of type T there,
+// which they are in a body that follows the documented form).
+inline bool rtc_compile_uncached(const std::string& body, int dtype, const char* arch, int grad_ncp, RtcResult& out, std::string& why) {
     const RtcApi& api = rtc();
     if (!api.ok()) { why = "hiprtc could not be loaded (libhiprtc.so; set GPHIP_HIPRTC_PATH)"; return false; }
-    std::string region;
-    if (!rtc_kernel_source(region, why)) return false;
-    std::string src = "#define GP_CUSTOM_KERNEL 1\n" + region;
+    std::string region, dual;
+    if (!rtc_kernel_source(region, dual, why)) return false;
+    std::string src = "#define GP_CUSTOM_KERNEL 1\n#define GP_HD __device__ __forceinline__\n";
+    if (grad_ncp >= 1) src += "#define GP_CUSTOM_GRAD 1\n#define GP_NCP " + std::to_string(grad_ncp) + "\n";
+    src += dual + "\n" + region;
     // names a Mathematica CForm of the function uses (GPHIP.wl translates a pure-function kernel that way)
     src += "\nnamespace gphip {\n"
-           "template <typename A, typename B> __device__ __forceinline__ auto Power(A a, B b) -> decltype(a * 1.0f) { return pow(a, (decltype(a * 1.0f))b); }\n"
+           "template <typename A, typename B> __device__ __forceinline__ auto Power(A a, B b) -> decltype(a * b * 1.0f) { typedef decltype(a * b * 1.0f) R; return pow((R)a, (R)b); }\n"
            "template <typename A> __device__ __forceinline__ A Sqrt(A a) { return sqrt(a); }\n"
            "template <typename A> __device__ __forceinline__ A Exp(A a) { return exp(a); }\n"
            "template <typename A> __device__ __forceinline__ A Log(A a) { return log(a); }\n"
@@ -140,25 +156,29 @@ inline bool rtc_compile_uncached(const std::string& body, int dtype, const char*
            "template <typename A> __device__ __forceinline__ A ArcTan(A a) { return atan(a); }\n"
            "template <typename A> __device__ __forceinline__ A Erf(A a) { return erf(a); }\n"
            "template <typename A> __device__ __forceinline__ A Erfc(A a) { return erfc(a); }\n"
-           "template <typename A, typename B> __device__ __forceinline__ auto Min(A a, B b) -> decltype(a + b) { return a < b ? a : b; }\n"
-           "template <typename A, typename B> __device__ __forceinline__ auto Max(A a, B b) -> decltype(a + b) { return a > b ? a : b; }\n"
+           "template <typename A, typename B> __device__ __forceinline__ auto Min(A a, B b) -> decltype(a + b) { typedef decltype(a + b) R; return a < b ? (R)a : (R)b; }\n"
+           "template <typename A, typename B> __device__ __forceinline__ auto Max(A a, B b) -> decltype(a + b) { typedef decltype(a + b) R; return a > b ? (R)a : (R)b; }\n"
            "constexpr double Pi = 3.14159265358979323846, E = 2.71828182845904523536;\n"
-           "template <typename T>\n"
-           "__device__ T gphip_custom_k(PointRef<T> X, PointRef<T> Y, const double* __restrict__ Pp, int D) {\n"
-           "#define P(k) ((T)Pp[(k)])\n";
+           "template <typename T, typename S>\n"
+           "__device__ T gphip_custom_k(PointRef<S> X, PointRef<S> Y, const double* __restrict__ Pp, int D) {\n"
+           "#define P(k) (gp_param_of<T>::get(Pp, (k)))\n";
     src += body;
     src += "\n#undef P\n}\n}  // namespace gphip\n";
     const std::string ty = dtype == 64 ? "double" : "float";
-    const std::string n_build = "gphip::kbuild_kernel<" + ty + ", 0, 3>", n_diag = "gphip::custom_diag_kernel<" + ty + ">",
-                      n_prep = "gphip::custom_prep_kernel<" + ty + ">";
+    std::vector<std::pair<std::string, std::string*>> names;
+    if (grad_ncp >= 1) {
+        names.push_back({"gphip::custom_grad_kernel<" + ty + ">", &out.grad});
+    } else {
+        names.push_back({"gphip::kbuild_kernel<" + ty + ", 0, 3>", &out.build});
+        names.push_back({"gphip::custom_diag_kernel<" + ty + ">", &out.diag});
+        names.push_back({"gphip::custom_prep_kernel<" + ty + ">", &out.prep});
+    }
     RtcApi::prog_t prog = nullptr;
     if (api.CreateProgram(&prog, src.c_str(), "gphip_custom_kernel.hip", 0, nullptr, nullptr) != 0) {
         why = "hiprtcCreateProgram failed";
         return false;
     }
-    api.AddNameExpression(prog, n_build.c_str());
-    api.AddNameExpression(prog, n_diag.c_str());
-    api.AddNameExpression(prog, n_prep.c_str());
+    for (auto& n : names) api.AddNameExpression(prog, n.first.c_str());
     const std::string archopt = std::string("--offload-arch=") + arch;
     const char* opts[] = {archopt.c_str(), "-O3", "-std=c++17"};
     const int rc = api.CompileProgram(prog, 3, opts);
@@ -171,11 +191,12 @@ inline bool rtc_compile_uncached(const std::string& body, int dtype, const char*
         api.DestroyProgram(&prog);
         return false;
     }
-    const char* low = nullptr;
     bool ok = true;
-    ok = ok && api.GetLoweredName(prog, n_build.c_str(), &low) == 0 && low; if (ok) out.build = low;
-    ok = ok && api.GetLoweredName(prog, n_diag.c_str(), &low) == 0 && low;  if (ok) out.diag = low;
-    ok = ok && api.GetLoweredName(prog, n_prep.c_str(), &low) == 0 && low;  if (ok) out.prep = low;
+    for (auto& n : names) {
+        const char* low = nullptr;
+        ok = ok && api.GetLoweredName(prog, n.first.c_str(), &low) == 0 && low;
+        if (ok) *n.second = low;
+    }
     size_t sz = 0;
     ok = ok && api.GetCodeSize(prog, &sz) == 0 && sz > 0;
     if (ok) {
@@ -189,17 +210,17 @@ inline bool rtc_compile_uncached(const std::string& body, int dtype, const char*
 
 // per-process cache of code objects, keyed by everything the compilation depends on (the kernel text is fixed per process)
 inline std::shared_ptr<const RtcResult> rtc_compile_custom(const std::string& body, int dtype, const char* arch, std::string& why,
-                                                            bool* cache_hit = nullptr) {
+                                                            bool* cache_hit = nullptr, int grad_ncp = -1) {
     static std::mutex mu;
     static std::map<std::string, std::shared_ptr<const RtcResult>> cache;
     const char* dev = getenv("GPHIP_SRC_DIR");
-    const std::string key = std::string(arch) + "|" + std::to_string(dtype) + "|" + (dev ? dev : "") + "|" + body;
+    const std::string key = std::string(arch) + "|" + std::to_string(dtype) + "|" + std::to_string(grad_ncp) + "|" + (dev ? dev : "") + "|" + body;
     std::lock_guard<std::mutex> lk(mu);
     auto it = cache.find(key);
     if (cache_hit) *cache_hit = it != cache.end();
     if (it != cache.end()) return it->second;
     auto r = std::make_shared<RtcResult>();
-    if (!rtc_compile_uncached(body, dtype, arch, *r, why)) return nullptr;
+    if (!rtc_compile_uncached(body, dtype, arch, grad_ncp, *r, why)) return nullptr;
     cache.emplace(key, r);
     return r;
 }

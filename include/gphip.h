@@ -82,8 +82,13 @@ typedef struct gphip_ctx* gphip_handle;
  * theta layout of such a handle:  [p_0 .. p_{nparams-1}] sn [mu].  The function may be non-stationary: the prior variance
  * k(x, x) is evaluated per point on the device (prediction variance, pivot tolerance of the factorisation).
  * Likelihoods, batches, fits, predictions, posterior-sample mixtures, covariance exports and the native sampler work as for the
- * named kernels; gphip_loglik_grad returns central differences of the likelihood (2 p + 1 points in one batched evaluation,
- * ~1e-7 relative) instead of the analytic gradient.  Replaces the reference's
+ * named kernels.  gphip_loglik_grad costs ONE factorisation, like the named kernels: the body is instantiated a second time
+ * with T = a forward-mode dual number (csrc/gp_dual.h: + - * / comparisons, exp log log1p expm1 sqrt pow fabs sin cos tan
+ * sinh cosh tanh atan erf erfc fmin fmax and the CForm names) inside the reduction 1/2 tr((alpha alpha^T - K^-1) dK/dp_m);
+ * intermediates that depend on a P(k) must therefore be of type T (not double / float).  A body that does not compile
+ * that way, more than 32 hyper-parameters, or option "custom_grad" = 0 fall back to central differences of the likelihood
+ * (2 p + 1 points in one batched evaluation; step eps^(1/3) max(|theta_k|, 1e-2) in the handle's arithmetic: ~1e-6 relative
+ * in fp64, ~1e-2 in fp32).  Option "grad_analytic" reads 1 after a call that took the one-factorisation route.  Replaces the reference's
  * `kernel @@ points[[{i,j}]]` for an arbitrary pure function (BGP:29-33, cross form BGP:100-109).
  * Errors: GPHIP_ERR_ARG = the body does not compile (gphip_create_error() returns the compiler's log),
  * GPHIP_ERR_UNSUPPORTED = no hiprtc (see csrc/rtc_dyn.h; $GPHIP_HIPRTC_PATH names the library explicitly). */
@@ -101,8 +106,11 @@ const char* gphip_create_error(void);
  * "gfx950").  Validates user input early; proves that a deployed libgphip.so finds hiprtc and carries its own kernel text (the
  * text of csrc/gp_kernels.h is embedded in the library at build time; $GPHIP_SRC_DIR overrides it for development); and warms
  * the per-process code-object cache (key: body, dtype, arch) that later gphip_create_custom* calls hit.  *cache_hit = 1 when
- * the code object was already there.  Errors as gphip_create_custom (gphip_create_error() = the compiler's log). */
-int gphip_custom_compile(const char* body, int dtype, const char* arch, int* cache_hit);
+ * the code object was already there.  grad_nparams < 0: the value program (kernel build + prior variance kernels);
+ * 1 .. 32: the GRADIENT program instead -- the same text instantiated with forward-mode dual numbers in its grad_nparams
+ * hyper-parameters (csrc/gp_dual.h), what the first gphip_loglik_grad of such a handle compiles.
+ * Errors as gphip_create_custom (gphip_create_error() = the compiler's log). */
+int gphip_custom_compile(const char* body, int dtype, const char* arch, int grad_nparams, int* cache_hit);
 #define GPHIP_MEAN_ZERO 0            /* Function[0]  (BGP:168,255)                                    */
 #define GPHIP_MEAN_CONST 1           /* Function[mu], mu = last entry of theta                        */
 

@@ -51,11 +51,11 @@ def _hiprtc():
     return None
 
 
-def _compile(body, dtype):
-    """through the library's own compile step (its prelude, its embedded kernel text)"""
+def _compile(body, dtype, grad=-1):
+    """through the library's own compile step (its prelude, its embedded kernel text); grad >= 1: the dual-number program"""
     lib = _lib.load()
     hit = C.c_int(0)
-    rc = lib.gphip_custom_compile(body.encode(), dtype, b"gfx950", C.byref(hit))
+    rc = lib.gphip_custom_compile(body.encode(), dtype, b"gfx950", grad, C.byref(hit))
     return rc, (lib.gphip_create_error() or b"").decode(errors="replace")
 
 
@@ -67,8 +67,15 @@ def test_kernel_build_region_compiles_under_hiprtc(dtype):
                  "return Min(P(0), 2) * Cos(Pi * Abs(X(0) - Y(0))) + Max(0, Tanh(X(1) * Y(1))) + Erf(P(1)) * Sqrt(1 + Power(X(0) - Y(0), 2));"):
         rc, log = _compile(body, dtype)
         assert rc == 0, log
+        rc, log = _compile(body, dtype, grad=4)                   # the same text with T = Dual<S, 4> (gp_dual.h)
+        assert rc == 0, log
     rc, log = _compile("return P(0) * undeclared_symbol;", dtype)
     assert rc == 1 and "undeclared_symbol" in log
+    # a body whose intermediates are not of type T: fine for the value program, refused by the gradient program (the handle
+    # then keeps central differences)
+    fixed = "double s = P(0); return (T)(s * exp(-fabs((double)(X(0) - Y(0)))));"
+    assert _compile(fixed, dtype)[0] == 0
+    assert _compile(fixed, dtype, grad=1)[0] == 1
 
 
 def test_rtc_region_has_no_host_only_dependencies():
@@ -95,20 +102,20 @@ def test_library_alone_compiles_custom_functions_and_caches_them(tmp_path):
     code = textwrap.dedent(f"""
         import ctypes as C, time, os
         L = C.CDLL({str(lib)!r})
-        L.gphip_custom_compile.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.POINTER(C.c_int)]
+        L.gphip_custom_compile.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int)]
         L.gphip_create_error.restype = C.c_char_p
         body = {SE_ARD_BODY!r}.encode()
         hit = C.c_int(-1)
-        t0 = time.perf_counter(); rc = L.gphip_custom_compile(body, 64, None, C.byref(hit)); t1 = time.perf_counter()
+        t0 = time.perf_counter(); rc = L.gphip_custom_compile(body, 64, None, -1, C.byref(hit)); t1 = time.perf_counter()
         assert rc == 0 and hit.value == 0, (rc, hit.value, L.gphip_create_error())
-        t2 = time.perf_counter(); rc = L.gphip_custom_compile(body, 64, b"gfx950", C.byref(hit)); t3 = time.perf_counter()
+        t2 = time.perf_counter(); rc = L.gphip_custom_compile(body, 64, b"gfx950", -1, C.byref(hit)); t3 = time.perf_counter()
         assert rc == 0 and hit.value == 1 and t3 - t2 < 5e-3, (rc, hit.value, t3 - t2)
-        rc = L.gphip_custom_compile(body, 32, None, C.byref(hit))
+        rc = L.gphip_custom_compile(body, 32, None, -1, C.byref(hit))
         assert rc == 0 and hit.value == 0                           # (another arithmetic type: another code object)
-        rc = L.gphip_custom_compile(b"return P(0) * undeclared_symbol;", 64, None, C.byref(hit))
+        rc = L.gphip_custom_compile(b"return P(0) * undeclared_symbol;", 64, None, -1, C.byref(hit))
         assert rc == 1 and b"undeclared_symbol" in L.gphip_create_error()
         os.environ["GPHIP_SRC_DIR"] = {str(tmp_path / "stale")!r}
-        rc = L.gphip_custom_compile(body + b" ", 64, None, C.byref(hit))
+        rc = L.gphip_custom_compile(body + b" ", 64, None, -1, C.byref(hit))
         assert rc != 0 and b"GP_RTC_ABI" in L.gphip_create_error(), L.gphip_create_error()
         print("first compile %.2f s, cached %.2e s" % (t1 - t0, t3 - t2))
     """)
@@ -117,6 +124,7 @@ def test_library_alone_compiles_custom_functions_and_caches_them(tmp_path):
     src = open(os.path.join(ROOT, "bayesianinference_amd", "csrc", "gp_kernels.h")).read()
     import re
     (stale / "gp_kernels.h").write_text(re.sub(r"#define GP_RTC_ABI \d+", "#define GP_RTC_ABI 9999", src))
+    shutil.copy(os.path.join(ROOT, "bayesianinference_amd", "csrc", "gp_dual.h"), stale / "gp_dual.h")
     env = {k: v for k, v in os.environ.items() if k != "GPHIP_SRC_DIR"}
     res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=str(tmp_path), env=env, timeout=300)
     assert res.returncode == 0, res.stdout + res.stderr
