@@ -2166,7 +2166,7 @@ int gphip_custom_compile(const char* body, int dtype, const char* arch, int grad
     if (!body || !*body || (dtype != 64 && dtype != 32)) { g_create_error = "null / empty function body or bad dtype"; return GPHIP_ERR_ARG; }
     bool hit = false;
     std::string msg;
-    if (grad_nparams == 0 || grad_nparams > 32) { g_create_error = "the gradient program takes 1 .. 32 hyper-parameters"; return GPHIP_ERR_ARG; }
+    if (grad_nparams == 0 || grad_nparams > 64) { g_create_error = "the gradient program takes 1 .. 64 hyper-parameters"; return GPHIP_ERR_ARG; }
     const std::shared_ptr<const RtcResult> r = rtc_compile_custom(body, dtype, (arch && *arch) ? arch : "gfx950", msg, &hit, grad_nparams < 0 ? -1 : grad_nparams);
     if (cache_hit) *cache_hit = hit ? 1 : 0;
     if (!r) {
@@ -2321,7 +2321,7 @@ int gphip_loglik_grad(gphip_handle h, const double* theta, int p, double* out, d
         // One factorisation: the function's text instantiated with forward-mode dual numbers inside the gradient reduction
         // (custom_grad_kernel), compiled on first use.  A body that does not compile that way (a math function gp_dual.h
         // does not differentiate, intermediates of a fixed scalar type, ..) keeps the difference route below.
-        constexpr int CGRAD_MAX_NCP = 32;
+        constexpr int CGRAD_MAX_NCP = 64;
         if (h->cgrad_state == 0 && h->custom_grad && h->ncp >= 1 && h->ncp <= CGRAD_MAX_NCP) {
             std::string msg;
             const std::shared_ptr<const RtcResult> r = rtc_compile_custom(h->custom_body, h->dtype, h->arch.c_str(), msg, nullptr, h->ncp);

@@ -6,7 +6,8 @@ instead (distributed.sharded_map, no collective).  One process per GPU; outer pa
 
     owner(k+1):  panel stream   LA(k): apply panel k to its own panel k+1; factor panel k+1; pack it
     everyone:    comm stream    broadcast(packed panel k+1)   <- the ONE real exchange step of the path
-    everyone:    main stream    REST(k): apply panel k to the owned panels j >= k+2 (+ corner tile on rank 0)
+    everyone:    main stream    REST(k): apply panel k to the owned panels j >= k+2 (+ corner tile on rank 0);
+                                owner(k+2) does panel k+2 FIRST (own event): LA(k+1) waits for that piece only
 
 so the broadcast of panel k+1 (<= 134 MB at N=32768, received over one xGMI link, ~1 ms) and the
 owner's panel factorisation both fly under the trailing update of panel k (look-ahead).  The
@@ -152,6 +153,7 @@ class DistributedCholesky:
         H, nouter = self.handles, self.nouter
         ev_rest = {r: [None] * (nouter + 1) for r in H}        # REST(k) done on rank r's main stream
         ev_bcast = {r: [None] * (nouter + 1) for r in H}       # packed panel k ready in bufs[r][k % 3]
+        ev_first = {r: [None] * (nouter + 1) for r in H}       # REST(k)'s piece on outer panel k+2 done (its owner only)
 
         def view(r, k):
             rows, cols = self.shapes[k]
@@ -206,7 +208,7 @@ class DistributedCholesky:
                 if o in H:                                     # LA(k) on the owner's panel stream
                     self.panel[o].wait_event(ev_bcast[o][k])
                     if k >= 1:
-                        self.panel[o].wait_event(ev_rest[o][k - 1])
+                        self.panel[o].wait_event(ev_first[o][k - 1])
                     with self.rt.on(self.panel[o]):
                         H[o].dist_update(k, view(o, k), k + 1, k + 2, True)
                 factor_and_broadcast(k + 1)
@@ -214,10 +216,18 @@ class DistributedCholesky:
                 self.main[r].wait_event(ev_bcast[r][k])
                 with self.rt.on(self.main[r]):
                     # (the last panel has no look-ahead step: its REST starts at the corner tile)
-                    h.dist_update(k, view(r, k), k + 2 if k + 1 < nouter else k + 1, nouter + 1, False)
+                    first = k + 2 if k + 1 < nouter else k + 1
+                    if self.world > 1 and k + 2 < nouter and r == self.owner(k + 2):
+                        h.dist_update(k, view(r, k), k + 2, k + 3, False)
+                        ev_first[r][k] = self.rt.event()
+                        ev_first[r][k].record(self.main[r])
+                        first = k + 3
+                    h.dist_update(k, view(r, k), first, nouter + 1, False)
                     ev = self.rt.event()
                     ev.record(self.main[r])
                     ev_rest[r][k] = ev
+                    if ev_first[r][k] is None:
+                        ev_first[r][k] = ev
         vals = {}
         for r, h in H.items():
             self.main[r].wait_stream(self.panel[r])

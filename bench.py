@@ -671,6 +671,11 @@ def main() -> None:
             out["strong_speedup"] = strong["speedup_vs_one_gpu_weak_step"] if ok else None
             out["strong_ms_per_eval"] = strong["ms_per_eval"] if ok else None
             out["rccl_ranks"] = strong["rccl_ranks"] if ok else None
+            # the fastest schedule variant whose results agreed with the default's (the default itself if none beat it)
+            bv = strong.get("best_variant", "default") if ok else None
+            out["strong_best_variant"] = bv
+            out["strong_best_speedup"] = (strong["variants"][bv]["speedup_vs_one_gpu_weak_step"] if ok and bv in strong.get("variants", {})
+                                          else out["strong_speedup"])
         if world == 1 and not args.no_extras and not args.no_live_pmc and args.mode == "theta":
             live = live_pmc_traffic(n, d, local_rank)
             if live is not None:

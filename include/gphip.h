@@ -86,7 +86,7 @@ typedef struct gphip_ctx* gphip_handle;
  * with T = a forward-mode dual number (csrc/gp_dual.h: + - * / comparisons, exp log log1p expm1 sqrt pow fabs sin cos tan
  * sinh cosh tanh atan erf erfc fmin fmax and the CForm names) inside the reduction 1/2 tr((alpha alpha^T - K^-1) dK/dp_m);
  * intermediates that depend on a P(k) must therefore be of type T (not double / float).  A body that does not compile
- * that way, more than 32 hyper-parameters, or option "custom_grad" = 0 fall back to central differences of the likelihood
+ * that way, more than 64 hyper-parameters, or option "custom_grad" = 0 fall back to central differences of the likelihood
  * (2 p + 1 points in one batched evaluation; step eps^(1/3) max(|theta_k|, 1e-2) in the handle's arithmetic: ~1e-6 relative
  * in fp64, ~1e-2 in fp32).  Option "grad_analytic" reads 1 after a call that took the one-factorisation route.  Replaces the reference's
  * `kernel @@ points[[{i,j}]]` for an arbitrary pure function (BGP:29-33, cross form BGP:100-109).
@@ -107,7 +107,7 @@ const char* gphip_create_error(void);
  * text of csrc/gp_kernels.h is embedded in the library at build time; $GPHIP_SRC_DIR overrides it for development); and warms
  * the per-process code-object cache (key: body, dtype, arch) that later gphip_create_custom* calls hit.  *cache_hit = 1 when
  * the code object was already there.  grad_nparams < 0: the value program (kernel build + prior variance kernels);
- * 1 .. 32: the GRADIENT program instead -- the same text instantiated with forward-mode dual numbers in its grad_nparams
+ * 1 .. 64: the GRADIENT program instead -- the same text instantiated with forward-mode dual numbers in its grad_nparams
  * hyper-parameters (csrc/gp_dual.h), what the first gphip_loglik_grad of such a handle compiles.
  * Errors as gphip_create_custom (gphip_create_error() = the compiler's log). */
 int gphip_custom_compile(const char* body, int dtype, const char* arch, int grad_nparams, int* cache_hit);

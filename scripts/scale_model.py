@@ -1,0 +1,142 @@
+"""Predicted time of ONE sharded N x N evaluation on 2 / 4 / 8 GPUs from measured single-GPU step times and a link model, so
+that the first SCALE record falsifies a number instead of an adjective (the schedule itself: csrc/gphip_multi.inc
+group_eval_run; no multi-GPU box has run it yet).
+
+Input: gpurun_out/owner_path_<N>.json (scripts/gpu_owner_path.py: per outer panel, with the chip to itself, the time of the
+panel factorisation, of the look-ahead update LA(k) of panel k+1 and of the trailing update REST(k) of everything behind it),
+and the link parameters alpha (seconds per collective call, launch to completion of an empty message) and beta (bytes / s a
+receiver sees from one broadcast).
+
+Model = the dependency graph of group_eval_run replayed with those durations, three streams per rank:
+    panel stream   LA(k) on owner(k+1): waits for panel k's arrival and for REST(k-1)'s piece on panel k+1;  then factor(k+1)
+    comm stream    broadcast of panel k+1: per tile column (bcast_chunks) as the columns become final, or one message;
+                   waits for the receive buffer (REST(k-2) done)
+    main stream    REST(k) on every rank: its share of the trailing panels (by tile count), owner(k+2) does panel k+2 first
+A rank's REST share shrinks with the world, but a launch never runs faster than `floor_us` (tail of a grid that no longer
+fills 256 CUs).  Panel-stream work and REST share one GPU: the makespan is at least each rank's total work.
+   python scripts/scale_model.py gpurun_out/owner_path_32768.json [alpha_us beta_GBs]"""
+import json
+import sys
+
+
+def simulate(data, mode, W, alpha_us, beta_gbs, chunks=True, two_hop=False, split_rest=True, floor_us=25.0, launch_us=6.0):
+    N, P = data["N"], data["panel_tiles"]
+    m = data["modes"][mode]
+    f, la, rest = m["factor_us"], m["la_us"], m["rest_us"]
+    nouter = len(f)
+    Nt = (N + 127) // 128
+    R = Nt + 1
+    width = [min(P, Nt - j * P) for j in range(nouter)]
+    # tiles of outer panel k (what a broadcast moves), tile columns c of the panel hold R - (kP + c) tiles
+    col_tiles = [[R - (k * P + c) for c in range(width[k])] for k in range(nouter)]
+    tile_bytes = 128 * 128 * 8
+    # weight of outer panel j in a trailing update (tiles touched): rows below its top x its width
+    wj = [(R - j * P) * width[j] for j in range(nouter)]
+    beta = beta_gbs * 1e9 * (W / 2.0 if two_hop and W > 2 else 1.0)          # two-hop: scatter + all-gather over all links
+    alpha = alpha_us * (2.0 if two_hop and W > 2 else 1.0)
+
+    def own(j):
+        return j % W
+
+    p = [0.0] * W
+    c = [0.0] * W
+    mn = [0.0] * W
+    work = [0.0] * W
+    B = [[0.0] * W for _ in range(nouter)]                 # arrival of panel k on rank i
+    first_done = [[0.0] * W for _ in range(nouter)]
+    rest_done = [[0.0] * W for _ in range(nouter)]
+
+    def factor_and_broadcast(k):
+        o = own(k)
+        start = p[o]
+        p[o] += f[k]
+        work[o] += f[k]
+        F = p[o]
+        if W == 1:
+            B[k][0] = F
+            return
+        nin = width[k]
+        for i in range(W):
+            t = c[i]
+            if k >= 3:
+                t = max(t, rest_done[k - 3][i])
+            if chunks:
+                for s2 in range(nin):
+                    ready = start + (s2 + 1) * (F - start) / nin
+                    t = max(t, ready) + alpha + col_tiles[k][s2] * tile_bytes / beta * 1e6
+            else:
+                t = max(t, F) + alpha + sum(col_tiles[k]) * tile_bytes / beta * 1e6
+            c[i] = t
+            B[k][i] = F if i == o else t            # (the owner reads its own storage: ready when factored)
+
+    factor_and_broadcast(0)
+    for k in range(nouter):
+        if k + 1 < nouter:
+            o = own(k + 1)
+            t = max(p[o], B[k][o])
+            if k >= 1:
+                t = max(t, first_done[k - 1][o] if split_rest else rest_done[k - 1][o])
+            p[o] = t + la[k]
+            work[o] += la[k]
+            factor_and_broadcast(k + 1)
+        lo = k + 2 if k + 1 < nouter else k + 1
+        tot = sum(wj[j] for j in range(lo, nouter)) or 1
+        for i in range(W):
+            t = max(mn[i], B[k][i])
+            mine = [j for j in range(lo, nouter) if own(j) == i]
+            share = sum(wj[j] for j in mine) / tot
+            dur_all = 0.0
+            if mine or (i == 0):                           # (rank 0 also updates the corner / rhs tile)
+                dur_all = max(rest[k] * share, floor_us if mine else 0.0) + launch_us
+            if W > 1 and split_rest and k + 2 < nouter and own(k + 2) == i:
+                d1 = max(rest[k] * wj[k + 2] / tot, floor_us) + launch_us
+                t += d1
+                first_done[k][i] = t
+                t += max(dur_all - d1, 0.0) + (launch_us if len(mine) > 1 else 0.0)
+                work[i] += max(dur_all, d1)
+            else:
+                t += dur_all
+                first_done[k][i] = t
+                work[i] += dur_all
+            rest_done[k][i] = t
+            mn[i] = t
+    path = max(max(mn), max(p)) + (alpha_us if W > 1 else 0.0)
+    return max(path, max(work)), path, max(work)
+
+
+def main():
+    path = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/owner_path_32768.json"
+    data = json.load(open(path))
+    a0 = float(sys.argv[2]) if len(sys.argv) > 2 else None
+    b0 = float(sys.argv[3]) if len(sys.argv) > 3 else None
+    links = [(a0, b0)] if a0 is not None and b0 is not None else [(10.0, 120.0), (20.0, 60.0), (40.0, 30.0)]
+    variants = [("default (per-tile-column broadcast)", "df0_fuse1", dict(chunks=True)),
+                ("dist_panel_df=2 (one launch per panel)", "df2_fuse0", dict(chunks=True)),
+                ("dist_panel_df=2 + two-hop broadcast", "df2_fuse0", dict(chunks=True, two_hop=True)),
+                ("default, REST(k-1) not split (round 4)", "df0_fuse1", dict(chunks=True, split_rest=False))]
+    print(f"# N = {data['N']}, outer panel = {data['panel_tiles']} tiles; times in ms; speed-up against the model's own one-rank time")
+    for alpha, beta in links:
+        print(f"## alpha = {alpha:.0f} us per collective, beta = {beta:.0f} GB/s per receiver")
+        print("| schedule | 1 GPU | 2 GPUs | 4 GPUs | 8 GPUs | speed-up at 8 | bound at 8 |")
+        print("|---|---|---|---|---|---|---|")
+        for name, mode, kw in variants:
+            if mode not in data["modes"]:
+                continue
+            t = {}
+            why = ""
+            for W in (1, 2, 4, 8):
+                tot, cp, wk = simulate(data, mode, W, alpha, beta, **kw)
+                t[W] = tot
+                if W == 8:
+                    why = "owner chain + links" if cp >= wk else "work per rank"
+            print(f"| {name} | {t[1] / 1e3:.1f} | {t[2] / 1e3:.1f} | {t[4] / 1e3:.1f} | {t[8] / 1e3:.1f} | {t[1] / t[8]:.2f}x | {why} |")
+        # what the chain alone costs at 8 ranks: the floor no link can beat
+        for name, mode, kw in variants[:2]:
+            if mode in data["modes"]:
+                m = data["modes"][mode]
+                print(f"   chain of '{name}': factor {sum(m['factor_us']) / 1e3:.1f} ms + look-ahead {sum(m['la_us']) / 1e3:.1f} ms; "
+                      f"trailing work {sum(m['rest_us']) / 1e3:.1f} ms / 8 = {sum(m['rest_us']) / 8e3:.1f} ms per rank")
+
+
+if __name__ == "__main__":
+    main()

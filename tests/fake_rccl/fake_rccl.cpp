@@ -7,7 +7,7 @@
 //     root:   stream-ordered D2H copy of its buffer into the segment, wait, barrier
 //     others: barrier, stream-ordered H2D copy out of the segment, wait;  barrier again before the segment is reused
 // Blocking the host inside a collective is slower than RCCL's asynchronous kernels but orders the data the same way.
-// Segment name: $FAKE_RCCL_SHM (every rank of a job gets the same value).
+// Segment name: $FAKE_RCCL_SHM (every rank of a job gets the same value) + the first four bytes of the unique id.
 // In-process mode (ncclCommInitAll: ONE process, several "devices" -- here the same GPU listed several times, which the
 // library accepts for RCCL only under GPHIP_COMM=rccl): calls between ncclGroupStart and ncclGroupEnd are recorded and
 // executed together at ncclGroupEnd -- the root's stream is drained, then every other rank's buffer is filled by a
@@ -32,7 +32,7 @@ struct Segment {
     double red[8 * 64];
     char data[CAP];
 };
-struct Comm { int rank, nranks; Segment* seg; };
+struct Comm { int rank, nranks; Segment* seg; char name[160]; };
 // kind: 0 broadcast (in-process mode only), 1 send (peer = root field), 2 recv (peer = root field), 3 all-gather (in-process mode)
 struct Op { const void* send; void* recv; size_t bytes; int root; Comm* comm; hipStream_t st; int kind; };
 int g_depth = 0;
@@ -46,9 +46,14 @@ struct FakeId { char internal[128]; };
 extern "C" {
 int ncclGetUniqueId(FakeId* id) { memset(id, 0, sizeof *id); memcpy(id->internal, "fake-rccl", 9); return 0; }
 
-int ncclCommInitRank(void** comm, int nranks, FakeId, int rank) {
-    const char* name = getenv("FAKE_RCCL_SHM");
-    if (!name) return 5;
+int ncclCommInitRank(void** comm, int nranks, FakeId id, int rank) {
+    const char* base = getenv("FAKE_RCCL_SHM");
+    if (!base) return 5;
+    // one segment per communicator: the job's name + the first bytes of the unique id (a job that makes a second communicator
+    // -- tests/multiproc_create_worker.py -- must not meet the first one's segment)
+    char name[160];
+    snprintf(name, sizeof name, "%.120s_%02x%02x%02x%02x", base, (unsigned char)id.internal[0], (unsigned char)id.internal[1],
+             (unsigned char)id.internal[2], (unsigned char)id.internal[3]);
     int fd = -1;
     if (rank == 0) {
         shm_unlink(name);
@@ -80,20 +85,22 @@ int ncclCommInitRank(void** comm, int nranks, FakeId, int rank) {
         for (int i = 0; i < 20000 && seg->ready.load() != 1; ++i) usleep(1000);
         if (seg->ready.load() != 1) return 2;
     }
-    *comm = new Comm{rank, nranks, seg};
+    Comm* cm = new Comm{rank, nranks, seg, {0}};
+    snprintf(cm->name, sizeof cm->name, "%s", name);
+    *comm = cm;
     pthread_barrier_wait(&seg->bar);
     return 0;
 }
 int ncclCommInitAll(void** comms, int n, const int*) {
     if (n > 64) return 3;
-    for (int i = 0; i < n; ++i) comms[i] = new Comm{i, n, nullptr};
+    for (int i = 0; i < n; ++i) comms[i] = new Comm{i, n, nullptr, {0}};
     return 0;
 }
 int ncclCommDestroy(void* c) {
     Comm* comm = static_cast<Comm*>(c);
     if (!comm->seg) { delete comm; return 0; }
     munmap(comm->seg, sizeof(Segment));
-    if (comm->rank == 0 && getenv("FAKE_RCCL_SHM")) shm_unlink(getenv("FAKE_RCCL_SHM"));
+    if (comm->rank == 0 && comm->name[0]) shm_unlink(comm->name);
     delete comm;
     return 0;
 }

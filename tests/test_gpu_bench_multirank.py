@@ -24,13 +24,13 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run(tmp_name, extra, world=2, timeout=600, want_rc=0):
+def _run(tmp_name, extra, world=2, timeout=600, want_rc=0, npoints=4096):
     fake = build.build_fake_rccl()
     env = dict(os.environ, GPHIP_BENCH_BACKEND="gloo", GPHIP_RCCL_PATH=fake, FAKE_RCCL_SHM=f"/gphip_bench_{os.getpid()}_{tmp_name}",
                LD_LIBRARY_PATH="/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "2",
-           "--warmup", "1", "--npoints", "4096"] + extra
+           "--warmup", "1", "--npoints", str(npoints)] + extra
     p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=timeout)
     assert (p.returncode == 0) == (want_rc == 0), (p.stdout + p.stderr)[-4000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
@@ -60,3 +60,21 @@ def test_strong_series_watchdog_keeps_the_headline():
     rec = _run("b", ["--strong-timeout", "0.001"], want_rc=3)
     assert rec["n_gpus"] == 2 and rec["value"] > 0
     assert "no result after" in rec["strong"]["error"] and rec["strong_speedup"] is None
+
+
+def test_eight_ranks_every_schedule_variant_at_sharding_size():
+    """The job the driver launches on an 8-GPU node -- 8 ranks, N large enough that the library shards by itself (16384 =
+    shard_min_n) -- with every schedule variant of the strong series: the default (per-tile-column broadcast, REST split so
+    that the look-ahead update waits for its own panel's piece only), the two-hop broadcast (grouped send / recv + in-place
+    all-gather), one-launch dataflow panels, and both together.  Eight processes share GPU 0 and the tests-only collective
+    library; what is checked is the control flow and that all variants return the same likelihoods."""
+    rec = _run("c", ["--strong-timeout", "600"], world=8, timeout=1500, npoints=16384)
+    assert rec["n_gpus"] == 8 and rec["value"] > 0 and rec["config"]["parallelism"] == "theta-sharded x8"
+    st = rec["strong"]
+    assert "error" not in st and "variants_error" not in st, st
+    assert st["rccl_ranks"] == 8 and st["all_ok"]
+    assert set(st["variants"]) == {"two_hop", "dist_panel_df", "two_hop_dist_panel_df"}
+    for name, v in st["variants"].items():
+        assert v["same_results"] and v["ms_per_eval"] > 0, (name, v)
+    assert st["two_hop_identical_results"] and st["best_variant"] in {"default", *st["variants"]}
+    assert rec["strong_best_variant"] == st["best_variant"] and rec["strong_best_speedup"] >= rec["strong_speedup"] > 0

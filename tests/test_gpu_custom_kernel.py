@@ -109,9 +109,9 @@ def test_arbitrary_covariance_functions_against_the_oracle(body, fn, npar, d, th
     hd = _lib.Handle(Xd, y, ck)
     zero_nug = th.copy(); zero_nug[-1] = 0.0
     assert hd.loglik(zero_nug)[1] == _lib.INFO_NOT_SPD and hd.loglik(th)[1] == 0
-    # gradient: central differences inside the library (no analytic derivative of a function it only has as text)
+    # gradient: one factorisation, the function instantiated with dual numbers (test_gradient_* below look closer)
     gl, gg, gi = h.loglik_grad(th)
-    assert gi == 0 and gl == ll
+    assert gi == 0 and close(gl, ll, n, 1e-12) and h.get_option("grad_analytic") == 1
     eps = 1e-5
     for k in range(len(th)):
         tp, tm = th.copy(), th.copy()
@@ -254,4 +254,93 @@ def test_cform_names_available_to_a_function_body():
     th = np.array([1.3, 0.2])
     ll, info = h.loglik(th)
     assert info == 0 and close(ll, orc.log_likelihood(ck, th, X, y), 200)
+    h.close()
+
+
+def _fd_grad(ck, th, X, y, mean="zero", eps=1e-5):
+    g = np.zeros(len(th))
+    for k in range(len(th)):
+        tp, tm = th.copy(), th.copy()
+        tp[k] += eps; tm[k] -= eps
+        g[k] = (orc.log_likelihood(ck, tp, X, y, mean) - orc.log_likelihood(ck, tm, X, y, mean)) / (2 * eps)
+    return g
+
+
+@pytest.mark.parametrize("n,d", [(700, 3), (1500, 8), (260, 40)])
+def test_gradient_by_dual_numbers_matches_the_named_kernel_and_the_oracle(n, d):
+    """SE-ARD handed over as text: gphip_loglik_grad instantiates the text with forward-mode dual numbers (gp_dual.h) inside
+    custom_grad_kernel -- ONE factorisation -- and must reproduce the oracle's analytic gradient (1e-7, the bar of the named
+    kernels' own gradient test) and the named kernel's device gradient.  d = 40: both points from global memory."""
+    X, y = syn.make_dataset(n, d)
+    th = syn.default_theta("se_ard", d) * np.concatenate([np.linspace(0.8, 1.3, d), [1.1, 1.0]])
+    ck = _lib.CustomKernel(SE_ARD_BODY, d + 1, fn=se_ard_fn)
+    h = _lib.Handle(X, y, ck)
+    h.set_option("profile", 1)
+    h.reset_profile()
+    ll, g, info = h.loglik_grad(th)
+    one = h.profile()["kbuild"]["bytes"]
+    assert info == 0 and h.get_option("grad_analytic") == 1
+    want = orc.log_likelihood_grad("se_ard", th, X, y)
+    np.testing.assert_allclose(g, want, rtol=1e-7, atol=1e-7 * n)
+    assert close(ll, orc.log_likelihood("se_ard", th, X, y), n)
+    if d <= 32:                                               # (the named kernels' gradient stops at 32 dimensions)
+        ref = _lib.Handle(X, y, "se_ard")
+        l0, g0, _ = ref.loglik_grad(th)
+        np.testing.assert_allclose(g, g0, rtol=1e-9, atol=1e-9 * n)
+        ref.close()
+    # the factor of theta stays resident, as after the named kernels' gradient
+    mu, var = h.predict(syn.make_test_points(20, d))
+    mo, so = orc.predict_internal(ck, th, X, y, syn.make_test_points(20, d))
+    np.testing.assert_allclose(mu, mo, rtol=1e-7, atol=1e-9)
+    # the difference route: 2 p + 1 kernel builds and factorisations for the same answer to ~1e-6
+    h.set_option("custom_grad", 0)
+    h.reset_profile()
+    ll2, g2, info2 = h.loglik_grad(th)
+    many = h.profile()["kbuild"]["bytes"]
+    assert info2 == 0 and h.get_option("grad_analytic") == 0
+    assert many >= (2 * len(th) + 1) * one * 0.99
+    np.testing.assert_allclose(g2, want, rtol=2e-5, atol=2e-5 * n)
+    h.close()
+
+
+@pytest.mark.parametrize("body,fn,ncp,d,theta", [
+    (NONSTAT_BODY, nonstat_fn, 3, 2, [0.9, 1.2, 0.7, 0.15]),
+    (PERIODIC_BODY, periodic_fn, 3, 1, [1.3, 0.8, 1.1, 0.2]),
+])
+def test_gradient_of_nonstationary_and_cform_functions(body, fn, ncp, d, theta):
+    n = 500
+    X, y = syn.make_dataset(n, d)
+    ck = _lib.CustomKernel(body, ncp, fn=fn)
+    for mean in ("zero", "const"):
+        th = np.array(theta + ([0.3] if mean == "const" else []))
+        h = _lib.Handle(X, y, ck, mean=mean)
+        ll, g, info = h.loglik_grad(th)
+        assert info == 0 and h.get_option("grad_analytic") == 1
+        np.testing.assert_allclose(g, _fd_grad(ck, th, X, y, mean), rtol=2e-6, atol=2e-6 * n)
+        h.close()
+
+
+def test_gradient_fp32_and_fallback_for_a_body_that_cannot_be_differentiated():
+    n, d = 600, 3
+    X, y = syn.make_dataset(n, d)
+    th = syn.default_theta("se_ard", d, dtype="f32")
+    ck = _lib.CustomKernel(SE_ARD_BODY, d + 1, fn=se_ard_fn)
+    want = orc.log_likelihood_grad("se_ard", th, X, y)
+    h32 = _lib.Handle(X, y, ck, dtype=32)
+    ll, g, info = h32.loglik_grad(th)
+    assert info == 0 and h32.get_option("grad_analytic") == 1
+    np.testing.assert_allclose(g, want, rtol=2e-2, atol=2e-2 * np.abs(want).max())
+    h32.set_option("custom_grad", 0)                          # fp32 differences: step 5e-3 |theta|, a few per cent
+    ll, g, info = h32.loglik_grad(th)
+    assert info == 0 and h32.get_option("grad_analytic") == 0
+    np.testing.assert_allclose(g, want, rtol=0.1, atol=0.1 * np.abs(want).max())
+    h32.close()
+    # intermediates of a fixed scalar type: the value program compiles, the dual-number program does not -> differences
+    fixed = ("double s = 0; for (int k = 0; k < D; ++k) { const double u = (double)(X(k) - Y(k)) / (double)P(k); s += u * u; } "
+             "return (T)((double)P(D) * (double)P(D) * exp(-0.5 * s));")
+    h = _lib.Handle(X, y, _lib.CustomKernel(fixed, d + 1, fn=se_ard_fn))
+    th64 = syn.default_theta("se_ard", d)
+    ll, g, info = h.loglik_grad(th64)
+    assert info == 0 and h.get_option("grad_analytic") == 0
+    np.testing.assert_allclose(g, orc.log_likelihood_grad("se_ard", th64, X, y), rtol=2e-5, atol=2e-5 * n)
     h.close()

@@ -141,3 +141,39 @@ def test_rank_local_failure_never_leaves_peers_in_a_collective(tmp_path, fault, 
         ll, ld, qd, info = r["after"]["value"]
         assert info == 0 and close(ll, want[0], n) and close(ld, want[1], n) and close(qd, want[2], n)
     assert any("another rank" in r["faulted"]["msg"] or "disagree" in r["faulted"]["msg"] for r in res if r["rank"] != fault_rank) or world == 1
+
+
+@pytest.mark.parametrize("world,bad_rank", [(2, 1), (3, 0)])
+def test_create_failure_on_one_rank_fails_every_rank(tmp_path, world, bad_rank):
+    """gphip_create_custom_rank with a covariance function that does not compile on ONE rank (tests/multiproc_create_worker.py):
+    the failing rank still joins the communicator and the ranks all-reduce a create status, so every rank comes back from the
+    create call with an error (the healthy ones: GPHIP_ERR_STATE, 'another rank ..') instead of waiting in ncclCommInitRank for
+    ever; the same processes then create a healthy job and evaluate."""
+    fake = build.build_fake_rccl()
+    env = dict(os.environ, GPHIP_NO_TORCH="1", GPHIP_RCCL_PATH=fake, FAKE_RCCL_SHM=f"/gphip_create_{os.getpid()}_{world}_{bad_rank}",
+               LD_LIBRARY_PATH="/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+    outs = [str(tmp_path / f"rank{r}.json") for r in range(world)]
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "multiproc_create_worker.py"), str(r), str(world), outs[r],
+                               str(bad_rank)], env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for r in range(world)]
+    logs = []
+    for p in procs:
+        try:
+            logs.append(p.communicate(timeout=240)[0])
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            pytest.fail("a rank hung in the create call of a job whose peer failed")
+    assert all(p.returncode == 0 for p in procs), "\n".join(logs)[-3000:]
+    res = [json.load(open(o)) for o in outs]
+    for r in res:
+        assert not r["first"]["ok"], r
+        if r["rank"] == bad_rank:
+            assert r["first"]["status"] == 1 and "this_symbol_does_not_exist" in r["first"]["msg"], r
+        else:
+            assert r["first"]["status"] == 4 and "another rank" in r["first"]["msg"], r
+    X, y = syn.make_dataset(700, 3)
+    want = orc.log_likelihood("se_ard", syn.default_theta("se_ard", 3), X, y, parts=True)
+    for r in res:
+        ll, ld, qd, info = r["second"]
+        assert info == 0 and close(ll, want[0], 700) and close(ld, want[1], 700) and close(qd, want[2], 700)
