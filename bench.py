@@ -51,7 +51,7 @@ def _roof(cls: dict, peak: float, unit: str, what: str) -> dict:
 
 def cpu_baseline(n_full: int, d: int, max_full_s: float = 600.0) -> dict:
     """Times the CPU oracle (numpy kernel-matrix build + scipy LAPACK LU, the algorithm LinearSolve uses) WHOLE, on the
-    host cores of this box: one evaluation at N = 8192 (thread-count ladder), one at N = 16384 and -- unless the N = 16384
+    host cores of this box: one evaluation at N = 8192, one at N = 16384 (LAPACK thread-count ladder there) and -- unless the N = 16384
     sample predicts more than `max_full_s` seconds ("32768 if < 10 min") -- one at the metric's own
     size N = n_full.  `value` is then MEASURED, not extrapolated; the cubic-law prediction from the smaller samples is
     kept under `also` so the two can be compared.  For information it also times a Cholesky variant and cfg 1
@@ -101,23 +101,39 @@ def cpu_baseline(n_full: int, d: int, max_full_s: float = 600.0) -> dict:
             t2 = time.perf_counter()
         return t1 - t0, t2 - t1, ll
 
-    # LAPACK on very many threads can be slower than on fewer: pick the LU's thread count on a short ladder AT N = 8192
-    # (round 3 chose it at N = 4096, where 16 threads won; the measured sizes are 4-8x larger)
-    ladder = sorted({t for t in (16, 32, 64, 128, threads) if t <= threads})
-    Xl, yl = syn.make_dataset(8192, d)
-    Kl = orc.covariance_matrix("se_ard", th, Xl)
+    # LAPACK on very many threads can be slower than on fewer: pick the LU's thread count on a short ladder AT N = 16384 (round 3
+    # chose it at N = 4096, round 4 at N = 8192 -- where the first LU of the process ran 1.5x slower than the N = 16384 one that
+    # followed it: cold pages / thread pool).  Every size is therefore WARMED once (an untimed LU of that size) before it is
+    # timed, and the ladder stops as soon as more threads have lost twice.
+    n_lad = 16384 if n_full > 16384 else max(2048, n_full // 2)
+    Xl, yl = syn.make_dataset(n_lad, d)
+    orc.BUILD_THREADS = build_threads
+    try:
+        with limited(1):
+            Kl = orc.covariance_matrix("se_ard", th, Xl)
+    finally:
+        orc.BUILD_THREADS = 1
     probe = {}
-    for t in ladder:
+    worse = 0
+    for i, t in enumerate(sorted({t for t in (8, 16, 32, 64, 128) if t <= threads} or {threads})):
         with limited(t):
-            Kc = Kl.copy()
-            t0 = time.perf_counter()
-            sla.lu_factor(Kc, overwrite_a=True, check_finite=False)
-            probe[t] = time.perf_counter() - t0
+            for rep in range(2 if i == 0 else 1):               # (first entry: one untimed LU warms the size)
+                Kc = Kl.copy()
+                t0 = time.perf_counter()
+                sla.lu_factor(Kc, overwrite_a=True, check_finite=False)
+                probe[t] = time.perf_counter() - t0
+        worse = worse + 1 if probe[t] > min(probe.values()) else 0
+        if worse >= 2:
+            break
     del Kl, Kc
     threads = min(probe, key=probe.get)
     measured = {}
     for n in (8192, 16384):
         if n < n_full:
+            if n != n_lad:
+                with limited(threads):                           # warm this size
+                    Xw2, _ = syn.make_dataset(n, d)
+                    sla.lu_factor(orc.covariance_matrix("se_ard", th, Xw2), overwrite_a=True, check_finite=False)
             tb, tf, ll = timed(n, threads)
             measured[n] = (tb, tf, ll)
     n_ref = max(measured) if measured else None
@@ -150,7 +166,7 @@ def cpu_baseline(n_full: int, d: int, max_full_s: float = 600.0) -> dict:
         t_cfg1 = (time.perf_counter() - t0) / 5
     return {"value": 1.0 / est, "unit": "evals/s", "cores": int(max(threads, build_threads)), "kind": "port",
             "threads": {"lu": int(threads), "build_pool": int(build_threads),
-                        "lu_ladder_s_at_N8192": {str(k): round(v, 3) for k, v in sorted(probe.items())}},
+                        "lu_ladder_at_N": int(n_lad), "lu_ladder_s": {str(k): round(v, 3) for k, v in sorted(probe.items())}},
             "sample": "CPU oracle (numpy build + scipy dgetrf/dgetrs LU restatement of BGP:29-43,130-141,181-199; not "
                       f"Mathematica), d={d}, whole evaluations. " + how,
             "measured": {f"N{n}": {"build_s": round(v[0], 3), "lu_solve_s": round(v[1], 3), "loglik": v[2]}
@@ -187,7 +203,7 @@ def under_profiler() -> bool:
     return any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
 
 
-def _pmc_pass(counters, n: int, d: int, device: int):
+def _pmc_pass(counters, n: int, d: int, device: int, probe: str = "--pmc-probe"):
     """One child process (`bench.py --pmc-probe`: this file, no torch, two evaluations) under `rocprofv3 --pmc <counters>` --
     counters only, no trace domain next to them, as MI355X_MICROARCH.md prescribes.  Returns the rows of the counter CSV, or
     None when rocprofv3 is missing, this process is itself being profiled, or the pass fails."""
@@ -204,7 +220,7 @@ def _pmc_pass(counters, n: int, d: int, device: int):
         env = dict(os.environ, TMPDIR="/tmp", GPHIP_NO_TORCH="1", HIP_VISIBLE_DEVICES=os.environ.get("HIP_VISIBLE_DEVICES", str(device)),
                    LD_LIBRARY_PATH="/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
         cmd = [exe, "--pmc"] + list(counters) + ["--output-format", "csv", "-d", tmp, "-o", "p", "--", sys.executable,
-               os.path.join(ROOT, "bench.py"), "--pmc-probe", "--npoints", str(n), "--dim", str(d)]
+               os.path.join(ROOT, "bench.py"), probe, "--npoints", str(n), "--dim", str(d)]
         res = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
         if res.returncode != 0:
             return None
@@ -296,6 +312,74 @@ def pmc_probe(n: int, d: int) -> None:
     h.close()
 
 
+SEPARATOR_KERNEL = "kbuild_kernel<double, 0, 2>"        # what a Matern-3/2 handle's covariance() launches: marks config boundaries
+
+
+def pmc_probe_mid() -> None:
+    """Child of mid_config_clocks: cfg 1, cfg 2 and a cfg-4 batch one after the other, a separator launch between them."""
+    from bayesianinference_amd import _lib, synthetic as syn
+    Xm, ym = syn.make_dataset(128, 2)
+    sep = _lib.Handle(Xm, ym, "matern32_ard")
+    ths = syn.default_theta("se_ard", 2)
+
+    def mark():
+        sep.covariance(ths)
+    for n, d, kernel, reps in ((512, 1, "se", 40), (8192, 8, "se_ard", 12)):
+        X, y = syn.make_dataset(n, d)
+        h = _lib.Handle(X, y, kernel)
+        th = syn.default_theta(kernel, d)
+        h.loglik(th); h.loglik(th)
+        mark()
+        for _ in range(reps):
+            h.loglik(th)
+        mark()
+        h.close()
+    X, y = syn.make_dataset(4096, 8)
+    Th = syn.theta_batch(200, "se_ard", 8)
+    Th[:, -1] = np.maximum(Th[:, -1], 0.05)
+    h = _lib.Handle(X, y, "se_ard")
+    h.loglik_batch(Th)
+    mark()
+    h.loglik_batch(Th)
+    mark()
+    h.close()
+    sep.close()
+
+
+def mid_config_clocks(device: int):
+    """Shader clock the chip holds while it runs cfg 1 / cfg 2 / the cfg-4 batch (one rocprofv3 --pmc SQ_BUSY_CYCLES pass over
+    bench.py --pmc-probe-mid): sum of SQ_BUSY_CYCLES / 32 shader engines over the config's launches / sum of their durations.
+    Lets a reader tell a slower box (lower clock, same code) from slower code (same clock)."""
+    rows = _pmc_pass(["SQ_BUSY_CYCLES"], 0, 0, device, probe="--pmc-probe-mid")
+    if rows is None:
+        return None
+    per = {}
+    for r in rows:
+        if r["Counter_Name"] != "SQ_BUSY_CYCLES":
+            continue
+        e = per.setdefault(int(r["Dispatch_Id"]), {"name": r["Kernel_Name"], "ns": float(r["End_Timestamp"]) - float(r["Start_Timestamp"]), "cyc": 0.0})
+        e["cyc"] += float(r["Counter_Value"]) / 32.0
+    seq = [per[k] for k in sorted(per)]
+    segs, cur, inside = [], [], False
+    for e in seq:
+        if SEPARATOR_KERNEL in e["name"]:
+            if inside:
+                segs.append(cur)
+            cur, inside = [], not inside
+        elif inside:
+            cur.append(e)
+    names = ["cfg1_n512_d1_f64", "cfg2_n8192_d8_f64", "cfg4_batch_200x4096_f64"]
+    if len(segs) != len(names):
+        return None
+    out = {}
+    for nm, seg in zip(names, segs):
+        big = [e for e in seg if e["ns"] > 2.0e4] or seg       # launches of >= 20 us carry the clock; tiny ones are dispatch-bound
+        ns, cyc = sum(e["ns"] for e in big), sum(e["cyc"] for e in big)
+        if ns > 0:
+            out[nm] = {"shader_clock_ghz": cyc / ns, "launches": len(seg), "kernel_ms_total": sum(e["ns"] for e in seg) * 1e-6}
+    return out
+
+
 def other_configs(local_rank: int) -> dict:
     """Short measurements of the other BASELINE.json configs on one GPU (reported next to the headline,
     never part of `value`): cfg 1 / cfg 2 = one theta at a time at N=512 d=1 and N=8192 d=8 (the
@@ -304,16 +388,34 @@ def other_configs(local_rank: int) -> dict:
     from bayesianinference_amd import _lib, synthetic as syn
     out = {}
     try:
-        for name, n, d, kernel, reps in (("cfg1_n512_d1_f64", 512, 1, "se", 200), ("cfg2_n8192_d8_f64", 8192, 8, "se_ard", 10)):
+        for name, n, d, kernel, reps in (("cfg1_n512_d1_f64", 512, 1, "se", 400), ("cfg2_n8192_d8_f64", 8192, 8, "se_ard", 60)):
             X, y = syn.make_dataset(n, d)
             th = syn.default_theta(kernel, d)
             h = _lib.Handle(X, y, kernel, device=local_rank)
-            h.loglik(th); h.loglik(th)
-            t0 = time.perf_counter()
-            for _ in range(reps):
+            for _ in range(5):
+                h.loglik(th)
+            # every evaluation timed on its own (host clock around the blocking call = what a sequential MCMC chain pays,
+            # BS:707-745): median and minimum say what the code does, the mean what a noisy box adds
+            ts = np.empty(reps)
+            for i in range(reps):
+                t0 = time.perf_counter()
                 _, info = h.loglik(th)
-            dt = (time.perf_counter() - t0) / reps
-            out[name] = {"ms_per_eval": dt * 1e3, "evals_per_s": 1.0 / dt, "info": int(info)}
+                ts[i] = time.perf_counter() - t0
+            # the same evaluation between HIP events on the library's stream (profile class eval_total: no host time)
+            h.set_option("profile", 1)
+            h.loglik(th)
+            h.reset_profile()
+            for _ in range(20):
+                h.loglik(th)
+            ev = h.profile()["eval_total"]
+            h.set_option("profile", 0)
+            med = float(np.median(ts))
+            out[name] = {"ms_per_eval": med * 1e3, "evals_per_s": 1.0 / med, "info": int(info), "reps": int(reps),
+                         "ms_min": float(ts.min()) * 1e3, "ms_mean": float(ts.mean()) * 1e3, "ms_p90": float(np.quantile(ts, 0.9)) * 1e3,
+                         "ms_hip_events": ev["ms"] / max(ev["launches"], 1),
+                         "cholesky_tflops_at_median": n ** 3 / 3.0 / med / 1e12,
+                         "timing": "median of per-evaluation host-clock times (blocking call); ms_hip_events = device time of the "
+                                   "same evaluation between HIP events on the library's stream"}
             h.close()
     except Exception as exc:                                    # never let an extra break the headline
         out["cfg1_cfg2_error"] = repr(exc)
@@ -324,11 +426,36 @@ def other_configs(local_rank: int) -> dict:
         h = _lib.Handle(X, y, "se_ard", device=local_rank)
         h.loglik_batch(Th[:8])
         h.loglik_batch(Th)
-        t0 = time.perf_counter()
-        _, info = h.loglik_batch(Th)
-        dt = time.perf_counter() - t0
+        ts = np.empty(5)
+        for i in range(5):
+            t0 = time.perf_counter()
+            _, info = h.loglik_batch(Th)
+            ts[i] = time.perf_counter() - t0
+        dt = float(np.median(ts))
+        # per launch class (HIP events of the library's profile mode, one more batch): which class holds the batch where
+        h.set_option("profile", 1)
+        h.loglik_batch(Th)
+        h.reset_profile()
+        h.loglik_batch(Th)
+        prof = h.profile()
+        h.set_option("profile", 0)
+        classes = {}
+        for cls, what, peak, unit in (("syrk_trailing", "trailing SYRK / GEMM updates (gemm_nt_kernel<double, 0, ..>)", FP64_MFMA_PEAK_TFLOPS, "TFLOP/s"),
+                                      ("gemm_panel", "in-panel and look-ahead GEMM updates (K = 128 .. 512)", FP64_MFMA_PEAK_TFLOPS, "TFLOP/s"),
+                                      ("trsm", "panel solves X <- A W^T (gemm_nt mode 1)", FP64_MFMA_PEAK_TFLOPS, "TFLOP/s"),
+                                      ("potrf", "128 x 128 diagonal blocks (potrf128_kernel / fused)", FP64_MFMA_PEAK_TFLOPS, "TFLOP/s"),
+                                      ("kbuild", "kernel-matrix build", HBM_PEAK_GBS, "GB/s")):
+            r = _roof(prof[cls], peak, unit, what)
+            if r:
+                r["ms_total"] = prof[cls]["ms"]
+                classes[cls] = r
         out["cfg4_batch_200x4096_f64"] = {"evals_per_s": 200 / dt, "tflops": 200 * 4096 ** 3 / 3 / dt / 1e12,
-                                          "failed": int((info != 0).sum())}
+                                          "frac_of_fp64_mfma_peak": 200 * 4096 ** 3 / 3 / dt / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+                                          "failed": int((info != 0).sum()), "ms_per_batch_median": dt * 1e3, "ms_per_batch_min": float(ts.min()) * 1e3,
+                                          "reps": 5, "ms_hip_events": prof["eval_total"]["ms"] / max(prof["eval_total"]["launches"], 1),
+                                          "classes": classes,
+                                          "classes_note": "profile mode brackets every launch with its own event pair: the classes' "
+                                                          "sum exceeds the un-profiled batch time where launches of the two streams overlap"}
         h.close()
     except Exception as exc:                                    # never let an extra break the headline
         out["cfg4_error"] = repr(exc)
@@ -398,6 +525,7 @@ def main() -> None:
                                                             "(profiling runs: keeps the rocprof launch statistics those of the timed schedule)")
     ap.add_argument("--no-extras", action="store_true", help="skip the short BASELINE.json cfg-4 / cfg-5 measurements")
     ap.add_argument("--pmc-probe", action="store_true", help=argparse.SUPPRESS)      # child mode of live_pmc_traffic
+    ap.add_argument("--pmc-probe-mid", action="store_true", help=argparse.SUPPRESS)  # child mode of mid_config_clocks
     ap.add_argument("--no-live-pmc", action="store_true", help="do not measure roofline.traffic in this run (two rocprofv3 --pmc "
                                                                "passes over a child process); replay profiles/ instead")
     ap.add_argument("--strong-timeout", type=float, default=180.0, help="seconds the strong-scaling series may take before the "
@@ -412,6 +540,9 @@ def main() -> None:
     if world != args.gpus and world > 1:
         args.gpus = world
 
+    if args.pmc_probe_mid:
+        pmc_probe_mid()
+        return
     if args.pmc_probe:
         pmc_probe(args.n, args.d)
         return
@@ -730,6 +861,11 @@ def main() -> None:
         if world == 1 and not args.no_extras:
             h.close()                                           # free the 8.7 GB workspace first
             out["other_configs"] = other_configs(local_rank)
+            if not args.no_live_pmc:
+                clocks = mid_config_clocks(local_rank)
+                for nm, v in (clocks or {}).items():
+                    if nm in out["other_configs"]:
+                        out["other_configs"][nm]["clock_probe"] = v
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(n, d)
         print(json.dumps(out), flush=True)

@@ -1,6 +1,9 @@
 """Condenses a gpurun_out/<tag>/ rocprofv3 capture (scripts/profile_gpu.sh) into the small text
 summaries committed under profiles/: the --kernel-trace --stats table and per-kernel PMC averages
-(HBM bytes per launch with the gfx950 FETCH_SIZE x2 correction of MI355X_MICROARCH.md §HBM)."""
+(HBM bytes per launch with the gfx950 FETCH_SIZE x2 correction of MI355X_MICROARCH.md §HBM).
+   python scripts/summarize_profile.py <capture dir> <dst dir> <tag> [trace subdir [comma-separated PMC subdirs]]
+   e.g.  ... gpurun_out/r05 profiles r05                      (trace/, pmc_fetch, pmc_write, pmc_sq, pmc_valu)
+         ... gpurun_out/r05 profiles r05_cfg4 trace_cfg4 pmc_cfg4_fetch,pmc_cfg4_write,pmc_cfg4_sq"""
 import collections
 import csv
 import os
@@ -8,11 +11,14 @@ import shutil
 import sys
 
 src, dst, tag = sys.argv[1], sys.argv[2], sys.argv[3]
+trace = sys.argv[4] if len(sys.argv) > 4 else "trace"
+subs = sys.argv[5].split(",") if len(sys.argv) > 5 else ["pmc_fetch", "pmc_write", "pmc_sq", "pmc_valu"]
 os.makedirs(dst, exist_ok=True)
-shutil.copy(os.path.join(src, "trace", "bench_kernel_stats.csv"), os.path.join(dst, f"{tag}_kernel_stats.csv"))
+if os.path.exists(os.path.join(src, trace, "bench_kernel_stats.csv")):
+    shutil.copy(os.path.join(src, trace, "bench_kernel_stats.csv"), os.path.join(dst, f"{tag}_kernel_stats.csv"))
 lines = []
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
-for sub in ("pmc_fetch", "pmc_write", "pmc_sq"):
+for sub in subs:
     path = os.path.join(src, sub, "bench_counter_collection.csv")
     if not os.path.exists(path):
         continue
@@ -40,6 +46,9 @@ for k in sorted(agg):
     b = agg[k].get("SQ_BUSY_CYCLES")
     if m and b and sum(m) > 0:
         lines.append(f"# {k}: SQ_VALU_MFMA_BUSY_CYCLES/launch {sum(m)/len(m):.4g}, SQ_BUSY_CYCLES/launch {sum(b)/len(b):.4g}")
+    iv, im = agg[k].get("SQ_INSTS_VALU"), agg[k].get("SQ_INSTS_MFMA")
+    if iv and "kbuild" in k:
+        lines.append(f"# {k}: SQ_INSTS_VALU/launch {sum(iv)/len(iv):.4g}" + (f", SQ_INSTS_MFMA/launch {sum(im)/len(im):.4g}" if im else ""))
 with open(os.path.join(dst, f"{tag}_pmc_summary.csv"), "w") as f:
     f.write("\n".join(lines) + "\n")
 print("\n".join(lines[-12:]))
