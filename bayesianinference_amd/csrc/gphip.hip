@@ -19,6 +19,7 @@
 #include <hip/hip_ext.h>
 
 #include <algorithm>
+#include <cctype>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -3458,6 +3459,8 @@ int gphip_sync(gphip_handle h) {
     HIPCHK(hipStreamSynchronize(h->stream));
     return GPHIP_OK;
 }
+
+#include "gphip_hostlogic.inc"
 
 }  // extern "C"
 

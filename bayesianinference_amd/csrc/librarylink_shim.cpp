@@ -18,6 +18,7 @@
 #include <algorithm>
 #include <limits>
 #include <cmath>
+#include <cstring>
 #include <vector>
 
 #include "WolframLibrary.h"
@@ -92,23 +93,47 @@ EXTERN_C DLLEXPORT int gphip_wl_create(WolframLibraryData lib, mint argc, MArgum
     return LIBRARY_NO_ERROR;
 }
 
-// gphip_wl_create_custom[X (N x d), y (N), body (C statements of the covariance function, see gphip_create_custom), nparams,
-// meanId, dtype, device] -> handle id.  ANY `kernel @@ points[[{i,j}]]` of the reference (BGP:29-33): GPHIP.wl prints the pure
-// function with CForm and hands the text over; the library compiles it at run time into its own kernel build.  A body that
-// does not compile returns LIBRARY_FUNCTION_ERROR (the package then falls back to the reference's own path).
+// gphip_wl_kernel_spec[name, d] -> {kernelId, term1, op, term2, offset, params of term 1, of term 2, 0-based index of sigma_n}
+// (gphip_kernel_parse: the kernel-name grammar lives in the library, not in the package); {-1, ..} = not a kernel of the library
+EXTERN_C DLLEXPORT int gphip_wl_kernel_spec(WolframLibraryData lib, mint argc, MArgument* args, MArgument res) {
+    if (argc != 2) return LIBRARY_FUNCTION_ERROR;
+    char* name = MArgument_getUTF8String(args[0]);
+    int spec[8];
+    const int rc = gphip_kernel_parse(name, (int64_t)MArgument_getInteger(args[1]), spec);
+    lib->UTF8String_disown(name);
+    MTensor r; mint dims[1] = {8};
+    if (lib->MTensor_new(MType_Integer, 1, dims, &r)) return LIBRARY_FUNCTION_ERROR;
+    for (int i = 0; i < 8; ++i) lib->MTensor_getIntegerData(r)[i] = rc == GPHIP_OK ? spec[i] : -1;
+    MArgument_setMTensor(res, r);
+    return LIBRARY_NO_ERROR;
+}
+
+// gphip_wl_create_custom[X (N x d), y (N), cform, nparams, meanId, dtype, devices (integer list, may be empty)] -> handle id.
+// ANY `kernel @@ points[[{i,j}]]` of the reference (BGP:29-33): GPHIP.wl applies the pure function to two points of stand-in
+// symbols (..gphipXc<k>, ..gphipYc<k>; hyper-parameters ..gphipPc<k>) and hands over ToString[CForm[..]] AS IT IS; the
+// translation to the function body (gphip_cform_to_body) and the run-time compilation into the library's kernel build happen
+// here.  Text that is no C expression, or does not compile, returns LIBRARY_FUNCTION_ERROR (the package then falls back to the
+// reference's own path; gphip_create_error() has the compiler's log).
 EXTERN_C DLLEXPORT int gphip_wl_create_custom(WolframLibraryData lib, mint argc, MArgument* args, MArgument res) {
     if (argc != 7) return LIBRARY_FUNCTION_ERROR;
-    MTensor X = MArgument_getMTensor(args[0]), y = MArgument_getMTensor(args[1]);
-    if (lib->MTensor_getRank(X) != 2 || lib->MTensor_getRank(y) != 1) return LIBRARY_RANK_ERROR;
-    if (lib->MTensor_getType(X) != MType_Real || lib->MTensor_getType(y) != MType_Real) return LIBRARY_TYPE_ERROR;
+    MTensor X = MArgument_getMTensor(args[0]), y = MArgument_getMTensor(args[1]), dv = MArgument_getMTensor(args[6]);
+    if (lib->MTensor_getRank(X) != 2 || lib->MTensor_getRank(y) != 1 || lib->MTensor_getRank(dv) != 1) return LIBRARY_RANK_ERROR;
+    if (lib->MTensor_getType(X) != MType_Real || lib->MTensor_getType(y) != MType_Real || lib->MTensor_getType(dv) != MType_Integer)
+        return LIBRARY_TYPE_ERROR;
     const mint* dims = lib->MTensor_getDimensions(X);
     if (lib->MTensor_getDimensions(y)[0] != dims[0]) return LIBRARY_DIMENSION_ERROR;
-    char* body = MArgument_getUTF8String(args[2]);
+    const mint ndev = lib->MTensor_getDimensions(dv)[0];
+    std::vector<int> devs((size_t)ndev);
+    for (mint i = 0; i < ndev; ++i) devs[(size_t)i] = (int)lib->MTensor_getIntegerData(dv)[i];
+    char* cform = MArgument_getUTF8String(args[2]);
+    std::vector<char> body(strlen(cform) + 64);
+    int rc = gphip_cform_to_body(cform, body.data(), (int64_t)body.size());
+    lib->UTF8String_disown(cform);
+    if (rc != GPHIP_OK) return LIBRARY_FUNCTION_ERROR;
     gphip_handle h = nullptr;
-    const int rc = gphip_create_custom(lib->MTensor_getRealData(X), lib->MTensor_getRealData(y), dims[0], dims[1], body,
-                                       (int)MArgument_getInteger(args[3]), (int)MArgument_getInteger(args[4]),
-                                       (int)MArgument_getInteger(args[5]), (int)MArgument_getInteger(args[6]), &h);
-    lib->UTF8String_disown(body);
+    rc = gphip_create_custom_devices(lib->MTensor_getRealData(X), lib->MTensor_getRealData(y), dims[0], dims[1], body.data(),
+                                     (int)MArgument_getInteger(args[3]), (int)MArgument_getInteger(args[4]),
+                                     (int)MArgument_getInteger(args[5]), ndev ? devs.data() : nullptr, (int)ndev, &h);
     if (rc == GPHIP_ERR_ARG) return LIBRARY_FUNCTION_ERROR;          // the body does not compile (gphip_create_error() has the log)
     if (rc != GPHIP_OK) return status_to_wl(rc);
     g_handles.push_back(h);
@@ -500,8 +525,8 @@ double tab_logprior(const double* th, int p, void* user) {
 }  // namespace
 
 // gphip_wl_nested_sampling_tab[h, box (p x 2), logPriorTables (p x m, m >= 4: log density of factor j at the m grid nodes of
-//   [min_j, max_j]), opts (as gphip_wl_nested_sampling), start (pool x p, REQUIRED: drawn from the prior by the caller)]
-//   -> n x (p + 3) rows as gphip_wl_nested_sampling
+//   [min_j, max_j]), opts (as gphip_wl_nested_sampling), start (pool x p, or {} = the library draws opts[[1]] points from the
+//   tabulated prior itself: gphip_tab_prior_sample, seeded with opts[[9]])]  -> n x (p + 3) rows as gphip_wl_nested_sampling
 EXTERN_C DLLEXPORT int gphip_wl_nested_sampling_tab(WolframLibraryData lib, mint argc, MArgument* args, MArgument res) {
     if (argc != 5) return LIBRARY_FUNCTION_ERROR;
     gphip_handle h = lookup(MArgument_getInteger(args[0]));
@@ -511,25 +536,33 @@ EXTERN_C DLLEXPORT int gphip_wl_nested_sampling_tab(WolframLibraryData lib, mint
     if (int e = want_real(lib, box, 2)) return e;
     if (int e = want_real(lib, tab, 2)) return e;
     if (int e = want_real(lib, ov, 1)) return e;
-    if (int e = want_real(lib, st, 2)) return e;
+    const bool draw = lib->MTensor_getRank(st) == 1 && lib->MTensor_getDimensions(st)[0] == 0;      // {}: no starting points given
+    if (!draw)
+        if (int e = want_real(lib, st, 2)) return e;
     int p = 0;
     gphip_num_params(h, &p);
     const mint m = lib->MTensor_getDimensions(tab)[1];
     if (lib->MTensor_getDimensions(box)[0] != p || lib->MTensor_getDimensions(box)[1] != 2 || lib->MTensor_getDimensions(tab)[0] != p ||
-        m < 4 || lib->MTensor_getDimensions(ov)[0] != 9 || lib->MTensor_getDimensions(st)[1] != p)
+        m < 4 || lib->MTensor_getDimensions(ov)[0] != 9 || (!draw && lib->MTensor_getDimensions(st)[1] != p))
         return LIBRARY_DIMENSION_ERROR;
     const double* o = lib->MTensor_getRealData(ov);
     gphip_ns_options opt;
     gphip_ns_default_options(&opt);
-    opt.pool = (int)lib->MTensor_getDimensions(st)[0]; opt.max_iterations = (int)o[1]; opt.min_iterations = (int)o[2]; opt.mc_steps = (int)o[3];
+    opt.pool = draw ? (int)o[0] : (int)lib->MTensor_getDimensions(st)[0]; opt.max_iterations = (int)o[1]; opt.min_iterations = (int)o[2];
+    opt.mc_steps = (int)o[3];
     opt.walkers = (int)o[4]; opt.termination_fraction = o[5]; opt.min_accept = o[6]; opt.max_accept = o[7]; opt.seed = (uint64_t)o[8];
     if (opt.pool < 2) return LIBRARY_DIMENSION_ERROR;
     TabPrior tp{p, m, lib->MTensor_getRealData(box), lib->MTensor_getRealData(tab)};
+    std::vector<double> drawn;
+    if (draw) {                                            // generateStartingPoints (BS:1046-1068): the pool comes from the prior
+        drawn.resize((size_t)opt.pool * p);
+        if (gphip_tab_prior_sample(tp.box, tp.tab, p, (int64_t)m, opt.pool, opt.seed, drawn.data()) != GPHIP_OK) return LIBRARY_NUMERICAL_ERROR;
+    }
     const int64_t cap = (int64_t)opt.pool + std::max(opt.max_iterations, opt.min_iterations) + 1;
     std::vector<double> pts((size_t)cap * p), ll((size_t)cap), lp((size_t)cap), ar((size_t)cap);
     int64_t n = 0, ne = 0;
     double z = 0.0;
-    int rc = gphip_nested_sampling(h, tp.box, nullptr, tab_logprior, &tp, &opt, lib->MTensor_getRealData(st), cap, pts.data(), ll.data(),
+    int rc = gphip_nested_sampling(h, tp.box, nullptr, tab_logprior, &tp, &opt, draw ? drawn.data() : lib->MTensor_getRealData(st), cap, pts.data(), ll.data(),
                                    lp.data(), ar.data(), &n, &z, &ne);
     if (rc != GPHIP_OK) return status_to_wl(rc);
     MTensor r; mint d[2] = {(mint)n, (mint)p + 3};

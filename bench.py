@@ -51,7 +51,7 @@ def _roof(cls: dict, peak: float, unit: str, what: str) -> dict:
 
 def cpu_baseline(n_full: int, d: int, max_full_s: float = 600.0) -> dict:
     """Times the CPU oracle (numpy kernel-matrix build + scipy LAPACK LU, the algorithm LinearSolve uses) WHOLE, on the
-    host cores of this box: one evaluation at N = 8192, one at N = 16384 (LAPACK thread-count ladder there) and -- unless the N = 16384
+    host cores of this box: one evaluation at N = 16384 (LAPACK thread-count ladder there) and -- unless the N = 16384
     sample predicts more than `max_full_s` seconds ("32768 if < 10 min") -- one at the metric's own
     size N = n_full.  `value` is then MEASURED, not extrapolated; the cubic-law prediction from the smaller samples is
     kept under `also` so the two can be compared.  For information it also times a Cholesky variant and cfg 1
@@ -128,14 +128,24 @@ def cpu_baseline(n_full: int, d: int, max_full_s: float = 600.0) -> dict:
     del Kl, Kc
     threads = min(probe, key=probe.get)
     measured = {}
-    for n in (8192, 16384):
+    for n in (16384,):
         if n < n_full:
-            if n != n_lad:
-                with limited(threads):                           # warm this size
-                    Xw2, _ = syn.make_dataset(n, d)
-                    sla.lu_factor(orc.covariance_matrix("se_ard", th, Xw2), overwrite_a=True, check_finite=False)
-            tb, tf, ll = timed(n, threads)
+            tb, tf, ll = timed(n, threads)                       # (the ladder above has warmed this size)
             measured[n] = (tb, tf, ll)
+    # cfg 2's size for information: LAPACK's best thread count is size dependent (on the 256-CPU hosts of this pool the LU at
+    # N = 8192 ran SLOWER on 16 threads than the N = 16384 one, rounds 3-5), so it gets its own short ladder, warmed
+    small = {}
+    if n_full > 8192:
+        X8, _ = syn.make_dataset(8192, d)
+        K8 = orc.covariance_matrix("se_ard", th, X8)
+        for i, t in enumerate(sorted({t for t in (4, 8, 16, 32) if t <= max(probe)} or {threads})):
+            with limited(t):
+                for rep in range(2 if i == 0 else 1):
+                    Kc = np.asfortranarray(K8)
+                    t0 = time.perf_counter()
+                    sla.lu_factor(Kc, overwrite_a=True, check_finite=False)
+                    small[t] = time.perf_counter() - t0
+        del K8, Kc
     n_ref = max(measured) if measured else None
     predicted = None
     if n_ref is not None:
@@ -174,6 +184,7 @@ def cpu_baseline(n_full: int, d: int, max_full_s: float = 600.0) -> dict:
             "also": {"predicted_s_at_n_full_from_smaller_sample": None if predicted is None else round(predicted, 1),
                      "cholesky_variant_s_at_N4096": round(t_chol, 4),
                      "cfg1_N512_d1_evals_per_s": round(1.0 / t_cfg1, 2),
+                     "lu_s_at_N8192_by_threads": {str(k): round(v, 3) for k, v in sorted(small.items())},
                      "host_logical_cpus": os.cpu_count()}}
 
 
@@ -432,18 +443,25 @@ def other_configs(local_rank: int) -> dict:
             _, info = h.loglik_batch(Th)
             ts[i] = time.perf_counter() - t0
         dt = float(np.median(ts))
-        # per launch class (HIP events of the library's profile mode, one more batch): which class holds the batch where
-        h.set_option("profile", 1)
+        # per launch class: HIP events of the library's profile mode 2 (EVERY launch between its own event pair) with the
+        # look-ahead schedule OFF for this one extra batch -- one stream, nothing overlaps, so a class's time is its own and
+        # the classes add up to that batch's time (with look-ahead on, launches of the two streams share the chip and the
+        # bracketed times double count)
+        h.set_option("lookahead", 0)
+        h.set_option("profile", 2)
         h.loglik_batch(Th)
         h.reset_profile()
+        t0 = time.perf_counter()
         h.loglik_batch(Th)
+        dt_serial = time.perf_counter() - t0
         prof = h.profile()
         h.set_option("profile", 0)
+        h.set_option("lookahead", 1)
         classes = {}
         for cls, what, peak, unit in (("syrk_trailing", "trailing SYRK / GEMM updates (gemm_nt_kernel<double, 0, ..>)", FP64_MFMA_PEAK_TFLOPS, "TFLOP/s"),
-                                      ("gemm_panel", "in-panel and look-ahead GEMM updates (K = 128 .. 512)", FP64_MFMA_PEAK_TFLOPS, "TFLOP/s"),
-                                      ("trsm", "panel solves X <- A W^T (gemm_nt mode 1)", FP64_MFMA_PEAK_TFLOPS, "TFLOP/s"),
-                                      ("potrf", "128 x 128 diagonal blocks (potrf128_kernel / fused)", FP64_MFMA_PEAK_TFLOPS, "TFLOP/s"),
+                                      ("gemm_panel", "in-panel GEMM updates, K = 128 .. 384 (gemm_nt_kernel<double, 1, ..>)", FP64_MFMA_PEAK_TFLOPS, "TFLOP/s"),
+                                      ("trsm", "panel solves X <- A W^T (gemm_nt_kernel<double, 2, ..>)", FP64_MFMA_PEAK_TFLOPS, "TFLOP/s"),
+                                      ("potrf", "128 x 128 diagonal blocks (potrf128_kernel)", FP64_MFMA_PEAK_TFLOPS, "TFLOP/s"),
                                       ("kbuild", "kernel-matrix build", HBM_PEAK_GBS, "GB/s")):
             r = _roof(prof[cls], peak, unit, what)
             if r:
@@ -454,8 +472,10 @@ def other_configs(local_rank: int) -> dict:
                                           "failed": int((info != 0).sum()), "ms_per_batch_median": dt * 1e3, "ms_per_batch_min": float(ts.min()) * 1e3,
                                           "reps": 5, "ms_hip_events": prof["eval_total"]["ms"] / max(prof["eval_total"]["launches"], 1),
                                           "classes": classes,
-                                          "classes_note": "profile mode brackets every launch with its own event pair: the classes' "
-                                                          "sum exceeds the un-profiled batch time where launches of the two streams overlap"}
+                                          "classes_serial_batch_ms": dt_serial * 1e3,
+                                          "classes_note": "measured in ONE extra batch with the look-ahead schedule off (single stream): "
+                                                          "exclusive times per launch class; their sum is that batch's time, which the "
+                                                          "two-stream schedule of the timed batches beats by overlapping the classes"}
         h.close()
     except Exception as exc:                                    # never let an extra break the headline
         out["cfg4_error"] = repr(exc)

@@ -111,6 +111,20 @@ const char* gphip_create_error(void);
  * hyper-parameters (csrc/gp_dual.h), what the first gphip_loglik_grad of such a handle compiles.
  * Errors as gphip_create_custom (gphip_create_error() = the compiler's log). */
 int gphip_custom_compile(const char* body, int dtype, const char* arch, int grad_nparams, int* cache_hit);
+
+/* ---- host logic shared by the two hosts (pure C++, no device; csrc/gphip_hostlogic.inc) ------------------------------------
+ * gphip_kernel_parse: the kernel-name grammar (spaces, underscores, case ignored)
+ *     term [(+|*) term] [+ const]    term: se, se_ard, matern52, matern52_ard, matern32, matern32_ard, rq, rq_ard;   null | none
+ * -> spec[8] = {kernel_id for gphip_create, term 1, op, term 2 (-1 none), offset, parameters of term 1, of term 2, 0-based
+ * position of sigma_n in theta}.  GPHIP_ERR_ARG: not a kernel of the library.
+ * gphip_cform_to_body: the text Mathematica's CForm prints for a covariance function whose coordinates / hyper-parameters
+ * were replaced by the stand-in symbols ..gphipXc<k> / ..gphipYc<k> / ..gphipPc<k>  ->  "return <C expression in X(k), Y(k),
+ * P(k)>;", the body gphip_create_custom takes (BGP:29-33: any pure function of two points).
+ * gphip_tab_prior_sample: `pool` draws from a separable prior given as log-density tables (p x m, uniform nodes over
+ * box[2j] .. box[2j+1]; <= -1e299 = log 0): the starting pool of the sampler (generateStartingPoints, BS:1046-1068). */
+int gphip_kernel_parse(const char* name, int64_t d, int* spec);
+int gphip_cform_to_body(const char* cform, char* out, int64_t cap);
+int gphip_tab_prior_sample(const double* box, const double* tab, int p, int64_t m, int pool, uint64_t seed, double* out);
 #define GPHIP_MEAN_ZERO 0            /* Function[0]  (BGP:168,255)                                    */
 #define GPHIP_MEAN_CONST 1           /* Function[mu], mu = last entry of theta                        */
 
