@@ -311,9 +311,15 @@ def test_native_sampler_with_a_tabulated_normal_prior_matches_quadrature_over_20
                 start[k, 1] = v
                 k += 1
         opts = np.array([pool, 10000, 100, 25, 32, 0.01, 0.0, 1.0, float(seed)])
-        rc, rows = K.call("gphip_wl_nested_sampling_tab", [hs, box, tab, opts, start])
+        # odd seeds: no starting points -- the library draws the pool from the tables itself (what GPHIP.wl does by default)
+        given = seed % 2 == 0
+        rc, rows = K.call("gphip_wl_nested_sampling_tab", [hs, box, tab, opts, start if given else np.zeros(0)])
         assert rc == NO_ERROR and rows.shape[1] == 5 and rows.shape[0] > pool
-        np.testing.assert_array_equal(rows[:pool, :2], start)
+        if given:
+            np.testing.assert_array_equal(rows[:pool, :2], start)
+        else:
+            assert np.all((rows[:pool, :2] >= box[:, 0]) & (rows[:pool, :2] <= box[:, 1]))
+            assert abs(rows[:pool, 1].mean() - m0) < 0.35             # (drawn from N(0.2, 0.5) cut to the box, not uniformly)
         i = pool + 7                                          # the recorded prior density IS the tabulated one (interpolated)
         assert abs(rows[i, 3] - logprior(rows[i, 0], rows[i, 1])) < 1e-8
         res = {"Points": rows[:, :2], "LogLikelihood": rows[:, 2], "LogPriorPDF": rows[:, 3], "AcceptanceRate": rows[:, 4],
@@ -339,11 +345,15 @@ def test_create_custom_through_the_shim_the_way_gphip_wl_drives_it():
     X, y = syn.make_dataset(n, d)
     live0, dis0 = K.lib.drv_live(), K.lib.drv_disowned()
     # Function[{p, q}, sf^2 Exp[-(p - q).(p - q)/(2 l^2)] (1 + c^2 p[[1]] q[[1]])] printed by CForm over {l, sf, c, sn}
+    # -- as ToString[CForm[..]] prints it with the package's stand-in symbols (their context is not on $ContextPath)
+    cform = ("(Power(GPHIP_Private_gphipPc1,2)*(1 + Power(GPHIP_Private_gphipPc2,2)*GPHIP_Private_gphipXc0*GPHIP_Private_gphipYc0))/"
+             "Power(E,(Power(GPHIP_Private_gphipXc0 - GPHIP_Private_gphipYc0,2) + Power(GPHIP_Private_gphipXc1 - GPHIP_Private_gphipYc1,2))/"
+             "(2.*Power(GPHIP_Private_gphipPc0,2)))")
     body = ("return (Power(P(1),2)*(1 + Power(P(2),2)*X(0)*Y(0)))/"
-            "Power(E,(Power(X(0) - Y(0),2) + Power(X(1) - Y(1),2))/(2.*Power(P(0),2)));")
+            "Power(E,(Power(X(0) - Y(0),2) + Power(X(1) - Y(1),2))/(2.*Power(P(0),2)));")        # what the shim makes of it
     fn = lambda A, B, p: p[1] ** 2 * np.exp(-0.5 * ((A - B) ** 2).sum(-1) / p[0] ** 2) * (1.0 + p[2] ** 2 * A[..., 0] * B[..., 0])  # noqa: E731
     ck = _lib.CustomKernel(body, 4, fn=fn)                     # all FOUR reference parameters are P(k); sn = P(3) is used by the nugget only
-    rc, h = K.call("gphip_wl_create_custom", [X, y, body, 4, 0, 64, 0], "int")
+    rc, h = K.call("gphip_wl_create_custom", [X, y, cform, 4, 0, 64, np.array([0])], "int")
     assert rc == NO_ERROR and K.lib.drv_disowned() == dis0 + 1
     theta = np.array([0.9, 1.2, 0.7, 0.15])
     lifted = np.append(theta, 1.0)[None, :]                    # GPHIP.wl: Join[theta, {1.}]
@@ -359,7 +369,13 @@ def test_create_custom_through_the_shim_the_way_gphip_wl_drives_it():
     np.testing.assert_allclose(np.sqrt(r[1, 0]), so, rtol=1e-7)
     assert K.call("gphip_wl_destroy", [h], "int") == (NO_ERROR, 0)
     # a body that does not compile: an error code (GPHIP.wl then falls back to the reference's own path), nothing leaked
-    assert K.call("gphip_wl_create_custom", [X, y, "return Undefined(P(0));", 1, 0, 64, 0], "int")[0] == FUNCTION_ERROR
-    assert K.call("gphip_wl_create_custom", [X, y[:-1], body, 4, 0, 64, 0], "int")[0] == DIMENSION_ERROR
+    assert K.call("gphip_wl_create_custom", [X, y, "Undefined(gphipPc0)", 1, 0, 64, np.array([0])], "int")[0] == FUNCTION_ERROR
+    assert K.call("gphip_wl_create_custom", [X, y, 'Foo("x") + gphipPc0', 1, 0, 64, np.array([0])], "int")[0] == FUNCTION_ERROR   # no C expression
+    assert K.call("gphip_wl_create_custom", [X, y[:-1], cform, 4, 0, 64, np.array([0])], "int")[0] == DIMENSION_ERROR
+    # the kernel-name grammar the package asks the library for
+    rc, spec = K.call("gphip_wl_kernel_spec", ["SEARD + Matern32 + Const", 3])
+    assert rc == NO_ERROR and list(spec) == [_lib.kernel_id("se_ard+matern32+const"), 1, 1, 5, 1, 4, 2, 7]
+    rc, spec = K.call("gphip_wl_kernel_spec", ["NotAKernel", 3])
+    assert rc == NO_ERROR and list(spec) == [-1] * 8
     assert K.lib.drv_live() == live0 and K.lib.drv_const_frees() == 0
     K.lib.WolframLibrary_uninitialize(K.data)

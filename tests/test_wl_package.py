@@ -11,15 +11,18 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 WL = os.path.join(ROOT, "bayesianinference_amd", "wl", "GPHIP.wl")
+WL_SAMPLER = os.path.join(ROOT, "bayesianinference_amd", "wl", "GPHIPSampler.wl")      # nestedSamplingHIP, loaded by GPHIP.wl
 SHIM = os.path.join(ROOT, "bayesianinference_amd", "csrc", "librarylink_shim.cpp")
 
 
 def wl_bindings():
-    """{shim function name: number of arguments} from the LibraryFunctionLoad calls of GPHIP.wl."""
-    text = open(WL).read()
+    """{shim function name: number of arguments} from the load["name", {argument types}, result] bindings of the two package
+    files (load = LibraryFunctionLoad[$GPHIPLibrary, ..]; the type shorthands m2, v1, any, iv count as one argument each)."""
+    text = open(WL).read() + open(WL_SAMPLER).read()
     text = re.sub(r"\(\*.*?\*\)", "", text, flags=re.S)
+    assert "load[name_, args_, ret_] := LibraryFunctionLoad[$GPHIPLibrary, name, args, ret];" in text
     out = {}
-    for m in re.finditer(r'LibraryFunctionLoad\[\$GPHIPLibrary,\s*"(\w+)",\s*\{', text):
+    for m in re.finditer(r'\bload\["(\w+)",\s*\{', text):
         i, depth, args, seen = m.end(), 1, 0, False
         while depth:                                   # count top-level elements of the argument list
             ch = text[i]
@@ -46,7 +49,7 @@ def shim_argc():
 
 def test_every_wl_binding_matches_a_shim_entry_point():
     wl, shim = wl_bindings(), shim_argc()
-    assert len(wl) == 20 and set(wl) == set(shim), (sorted(wl), sorted(shim))
+    assert len(wl) == 21 and set(wl) == set(shim), (sorted(wl), sorted(shim))
     assert wl == shim, {k: (wl[k], shim[k]) for k in wl if wl[k] != shim[k]}
 
 
@@ -69,6 +72,45 @@ def test_shim_compiles_against_stub_header_and_exports_the_lifecycle():
         fn.restype = C.c_int
         fn.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
         assert fn(data, n + 1, None, None) == 6, name
+
+
+def test_wl_package_stays_thin():
+    """the untestable WL side stays small, all logic that needs no Wolfram kernel lives behind the C ABI."""
+    assert len(open(WL).read().splitlines()) <= 300
+    assert len(open(WL_SAMPLER).read().splitlines()) <= 100
+    for path in (WL, WL_SAMPLER):                      # no text processing / parsing left on this side
+        text = open(path).read()
+        assert "RegularExpression" not in text and "StringSplit" not in text and "RandomVariate" not in text, path
+    for path in (WL, WL_SAMPLER):                      # brackets balance (outside strings and comments)
+        t, stack, i = open(path).read(), [], 0
+        close = {")": "(", "]": "[", "}": "{"}
+        while i < len(t):
+            if t.startswith("(*", i):
+                depth, i = 1, i + 2
+                while depth:
+                    if t.startswith("(*", i):
+                        depth, i = depth + 1, i + 2
+                    elif t.startswith("*)", i):
+                        depth, i = depth - 1, i + 2
+                    else:
+                        i += 1
+                continue
+            if t[i] == '"':
+                i += 1
+                while t[i] != '"':
+                    i += 2 if t[i] == "\\" else 1
+                i += 1
+                continue
+            if t.startswith("<|", i):
+                stack.append("<|"); i += 2; continue
+            if t.startswith("|>", i):
+                assert stack.pop() == "<|", (path, i); i += 2; continue
+            if t[i] in "([{":
+                stack.append(t[i])
+            elif t[i] in ")]}":
+                assert stack.pop() == close[t[i]], (path, t[max(0, i - 60):i + 1])
+            i += 1
+        assert not stack, (path, stack)
 
 
 def test_wl_package_keeps_reference_shapes():
@@ -105,5 +147,6 @@ def test_wl_package_keeps_reference_shapes():
     assert re.search(r"defineGaussianProcessHIP\[\s*dataIn_List.*?kerf_, nugf_, meanf_,", text, flags=re.S)     # BGP:228-234
     assert "Return @ defineGaussianProcess[dataIn -> dataOut, kerf, nugf, meanf, variables, variablePrior" in text
     assert "Mod[$KernelID, Max[gpDevices[], 1]]" in text and "Mod[$KernelID, 8]" not in text
-    assert "evidenceSampling[" in text and "gpNested[" in text                                               # BS:1158-1291
+    sampler = open(WL_SAMPLER).read()
+    assert "evidenceSampling[" in sampler and "gpNested[" in sampler and 'Get[FileNameJoin[{DirectoryName[$InputFileName], "GPHIPSampler.wl"}]]' in text   # BS:1158-1291
     assert "expressionToFunction[nugf, vars -> paramVector]" in text                                       # BGP:257-262
