@@ -41,13 +41,8 @@ namespace gphip {
 // (KBuildArgs, SLOTP, the tile layout): rtc_dyn.h refuses a source tree whose value differs from the library's own.
 #define GP_RTC_ABI 3
 constexpr int TB = 128;         // tile edge
-// Elements between consecutive tiles of the packed workspace: 128 x 128 plus a pad.  Without the pad every tile starts on
-// a 128 KiB (fp64) boundary and the workgroups of a launch, which walk their operand tiles in lock step, all touch the
-// same offsets modulo 128 KiB at the same time -- the same few HBM channels (measured: see DESIGN.md section 3).
-#ifndef GP_TILE_PAD
-#define GP_TILE_PAD 0
-#endif
-constexpr long TS = (long)TB * TB + GP_TILE_PAD;
+// elements between consecutive tiles of the packed workspace (a pad behind every tile was measured in round 3: no gain)
+constexpr long TS = (long)TB * TB;
 
 // index (in tiles) of tile (ti, tj), ti >= tj, in the packed lower-triangular tile-major workspace of R tile rows
 __host__ __device__ __forceinline__ long tile_index(int ti, int tj, int R) {
@@ -125,33 +120,9 @@ __device__ __forceinline__ double exp_tab(double w, const double* __restrict__ t
     const int ki = __double2loint(t);
     return __builtin_ldexp(tab[ki & (EXP_TAB - 1)] * p, ki >> 9);
 }
-// The same table with the argument ALREADY in table units (round 4: the kernel build is fp64-VALU bound on a chip that runs it
-// at a low shader clock, so every instruction of the inner loop shows):   sf2 exp(-u ln2/512) = sf2 2^(-u/512),  u >= 0.
-//   t  = MAGIC - u            (k = -rint(u) lands in the low mantissa bits)
-//   r' = -u - k               EXACT (|r'| <= 1/2: the difference of two doubles that agree in their leading bits) -- no Cody-Waite
-//                             split, no multiplication by ln2/512: that factor sits in the polynomial's coefficients
-//   sf2 2^(-u/512) = 2^(k >> 9) * TAB[k & 511] * (1 + c1 r' + c2 r'^2 + c3 r'^3 + c4 r'^4),   c_n = (ln2/512)^n / n!
-// 10 fp64 VALU instructions instead of 12 (+ the same 3 integer ones).  For the squared exponential the caller scales the
-// point coordinates by sqrt(512 / (2 ln2)) once per tile, so that the accumulated squared distance IS u.
-constexpr double EXP_U_PER_ARG = 738.6598609351493;          // 512 / ln 2: u = EXP_U_PER_ARG * (the exponent's magnitude)
-constexpr double EXP_COORD_SCALE_SE = 19.217958540583197;    // sqrt(512 / (2 ln 2)): coordinates -> sum of squares = u of exp(-r2/2)
-__device__ __forceinline__ double exp_tab_u(double u, const double* __restrict__ tab) {
-    constexpr double MAGIC = 6755399441055744.0;             // 1.5 * 2^52
-    constexpr double C1 = 1.3538030870311431e-03;            // ln2 / 512
-    constexpr double C2 = 9.163913992275265e-07;             // C1^2 / 2
-    constexpr double C3 = 4.1353783506767136e-10;           // C1^3 / 6
-    constexpr double C4 = 1.399621994296973e-13;             // C1^4 / 24
-    u = fmin(u, 1.0e6);                                      // 2^-1953 = 0 in fp64: keeps k inside the int range
-    const double t = MAGIC - u;
-    const double kd = t - MAGIC;                             // -rint(u), exact
-    const double r = -kd - u;                                // exact
-    double p = __builtin_fma(C4, r, C3);
-    p = __builtin_fma(p, r, C2);
-    p = __builtin_fma(p, r, C1);
-    p = __builtin_fma(p, r, 1.0);
-    const int ki = __double2loint(t);
-    return __builtin_ldexp(tab[ki & (EXP_TAB - 1)] * p, ki >> 9);
-}
+// table units: sf2 exp(-w ln2/512) = sf2 2^(-w/512); kbuild_mfma_kernel scales the coordinates so that its accumulator IS w
+constexpr double EXP_U_PER_ARG = 738.6598609351493;          // 512 / ln 2: w = EXP_U_PER_ARG * (the exponent's magnitude)
+constexpr double EXP_COORD_SCALE_SE = 19.217958540583197;    // sqrt(512 / (2 ln 2)): coordinates -> sum of squares = w of exp(-r2/2)
 
 // Per-type numerics and MFMA shape
 template <typename T> struct Num;
@@ -426,21 +397,13 @@ __global__ __launch_bounds__(256) void kbuild_kernel(KBuildArgs<T> a) {
     double* etab = lds_raw + (glb ? 0 : ((D > 0) ? D : 2 * d) * TB);
     if (sizeof(T) == 8 && KT < 2)
         for (int idx = tid; idx < EXP_TAB; idx += 256) etab[idx] = sp[0] * a.exp2tab[idx];
-    // fp64 squared exponential: coordinates in units in which the squared distance IS the exp table's argument (exp_tab_u)
-    // (GP_KBUILD_USCALE: round-4 experiment, off.  10 instead of 12 fp64 instructions per exponential bought 1 % on the boxes
-    //  measured -- the build is not purely VALU bound there -- and the different rounding moved the SPD verdict of the
-    //  multi-kernel schedule inside the sentinel band of tests/test_gpu_sentinel_band.py (cond 7e13): not worth it.)
-#ifndef GP_KBUILD_USCALE
-#define GP_KBUILD_USCALE 0
-#endif
-    constexpr bool USCALE = GP_KBUILD_USCALE && sizeof(T) == 8 && KT == 0 && D > 0;
     // fp32 fast path below: sum of squares = r2 log2(e) / 2 (SE) or 5 r2 (Matern-5/2)
     constexpr bool F32FAST = sizeof(T) == 4 && D > 0 && KT < 2;
     constexpr float CS32 = KT == 0 ? 0.84932180028801904f /* sqrt(log2(e) / 2) */ : 2.2360679774997896f /* sqrt 5 */;
-    const T cscale = USCALE ? (T)EXP_COORD_SCALE_SE : (F32FAST ? (T)CS32 : (T)1);
+    const T cscale = F32FAST ? (T)CS32 : (T)1;
     for (int idx = tid; idx < (glb ? 0 : d * TB); idx += 256) {
         const int dd = idx >> 7, c = idx & 127;
-        xjs[idx] = (USCALE || F32FAST) ? xjg[(long)dd * a.npad_j + c] * cscale : xjg[(long)dd * a.npad_j + c];
+        xjs[idx] = F32FAST ? xjg[(long)dd * a.npad_j + c] * cscale : xjg[(long)dd * a.npad_j + c];
         if (D == 0) xis[idx] = xig[(long)dd * a.npad_i + c];
         if (KT == 2 && two) {
             xjs2[idx] = a.xj2[(long)slot * a.xj_bstride + (long)tj * TB + (long)dd * a.npad_j + c];
@@ -452,8 +415,8 @@ __global__ __launch_bounds__(256) void kbuild_kernel(KBuildArgs<T> a) {
 #pragma unroll
         for (int dd = 0; dd < D; ++dd) {
             const pair_t v = *reinterpret_cast<const pair_t*>(xig + (long)dd * a.npad_i + r0);
-            xa[dd] = USCALE ? v.x * cscale : v.x;
-            xb[dd] = USCALE ? v.y * cscale : v.y;
+            xa[dd] = v.x;
+            xb[dd] = v.y;
         }
     }
     __syncthreads();
@@ -583,13 +546,8 @@ __global__ __launch_bounds__(256) void kbuild_kernel(KBuildArgs<T> a) {
             vb = kgeneral<T>(a.ks, rb, rb2, sp);
         } else if constexpr (sizeof(T) == 8) {
             if (KT == 0) {
-                if constexpr (USCALE) {
-                    va = exp_tab_u(ra, etab);
-                    vb = exp_tab_u(rb, etab);
-                } else {
-                    va = exp_tab<true>(ra, etab);
-                    vb = exp_tab<true>(rb, etab);
-                }
+                va = exp_tab<true>(ra, etab);
+                vb = exp_tab<true>(rb, etab);
             } else {
                 const double sa = __builtin_sqrt(5.0 * ra), sb = __builtin_sqrt(5.0 * rb);
                 va = (1.0 + sa + (5.0 / 3.0) * ra) * exp_tab<false>(sa, etab);
@@ -1449,8 +1407,7 @@ struct GemmArgs {
     int nrect;                                   // tiles in the full-height rectangle part
     int ntiles;
     int swizzle;                                 // XCD-aware block remap
-    int super;                                   // 1: pure-triangle launch enumerated in 8x8 super-tiles,
-                                                 //    one super-tile per XCD at a time (L2 reuse)
+    int super;                                   // 2: pure-triangle launch whose tile list is enumerated in 8x8 super-tiles
     int mode;                                    // ROLE 3 only: 0: C -= A B ; 1: C = A B
     int ktri;                                    // 1: tile (ti,tj) contracts k >= ti*128 only (operands upper
                                                  //    triangular in (row, k): the U U^T product of the gradient)
@@ -1603,20 +1560,6 @@ __global__ __launch_bounds__(64 * NWI * NWJ, (NWI * NWJ == 4) ? 2 : 4) void gemm
         }
         int u, v;
         blocked_tri_decode(bid, H, u, v);
-        ti = g.r0 + u;
-        tj = g.r0 + v;
-    } else if (g.super) {
-        // Blocks b, b+8, b+16, .. run on XCD b % 8 (observed dispatch rule; speed only).  Give each
-        // XCD whole 8x8 super-tiles: its 64 resident workgroups then share 8 row panels and 8
-        // column panels through that XCD's private 4 MiB L2 instead of streaming 65 panels.
-        const int H = g.r1 - g.r0, S = (H + 7) >> 3;
-        const int x = bid & 7, q = bid >> 3;
-        const int sidx = (q >> 6) * 8 + x, within = q & 63;
-        if (sidx >= S * (S + 1) / 2) return;
-        int I, J;
-        tri_decode(sidx, S, I, J);
-        const int u = 8 * I + (within & 7), v = 8 * J + (within >> 3);
-        if (u >= H || v > u) return;
         ti = g.r0 + u;
         tj = g.r0 + v;
     } else {
@@ -1928,143 +1871,6 @@ __global__ __launch_bounds__(64 * NWI * NWJ, (NWI * NWJ == 4) ? 2 : 4) void gemm
 }
 
 // ---------------------------------------------------------------------------------------------
-// panel_rows: everything an outer panel [K0, K0 + nin) does to ONE tile row below its diagonal block, in one workgroup
-// (batches of thetas, round 4).  The multi-kernel panel factorisation touches every tile of the panel twice per column step
-// -- in-panel update (read C, read the row's earlier X tiles, write C), then the solve (read C, write X): 22 tile transfers
-// per row of a 4-column panel at K = 128 per pass, i.e. ~8 flop per HBM byte, and a batch of 200 thetas does not fit any
-// cache: those launches ran at 25-30 TFLOP/s, 45 % of a batch's time for 23 % of its flops.  Here the diagonal block of the
-// panel (its L tiles and W_b = L_bb^-1) is factored first for all slots (small launches), and then one workgroup per
-// (row tile, slot) walks the columns b = 0 .. nin - 1:
-//     acc = C(i, b);   acc -= sum_{a < b} X(i, a) L(b, a)^T     (one pipelined pass over the b slabs)
-//     pre-solve tile -> memory (it has to become an MFMA operand);   X(i, b) = pre W_b^T;   X(i, b) -> memory
-// Each C tile is read from HBM once and each X tile written once (4 + 4 transfers per row instead of 22); the earlier X tiles
-// of the row and the pre-solve tile come back through the L2 this workgroup has just written them to, L and W of the
-// diagonal block are shared by every row of the slot.  Same arithmetic in the same order as the launches it replaces
-// (left-looking in-panel update with K = 128 b, then the explicit-inverse solve): results are bit-identical.
-// ---------------------------------------------------------------------------------------------
-template <typename T>
-struct PanelRowsArgs {
-    T* A; long bstride;            // packed tile-major workspace (slot 0), elements between slots
-    int R;                         // tile rows of the workspace
-    int K0, nin;                   // the panel's tile columns
-    const T* W; long w_bstride;    // W_b blocks: [slot][tile column][128 x 128]
-    int r_first;                   // first tile row of this launch (K0 + nin); blockIdx.x counts rows from there
-};
-
-template <typename T>
-__global__ __launch_bounds__(256, 2) void panel_rows_kernel(PanelRowsArgs<T> g) {
-    constexpr int FI = 4, FJ = 4, WT = 64;
-    extern __shared__ double smem_raw[];
-    T* smem = reinterpret_cast<T*>(smem_raw);
-    typedef typename Num<T>::acc_t acc_t;
-    constexpr int GK = Num<T>::GK;
-    constexpr int STAGE = STAGE_BYTES / (int)sizeof(T);
-    constexpr int JOFF = STAGE / 2;
-    constexpr bool F64 = sizeof(T) == 8;
-    constexpr int SPB = TB / GK;                            // LDS stages per 128-wide slab
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wi = wave & 1, wj = wave >> 1;
-    const int l15 = lane & 15, l4 = lane >> 4;
-    const int uw = __builtin_amdgcn_readfirstlane(wave);
-    const int slot = blockIdx.y, ti = g.r_first + blockIdx.x;
-    T* As = g.A + (long)slot * g.bstride;
-    const T* Ws = g.W + (long)slot * g.w_bstride;
-    auto tptr = [&](int ti_, int tj_) -> T* { return As + tile_index(ti_, tj_, g.R) * TS; };
-    acc_t acc[FJ][FI];
-    auto c_ptr = [&](T* base) { return base + (long)(wj * WT) * TB + wi * WT + l15; };
-    auto load_c = [&](const T* base) {
-        const T* cp = c_ptr(const_cast<T*>(base));
-#pragma unroll
-        for (int x = 0; x < FJ; ++x)
-#pragma unroll
-            for (int y = 0; y < FI; ++y)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc[x][y][r] = cp[(long)(x * 16 + Num<T>::drow(l4, r)) * TB + y * 16];
-    };
-    // write-through (agent scope) stores: the tile is re-read by this workgroup's own LDS-DMA a moment later
-    auto store_c = [&](T* base) {
-        T* cp0 = c_ptr(base);
-#pragma unroll
-        for (int x = 0; x < FJ; ++x)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                T* cp = cp0 + (long)(x * 16 + Num<T>::drow(l4, r)) * TB;
-#pragma unroll
-                for (int y = 0; y < FI; ++y) __hip_atomic_store(cp + y * 16, acc[x][y][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-    };
-    // acc (+/-)= I J^T over nslab 128-wide slabs: slab s reads I from tile (ti, K0 + s) and J from Jtile(s) (column-major,
-    // leading dimension 128 both).  LDS-DMA double buffer as in gemm_nt.
-    auto run = [&](int nslab, bool negate, auto itile, auto jtile) {
-        const int nk = nslab * SPB;
-        auto stage = [&](int kb, int st) {
-            T* Is = smem + st * STAGE;
-            T* Js = Is + JOFF;
-            const int sl = kb / SPB;
-            const long o = (long)(kb % SPB) * GK * TB;
-            const T* Ig = itile(sl) + o;
-            const T* Jg = jtile(sl) + o;
-#pragma unroll
-            for (int s2 = 0; s2 < 4; ++s2) {
-                const int qq = uw + 4 * s2;
-                if (F64) {
-                    __builtin_amdgcn_global_load_lds((glb_void*)(Ig + (long)qq * TB + 2 * lane), (lds_void*)(Is + qq * LDT), 16, 0, 0);
-                    __builtin_amdgcn_global_load_lds((glb_void*)(Jg + (long)qq * TB + 2 * lane), (lds_void*)(Js + qq * LDT), 16, 0, 0);
-                } else {
-                    const long kcol = 4 * (qq >> 1) + (qq & 1) + 2 * (lane >> 5);
-                    const int row = 4 * (lane & 31);
-                    __builtin_amdgcn_global_load_lds((glb_void*)(Ig + kcol * TB + row), (lds_void*)(Is + qq * LDP), 16, 0, 0);
-                    __builtin_amdgcn_global_load_lds((glb_void*)(Jg + kcol * TB + row), (lds_void*)(Js + qq * LDP), 16, 0, 0);
-                }
-            }
-        };
-        stage(0, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        for (int kb = 0; kb < nk; ++kb) {
-            const int cur = kb & 1;
-            if (kb + 1 < nk) stage(kb + 1, cur ^ 1);
-            const T* Is = smem + cur * STAGE + wi * WT + l15;
-            const T* Js = smem + cur * STAGE + JOFF + wj * WT + l15;
-#pragma unroll
-            for (int kk = 0; kk < GK / 4; ++kk) {
-                const int k = 4 * kk + l4;
-                T fi[FI], fj[FJ];
-#pragma unroll
-                for (int f = 0; f < FI; ++f) fi[f] = Is[lds_off<T>(k, f * 16)];
-#pragma unroll
-                for (int f = 0; f < FJ; ++f) fj[f] = negate ? -Js[lds_off<T>(k, f * 16)] : Js[lds_off<T>(k, f * 16)];
-#pragma unroll
-                for (int x = 0; x < FJ; ++x)
-#pragma unroll
-                    for (int y = 0; y < FI; ++y) acc[x][y] = Num<T>::mfma(fj[x], fi[y], acc[x][y]);
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-        }
-    };
-    for (int b = 0; b < g.nin; ++b) {
-        T* Cb = tptr(ti, g.K0 + b);
-        if (b > 0) {
-            load_c(Cb);
-            run(b, true, [&](int s) { return (const T*)tptr(ti, g.K0 + s); }, [&](int s) { return (const T*)tptr(g.K0 + b, g.K0 + s); });
-            store_c(Cb);                                    // the pre-solve tile
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-        }
-#pragma unroll
-        for (int x = 0; x < FJ; ++x)
-#pragma unroll
-            for (int y = 0; y < FI; ++y) acc[x][y] = (acc_t){0, 0, 0, 0};
-        const T* Wb = Ws + (long)(g.K0 + b) * TB * TB;
-        run(1, false, [&](int) { return (const T*)Cb; }, [&](int) { return Wb; });
-        store_c(Cb);                                        // X(i, b)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
 // chol_dataflow: the whole bordered Cholesky of small / mid problems in ONE launch.
 //
 // The multi-kernel schedule above is bound, below N ~ 8k, by the serial chain of dependent launches
@@ -2108,9 +1914,6 @@ struct DfArgs {
                                               // FINISHED outer panel (operands only, read through Aprev -- the owner's receive buffer,
                                               // addressed with the same global tile indices); task numbering starts at task0 = the
                                               // first task of column nprev.  The launch applies that panel to its own columns itself.
-    int cw;                                   // split launch: tiles per column (from the diagonal down) that belong to the chain launch
-    int role;                                 // 0: this launch runs every task; split launch on CU-masked streams: 1 = the
-                                              // diagonal (chain) tasks on the reserved CUs, 2 = all other tasks on the rest
     int* park;                                // 64-tiles, two workgroups per CU: [DF_PARK_SLOTS] counters "a chain task is in its critical
                                               // section on this CU" (index = XCC / SE / SH / CU id); the neighbour sleeps meanwhile; or null
     long long* trace;                         // developer timing (scripts/micro/df_trace.hip): 8 stamps per task, or null
@@ -2214,29 +2017,12 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g, Th
     const int R = g.nd + 1;
     const int slot = task % g.nslots, q = task / g.nslots + (int)g.task0;
     // q -> (j, i): column-major over the lower triangle, column j starts at off(j) = jR - j(j-1)/2.
-    // Split launch (g.role, launch_dataflow): role 1 = the diagonal tasks in order (q = j), role 2 = every other task, still
-    // column-major (the strictly lower triangle = a lower triangle of R - 1 rows, shifted down by one).  Each launch hands
-    // out ITS tasks in the global topological order, so the lowest unfinished task of either launch is always resident and
-    // the lowest unfinished task overall has all its dependencies finished: the deadlock argument above carries over.
-    // (chain width cw = g.cw >= 1: the chain launch takes the cw tiles of every column nearest the diagonal -- the diagonal
-    //  task, the sub-diagonal one that feeds it, ..; its last cw - 1 columns are shorter)
-    const int cw = g.role ? g.cw : 0;
-    const int Rq = g.role == 2 ? R - cw : R;
-    int j = (int)(((double)(2 * Rq + 1) - sqrt((double)(2 * Rq + 1) * (2 * Rq + 1) - 8.0 * q)) * 0.5);
+    int j = (int)(((double)(2 * R + 1) - sqrt((double)(2 * R + 1) * (2 * R + 1) - 8.0 * q)) * 0.5);
     if (j < 0) j = 0;
-    if (j > Rq - 1) j = Rq - 1;
-    while (j + 1 < Rq && (j + 1) * Rq - (j + 1) * j / 2 <= q) ++j;
-    while (j > 0 && j * Rq - j * (j - 1) / 2 > q) --j;
-    int i = j + (q - (j * Rq - j * (j - 1) / 2)) + (g.role == 2 ? cw : 0);
-    if (g.role == 1) {
-        const int full = R - cw + 1;                       // columns 0 .. full - 1 have cw chain tiles each
-        if (q < full * cw) { j = q / cw; i = j + q % cw; }
-        else {                                              // the short columns at the end: a cw - 1 triangle
-            int rest = q - full * cw, jj = full, len = cw - 1;
-            while (rest >= len) { rest -= len; ++jj; --len; }
-            j = jj; i = jj + rest;
-        }
-    }
+    if (j > R - 1) j = R - 1;
+    while (j + 1 < R && (j + 1) * R - (j + 1) * j / 2 <= q) ++j;
+    while (j > 0 && j * R - j * (j - 1) / 2 > q) --j;
+    int i = j + (q - (j * R - j * (j - 1) / 2));
     j = __builtin_amdgcn_readfirstlane(j);                 // (through the vector sqrt: back to the scalar unit)
     i = __builtin_amdgcn_readfirstlane(i);
 

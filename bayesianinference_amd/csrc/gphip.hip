@@ -37,8 +37,7 @@ namespace {
 constexpr double LOG_TWO_PI = 1.8378770664093454835606594728112;
 constexpr size_t GEMM_LDS = 2 * STAGE_BYTES;
 // dTicket: [0] ticket, [1] abort word, [2 ..] DF_PARK_SLOTS ints of per-CU park counters, then the chain launch's ticket
-constexpr size_t DF_TICKET2 = 2 + DF_PARK_SLOTS * 4 / 8;
-constexpr size_t DF_TICKET_BYTES = (DF_TICKET2 + 2) * 8;
+constexpr size_t DF_TICKET_BYTES = (2 + DF_PARK_SLOTS * 4 / 8 + 2) * 8;
 
 struct ProfRec {
     int cls;
@@ -55,16 +54,13 @@ struct gphip_ctx {
     size_t es = 8;                     // element size of the device arithmetic type
     hipStream_t stream = nullptr;      // main stream: build, trailing updates, copies
     hipStream_t pstream = nullptr;     // panel stream (high priority): look-ahead panel factorisation
-    hipStream_t stream2 = nullptr;     // second trailing-update stream (split REST: the two halves fill each other's launch tails)
     hipStream_t cs = nullptr;          // stream the launch helpers currently target
     std::vector<hipEvent_t> sync_events;
     size_t sync_used = 0;
-    hipEvent_t ev_built0 = nullptr;              // queue_build -> queue_factor: "the tile columns of panel 0 are built" (split build)
     int dist_first_factored = -1;                // sharded evaluation: outer panel whose first diagonal block the last LA update factored
     int bcast_chunks = 1;                        // sharded evaluation: a factored panel is broadcast one tile column at a time
     const void* df_prev_ptr = nullptr; int df_prev_k = -2;   // dist_panel_df = 2: where the previous outer panel lies (gphip_dist_update's deferred look-ahead step)
-    int dist_df_occ3_tasks = 1 << 30;            // dist_panel_df = 2: fused panel launches of at least this many tile tasks run three workgroups per CU
-    int df_panel_one_wg_tasks = 600;             // sharded schedule, dataflow panels: one workgroup per CU up to this many tile tasks
+    static constexpr int df_panel_one_wg_tasks = 600;   // sharded schedule, dataflow panels: one workgroup per CU up to this many tile tasks
     // covariance function supplied as source text (gphip_create_custom): compiled at run time into the kernel build
     bool custom = false; int ncp = 0;            // ncp = its hyper-parameters p_0 .. p_{ncp-1}
     hipModule_t cmod = nullptr; hipFunction_t f_cbuild = nullptr, f_cdiag = nullptr, f_cprep = nullptr;
@@ -91,22 +87,6 @@ struct gphip_ctx {
     int dataflow_occ3 = -1;                      // 64-tile kernel built for three workgroups per CU: -1 auto (>= 8 000 tasks), 0 never, 1 always
     int dataflow_park = 1;                       // 64-tile dataflow, two workgroups per CU: park the neighbour of a chain task
     int dataflow_lds_kib = -1;                   // LDS request of the 64-tile dataflow kernel (> 80: ONE workgroup per CU); -1 auto, 0 off
-    // Split dataflow launch (64-tiles): the diagonal (chain) tasks run as their OWN launch on a stream whose CU mask reserves
-    // `df_split` CUs per XCD, every other task on a stream masked to the remaining CUs -- the chain never shares a SIMD, an
-    // LDS or a dispatch slot with the throughput work.  -1 auto (by task count), 0 off.
-    int df_split = 0, df_split_lds_kib = 84, df_split_min_tasks = 5000, df_split_auto = 3, df_split_width = 1;
-    hipStream_t chain_stream = nullptr, bulk_stream = nullptr;
-    // Look-ahead schedule, mid sizes: the trailing updates REST(k) run on a stream whose CU mask leaves `rest_mask` CUs per XCD
-    // free, so that the latency-shaped kernels of the panel stream (fused potrf, panel solves, in-panel updates) find a CU
-    // at once instead of waiting for a trailing-update workgroup to retire.  0 off, -1 auto.
-    int rest_mask = 0, rest_mask_max_nt = 192;
-    hipStream_t rest_stream = nullptr;
-    int rest_stream_for = 0;
-    int split_streams_for = 0;                   // reserved CUs per XCD the two masked streams were created for
-    unsigned long long ticket_base2 = 0;         // chain launch's own ticket counter (dTicket + DF_TICKET2)
-    int panel_rows = 0;                           // (measured: bit-identical, 2 % slower -- off) batches: rows below a panel's diagonal block handled by panel_rows_kernel
-    int build_overlap = 0;                       // option: factor panel 0 under the rest of the kernel build (measured: -0.1 % per
-                                                 // evaluation, but the build itself slows 4-15 % while it shares the chip: off)
     bool own_streams = true;
     int dist_rank = 0, dist_world = 0;  // > 0 between gphip_dist_begin and gphip_dist_end
     bool dist_theta_ok = true;
@@ -141,17 +121,16 @@ struct gphip_ctx {
     int* hInfo = nullptr;
     // options
     int panel = 4, profile = 0, swizzle = 1, max_slots = 256, lookahead = 1;
-    int supertile = 2;                 // trailing SYRK tile order: 0 column-major chunks per XCD, 1 static 8x8 super-tiles per XCD
-                                       // (measured slower: unequal loads), 2 the tile LIST in 8x8 super-tile order, equal chunks per XCD
-    int latency_gemm = 1, latency_tiles = 256;   // launches of <= latency_tiles tiles use the latency GEMM shape
+    int supertile = 2;                 // trailing SYRK tile order: 0 column-major chunks per XCD, 2 the tile LIST in 8x8 super-tile order,
+                                       // equal chunks per XCD (3: for batches too)
+    int latency_gemm = 1;                        // launches of <= latency_tiles tiles use the latency GEMM shape
+    static constexpr int latency_tiles = 256;
     int latency_max_nt = 48;                     // ... for problems of at most this many tile columns (beyond: its 147 KB of LDS evicts trailing-SYRK workgroups)
     int dataflow = 1, dataflow_max_nt = 96, dataflow_max_slots = 8;   // single-launch dataflow Cholesky: latency regime only
     int dataflow_fine_nt = 96;                   // ... with 64x64 tiles up to this many 128-tiles (fp64; measured best up to N = 12288)
     int panel_left = -1;                         // in-panel updates left-looking: -1 auto (batches), 0 never, 1 always
     int fuse_option = 1;                         // allow the single-launch evaluation (option "fused_eval")
     int grad_potri = 1;                          // gradient: K^-1 = U U^T in one go when the memory is there
-    int rest_split = 0;                          // REST(k) as two grouped launches (even / odd 2-tile column groups) on two streams
-    int la_main = 0;                             // 1: look-ahead update LA(k) on the main stream ahead of REST(k) (measured slower: 189.4 vs 186.2 ms)
     int panel_wide = 1;                          // wider outer panels while the trailing matrix is large (queue_factor)
     int thin_tiles = 1;                          // gemm_nt: skip the zero rows of the rhs block-row and the unread upper quadrant of diagonal tiles
     int debug_fail_alloc = 0;                    // tests: make the n-th device allocation of the next slot (re)allocation fail
@@ -324,7 +303,7 @@ void free_slots(gphip_ctx* h) {
     h->dXs2 = nullptr; h->dInvEll2 = h->hInvEll2 = nullptr;
     (void)hipFree(h->dCustomP); (void)hipHostFree(h->hCustomP);
     h->dCustomP = h->hCustomP = nullptr;
-    h->dFlags = nullptr; h->dTicket = nullptr; h->ticket_base = 0; h->ticket_base2 = 0;
+    h->dFlags = nullptr; h->dTicket = nullptr; h->ticket_base = 0;
     (void)hipHostFree(h->hInvEll); (void)hipHostFree(h->hSlotp); (void)hipHostFree(h->hRes);
     (void)hipHostFree(h->hInfo);
     if (h->dist_base == h->dA) { h->dist_base = nullptr; if (h->lay_full == 1) { h->lay_rank = -1; h->lay_full = -1; } }
@@ -500,13 +479,9 @@ std::vector<int> panel_bounds(const gphip_ctx* h) {
 bool use_dataflow(const gphip_ctx* h, int nslots);
 hipEvent_t sync_event(gphip_ctx* h);
 
-// queue k_scale + kbuild for nslots slots (theta already staged in dInvEll / dSlotp).  for_factor: the look-ahead
-// factorisation follows on this handle's streams -- the build is then split after the tile columns of outer panel 0 and an
-// event tells queue_factor's panel stream that it may start on them while the main stream builds the rest (the build is
-// HBM-store bound, the first panel's factorisation latency / MFMA bound: they overlap almost for free, and nothing else
-// hides panel 0).
+// queue k_scale + kbuild for nslots slots (theta already staged in dInvEll / dSlotp)
 template <typename T>
-int queue_build(gphip_ctx* h, int nslots, bool for_factor = false) {
+int queue_build(gphip_ctx* h, int nslots) {
     const long tot = (long)h->d * h->Npad;
     int gx = (int)((tot + 255) / 256);
     if (gx > 1024) gx = 1024;
@@ -545,21 +520,6 @@ int queue_build(gphip_ctx* h, int nslots, bool for_factor = false) {
     a.pw_bstride = h->Npad;
     const long ntiles = (long)(h->Nt + 1) * (h->Nt + 2) / 2;
     ProfScope ps(h, 0, 0.0, (double)sizeof(T) * nslots * ((double)h->N * (h->N + 1) / 2 + (double)h->N * h->d));
-    h->ev_built0 = nullptr;
-    if (for_factor && h->build_overlap && h->lookahead && h->dist_world == 0 && h->cs == h->stream && !use_dataflow(h, nslots)) {
-        const std::vector<int> bnd = panel_bounds(h);
-        if (bnd.size() >= 3) {                                         // >= 2 outer panels: queue_factor runs the look-ahead schedule
-            const long c = bnd[1], R = h->Nt + 1;
-            const long first = c * R - c * (c - 1) / 2;                // tiles of the tile columns [0, c) (column-major packed order)
-            launch_kbuild<T>(h, a, dim3((unsigned)first, nslots), (const T*)h->dXt, (const T*)h->dXt);
-            h->sync_used = 0;
-            h->ev_built0 = sync_event(h);
-            HIPCHK(hipEventRecord(h->ev_built0, h->stream));
-            a.t0 = (int)first;
-            launch_kbuild<T>(h, a, dim3((unsigned)(ntiles - first), nslots), (const T*)h->dXt, (const T*)h->dXt);
-            return 0;
-        }
-    }
     launch_kbuild<T>(h, a, dim3((unsigned)ntiles, nslots), (const T*)h->dXt, (const T*)h->dXt);
     return 0;
 }
@@ -627,11 +587,6 @@ void launch_gemm(gphip_ctx* h, int cls, Opnd<T> Co, Opnd<T> Ao, Opnd<T> Bo, int 
     int grid_x = g.ntiles;
     if (tri && r0 == c0 && W == H && h->supertile >= 2 && H >= 16 && mode == 0 && groups == 1 && (nslots == 1 || h->supertile == 3)) {
         g.super = 2;                            // the tile list in blocked (8 x 8 super-tile) order, equal chunks per XCD
-    } else if (tri && r0 == c0 && W == H && h->supertile == 1 && H >= 16 && mode == 0) {   // pure triangle: 8x8 super-tiles, static split
-        const int S = (H + 7) / 8;
-        const int nsuper = (S * (S + 1) / 2 + 7) / 8 * 8;
-        g.super = 1;
-        grid_x = nsuper * 64;
     }
     double flops = 2.0 * TB * TB * (double)K * g.ntiles * nslots;       // tile-granular (what the MFMA pipe executes)
     if (g.grp_stride > 0) {
@@ -731,30 +686,6 @@ int queue_panel(gphip_ctx* h, int K0, int nin, int nslots, bool first_factored =
     // registers halve the resident waves of what are then BIG update launches (200 x N=4096: 86 -> 91 ms): not there.
     const bool fuse = h->fuse_potrf && nslots <= 8;
     bool factored = first_factored;
-    // Batches (option "panel_rows", default on): the diagonal block of the panel first -- the same launches restricted to its
-    // own tile rows -- then ONE launch in which a workgroup takes a whole tile row below it through all nin columns
-    // (panel_rows_kernel: each C tile read once, each X tile written once; bit-identical results).
-    if (h->panel_rows && left && nslots > h->dataflow_max_slots && !h->col_events && !first_factored && K0 + nin <= Nt) {
-        const int rend = K0 + nin;
-        for (int s = 0; s < nin; ++s) {
-            const int b = K0 + s;
-            if (s > 0) launch_gemm<T>(h, 3, tl<T>(h), tl<T>(h, K0), tl<T>(h, K0), s * TB, b, rend, b, b + 1, 1, nslots, 0, 0, Nt);
-            {
-                ProfScope ps(h, 1, 2.0 * TB * TB * TB / 3.0 * nslots, 0.0);
-                hipLaunchKernelGGL(potrf128_kernel<T>, dim3(nslots), dim3(256), potrf_lds<T>(), h->cs, A, bs, b, W,
-                                   h->dPartial, Nt, h->dInfo, h->dSlotp);
-            }
-            if (b + 1 < rend)
-                launch_gemm<T>(h, 2, tl<T>(h), tl<T>(h, b), wb<T>(W, b, lrs), TB, b + 1, rend, b, b + 1, 0, nslots, 1, 0, Nt);
-        }
-        PanelRowsArgs<T> pr{};
-        pr.A = A; pr.bstride = bs; pr.R = R; pr.K0 = K0; pr.nin = nin; pr.W = W; pr.w_bstride = lrs; pr.r_first = rend;
-        const int rows = R - rend;                                     // (>= 1: the rhs tile row)
-        const double prods = (double)nin * (nin + 1) / 2.0;            // K = 128 products per row: nin solves + nin (nin - 1) / 2 updates
-        ProfScope ps(h, 3, 2.0 * TB * TB * TB * prods * rows * nslots, (double)sizeof(T) * 2.0 * TB * TB * nin * rows * nslots);
-        hipLaunchKernelGGL(panel_rows_kernel<T>, dim3((unsigned)rows, (unsigned)nslots), dim3(256), GEMM_LDS, h->cs, pr);
-        return 0;
-    }
     for (int s = 0; s < nin; ++s) {
         const int b = K0 + s;
         if (left && s > 0) {
@@ -796,7 +727,7 @@ int queue_panel(gphip_ctx* h, int K0, int nin, int nslots, bool first_factored =
 // 14336 18.9 -> 18.4; no gain at N <= 10240, a loss from N = 16384 on, where the panel launches starve behind the
 // trailing update's one-workgroup-per-CU GEMM).
 bool panel_df_on(const gphip_ctx* h, int nslots) {
-    if (h->dtype != 64 || nslots != 1 || !h->dataflow || !h->lookahead || h->dist_world > 0 || h->la_main || h->rest_split) return false;
+    if (h->dtype != 64 || nslots != 1 || !h->dataflow || !h->lookahead || h->dist_world > 0) return false;
     if ((h->Nt + h->panel - 1) / h->panel < 2) return false;
     if (h->panel_df >= 0) return h->panel_df != 0;
     return h->Nt >= 92 && h->Nt <= 120;
@@ -816,54 +747,6 @@ bool use_dataflow(const gphip_ctx* h, int nslots) {
     if (h->dtype == 32 && h->Nt > 64) return false;        // fp32 has 128-tiles only: measured range ends at N = 8192
     const long tasks = (long)(2 * h->Nt + 1) * (2 * h->Nt + 2) / 2 * nslots;
     return tasks < (1l << 30);
-}
-
-// The two CU-masked streams of a split dataflow launch.  Mask bit i of hipExtStreamCreateWithCUMask is CU (i / 8) / 4 of shader
-// engine (i / 8) % 4 of XCD i % 8 on this stack (measured bit by bit: scripts/micro/cumask_map.hip) -- bits x + 8 k, k < res,
-// reserve `res` CUs in EVERY XCD (the workgroup dispatcher deals a grid round-robin over the XCDs, so an uneven mask would make
-// the smallest XCD the pace of the bulk launch).  false = not available (the caller falls back to the single launch).
-bool split_streams(gphip_ctx* h, int res) {
-    if (res > 8) res = 8;
-    if (h->chain_stream && h->split_streams_for == res) return true;
-    int ncu = 0;
-    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess || ncu != 256) return false;
-    if (h->chain_stream) { (void)hipStreamDestroy(h->chain_stream); h->chain_stream = nullptr; }
-    if (h->bulk_stream) { (void)hipStreamDestroy(h->bulk_stream); h->bulk_stream = nullptr; }
-    uint32_t cm[8] = {0, 0, 0, 0, 0, 0, 0, 0}, bm[8];
-    for (int x = 0; x < 8; ++x)
-        for (int k = 0; k < res; ++k) {
-            const int b = x + 8 * k;
-            cm[b / 32] |= 1u << (b % 32);
-        }
-    for (int w = 0; w < 8; ++w) bm[w] = ~cm[w];
-    if (hipExtStreamCreateWithCUMask(&h->chain_stream, 8, cm) != hipSuccess ||
-        hipExtStreamCreateWithCUMask(&h->bulk_stream, 8, bm) != hipSuccess) {
-        (void)hipGetLastError();
-        if (h->chain_stream) { (void)hipStreamDestroy(h->chain_stream); h->chain_stream = nullptr; }
-        h->bulk_stream = nullptr;
-        return false;
-    }
-    h->split_streams_for = res;
-    return true;
-}
-
-// the trailing updates' stream: every CU except `res` per XCD (mask layout: see split_streams)
-hipStream_t masked_rest_stream(gphip_ctx* h, int res) {
-    if (res > 8) res = 8;
-    if (h->rest_stream && h->rest_stream_for == res) return h->rest_stream;
-    int ncu = 0;
-    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess || ncu != 256) return nullptr;
-    if (h->rest_stream) { (void)hipStreamDestroy(h->rest_stream); h->rest_stream = nullptr; }
-    uint32_t m[8];
-    for (int w = 0; w < 8; ++w) m[w] = 0xffffffffu;
-    for (int x = 0; x < 8; ++x)
-        for (int k = 0; k < res; ++k) {
-            const int b = x + 8 * k;
-            m[b / 32] &= ~(1u << (b % 32));
-        }
-    if (hipExtStreamCreateWithCUMask(&h->rest_stream, 8, m) != hipSuccess) { (void)hipGetLastError(); h->rest_stream = nullptr; return nullptr; }
-    h->rest_stream_for = res;
-    return h->rest_stream;
 }
 
 // c0 > 0 (128-tiles only): factor the trailing submatrix that starts at tile column c0 -- the tail of the
@@ -915,38 +798,6 @@ void launch_dataflow(gphip_ctx* h, int nslots, int c0 = 0, double* part = nullpt
         if ((size_t)kib * 1024 > lds) lds = (size_t)kib * 1024;
         // two workgroups per CU: the neighbour of a diagonal task steps aside while that task is on the chain
         if (lds <= 80 * 1024 && h->dataflow_park) g.park = reinterpret_cast<int*>(h->dTicket + 2);
-    }
-    if constexpr (TBX == 64) {
-        const int res = h->df_split >= 0 ? h->df_split : (tasks >= h->df_split_min_tasks && nslots == 1 ? h->df_split_auto : 0);
-        if (res > 0 && R >= 4 && g.ncols == 0 && split_streams(h, res)) {
-            // chain launch: diagonal tasks, ONE workgroup per reserved CU (LDS request); bulk launch: everything else
-            hipEvent_t e0 = sync_event(h), e1 = sync_event(h), e2 = sync_event(h);
-            (void)hipEventRecord(e0, h->stream);
-            (void)hipStreamWaitEvent(h->chain_stream, e0, 0);
-            (void)hipStreamWaitEvent(h->bulk_stream, e0, 0);
-            DfArgs<T> gc = g, gb = g;
-            gc.role = 1; gc.park = nullptr;
-            gc.ticket = h->dTicket + DF_TICKET2; gc.ticket_base = h->ticket_base2;
-            int cw = h->df_split_width < 1 ? 1 : h->df_split_width;
-            if (cw > R - 1) cw = R - 1;
-            gc.cw = gb.cw = cw;
-            // chain tiles: cw per column for the first R - cw + 1 columns, then cw - 1, .., 1
-            const long ctasks = ((long)(R - cw + 1) * cw + (long)cw * (cw - 1) / 2) * nslots;
-            h->ticket_base2 += (unsigned long long)ctasks;
-            gb.role = 2; gb.park = nullptr;
-            h->ticket_base -= (unsigned long long)ctasks;             // (the bulk launch draws tasks - ctasks tickets)
-            size_t clds = df_lds_bytes<T, TBX, NST>();
-            if ((size_t)h->df_split_lds_kib * 1024 > clds) clds = (size_t)h->df_split_lds_kib * 1024;
-            hipLaunchKernelGGL((chol_dataflow_kernel<T, TBX, 2, NST, BUILD>), dim3((unsigned)ctasks), dim3(256), clds, h->chain_stream, gc, tp);
-            const size_t blds = df_lds_bytes<T, TBX, NST>();
-            hipLaunchKernelGGL((chol_dataflow_kernel<T, TBX, OCC, NST, BUILD>), dim3((unsigned)(tasks - ctasks)), dim3(256), blds,
-                               h->bulk_stream, gb, tp);
-            (void)hipEventRecord(e1, h->chain_stream);
-            (void)hipEventRecord(e2, h->bulk_stream);
-            (void)hipStreamWaitEvent(h->stream, e1, 0);
-            (void)hipStreamWaitEvent(h->stream, e2, 0);
-            return;
-        }
     }
     hipLaunchKernelGGL((chol_dataflow_kernel<T, TBX, OCC, NST, BUILD>), dim3((unsigned)tasks), dim3(256), lds, h->stream, g, tp);
 }
@@ -1008,35 +859,12 @@ template <typename T>
 int queue_factor(gphip_ctx* h, int nslots) {
     const int Nt = (int)h->Nt, R = Nt + 1;     // R = tile rows incl. the rhs block-row
     const std::vector<int> bnd = panel_bounds(h);
-    hipEvent_t built0 = h->ev_built0;           // set by a split build: panel 0's tile columns are ready before the rest
-    h->ev_built0 = nullptr;
     const int nouter = (int)bnd.size() - 1;
     auto k0 = [&](int k) { return bnd[(size_t)std::min(k, nouter)]; };
     auto trailing = [&](int k, int c_lo, int c_hi, int cls) {      // apply panel k to tile columns [c_lo,c_hi)
         launch_gemm<T>(h, cls, tl<T>(h), tl<T>(h, k0(k)), tl<T>(h, k0(k)), (k0(k + 1) - k0(k)) * TB, c_lo, R, c_lo, c_hi, 1,
                        nslots, 0, 0, Nt);
     };
-    // Option "rest_split" (off by default): REST(k) as TWO grouped launches on two streams -- tile-column groups of
-    // width 2 alternate between them.  Each half depends only on the panel and on ITS OWN half of REST(k-1), so half A
-    // of step k+1 starts while half B of step k still runs and a launch's partial last wave of workgroups is filled by
-    // the other half: 187.7 -> 185.6 ms at N=32768 on the same box.  Off because it makes the per-launch SYRK statistic
-    // meaningless (two concurrent launches each last the whole step: the HIP-event / rocprof "average launch duration"
-    // doubles while the job gets faster) for a gain inside the box-to-box spread.
-    auto trailing_half = [&](int k, int c_lo, int parity) {       // columns >= c_lo (even), groups with (col/2) % 2 == parity
-        int first = c_lo / 2;
-        if ((first & 1) != parity) ++first;
-        const int c0 = 2 * first;
-        if (c0 >= R) return;
-        const int groups = (R - c0 + 3) / 4;                        // group starts c0, c0 + 4, .. < R
-        if (groups == 1)
-            launch_gemm<T>(h, 4, tl<T>(h), tl<T>(h, k0(k)), tl<T>(h, k0(k)), (k0(k + 1) - k0(k)) * TB, c0, R, c0,
-                           std::min(c0 + 2, R), 1, nslots, 0, 0, Nt);
-        else
-            launch_gemm<T>(h, 4, tl<T>(h), tl<T>(h, k0(k)), tl<T>(h, k0(k)), (k0(k + 1) - k0(k)) * TB, c0, R, c0, R, 1, nslots,
-                           0, 0, Nt, groups, 4, 2);
-    };
-    bool split = h->rest_split && nslots == 1 && h->lookahead && h->stream2 && !h->supertile;
-    for (int b : bnd) split = split && (b % 2 == 0 || b == Nt);
     if (use_dataflow(h, nslots)) return queue_factor_dataflow<T>(h, nslots);
     double* tail_part = nullptr;               // a 64-tile dataflow tail keeps its block partials here
     int tail_n = 0, tail_k0 = -1;
@@ -1044,7 +872,7 @@ int queue_factor(gphip_ctx* h, int nslots) {
     // factorisation -- is ONE 64-tile dataflow launch on the panel stream (the sharded schedule's dist_panel_df = 2 form).
     // All log-det partials are then per 64-block (dPartial[0 .. 2 Nt), the tail's too).
     bool pdf = false;
-    if constexpr (sizeof(T) == 8) pdf = panel_df_on(h, nslots) && nouter >= 2 && !split;
+    if constexpr (sizeof(T) == 8) pdf = panel_df_on(h, nslots) && nouter >= 2;
     auto df_panel = [&](int kp, int kprev) {
         if constexpr (sizeof(T) == 8) {
             hipStream_t keep = h->stream;
@@ -1061,25 +889,16 @@ int queue_factor(gphip_ctx* h, int nslots) {
             trailing(k, k0(k + 1), R, 4);
         }
     } else {
-        if (!built0) h->sync_used = 0;          // (the split build took the first event of this evaluation)
+        h->sync_used = 0;
         hipEvent_t built = sync_event(h);
         HIPCHK(hipEventRecord(built, h->stream));
-        HIPCHK(hipStreamWaitEvent(h->pstream, built0 ? built0 : built, 0));
-        // the trailing updates' stream (CU-masked for mid sizes, see gphip_ctx::rest_mask)
-        hipStream_t rs = h->stream;
-        {
-            const int res = h->rest_mask >= 0 ? h->rest_mask : 0;
-            if (res > 0 && nslots == 1 && !split && Nt <= h->rest_mask_max_nt && h->dist_world == 0) {
-                hipStream_t m = masked_rest_stream(h, res);
-                if (m) { rs = m; HIPCHK(hipStreamWaitEvent(rs, built, 0)); }
-            }
-        }
+        HIPCHK(hipStreamWaitEvent(h->pstream, built, 0));
         h->cs = h->pstream;
         if (pdf) df_panel(0, -1);
         else queue_panel<T>(h, 0, k0(1), nslots);
         hipEvent_t ev_panel = sync_event(h);
         HIPCHK(hipEventRecord(ev_panel, h->pstream));
-        hipEvent_t ev_rest = nullptr, ev_rest2 = nullptr;
+        hipEvent_t ev_rest = nullptr;
         // tail: once only `dataflow_tail` tile columns are left the dataflow kernel finishes the job in one
         // launch -- the last panels are chain bound, the regime the dataflow schedule wins
         int kc = nouter;
@@ -1094,8 +913,6 @@ int queue_factor(gphip_ctx* h, int nslots) {
             if (k + 1 == kc) {                  // last multi-kernel panel: apply it to everything, then cut over
                 h->cs = h->stream;
                 HIPCHK(hipStreamWaitEvent(h->stream, ev_panel, 0));
-                if (rs != h->stream && ev_rest) HIPCHK(hipStreamWaitEvent(h->stream, ev_rest, 0));
-                if (ev_rest2) HIPCHK(hipStreamWaitEvent(h->stream, ev_rest2, 0));
                 trailing(k, k0(k + 1), R, 4);
                 const int rem = Nt - k0(kc);                       // tile columns left
                 if (rem == 0) break;                               // (no tail: this was the last panel -- batches, or dataflow_tail off)
@@ -1114,27 +931,9 @@ int queue_factor(gphip_ctx* h, int nslots) {
                 launch_dataflow<T, 128, 1>(h, nslots, k0(kc));
                 break;
             }
-            if (k + 1 < nouter && h->la_main) {
-                // experiment (option "la_main", off): LA(k) FIRST on the main stream, with the chip to itself, the panel
-                // stream factoring panel k+1 when it is done -- under REST(k).  The contended SYRK number rises (0.74 ->
-                // 0.78 of peak in-run) because REST(k) no longer shares the CUs with LA(k), but the evaluation gets
-                // SLOWER (186.2 -> 189.4 ms): run back to back, LA(k) and REST(k) each pay their own partial last wave
-                // of workgroups; run together they fill each other's tails.
-                h->cs = h->stream;
-                HIPCHK(hipStreamWaitEvent(h->stream, ev_panel, 0));
-                trailing(k, k0(k + 1), k0(k + 2), 4);                          // LA(k)
-                hipEvent_t ev_la = sync_event(h);
-                HIPCHK(hipEventRecord(ev_la, h->stream));
+            if (k + 1 < nouter) {
                 h->cs = h->pstream;
-                HIPCHK(hipStreamWaitEvent(h->pstream, ev_la, 0));
-                queue_panel<T>(h, k0(k + 1), k0(k + 2) - k0(k + 1), nslots);    // factor panel k+1
-                ev_next = sync_event(h);
-                HIPCHK(hipEventRecord(ev_next, h->pstream));
-            } else if (k + 1 < nouter) {
-                h->cs = h->pstream;
-                if (k == 0 && built0) HIPCHK(hipStreamWaitEvent(h->pstream, built, 0));     // LA(0) reads columns the rest of the build writes
                 if (ev_rest) HIPCHK(hipStreamWaitEvent(h->pstream, ev_rest, 0));
-                if (ev_rest2) HIPCHK(hipStreamWaitEvent(h->pstream, ev_rest2, 0));
                 if (pdf) {
                     df_panel(k + 1, k);                                        // LA(k) + factor panel k+1, one launch
                 } else {
@@ -1146,29 +945,14 @@ int queue_factor(gphip_ctx* h, int nslots) {
                 ev_next = sync_event(h);
                 HIPCHK(hipEventRecord(ev_next, h->pstream));
             }
-            if (split && k0(k + 2) % 2 == 0) {
-                h->cs = h->stream2;
-                if (k == 0 && built0) HIPCHK(hipStreamWaitEvent(h->stream2, built, 0));
-                HIPCHK(hipStreamWaitEvent(h->stream2, ev_panel, 0));
-                trailing_half(k, k0(k + 2), 1);                                // REST(k), odd groups
-                ev_rest2 = sync_event(h);
-                HIPCHK(hipEventRecord(ev_rest2, h->stream2));
-                h->cs = h->stream;
-                HIPCHK(hipStreamWaitEvent(h->stream, ev_panel, 0));
-                trailing_half(k, k0(k + 2), 0);                                // REST(k), even groups
-            } else {
-                h->cs = rs;
-                HIPCHK(hipStreamWaitEvent(rs, ev_panel, 0));
-                if (ev_rest2) HIPCHK(hipStreamWaitEvent(rs, ev_rest2, 0));
-                trailing(k, k0(k + 2), R, 4);                                  // REST(k)
-            }
+            h->cs = h->stream;
+            HIPCHK(hipStreamWaitEvent(h->stream, ev_panel, 0));
+            trailing(k, k0(k + 2), R, 4);                                      // REST(k)
             ev_rest = sync_event(h);
-            HIPCHK(hipEventRecord(ev_rest, split && k0(k + 2) % 2 == 0 ? h->stream : rs));
+            HIPCHK(hipEventRecord(ev_rest, h->stream));
             ev_panel = ev_next;
         }
         h->cs = h->stream;
-        if (ev_rest2) HIPCHK(hipStreamWaitEvent(h->stream, ev_rest2, 0));
-        if (rs != h->stream && ev_rest) HIPCHK(hipStreamWaitEvent(h->stream, ev_rest, 0));
     }
     if (pdf) {
         launch_finalize<T>(h, nslots, 2 * Nt);
@@ -1449,7 +1233,7 @@ int eval_chunk(gphip_ctx* h, const double* Theta, int nb, double* out, double* p
     h->cs = h->stream;
     {
         ProfScope ps(h, 5, 0.0, 0.0);
-        if (!h->fused_eval) DISPATCH(h, queue_build, h, nb, true);
+        if (!h->fused_eval) DISPATCH(h, queue_build, h, nb);
         DISPATCH(h, queue_factor, h, nb);
     }
     h->fused_eval = false;
@@ -1523,8 +1307,6 @@ int set_func_attrs(gphip_ctx* h) {
     }
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trtri128_kernel<T>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)potrf_lds<T>()));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(panel_rows_kernel<T>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS));
     if (h->kt == 2 && h->d <= KB_LDS_MAXD) {   // general covariance form: both terms' row and column points in LDS
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>((kbuild_kernel<T, 0, 2>)),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * h->d * TB * sizeof(T))));
@@ -2090,7 +1872,6 @@ static int create_ctx(const void* X, const void* y, int64_t N, int64_t d, int ke
         (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
         if (hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, least) != hipSuccess) return bail(GPHIP_ERR_HIP);
         if (hipStreamCreateWithPriority(&h->pstream, hipStreamNonBlocking, greatest) != hipSuccess) return bail(GPHIP_ERR_HIP);
-        if (hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, least) != hipSuccess) return bail(GPHIP_ERR_HIP);
         h->cs = h->stream;
     }
     std::vector<double> xt((size_t)d * h->Npad, 0.0), yp((size_t)h->Npad, 0.0);
@@ -2275,10 +2056,6 @@ int gphip_destroy(gphip_handle h) {
     (void)hipFree(h->dNullMu); (void)hipFree(h->dNullOut); (void)hipFree(h->dPart);
     for (auto e : h->pool) (void)hipEventDestroy(e);
     for (auto e : h->sync_events) (void)hipEventDestroy(e);
-    if (h->stream2) { (void)hipStreamSynchronize(h->stream2); (void)hipStreamDestroy(h->stream2); }
-    if (h->chain_stream) (void)hipStreamDestroy(h->chain_stream);
-    if (h->rest_stream) (void)hipStreamDestroy(h->rest_stream);
-    if (h->bulk_stream) (void)hipStreamDestroy(h->bulk_stream);
     if (h->own_streams) {
         if (h->pstream) (void)hipStreamDestroy(h->pstream);
         if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -3240,7 +3017,7 @@ int gphip_dist_factor_panel(gphip_handle h, int k, void* packed) {
             const char* pbase = static_cast<const char*>(h->df_prev_ptr) - dist_panel_first(h, k - 1) * TS * (long)h->es;
             // (three workgroups per CU once the launch is throughput bound: the early, tall panels)
             const long ptasks = (long)2 * (K1 - K0) * (2 * (h->Nt - K0) + 1);
-            if (h->dataflow_occ3 > 0 || (h->dataflow_occ3 < 0 && ptasks >= h->dist_df_occ3_tasks))
+            if (h->dataflow_occ3 > 0)
                 launch_dataflow<double, 64, 3>(h, 1, 2 * (int)Kp, nullptr, 0, 2 * (int)(K1 - Kp), 2 * (int)(K0 - Kp), pbase);
             else
                 launch_dataflow<double, 64>(h, 1, 2 * (int)Kp, nullptr, 0, 2 * (int)(K1 - Kp), 2 * (int)(K0 - Kp), pbase);
@@ -3350,19 +3127,20 @@ int* option_slot(gphip_ctx* h, const char* name) {
     struct Entry { const char* name; int gphip_ctx::*field; };
     static const Entry table[] = {
         {"panel", &gphip_ctx::panel}, {"profile", &gphip_ctx::profile}, {"xcd_swizzle", &gphip_ctx::swizzle},
-        {"lookahead", &gphip_ctx::lookahead}, {"supertile", &gphip_ctx::supertile},
-        {"latency_gemm", &gphip_ctx::latency_gemm}, {"latency_tiles", &gphip_ctx::latency_tiles}, {"latency_max_nt", &gphip_ctx::latency_max_nt},
+        {"lookahead", &gphip_ctx::lookahead}, {"supertile", &gphip_ctx::supertile}, {"panel_wide", &gphip_ctx::panel_wide},
+        {"panel_left", &gphip_ctx::panel_left}, {"thin_tiles", &gphip_ctx::thin_tiles}, {"fuse_potrf", &gphip_ctx::fuse_potrf},
+        {"latency_gemm", &gphip_ctx::latency_gemm}, {"latency_max_nt", &gphip_ctx::latency_max_nt},
         {"dataflow", &gphip_ctx::dataflow}, {"dataflow_max_nt", &gphip_ctx::dataflow_max_nt},
         {"dataflow_max_slots", &gphip_ctx::dataflow_max_slots}, {"dataflow_fine_nt", &gphip_ctx::dataflow_fine_nt},
-        {"dataflow_tail", &gphip_ctx::dataflow_tail}, {"grad_potri", &gphip_ctx::grad_potri},
-        {"fused_eval", &gphip_ctx::fuse_option}, {"panel_left", &gphip_ctx::panel_left}, {"build_overlap", &gphip_ctx::build_overlap}, {"dataflow_lds_kib", &gphip_ctx::dataflow_lds_kib}, {"dataflow_park", &gphip_ctx::dataflow_park}, {"fuse_potrf", &gphip_ctx::fuse_potrf}, {"bcast_chunks", &gphip_ctx::bcast_chunks}, {"bcast_two_hop", &gphip_ctx::bcast_two_hop}, {"dist_panel_df", &gphip_ctx::dist_panel_df}, {"panel_df", &gphip_ctx::panel_df}, {"df_panel_one_wg_tasks", &gphip_ctx::df_panel_one_wg_tasks}, {"dist_df_occ3_tasks", &gphip_ctx::dist_df_occ3_tasks}, {"dataflow_occ3", &gphip_ctx::dataflow_occ3}, {"panel_rows", &gphip_ctx::panel_rows}, {"df_split", &gphip_ctx::df_split}, {"df_split_lds_kib", &gphip_ctx::df_split_lds_kib}, {"df_split_min_tasks", &gphip_ctx::df_split_min_tasks}, {"rest_mask", &gphip_ctx::rest_mask}, {"rest_mask_max_nt", &gphip_ctx::rest_mask_max_nt}, {"df_split_auto", &gphip_ctx::df_split_auto}, {"df_split_width", &gphip_ctx::df_split_width},
-        {"max_slots", &gphip_ctx::max_slots}, {"shard_min_n", &gphip_ctx::shard_min_n},
-        {"thin_tiles", &gphip_ctx::thin_tiles}, {"panel_wide", &gphip_ctx::panel_wide},
-        {"la_main", &gphip_ctx::la_main}, {"rest_split", &gphip_ctx::rest_split},
-        {"debug_fail_alloc", &gphip_ctx::debug_fail_alloc}, {"debug_fail_hip", &gphip_ctx::debug_fail_hip}, {"replicate_factor", &gphip_ctx::replicate_factor},
-        {"share_local_panels", &gphip_ctx::share_local_panels},
+        {"dataflow_tail", &gphip_ctx::dataflow_tail}, {"dataflow_lds_kib", &gphip_ctx::dataflow_lds_kib},
+        {"dataflow_park", &gphip_ctx::dataflow_park}, {"dataflow_occ3", &gphip_ctx::dataflow_occ3},
+        {"fused_eval", &gphip_ctx::fuse_option}, {"panel_df", &gphip_ctx::panel_df}, {"grad_potri", &gphip_ctx::grad_potri},
         {"kbuild_mfma", &gphip_ctx::kbuild_mfma}, {"kbuild_mfma_bound", &gphip_ctx::kbuild_mfma_bound},
         {"custom_grad", &gphip_ctx::custom_grad}, {"grad_analytic", &gphip_ctx::grad_analytic},
+        {"max_slots", &gphip_ctx::max_slots}, {"shard_min_n", &gphip_ctx::shard_min_n},
+        {"replicate_factor", &gphip_ctx::replicate_factor}, {"share_local_panels", &gphip_ctx::share_local_panels},
+        {"bcast_chunks", &gphip_ctx::bcast_chunks}, {"bcast_two_hop", &gphip_ctx::bcast_two_hop}, {"dist_panel_df", &gphip_ctx::dist_panel_df},
+        {"debug_fail_alloc", &gphip_ctx::debug_fail_alloc}, {"debug_fail_hip", &gphip_ctx::debug_fail_hip},
     };
     for (const Entry& e : table)
         if (!strcmp(name, e.name)) return &(h->*(e.field));

@@ -263,7 +263,7 @@ int gphip_ns_crude_weights(const double* points, const double* loglik, int64_t m
  *                  less cache-to-L2 traffic, SYRK alone 0.849 -> 0.861 of peak); 3 = 2, for batches of thetas too (measured: no
  *                  difference there)
  *   "lookahead"    0/1 factor panel k+1 on a second stream under the trailing update of panel k (default 1)
- *   "latency_gemm" / "latency_tiles"   4x4-wave GEMM shape for launches of <= latency_tiles tiles (small N)
+ *   "latency_gemm" 0/1 4x4-wave GEMM shape for launches of <= 256 tiles of problems up to "latency_max_nt" tile columns
  *   "dataflow"     0/1 single-launch dataflow Cholesky (one workgroup per tile, flags instead of launches)
  *                  for problems of <= "dataflow_max_nt" 128-tiles (default 96, N <= 12288) and
  *                  <= "dataflow_max_slots" thetas per call (default 8), with 64x64 tiles up to
@@ -283,19 +283,11 @@ int gphip_ns_crude_weights(const double* points, const double* loglik, int64_t m
  *                  auto = launches of >= 6 000 tile tasks, which are throughput bound (N = 12288: -6.5 %)
  *   "dataflow_park" 0/1 (default 1): 64-tile dataflow launches with two workgroups per CU -- the workgroup sharing a CU with a
  *                  diagonal (chain) task sleeps while that task is in its critical section (N = 6144: -9 %, 8192: -1 %)
- *   "build_overlap" 0/1 (default 0): the look-ahead schedule builds the tile columns of outer panel 0 first and starts
- *                  factoring them on the panel stream while the main stream builds the rest of K (measured: the first
- *                  trailing update starts 0.2-0.7 ms earlier, -0.1 % at N = 32768, noise for batches whose build fills
- *                  every CU anyway -- while the build kernel itself runs 4-15 % slower sharing the chip; kept off)
  *   "fused_eval"   0/1 (default 1): a pure likelihood call of <= 8 thetas that qualifies for 64-tile dataflow
  *                  runs as ONE kernel launch (K(theta) tiles built inside the kernel, results written to
  *                  pinned host memory by its last task)
  *   "grad_potri"   0/1 gradient: form K^-1 = U U^T in one go when 2 N^2 of scratch fits (default 1), else
  *                  stream it in row blocks through forward + backward substitution
- *   "rest_split"   0/1 (default 0): experiment -- each trailing update as two grouped launches (alternating 2-tile column
- *                  groups) on two streams, so that consecutive steps overlap their launch tails (-1.1 % at N=32768)
- *   "la_main"      0/1 (default 0): experiment -- look-ahead update on the main stream ahead of the trailing update instead of
- *                  beside it on the panel stream (higher contended SYRK rate, slower evaluation)
  *   "thin_tiles"   0/1 (default 1): the GEMM kernel skips work whose result is known or never read -- all but the first
  *                  of the 128 bordered right-hand-side rows (zero), and the strictly-upper quadrant of diagonal tiles
  *   "max_slots"    cap on concurrently resident batch matrices
@@ -321,12 +313,13 @@ int gphip_ns_crude_weights(const double* points, const double* loglik, int64_t m
  *                  chain of kernels 31.8 -> 22.6 ms per N = 32768 evaluation with the chip to itself, but a panel is then final only
  *                  when its launch ends, so "bcast_chunks" cannot overlap its columns with the factorisation any more (which side
  *                  wins depends on the link bandwidth: bench.py --gpus N times both).  Rank-local: need not agree across ranks.
- *   Round-4 experiments, all bit-identical to the default and all measured SLOWER on one MI355X (kept off):
- *   "df_split" r / "df_split_width" w / "df_split_lds_kib": the 64-tile dataflow launch split over two CU-masked streams --
- *                  the w tiles of every column nearest the diagonal as their own launch on r reserved CUs per XCD;
- *   "rest_mask" r: look-ahead schedule, the trailing updates on a stream whose CU mask leaves r CUs per XCD to the panel stream;
- *   "batch_groups" g / "batch_group_min": a large theta batch as g phase-shifted slot groups on their own stream pairs;
- *   "panel_rows"   batches: the rows below a panel's diagonal block handled by one fused row-panel kernel.
+ *   "kbuild_mfma"  0 / 1 (default) / 2: the kernel-matrix build of the SE / Matern-5/2 kernels with the cross term of the squared
+ *                  distances on the matrix pipe (kbuild_mfma_kernel): never / for every theta whose accuracy bound
+ *                  sum_k (halfrange_k / l_k)^2 <= "kbuild_mfma_bound" (default 512; fp32: / 8) holds / always (tests).  Slots above
+ *                  the bound are built by the direct-difference kernel, per theta of a batch.
+ *   "custom_grad"  0/1 (default 1): gphip_loglik_grad of a run-time compiled covariance function through forward-mode dual
+ *                  numbers (one factorisation); 0 = central differences.  "grad_analytic" (read-only) = 1 after a gradient call
+ *                  that took the one-factorisation route.
  *   "debug_fail_alloc" / "debug_fail_hip" n: tests only -- the n-th device allocation of the next slot allocation / the n-th checked
  *                  HIP call of the next collective sequence fails (fault injection of the multi-process tests).
  *   "panel", "shard_min_n", "replicate_factor", "bcast_chunks", "bcast_two_hop" must have the same value on every rank of a

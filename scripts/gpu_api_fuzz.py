@@ -56,18 +56,15 @@ while time.time() < t_end:
         if op == "option":
             name = str(rng.choice(["panel", "dataflow", "lookahead", "thin_tiles", "fused_eval", "dataflow_fine_nt", "panel_wide",
                                    "dataflow_tail", "grad_potri", "max_slots", "latency_gemm", "shard_min_n", "panel_left",
-                                   "replicate_factor", "share_local_panels", "debug_fail_alloc", "supertile", "build_overlap", "dataflow_park", "dataflow_lds_kib", "fuse_potrf", "bcast_chunks",
-                                   "df_split", "df_split_width", "batch_groups", "batch_group_min", "panel_rows", "rest_mask", "dist_panel_df", "bcast_two_hop", "panel_df", "df_panel_one_wg_tasks"]))
+                                   "replicate_factor", "share_local_panels", "debug_fail_alloc", "supertile", "dataflow_park", "dataflow_lds_kib", "fuse_potrf", "bcast_chunks",
+                                   "dist_panel_df", "bcast_two_hop", "panel_df"]))
             if name == "debug_fail_alloc" and rng.random() < 0.7:
                 name = "panel"
             val = {"panel": int(rng.choice([1, 2, 3, 4, 6])), "dataflow_fine_nt": int(rng.choice([0, 96])),
                    "debug_fail_alloc": int(rng.choice([1, 3, 7, 10])),
                    "dataflow_tail": int(rng.choice([0, 7, 64])), "max_slots": int(rng.choice([1, 3, 256])),
-                   "shard_min_n": int(rng.choice([0, 1 << 30])), "panel_left": int(rng.choice([-1, 0, 1])), "supertile": int(rng.choice([0, 1, 2, 3])), "dataflow_lds_kib": int(rng.choice([-1, 0, 84])),
-                   "df_split": int(rng.choice([0, 1, 3])), "df_split_width": int(rng.choice([1, 2, 4])), "batch_groups": int(rng.choice([1, 2, 3, -1])),
-                   "batch_group_min": int(rng.choice([9, 12, 48])), "rest_mask": int(rng.choice([0, 1, 3])),
-                   "dist_panel_df": int(rng.choice([0, 1, 2])), "panel_df": int(rng.choice([-1, 0, 1])),
-                   "df_panel_one_wg_tasks": int(rng.choice([0, 600, 2700]))}.get(name, int(rng.integers(0, 2)))
+                   "shard_min_n": int(rng.choice([0, 1 << 30])), "panel_left": int(rng.choice([-1, 0, 1])), "supertile": int(rng.choice([0, 2, 3])), "dataflow_lds_kib": int(rng.choice([-1, 0, 84])),
+                   "dist_panel_df": int(rng.choice([0, 1, 2])), "panel_df": int(rng.choice([-1, 0, 1]))}.get(name, int(rng.integers(0, 2)))
             print(f'    {name}={val}', file=log, flush=True)
             if name == "debug_fail_alloc":
                 # fault injection: the next slot (re)allocation fails at its val-th device allocation; the call must

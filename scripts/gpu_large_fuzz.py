@@ -1,5 +1,5 @@
 """Large-N option fuzz: N in {8209, 10000, 12301} (ragged), one numpy reference per handle, then every option combination
-must reproduce it: look-ahead, panel width, wide panels, thin tiles, dataflow tail, la_main, rest_split, gradient routes;
+must reproduce it: look-ahead, panel width, wide panels, thin tiles, dataflow tail, gradient routes;
 fit -> solve / predict consistency."""
 import os, sys, time
 import numpy as np
@@ -22,8 +22,8 @@ for n in (8209, 10000, 12301):
     for it in range(10):
         opts = {"dataflow": int(rng.integers(0, 2)), "lookahead": int(rng.integers(0, 2)), "panel": int(rng.choice([2, 3, 4, 6])),
                 "panel_wide": int(rng.integers(0, 2)), "thin_tiles": int(rng.integers(0, 2)), "dataflow_tail": int(rng.choice([0, 13, 40, 64])),
-                "la_main": int(rng.integers(0, 2)), "rest_split": int(rng.integers(0, 2)), "grad_potri": int(rng.integers(0, 2)),
-                "supertile": int(rng.choice([0, 1, 2, 3])), "build_overlap": int(rng.integers(0, 2)), "fuse_potrf": int(rng.integers(0, 2)),
+                "grad_potri": int(rng.integers(0, 2)),
+                "supertile": int(rng.choice([0, 2, 3])), "fuse_potrf": int(rng.integers(0, 2)),
                 "panel_left": int(rng.choice([-1, 0, 1]))}
         for k, v in opts.items(): h.set_option(k, v)
         ll, info = h.loglik(th)
