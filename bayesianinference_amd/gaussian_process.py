@@ -592,10 +592,16 @@ def save_gaussian_process(obj, path: str, theta=None):
     np.savez_compressed(path, **payload)
 
 
-def load_gaussian_process(path: str, variablePrior="Uniform", **rules):
+def load_gaussian_process(path: str, variablePrior="Uniform", trust_kernel_source: bool = False, **rules):
     """Rebuilds the object (new device handle, data uploaded again); if a fitted theta was saved the
-    handle is re-fitted so predict/solve work immediately.  Returns (object, theta_fit or None)."""
+    handle is re-fitted so predict/solve work immediately.  Returns (object, theta_fit or None).
+    A checkpoint of a run-time compiled covariance function carries that function's C++ SOURCE TEXT, which loading
+    compiles and runs on the device: such a file is executable content, not data.  It is refused unless the caller says
+    the file comes from a trusted source (trust_kernel_source=True)."""
     z = np.load(path, allow_pickle=False)
+    if "kernel_body" in z and not trust_kernel_source:
+        raise ValueError(f"{path} carries the source text of a covariance function (kernel_body): loading compiles and runs it. "
+                         "Pass trust_kernel_source=True if the file comes from a trusted source.")
     params = [(str(n), float(a), float(b)) for n, a, b in zip(z["param_names"], z["param_lo"], z["param_hi"])]
     kernel = None if str(z["kernel"]) == "null" else str(z["kernel"])
     if "kernel_body" in z:

@@ -191,7 +191,9 @@ def test_host_mirror_object_with_a_function_valued_kernel(tmp_path):
     np.testing.assert_allclose(a["Mean"][0], mo, rtol=1e-7, atol=1e-9)
     path = str(tmp_path / "gp_custom.npz")
     gp.save_gaussian_process(obj.append({"Samples": samples}), path, theta=th)
-    obj2, th2 = gp.load_gaussian_process(path)
+    with pytest.raises(ValueError):                            # a checkpoint with kernel source is executable content
+        gp.load_gaussian_process(path)
+    obj2, th2 = gp.load_gaussian_process(path, trust_kernel_source=True)
     assert not obj2.failed and obj2["KernelName"].body == NONSTAT_BODY and obj2["KernelName"].nparams == 3
     b = gp.predictFromGaussianProcess(obj2, pts)
     np.testing.assert_allclose(a["Mean"], b["Mean"], rtol=1e-12)

@@ -265,7 +265,7 @@ def test_new_shim_entry_points_pointwise_kernels_device_count_and_native_sampler
     K.lib.WolframLibrary_uninitialize(K.data)
 
 
-def test_native_sampler_with_a_tabulated_normal_prior_matches_quadrature_over_20_seeds():
+def test_native_sampler_with_a_tabulated_normal_prior_matches_quadrature_over_30_seeds():
     """nestedSamplingHIP for a NON-uniform (separable) prior: gphip_wl_nested_sampling_tab takes each factor's log density as a
     table over the parameter's range (what GPHIP.wl sends for a ProductDistribution of univariate distributions) and a
     starting pool drawn from the prior.  Null kernel + constant mean: log L(sn, mu) is analytic, so the evidence under
@@ -300,7 +300,7 @@ def test_native_sampler_with_a_tabulated_normal_prior_matches_quadrature_over_20
     rc, hs = K.call("gphip_wl_create", [X, y, 4, 1, 64, np.array([0])], "int")          # null kernel, constant mean
     assert rc == NO_ERROR
     pool, zs = 60, []
-    for seed in range(20):
+    for seed in range(30):
         r = np.random.default_rng(100 + seed)
         start = np.empty((pool, 2))
         start[:, 0] = r.uniform(box[0, 0], box[0, 1], pool)
@@ -327,7 +327,9 @@ def test_native_sampler_with_a_tabulated_normal_prior_matches_quadrature_over_20
         out = ns.evidence_sampling(res, ["sn", "mu"], pool, np.random.default_rng(seed))
         zs.append((out["LogEvidence"]["Mean"] - want) / out["LogEvidence"]["StandardError"])
     zs = np.array(zs)
-    assert abs(zs.mean()) < 0.5 and np.all(np.abs(zs) < 4.0), zs
+    # (30 seeds: the mean of unbiased z-scores has sigma 0.18; 60-seed runs of scripts/gpu_tab_pool_bias.py: -0.02 +- 0.14 with
+    #  the pool given, -0.20 +- 0.13 with the pool drawn by the library)
+    assert abs(zs.mean()) < 0.55 and np.all(np.abs(zs) < 4.0), zs
     assert 0.5 < zs.std(ddof=1) < 2.0, zs
     # argument checks: table row count, too few nodes, missing pool
     assert K.call("gphip_wl_nested_sampling_tab", [hs, box, tab[:1], opts, start])[0] == DIMENSION_ERROR
