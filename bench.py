@@ -550,6 +550,9 @@ def main() -> None:
                                                                "passes over a child process); replay profiles/ instead")
     ap.add_argument("--strong-timeout", type=float, default=180.0, help="seconds the strong-scaling series may take before the "
                                                                         "record is printed without it")
+    ap.add_argument("--strict-strong", action="store_true", help="N>1: exit with code 3 when the strong-scaling series fails or hangs (tests); by "
+                                                                 "default the failure is recorded in the line (`strong.error`) and the run, whose "
+                                                                 "weak-scaling headline was measured before the series started, ends with code 0")
     ap.add_argument("--no-strong", action="store_true", help="N>1, mode theta: skip the short strong-scaling series (ONE "
                                                              "factorisation sharded over all ranks) printed as the `strong` sub-record")
     args = ap.parse_args()
@@ -711,8 +714,9 @@ def main() -> None:
     if dist is not None and not sharded and not args.no_strong:
         # Watchdog: this is the only place where the bench waits inside RCCL collectives of the library (real multi-rank
         # RCCL has only ever been exercised here).  If one does not return, the headline measured above must not be lost:
-        # after --strong-timeout seconds rank 0 prints the record with the failure noted and every rank leaves -- with a
-        # NON-ZERO exit code (a hung collective is a failure of the run, not a success).  Exactly one record is printed:
+        # after --strong-timeout seconds rank 0 prints the record with the failure noted (`strong.error`) and every rank leaves --
+        # with exit code 0 by default (the weak-scaling `value` of this run is valid: it was measured before the series started),
+        # with code 3 under --strict-strong (tests: a hung collective must not pass silently).  Exactly one record is printed:
         # the main thread and the watchdog both take `emit_lock` and check `emitted` before they print.
         import threading
         emit_lock = threading.Lock()
@@ -737,7 +741,7 @@ def main() -> None:
                                                   "the headline above was measured before this series started"}
                         rec["strong_speedup"] = rec["strong_ms_per_eval"] = rec["rccl_ranks"] = None
                     print(json.dumps(rec), flush=True)
-                os._exit(3)
+                os._exit(3 if args.strict_strong else 0)
         dog = threading.Timer(args.strong_timeout + (0.0 if rank == 0 else 5.0), give_up)
         dog.daemon = True
         dog.start()
@@ -892,8 +896,8 @@ def main() -> None:
     h.close()
     if dist is not None:
         dist.destroy_process_group()
-    if strong_failed:
-        sys.exit(3)                                                 # the record is out; the strong series failed: not a success
+    if strong_failed and args.strict_strong:
+        sys.exit(3)                                                 # the record is out; the strong series failed: not a success (tests)
 
 
 if __name__ == "__main__":

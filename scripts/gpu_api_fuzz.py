@@ -57,14 +57,15 @@ while time.time() < t_end:
             name = str(rng.choice(["panel", "dataflow", "lookahead", "thin_tiles", "fused_eval", "dataflow_fine_nt", "panel_wide",
                                    "dataflow_tail", "grad_potri", "max_slots", "latency_gemm", "shard_min_n", "panel_left",
                                    "replicate_factor", "share_local_panels", "debug_fail_alloc", "supertile", "dataflow_park", "dataflow_lds_kib", "fuse_potrf", "bcast_chunks",
-                                   "dist_panel_df", "bcast_two_hop", "panel_df"]))
+                                   "dist_panel_df", "bcast_two_hop", "panel_df", "kbuild_mfma", "kbuild_mfma_bound", "custom_grad"]))
             if name == "debug_fail_alloc" and rng.random() < 0.7:
                 name = "panel"
             val = {"panel": int(rng.choice([1, 2, 3, 4, 6])), "dataflow_fine_nt": int(rng.choice([0, 96])),
                    "debug_fail_alloc": int(rng.choice([1, 3, 7, 10])),
                    "dataflow_tail": int(rng.choice([0, 7, 64])), "max_slots": int(rng.choice([1, 3, 256])),
                    "shard_min_n": int(rng.choice([0, 1 << 30])), "panel_left": int(rng.choice([-1, 0, 1])), "supertile": int(rng.choice([0, 2, 3])), "dataflow_lds_kib": int(rng.choice([-1, 0, 84])),
-                   "dist_panel_df": int(rng.choice([0, 1, 2])), "panel_df": int(rng.choice([-1, 0, 1]))}.get(name, int(rng.integers(0, 2)))
+                   "dist_panel_df": int(rng.choice([0, 1, 2])), "panel_df": int(rng.choice([-1, 0, 1])),
+                   "kbuild_mfma": int(rng.choice([0, 1, 2])), "kbuild_mfma_bound": int(rng.choice([1, 64, 512]))}.get(name, int(rng.integers(0, 2)))
             print(f'    {name}={val}', file=log, flush=True)
             if name == "debug_fail_alloc":
                 # fault injection: the next slot (re)allocation fails at its val-th device allocation; the call must
