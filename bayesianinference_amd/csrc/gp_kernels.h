@@ -39,7 +39,7 @@ namespace gphip {
 
 // Bumped whenever a struct or constant the run-time compiled copy of this region shares with the offline library changes
 // (KBuildArgs, SLOTP, the tile layout): rtc_dyn.h refuses a source tree whose value differs from the library's own.
-#define GP_RTC_ABI 3
+#define GP_RTC_ABI 4
 constexpr int TB = 128;         // tile edge
 // elements between consecutive tiles of the packed workspace (a pad behind every tile was measured in round 3: no gain)
 constexpr long TS = (long)TB * TB;
@@ -638,6 +638,8 @@ struct GradArgs {
     double* gacc;                   // [d + 2]; general form: [2 d + 6], see grad_reduce_general_kernel
     const T* xs2;                   // general form: inputs scaled by the second term's length scales (or null)
     KSpec ks;
+    int d0;                         // general form, more than KB_LDS_MAXD dimensions: this launch accumulates the length-scale
+                                    // derivatives of dimensions [d0, d0 + 32) only (and the scalar ones when d0 == 0)
 };
 
 #if defined(GP_CUSTOM_KERNEL) && defined(GP_CUSTOM_GRAD)
@@ -2755,11 +2757,16 @@ template <typename T>
 __global__ __launch_bounds__(256) void grad_reduce_general_kernel(GradArgs<T> a) {
     extern __shared__ double lds_raw[];
     const int d = a.d;
+    // Beyond KB_LDS_MAXD dimensions the point tiles do not fit in LDS and 32 accumulators per term are all the registers
+    // hold: the points are then read from global memory (L1 / L2 resident: 2 x 128 points per workgroup) and the launch
+    // covers the length-scale derivatives of the dimension window [d0, d0 + 32) only -- the host launches ceil(d / 32) times.
+    const bool glb = d > KB_LDS_MAXD;
+    const int d0 = glb ? a.d0 : 0;
     T* xjs = reinterpret_cast<T*>(lds_raw);      // [d][128] column points (term 1), then rows, then the same for term 2
-    T* xis = xjs + d * TB;
-    T* xjs2 = xis + d * TB;
-    T* xis2 = xjs2 + d * TB;
-    T* aj = xis2 + d * TB;
+    T* xis = xjs + (glb ? 0 : d * TB);
+    T* xjs2 = xis + (glb ? 0 : d * TB);
+    T* xis2 = xjs2 + (glb ? 0 : d * TB);
+    T* aj = xis2 + (glb ? 0 : d * TB);
     const bool two = a.ks.op != 0;
     const int tid = threadIdx.x, row = tid & 127, half = tid >> 7;
     const int ti = blockIdx.x, tj = blockIdx.y;
@@ -2767,7 +2774,7 @@ __global__ __launch_bounds__(256) void grad_reduce_general_kernel(GradArgs<T> a)
     const double wt = (a.tri && tj < ti) ? 2.0 : 1.0;
     const int t = ti * TB + row, g = a.c0 + t;
     const int g0 = a.c0 + ti * TB;               // first row point of this tile
-    for (int idx = tid; idx < d * TB; idx += 256) {
+    for (int idx = tid; idx < (glb ? 0 : d * TB); idx += 256) {
         const int dd = idx >> 7, c = idx & 127;
         xjs[idx] = a.xs[(long)dd * a.npad + tj * TB + c];
         xis[idx] = (g0 + c < a.npad) ? a.xs[(long)dd * a.npad + g0 + c] : (T)0;
@@ -2777,6 +2784,11 @@ __global__ __launch_bounds__(256) void grad_reduce_general_kernel(GradArgs<T> a)
         }
     }
     if (tid < TB) aj[tid] = a.alpha[tj * TB + tid];
+    // coordinate dd of this thread's row point / of column point jj, term 1 and term 2
+    auto xi1 = [&](int dd) -> T { return glb ? a.xs[(long)dd * a.npad + g] : xis[dd * TB + row]; };
+    auto xj1 = [&](int dd, int jj) -> T { return glb ? a.xs[(long)dd * a.npad + tj * TB + jj] : xjs[dd * TB + jj]; };
+    auto xi2 = [&](int dd) -> T { return glb ? a.xs2[(long)dd * a.npad + g] : xis2[dd * TB + row]; };
+    auto xj2 = [&](int dd, int jj) -> T { return glb ? a.xs2[(long)dd * a.npad + tj * TB + jj] : xjs2[dd * TB + jj]; };
     double acc1[32], acc2[32];
 #pragma unroll
     for (int dd = 0; dd < 32; ++dd) acc1[dd] = acc2[dd] = 0.0;
@@ -2791,12 +2803,12 @@ __global__ __launch_bounds__(256) void grad_reduce_general_kernel(GradArgs<T> a)
             if (j >= a.n) break;
             T r2a = (T)0, r2b = (T)0;
             for (int dd = 0; dd < d; ++dd) {
-                const T u = xis[dd * TB + row] - xjs[dd * TB + jj];
+                const T u = xi1(dd) - xj1(dd, jj);
                 r2a += u * u;
             }
             if (two)
                 for (int dd = 0; dd < d; ++dd) {
-                    const T u = xis2[dd * TB + row] - xjs2[dd * TB + jj];
+                    const T u = xi2(dd) - xj2(dd, jj);
                     r2b += u * u;
                 }
             T g1, m1, da1, g2 = (T)0, m2 = (T)0, da2 = (T)0;
@@ -2807,17 +2819,17 @@ __global__ __launch_bounds__(256) void grad_reduce_general_kernel(GradArgs<T> a)
             const double w = wt * ((double)ag * (double)aj[jj] - (double)a.Kinv[(long)j * a.ldv + t]);
             const double f1 = w * dk1 * (double)sf2a * (double)m1, f2 = w * dk2 * (double)sf2b * (double)m2;
 #pragma unroll
-            for (int dd = 0; dd < 32; ++dd)            // (static indices: the accumulators stay in registers)
-                if (dd < d) {
-                    const double u = (double)(xis[dd * TB + row] - xjs[dd * TB + jj]);
-                    acc1[dd] = __builtin_fma(f1, u * u, acc1[dd]);
+            for (int q = 0; q < 32; ++q)               // (static indices: the accumulators stay in registers)
+                if (d0 + q < d) {
+                    const double u = (double)(xi1(d0 + q) - xj1(d0 + q, jj));
+                    acc1[q] = __builtin_fma(f1, u * u, acc1[q]);
                 }
             if (two) {
 #pragma unroll
-                for (int dd = 0; dd < 32; ++dd)
-                    if (dd < d) {
-                        const double u = (double)(xis2[dd * TB + row] - xjs2[dd * TB + jj]);
-                        acc2[dd] = __builtin_fma(f2, u * u, acc2[dd]);
+                for (int q = 0; q < 32; ++q)
+                    if (d0 + q < d) {
+                        const double u = (double)(xi2(d0 + q) - xj2(d0 + q, jj));
+                        acc2[q] = __builtin_fma(f2, u * u, acc2[q]);
                     }
             }
             acc_sf1 = __builtin_fma(w * dk1, k1, acc_sf1);
@@ -2834,17 +2846,19 @@ __global__ __launch_bounds__(256) void grad_reduce_general_kernel(GradArgs<T> a)
         if (lane == 0) atomicAdd(dst, v);
     };
 #pragma unroll
-    for (int dd = 0; dd < 32; ++dd)
-        if (dd < d) {
-            wave_add(acc1[dd], a.gacc + dd);
-            if (two) wave_add(acc2[dd], a.gacc + d + 2 + dd);
+    for (int q = 0; q < 32; ++q)
+        if (d0 + q < d) {
+            wave_add(acc1[q], a.gacc + d0 + q);
+            if (two) wave_add(acc2[q], a.gacc + d + 2 + d0 + q);
         }
-    wave_add(acc_sf1, a.gacc + d);
-    wave_add(acc_dg, a.gacc + d + 1);
-    if (two) wave_add(acc_sf2, a.gacc + 2 * d + 2);
-    wave_add(acc_a1, a.gacc + 2 * d + 3);
-    if (two) wave_add(acc_a2, a.gacc + 2 * d + 4);
-    wave_add(acc_c, a.gacc + 2 * d + 5);
+    if (d0 == 0) {                                 // the scalar derivatives once, whatever the number of windows
+        wave_add(acc_sf1, a.gacc + d);
+        wave_add(acc_dg, a.gacc + d + 1);
+        if (two) wave_add(acc_sf2, a.gacc + 2 * d + 2);
+        wave_add(acc_a1, a.gacc + 2 * d + 3);
+        if (two) wave_add(acc_a2, a.gacc + 2 * d + 4);
+        wave_add(acc_c, a.gacc + 2 * d + 5);
+    }
 }
 
 // Null kernel Function[0] (BGP:25-27, 156-159): K = diag(sn^2), so the quadratic form is

@@ -1614,6 +1614,15 @@ void launch_grad(gphip_ctx* h, GradArgs<T>& a, dim3 grid) {
         (void)hipModuleLaunchKernel(h->f_cgrad, grid.x, grid.y, grid.z, 256, 1, 1, (unsigned)lds, h->cs, params, nullptr);
         return;
     }
+    if (a.d > KB_LDS_MAXD) {
+        // any form, more dimensions than the specialised kernels hold in LDS / registers: the general kernel reading the points
+        // from global memory, one launch per window of 32 length-scale derivatives
+        a.ks = h->ks; a.xs2 = (const T*)h->dXs2;
+        for (a.d0 = 0; a.d0 < a.d; a.d0 += 32)
+            hipLaunchKernelGGL(grad_reduce_general_kernel<T>, grid, dim3(256), (size_t)TB * sizeof(T), h->cs, a);
+        a.d0 = 0;
+        return;
+    }
     if (h->kt == 0) launch_grad_kt<T, 0>(h, a, grid);
     else if (h->kt == 1) launch_grad_kt<T, 1>(h, a, grid);
     else {
@@ -2142,9 +2151,8 @@ int gphip_loglik_grad(gphip_handle h, const double* theta, int p, double* out, d
                           ? (ll[(size_t)1 + 2 * k] - ll[(size_t)2 + 2 * k]) / (2.0 * step[(size_t)k]) : std::nan("");
         return GPHIP_OK;
     }
-    // the gradient reductions keep (d + 1) point tiles (general form: 4 d + 1) in LDS: beyond KB_LDS_MAXD dimensions only the
-    // likelihood / fit / prediction paths are implemented (they read the points from global memory instead)
-    if (!h->custom && h->d > KB_LDS_MAXD) return fail(h, GPHIP_ERR_UNSUPPORTED, "gphip_loglik_grad supports input dimensions up to 32");
+    // (the gradient reductions keep (d + 1) point tiles -- general form: 4 d + 1 -- in LDS up to KB_LDS_MAXD dimensions; beyond,
+    //  launch_grad reads the points from global memory in windows of 32 length-scale derivatives)
     double parts[2] = {0, 0};
     h->want_w = true;                          // (a multi-device handle factors on its first device: the K^-1 contraction needs the whole factor)
     int rc = eval_batch_local(h, theta, 1, p, out, parts, info);

@@ -543,9 +543,13 @@ def test_edge_shapes_and_chunking():
         mo, so = orc.predict_internal(kern, th, X, y, Xs)
         np.testing.assert_allclose(mu, mo, rtol=1e-7 if dtype == 64 else 2e-3, atol=1e-9 if dtype == 64 else 2e-3)
         np.testing.assert_allclose(np.sqrt(var), so, rtol=1e-7 if dtype == 64 else 2e-3)
-        with pytest.raises(_lib.GphipError) as e:
-            h.loglik_grad(th)
-        assert e.value.status == 6                               # gradients: d <= 32
+        # gradients beyond 32 dimensions (round 5): the general reduction reading the points from global memory, one launch per
+        # window of 32 length-scale derivatives -- against the oracle's analytic gradient
+        gl, gg, gi = h.loglik_grad(th)
+        want = orc.log_likelihood_grad(kern, th, X, y)
+        assert gi == 0 and close(gl, ll, 300, 1e-10 if dtype == 64 else 1e-4)
+        gtol = 3e-2 if dtype == 32 else (2e-6 if "+" in kern else 1e-7)       # (composed forms: the oracle differentiates numerically)
+        np.testing.assert_allclose(gg, want, rtol=gtol, atol=gtol * max(1.0, np.abs(want).max()))
         h.close()
     # nrhs = 2100 > 2048 -> two chunks through gphip_solve
     X, y = syn.make_dataset(130, 2)
