@@ -4,4 +4,4 @@ Drop-in for the GP hot path of ssmit1986/BayesianInference: hand
 kernels for gfx950 behind a plain C ABI (include/gphip.h), with a Python host-side mirror of the
 reference's `defineGaussianProcess` / `predictFromGaussianProcess` / `inferenceObject` interface.
 """
-__version__ = "0.3.0"
+__version__ = "0.5.0"

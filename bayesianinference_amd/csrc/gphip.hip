@@ -1794,7 +1794,7 @@ int eval_batch(gphip_ctx* h, const double* Theta, int B, int p, double* out, dou
 
 extern "C" {
 
-const char* gphip_version(void) { return "gphip 0.4.0 (gfx950; fp64 + fp32; multi-device; tile-major)"; }
+const char* gphip_version(void) { return "gphip 0.5.0 (gfx950; fp64 + fp32; multi-device; tile-major; MFMA kernel build)"; }
 
 int gphip_device_count(int* n) {
     if (!n) return GPHIP_ERR_ARG;
