@@ -868,16 +868,9 @@ __global__ __launch_bounds__(256, 2) void kbuild_mfma_kernel(KBuildMArgs<T> m) {
     // MFMA and VALU phases overlap -- and the code small
 #pragma unroll 1
     for (int step = 0; step < 2 * NIB; ++step) {
-#ifndef GP_KM_INTERLEAVE
-#define GP_KM_INTERLEAVE 1
-#endif
-        // which 16-column block x row block this wave takes in this step.  0: a wave owns 32 columns (two blocks) and walks the
-        // rows; 1: waves take ADJACENT column blocks (w, w + 4) -- the workgroup's stores of a moment fall into one contiguous
-        // 64 KiB of the tile; 2: the waves split the ROWS of one column block -- one contiguous 16 KiB at a time
-        int jb, ib;
-        if (GP_KM_INTERLEAVE == 2) { ib = wave % NIB; jb = step * (4 / NIB) + wave / NIB; }
-        else if (GP_KM_INTERLEAVE == 1) { jb = wave + 4 * (step / NIB); ib = step % NIB; }
-        else { jb = 2 * wave + step / NIB; ib = step % NIB; }
+        // the four waves take ADJACENT 16-column blocks (w, w + 4): the workgroup's stores of a moment fall into one contiguous
+        // 64 KiB of its tile (measured against a wave owning 32 columns: 0.69 -> 0.72 of 8 TB/s; profiles/r05_kbuild_store_order.txt)
+        const int jb = wave + 4 * (step / NIB), ib = step % NIB;
         const int j0 = jb * 16, i0 = ib * IBR + NQ * c;
         const vec_t nai = *reinterpret_cast<const vec_t*>(nrm + TB + i0);
         acc_t acc[NQ];

@@ -414,15 +414,14 @@ void launch_kbuild_kt(gphip_ctx* h, const KBuildArgs<T>& a, dim3 grid) {
 template <typename T, int KT>
 void launch_kbuild_mfma_kt(gphip_ctx* h, const KBuildMArgs<T>& m, dim3 grid) {
     const int d = m.b.d;
-    static const size_t pad = getenv("GPHIP_KM_LDS_KIB") ? (size_t)atoi(getenv("GPHIP_KM_LDS_KIB")) * 1024 : 0;   // (developer: occupancy experiments)
 #define KM_CASE(KS)                                                                                                  \
     case KS:                                                                                                         \
-        hipLaunchKernelGGL((kbuild_mfma_kernel<T, KS, KT>), grid, dim3(256), std::max(pad, kbuild_mfma_lds<T, KS>(d)), h->cs, m); \
+        hipLaunchKernelGGL((kbuild_mfma_kernel<T, KS, KT>), grid, dim3(256), (kbuild_mfma_lds<T, KS>(d)), h->cs, m); \
         break;
     switch ((d + 3) / 4) {
         KM_CASE(1) KM_CASE(2) KM_CASE(3) KM_CASE(4)
         default:
-            hipLaunchKernelGGL((kbuild_mfma_kernel<T, 0, KT>), grid, dim3(256), std::max(pad, kbuild_mfma_lds<T, 0>(d)), h->cs, m);
+            hipLaunchKernelGGL((kbuild_mfma_kernel<T, 0, KT>), grid, dim3(256), (kbuild_mfma_lds<T, 0>(d)), h->cs, m);
     }
 #undef KM_CASE
 }
@@ -1285,11 +1284,6 @@ int eval_batch_local(gphip_ctx* h, const double* Theta, int B, int p, double* ou
 
 template <typename T>
 int set_func_attrs(gphip_ctx* h) {
-    if (getenv("GPHIP_KM_LDS_KIB")) {              // (developer: kernel-build occupancy experiments ask for more LDS than the default limit)
-#define KM_ATTR(KS, KT) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>((kbuild_mfma_kernel<T, KS, KT>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        KM_ATTR(0, 0) KM_ATTR(1, 0) KM_ATTR(2, 0) KM_ATTR(3, 0) KM_ATTR(4, 0) KM_ATTR(0, 1) KM_ATTR(1, 1) KM_ATTR(2, 1) KM_ATTR(3, 1) KM_ATTR(4, 1)
-#undef KM_ATTR
-    }
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(potrf128_kernel<T>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)potrf_lds<T>()));
     constexpr int df128 = (int)df_lds_bytes<T, 128, 2>(), df128x = (int)df_lds_bytes<T, 128, 4>();
@@ -3030,7 +3024,6 @@ int gphip_dist_factor_panel(gphip_handle h, int k, void* packed) {
             const int64_t Kp = K0 - h->panel;
             const char* pbase = static_cast<const char*>(h->df_prev_ptr) - dist_panel_first(h, k - 1) * TS * (long)h->es;
             // (three workgroups per CU once the launch is throughput bound: the early, tall panels)
-            const long ptasks = (long)2 * (K1 - K0) * (2 * (h->Nt - K0) + 1);
             if (h->dataflow_occ3 > 0)
                 launch_dataflow<double, 64, 3>(h, 1, 2 * (int)Kp, nullptr, 0, 2 * (int)(K1 - Kp), 2 * (int)(K0 - Kp), pbase);
             else
@@ -3252,8 +3245,7 @@ int gphip_sync(gphip_handle h) {
     return GPHIP_OK;
 }
 
-#include "gphip_hostlogic.inc"
-
 }  // extern "C"
 
+#include "gphip_hostlogic.inc"
 #include "gphip_sampler.inc"

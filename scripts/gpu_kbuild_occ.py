@@ -1,6 +1,7 @@
 """Kernel-build time (HIP events, profile class kbuild) of the CURRENT library at N = 32768, fp64 SE-ARD d = 8 and fp32 Matern
-d = 16 -- one line per process, so that environment knobs (GPHIP_LIB = another build, GPHIP_KM_LDS_KIB = LDS request of
-kbuild_mfma_kernel, i.e. workgroups per CU) can be swept from a shell loop:   python scripts/gpu_kbuild_occ.py <tag>"""
+d = 16 -- one line per process, so that builds (GPHIP_LIB = a variant of scripts/ab_build.py) can be compared from a shell loop
+(round 5: store order and occupancy of kbuild_mfma_kernel, profiles/r05_kbuild_store_order.txt, r05_kbuild_occupancy.txt):
+   python scripts/gpu_kbuild_occ.py <tag>"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
