@@ -29,8 +29,30 @@ static std::vector<mint> g_n;              // training-set size per handle
 static std::vector<mint> g_d;              // input dimension per handle (test points must have this many columns)
 
 EXTERN_C DLLEXPORT mint WolframLibrary_getVersion() { return WolframLibraryVersion; }
-EXTERN_C DLLEXPORT int WolframLibrary_initialize(WolframLibraryData) { return LIBRARY_NO_ERROR; }
-EXTERN_C DLLEXPORT void WolframLibrary_uninitialize(WolframLibraryData) {
+// The log-prior of a JOINT (non-separable) prior reaches the native sampler as a LibraryLink callback: the reference's own
+// "LogPriorPDFFunction" is a CompiledFunction of one real vector (Compile[{{param, _Real, 1}}, ..], BS:412-427), which
+// ConnectLibraryCallbackFunction["gphip_logprior", f] hands to this manager; gphip_wl_nested_sampling_cb evaluates it through
+// callLibraryCallbackFunction once per proposed point.
+static mint g_prior_cb = 0;                       // id of the connected function (0: none)
+static mbool logprior_manager(WolframLibraryData lib, mint id, MTensor argtypes) {
+    if (g_prior_cb) { lib->releaseLibraryCallbackFunction(g_prior_cb); g_prior_cb = 0; }
+    // exactly one argument {Real, rank 1} and a {Real, rank 0} result: rows {type, rank} of a 2 x 2 integer table
+    if (lib->MTensor_getRank(argtypes) != 2 || lib->MTensor_getDimensions(argtypes)[0] != 2 || lib->MTensor_getDimensions(argtypes)[1] != 2)
+        return False;
+    const mint* tr = lib->MTensor_getIntegerData(argtypes);
+    if (tr[0] != MType_Real || tr[1] != 1 || tr[2] != MType_Real || tr[3] != 0) return False;
+    g_prior_cb = id;
+    return True;
+}
+EXTERN_C DLLEXPORT int WolframLibrary_initialize(WolframLibraryData lib) {
+    g_prior_cb = 0;
+    return lib ? lib->registerLibraryCallbackManager("gphip_logprior", logprior_manager) : LIBRARY_NO_ERROR;
+}
+EXTERN_C DLLEXPORT void WolframLibrary_uninitialize(WolframLibraryData lib) {
+    if (lib) {
+        if (g_prior_cb) { lib->releaseLibraryCallbackFunction(g_prior_cb); g_prior_cb = 0; }
+        lib->unregisterLibraryCallbackManager("gphip_logprior");
+    }
     for (auto h : g_handles) gphip_destroy(h);
     g_handles.clear();
     g_n.clear();
@@ -565,6 +587,68 @@ EXTERN_C DLLEXPORT int gphip_wl_nested_sampling_tab(WolframLibraryData lib, mint
     int rc = gphip_nested_sampling(h, tp.box, nullptr, tab_logprior, &tp, &opt, draw ? drawn.data() : lib->MTensor_getRealData(st), cap, pts.data(), ll.data(),
                                    lp.data(), ar.data(), &n, &z, &ne);
     if (rc != GPHIP_OK) return status_to_wl(rc);
+    MTensor r; mint d[2] = {(mint)n, (mint)p + 3};
+    if (lib->MTensor_new(MType_Real, 2, d, &r)) return LIBRARY_FUNCTION_ERROR;
+    double* out = lib->MTensor_getRealData(r);
+    for (int64_t i = 0; i < n; ++i) {
+        for (int j = 0; j < p; ++j) out[i * (p + 3) + j] = pts[(size_t)(i * p + j)];
+        out[i * (p + 3) + p] = ll[(size_t)i];
+        out[i * (p + 3) + p + 1] = lp[(size_t)i];
+        out[i * (p + 3) + p + 2] = ar[(size_t)i];
+    }
+    MArgument_setMTensor(res, r);
+    return LIBRARY_NO_ERROR;
+}
+
+// gphip_wl_nested_sampling_cb[h, box (p x 2), opts (as gphip_wl_nested_sampling), start (pool x p: drawn from the prior by the caller,
+//   generateStartingPoints BS:1046-1068)] -> n x (p + 3) rows as gphip_wl_nested_sampling.  The prior is the function connected with
+//   ConnectLibraryCallbackFunction["gphip_logprior", logPriorPDFFunction] -- ANY "LogPriorPDFFunction" (BS:256-274), joint priors
+//   included; values <= -1e300 (the reference's $MachineLogZero outside the constraints), NaN or a failing evaluation read as log 0.
+namespace {
+struct CbPrior { WolframLibraryData lib; MTensor arg; int failed; };
+double cb_logprior(const double* th, int p, void* user) {
+    CbPrior* c = static_cast<CbPrior*>(user);
+    double* dst = c->lib->MTensor_getRealData(c->arg);
+    for (int j = 0; j < p; ++j) dst[j] = th[j];
+    mreal value = 0.0;
+    MArgument args[1], res;
+    MArgument_getMTensorAddress(args[0]) = &c->arg;
+    MArgument_getRealAddress(res) = &value;
+    if (c->lib->callLibraryCallbackFunction(g_prior_cb, 1, args, res) != LIBRARY_NO_ERROR) { c->failed = 1; return -INFINITY; }
+    return (value > -1e300) ? value : -INFINITY;             // (NaN compares false: log 0)
+}
+}  // namespace
+EXTERN_C DLLEXPORT int gphip_wl_nested_sampling_cb(WolframLibraryData lib, mint argc, MArgument* args, MArgument res) {
+    if (argc != 4) return LIBRARY_FUNCTION_ERROR;
+    gphip_handle h = lookup(MArgument_getInteger(args[0]));
+    MTensor box = MArgument_getMTensor(args[1]), ov = MArgument_getMTensor(args[2]), st = MArgument_getMTensor(args[3]);
+    if (!h || !g_prior_cb) return LIBRARY_FUNCTION_ERROR;   // (no function connected: ConnectLibraryCallbackFunction first)
+    if (int e = want_real(lib, box, 2)) return e;
+    if (int e = want_real(lib, ov, 1)) return e;
+    if (int e = want_real(lib, st, 2)) return e;
+    int p = 0;
+    gphip_num_params(h, &p);
+    if (lib->MTensor_getDimensions(box)[0] != p || lib->MTensor_getDimensions(box)[1] != 2 || lib->MTensor_getDimensions(ov)[0] != 9 ||
+        lib->MTensor_getDimensions(st)[1] != p)
+        return LIBRARY_DIMENSION_ERROR;
+    const double* o = lib->MTensor_getRealData(ov);
+    gphip_ns_options opt;
+    gphip_ns_default_options(&opt);
+    opt.pool = (int)lib->MTensor_getDimensions(st)[0]; opt.max_iterations = (int)o[1]; opt.min_iterations = (int)o[2]; opt.mc_steps = (int)o[3];
+    opt.walkers = (int)o[4]; opt.termination_fraction = o[5]; opt.min_accept = o[6]; opt.max_accept = o[7]; opt.seed = (uint64_t)o[8];
+    if (opt.pool < 2) return LIBRARY_DIMENSION_ERROR;
+    CbPrior cb{lib, nullptr, 0};
+    mint pd[1] = {(mint)p};
+    if (lib->MTensor_new(MType_Real, 1, pd, &cb.arg)) return LIBRARY_FUNCTION_ERROR;
+    const int64_t cap = (int64_t)opt.pool + std::max(opt.max_iterations, opt.min_iterations) + 1;
+    std::vector<double> pts((size_t)cap * p), ll((size_t)cap), lp((size_t)cap), ar((size_t)cap);
+    int64_t n = 0, ne = 0;
+    double z = 0.0;
+    const int rc = gphip_nested_sampling(h, lib->MTensor_getRealData(box), nullptr, cb_logprior, &cb, &opt, lib->MTensor_getRealData(st), cap,
+                                         pts.data(), ll.data(), lp.data(), ar.data(), &n, &z, &ne);
+    lib->MTensor_free(cb.arg);
+    if (rc != GPHIP_OK) return status_to_wl(rc);
+    if (cb.failed) return LIBRARY_FUNCTION_ERROR;           // the connected function could not be evaluated
     MTensor r; mint d[2] = {(mint)n, (mint)p + 3};
     if (lib->MTensor_new(MType_Real, 2, d, &r)) return LIBRARY_FUNCTION_ERROR;
     double* out = lib->MTensor_getRealData(r);

@@ -5,6 +5,7 @@
 
 gpNested := gpNested = load["gphip_wl_nested_sampling", {Integer, m2, iv, v1, any}, {Real, 2}];
 gpNestedTab := gpNestedTab = load["gphip_wl_nested_sampling_tab", {Integer, m2, m2, v1, any}, {Real, 2}];
+gpNestedCb := gpNestedCb = load["gphip_wl_nested_sampling_cb", {Integer, m2, v1, m2}, {Real, 2}];
 
 (* ---- the native batched sampler (gphip_nested_sampling): nestedSamplingInternal's job (BayesianStatistics.wl:859-1040)
    done inside the library, `Walkers` constrained-prior chains in lock step = one batched likelihood call per Metropolis
@@ -20,7 +21,11 @@ uniformPriorQ[prior_, p_] := MatchQ[prior, "Uniform" | _UniformDistribution |
    parameter): its "LogPriorPDFFunction" (BayesianStatistics.wl:256-274) is the sum of the factors' log densities, which travel
    to the native driver as tables on a uniform grid over each parameter's {min, max}; zeros of a density become -1.*^300 (read
    as -Infinity by the shim); the starting pool is drawn from the tables by the library (generateStartingPoints, BS:1046-1068).
-   $Failed for anything else (joint distributions): those runs stay with nestedSampling. *)
+   $Failed for anything else.  A JOINT prior travels as a LibraryLink callback instead: the object's compiled
+   "LogPriorPDFFunction" (BS:412-427) is connected to the library's "gphip_logprior" manager and evaluated by the native driver
+   once per proposed point; its starting pool comes from the reference's own generateStartingPoints (BS:1055-1068). *)
+connectPrior[f_CompiledFunction] := (gpNestedCb; TrueQ @ Quiet @ ConnectLibraryCallbackFunction["gphip_logprior", f]);
+connectPrior[_] := False;
 priorFactors[ProductDistribution[d__], p_] := With[{f = Flatten[Replace[{d}, {dist_, n_Integer} :> ConstantArray[dist, n], {1}]]},
 	If[Length[f] === p && AllTrue[f, UnivariateDistributionQ], f, $Failed]];
 priorFactors[d_?UnivariateDistributionQ, 1] := {d};
@@ -32,26 +37,31 @@ priorTables[factors_List, params_, m_Integer] := MapThread[
 nestedSamplingHIP[inferenceObject[assoc_?AssociationQ], opts : OptionsPattern[]] /;
 	KeyExistsQ[Lookup[assoc, "GaussianProcessData", <||>], "HIPHandle"] := Module[{
 	h = assoc["GaussianProcessData", "HIPHandle"],
-	params = assoc["Parameters"], p, pool, kinds, factors, nsOpts, start, rows, samples, result,
+	params = assoc["Parameters"], p, pool, kinds, factors, joint = False, nsOpts, start, rows, samples, result,
 	pwFlags = Lookup[assoc["GaussianProcessData"], "PointwiseFunctions", {False, False}]
 },
 	p = Length[params];
 	kinds = Replace[OptionValue["PriorKinds"], Automatic :> If[uniformPriorQ[assoc["PriorDistribution"], p], ConstantArray[0, p], $Failed]];
 	factors = If[kinds === $Failed, priorFactors[assoc["PriorDistribution"], p], $Failed];
-	(* point-dependent nugget / mean functions live in this kernel process, and so do NON-separable priors: those runs go
-	   through the reference's own driver with the GPU closure *)
-	If[ (kinds === $Failed && factors === $Failed) || Or @@ pwFlags,
+	start = Replace[OptionValue["StartingPoints"], Except[_?(MatrixQ[#, NumericQ]&)] :> Lookup[assoc, "StartingPoints", {}]];
+	If[ kinds === $Failed && factors === $Failed && !Or @@ pwFlags,
+		If[ !MatrixQ[start], start = generateStartingPoints[assoc, OptionValue["SamplePoolSize"]]];
+		joint = MatrixQ[start, NumericQ] && connectPrior[assoc["LogPriorPDFFunction"]]
+	];
+	(* point-dependent nugget / mean functions live in this kernel process, and so does a prior that is not a compiled
+	   function of the parameter vector: those runs go through the reference's own driver with the GPU closure *)
+	If[ (kinds === $Failed && factors === $Failed && !joint) || Or @@ pwFlags,
 		Return @ nestedSampling[inferenceObject[assoc], Sequence @@ FilterRules[{opts}, Options[nestedSampling]]]
 	];
-	start = Replace[OptionValue["StartingPoints"], Except[_?(MatrixQ[#, NumericQ]&)] :> Lookup[assoc, "StartingPoints", {}]];
 	pool = If[MatrixQ[start], Length[start], OptionValue["SamplePoolSize"]];
 	touch[h];
 	nsOpts = N @ {pool, OptionValue["MaxIterations"], OptionValue["MinIterations"], OptionValue["MonteCarloSteps"], OptionValue["Walkers"],
 		OptionValue["TerminationFraction"], Sequence @@ OptionValue["MinMaxAcceptanceRate"], OptionValue["Seed"]};
-	rows = If[ kinds =!= $Failed,
-		gpNested[h, N @ params[[All, {2, 3}]], kinds, nsOpts, If[MatrixQ[start], N @ start, {}]],
+	rows = Which[
+		joint, gpNestedCb[h, N @ params[[All, {2, 3}]], nsOpts, N @ start],
+		kinds =!= $Failed, gpNested[h, N @ params[[All, {2, 3}]], kinds, nsOpts, If[MatrixQ[start], N @ start, {}]],
 		(* separable prior: tabulated factors; without starting points the library draws the pool from the tables itself *)
-		gpNestedTab[h, N @ params[[All, {2, 3}]], priorTables[factors, params, 2049], nsOpts, If[MatrixQ[start], N @ start, {}]]
+		True, gpNestedTab[h, N @ params[[All, {2, 3}]], priorTables[factors, params, 2049], nsOpts, If[MatrixQ[start], N @ start, {}]]
 	];
 	If[ !MatrixQ[rows], Return["Bad likelihood function"]];     (* BayesianStatistics.wl:917-921 *)
 	samples = Association @ MapIndexed[

@@ -381,3 +381,91 @@ def test_create_custom_through_the_shim_the_way_gphip_wl_drives_it():
     assert rc == NO_ERROR and list(spec) == [-1] * 8
     assert K.lib.drv_live() == live0 and K.lib.drv_const_frees() == 0
     K.lib.WolframLibrary_uninitialize(K.data)
+
+
+def test_native_sampler_with_a_joint_prior_through_a_library_callback():
+    """nestedSamplingHIP for a JOINT (non-separable) prior: the reference's "LogPriorPDFFunction" -- a CompiledFunction of one real
+    vector (BS:412-427) -- is connected with ConnectLibraryCallbackFunction["gphip_logprior", f] and evaluated by the native driver
+    through callLibraryCallbackFunction (gphip_wl_nested_sampling_cb).  Here the fake kernel connects a C function pointer standing
+    in for the CompiledFunction: a CORRELATED bivariate normal over (sn, mu), cut to the box.  Null kernel + constant mean: the
+    evidence is a smooth 2-D integral (midpoint rule, 1200 x 1200); z-scores over 24 seeds."""
+    import math
+    from bayesianinference_amd import nested_sampling as ns
+    K = Kernel()
+    L = K.lib
+    CFN = C.CFUNCTYPE(C.c_double, C.POINTER(C.c_double), C.c_int64)
+    L.drv_connect_callback.argtypes = [C.c_char_p, CFN, C.c_int]
+    L.drv_cb_released.restype = L.drv_cb_calls.restype = C.c_long
+    rng = np.random.default_rng(5)
+    n = 40
+    X = rng.random((n, 1))
+    y = 0.3 + 0.8 * rng.standard_normal(n)
+    box = np.array([[0.4, 2.0], [-1.0, 1.5]])
+    m = np.array([1.0, 0.3])
+    S = np.array([[0.16, 0.09], [0.09, 0.25]])               # correlation 0.45: not a product of its marginals
+    Si = np.linalg.inv(S)
+    g = 1200
+    sn = box[0, 0] + (np.arange(g) + 0.5) * (box[0, 1] - box[0, 0]) / g
+    mu = box[1, 0] + (np.arange(g) + 0.5) * (box[1, 1] - box[1, 0]) / g
+    dsn, dmu = sn[:, None] - m[0], mu[None, :] - m[1]
+    lq = -0.5 * (Si[0, 0] * dsn * dsn + 2 * Si[0, 1] * dsn * dmu + Si[1, 1] * dmu * dmu)
+    cell = (box[0, 1] - box[0, 0]) / g * (box[1, 1] - box[1, 0]) / g
+    lognorm = ns.log_sum_exp(lq.ravel()) + math.log(cell)     # the prior is the Gaussian restricted to the box, normalised there
+    s1, s2 = y.sum(), (y * y).sum()
+    quad = (s2 - 2 * mu[None, :] * s1 + n * mu[None, :] ** 2) / sn[:, None] ** 2
+    ll = -0.5 * (n * math.log(2 * math.pi) + 2 * n * np.log(sn)[:, None] + quad)
+    want = ns.log_sum_exp((ll + lq - lognorm).ravel()) + math.log(cell)
+    calls = [0]
+
+    def logprior(th, p):
+        calls[0] += 1
+        if p != 2 or not (box[0, 0] <= th[0] <= box[0, 1] and box[1, 0] <= th[1] <= box[1, 1]):
+            return -1.7976931348623157e308                    # $MachineLogZero outside the constraints
+        v = np.array([th[0] - m[0], th[1] - m[1]])
+        return float(-0.5 * v @ Si @ v - lognorm)
+    cf = CFN(logprior)
+    rc, hs = K.call("gphip_wl_create", [X, y, 4, 1, 64, np.array([0])], "int")
+    assert rc == NO_ERROR
+    opts0 = np.array([60, 10000, 100, 25, 32, 0.01, 0.0, 1.0, 0.0])
+    start0 = np.tile(np.array([[1.0, 0.3]]), (60, 1))
+    # no function connected yet: an error, not a crash
+    assert K.call("gphip_wl_nested_sampling_cb", [hs, box, opts0, start0])[0] == FUNCTION_ERROR
+    # a function of the wrong shape (rank-2 argument) is refused by the manager; the right one is accepted
+    assert L.drv_connect_callback(b"gphip_logprior", cf, 1) == 0
+    assert K.call("gphip_wl_nested_sampling_cb", [hs, box, opts0, start0])[0] == FUNCTION_ERROR
+    assert L.drv_connect_callback(b"no_such_manager", cf, 0) == -1
+    assert L.drv_connect_callback(b"gphip_logprior", cf, 0) == 1
+    pool, zs = 60, []
+    Lc = np.linalg.cholesky(S)
+    for seed in range(24):
+        r = np.random.default_rng(300 + seed)
+        start = np.empty((pool, 2))
+        k = 0
+        while k < pool:                                       # RandomVariate[prior, ..] + Select inside the box
+            v = m + Lc @ r.standard_normal(2)
+            if box[0, 0] <= v[0] <= box[0, 1] and box[1, 0] <= v[1] <= box[1, 1]:
+                start[k] = v
+                k += 1
+        opts = np.array([pool, 10000, 100, 25, 32, 0.01, 0.0, 1.0, float(seed)])
+        rc, rows = K.call("gphip_wl_nested_sampling_cb", [hs, box, opts, start])
+        assert rc == NO_ERROR and rows.shape[1] == 5 and rows.shape[0] > pool
+        np.testing.assert_array_equal(rows[:pool, :2], start)
+        i = pool + 5
+        assert abs(rows[i, 3] - logprior(rows[i, :2], 2)) < 1e-12          # the recorded prior density is the callback's value
+        res = {"Points": rows[:, :2], "LogLikelihood": rows[:, 2], "LogPriorPDF": rows[:, 3], "AcceptanceRate": rows[:, 4],
+               "SamplePoolSize": pool, "GeneratedNestedSamples": len(rows) - pool, "TotalSamples": len(rows)}
+        out = ns.evidence_sampling(res, ["sn", "mu"], pool, np.random.default_rng(seed))
+        zs.append((out["LogEvidence"]["Mean"] - want) / out["LogEvidence"]["StandardError"])
+    zs = np.array(zs)
+    assert abs(zs.mean()) < 0.6 and np.all(np.abs(zs) < 4.0), zs
+    assert 0.5 < zs.std(ddof=1) < 2.0, zs
+    assert calls[0] > 24 * 1000 and L.drv_cb_calls() == calls[0] - 24     # (24 direct calls in the check above)
+    # connecting another function releases the previous one; argument checks; uninitialize releases the last one
+    rel0 = L.drv_cb_released()
+    assert L.drv_connect_callback(b"gphip_logprior", cf, 0) == 1 and L.drv_cb_released() == rel0 + 1
+    assert K.call("gphip_wl_nested_sampling_cb", [hs, box[:1], opts0, start0])[0] == DIMENSION_ERROR
+    assert K.call("gphip_wl_nested_sampling_cb", [hs, box, opts0[:5], start0])[0] == DIMENSION_ERROR
+    assert K.call("gphip_wl_nested_sampling_cb", [hs, box, opts0, start0[:, :1]])[0] == DIMENSION_ERROR
+    assert K.call("gphip_wl_destroy", [hs], "int") == (NO_ERROR, 0)
+    K.lib.WolframLibrary_uninitialize(K.data)
+    assert L.drv_cb_released() == rel0 + 2

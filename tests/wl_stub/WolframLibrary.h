@@ -65,8 +65,14 @@ typedef union {
 #define MArgument_setInteger(a, v) ((*((a).integer)) = (v))
 #define MArgument_setReal(a, v) ((*((a).real)) = (v))
 #define MArgument_setMTensor(a, v) ((*((a).tensor)) = (v))
+#define MArgument_getRealAddress(a) ((a).real)
+#define MArgument_getMTensorAddress(a) ((a).tensor)
+#define True 1
+#define False 0
 
-typedef struct st_WolframLibraryData {
+struct st_WolframLibraryData;
+typedef struct st_WolframLibraryData* WolframLibraryData;
+struct st_WolframLibraryData {
     void (*UTF8String_disown)(char*);
     int (*MTensor_new)(mint type, mint rank, const mint* dims, MTensor* out);
     void (*MTensor_free)(MTensor);
@@ -78,6 +84,13 @@ typedef struct st_WolframLibraryData {
     mreal* (*MTensor_getRealData)(MTensor);
     void (*Message)(const char*);
     mint (*AbortQ)(void);
-} * WolframLibraryData;
+    /* "Callback Evaluations" (LibraryLink user guide): ConnectLibraryCallbackFunction["name", compiledFunction] makes the kernel
+     * call the manager registered under "name" with an id and the (nargs + 1) x 2 {type, rank} table of the function's arguments
+     * and result; the library then evaluates the function with callLibraryCallbackFunction(id, ..) */
+    int (*registerLibraryCallbackManager)(const char* name, mbool (*mfun)(WolframLibraryData, mint, MTensor));
+    int (*unregisterLibraryCallbackManager)(const char* name);
+    int (*callLibraryCallbackFunction)(mint id, mint ArgC, MArgument* Args, MArgument Res);
+    int (*releaseLibraryCallbackFunction)(mint id);
+};
 
 #endif

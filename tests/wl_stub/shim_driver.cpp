@@ -36,7 +36,43 @@ static void s_disown(char*) { ++g_disowned; }
 static void msg(const char*) {}
 static mint abortq(void) { return 0; }
 
-static st_WolframLibraryData g_data = {s_disown, t_new, t_free, t_rank, t_dims, t_type, t_flat, t_idata, t_rdata, msg, abortq};
+// ---- callback evaluations: one manager per name, one connected function (a C function pointer standing in for the
+// CompiledFunction: theta (Real, rank 1) -> Real) per id
+typedef mbool (*manager_fn)(WolframLibraryData, mint, MTensor);
+typedef double (*compiled_fn)(const double* theta, mint n);
+static struct { char name[64]; manager_fn fn; } g_managers[8];
+static int g_nmanagers = 0;
+static compiled_fn g_connected[16];
+static mint g_next_id = 1;
+static long g_released = 0, g_cb_calls = 0;
+static int cb_register(const char* name, manager_fn fn) {
+    for (int i = 0; i < g_nmanagers; ++i)               // (a library initialised twice in one process registers the same name again)
+        if (!strcmp(g_managers[i].name, name)) { g_managers[i].fn = fn; return LIBRARY_NO_ERROR; }
+    if (g_nmanagers >= 8) return LIBRARY_FUNCTION_ERROR;
+    strncpy(g_managers[g_nmanagers].name, name, 63);
+    g_managers[g_nmanagers++].fn = fn;
+    return LIBRARY_NO_ERROR;
+}
+static int cb_unregister(const char* name) {
+    for (int i = 0; i < g_nmanagers; ++i)
+        if (!strcmp(g_managers[i].name, name)) { g_managers[i] = g_managers[--g_nmanagers]; return LIBRARY_NO_ERROR; }
+    return LIBRARY_FUNCTION_ERROR;
+}
+static int cb_call(mint id, mint argc, MArgument* args, MArgument res) {
+    if (id < 1 || id >= 16 || !g_connected[id] || argc != 1) return LIBRARY_FUNCTION_ERROR;
+    MTensor t = MArgument_getMTensor(args[0]);
+    if (!t || t->type != MType_Real || t->rank != 1) return LIBRARY_TYPE_ERROR;
+    ++g_cb_calls;
+    *MArgument_getRealAddress(res) = g_connected[id](static_cast<const double*>(t->data), t->dims[0]);
+    return LIBRARY_NO_ERROR;
+}
+static int cb_release(mint id) {
+    if (id >= 1 && id < 16 && g_connected[id]) { g_connected[id] = nullptr; ++g_released; }
+    return LIBRARY_NO_ERROR;
+}
+
+static st_WolframLibraryData g_data = {s_disown, t_new, t_free, t_rank, t_dims, t_type, t_flat, t_idata, t_rdata, msg, abortq,
+                                       cb_register, cb_unregister, cb_call, cb_release};
 
 extern "C" {
 DLLEXPORT WolframLibraryData drv_libdata(void) { return &g_data; }
@@ -61,4 +97,24 @@ DLLEXPORT void* drv_data(MTensor t) { return t->data; }
 DLLEXPORT long drv_live(void) { return g_live; }
 DLLEXPORT long drv_disowned(void) { return g_disowned; }
 DLLEXPORT long drv_const_frees(void) { return g_const_frees; }
+// ConnectLibraryCallbackFunction[name, f] as the kernel does it: the manager gets a fresh id and the {type, rank} table
+// (here: one Real vector argument, a Real scalar result -- or, wrong = 1, a table the manager must refuse); returns the
+// manager's verdict (1 = connected), -1 = no such manager
+DLLEXPORT int drv_connect_callback(const char* name, compiled_fn f, int wrong) {
+    for (int i = 0; i < g_nmanagers; ++i)
+        if (!strcmp(g_managers[i].name, name)) {
+            const mint id = g_next_id < 16 ? g_next_id++ : 15;
+            g_connected[id] = f;
+            const mint dims[2] = {2, 2};
+            const mint table[4] = {MType_Real, wrong ? 2 : 1, MType_Real, 0};
+            MTensor t = drv_tensor(MType_Integer, 2, dims, table);
+            const mbool ok = g_managers[i].fn(&g_data, id, t);
+            drv_release(t);
+            if (!ok) g_connected[id] = nullptr;
+            return ok ? 1 : 0;
+        }
+    return -1;
+}
+DLLEXPORT long drv_cb_released(void) { return g_released; }
+DLLEXPORT long drv_cb_calls(void) { return g_cb_calls; }
 }
