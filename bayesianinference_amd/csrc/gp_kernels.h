@@ -39,7 +39,14 @@ namespace gphip {
 
 // Bumped whenever a struct or constant the run-time compiled copy of this region shares with the offline library changes
 // (KBuildArgs, SLOTP, the tile layout): rtc_dyn.h refuses a source tree whose value differs from the library's own.
-#define GP_RTC_ABI 4
+#define GP_RTC_ABI 5
+// A run-time compiled program is built for ONE handle, whose input dimension is known: the generated source defines GP_D and the
+// dimension loops of the caller's function unroll (their per-dimension reciprocals then leave the column loop).  Offline: the argument.
+#ifdef GP_D
+#define GP_DIM(x) (GP_D)
+#else
+#define GP_DIM(x) (x)
+#endif
 constexpr int TB = 128;         // tile edge
 // elements between consecutive tiles of the packed workspace (a pad behind every tile was measured in round 3: no gain)
 constexpr long TS = (long)TB * TB;
@@ -378,7 +385,7 @@ __global__ __launch_bounds__(256) void kbuild_kernel(KBuildArgs<T> a) {
         return;
     }
 
-    const int d = (D > 0) ? D : a.d;
+    const int d = (D > 0) ? D : GP_DIM(a.d);
     const T* xjg = a.xj + (long)slot * a.xj_bstride + (long)tj * TB;
     const T* xig = a.xi + (long)slot * a.xi_bstride + (long)ti * TB;
     T* xjs = lds;
@@ -397,6 +404,12 @@ __global__ __launch_bounds__(256) void kbuild_kernel(KBuildArgs<T> a) {
     double* etab = lds_raw + (glb ? 0 : ((D > 0) ? D : 2 * d) * TB);
     if (sizeof(T) == 8 && KT < 2)
         for (int idx = tid; idx < EXP_TAB; idx += 256) etab[idx] = sp[0] * a.exp2tab[idx];
+    // KT = 3: the function's hyper-parameters behind the point tiles.  Read from LDS (never written inside the column loop, and
+    // not aliased by the tile stores) their loads -- and what the function computes from them alone, e.g. 1 / l_k -- are
+    // loop invariant for the compiler; read through the global pointer every column would fetch and divide again.
+    double* cpl = lds_raw + (glb ? 0 : (size_t)2 * d * TB * sizeof(T) / sizeof(double));
+    if constexpr (KT == 3)
+        for (int idx = tid; idx < a.ncp; idx += 256) cpl[idx] = a.cp[(long)slot * a.ncp + idx];
     // fp32 fast path below: sum of squares = r2 log2(e) / 2 (SE) or 5 r2 (Matern-5/2)
     constexpr bool F32FAST = sizeof(T) == 4 && D > 0 && KT < 2;
     constexpr float CS32 = KT == 0 ? 0.84932180028801904f /* sqrt(log2(e) / 2) */ : 2.2360679774997896f /* sqrt 5 */;
@@ -516,7 +529,7 @@ __global__ __launch_bounds__(256) void kbuild_kernel(KBuildArgs<T> a) {
         }
         T va, vb;
         if constexpr (KT == 3) {
-            const double* cp = a.cp + (long)slot * a.ncp;
+            const double* cp = cpl;
             const PointRef<T> Yj{glb ? xjg + jj : xjs + jj, glb ? (long)a.npad_j : (long)TB};
             const PointRef<T> Xa{glb ? xig + r0 : xis + r0, glb ? (long)a.npad_i : (long)TB};
             const PointRef<T> Xb{Xa.base + 1, Xa.stride};
@@ -588,7 +601,7 @@ __global__ void custom_diag_kernel(const T* __restrict__ x, long x_bstride, int 
     const int i = blockIdx.x * blockDim.x + threadIdx.x, slot = blockIdx.y;
     if (i >= n) return;
     const PointRef<T> X{x + (long)slot * x_bstride + i, (long)npad};
-    out[(long)slot * ostride + i] = (double)gphip_custom_k<T, T>(X, X, cp + (long)slot * ncp, d);
+    out[(long)slot * ostride + i] = (double)gphip_custom_k<T, T>(X, X, cp + (long)slot * ncp, GP_DIM(d));
 }
 // Per slot: the largest prior variance over the training points scales the pivot tolerance of the factorisation (the
 // named kernels know k(x, x) = sf^2 on the host; here only the device can evaluate the function).  The host left the
@@ -602,7 +615,7 @@ __global__ __launch_bounds__(256) void custom_prep_kernel(const T* __restrict__ 
     bool bad = false;
     for (int i = threadIdx.x; i < n; i += 256) {
         const PointRef<T> X{x + i, (long)npad};
-        const double v = (double)gphip_custom_k<T, T>(X, X, cp + (long)slot * ncp, d);
+        const double v = (double)gphip_custom_k<T, T>(X, X, cp + (long)slot * ncp, GP_DIM(d));
         if (!(fabs(v) <= 1.0e300)) bad = true;
         m = fmax(m, fabs(v));
     }
@@ -653,7 +666,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void custom_grad_kernel(GradArgs<T> a, const double* __restrict__ cp, int ncp) {
     extern __shared__ double lds_raw[];
     typedef Dual<T, GP_NCP> dual_t;
-    const int d = a.d;
+    const int d = GP_DIM(a.d);
     const bool glb = d > KB_LDS_MAXD;
     T* xjs = reinterpret_cast<T*>(lds_raw);      // [d][128] column points (when they fit), then alpha_j [128]
     T* aj = xjs + (glb ? 0 : d * TB);

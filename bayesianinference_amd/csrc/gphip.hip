@@ -450,7 +450,7 @@ void launch_kbuild(gphip_ctx* h, const KBuildArgs<T>& a0, dim3 grid, const T* xr
         KBuildArgs<T> a = a0;
         a.cp = h->dCustomP; a.ncp = std::max(h->ncp, 1);
         void* params[] = {&a};
-        const size_t lds = a.d > KB_LDS_MAXD ? 64 : (size_t)2 * a.d * TB * sizeof(T);
+        const size_t lds = (a.d > KB_LDS_MAXD ? 0 : (size_t)2 * a.d * TB * sizeof(T)) + (size_t)a.ncp * sizeof(double);   // point tiles + hyper-parameters
         (void)hipModuleLaunchKernel(h->f_cbuild, grid.x, grid.y, grid.z, 256, 1, 1, (unsigned)lds, h->cs, params, nullptr);
         return;
     }
@@ -1928,7 +1928,7 @@ static int create_ctx(const void* X, const void* y, int64_t N, int64_t d, int ke
         arch = arch.substr(0, arch.find(':'));
         std::string msg;
         h->custom_body = custom_body; h->arch = arch;
-        const std::shared_ptr<const RtcResult> r = rtc_compile_custom(custom_body, dtype, arch.c_str(), msg);
+        const std::shared_ptr<const RtcResult> r = rtc_compile_custom(custom_body, dtype, arch.c_str(), msg, nullptr, -1, (int)d);
         if (!r) {
             if (why) *why = msg;
             return bail(rtc().ok() ? GPHIP_ERR_ARG : GPHIP_ERR_UNSUPPORTED);
@@ -2111,7 +2111,7 @@ int gphip_loglik_grad(gphip_handle h, const double* theta, int p, double* out, d
         constexpr int CGRAD_MAX_NCP = 64;
         if (h->cgrad_state == 0 && h->custom_grad && h->ncp >= 1 && h->ncp <= CGRAD_MAX_NCP) {
             std::string msg;
-            const std::shared_ptr<const RtcResult> r = rtc_compile_custom(h->custom_body, h->dtype, h->arch.c_str(), msg, nullptr, h->ncp);
+            const std::shared_ptr<const RtcResult> r = rtc_compile_custom(h->custom_body, h->dtype, h->arch.c_str(), msg, nullptr, h->ncp, h->d);
             h->cgrad_state = -1;
             HIPCHK(hipSetDevice(h->device));
             if (r && hipModuleLoadData(&h->cgmod, r->code.data()) == hipSuccess &&

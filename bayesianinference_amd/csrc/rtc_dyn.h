@@ -121,6 +121,7 @@ inline bool rtc_kernel_source(std::string& region, std::string& dual, std::strin
     return true;
 }
 
+constexpr int RTC_SPEC_MAXD = 32;          // beyond: the generic-dimension program (its loops stay rolled, the points come from global memory)
 struct RtcResult {
     std::vector<char> code;                      // the code object for hipModuleLoadData
     std::string build, diag, prep;               // lowered names of the three kernels of the value program ...
@@ -132,17 +133,23 @@ struct RtcResult {
 // grad_ncp < 0: the value program (kernel build, k(x, x) kernels).  grad_ncp >= 1: the gradient program -- the same text
 // instantiated with T = Dual<S, grad_ncp> inside custom_grad_kernel (intermediates that depend on P must be of type T there,
 // which they are in a body that follows the documented form).
-inline bool rtc_compile_uncached(const std::string& body, int dtype, const char* arch, int grad_ncp, RtcResult& out, std::string& why) {
+inline bool rtc_compile_uncached(const std::string& body, int dtype, const char* arch, int grad_ncp, int spec_d, RtcResult& out, std::string& why) {
     const RtcApi& api = rtc();
     if (!api.ok()) { why = "hiprtc could not be loaded (libhiprtc.so; set GPHIP_HIPRTC_PATH)"; return false; }
     std::string region, dual;
     if (!rtc_kernel_source(region, dual, why)) return false;
     std::string src = "#define GP_CUSTOM_KERNEL 1\n#define GP_HD __device__ __forceinline__\n";
     if (grad_ncp >= 1) src += "#define GP_CUSTOM_GRAD 1\n#define GP_NCP " + std::to_string(grad_ncp) + "\n";
+    // the program of ONE handle: its input dimension as a compile-time constant (up to RTC_SPEC_MAXD), so that `D` in the
+    // function's text is one and its dimension loops unroll
+    if (spec_d >= 1 && spec_d <= RTC_SPEC_MAXD) src += "#define GP_D " + std::to_string(spec_d) + "\n";
     src += dual + "\n" + region;
     // names a Mathematica CForm of the function uses (GPHIP.wl translates a pure-function kernel that way)
     src += "\nnamespace gphip {\n"
            "template <typename A, typename B> __device__ __forceinline__ auto Power(A a, B b) -> decltype(a * b * 1.0f) { typedef decltype(a * b * 1.0f) R; return pow((R)a, (R)b); }\n"
+           // (an integer exponent -- what CForm prints for x^2, 1/l^2 -- is repeated multiplication: exact derivative, no pow call)
+           "template <typename A> __device__ __forceinline__ auto Power(A a, int n) -> decltype(a * 1.0f) { typedef decltype(a * 1.0f) R; R r = (R)1, b = (R)a; "
+           "unsigned m = n < 0 ? 0u - (unsigned)n : (unsigned)n; while (m) { if (m & 1u) r = r * b; m >>= 1; if (m) b = b * b; } return n < 0 ? (R)1 / r : r; }\n"
            "template <typename A> __device__ __forceinline__ A Sqrt(A a) { return sqrt(a); }\n"
            "template <typename A> __device__ __forceinline__ A Exp(A a) { return exp(a); }\n"
            "template <typename A> __device__ __forceinline__ A Log(A a) { return log(a); }\n"
@@ -160,7 +167,8 @@ inline bool rtc_compile_uncached(const std::string& body, int dtype, const char*
            "template <typename A, typename B> __device__ __forceinline__ auto Max(A a, B b) -> decltype(a + b) { typedef decltype(a + b) R; return a > b ? (R)a : (R)b; }\n"
            "constexpr double Pi = 3.14159265358979323846, E = 2.71828182845904523536;\n"
            "template <typename T, typename S>\n"
-           "__device__ T gphip_custom_k(PointRef<S> X, PointRef<S> Y, const double* __restrict__ Pp, int D) {\n"
+           "__device__ __forceinline__ T gphip_custom_k(PointRef<S> X, PointRef<S> Y, const double* __restrict__ Pp, int gphip_d_) {\n"
+           "#ifdef GP_D\n    constexpr int D = GP_D; (void)gphip_d_;\n#else\n    const int D = gphip_d_;\n#endif\n"
            "#define P(k) (gp_param_of<T>::get(Pp, (k)))\n";
     src += body;
     src += "\n#undef P\n}\n}  // namespace gphip\n";
@@ -180,8 +188,11 @@ inline bool rtc_compile_uncached(const std::string& body, int dtype, const char*
     }
     for (auto& n : names) api.AddNameExpression(prog, n.first.c_str());
     const std::string archopt = std::string("--offload-arch=") + arch;
-    const char* opts[] = {archopt.c_str(), "-O3", "-std=c++17"};
-    const int rc = api.CompileProgram(prog, 3, opts);
+    // -freciprocal-math: x / p may become x * (1 / p) -- with the hyper-parameters loop invariant (see kbuild_kernel) the per-entry
+    // fp64 divisions of a typical function (one per dimension, ~15 instructions each) leave the inner loop; <= 1 ulp per quotient,
+    // the same form the named kernels use (inputs pre-multiplied by 1 / l_k).  No other fast-math relaxation.
+    const char* opts[] = {archopt.c_str(), "-O3", "-std=c++17", "-freciprocal-math"};
+    const int rc = api.CompileProgram(prog, 4, opts);
     if (rc != 0) {
         size_t n = 0;
         api.GetProgramLogSize(prog, &n);
@@ -210,17 +221,18 @@ inline bool rtc_compile_uncached(const std::string& body, int dtype, const char*
 
 // per-process cache of code objects, keyed by everything the compilation depends on (the kernel text is fixed per process)
 inline std::shared_ptr<const RtcResult> rtc_compile_custom(const std::string& body, int dtype, const char* arch, std::string& why,
-                                                            bool* cache_hit = nullptr, int grad_ncp = -1) {
+                                                            bool* cache_hit = nullptr, int grad_ncp = -1, int spec_d = 0) {
+    if (spec_d < 1 || spec_d > RTC_SPEC_MAXD) spec_d = 0;
     static std::mutex mu;
     static std::map<std::string, std::shared_ptr<const RtcResult>> cache;
     const char* dev = getenv("GPHIP_SRC_DIR");
-    const std::string key = std::string(arch) + "|" + std::to_string(dtype) + "|" + std::to_string(grad_ncp) + "|" + (dev ? dev : "") + "|" + body;
+    const std::string key = std::string(arch) + "|" + std::to_string(dtype) + "|" + std::to_string(grad_ncp) + "|" + std::to_string(spec_d) + "|" + (dev ? dev : "") + "|" + body;
     std::lock_guard<std::mutex> lk(mu);
     auto it = cache.find(key);
     if (cache_hit) *cache_hit = it != cache.end();
     if (it != cache.end()) return it->second;
     auto r = std::make_shared<RtcResult>();
-    if (!rtc_compile_uncached(body, dtype, arch, grad_ncp, *r, why)) return nullptr;
+    if (!rtc_compile_uncached(body, dtype, arch, grad_ncp, spec_d, *r, why)) return nullptr;
     cache.emplace(key, r);
     return r;
 }

@@ -10,7 +10,9 @@ d = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 BODY = "T s = 0; for (int k = 0; k < D; ++k) { const T u = (X(k) - Y(k)) / P(k); s += u * u; } return P(D) * P(D) * exp((T)-0.5 * s);"
 X, y = syn.make_dataset(n, d)
 th = syn.default_theta("se_ard", d)
-for name, kern in (("named se_ard", "se_ard"), ("source text", _lib.CustomKernel(BODY, d + 1))):
+# the same function as Mathematica's CForm prints it (Power with integer exponents, one quotient per dimension)
+CFORM = "return Power(P(%d),2)*Exp(-0.5*(%s));" % (d, " + ".join(f"Power(X({k}) - Y({k}),2)/Power(P({k}),2)" for k in range(d)))
+for name, kern in (("named se_ard", "se_ard"), ("source text", _lib.CustomKernel(BODY, d + 1)), ("CForm text", _lib.CustomKernel(CFORM, d + 1))):
     t0 = time.perf_counter()
     h = _lib.Handle(X, y, kern)
     tc = time.perf_counter() - t0
