@@ -978,12 +978,15 @@ __device__ __forceinline__ int ptile(int bi, int bj) { return ((bi * (bi + 1) / 
 // L tiles and the diagonal inverses W_rr are read from LDS; the W[r][PB] this wave has already
 // produced stay in registers in the MFMA D layout, which is exactly the B-operand layout of the
 // next product (Num<T>::kidx), and go straight to the Winv workspace.
-template <typename T, int PB, int NB = 8, bool WT = false>
-__device__ __forceinline__ void inv_block_column(const T* __restrict__ Ls, T* __restrict__ Wg, int l15, int l4) {
+// Wd: the diagonal inverses W_bb as separate 16x16 tiles [b][col * 16 + row] (the 64-block path, whose factor phase produces
+// them on the side and keeps the L image whole), or null: they sit in the diagonal tiles of the image itself.
+template <typename T, int PB, int NB = 8, bool WT = false, bool SEPW = false>
+__device__ __forceinline__ void inv_block_column(const T* __restrict__ Ls, T* __restrict__ Wg, int l15, int l4,
+                                                 const T* __restrict__ Wd = nullptr) {
     typedef typename Num<T>::acc_t acc_t;
     constexpr int NQ = NB - 1 - PB;
     acc_t w[NQ > 0 ? NQ : 1];
-    const T* Wpp = Ls + ptile(PB, PB);
+    const T* Wpp = SEPW ? Wd + PB * 256 : Ls + ptile(PB, PB);
 #pragma unroll
     for (int qq = 0; qq < NQ; ++qq) {
         const int q = PB + 1 + qq;
@@ -993,7 +996,7 @@ __device__ __forceinline__ void inv_block_column(const T* __restrict__ Ls, T* __
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
                 const int k = Num<T>::kidx(kk, l4);
-                const T fb = (k >= l15) ? Wpp[l15 * 16 + k] : (T)0;              // W_pp(k, j = l15), lower
+                const T fb = (k >= l15) ? Wpp[SEPW ? k * 16 + l15 : l15 * 16 + k] : (T)0;   // W_pp(k, j = l15), lower (Wd tiles: [row][col])
                 sacc = Num<T>::mfma(Lq[k * 16 + l15], fb, sacc);
             }
         }
@@ -1004,12 +1007,12 @@ __device__ __forceinline__ void inv_block_column(const T* __restrict__ Ls, T* __
             for (int kk = 0; kk < 4; ++kk)
                 sacc = Num<T>::mfma(Lqr[Num<T>::kidx(kk, l4) * 16 + l15], w[rr][kk], sacc);
         }
-        const T* Wqq = Ls + ptile(q, q);
+        const T* Wqq = SEPW ? Wd + q * 256 : Ls + ptile(q, q);
         acc_t out = (acc_t){0, 0, 0, 0};
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             const int k = Num<T>::kidx(kk, l4);
-            const T fa = (l15 >= k) ? Wqq[k * 16 + l15] : (T)0;                  // W_qq(i = l15, k), lower
+            const T fa = (l15 >= k) ? Wqq[SEPW ? l15 * 16 + k : k * 16 + l15] : (T)0;   // W_qq(i = l15, k), lower
             out = Num<T>::mfma(-fa, sacc[kk], out);
         }
         w[qq] = out;
@@ -1064,14 +1067,16 @@ __device__ __forceinline__ void potrf_update(T* __restrict__ Ls, int p, int t, i
 // image): (i) the NB 16x16 diagonal inverses, (ii) the off-diagonal blocks column by column on the
 // MFMA, (iii) W (with an explicit zero upper triangle) to Wg, leading dimension 16 NB.
 // dinv[c] = 1 / L_cc.  All 256 threads; ends without a barrier.
-template <typename T, int NB, bool WT = false>
-__device__ __forceinline__ void tri_inverse_lds(T* __restrict__ Ls, const T* __restrict__ dinv, T* __restrict__ Wg) {
+// SEPW: step (i) has been done by the factor phase, the diagonal inverses are the tiles at Wd and the L image stays whole.
+template <typename T, int NB, bool WT = false, bool SEPW = false>
+__device__ __forceinline__ void tri_inverse_lds(T* __restrict__ Ls, const T* __restrict__ dinv, T* __restrict__ Wg,
+                                                const T* __restrict__ Wd = nullptr) {
     constexpr int NE = 16 * NB;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
     const int er = tid & 15, ec = tid >> 4;
     // ------------------------------ inverse phase ------------------------------
-    {   // (i) the eight 16x16 diagonal inverses: thread = (block, column)
+    if constexpr (!SEPW) {   // (i) the eight 16x16 diagonal inverses: thread = (block, column)
         T w[16];
         const int blk = tid >> 4, c = tid & 15;
         T* Dbb = Ls + ptile(blk & (NB - 1), blk & (NB - 1));
@@ -1112,9 +1117,9 @@ __device__ __forceinline__ void tri_inverse_lds(T* __restrict__ Ls, const T* __r
                 inv_block_column<T, 4, 8, WT>(Ls, Wg, l15, l4);
             }
         } else {
-            if (uw == 0) inv_block_column<T, 0, 4, WT>(Ls, Wg, l15, l4);
-            else if (uw == 1) inv_block_column<T, 1, 4, WT>(Ls, Wg, l15, l4);
-            else if (uw == 2) inv_block_column<T, 2, 4, WT>(Ls, Wg, l15, l4);
+            if (uw == 0) inv_block_column<T, 0, 4, WT, SEPW>(Ls, Wg, l15, l4, Wd);
+            else if (uw == 1) inv_block_column<T, 1, 4, WT, SEPW>(Ls, Wg, l15, l4, Wd);
+            else if (uw == 2) inv_block_column<T, 2, 4, WT, SEPW>(Ls, Wg, l15, l4, Wd);
         }
     }
     GP_STAMP(33);
@@ -1122,9 +1127,21 @@ __device__ __forceinline__ void tri_inverse_lds(T* __restrict__ Ls, const T* __r
     for (int bi = 0; bi < NB; ++bi)
         for (int bj = bi; bj < NB; ++bj) {
             T v = (T)0;
-            if (bi == bj && er >= ec) v = Ls[ptile(bi, bj) + tid];
+            if (bi == bj && er >= ec) v = SEPW ? Wd[bi * 256 + er * 16 + ec] : Ls[ptile(bi, bj) + tid];
             gst<WT>(Wg + (bj * 16 + ec) * NE + bi * 16 + er, v);
         }
+}
+
+// 64-block path (fp64): behind the 10 tiles + dinv[64] of the image sit four tiles Wd that start as the identity and end as the
+// diagonal inverses, and a copy S of tile (0,0).  The caller fills them with the image, before its barrier: potrf64_aux_init by
+// all 256 threads, S by whoever writes tile (0,0) (same [col * 16 + row] order).
+constexpr int PT64_WD = 10 * 256 + 64, PT64_S = PT64_WD + 4 * 256;      // element offsets from Ls
+template <typename T>
+__device__ __forceinline__ void potrf64_aux_init(T* __restrict__ Ls) {
+    const int tid = threadIdx.x;
+    const T v = ((tid >> 4) == (tid & 15)) ? (T)1 : (T)0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) Ls[PT64_WD + b * 256 + tid] = v;
 }
 
 // Core of potrf128 on a tile-packed LDS image that is already in place (all 256 threads; the caller
@@ -1135,11 +1152,13 @@ __device__ __forceinline__ void tri_inverse_lds(T* __restrict__ Ls, const T* __r
 template <typename T, int NB = 8, bool WT = false>
 __device__ __forceinline__ void potrf128_core(double* __restrict__ lds_raw, T* __restrict__ Ad, long ld,
                                               T* __restrict__ Wg, double* __restrict__ logdet_out,
-                                              int* __restrict__ info_out, T tol) {
+                                              int* __restrict__ info_out, T tol, int* pub_flag = nullptr, int pub_epoch = 0) {
     double* red = lds_raw;                      // 2 doubles
     constexpr int NE = 16 * NB;                 // block edge
-    T* Ls = reinterpret_cast<T*>(lds_raw + 2);  // NB(NB+1)/2 tiles + dinv[NE]
+    T* Ls = reinterpret_cast<T*>(lds_raw + 2);  // NB(NB+1)/2 tiles + dinv[NE] (+ 64-block path: NB diagonal-inverse tiles)
     T* dinv = Ls + (NB * (NB + 1) / 2) * 256;
+    constexpr bool SEPW = NB == 4 && sizeof(T) == 8;
+    T* Wd = dinv + NE;                          // SEPW only: = Ls + PT64_WD; the copy S of tile (0,0) behind the four tiles
     typedef typename Num<T>::acc_t acc_t;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
@@ -1157,6 +1176,8 @@ __device__ __forceinline__ void potrf128_core(double* __restrict__ lds_raw, T* _
         // x[c2] -= x[c] L[c2][c] with the pivot row's values broadcast by v_readlane.  No D-layout
         // gather, no separate row-solve pass, one barrier per panel.  Wave 0 first applies panel p-1 to
         // its own block column (<= 3 tiles) while waves 1-3 take the other trailing tiles.
+        // (unrolled: with p a constant the roles below fold and the update's tile loops unroll -- 22.6 -> 20.9 us per hop)
+#pragma unroll
         for (int p = 0; p < NB; ++p) {
             GP_STAMP(2 + 3 * p);
             if (p > 0) {
@@ -1168,10 +1189,22 @@ __device__ __forceinline__ void potrf128_core(double* __restrict__ lds_raw, T* _
                     if (tt >= 0) potrf_update<T, 1>(Ls, p - 1, t, tt, 1 << 20, l15, l4);
                 }
             }
-            if (uwv == 0) {
+            // The diagonal inverse W_pp rides along: sixteen lanes start from the rows of the identity and go through the same
+            // elimination, [I] L_pp^-T = W_pp^T -- the free lanes 48-63 of wave 0 for p > 0; for p = 0 (all 64 lanes are rows)
+            // wave 1, idle in that panel, repeats the elimination of the diagonal tile (from the copy S, which wave 0 never
+            // writes) with the identity in its lanes 16-31.  The identity rows are LDS tiles like any other (potrf64_aux_init),
+            // so those lanes run the very same load / eliminate / store code through their own pointer: tile p of Wd receives
+            // W_pp in [row * 16 + col] order.  Same operations in the same order as the substitution it replaces
+            // (tri_inverse_lds step (i)), off the chain.
+            const bool w1 = p == 0 && uwv == 1;
+            if (uwv == 0 || w1) {
                 const int nrows = NE - 16 * p;
-                const bool live = lane < nrows;
-                T* Xr = Ls + ptile(live ? p + (lane >> 4) : p, p) + (lane & 15);
+                const int idl = w1 ? 16 : 48;
+                const bool isid = (w1 || p > 0) && lane >= idl && lane < idl + 16;
+                const bool rowl = !w1 && lane < nrows;
+                const bool live = rowl || isid;
+                T* Xr = isid ? Wd + p * 256 + (lane - idl)
+                             : (rowl ? Ls + ptile(p + (lane >> 4), p) : (w1 ? Wd + NB * 256 : Ls + ptile(p, p))) + (lane & 15);
                 double x[16], dv = 0.0;
 #pragma unroll
                 for (int c = 0; c < 16; ++c) x[c] = (double)Xr[c * 16];
@@ -1192,7 +1225,7 @@ __device__ __forceinline__ void potrf128_core(double* __restrict__ lds_raw, T* _
 #pragma unroll
                     for (int c = 0; c < 16; ++c) Xr[c * 16] = (T)x[c];
                 }
-                if (lane < 16) dinv[16 * p + lane] = (T)dv;
+                if (uwv == 0 && lane < 16) dinv[16 * p + lane] = (T)dv;
             }
             __syncthreads();
             GP_STAMP(3 + 3 * p);
@@ -1311,6 +1344,33 @@ __device__ __forceinline__ void potrf128_core(double* __restrict__ lds_raw, T* _
     }
 
     GP_STAMP(30);
+    if constexpr (SEPW) {
+        // 64-block path (the dataflow kernel's chain): nobody inside the launch reads L_jj -- its consumers (solves, prediction,
+        // the broadcast of a sharded panel) come after the kernel -- so the order is W first, then the hand-over to the next hop
+        // (flag), and the L tile goes out behind it.  The log-det partial and the info word precede the flag: the corner task
+        // of the one-launch evaluation reads them.
+        if (uwv == 3) {                                                  // (idle in the inverse phase; NE = 64 = one wave)
+            double lg = -log((double)dinv[lane]);
+            for (int off = 32; off > 0; off >>= 1) lg += __shfl_down(lg, off);
+            if (lane == 0) gst<WT>(logdet_out, lg);
+        }
+        if (tid == 0 && bad) gst<WT>(info_out, 1);
+        GP_STAMP(31);
+        GP_STAMP(32);
+        tri_inverse_lds<T, NB, WT, true>(Ls, dinv, Wg, Wd);
+        GP_STAMP(34);
+        if (pub_flag) {                                                  // (WT stores: at the coherent level once vmcnt drains)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store(pub_flag, pub_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        GP_STAMP(35);
+        for (int bi = 0; bi < NB; ++bi)
+            for (int bj = 0; bj <= bi; ++bj)
+                gst<WT>(Ad + (long)(bj * 16 + ec) * ld + bi * 16 + er, Ls[ptile(bi, bj) + tid]);
+        GP_STAMP(36);
+        return;
+    }
     // L back to HBM (lower-triangle tiles; diagonal tiles whole, their upper part is never read)
     for (int bi = 0; bi < NB; ++bi)
         for (int bj = 0; bj <= bi; ++bj)
@@ -1335,8 +1395,8 @@ __device__ __forceinline__ void potrf128_core(double* __restrict__ lds_raw, T* _
 // the accumulator-heavy MFMA loops of that kernel (inlined, the allocator spills accumulators there).
 template <typename T, int NB, bool WT = false>
 __device__ __noinline__ void potrf128_core_call(double* lds_raw, T* Ad, long ld, T* Wg, double* logdet_out,
-                                                int* info_out, T tol) {
-    potrf128_core<T, NB, WT>(lds_raw, Ad, ld, Wg, logdet_out, info_out, tol);
+                                                int* info_out, T tol, int* pub_flag, int pub_epoch) {
+    potrf128_core<T, NB, WT>(lds_raw, Ad, ld, Wg, logdet_out, info_out, tol, pub_flag, pub_epoch);
 }
 template <typename T>
 __global__ __launch_bounds__(256) void potrf128_kernel(T* __restrict__ Abase, long bstride, int b,
@@ -1854,7 +1914,7 @@ __global__ __launch_bounds__(64 * NWI * NWJ, (NWI * NWJ == 4) ? 2 : 4) void gemm
                 T* Ct = Cg - ((long)(wj * (16 * FJ)) * ldc + wi * (16 * FI) + (lane & 15));        // tile base
                 potrf128_core_call<T, 8>(smem_raw, Ct, ldc, g.fuse_W + ((long)slot * g.fuse_nt + g.fuse_b) * TB * TB,
                                          g.fuse_partial + (long)slot * g.fuse_nt + g.fuse_b, g.fuse_info + slot,
-                                         (T)g.fuse_slotp[(long)slot * SLOTP + 3]);
+                                         (T)g.fuse_slotp[(long)slot * SLOTP + 3], nullptr, 0);
             }
         }
         return;
@@ -2000,7 +2060,7 @@ template <typename T, int TBX> constexpr int df_stage_elems() {
 template <typename T, int TBX, int NST = 2> constexpr size_t df_lds_bytes() {
     constexpr size_t gemm = NST * (size_t)df_stage_elems<T, TBX>() * sizeof(T);
     constexpr size_t nb = TBX / 16;
-    constexpr size_t potrf = 16 + (nb * (nb + 1) / 2 * 256 + TBX) * sizeof(T);
+    constexpr size_t potrf = 16 + (nb * (nb + 1) / 2 * 256 + TBX + (TBX == 64 ? (nb + 1) * 256 : 0)) * sizeof(T);
     return gemm > potrf ? gemm : potrf;
 }
 
@@ -2497,18 +2557,26 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g, Th
                 if (bi >= bj) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) Ls[ptile(bi, bj) + Num<T>::drow(l4, r) * 16 + l15] = acc[x][y][r];
+                    if (TBX == 64 && bi == 0 && bj == 0) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) Ls[PT64_S + Num<T>::drow(l4, r) * 16 + l15] = acc[x][y][r];
+                    }
                 }
             }
+        if constexpr (TBX == 64) potrf64_aux_init<T>(Ls);
         __syncthreads();
         stamp(2);
         // (GP_DF_WT_POTRF: potrf's L, W, log-det and info stores write-through too, so that this publish needs no fence either)
 #ifndef GP_DF_WT_POTRF
 #define GP_DF_WT_POTRF 1
 #endif
+        // 64-tiles: the core publishes ready(j,j) itself, as soon as W_j is out and before the L tile
+        int* pubf = (TBX == 64 && GP_DF_WT_POTRF) ? F + j * R + j : nullptr;
         potrf128_core_call<T, TBX / 16, GP_DF_WT_POTRF != 0>(smem_raw, Ct, LDA, Wj, g.partial + (long)slot * g.p_bstride + j, g.info + slot,
-                                                              (T)sp[3]);
+                                                              (T)sp[3], pubf, g.epoch);
         stamp(3);
-        if (GP_DF_WT_POTRF) publish_wt(j, j);
+        if (pubf) { }
+        else if (GP_DF_WT_POTRF) publish_wt(j, j);
         else publish(j, j);
         leave_critical();
         stamp(4);

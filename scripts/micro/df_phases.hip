@@ -55,17 +55,20 @@ int main(int argc, char** argv) {
     auto us = [&](long long v) { return v ? (v - t0) / 100.0 : -1.0; };
     auto hop = [&](int j) {
         const long long* d = &tr[(size_t)off(j) * 8]; const long long* p = &tr[(size_t)off(j - 1) * 8];
-        const double t = us(p[4]);
-        printf("hop diag(%d): prev pub %.1f | flags seen +%.1f | solve+store+publish +%.1f | slab +%.1f | packed +%.1f | potrf end +%.1f | pub +%.1f\n",
-               j, t, us(d[5]) - t, us(d[7]) - t, us(d[6]) - t, us(d[2]) - t, us(d[3]) - t, us(d[4]) - t);
+        const long bp = block_of[(size_t)off(j - 1)];
+        // ready(j-1,j-1) goes out INSIDE the potrf body (stamp 35 of that workgroup), before its L tile
+        const double t = (bp >= 0 && st[(size_t)bp * 64 + 35]) ? us(st[(size_t)bp * 64 + 35]) : us(p[4]);
+        printf("hop diag(%d): prev pub %.1f | flags seen +%.1f | solve+store+publish +%.1f | slab +%.1f | packed +%.1f | potrf call end +%.1f\n",
+               j, t, us(d[5]) - t, us(d[7]) - t, us(d[6]) - t, us(d[2]) - t, us(d[3]) - t);
         const long b = block_of[(size_t)off(j)];
         if (b < 0) return;
         const long long* s = &st[(size_t)b * 64];
         auto du = [&](int a, int c) { return (s[c] - s[a]) / 100.0; };
         printf("   potrf64 phases (us): entry %.2f |", du(1, 2));
         for (int q = 0; q < 4; ++q) printf(" panel %d: upd+elim %.2f%s", q, du(2 + 3 * q, 3 + 3 * q), q < 3 ? "," : " |");
-        printf(" L store+logdet %.2f | diag inv %.2f | block inv %.2f | W store %.2f | total %.2f   (call overhead: %.2f before, %.2f after)\n",
-               du(12, 31), du(31, 32), du(32, 33), du(33, 34), du(1, 34), (s[1] - d[2]) / 100.0, (d[3] - s[34]) / 100.0);
+        // (round 5: the diagonal inverses come out of the elimination; order = logdet, block inverses, W store, publish, L store)
+        printf(" logdet %.2f | block inv %.2f | W store %.2f | publish %.2f | L store (behind the flag) %.2f | entry..publish %.2f   (call overhead: %.2f before, %.2f after)\n",
+               du(12, 31), du(32, 33), du(33, 34), du(34, 35), du(35, 36), du(1, 35), (s[1] - d[2]) / 100.0, (d[3] - s[36]) / 100.0);
     };
     for (int j : {nd / 8, nd / 4, nd / 2, nd / 2 + 1, nd / 2 + 2, nd / 2 + 3, 3 * nd / 4, nd - 3}) if (j >= 1 && j < nd) hop(j);
     long long tend = 0; for (long q = 0; q < ntask; ++q) for (int k = 0; k < 8; ++k) tend = std::max(tend, tr[(size_t)q * 8 + k]);
