@@ -1994,6 +1994,11 @@ struct DfArgs {
                                               // first task of column nprev.  The launch applies that panel to its own columns itself.
     int* park;                                // 64-tiles, two workgroups per CU: [DF_PARK_SLOTS] counters "a chain task is in its critical
                                               // section on this CU" (index = XCC / SE / SH / CU id); the neighbour sleeps meanwhile; or null
+    T* U; long ldu;                           // INVERSE launch (gradient, K^-1 = U U^T): the factor is final, every task is a tile of
+                                              // U = L^-T (column-major, leading dimension ldu, pre-zeroed):  U(rb,cb), rb <= cb, =
+                                              // (E - sum_{k=rb}^{cb-1} U(rb,k) L(cb,k)^T) W_cb^T.  Tasks in column order (cb, then
+                                              // rb), nd (nd + 1) / 2 of them, one slot; the flag matrix serves U's own hand-overs
+                                              // (ready(rb,cb) at rb * (nd + 1) + cb, a fresh epoch).  null: the factorisation
     long long* trace;                         // developer timing (scripts/micro/df_trace.hip): 8 stamps per task, or null
     // BUILD variant only (one launch per evaluation: tiles built in-kernel, results exported by the corner task)
     const T* xt; const T* yv;                 // unscaled inputs [d][npad], outputs [npad]
@@ -2115,7 +2120,15 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g, Th
 #ifndef GP_DF_PRIO
 #define GP_DF_PRIO 3
 #endif
-    if (GP_DF_PRIO > 0 && (i == j || (TBX == 64 && i == j + 1))) __builtin_amdgcn_s_setprio(GP_DF_PRIO);
+    const bool inverse = g.U != nullptr;
+    if (inverse) {                                          // task q -> (rb, cb), rb <= cb, column cb first: q = cb (cb + 1) / 2 + rb
+        int cb = (int)((sqrt(8.0 * (double)q + 1.0) - 1.0) * 0.5);
+        while ((long)(cb + 1) * (cb + 2) / 2 <= q) ++cb;
+        while (cb > 0 && (long)cb * (cb + 1) / 2 > q) --cb;
+        i = __builtin_amdgcn_readfirstlane(cb);             // i = column block cb, j = row block rb: tile (i, j) of L exists
+        j = __builtin_amdgcn_readfirstlane((int)(q - (long)cb * (cb + 1) / 2));
+    }
+    if (GP_DF_PRIO > 0 && !inverse && (i == j || (TBX == 64 && i == j + 1))) __builtin_amdgcn_s_setprio(GP_DF_PRIO);
     // Per-phase stamps (scripts/micro/df_phases.hip) show every phase of a diagonal task's potrf / solve running 1.6-1.8x slower
     // next to a co-resident workgroup's back-to-back MFMAs (and at its stand-alone pace with the CU to itself).  So while a
     // diagonal task is in its critical section -- dependencies met, nothing but its own work between it and ready(j,j) -- it
@@ -2265,18 +2278,22 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g, Th
     // this loop makes the register allocator spill accumulators around it.
     // mi >= 0: both operands walk the finished tile columns 0, 1, .. of tile rows mi / mj (one TBX-wide slab = SPB
     // stages per column; the columns are separate tiles of the packed workspace); otherwise Ig / Jg are contiguous in k.
+    // multi_c = 2 (inverse launch): I contiguous in k (a row block of U), J walks the tiles (mj, mi), (mj, mi + 1), ..
     auto run_k_impl = [&](auto multi_c, acc_t (&A)[FJ][FI], const T* Ig0, long ldi, const T* Jg0, long ldj, int nk, bool negate,
                           int mi, int mj) {
-        constexpr bool MULTI = decltype(multi_c)::value;
+        constexpr int MULTI = (int)decltype(multi_c)::value;
         auto stage = [&](int kb, int st) {
             T* Is = smem + st * STAGE;
             T* Js = Is + JOFF;
             const T *Ig, *Jg;                               // column 0 of stage kb
-            if constexpr (MULTI) {
+            if constexpr (MULTI == 1) {
                 const int bcol = kb / SPB;
                 const long o = (long)(kb % SPB) * GK * LDA;
                 Ig = tptr(mi, bcol) + o;
                 Jg = tptr(mj, bcol) + o;
+            } else if constexpr (MULTI == 2) {
+                Ig = Ig0 + (long)kb * GK * ldi;
+                Jg = tptr(mj, mi + kb / SPB) + (long)(kb % SPB) * GK * LDA;
             } else {
                 Ig = Ig0 + (long)kb * GK * ldi;
                 Jg = Jg0 + (long)kb * GK * ldj;
@@ -2386,7 +2403,7 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g, Th
         }
     };
     auto run_k = [&](acc_t (&A)[FJ][FI], const T* Ig0, long ldi, const T* Jg0, long ldj, int nk, bool negate) {
-        run_k_impl(std::false_type{}, A, Ig0, ldi, Jg0, ldj, nk, negate, 0, 0);
+        run_k_impl(std::integral_constant<int, 0>{}, A, Ig0, ldi, Jg0, ldj, nk, negate, 0, 0);
     };
     // Publishing a tile whose ONLY payload is store_c's write-through (sc1) stores needs no L2 write-back at all: the stores
     // are at the device-coherent level once this wave's vmcnt has drained, the barrier collects all waves, then the flag goes
@@ -2409,6 +2426,65 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g, Th
         // orders them before this store -- a second release here would only repeat the L2 write-back
         if (tid == 0) __hip_atomic_store(F + fi_ * R + fj_, g.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
+
+    if (inverse) {
+        // ---- a tile of U = L^-T.  Row block rb of U advances one column block per task: the k-th slab needs U(rb,k), i.e. the
+        // task before this one in the row -- a chain of nd - rb hops per row, nd rows side by side.
+        const int cb = i, rb = j, nsl = cb - rb;
+        T* Ut = g.U + (long)cb * TBX * g.ldu + (long)rb * TBX;
+        const T* Urow = g.U + (long)rb * TBX;               // U(rb rows, column c) at Urow[r + c * ldu]
+        zero_c(acc);
+        if (nsl == 0) {
+#pragma unroll
+            for (int x = 0; x < FJ; ++x)
+#pragma unroll
+                for (int y = 0; y < FI; ++y)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (wi * WT + y * 16 + l15 == wj * WT + x * 16 + Num<T>::drow(l4, r)) acc[x][y][r] = (T)1;
+        }
+        int known = 0;
+        if (nsl > 1) {                                      // the leading run of finished columns: one parallel peek
+            if (wave == 0) {
+                int run = 0;
+                for (int c0 = 0; c0 < nsl; c0 += 64) {
+                    const int c = c0 + lane;
+                    const bool ready = c < nsl &&
+                        __hip_atomic_load(F + rb * R + rb + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == g.epoch;
+                    const unsigned long long miss = ~__ballot(ready);
+                    const int lead = miss ? __builtin_ctzll(miss) : 64;
+                    run += lead;
+                    if (lead < 64) break;
+                }
+                if (lane == 0) s_task = run < nsl ? run : nsl;
+            }
+            __syncthreads();
+            known = __builtin_amdgcn_readfirstlane(s_task);
+            if (known > 0 && GP_DF_ACQUIRE) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        int b0 = 0;
+        if constexpr (TBX == 64) {
+            if (known > 0) {
+                run_k_impl(std::integral_constant<int, 2>{}, acc, Urow + (long)rb * TBX * g.ldu, g.ldu, nullptr, LDA, known * SPB, true, rb, cb);
+                b0 = known;
+            }
+        }
+        for (int b = b0; b < nsl; ++b) {
+            if (b >= known) {
+                if (wave == 0) df_wait(F + rb * R + rb + b, g.epoch, g.abort_flag);
+                __syncthreads();
+            }
+            run_k(acc, Urow + (long)(rb + b) * TBX * g.ldu, g.ldu, tptr(cb, rb + b), LDA, SPB, true);
+        }
+        store_c(acc, Ut, g.ldu);                            // the pre-solve tile becomes an MFMA operand through memory
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        zero_c(acc);
+        run_k(acc, Ut, g.ldu, g.W + (long)slot * g.w_bstride + (long)cb * TBX * TBX, TBX, SPB, false);
+        store_c(acc, Ut, g.ldu);
+        publish_wt(rb, cb);
+        return;
+    }
 
     // 64-tiles fuse the critical chain: the diagonal task (j,j) ALSO solves its own sub-diagonal tile (j,j-1)
     // (whose owner only accumulates it and hands the pre-solve tile over through memory) and applies that
@@ -2453,7 +2529,7 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g, Th
         // would cost as much as its MFMAs).  Not for 128-tiles: with 128 accumulator registers a variable
         // trip count makes the allocator spill inside the stage loop.
         if (known > 0) {
-            run_k_impl(std::true_type{}, acc, nullptr, LDA, nullptr, LDA, known * SPB, true, i, j);
+            run_k_impl(std::integral_constant<int, 1>{}, acc, nullptr, LDA, nullptr, LDA, known * SPB, true, i, j);
             b0 = known;
         }
     }
@@ -2727,6 +2803,28 @@ __global__ void gather_rhs_row_kernel(const T* __restrict__ Abase, int R, int ro
                                       int j_first = 0) {
     const int j = j_first + blockIdx.x * blockDim.x + threadIdx.x;        // columns [j_first, npad)
     if (j < npad) out[(long)j * ldo] = Abase[tile_index(R - 1, j >> 7, R) * TS + (long)(j & 127) * TB + row];
+}
+
+// alpha = U z for the explicit upper-triangular U = L^-T (column-major, leading dimension ld; zeros below the diagonal): the
+// gradient's alpha = K^-1 r = L^-T (L^-1 r) once U exists, as one pass over U instead of a backward substitution of ~2 launches
+// per tile column.  Fixed summation order: a partial sum per (row, chunk of `chunk` columns), then the chunks in order.
+template <typename T>
+__global__ __launch_bounds__(128) void utri_gemv_partial_kernel(const T* __restrict__ U, long ld, const T* __restrict__ z, int npad,
+                                                                int chunk, double* __restrict__ part) {
+    const int r = blockIdx.x * TB + threadIdx.x;                                // one tile row of U per workgroup (128 threads)
+    const int c1 = min((int)(blockIdx.y + 1) * chunk, npad);
+    const int c0 = max((int)blockIdx.y * chunk, (int)(blockIdx.x * TB));        // (row r has nothing left of column r)
+    double s = 0.0;
+    for (int c = c0; c < c1; ++c) s = __builtin_fma((double)U[(long)c * ld + r], (double)z[c], s);
+    part[(long)blockIdx.y * npad + r] = s;
+}
+template <typename T>
+__global__ void utri_gemv_finish_kernel(const double* __restrict__ part, int nchunks, int npad, T* __restrict__ out) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= npad) return;
+    double s = 0.0;
+    for (int y = 0; y < nchunks; ++y) s += part[(long)y * npad + r];
+    out[r] = (T)s;
 }
 
 template <typename T>

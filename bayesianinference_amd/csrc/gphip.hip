@@ -131,6 +131,7 @@ struct gphip_ctx {
     int panel_left = -1;                         // in-panel updates left-looking: -1 auto (batches), 0 never, 1 always
     int fuse_option = 1;                         // allow the single-launch evaluation (option "fused_eval")
     int grad_potri = 1;                          // gradient: K^-1 = U U^T in one go when the memory is there
+    int grad_df_inverse = 1;                     // ... with U = L^-T from the dataflow kernel's inverse launch where the factor came from one launch
     int panel_wide = 1;                          // wider outer panels while the trailing matrix is large (queue_factor)
     int thin_tiles = 1;                          // gemm_nt: skip the zero rows of the rhs block-row and the unread upper quadrant of diagonal tiles
     int debug_fail_alloc = 0;                    // tests: make the n-th device allocation of the next slot (re)allocation fail
@@ -138,6 +139,8 @@ struct gphip_ctx {
     bool fused_eval = false;                     // eval_chunk: the whole evaluation is ONE dataflow launch (build + factor + results)
     bool theta_packed = false;                   // eval_chunk: hyper-parameters travel as kernel arguments (k_scale_theta)
     bool want_w = false;                         // the caller substitutes with W_b afterwards (fit / predict / gradient)
+    bool want_u = false, u_ready = false;        // gradient: a single-launch factorisation is followed by the inverse launch of the same
+                                                 // kernel (U = L^-T into dV, see DfArgs::U); u_ready: it ran for the current factor
     int* dFlags = nullptr;                       // [slots][(Nt+1)^2] ready flags (value = epoch)
     unsigned long long* dTicket = nullptr;       // task ticket counter (+ abort flag in the next word)
     unsigned long long ticket_base = 0;
@@ -158,7 +161,7 @@ struct gphip_ctx {
     size_t part_cap = 0;
     int64_t vcap = 0;
     void* dAlpha = nullptr;                                  // typed [Npad] (gradient)
-    void* dKinv = nullptr;                                   // typed [Npad x Npad] lower tiles of K^-1 (gradient, potri route)
+    void* dKinv = nullptr;                                   // typed [(Npad + GRAD_LD_PAD) x Npad] lower tiles of K^-1 (gradient, potri route)
     double* dGacc = nullptr;                                 // [d + 2] gradient accumulators
     // profiling
     std::vector<ProfRec> recs;
@@ -583,7 +586,9 @@ void launch_gemm(gphip_ctx* h, int cls, Opnd<T> Co, Opnd<T> Ao, Opnd<T> Bo, int 
         g.nrect = nrc * H;
         g.ntiles = g.nrect + ntc * H - ntc * (ntc - 1) / 2;
     }
-    g.swizzle = h->swizzle && g.ntiles >= 64;
+    // (not for ktri launches: their tiles contract k >= 128 ti only, so equal COUNTS of the column-major list are unequal work --
+    //  the first XCD's chunk holds 17 % of it at N = 8192; dealt round-robin the XCDs finish together)
+    g.swizzle = h->swizzle && g.ntiles >= 64 && !ktri;
     int grid_x = g.ntiles;
     if (tri && r0 == c0 && W == H && h->supertile >= 2 && H >= 16 && mode == 0 && groups == 1 && (nslots == 1 || h->supertile == 3)) {
         g.super = 2;                            // the tile list in blocked (8 x 8 super-tile) order, equal chunks per XCD
@@ -734,7 +739,8 @@ bool panel_df_on(const gphip_ctx* h, int nslots) {
 }
 
 bool use_dataflow(const gphip_ctx* h, int nslots) {
-    if (panel_df_on(h, nslots)) return false;
+    // (a gradient call prefers the single launch where it is allowed at all: its inverse launch follows, launch_dataflow_inverse)
+    if (panel_df_on(h, nslots) && !(h->want_u && h->Nt <= h->dataflow_max_nt)) return false;
     // measured: wins 1.05-2.3x for one theta up to N = 12288, ties at 8-16 slots, loses 2x at 200 slots
     // (there the multi-kernel schedule's big launches are throughput bound, not latency bound)
     if (!h->dataflow || h->dist_world > 0 || h->Nt > h->dataflow_max_nt) return false;
@@ -802,6 +808,35 @@ void launch_dataflow(gphip_ctx* h, int nslots, int c0 = 0, double* part = nullpt
     hipLaunchKernelGGL((chol_dataflow_kernel<T, TBX, OCC, NST, BUILD>), dim3((unsigned)tasks), dim3(256), lds, h->stream, g, tp);
 }
 
+// U = L^-T of the factor a single dataflow launch has just queued (one slot), by a second launch of the same kernel whose
+// tasks are the tiles of U (DfArgs::U): column-major Npad x Npad in dKinv (queue_grad_potri then contracts K^-1 = U U^T into dV).
+// The multi-kernel route to the same U (queue_forward_rows over the identity) is a chain of ~3 launches per tile column.
+// Column-major U / K^-1 of the inverse-launch route use a leading dimension that is NOT a multiple of a large power of two
+// (Npad + 16 elements): with ld = Npad = 8192 doubles every k-column of an operand tile starts 64 KiB after the previous one
+constexpr int64_t GRAD_LD_PAD = 16;
+template <typename T, int TBX, int OCC = 2, int NST = 2>
+void launch_dataflow_inverse(gphip_ctx* h) {
+    const int nd = (int)(h->Npad / TBX);
+    const long tasks = (long)nd * (nd + 1) / 2;
+    (void)hipMemsetAsync(h->dKinv, 0, (size_t)(h->Npad + GRAD_LD_PAD) * h->Npad * sizeof(T), h->stream);      // (dV stays free for the alpha solve)
+    DfArgs<T> g{};
+    g.A = (T*)h->dA; g.bstride = h->slot_elems; g.R128 = (int)h->R; g.c0 = 0;
+    g.W = (T*)h->dW; g.w_bstride = (long)h->Nt * TB * TB;
+    g.partial = h->dPartial; g.p_bstride = h->Npad / TBX;
+    g.info = h->dInfo; g.slotp = h->dSlotp;
+    g.flags = h->dFlags; g.f_bstride = (long)(2 * h->Nt + 1) * (2 * h->Nt + 1);
+    g.ticket = h->dTicket; g.ticket_base = h->ticket_base;
+    g.abort_flag = reinterpret_cast<int*>(h->dTicket + 1);
+    g.nd = nd; g.nslots = 1; g.epoch = ++h->epoch;
+    g.U = (T*)h->dKinv; g.ldu = (long)(h->Npad + GRAD_LD_PAD);
+    h->ticket_base += (unsigned long long)tasks;
+    ProfScope ps(h, 2, ((double)h->Npad * h->Npad * h->Npad) / 3.0, 0.0);
+    const size_t lds = df_lds_bytes<T, TBX, NST>();
+    ThetaPack tp;
+    hipLaunchKernelGGL((chol_dataflow_kernel<T, TBX, OCC, NST, false>), dim3((unsigned)tasks), dim3(256), lds, h->stream, g, tp);
+    h->u_ready = true;
+}
+
 template <typename T>
 void launch_finalize(gphip_ctx* h, int nslots, int nparts, int pstride = 0, const double* part2 = nullptr, int n2 = 0) {
     hipLaunchKernelGGL(finalize_kernel<T>, dim3(nslots), dim3(64), 0, h->stream, (const T*)h->dA, (long)h->slot_elems,
@@ -828,6 +863,10 @@ int queue_factor_dataflow(gphip_ctx* h, int nslots) {
             if (occ3) launch_dataflow<T, 64, 3>(h, nslots);
             else launch_dataflow<T, 64>(h, nslots);
             launch_finalize<T>(h, nslots, 2 * (int)h->Nt);
+            if (h->want_u && nslots == 1) {    // (before the 128-block inverses below overwrite the 64-block ones)
+                if (occ3) launch_dataflow_inverse<T, 64, 3>(h);
+                else launch_dataflow_inverse<T, 64>(h);
+            }
             if (h->want_w)
                 hipLaunchKernelGGL(trtri128_kernel<T>, dim3((unsigned)h->Nt, nslots), dim3(256), potrf_lds<T>(), h->stream,
                                    (const T*)h->dA, (long)h->slot_elems, (T*)h->dW, (int)h->Nt);
@@ -841,12 +880,14 @@ int queue_factor_dataflow(gphip_ctx* h, int nslots) {
         if (h->Nt <= 32) {
             launch_dataflow<T, 128, 2>(h, nslots);
             launch_finalize<T>(h, nslots, (int)h->Nt);
+            if (h->want_u && nslots == 1) launch_dataflow_inverse<T, 128, 2>(h);
             return 0;
         }
     }
     if (h->Nt <= 48) launch_dataflow<T, 128, 1, 4>(h, nslots);             // chain bound: deep DMA pipeline
     else launch_dataflow<T, 128, 1>(h, nslots);
     launch_finalize<T>(h, nslots, (int)h->Nt);
+    if (h->want_u && nslots == 1) launch_dataflow_inverse<T, 128, 1>(h);
     return 0;
 }
 
@@ -1658,6 +1699,22 @@ int queue_grad_chunk(gphip_ctx* h, int64_t c0, int64_t mc, int64_t mpad) {
     return GPHIP_OK;
 }
 
+// alpha = L^-T z with the explicit U = L^-T that launch_dataflow_inverse left in dKinv (z = the factored right-hand-side row);
+// scratch: the head of dV (z, then the per-chunk partial sums), free until K^-1 is contracted into it
+template <typename T>
+int queue_alpha_from_u(gphip_ctx* h) {
+    const int npad = (int)h->Npad, chunk = 512, nch = (npad + chunk - 1) / chunk;
+    T* z = (T*)h->dV;
+    double* part = reinterpret_cast<double*>(static_cast<char*>(h->dV) + (((size_t)npad * sizeof(T) + 255) / 256) * 256);
+    hipLaunchKernelGGL(gather_rhs_row_kernel<T>, dim3((unsigned)((npad + 255) / 256)), dim3(256), 0, h->stream, (const T*)h->dA,
+                       (int)h->R, 0, npad, z, 1l);
+    hipLaunchKernelGGL(utri_gemv_partial_kernel<T>, dim3((unsigned)(npad / TB), (unsigned)nch), dim3(TB), 0, h->stream,
+                       (const T*)h->dKinv, (long)(npad + GRAD_LD_PAD), (const T*)z, npad, chunk, part);
+    hipLaunchKernelGGL(utri_gemv_finish_kernel<T>, dim3((unsigned)((npad + 255) / 256)), dim3(256), 0, h->stream, (const double*)part, nch,
+                       npad, (T*)h->dAlpha);
+    return GPHIP_OK;
+}
+
 // The whole of K^-1 at once, LAPACK potri style (2/3 N^3 instead of the 4/3 N^3 of forward + backward
 // substitution): U = L^-T from a forward pass over all identity rows (upper triangular, zero tiles
 // skipped), then the lower tiles of K^-1 = U U^T as ONE triangular launch whose tile (i,j) contracts
@@ -1668,12 +1725,20 @@ int queue_grad_potri(gphip_ctx* h) {
     const long tot = npad * npad;
     int gx = (int)((tot + 255) / 256);
     if (gx > 4096) gx = 4096;
-    hipLaunchKernelGGL(identity_rows_kernel<T>, dim3(gx), dim3(256), 0, h->stream, (T*)h->dV, npad, (int)npad, 0, (int)h->N);
-    queue_forward_rows<T>(h, npad, 1, 0, true);
-    launch_gemm<T>(h, 2, cm<T>((const T*)h->dKinv, npad, 0), cm<T>((const T*)h->dV, npad, 0), cm<T>((const T*)h->dV, npad, 0),
+    // a single-launch factorisation has left U = L^-T in dKinv already (launch_dataflow_inverse): K^-1 then goes to dV
+    const bool pre = h->u_ready;
+    h->u_ready = false;
+    const T* Ub = (const T*)(pre ? h->dKinv : h->dV);
+    const T* Kb = (const T*)(pre ? h->dV : h->dKinv);
+    if (!pre) {
+        hipLaunchKernelGGL(identity_rows_kernel<T>, dim3(gx), dim3(256), 0, h->stream, (T*)h->dV, npad, (int)npad, 0, (int)h->N);
+        queue_forward_rows<T>(h, npad, 1, 0, true);
+    }
+    const long ldk = pre ? npad + GRAD_LD_PAD : npad;
+    launch_gemm<T>(h, 2, cm<T>(Kb, ldk, 0), cm<T>(Ub, ldk, 0), cm<T>(Ub, ldk, 0),
                    (int)npad, 0, (int)h->Nt, 0, (int)h->Nt, 1, 1, 1, 1);
     GradArgs<T> a{};
-    a.Kinv = (const T*)h->dKinv; a.ldv = npad; a.alpha = (const T*)h->dAlpha; a.xs = (const T*)h->dXs;
+    a.Kinv = Kb; a.ldv = ldk; a.alpha = (const T*)h->dAlpha; a.xs = (const T*)h->dXs;
     a.npad = (int)npad; a.n = (int)h->N; a.c0 = 0; a.mc = (int)h->N; a.d = (int)h->d; a.tri = 1;
     a.slotp = h->dSlotp; a.gacc = h->dGacc;
     const dim3 grid((unsigned)h->Nt, (unsigned)h->Nt);
@@ -2148,36 +2213,39 @@ int gphip_loglik_grad(gphip_handle h, const double* theta, int p, double* out, d
     // (the gradient reductions keep (d + 1) point tiles -- general form: 4 d + 1 -- in LDS up to KB_LDS_MAXD dimensions; beyond,
     //  launch_grad reads the points from global memory in windows of 32 length-scale derivatives)
     double parts[2] = {0, 0};
-    h->want_w = true;                          // (a multi-device handle factors on its first device: the K^-1 contraction needs the whole factor)
-    int rc = eval_batch_local(h, theta, 1, p, out, parts, info);
-    h->want_w = false;
-    if (rc) return rc;
-    for (int i = 0; i < p; ++i) grad[i] = std::nan("");
-    if (*info != 0) return GPHIP_OK;
     HIPCHK(hipSetDevice(h->device));
     const int64_t N = h->N, Npad = h->Npad, d = h->d;
-    if (!h->dAlpha) HIPCHK(hipMalloc(&h->dAlpha, (size_t)Npad * h->es));
-    // general form: both terms' length scales, sf, alpha, c, sn; run-time compiled function: its ncp parameters, sn
-    const size_t ngacc = std::max((size_t)2 * d + 6, (size_t)h->ncp + 1);
-    if (!h->dGacc) HIPCHK(hipMalloc(&h->dGacc, ngacc * 8));
+    int rc = GPHIP_OK;
     // potri route when U (Npad x Npad scratch) and the lower tiles of K^-1 both fit in a quarter of the HBM
     // that is free right now; otherwise K^-1 is streamed in row blocks through forward + backward substitution
     bool potri = h->grad_potri != 0;
-    if (potri && !(h->dKinv && h->vcap >= Npad)) {
+    if (potri && !(h->dKinv && h->vcap >= Npad + GRAD_LD_PAD)) {
         size_t fr = 0, tot = 0;
         HIPCHK(hipMemGetInfo(&fr, &tot));
-        const size_t need = (size_t)(h->dKinv ? 1 : 2) * Npad * Npad * h->es;
+        const size_t need = (size_t)(h->dKinv ? 1 : 2) * (Npad + GRAD_LD_PAD) * Npad * h->es;
         potri = need <= fr / 4;
     }
     if (potri) {
-        rc = ensure_vbuf(h, Npad);
-        if (rc == GPHIP_OK && !h->dKinv && hipMalloc(&h->dKinv, (size_t)Npad * Npad * h->es) != hipSuccess) {
+        rc = ensure_vbuf(h, Npad + GRAD_LD_PAD);
+        if (rc == GPHIP_OK && !h->dKinv && hipMalloc(&h->dKinv, (size_t)(Npad + GRAD_LD_PAD) * Npad * h->es) != hipSuccess) {
             (void)hipGetLastError();
             h->dKinv = nullptr;
             potri = false;
         }
         if (rc != GPHIP_OK) { (void)hipGetLastError(); potri = false; }
     }
+    h->want_w = true;                          // (a multi-device handle factors on its first device: the K^-1 contraction needs the whole factor)
+    h->want_u = potri && h->grad_df_inverse;   // a single-launch factorisation goes on to U = L^-T in dV (launch_dataflow_inverse)
+    h->u_ready = false;
+    rc = eval_batch_local(h, theta, 1, p, out, parts, info);
+    h->want_w = h->want_u = false;
+    if (rc) { h->u_ready = false; return rc; }
+    for (int i = 0; i < p; ++i) grad[i] = std::nan("");
+    if (*info != 0) { h->u_ready = false; return GPHIP_OK; }
+    if (!h->dAlpha) HIPCHK(hipMalloc(&h->dAlpha, (size_t)Npad * h->es));
+    // general form: both terms' length scales, sf, alpha, c, sn; run-time compiled function: its ncp parameters, sn
+    const size_t ngacc = std::max((size_t)2 * d + 6, (size_t)h->ncp + 1);
+    if (!h->dGacc) HIPCHK(hipMalloc(&h->dGacc, ngacc * 8));
     int64_t MC = 0;
     if (!potri) {
         // rows of K^-1 per pass: as many as keep the scratch block within ~8 GiB (each pass runs a forward and a
@@ -2194,7 +2262,7 @@ int gphip_loglik_grad(gphip_handle h, const double* theta, int p, double* out, d
         if (rc) return rc;
     }
     h->cs = h->stream;
-    rc = DISPATCH(h, queue_alpha, h);
+    rc = (potri && h->u_ready) ? DISPATCH(h, queue_alpha_from_u, h) : DISPATCH(h, queue_alpha, h);
     if (rc) return rc;
     HIPCHK(hipMemsetAsync(h->dGacc, 0, ngacc * 8, h->stream));
     if (potri) {
@@ -3141,7 +3209,7 @@ int* option_slot(gphip_ctx* h, const char* name) {
         {"dataflow_max_slots", &gphip_ctx::dataflow_max_slots}, {"dataflow_fine_nt", &gphip_ctx::dataflow_fine_nt},
         {"dataflow_tail", &gphip_ctx::dataflow_tail}, {"dataflow_lds_kib", &gphip_ctx::dataflow_lds_kib},
         {"dataflow_park", &gphip_ctx::dataflow_park}, {"dataflow_occ3", &gphip_ctx::dataflow_occ3},
-        {"fused_eval", &gphip_ctx::fuse_option}, {"panel_df", &gphip_ctx::panel_df}, {"grad_potri", &gphip_ctx::grad_potri},
+        {"fused_eval", &gphip_ctx::fuse_option}, {"panel_df", &gphip_ctx::panel_df}, {"grad_potri", &gphip_ctx::grad_potri}, {"grad_df_inverse", &gphip_ctx::grad_df_inverse},
         {"kbuild_mfma", &gphip_ctx::kbuild_mfma}, {"kbuild_mfma_bound", &gphip_ctx::kbuild_mfma_bound},
         {"custom_grad", &gphip_ctx::custom_grad}, {"grad_analytic", &gphip_ctx::grad_analytic},
         {"max_slots", &gphip_ctx::max_slots}, {"shard_min_n", &gphip_ctx::shard_min_n},

@@ -288,6 +288,9 @@ int gphip_ns_crude_weights(const double* points, const double* loglik, int64_t m
  *                  pinned host memory by its last task)
  *   "grad_potri"   0/1 gradient: form K^-1 = U U^T in one go when 2 N^2 of scratch fits (default 1), else
  *                  stream it in row blocks through forward + backward substitution
+ *   "grad_df_inverse" 0/1 (default 1): where the factorisation is ONE dataflow launch (N <= 12288 in fp64), U = L^-T for that
+ *                  contraction comes from a second launch of the same kernel whose tasks are the tiles of U, and alpha = U z
+ *                  from one pass over U -- instead of ~5 dependent launches per tile column
  *   "thin_tiles"   0/1 (default 1): the GEMM kernel skips work whose result is known or never read -- all but the first
  *                  of the 128 bordered right-hand-side rows (zero), and the strictly-upper quadrant of diagonal tiles
  *   "max_slots"    cap on concurrently resident batch matrices

@@ -625,14 +625,44 @@ def test_loglik_gradient_matches_oracle(kernel, d, n, mean):
         th = np.append(th, 0.2)
     h = _lib.Handle(X, y, kernel, mean)
     want = orc.log_likelihood_grad(kernel, th, X, y, mean)
-    for potri in (1, 0):          # K^-1 = U U^T in one go (potri) / streamed through forward + backward substitution
+    # K^-1 = U U^T in one go (potri) with U = L^-T from the dataflow kernel's inverse launch / from the multi-kernel forward
+    # pass; or streamed through forward + backward substitution
+    for potri, inverse in ((1, 1), (1, 0), (0, 0)):
         h.set_option("grad_potri", potri)
+        h.set_option("grad_df_inverse", inverse)
         ll, grad, info = h.loglik_grad(th)
         assert info == 0 and close(ll, orc.log_likelihood(kernel, th, X, y, mean), n)
         np.testing.assert_allclose(grad, want, rtol=1e-7, atol=1e-7 * np.abs(want).max())
     mu, var = h.predict(X[:3])                            # the factor stays resident after the gradient
     mo, so = orc.predict_internal(kernel, th, X, y, X[:3], mean)
     np.testing.assert_allclose(mu, mo, rtol=1e-7, atol=1e-9)
+    h.close()
+
+
+@pytest.mark.parametrize("n,d,dtype", [(7300, 4, 64), (3000, 3, 32), (5000, 3, 32), (1100, 2, 64)])
+def test_gradient_inverse_launch_equals_forward_pass(n, d, dtype):
+    """U = L^-T as tasks of the single-launch dataflow kernel (launch_dataflow_inverse: 64-tiles two / three workgroups per CU,
+    fp32 128-tiles in both pipeline depths) against the multi-kernel forward substitution over the identity -- the same U up to
+    rounding, so the gradients agree far inside the oracle tolerance; and the inverse route is a handful of launches."""
+    X, y = syn.make_dataset(n, d)
+    kernel = "se_ard"
+    th = syn.default_theta(kernel, d, dtype="f32" if dtype == 32 else "f64")
+    h = _lib.Handle(X, y, kernel, dtype=dtype)
+    out = {}
+    for inverse in (1, 0):
+        h.set_option("grad_df_inverse", inverse)
+        ll, grad, info = h.loglik_grad(th)
+        assert info == 0
+        out[inverse] = (ll, grad)
+        h.set_option("profile", 2); h.reset_profile(); h.loglik_grad(th)
+        out[("launches", inverse)] = sum(int(v["launches"]) for v in h.profile().values())
+        h.set_option("profile", 0)
+    tol = 1e-9 if dtype == 64 else 2e-3
+    assert out[1][0] == out[0][0]
+    np.testing.assert_allclose(out[1][1], out[0][1], rtol=tol, atol=tol * np.abs(out[0][1]).max())
+    assert out[("launches", 1)] <= 8 < out[("launches", 0)], out
+    mu, var = h.predict(X[:3])                            # the factor (and its 128-block inverses) stays usable
+    assert np.all(np.isfinite(mu)) and np.all(var > 0)
     h.close()
 
 
