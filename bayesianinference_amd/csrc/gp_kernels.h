@@ -1999,6 +1999,10 @@ struct DfArgs {
                                               // (E - sum_{k=rb}^{cb-1} U(rb,k) L(cb,k)^T) W_cb^T.  Tasks in column order (cb, then
                                               // rb), nd (nd + 1) / 2 of them, one slot; the flag matrix serves U's own hand-overs
                                               // (ready(rb,cb) at rb * (nd + 1) + cb, a fresh epoch).  null: the factorisation
+    int u_rows;                               // > 0: FORWARD launch -- U is a dense block of u_rows row blocks x nd column blocks that holds
+                                              // right-hand sides as ROWS (test-point covariances k*^T); every task turns one tile into
+                                              // the same tile of U L^-T: U(rb,cb) = (U(rb,cb) - sum_{k<cb} U(rb,k) L(cb,k)^T) W_cb^T,
+                                              // in place.  Tasks in column order, u_rows * nd of them; needs u_rows <= nd + 1
     long long* trace;                         // developer timing (scripts/micro/df_trace.hip): 8 stamps per task, or null
     // BUILD variant only (one launch per evaluation: tiles built in-kernel, results exported by the corner task)
     const T* xt; const T* yv;                 // unscaled inputs [d][npad], outputs [npad]
@@ -2121,7 +2125,10 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g, Th
 #define GP_DF_PRIO 3
 #endif
     const bool inverse = g.U != nullptr;
-    if (inverse) {                                          // task q -> (rb, cb), rb <= cb, column cb first: q = cb (cb + 1) / 2 + rb
+    if (inverse && g.u_rows > 0) {                          // forward launch: q = cb * u_rows + rb
+        i = __builtin_amdgcn_readfirstlane(q / g.u_rows);
+        j = __builtin_amdgcn_readfirstlane(q % g.u_rows);
+    } else if (inverse) {                                   // task q -> (rb, cb), rb <= cb, column cb first: q = cb (cb + 1) / 2 + rb
         int cb = (int)((sqrt(8.0 * (double)q + 1.0) - 1.0) * 0.5);
         while ((long)(cb + 1) * (cb + 2) / 2 <= q) ++cb;
         while (cb > 0 && (long)cb * (cb + 1) / 2 > q) --cb;
@@ -2167,7 +2174,7 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g, Th
         else return base + tile_index(gi >> 1, gj >> 1, g.R128) * TS + (long)(gj & 1) * 64 * TB + (gi & 1) * 64;
     };
     constexpr long LDA = TB;
-    T* Ct = tptr(i, j);                                    // tile (i,j)
+    T* Ct = tptr(i, (inverse && j > i) ? i : j);           // tile (i,j)  (a forward launch's row block index is not a tile column)
     // per-slot scalars {sf2, sn2, mu, pivot tol, ..}: from the argument pack (BUILD) or from device memory
     const double* sp = BUILD ? tp.v + g.nslots * g.d + slot * SLOTP : g.slotp + (long)slot * SLOTP;
     // task (0,0) of the slot precedes every potrf of the slot.  WRITE-THROUGH: no publish of this kernel flushes plain stores any
@@ -2430,11 +2437,15 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g, Th
     if (inverse) {
         // ---- a tile of U = L^-T.  Row block rb of U advances one column block per task: the k-th slab needs U(rb,k), i.e. the
         // task before this one in the row -- a chain of nd - rb hops per row, nd rows side by side.
-        const int cb = i, rb = j, nsl = cb - rb;
+        // Forward launch (u_rows > 0): the same recurrence on a dense block of right-hand-side rows, from column 0, starting
+        // from the tile's own content instead of the identity.
+        const bool fwd = g.u_rows > 0;
+        const int cb = i, rb = j, kf = fwd ? 0 : rb, nsl = cb - kf;          // slabs k = kf .. cb - 1
         T* Ut = g.U + (long)cb * TBX * g.ldu + (long)rb * TBX;
         const T* Urow = g.U + (long)rb * TBX;               // U(rb rows, column c) at Urow[r + c * ldu]
-        zero_c(acc);
-        if (nsl == 0) {
+        if (fwd) load_c(acc, Ut, g.ldu);
+        else zero_c(acc);
+        if (!fwd && nsl == 0) {
 #pragma unroll
             for (int x = 0; x < FJ; ++x)
 #pragma unroll
@@ -2450,7 +2461,7 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g, Th
                 for (int c0 = 0; c0 < nsl; c0 += 64) {
                     const int c = c0 + lane;
                     const bool ready = c < nsl &&
-                        __hip_atomic_load(F + rb * R + rb + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == g.epoch;
+                        __hip_atomic_load(F + rb * R + kf + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == g.epoch;
                     const unsigned long long miss = ~__ballot(ready);
                     const int lead = miss ? __builtin_ctzll(miss) : 64;
                     run += lead;
@@ -2465,16 +2476,16 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g, Th
         int b0 = 0;
         if constexpr (TBX == 64) {
             if (known > 0) {
-                run_k_impl(std::integral_constant<int, 2>{}, acc, Urow + (long)rb * TBX * g.ldu, g.ldu, nullptr, LDA, known * SPB, true, rb, cb);
+                run_k_impl(std::integral_constant<int, 2>{}, acc, Urow + (long)kf * TBX * g.ldu, g.ldu, nullptr, LDA, known * SPB, true, kf, cb);
                 b0 = known;
             }
         }
         for (int b = b0; b < nsl; ++b) {
             if (b >= known) {
-                if (wave == 0) df_wait(F + rb * R + rb + b, g.epoch, g.abort_flag);
+                if (wave == 0) df_wait(F + rb * R + kf + b, g.epoch, g.abort_flag);
                 __syncthreads();
             }
-            run_k(acc, Urow + (long)(rb + b) * TBX * g.ldu, g.ldu, tptr(cb, rb + b), LDA, SPB, true);
+            run_k(acc, Urow + (long)(kf + b) * TBX * g.ldu, g.ldu, tptr(cb, kf + b), LDA, SPB, true);
         }
         store_c(acc, Ut, g.ldu);                            // the pre-solve tile becomes an MFMA operand through memory
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

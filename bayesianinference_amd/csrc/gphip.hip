@@ -85,7 +85,7 @@ struct gphip_ctx {
     int fuse_b = -1;                             // launch_gemm: request (tile to factor) ...
     bool fuse_done = false;                      // ... and answer (the launch took it)
     int dataflow_occ3 = -1;                      // 64-tile kernel built for three workgroups per CU: -1 auto (>= 8 000 tasks), 0 never, 1 always
-    int dataflow_park = 1;                       // 64-tile dataflow, two workgroups per CU: park the neighbour of a chain task
+    static constexpr int dataflow_park = 1;      // 64-tile dataflow, two workgroups per CU: park the neighbour of a chain task (round 5 retune: never worse)
     int dataflow_lds_kib = -1;                   // LDS request of the 64-tile dataflow kernel (> 80: ONE workgroup per CU); -1 auto, 0 off
     bool own_streams = true;
     int dist_rank = 0, dist_world = 0;  // > 0 between gphip_dist_begin and gphip_dist_end
@@ -115,6 +115,9 @@ struct gphip_ctx {
     // batch workspace
     int slots = 0;
     void *dA = nullptr, *dXs = nullptr, *dW = nullptr;      // typed
+    void* dW64 = nullptr;                                   // typed [2 Nt][64 x 64]: the 64-block inverses of a single-launch factorisation
+                                                            // whose caller substitutes afterwards (fit, gradient); dW then takes the 128-blocks
+    unsigned long w64_gen = ~0ul;                           // ws_gen of the factor dW64 belongs to
     double *dInvEll = nullptr, *dSlotp = nullptr, *dPartial = nullptr, *dRes = nullptr;
     int* dInfo = nullptr;
     double *hInvEll = nullptr, *hSlotp = nullptr, *hRes = nullptr;
@@ -130,8 +133,10 @@ struct gphip_ctx {
     int dataflow_fine_nt = 96;                   // ... with 64x64 tiles up to this many 128-tiles (fp64; measured best up to N = 12288)
     int panel_left = -1;                         // in-panel updates left-looking: -1 auto (batches), 0 never, 1 always
     int fuse_option = 1;                         // allow the single-launch evaluation (option "fused_eval")
-    int grad_potri = 1;                          // gradient: K^-1 = U U^T in one go when the memory is there
-    int grad_df_inverse = 1;                     // ... with U = L^-T from the dataflow kernel's inverse launch where the factor came from one launch
+    int grad_potri = 1;                          // gradient: K^-1 = U U^T in one go when the memory is there (1: U = L^-T from the dataflow kernel's
+                                                 // inverse launch where the factor came from one launch; 2: always from the multi-kernel forward pass)
+    int predict_df = 2048;                       // prediction after a single-launch fit: forward substitution as ONE dataflow launch up to this many (padded) test points
+                                                 // (twice that up to N = 8192); 0 = never
     int panel_wide = 1;                          // wider outer panels while the trailing matrix is large (queue_factor)
     int thin_tiles = 1;                          // gemm_nt: skip the zero rows of the rhs block-row and the unread upper quadrant of diagonal tiles
     int debug_fail_alloc = 0;                    // tests: make the n-th device allocation of the next slot (re)allocation fail
@@ -299,7 +304,8 @@ void harvest(gphip_ctx* h) {   // call after stream sync
 void free_slots(gphip_ctx* h) {
     (void)hipFree(h->dA); (void)hipFree(h->dXs); (void)hipFree(h->dInvEll); (void)hipFree(h->dSlotp);
     (void)hipFree(h->dW); (void)hipFree(h->dPartial); (void)hipFree(h->dRes); (void)hipFree(h->dInfo);
-    (void)hipFree(h->dFlags); (void)hipFree(h->dTicket);
+    (void)hipFree(h->dFlags); (void)hipFree(h->dTicket); (void)hipFree(h->dW64);
+    h->dW64 = nullptr; h->w64_gen = ~0ul;
     (void)hipFree(h->dPwMean); (void)hipFree(h->dPwNug);
     h->dPwMean = h->dPwNug = nullptr; h->pw_cap = 0;
     (void)hipFree(h->dXs2); (void)hipFree(h->dInvEll2); (void)hipHostFree(h->hInvEll2);
@@ -739,8 +745,9 @@ bool panel_df_on(const gphip_ctx* h, int nslots) {
 }
 
 bool use_dataflow(const gphip_ctx* h, int nslots) {
-    // (a gradient call prefers the single launch where it is allowed at all: its inverse launch follows, launch_dataflow_inverse)
-    if (panel_df_on(h, nslots) && !(h->want_u && h->Nt <= h->dataflow_max_nt)) return false;
+    // (a fit or a gradient call prefers the single launch where it is allowed at all: its 64-block inverses serve the forward /
+    //  inverse launches that follow, launch_dataflow_inverse)
+    if (panel_df_on(h, nslots) && !((h->want_u || h->want_w) && h->Nt <= h->dataflow_max_nt)) return false;
     // measured: wins 1.05-2.3x for one theta up to N = 12288, ties at 8-16 slots, loses 2x at 200 slots
     // (there the multi-kernel schedule's big launches are throughput bound, not latency bound)
     if (!h->dataflow || h->dist_world > 0 || h->Nt > h->dataflow_max_nt) return false;
@@ -770,6 +777,14 @@ void launch_dataflow(gphip_ctx* h, int nslots, int c0 = 0, double* part = nullpt
     g.A = (T*)(h->ws_override ? h->ws_override : h->dA); g.bstride = h->slot_elems; g.R128 = (int)h->R; g.c0 = c0;
     g.ncols = (ncols > 0 && ncols < R) ? ncols : 0;
     g.W = (T*)h->dW + (long)c0 * TBX * TBX; g.w_bstride = (long)h->Nt * TB * TB;
+    if constexpr (TBX == 64) {
+        // the whole factor in one launch for a caller that substitutes afterwards: the 64-block inverses get a buffer of their
+        // own (the 128-blocks rebuilt from L go to dW), so that the inverse / forward launches of this kernel find them later
+        if (h->want_w && nslots == 1 && c0 == 0 && g.ncols == 0 && nprev == 0) {
+            if (!h->dW64 && hipMalloc(&h->dW64, (size_t)h->Nt * TB * TB * sizeof(T)) != hipSuccess) { (void)hipGetLastError(); h->dW64 = nullptr; }
+            if (h->dW64) { g.W = (T*)h->dW64; h->w64_gen = h->ws_gen; }
+        }
+    }
     g.partial = h->dPartial + c0; g.p_bstride = h->Npad / TBX;
     if (part) { g.partial = part; g.p_bstride = pstride; }       // (a 64-tile tail keeps its own list of blocks)
     g.info = h->dInfo; g.slotp = h->dSlotp;
@@ -814,14 +829,18 @@ void launch_dataflow(gphip_ctx* h, int nslots, int c0 = 0, double* part = nullpt
 // Column-major U / K^-1 of the inverse-launch route use a leading dimension that is NOT a multiple of a large power of two
 // (Npad + 16 elements): with ld = Npad = 8192 doubles every k-column of an operand tile starts 64 KiB after the previous one
 constexpr int64_t GRAD_LD_PAD = 16;
+// fwd_rows > 0: the FORWARD launch instead -- dV holds fwd_rows right-hand sides as rows (leading dimension fwd_rows), every
+// task turns one tile of them into the same tile of V L^-T (DfArgs::u_rows): the forward substitution of a prediction with
+// few test points as ONE launch whose chain is a handful of microseconds per 64 columns, not two launches per tile column.
 template <typename T, int TBX, int OCC = 2, int NST = 2>
-void launch_dataflow_inverse(gphip_ctx* h) {
+void launch_dataflow_inverse(gphip_ctx* h, int64_t fwd_rows = 0) {
     const int nd = (int)(h->Npad / TBX);
-    const long tasks = (long)nd * (nd + 1) / 2;
-    (void)hipMemsetAsync(h->dKinv, 0, (size_t)(h->Npad + GRAD_LD_PAD) * h->Npad * sizeof(T), h->stream);      // (dV stays free for the alpha solve)
+    const long tasks = fwd_rows > 0 ? (long)(fwd_rows / TBX) * nd : (long)nd * (nd + 1) / 2;
+    if (fwd_rows == 0)
+        (void)hipMemsetAsync(h->dKinv, 0, (size_t)(h->Npad + GRAD_LD_PAD) * h->Npad * sizeof(T), h->stream);      // (dV stays free for the alpha solve)
     DfArgs<T> g{};
     g.A = (T*)h->dA; g.bstride = h->slot_elems; g.R128 = (int)h->R; g.c0 = 0;
-    g.W = (T*)h->dW; g.w_bstride = (long)h->Nt * TB * TB;
+    g.W = (T*)((TBX == 64 && h->dW64 && h->w64_gen == h->ws_gen) ? h->dW64 : h->dW); g.w_bstride = (long)h->Nt * TB * TB;
     g.partial = h->dPartial; g.p_bstride = h->Npad / TBX;
     g.info = h->dInfo; g.slotp = h->dSlotp;
     g.flags = h->dFlags; g.f_bstride = (long)(2 * h->Nt + 1) * (2 * h->Nt + 1);
@@ -829,12 +848,22 @@ void launch_dataflow_inverse(gphip_ctx* h) {
     g.abort_flag = reinterpret_cast<int*>(h->dTicket + 1);
     g.nd = nd; g.nslots = 1; g.epoch = ++h->epoch;
     g.U = (T*)h->dKinv; g.ldu = (long)(h->Npad + GRAD_LD_PAD);
+    if (fwd_rows > 0) { g.U = (T*)h->dV; g.ldu = (long)fwd_rows; g.u_rows = (int)(fwd_rows / TBX); }
     h->ticket_base += (unsigned long long)tasks;
-    ProfScope ps(h, 2, ((double)h->Npad * h->Npad * h->Npad) / 3.0, 0.0);
+    ProfScope ps(h, 2, fwd_rows > 0 ? (double)fwd_rows * h->Npad * h->Npad : ((double)h->Npad * h->Npad * h->Npad) / 3.0, 0.0);
     const size_t lds = df_lds_bytes<T, TBX, NST>();
     ThetaPack tp;
     hipLaunchKernelGGL((chol_dataflow_kernel<T, TBX, OCC, NST, false>), dim3((unsigned)tasks), dim3(256), lds, h->stream, g, tp);
-    h->u_ready = true;
+    if (fwd_rows == 0) h->u_ready = true;
+}
+
+// a prediction of few test points against a factor that came from the 64-tile single launch (its 64-block inverses are still
+// there): the forward substitution as one dataflow launch.  Measured against the multi-kernel substitution
+// (scripts/gpu_predict_df_sweep.py, profiles/r05_predict_df_sweep.txt): 100 test points 3.1x faster at N = 2048-12288, 2048
+// points 1.3-2x, 4096 points 1.1-1.3x up to N = 8192 and a tie at 12288, 8192 points 15-20 % slower
+bool df_forward_ok(const gphip_ctx* h, int64_t mpad) {
+    return h->dataflow && h->predict_df > 0 && h->dtype == 64 && h->dist_world == 0 && h->dW64 && h->w64_gen == h->ws_gen &&
+           h->w64_gen == h->fit_gen && mpad <= (h->Npad <= 8192 ? 2 : 1) * (int64_t)h->predict_df && mpad / 64 <= h->Npad / 64;
 }
 
 template <typename T>
@@ -2235,7 +2264,7 @@ int gphip_loglik_grad(gphip_handle h, const double* theta, int p, double* out, d
         if (rc != GPHIP_OK) { (void)hipGetLastError(); potri = false; }
     }
     h->want_w = true;                          // (a multi-device handle factors on its first device: the K^-1 contraction needs the whole factor)
-    h->want_u = potri && h->grad_df_inverse;   // a single-launch factorisation goes on to U = L^-T in dV (launch_dataflow_inverse)
+    h->want_u = potri && h->grad_potri == 1;   // a single-launch factorisation goes on to U = L^-T in dV (launch_dataflow_inverse)
     h->u_ready = false;
     rc = eval_batch_local(h, theta, 1, p, out, parts, info);
     h->want_w = h->want_u = false;
@@ -2580,7 +2609,8 @@ static int predict_local(gphip_handle h, const void* Xs, int64_t M, double* mean
         rc = upload_pw_test(h, 0, 1, m0, mc, mpad);
         if (rc) return rc;
         DISPATCH(h, queue_cross, h, mc, mpad, 1);
-        DISPATCH(h, queue_forward_rows, h, mpad, 1);
+        if (df_forward_ok(h, mpad)) launch_dataflow_inverse<double, 64>(h, mpad);
+        else DISPATCH(h, queue_forward_rows, h, mpad, 1);
         DISPATCH(h, queue_predict_reduce, h, mc, mpad, 1);
         HIPCHK(hipMemcpyAsync(mean + m0, h->dMean, (size_t)mc * 8, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipMemcpyAsync(var + m0, h->dVar, (size_t)mc * 8, hipMemcpyDeviceToHost, h->stream));
@@ -3208,8 +3238,8 @@ int* option_slot(gphip_ctx* h, const char* name) {
         {"dataflow", &gphip_ctx::dataflow}, {"dataflow_max_nt", &gphip_ctx::dataflow_max_nt},
         {"dataflow_max_slots", &gphip_ctx::dataflow_max_slots}, {"dataflow_fine_nt", &gphip_ctx::dataflow_fine_nt},
         {"dataflow_tail", &gphip_ctx::dataflow_tail}, {"dataflow_lds_kib", &gphip_ctx::dataflow_lds_kib},
-        {"dataflow_park", &gphip_ctx::dataflow_park}, {"dataflow_occ3", &gphip_ctx::dataflow_occ3},
-        {"fused_eval", &gphip_ctx::fuse_option}, {"panel_df", &gphip_ctx::panel_df}, {"grad_potri", &gphip_ctx::grad_potri}, {"grad_df_inverse", &gphip_ctx::grad_df_inverse},
+        {"dataflow_occ3", &gphip_ctx::dataflow_occ3},
+        {"fused_eval", &gphip_ctx::fuse_option}, {"panel_df", &gphip_ctx::panel_df}, {"grad_potri", &gphip_ctx::grad_potri}, {"predict_df", &gphip_ctx::predict_df},
         {"kbuild_mfma", &gphip_ctx::kbuild_mfma}, {"kbuild_mfma_bound", &gphip_ctx::kbuild_mfma_bound},
         {"custom_grad", &gphip_ctx::custom_grad}, {"grad_analytic", &gphip_ctx::grad_analytic},
         {"max_slots", &gphip_ctx::max_slots}, {"shard_min_n", &gphip_ctx::shard_min_n},

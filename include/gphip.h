@@ -281,16 +281,17 @@ int gphip_ns_crude_weights(const double* points, const double* loglik, int64_t m
  *                  it (no separate potrf128 launch, which waits 100-250 us for a CU slot under the trailing update): N = 16384 -3 %
  *   "dataflow_occ3" -1 auto (default) / 0 / 1: the 64-tile dataflow kernel in its three-workgroups-per-CU build (166 registers);
  *                  auto = launches of >= 6 000 tile tasks, which are throughput bound (N = 12288: -6.5 %)
- *   "dataflow_park" 0/1 (default 1): 64-tile dataflow launches with two workgroups per CU -- the workgroup sharing a CU with a
- *                  diagonal (chain) task sleeps while that task is in its critical section (N = 6144: -9 %, 8192: -1 %)
  *   "fused_eval"   0/1 (default 1): a pure likelihood call of <= 8 thetas that qualifies for 64-tile dataflow
  *                  runs as ONE kernel launch (K(theta) tiles built inside the kernel, results written to
  *                  pinned host memory by its last task)
  *   "grad_potri"   0/1 gradient: form K^-1 = U U^T in one go when 2 N^2 of scratch fits (default 1), else
  *                  stream it in row blocks through forward + backward substitution
- *   "grad_df_inverse" 0/1 (default 1): where the factorisation is ONE dataflow launch (N <= 12288 in fp64), U = L^-T for that
- *                  contraction comes from a second launch of the same kernel whose tasks are the tiles of U, and alpha = U z
- *                  from one pass over U -- instead of ~5 dependent launches per tile column
+ *                  (1: where the factorisation is ONE dataflow launch -- N <= 12288 in fp64 -- U = L^-T for that contraction
+ *                  comes from a second launch of the same kernel whose tasks are the tiles of U, and alpha = U z from one pass
+ *                  over U, instead of ~5 dependent launches per tile column; 2: U always from the multi-kernel forward pass)
+ *   "predict_df"   (default 2048; 0 = off): gphip_predict after a fit that was ONE dataflow launch runs the forward substitution
+ *                  L^-1 k* of up to this many test points (twice that up to N = 8192) as one launch of the same kernel
+ *                  (tasks = 64 x 64 tiles of the right-hand-side rows) instead of two launches per tile column
  *   "thin_tiles"   0/1 (default 1): the GEMM kernel skips work whose result is known or never read -- all but the first
  *                  of the 128 bordered right-hand-side rows (zero), and the strictly-upper quadrant of diagonal tiles
  *   "max_slots"    cap on concurrently resident batch matrices

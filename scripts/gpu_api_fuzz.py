@@ -56,7 +56,7 @@ while time.time() < t_end:
         if op == "option":
             name = str(rng.choice(["panel", "dataflow", "lookahead", "thin_tiles", "fused_eval", "dataflow_fine_nt", "panel_wide",
                                    "dataflow_tail", "grad_potri", "max_slots", "latency_gemm", "shard_min_n", "panel_left",
-                                   "replicate_factor", "share_local_panels", "debug_fail_alloc", "supertile", "dataflow_park", "dataflow_lds_kib", "fuse_potrf", "bcast_chunks",
+                                   "replicate_factor", "share_local_panels", "debug_fail_alloc", "supertile", "dataflow_lds_kib", "fuse_potrf", "bcast_chunks",
                                    "dist_panel_df", "bcast_two_hop", "panel_df", "kbuild_mfma", "kbuild_mfma_bound", "custom_grad"]))
             if name == "debug_fail_alloc" and rng.random() < 0.7:
                 name = "panel"

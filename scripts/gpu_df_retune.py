@@ -19,9 +19,8 @@ if mode == "occ":
         h = _lib.Handle(X, y, "se_ard")
         row = [f"N={n:5d}"]
         for name, o in (("auto", {"dataflow_lds_kib": -1, "dataflow_occ3": -1}), ("1/CU", {"dataflow_lds_kib": 84, "dataflow_occ3": 0}),
-                        ("2/CU", {"dataflow_lds_kib": 0, "dataflow_occ3": 0}), ("2/CU nopark", {"dataflow_lds_kib": 0, "dataflow_occ3": 0, "dataflow_park": 0}),
+                        ("2/CU", {"dataflow_lds_kib": 0, "dataflow_occ3": 0}),
                         ("3/CU", {"dataflow_lds_kib": 0, "dataflow_occ3": 1})):
-            h.set_option("dataflow_park", 1)
             for k, v in o.items():
                 h.set_option(k, v)
             row.append(f"{name}: {t(h, th, 20 if n <= 6144 else 10):6.3f}")

@@ -22,7 +22,6 @@ while time.time() < t_end:
     ref, iref = h.loglik_batch(Th)
     h.set_option("dataflow", 1)
     h.set_option("dataflow_lds_kib", int(rng.choice([-1, -1, 0, 84])))      # occupancy rule: auto / two per CU / one per CU
-    h.set_option("dataflow_park", int(rng.choice([1, 1, 0])))
     h.set_option("dataflow_occ3", int(rng.choice([-1, -1, 0, 1])))          # three-per-CU build: auto / never / always
     first = None
     for rep in range(int(rng.integers(3, 12))):

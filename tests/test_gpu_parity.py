@@ -627,9 +627,8 @@ def test_loglik_gradient_matches_oracle(kernel, d, n, mean):
     want = orc.log_likelihood_grad(kernel, th, X, y, mean)
     # K^-1 = U U^T in one go (potri) with U = L^-T from the dataflow kernel's inverse launch / from the multi-kernel forward
     # pass; or streamed through forward + backward substitution
-    for potri, inverse in ((1, 1), (1, 0), (0, 0)):
+    for potri in (1, 2, 0):
         h.set_option("grad_potri", potri)
-        h.set_option("grad_df_inverse", inverse)
         ll, grad, info = h.loglik_grad(th)
         assert info == 0 and close(ll, orc.log_likelihood(kernel, th, X, y, mean), n)
         np.testing.assert_allclose(grad, want, rtol=1e-7, atol=1e-7 * np.abs(want).max())
@@ -650,7 +649,7 @@ def test_gradient_inverse_launch_equals_forward_pass(n, d, dtype):
     h = _lib.Handle(X, y, kernel, dtype=dtype)
     out = {}
     for inverse in (1, 0):
-        h.set_option("grad_df_inverse", inverse)
+        h.set_option("grad_potri", 1 if inverse else 2)
         ll, grad, info = h.loglik_grad(th)
         assert info == 0
         out[inverse] = (ll, grad)
@@ -663,6 +662,46 @@ def test_gradient_inverse_launch_equals_forward_pass(n, d, dtype):
     assert out[("launches", 1)] <= 8 < out[("launches", 0)], out
     mu, var = h.predict(X[:3])                            # the factor (and its 128-block inverses) stays usable
     assert np.all(np.isfinite(mu)) and np.all(var > 0)
+    h.close()
+
+
+@pytest.mark.parametrize("n,d,m", [(1900, 3, 70), (3000, 2, 1), (700, 5, 640), (9000, 4, 200), (300, 2, 500)])
+def test_prediction_forward_launch_equals_multi_kernel_substitution(n, d, m):
+    """a7: after a fit that came from the 64-tile single launch, a prediction of few test points runs its forward substitution
+    v = L^-1 k* as ONE dataflow launch (tasks = 64 x 64 tiles of the right-hand-side rows, DfArgs::u_rows) -- against the
+    multi-kernel substitution (option predict_df = 0) and, where the oracle is quick, against predictFromGaussianProcessInternal
+    (BGP:396-422).  m = 500 at n = 300 has more row blocks than the factor has columns: stays on the multi-kernel path."""
+    X, y = syn.make_dataset(n, d)
+    kernel = "matern52_ard" if d == 2 else "se_ard"
+    th = syn.default_theta(kernel, d)
+    Xs = syn.make_test_points(m, d)
+    h = _lib.Handle(X, y, kernel)
+    out = {}
+    for mode in (1, 0):
+        h.set_option("predict_df", 2048 if mode else 0)
+        assert h.fit(th) == 0
+        out[mode] = h.predict(Xs)
+        h.set_option("profile", 2); h.reset_profile(); h.predict(Xs)
+        out[("launches", mode)] = sum(int(v["launches"]) for k, v in h.profile().items() if k in ("trsm", "gemm_panel"))
+        h.set_option("profile", 0)
+    np.testing.assert_allclose(out[1][0], out[0][0], rtol=1e-9, atol=1e-10)
+    np.testing.assert_allclose(out[1][1], out[0][1], rtol=1e-9, atol=1e-11)
+    if n > m:
+        assert out[("launches", 1)] == 1 < out[("launches", 0)], out
+    else:
+        assert out[("launches", 1)] == out[("launches", 0)]
+    if n <= 3000:
+        mo, so = orc.predict_internal(kernel, th, X, y, Xs)
+        np.testing.assert_allclose(out[1][0], mo, rtol=1e-7, atol=1e-9)
+        np.testing.assert_allclose(np.sqrt(out[1][1]), so, rtol=1e-7, atol=1e-9)
+    # a likelihood call in between ends the fit's life: the next prediction needs a new fit (and gets the right inverses)
+    h.set_option("predict_df", 2048)
+    h.loglik(th * 1.1)
+    with pytest.raises(Exception):
+        h.predict(Xs)
+    assert h.fit(th) == 0
+    mu2, var2 = h.predict(Xs)
+    np.testing.assert_array_equal(mu2, out[1][0])
     h.close()
 
 
