@@ -427,6 +427,20 @@ def other_configs(local_rank: int) -> dict:
                          "cholesky_tflops_at_median": n ** 3 / 3.0 / med / 1e12,
                          "timing": "median of per-evaluation host-clock times (blocking call); ms_hip_events = device time of the "
                                    "same evaluation between HIP events on the library's stream"}
+            if n == 8192:
+                # the rows either side of the likelihood at the same size: fit + prediction of 100 test points (a7) and
+                # likelihood + gradient (f3), median of 10 blocking calls each
+                def med_ms(f, k=10):
+                    f()
+                    tt = np.empty(k)
+                    for i in range(k):
+                        t0 = time.perf_counter()
+                        f()
+                        tt[i] = time.perf_counter() - t0
+                    return float(np.median(tt)) * 1e3
+                Xs = syn.make_test_points(100, d)
+                out[name]["next_rows"] = {"fit_ms": med_ms(lambda: h.fit(th)), "predict_100_points_ms": med_ms(lambda: h.predict(Xs)),
+                                          "loglik_and_gradient_ms": med_ms(lambda: h.loglik_grad(th))}
             h.close()
     except Exception as exc:                                    # never let an extra break the headline
         out["cfg1_cfg2_error"] = repr(exc)
