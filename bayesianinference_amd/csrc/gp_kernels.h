@@ -1152,7 +1152,8 @@ __device__ __forceinline__ void potrf64_aux_init(T* __restrict__ Ls) {
 template <typename T, int NB = 8, bool WT = false>
 __device__ __forceinline__ void potrf128_core(double* __restrict__ lds_raw, T* __restrict__ Ad, long ld,
                                               T* __restrict__ Wg, double* __restrict__ logdet_out,
-                                              int* __restrict__ info_out, T tol, int* pub_flag = nullptr, int pub_epoch = 0) {
+                                              int* __restrict__ info_out, T tol, int* pub_flag = nullptr, int pub_epoch = 0,
+                                              int* chain_flag = nullptr, T* __restrict__ Dg = nullptr) {
     double* red = lds_raw;                      // 2 doubles
     constexpr int NE = 16 * NB;                 // block edge
     T* Ls = reinterpret_cast<T*>(lds_raw + 2);  // NB(NB+1)/2 tiles + dinv[NE] (+ 64-block path: NB diagonal-inverse tiles)
@@ -1356,6 +1357,21 @@ __device__ __forceinline__ void potrf128_core(double* __restrict__ lds_raw, T* _
         }
         if (tid == 0 && bad) gst<WT>(info_out, 1);
         GP_STAMP(31);
+        if (Dg) {
+            // Chain hand-over (Dg given): the next hop's sub-diagonal solve substitutes with L_jj and the four diagonal
+            // inverses only, so THOSE go out first, under their own flag; the off-diagonal blocks of W_j -- for the panel
+            // solves below, which have slack -- are computed and published behind it.
+            for (int bi = 0; bi < NB; ++bi)
+                for (int bj = 0; bj <= bi; ++bj)
+                    gst<WT>(Ad + (long)(bj * 16 + ec) * ld + bi * 16 + er, Ls[ptile(bi, bj) + tid]);
+#pragma unroll
+            for (int b = 0; b < NB; ++b) gst<WT>(Dg + b * 256 + tid, Wd[b * 256 + er * 16 + ec]);    // [col * 16 + row] out of [row][col]
+            if (chain_flag) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (tid == 0) __hip_atomic_store(chain_flag, pub_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
         GP_STAMP(32);
         tri_inverse_lds<T, NB, WT, true>(Ls, dinv, Wg, Wd);
         GP_STAMP(34);
@@ -1365,9 +1381,11 @@ __device__ __forceinline__ void potrf128_core(double* __restrict__ lds_raw, T* _
             if (tid == 0) __hip_atomic_store(pub_flag, pub_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         GP_STAMP(35);
-        for (int bi = 0; bi < NB; ++bi)
-            for (int bj = 0; bj <= bi; ++bj)
-                gst<WT>(Ad + (long)(bj * 16 + ec) * ld + bi * 16 + er, Ls[ptile(bi, bj) + tid]);
+        if (!Dg) {
+            for (int bi = 0; bi < NB; ++bi)
+                for (int bj = 0; bj <= bi; ++bj)
+                    gst<WT>(Ad + (long)(bj * 16 + ec) * ld + bi * 16 + er, Ls[ptile(bi, bj) + tid]);
+        }
         GP_STAMP(36);
         return;
     }
@@ -1395,8 +1413,8 @@ __device__ __forceinline__ void potrf128_core(double* __restrict__ lds_raw, T* _
 // the accumulator-heavy MFMA loops of that kernel (inlined, the allocator spills accumulators there).
 template <typename T, int NB, bool WT = false>
 __device__ __noinline__ void potrf128_core_call(double* lds_raw, T* Ad, long ld, T* Wg, double* logdet_out,
-                                                int* info_out, T tol, int* pub_flag, int pub_epoch) {
-    potrf128_core<T, NB, WT>(lds_raw, Ad, ld, Wg, logdet_out, info_out, tol, pub_flag, pub_epoch);
+                                                int* info_out, T tol, int* pub_flag, int pub_epoch, int* chain_flag, T* Dg) {
+    potrf128_core<T, NB, WT>(lds_raw, Ad, ld, Wg, logdet_out, info_out, tol, pub_flag, pub_epoch, chain_flag, Dg);
 }
 template <typename T>
 __global__ __launch_bounds__(256) void potrf128_kernel(T* __restrict__ Abase, long bstride, int b,
@@ -1914,7 +1932,7 @@ __global__ __launch_bounds__(64 * NWI * NWJ, (NWI * NWJ == 4) ? 2 : 4) void gemm
                 T* Ct = Cg - ((long)(wj * (16 * FJ)) * ldc + wi * (16 * FI) + (lane & 15));        // tile base
                 potrf128_core_call<T, 8>(smem_raw, Ct, ldc, g.fuse_W + ((long)slot * g.fuse_nt + g.fuse_b) * TB * TB,
                                          g.fuse_partial + (long)slot * g.fuse_nt + g.fuse_b, g.fuse_info + slot,
-                                         (T)g.fuse_slotp[(long)slot * SLOTP + 3], nullptr, 0);
+                                         (T)g.fuse_slotp[(long)slot * SLOTP + 3], nullptr, 0, nullptr, nullptr);
             }
         }
         return;
@@ -1994,6 +2012,10 @@ struct DfArgs {
                                               // first task of column nprev.  The launch applies that panel to its own columns itself.
     int* park;                                // 64-tiles, two workgroups per CU: [DF_PARK_SLOTS] counters "a chain task is in its critical
                                               // section on this CU" (index = XCC / SE / SH / CU id); the neighbour sleeps meanwhile; or null
+    T* D; long d_bstride;                     // 64-tiles: the 16x16 diagonal inverses of every 64-block, [slot][nd][4][col * 16 + row] -- with L_jj what the
+                                              // NEXT hop of the chain needs (its sub-diagonal solve is a blocked substitution), handed over under
+                                              // the chain flag (j, j+2) BEFORE the off-diagonal blocks of W_j are even computed; null: the chain
+                                              // waits for W_j like everybody else
     T* U; long ldu;                           // INVERSE launch (gradient, K^-1 = U U^T): the factor is final, every task is a tile of
                                               // U = L^-T (column-major, leading dimension ldu, pre-zeroed):  U(rb,cb), rb <= cb, =
                                               // (E - sum_{k=rb}^{cb-1} U(rb,k) L(cb,k)^T) W_cb^T.  Tasks in column order (cb, then
@@ -2070,7 +2092,8 @@ template <typename T, int TBX, int NST = 2> constexpr size_t df_lds_bytes() {
     constexpr size_t gemm = NST * (size_t)df_stage_elems<T, TBX>() * sizeof(T);
     constexpr size_t nb = TBX / 16;
     constexpr size_t potrf = 16 + (nb * (nb + 1) / 2 * 256 + TBX + (TBX == 64 ? (nb + 1) * 256 : 0)) * sizeof(T);
-    return gemm > potrf ? gemm : potrf;
+    constexpr size_t chain = TBX == 64 ? (size_t)(32 * LD64 + 1024) * sizeof(T) : 0;   // L tile image + diagonal inverses (diagx)
+    return (gemm > potrf ? gemm : potrf) > chain ? (gemm > potrf ? gemm : potrf) : chain;
 }
 
 // OCC = workgroups per CU the register budget is sized for: 2 (256 registers: 64-tiles, fp32 128-tiles) or
@@ -2420,6 +2443,10 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g, Th
 #ifndef GP_DF_LIGHT_PUBLISH
 #define GP_DF_LIGHT_PUBLISH 1
 #endif
+    // (GP_DF_WT_POTRF: potrf's L, W, log-det and info stores write-through too, so that its publishes need no fence either)
+#ifndef GP_DF_WT_POTRF
+#define GP_DF_WT_POTRF 1
+#endif
     auto publish_wt = [&](int fi_, int fj_) {
         if (GP_DF_LIGHT_PUBLISH) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else __threadfence();
@@ -2567,6 +2594,68 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g, Th
         if (diagx) {
             const int jm = j - 1;
             T* Xt = tptr(j, jm);                                           // tile (j, j-1)
+            constexpr int XIMG = 8 * LD64;
+            if (g.D && GP_DF_WT_POTRF) {
+                // X = pre L^-T by BLOCKED SUBSTITUTION with L_{j-1,j-1} and its four 16x16 diagonal inverses -- available under
+                // the chain flag (j-1, j+1), several microseconds before W_{j-1} (potrf128_core).  Wave w owns rows 16 w .. of the
+                // tile and holds the TRANSPOSED 16x16 blocks X^T(b) in the MFMA D layout (register r of lane (l15, l4) = row
+                // 16 w + l15, column 16 b + drow(l4, r)), so that
+                //     X^T(k) = W_kk S_k ;   S_b -= L(b,k) X^T(k)  (b > k)        [S_b starts as pre^T(b)]
+                // are LEFT multiplications whose right-hand operand is the previous result's registers as they are (kidx):
+                // 40 dependent-free-of-memory MFMAs per wave instead of a 64-MFMA product after the 36-MFMA block inverse.
+                const T* Lg = tptr(jm, jm);
+                const T* Dg = g.D + (long)slot * g.d_bstride + (long)jm * 1024;
+                if (wave == 0) df_wait(F + jm * R + j, g.epoch, g.abort_flag);           // pre-solve tile stored by its owner
+                __syncthreads();
+                acc_t sb[4], xb[4];
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        sb[b][r] = __hip_atomic_load(Xt + (long)(16 * b + Num<T>::drow(l4, r)) * LDA + 16 * uw + l15, __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_AGENT);
+                if (wave == 0) df_wait(F + jm * R + j + 1, g.epoch, g.abort_flag);       // chain flag of column j-1: L, diagonal inverses
+                __syncthreads();
+                enter_critical();                          // from here to ready(j,j) nothing but this workgroup's own work
+                stamp(5);
+                T* Limg = smem;                            // the 64 x 64 tile as ONE 64-column stage image; behind it the inverses
+                T* Dimg = smem + 32 * LD64;
+#pragma unroll
+                for (int s2 = 0; s2 < 8; ++s2) {
+                    const int qq = uw + 4 * s2;
+                    const long kcol = 4 * (qq >> 1) + (qq & 1) + 2 * (lane >> 5);
+                    __builtin_amdgcn_global_load_lds((glb_void*)(Lg + kcol * LDA + 2 * (lane & 31)), (lds_void*)(Limg + qq * LD64), 16, 0,
+                                                     GP_DF_DMA_AUX);
+                }
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const int q2 = uw + 4 * s2;
+                    __builtin_amdgcn_global_load_lds((glb_void*)(Dg + q2 * 128 + 2 * lane), (lds_void*)(Dimg + q2 * 128), 16, 0, GP_DF_DMA_AUX);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    xb[k] = (acc_t){0, 0, 0, 0};
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk)
+                        xb[k] = Num<T>::mfma(Dimg[k * 256 + Num<T>::kidx(kk, l4) * 16 + l15], sb[k][kk], xb[k]);
+#pragma unroll
+                    for (int b = k + 1; b < 4; ++b)
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk)
+                            sb[b] = Num<T>::mfma(-Limg[df_lds_off<T, TBX>(16 * k + Num<T>::kidx(kk, l4), 16 * b + l15)], xb[k][kk], sb[b]);
+                }
+                __syncthreads();                           // every wave is done with the L image: the X images take its place
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int c = 16 * b + Num<T>::drow(l4, r), irow = 16 * uw + l15;
+                        __hip_atomic_store(Xt + (long)c * LDA + irow, (T)xb[b][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        smem[(c >> 4) * XIMG + df_lds_off<T, TBX>(c & 15, irow)] = (T)xb[b][r];
+                    }
+            } else {
             if (wave == 0) {
                 df_wait(F + jm * R + j, g.epoch, g.abort_flag);           // pre-solve tile stored by its owner
                 df_wait(F + jm * R + jm, g.epoch, g.abort_flag);          // W_{j-1}
@@ -2579,7 +2668,6 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g, Th
             run_k(accx, Xt, LDA, g.W + (long)slot * g.w_bstride + (long)jm * TBX * TBX, TBX, SPB, false);
             store_c(accx, Xt, LDA);                        // X(j,j-1): the column below waits for it
             // X -> four 16-column LDS images [k][row] (both MFMA operands of X X^T read the same image)
-            constexpr int XIMG = 8 * LD64;
 #pragma unroll
             for (int x = 0; x < FJ; ++x)
 #pragma unroll
@@ -2589,7 +2677,12 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g, Th
                         const int c = wj * WT + x * 16 + Num<T>::drow(l4, r), irow = wi * WT + y * 16 + l15;
                         smem[(c >> 4) * XIMG + df_lds_off<T, TBX>(c & 15, irow)] = accx[x][y][r];
                     }
-            publish_wt(j, jm);                              // (its barrier also orders the LDS image)
+            }
+            // ready(j,j-1) waits until the product below is done: draining the write-through stores of X here (vmcnt(0)) would sit
+            // on the chain, and the tasks that read X(j,j-1) are not on it.  Only the LDS images must be complete now (a raw
+            // barrier: __syncthreads() would drain the stores as well).
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
             stamp(7);
 #pragma unroll
             for (int st = 0; st < TBX / 16; ++st)
@@ -2607,7 +2700,9 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g, Th
 #pragma unroll
                         for (int y = 0; y < FI; ++y) acc[x][y] = Num<T>::mfma(fj[x], fi[y], acc[x][y]);
                 }
-            __syncthreads();                                // the images make way for the potrf image
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // X(j,j-1) is at the coherent level (sc1 stores) ..
+            __syncthreads();                                // .. for every wave; and the images make way for the potrf image
+            if (tid == 0) __hip_atomic_store(F + j * R + jm, g.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             stamp(6);
         }
     }
@@ -2653,14 +2748,12 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g, Th
         if constexpr (TBX == 64) potrf64_aux_init<T>(Ls);
         __syncthreads();
         stamp(2);
-        // (GP_DF_WT_POTRF: potrf's L, W, log-det and info stores write-through too, so that this publish needs no fence either)
-#ifndef GP_DF_WT_POTRF
-#define GP_DF_WT_POTRF 1
-#endif
         // 64-tiles: the core publishes ready(j,j) itself, as soon as W_j is out and before the L tile
         int* pubf = (TBX == 64 && GP_DF_WT_POTRF) ? F + j * R + j : nullptr;
+        T* Dj = (pubf && g.D) ? g.D + (long)slot * g.d_bstride + (long)j * 1024 : nullptr;
+        int* chainf = (Dj && j + 2 <= g.nd) ? F + j * R + j + 2 : nullptr;        // (the last column has no successor on the chain)
         potrf128_core_call<T, TBX / 16, GP_DF_WT_POTRF != 0>(smem_raw, Ct, LDA, Wj, g.partial + (long)slot * g.p_bstride + j, g.info + slot,
-                                                              (T)sp[3], pubf, g.epoch);
+                                                              (T)sp[3], pubf, g.epoch, chainf, Dj);
         stamp(3);
         if (pubf) { }
         else if (GP_DF_WT_POTRF) publish_wt(j, j);

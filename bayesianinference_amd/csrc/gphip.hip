@@ -115,6 +115,7 @@ struct gphip_ctx {
     // batch workspace
     int slots = 0;
     void *dA = nullptr, *dXs = nullptr, *dW = nullptr;      // typed
+    void* dDinv = nullptr;                                  // typed [slots][2 Nt][4][16 x 16]: DfArgs::D
     void* dW64 = nullptr;                                   // typed [2 Nt][64 x 64]: the 64-block inverses of a single-launch factorisation
                                                             // whose caller substitutes afterwards (fit, gradient); dW then takes the 128-blocks
     unsigned long w64_gen = ~0ul;                           // ws_gen of the factor dW64 belongs to
@@ -304,8 +305,8 @@ void harvest(gphip_ctx* h) {   // call after stream sync
 void free_slots(gphip_ctx* h) {
     (void)hipFree(h->dA); (void)hipFree(h->dXs); (void)hipFree(h->dInvEll); (void)hipFree(h->dSlotp);
     (void)hipFree(h->dW); (void)hipFree(h->dPartial); (void)hipFree(h->dRes); (void)hipFree(h->dInfo);
-    (void)hipFree(h->dFlags); (void)hipFree(h->dTicket); (void)hipFree(h->dW64);
-    h->dW64 = nullptr; h->w64_gen = ~0ul;
+    (void)hipFree(h->dFlags); (void)hipFree(h->dTicket); (void)hipFree(h->dW64); (void)hipFree(h->dDinv);
+    h->dW64 = h->dDinv = nullptr; h->w64_gen = ~0ul;
     (void)hipFree(h->dPwMean); (void)hipFree(h->dPwNug);
     h->dPwMean = h->dPwNug = nullptr; h->pw_cap = 0;
     (void)hipFree(h->dXs2); (void)hipFree(h->dInvEll2); (void)hipHostFree(h->hInvEll2);
@@ -362,6 +363,7 @@ int ensure_slots(gphip_ctx* h, int want, bool workspace = true) {
     if (workspace) dev(&h->dA, S * (size_t)h->slot_elems * h->es, "workspace");
     dev(&h->dXs, S * h->d * h->Npad * h->es, "scaled inputs");
     dev(&h->dW, S * h->Nt * TB * TB * h->es, "block inverses");
+    dev(&h->dDinv, S * 2 * h->Nt * 1024 * h->es, "diagonal inverses of the 64-blocks");      // (64-tile dataflow chain, DfArgs::D)
     dev((void**)&h->dInvEll, S * h->d * 8, "inverse length scales");
     if (h->nl2 > 0) {                          // second term of a sum / product kernel: its own scaled copy of the inputs
         dev(&h->dXs2, S * h->d * h->Npad * h->es, "scaled inputs (term 2)");
@@ -784,6 +786,9 @@ void launch_dataflow(gphip_ctx* h, int nslots, int c0 = 0, double* part = nullpt
             if (!h->dW64 && hipMalloc(&h->dW64, (size_t)h->Nt * TB * TB * sizeof(T)) != hipSuccess) { (void)hipGetLastError(); h->dW64 = nullptr; }
             if (h->dW64) { g.W = (T*)h->dW64; h->w64_gen = h->ws_gen; }
         }
+    }
+    if constexpr (TBX == 64) {
+        g.D = (T*)h->dDinv + (long)c0 * 1024; g.d_bstride = (long)2 * h->Nt * 1024;      // chain hand-over by blocked substitution
     }
     g.partial = h->dPartial + c0; g.p_bstride = h->Npad / TBX;
     if (part) { g.partial = part; g.p_bstride = pstride; }       // (a 64-tile tail keeps its own list of blocks)

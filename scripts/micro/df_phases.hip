@@ -24,8 +24,8 @@ int main(int argc, char** argv) {
     for (int j = 0; j < n; ++j) at(n, j) = std::sin(0.01 * j);                 // the rhs row
     for (int r = 1; r < TB; ++r) at(n + r, n + r) = 1.0;
     const long ntask = (long)R * (R + 1) / 2;
-    double *dA, *dW, *dP, *dS; int *dI, *dF; unsigned long long* dT; long long *dTr, *dSt;
-    hipMalloc(&dA, A.size() * 8); hipMalloc(&dW, (size_t)Nt * TB * TB * 8); hipMalloc(&dP, nd * 8); hipMalloc(&dS, 128);
+    double *dA, *dW, *dP, *dS, *dD; int *dI, *dF; unsigned long long* dT; long long *dTr, *dSt;
+    hipMalloc(&dA, A.size() * 8); hipMalloc(&dW, (size_t)Nt * TB * TB * 8); hipMalloc(&dP, nd * 8); hipMalloc(&dS, 128); hipMalloc(&dD, (size_t)nd * 1024 * 8);
     hipMalloc(&dI, 4); hipMalloc(&dF, (size_t)R * R * 4); hipMalloc(&dT, 16); hipMalloc(&dTr, ntask * 64); hipMalloc(&dSt, ntask * 512);
     double sp[SLOTP] = {1.0, 0.1, 0.0, 1e-14};
     hipMemcpy(dS, sp, sizeof sp, hipMemcpyHostToDevice); hipMemset(dI, 0, 4); hipMemset(dF, 0, (size_t)R * R * 4); hipMemset(dT, 0, 16);
@@ -42,7 +42,7 @@ int main(int argc, char** argv) {
         g.A = dA; g.bstride = slot_elems; g.R128 = R128; g.c0 = 0; g.W = dW; g.w_bstride = (long)Nt * TB * TB; g.partial = dP;
         g.p_bstride = nd; g.info = dI; g.slotp = dS; g.flags = dF; g.f_bstride = (long)R * R; g.ticket = dT;
         g.ticket_base = (unsigned long long)rep * ntask; g.abort_flag = (int*)(dT + 1); g.nd = nd; g.nslots = 1; g.epoch = rep + 1;
-        g.trace = dTr;
+        g.trace = dTr; g.D = dD; g.d_bstride = (long)nd * 1024;
         hipLaunchKernelGGL(kern, dim3((unsigned)ntask), dim3(256), lds, 0, g, ThetaPack{});
         if (hipDeviceSynchronize() != hipSuccess) { printf("launch failed\n"); return 1; }
     }
@@ -57,7 +57,8 @@ int main(int argc, char** argv) {
         const long long* d = &tr[(size_t)off(j) * 8]; const long long* p = &tr[(size_t)off(j - 1) * 8];
         const long bp = block_of[(size_t)off(j - 1)];
         // ready(j-1,j-1) goes out INSIDE the potrf body (stamp 35 of that workgroup), before its L tile
-        const double t = (bp >= 0 && st[(size_t)bp * 64 + 35]) ? us(st[(size_t)bp * 64 + 35]) : us(p[4]);
+        // (the chain's own hand-over is earlier still: stamp 32, after the L tile + diagonal inverses and their flag)
+        const double t = (bp >= 0 && st[(size_t)bp * 64 + 32]) ? us(st[(size_t)bp * 64 + 32]) : us(p[4]);
         printf("hop diag(%d): prev pub %.1f | flags seen +%.1f | solve+store+publish +%.1f | slab +%.1f | packed +%.1f | potrf call end +%.1f\n",
                j, t, us(d[5]) - t, us(d[7]) - t, us(d[6]) - t, us(d[2]) - t, us(d[3]) - t);
         const long b = block_of[(size_t)off(j)];
@@ -67,8 +68,8 @@ int main(int argc, char** argv) {
         printf("   potrf64 phases (us): entry %.2f |", du(1, 2));
         for (int q = 0; q < 4; ++q) printf(" panel %d: upd+elim %.2f%s", q, du(2 + 3 * q, 3 + 3 * q), q < 3 ? "," : " |");
         // (round 5: the diagonal inverses come out of the elimination; order = logdet, block inverses, W store, publish, L store)
-        printf(" logdet %.2f | block inv %.2f | W store %.2f | publish %.2f | L store (behind the flag) %.2f | entry..publish %.2f   (call overhead: %.2f before, %.2f after)\n",
-               du(12, 31), du(32, 33), du(33, 34), du(34, 35), du(35, 36), du(1, 35), (s[1] - d[2]) / 100.0, (d[3] - s[36]) / 100.0);
+        printf(" L + diagonal inverses + chain flag %.2f | entry..chain flag %.2f || off the chain: block inv %.2f | W store %.2f | publish %.2f   (call overhead: %.2f before, %.2f after)\n",
+               du(12, 32), du(1, 32), du(32, 33), du(33, 34), du(34, 35), (s[1] - d[2]) / 100.0, (d[3] - s[36]) / 100.0);
     };
     for (int j : {nd / 8, nd / 4, nd / 2, nd / 2 + 1, nd / 2 + 2, nd / 2 + 3, 3 * nd / 4, nd - 3}) if (j >= 1 && j < nd) hop(j);
     long long tend = 0; for (long q = 0; q < ntask; ++q) for (int k = 0; k < 8; ++k) tend = std::max(tend, tr[(size_t)q * 8 + k]);
