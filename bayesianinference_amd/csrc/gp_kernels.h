@@ -1132,6 +1132,43 @@ __device__ __forceinline__ void tri_inverse_lds(T* __restrict__ Ls, const T* __r
         }
 }
 
+// X (the chain's freshly solved 64 x 64 sub-diagonal tile) as the dataflow kernel keeps it in LDS: four 16-column images
+// [k][row] in the 64-tile stage layout (chol_dataflow_kernel, diagx).  x64_off = df_lds_off<double, 64>.
+constexpr int X64_LD = 144, X64_IMG = 8 * X64_LD;
+__device__ __forceinline__ int x64_off(int k, int row) { return ((k >> 2) * 2 + (k & 1)) * X64_LD + ((k >> 1) & 1) * 64 + row; }
+// 16x16 block (bi, bj) of the potrf image -= X(16 bi.., :) X(16 bj.., :)^T, by ONE wave: the last slab of the diagonal tile's
+// update, block by block, so that the factorisation of block column 0 can start while other waves still apply it to the rest.
+template <typename T>
+__device__ __forceinline__ void xx_block_rmw(T* __restrict__ Ls, const T* __restrict__ Ximg, int bi, int bj, int l15, int l4, T* __restrict__ copy = nullptr) {
+    typedef typename Num<T>::acc_t acc_t;
+    T* Cb = Ls + ptile(bi, bj) + l15;
+    acc_t a;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) a[r] = Cb[Num<T>::drow(l4, r) * 16];
+#pragma unroll
+    for (int st = 0; st < 4; ++st)
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const T* Im = Ximg + st * X64_IMG + l15;
+            const int kq = 4 * kk + l4;
+            a = Num<T>::mfma(-Im[x64_off(kq, 16 * bj)], Im[x64_off(kq, 16 * bi)], a);
+        }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Cb[Num<T>::drow(l4, r) * 16] = a[r];
+    if (copy) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) copy[Num<T>::drow(l4, r) * 16 + l15] = a[r];
+    }
+}
+
+// Out-of-line for the use INSIDE the potrf body (idle waves of panels 0 and 1): inlined six times there it changed the register
+// allocation of every panel of the factorisation (+0.3 us per panel on the chain); the call itself runs off the chain.
+template <typename T>
+__device__ __noinline__ void xx_blocks_call(T* Ls, const T* Ximg, int b0i, int b0j, int b1i, int b1j, int l15, int l4) {
+    xx_block_rmw<T>(Ls, Ximg, b0i, b0j, l15, l4);
+    if (b1i >= 0) xx_block_rmw<T>(Ls, Ximg, b1i, b1j, l15, l4);
+}
+
 // 64-block path (fp64): behind the 10 tiles + dinv[64] of the image sit four tiles Wd that start as the identity and end as the
 // diagonal inverses, and a copy S of tile (0,0).  The caller fills them with the image, before its barrier: potrf64_aux_init by
 // all 256 threads, S by whoever writes tile (0,0) (same [col * 16 + row] order).
@@ -1153,7 +1190,7 @@ template <typename T, int NB = 8, bool WT = false>
 __device__ __forceinline__ void potrf128_core(double* __restrict__ lds_raw, T* __restrict__ Ad, long ld,
                                               T* __restrict__ Wg, double* __restrict__ logdet_out,
                                               int* __restrict__ info_out, T tol, int* pub_flag = nullptr, int pub_epoch = 0,
-                                              int* chain_flag = nullptr, T* __restrict__ Dg = nullptr) {
+                                              int* chain_flag = nullptr, T* __restrict__ Dg = nullptr, const T* __restrict__ Ximg = nullptr) {
     double* red = lds_raw;                      // 2 doubles
     constexpr int NE = 16 * NB;                 // block edge
     T* Ls = reinterpret_cast<T*>(lds_raw + 2);  // NB(NB+1)/2 tiles + dinv[NE] (+ 64-block path: NB diagonal-inverse tiles)
@@ -1187,6 +1224,8 @@ __device__ __forceinline__ void potrf128_core(double* __restrict__ lds_raw, T* _
                     for (int u = 0; u < t; ++u) potrf_update<T, 1>(Ls, p - 1, t, u * (u + 1) / 2, 1 << 20, l15, l4);
                 } else {
                     const int tt = (t == 3) ? (uwv == 1 ? 2 : (uwv == 2 ? 4 : 5)) : ((t == 2 && uwv == 1) ? 2 : -1);
+                    // (p = 1 with X images: this wave's tile -- (2,2), (3,2) or (3,3) -- first receives its share of -X X^T)
+                    if (p == 1 && Ximg) xx_blocks_call<T>(Ls, Ximg, uwv == 1 ? 2 : 3, uwv == 3 ? 3 : 2, -1, -1, l15, l4);
                     if (tt >= 0) potrf_update<T, 1>(Ls, p - 1, t, tt, 1 << 20, l15, l4);
                 }
             }
@@ -1227,6 +1266,13 @@ __device__ __forceinline__ void potrf128_core(double* __restrict__ lds_raw, T* _
                     for (int c = 0; c < 16; ++c) Xr[c * 16] = (T)x[c];
                 }
                 if (uwv == 0 && lane < 16) dinv[16 * p + lane] = (T)dv;
+            }
+            // Ximg given: the image's block column 0 is final, the other lower blocks still lack the last slab -X X^T of the
+            // diagonal tile's update.  Block column 1 (needed by panel 1): waves 2 and 3, idle in this panel, under the
+            // elimination of panel 0; blocks (2,2), (3,2), (3,3): in panel 1, by the waves that own them there (above).
+            if (p == 0 && Ximg) {
+                if (uwv == 2) xx_blocks_call<T>(Ls, Ximg, 1, 1, 2, 1, l15, l4);
+                if (uwv == 3) xx_blocks_call<T>(Ls, Ximg, 3, 1, -1, -1, l15, l4);
             }
             __syncthreads();
             GP_STAMP(3 + 3 * p);
@@ -1411,10 +1457,15 @@ __device__ __forceinline__ void potrf128_core(double* __restrict__ lds_raw, T* _
 
 // Out-of-line copy for chol_dataflow_kernel: keeps the factorisation's register allocation apart from
 // the accumulator-heavy MFMA loops of that kernel (inlined, the allocator spills accumulators there).
-template <typename T, int NB, bool WT = false>
-__device__ __noinline__ void potrf128_core_call(double* lds_raw, T* Ad, long ld, T* Wg, double* logdet_out,
-                                                int* info_out, T tol, int* pub_flag, int pub_epoch, int* chain_flag, T* Dg) {
-    potrf128_core<T, NB, WT>(lds_raw, Ad, ld, Wg, logdet_out, info_out, tol, pub_flag, pub_epoch, chain_flag, Dg);
+// The image's place in the dynamic LDS is a TEMPLATE argument (doubles from its start; XOFF likewise for the X images): handed
+// over as a run-time pointer -- or as a constant that differs between the call sites of one instantiation -- the body addresses
+// it with flat instructions (measured: +0.3 us per panel, +1.2 us per hop).
+template <typename T, int NB, bool WT = false, int LDSOFF = 0, bool XIMG0 = false>
+__device__ __noinline__ void potrf128_core_call(T* Ad, long ld, T* Wg, double* logdet_out,
+                                                int* info_out, T tol, int* pub_flag, int pub_epoch, int* chain_flag, T* Dg, bool xx) {
+    extern __shared__ double potrf_lds_dyn[];
+    potrf128_core<T, NB, WT>(potrf_lds_dyn + LDSOFF, Ad, ld, Wg, logdet_out, info_out, tol, pub_flag, pub_epoch, chain_flag, Dg,
+                             (XIMG0 && xx) ? reinterpret_cast<const T*>(potrf_lds_dyn) : nullptr);
 }
 template <typename T>
 __global__ __launch_bounds__(256) void potrf128_kernel(T* __restrict__ Abase, long bstride, int b,
@@ -1930,9 +1981,9 @@ __global__ __launch_bounds__(64 * NWI * NWJ, (NWI * NWJ == 4) ? 2 : 4) void gemm
                 }
                 __syncthreads();
                 T* Ct = Cg - ((long)(wj * (16 * FJ)) * ldc + wi * (16 * FI) + (lane & 15));        // tile base
-                potrf128_core_call<T, 8>(smem_raw, Ct, ldc, g.fuse_W + ((long)slot * g.fuse_nt + g.fuse_b) * TB * TB,
+                potrf128_core_call<T, 8>(Ct, ldc, g.fuse_W + ((long)slot * g.fuse_nt + g.fuse_b) * TB * TB,
                                          g.fuse_partial + (long)slot * g.fuse_nt + g.fuse_b, g.fuse_info + slot,
-                                         (T)g.fuse_slotp[(long)slot * SLOTP + 3], nullptr, 0, nullptr, nullptr);
+                                         (T)g.fuse_slotp[(long)slot * SLOTP + 3], nullptr, 0, nullptr, nullptr, false);
             }
         }
         return;
@@ -2088,6 +2139,10 @@ template <typename T, int TBX> constexpr int df_stage_elems() {
 // NST = LDS stages of the slab pipeline: 2 (double buffer), or 4 with counted DMA waits for a workgroup that
 // has the CU to itself (fp64 128-tiles) while the schedule is chain bound: its on-chain products have no
 // co-resident workgroup to hide the DMA latency behind (N=4096 -6 %; at N=8192, throughput bound, +4 %).
+// 64-tiles, builds with at most two workgroups per CU (DF_XXF): the potrf image lives BEHIND the stage area, so that it can be
+// filled before the chain's solve and updated block by block while the X images are still in place (diagx)
+constexpr int DF_XXF_POTRF_AT = 32 * LD64 + 1024;            // doubles from the start of the dynamic LDS: [stage / L image / X images | inverses | potrf image]
+constexpr size_t DF_XXF_LDS = (size_t)(DF_XXF_POTRF_AT + 2 + PT64_S + 256) * 8;
 template <typename T, int TBX, int NST = 2> constexpr size_t df_lds_bytes() {
     constexpr size_t gemm = NST * (size_t)df_stage_elems<T, TBX>() * sizeof(T);
     constexpr size_t nb = TBX / 16;
@@ -2524,6 +2579,29 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g, Th
         return;
     }
 
+    // accumulators -> tile-packed potrf image of the lower triangle (+ the copy of tile (0,0) and the identity tiles of the
+    // 64-block path); the caller synchronises
+    constexpr bool XXF = TBX == 64 && OCC <= 2;
+    bool image_done = false;
+    const T* ximg = nullptr;
+    auto fill_image = [&](T* Ls) {
+#pragma unroll
+        for (int x = 0; x < FJ; ++x)
+#pragma unroll
+            for (int y = 0; y < FI; ++y) {
+                const int bi = wi * FI + y, bj = wj * FJ + x;
+                if (bi >= bj) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) Ls[ptile(bi, bj) + Num<T>::drow(l4, r) * 16 + l15] = acc[x][y][r];
+                    if (TBX == 64 && bi == 0 && bj == 0) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) Ls[PT64_S + Num<T>::drow(l4, r) * 16 + l15] = acc[x][y][r];
+                    }
+                }
+            }
+        if constexpr (TBX == 64) potrf64_aux_init<T>(Ls);
+    };
+
     // 64-tiles fuse the critical chain: the diagonal task (j,j) ALSO solves its own sub-diagonal tile (j,j-1)
     // (whose owner only accumulates it and hands the pre-solve tile over through memory) and applies that
     // last slab straight from LDS -- one flag hop per column on the chain instead of two.
@@ -2595,6 +2673,13 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g, Th
             const int jm = j - 1;
             T* Xt = tptr(j, jm);                                           // tile (j, j-1)
             constexpr int XIMG = 8 * LD64;
+            static_assert(XIMG == X64_IMG && LD64 == X64_LD, "xx_block_rmw reads the X images of this kernel");
+            if (XXF && g.D && GP_DF_WT_POTRF) {
+                // (1) the diagonal tile as accumulated so far goes to the potrf image NOW (it sits behind the stage area in
+                // this build), which frees its 64 accumulator registers for the substitution
+                fill_image(reinterpret_cast<T*>(smem_raw + DF_XXF_POTRF_AT + 2));
+                image_done = true;
+            }
             if (g.D && GP_DF_WT_POTRF) {
                 // X = pre L^-T by BLOCKED SUBSTITUTION with L_{j-1,j-1} and its four 16x16 diagonal inverses -- available under
                 // the chain flag (j-1, j+1), several microseconds before W_{j-1} (potrf128_core).  Wave w owns rows 16 w .. of the
@@ -2684,6 +2769,17 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g, Th
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             stamp(7);
+            if (image_done) {
+                // (2) only block column 0 of the image before the factorisation starts: one 16x16 block per wave (16 MFMAs
+                // instead of 64); the other six lower blocks are applied by waves 2 and 3 under the elimination of panel 0
+                T* Lsx = reinterpret_cast<T*>(smem_raw + DF_XXF_POTRF_AT + 2);
+                xx_block_rmw<T>(Lsx, smem, uw, 0, l15, l4, uw == 0 ? Lsx + PT64_S : nullptr);
+                ximg = smem;
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // X(j,j-1) is at the coherent level (sc1 stores) ..
+                __syncthreads();                                // .. for every wave; block column 0 of the image is complete
+                if (tid == 0) __hip_atomic_store(F + j * R + jm, g.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                stamp(6);
+            } else {
 #pragma unroll
             for (int st = 0; st < TBX / 16; ++st)
 #pragma unroll
@@ -2704,6 +2800,7 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g, Th
             __syncthreads();                                // .. for every wave; and the images make way for the potrf image
             if (tid == 0) __hip_atomic_store(F + j * R + jm, g.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             stamp(6);
+            }
         }
     }
 
@@ -2730,30 +2827,20 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g, Th
         }
         enter_critical();                                   // (column 0 has no sub-diagonal solve before it)
         // accumulators -> tile-packed LDS image of the lower triangle, then factor + invert in place
-        T* Ls = reinterpret_cast<T*>(smem_raw + 2);
-#pragma unroll
-        for (int x = 0; x < FJ; ++x)
-#pragma unroll
-            for (int y = 0; y < FI; ++y) {
-                const int bi = wi * FI + y, bj = wj * FJ + x;
-                if (bi >= bj) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) Ls[ptile(bi, bj) + Num<T>::drow(l4, r) * 16 + l15] = acc[x][y][r];
-                    if (TBX == 64 && bi == 0 && bj == 0) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) Ls[PT64_S + Num<T>::drow(l4, r) * 16 + l15] = acc[x][y][r];
-                    }
-                }
-            }
-        if constexpr (TBX == 64) potrf64_aux_init<T>(Ls);
-        __syncthreads();
+        // (XXF builds keep the image behind the stage area ALWAYS: a compile-time LDS address at the one call site lets the
+        //  out-of-line potrf body address it as LDS; a run-time choice of pointer turned every access in there into a flat one)
+        double* praw = XXF ? smem_raw + DF_XXF_POTRF_AT : smem_raw;
+        if (!image_done) {
+            fill_image(reinterpret_cast<T*>(praw + 2));
+            __syncthreads();
+        }
         stamp(2);
         // 64-tiles: the core publishes ready(j,j) itself, as soon as W_j is out and before the L tile
         int* pubf = (TBX == 64 && GP_DF_WT_POTRF) ? F + j * R + j : nullptr;
         T* Dj = (pubf && g.D) ? g.D + (long)slot * g.d_bstride + (long)j * 1024 : nullptr;
         int* chainf = (Dj && j + 2 <= g.nd) ? F + j * R + j + 2 : nullptr;        // (the last column has no successor on the chain)
-        potrf128_core_call<T, TBX / 16, GP_DF_WT_POTRF != 0>(smem_raw, Ct, LDA, Wj, g.partial + (long)slot * g.p_bstride + j, g.info + slot,
-                                                              (T)sp[3], pubf, g.epoch, chainf, Dj);
+        potrf128_core_call<T, TBX / 16, GP_DF_WT_POTRF != 0, XXF ? DF_XXF_POTRF_AT : 0, XXF>(
+            Ct, LDA, Wj, g.partial + (long)slot * g.p_bstride + j, g.info + slot, (T)sp[3], pubf, g.epoch, chainf, Dj, ximg != nullptr);
         stamp(3);
         if (pubf) { }
         else if (GP_DF_WT_POTRF) publish_wt(j, j);

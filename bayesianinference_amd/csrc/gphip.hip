@@ -810,6 +810,7 @@ void launch_dataflow(gphip_ctx* h, int nslots, int c0 = 0, double* part = nullpt
         h->hInfo[nslots] = 0;                  // the abort word: only ever SET by the kernel
     }
     size_t lds = df_lds_bytes<T, TBX, NST>();
+    if (TBX == 64 && OCC <= 2 && lds < DF_XXF_LDS) lds = DF_XXF_LDS;      // (potrf image behind the stage area, see DF_XXF_POTRF_AT)
     g.park = nullptr;
     if constexpr (TBX == 64) {
         // ONE workgroup per CU while the launch is chain bound: the chain's latency-bound potrf / solve waves then never share
@@ -856,7 +857,8 @@ void launch_dataflow_inverse(gphip_ctx* h, int64_t fwd_rows = 0) {
     if (fwd_rows > 0) { g.U = (T*)h->dV; g.ldu = (long)fwd_rows; g.u_rows = (int)(fwd_rows / TBX); }
     h->ticket_base += (unsigned long long)tasks;
     ProfScope ps(h, 2, fwd_rows > 0 ? (double)fwd_rows * h->Npad * h->Npad : ((double)h->Npad * h->Npad * h->Npad) / 3.0, 0.0);
-    const size_t lds = df_lds_bytes<T, TBX, NST>();
+    size_t lds = df_lds_bytes<T, TBX, NST>();
+    if (TBX == 64 && OCC <= 2 && lds < DF_XXF_LDS) lds = DF_XXF_LDS;
     ThetaPack tp;
     hipLaunchKernelGGL((chol_dataflow_kernel<T, TBX, OCC, NST, false>), dim3((unsigned)tasks), dim3(256), lds, h->stream, g, tp);
     if (fwd_rows == 0) h->u_ready = true;

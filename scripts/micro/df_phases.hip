@@ -30,7 +30,7 @@ int main(int argc, char** argv) {
     double sp[SLOTP] = {1.0, 0.1, 0.0, 1e-14};
     hipMemcpy(dS, sp, sizeof sp, hipMemcpyHostToDevice); hipMemset(dI, 0, 4); hipMemset(dF, 0, (size_t)R * R * 4); hipMemset(dT, 0, 16);
     hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_buf), &dSt, sizeof dSt);
-    size_t lds = df_lds_bytes<double, 64, 2>();
+    size_t lds = std::max(df_lds_bytes<double, 64, 2>(), DF_XXF_LDS);
     if (argc > 2 && (size_t)atoi(argv[2]) * 1024 > lds) lds = (size_t)atoi(argv[2]) * 1024;      // > 80 KiB: one workgroup per CU
     auto kern = chol_dataflow_kernel<double, 64, 2, 2, false>;
     hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
