@@ -820,7 +820,8 @@ void launch_dataflow(gphip_ctx* h, int nslots, int c0 = 0, double* part = nullpt
         // 2 thetas up to N = 3072, 4 up to 2048, 8 up to 1536.  Occupancy is set through the LDS request (> 80 KiB).
         // (an owner's panel launch of the sharded schedule, chip to itself, has many rows per chain hop: throughput bound down to
         //  far fewer tasks -- owner chain 26.2 -> 22.6 ms at N=32768; under the one-GPU schedule's trailing update no difference)
-        const long one_wg_tasks = (g.ncols > 0 && h->dist_world > 0) ? h->df_panel_one_wg_tasks : 2700;
+        // (round 5, after the chain got 30 % shorter: the crossover moved down -- N = 3584 one per CU 0.85 vs 0.87 ms, N = 4096 1.05 vs 1.00)
+        const long one_wg_tasks = (g.ncols > 0 && h->dist_world > 0) ? h->df_panel_one_wg_tasks : 1900;
         const int kib = h->dataflow_lds_kib < 0 ? (tasks <= one_wg_tasks ? 84 : 0) : h->dataflow_lds_kib;   // (round 4, after the fence changes: N=4096 1/CU 1.34 vs 1.36, N=5120 1.83 vs 1.72 two per CU)
         if ((size_t)kib * 1024 > lds) lds = (size_t)kib * 1024;
         // two workgroups per CU: the neighbour of a diagonal task steps aside while that task is on the chain
