@@ -1407,16 +1407,19 @@ __device__ __forceinline__ void potrf128_core(double* __restrict__ lds_raw, T* _
             // Chain hand-over (Dg given): the next hop's sub-diagonal solve substitutes with L_jj and the four diagonal
             // inverses only, so THOSE go out first, under their own flag; the off-diagonal blocks of W_j -- for the panel
             // solves below, which have slack -- are computed and published behind it.
-            for (int bi = 0; bi < NB; ++bi)
-                for (int bj = 0; bj <= bi; ++bj)
-                    gst<WT>(Ad + (long)(bj * 16 + ec) * ld + bi * 16 + er, Ls[ptile(bi, bj) + tid]);
+            // (the substitution reads the six OFF-diagonal 16x16 blocks of L and the inverses of the diagonal ones: those first;
+            //  the diagonal blocks of L, which nobody inside the launch reads, behind the flag)
 #pragma unroll
             for (int b = 0; b < NB; ++b) gst<WT>(Dg + b * 256 + tid, Wd[b * 256 + er * 16 + ec]);    // [col * 16 + row] out of [row][col]
+            for (int bi = 1; bi < NB; ++bi)
+                for (int bj = 0; bj < bi; ++bj)
+                    gst<WT>(Ad + (long)(bj * 16 + ec) * ld + bi * 16 + er, Ls[ptile(bi, bj) + tid]);
             if (chain_flag) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
                 if (tid == 0) __hip_atomic_store(chain_flag, pub_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
+            for (int bi = 0; bi < NB; ++bi) gst<WT>(Ad + (long)(bi * 16 + ec) * ld + bi * 16 + er, Ls[ptile(bi, bi) + tid]);
         }
         GP_STAMP(32);
         tri_inverse_lds<T, NB, WT, true>(Ls, dinv, Wg, Wd);
