@@ -2519,6 +2519,7 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g, Th
         if (tid == 0) __hip_atomic_store(F + fi_ * R + fj_, g.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
 
+    constexpr bool XXF = TBX == 64 && OCC <= 2;           // builds whose LDS holds the stage area AND a second 36 KiB region (DF_XXF_LDS)
     if (inverse) {
         // ---- a tile of U = L^-T.  Row block rb of U advances one column block per task: the k-th slab needs U(rb,k), i.e. the
         // task before this one in the row -- a chain of nd - rb hops per row, nd rows side by side.
@@ -2528,6 +2529,22 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g, Th
         const int cb = i, rb = j, kf = fwd ? 0 : rb, nsl = cb - kf;          // slabs k = kf .. cb - 1
         T* Ut = g.U + (long)cb * TBX * g.ldu + (long)rb * TBX;
         const T* Urow = g.U + (long)rb * TBX;               // U(rb rows, column c) at Urow[r + c * ldu]
+        // two-per-CU builds (76 KiB of LDS): W_cb is prefetched behind the stage area now -- the factor is final -- and the
+        // tile's solve at the end takes both operands from LDS (the accumulators written out as the I image) instead of
+        // storing the pre-solve tile, draining the store and loading it back: ~2 of the ~8 us of a hop on the row's chain
+        const T* Wcb = g.W + (long)slot * g.w_bstride + (long)cb * TBX * TBX;
+        constexpr int IMG16 = (TBX / 2) * LD64 / 4;        // doubles per 16 k-columns of one operand image (= X64_IMG for 64-tiles)
+        if constexpr (XXF) {
+#pragma unroll
+            for (int kb = 0; kb < SPB; ++kb)
+#pragma unroll
+                for (int s2 = 0; s2 < GK / 8; ++s2) {
+                    const int qq = uw + 4 * s2;
+                    const long kcol = (long)kb * GK + 4 * (qq >> 1) + (qq & 1) + 2 * (lane >> 5);
+                    __builtin_amdgcn_global_load_lds((glb_void*)(Wcb + kcol * TBX + 2 * (lane & 31)),
+                                                     (lds_void*)(smem + SPB * IMG16 + kb * IMG16 + qq * LD64), 16, 0, GP_DF_DMA_AUX);
+                }
+        }
         if (fwd) load_c(acc, Ut, g.ldu);
         else zero_c(acc);
         if (!fwd && nsl == 0) {
@@ -2572,11 +2589,47 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g, Th
             }
             run_k(acc, Urow + (long)(kf + b) * TBX * g.ldu, g.ldu, tptr(cb, kf + b), LDA, SPB, true);
         }
+        if constexpr (XXF) {
+            static_assert(IMG16 == X64_IMG, "operand image of 16 k-columns");
+            acc_t res[FJ][FI];
+#pragma unroll
+            for (int x = 0; x < FJ; ++x)
+#pragma unroll
+                for (int y = 0; y < FI; ++y)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int c = wj * WT + x * 16 + Num<T>::drow(l4, r), irow = wi * WT + y * 16 + l15;
+                        smem[(c >> 4) * IMG16 + df_lds_off<T, TBX>(c & 15, irow)] = acc[x][y][r];
+                    }
+            zero_c(res);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (this wave's share of the W image: landed long ago)
+            __syncthreads();
+#pragma unroll
+            for (int kb = 0; kb < SPB; ++kb)
+#pragma unroll
+                for (int kk = 0; kk < GK / 4; ++kk) {
+                    const T* Is = smem + kb * IMG16 + wi * WT + l15;
+                    const T* Js = smem + SPB * IMG16 + kb * IMG16 + wj * WT + l15;
+                    const int k = 4 * kk + l4;
+                    T fi[FI], fj[FJ];
+#pragma unroll
+                    for (int f = 0; f < FI; ++f) fi[f] = Is[df_lds_off<T, TBX>(k, f * 16)];
+#pragma unroll
+                    for (int f = 0; f < FJ; ++f) fj[f] = Js[df_lds_off<T, TBX>(k, f * 16)];
+#pragma unroll
+                    for (int x = 0; x < FJ; ++x)
+#pragma unroll
+                        for (int y = 0; y < FI; ++y) res[x][y] = Num<T>::mfma(fj[x], fi[y], res[x][y]);
+                }
+            store_c(res, Ut, g.ldu);
+            publish_wt(rb, cb);
+            return;
+        }
         store_c(acc, Ut, g.ldu);                            // the pre-solve tile becomes an MFMA operand through memory
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         zero_c(acc);
-        run_k(acc, Ut, g.ldu, g.W + (long)slot * g.w_bstride + (long)cb * TBX * TBX, TBX, SPB, false);
+        run_k(acc, Ut, g.ldu, Wcb, TBX, SPB, false);
         store_c(acc, Ut, g.ldu);
         publish_wt(rb, cb);
         return;
@@ -2584,7 +2637,6 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g, Th
 
     // accumulators -> tile-packed potrf image of the lower triangle (+ the copy of tile (0,0) and the identity tiles of the
     // 64-block path); the caller synchronises
-    constexpr bool XXF = TBX == 64 && OCC <= 2;
     bool image_done = false;
     const T* ximg = nullptr;
     auto fill_image = [&](T* Ls) {
