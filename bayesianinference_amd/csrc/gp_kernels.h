@@ -2796,27 +2796,27 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g, Th
                         smem[(c >> 4) * XIMG + df_lds_off<T, TBX>(c & 15, irow)] = (T)xb[b][r];
                     }
             } else {
-            if (wave == 0) {
-                df_wait(F + jm * R + j, g.epoch, g.abort_flag);           // pre-solve tile stored by its owner
-                df_wait(F + jm * R + jm, g.epoch, g.abort_flag);          // W_{j-1}
-            }
-            __syncthreads();
-            enter_critical();                              // from here to ready(j,j) nothing but this workgroup's own work
-            stamp(5);
-            acc_t accx[FJ][FI];
-            zero_c(accx);
-            run_k(accx, Xt, LDA, g.W + (long)slot * g.w_bstride + (long)jm * TBX * TBX, TBX, SPB, false);
-            store_c(accx, Xt, LDA);                        // X(j,j-1): the column below waits for it
-            // X -> four 16-column LDS images [k][row] (both MFMA operands of X X^T read the same image)
+                if (wave == 0) {
+                    df_wait(F + jm * R + j, g.epoch, g.abort_flag);           // pre-solve tile stored by its owner
+                    df_wait(F + jm * R + jm, g.epoch, g.abort_flag);          // W_{j-1}
+                }
+                __syncthreads();
+                enter_critical();                              // from here to ready(j,j) nothing but this workgroup's own work
+                stamp(5);
+                acc_t accx[FJ][FI];
+                zero_c(accx);
+                run_k(accx, Xt, LDA, g.W + (long)slot * g.w_bstride + (long)jm * TBX * TBX, TBX, SPB, false);
+                store_c(accx, Xt, LDA);                        // X(j,j-1): the column below waits for it
+                // X -> four 16-column LDS images [k][row] (both MFMA operands of X X^T read the same image)
 #pragma unroll
-            for (int x = 0; x < FJ; ++x)
+                for (int x = 0; x < FJ; ++x)
 #pragma unroll
-                for (int y = 0; y < FI; ++y)
+                    for (int y = 0; y < FI; ++y)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int c = wj * WT + x * 16 + Num<T>::drow(l4, r), irow = wi * WT + y * 16 + l15;
-                        smem[(c >> 4) * XIMG + df_lds_off<T, TBX>(c & 15, irow)] = accx[x][y][r];
-                    }
+                        for (int r = 0; r < 4; ++r) {
+                            const int c = wj * WT + x * 16 + Num<T>::drow(l4, r), irow = wi * WT + y * 16 + l15;
+                            smem[(c >> 4) * XIMG + df_lds_off<T, TBX>(c & 15, irow)] = accx[x][y][r];
+                        }
             }
             // ready(j,j-1) waits until the product below is done: draining the write-through stores of X here (vmcnt(0)) would sit
             // on the chain, and the tasks that read X(j,j-1) are not on it.  Only the LDS images must be complete now (a raw
@@ -2836,25 +2836,25 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g, Th
                 stamp(6);
             } else {
 #pragma unroll
-            for (int st = 0; st < TBX / 16; ++st)
+                for (int st = 0; st < TBX / 16; ++st)
 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-                    const T* Im = smem + st * XIMG + l15;
-                    const int kq = 4 * kk + l4;
-                    T fi[FI], fj[FJ];
+                    for (int kk = 0; kk < 4; ++kk) {
+                        const T* Im = smem + st * XIMG + l15;
+                        const int kq = 4 * kk + l4;
+                        T fi[FI], fj[FJ];
 #pragma unroll
-                    for (int f = 0; f < FI; ++f) fi[f] = Im[df_lds_off<T, TBX>(kq, wi * WT + f * 16)];
+                        for (int f = 0; f < FI; ++f) fi[f] = Im[df_lds_off<T, TBX>(kq, wi * WT + f * 16)];
 #pragma unroll
-                    for (int f = 0; f < FJ; ++f) fj[f] = -Im[df_lds_off<T, TBX>(kq, wj * WT + f * 16)];
+                        for (int f = 0; f < FJ; ++f) fj[f] = -Im[df_lds_off<T, TBX>(kq, wj * WT + f * 16)];
 #pragma unroll
-                    for (int x = 0; x < FJ; ++x)
+                        for (int x = 0; x < FJ; ++x)
 #pragma unroll
-                        for (int y = 0; y < FI; ++y) acc[x][y] = Num<T>::mfma(fj[x], fi[y], acc[x][y]);
-                }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // X(j,j-1) is at the coherent level (sc1 stores) ..
-            __syncthreads();                                // .. for every wave; and the images make way for the potrf image
-            if (tid == 0) __hip_atomic_store(F + j * R + jm, g.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            stamp(6);
+                            for (int y = 0; y < FI; ++y) acc[x][y] = Num<T>::mfma(fj[x], fi[y], acc[x][y]);
+                    }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // X(j,j-1) is at the coherent level (sc1 stores) ..
+                __syncthreads();                                // .. for every wave; and the images make way for the potrf image
+                if (tid == 0) __hip_atomic_store(F + j * R + jm, g.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                stamp(6);
             }
         }
     }
