@@ -327,7 +327,7 @@ void free_slots(gphip_ctx* h) {
 }
 
 size_t slot_bytes(const gphip_ctx* h) {
-    return ((size_t)h->slot_elems + (size_t)(h->nl2 > 0 ? 2 : 1) * h->d * h->Npad + (size_t)h->Nt * TB * TB) * h->es +
+    return ((size_t)h->slot_elems + (size_t)(h->nl2 > 0 ? 2 : 1) * h->d * h->Npad + (size_t)h->Nt * TB * TB + (size_t)2 * h->Nt * 1024) * h->es +
            (size_t)h->Nt * 16 + (size_t)(2 * h->Nt + 1) * (2 * h->Nt + 1) * 4 + 4096;
 }
 
