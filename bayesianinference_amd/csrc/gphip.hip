@@ -3015,7 +3015,8 @@ int gphip_solve(gphip_handle h, const double* rhs, int64_t nrhs, double* out) {
             for (int64_t j = 0; j < N; ++j) v[(size_t)j * mpad + t] = rhs[(m0 + t) * N + j];
         rc = DISPATCH(h, upload, h, h->dV, v, h->stream);
         if (rc) return rc;
-        DISPATCH(h, queue_forward_rows, h, mpad, 1);
+        if (df_forward_ok(h, mpad)) launch_dataflow_inverse<double, 64>(h, mpad);      // (the forward half as one dataflow launch, as in gphip_predict)
+        else DISPATCH(h, queue_forward_rows, h, mpad, 1);
         DISPATCH(h, queue_backward_rows, h, mpad);
         rc = DISPATCH(h, download, h, v, h->dV, (size_t)mpad * Npad, h->stream);
         if (rc) return rc;
