@@ -2079,6 +2079,10 @@ struct DfArgs {
                                               // right-hand sides as ROWS (test-point covariances k*^T); every task turns one tile into
                                               // the same tile of U L^-T: U(rb,cb) = (U(rb,cb) - sum_{k<cb} U(rb,k) L(cb,k)^T) W_cb^T,
                                               // in place.  Tasks in column order, u_rows * nd of them; needs u_rows <= nd + 1
+    const T* LT; int u_back;                  // BACKWARD launch (u_rows > 0, u_back = 1): the rows of U become U L^-1 -- the second half of a solve with K.
+                                              // LT = a copy of the factor whose 64x64 blocks are stored TRANSPOSED in place (tile (k, cb) holds L(k,cb)^T),
+                                              // W = the transposed 64-block inverses: with them U(rb,cb) = (U(rb,cb) - sum_{k>cb} U(rb,k) L(k,cb)) W_cb is
+                                              // the forward task's recurrence read from the other end (columns nd-1 .. 0)
     long long* trace;                         // developer timing (scripts/micro/df_trace.hip): 8 stamps per task, or null
     // BUILD variant only (one launch per evaluation: tiles built in-kernel, results exported by the corner task)
     const T* xt; const T* yv;                 // unscaled inputs [d][npad], outputs [npad]
@@ -2166,6 +2170,8 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g, Th
     constexpr int FI = TBX / 32, FJ = TBX / 32, WT = TBX / 2;   // MFMA tiles per wave, wave tile edge
     extern __shared__ double smem_raw[];
     __shared__ int s_task;
+    __shared__ int s_known;                                // (NOT s_task again: wave 0 could write the peek's result there before a slow wave
+                                                           //  has read its ticket -- waves of one workgroup on different tasks = mismatched barriers = a hung launch)
     __shared__ int s_park;
     T* smem = reinterpret_cast<T*>(smem_raw);
     typedef typename Num<T>::acc_t acc_t;
@@ -2206,8 +2212,9 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g, Th
 #define GP_DF_PRIO 3
 #endif
     const bool inverse = g.U != nullptr;
-    if (inverse && g.u_rows > 0) {                          // forward launch: q = cb * u_rows + rb
-        i = __builtin_amdgcn_readfirstlane(q / g.u_rows);
+    if (inverse && g.u_rows > 0) {                          // forward launch: q = cb * u_rows + rb; backward: columns from the last one
+        const int cq = q / g.u_rows;
+        i = __builtin_amdgcn_readfirstlane(g.u_back ? g.nd - 1 - cq : cq);
         j = __builtin_amdgcn_readfirstlane(q % g.u_rows);
     } else if (inverse) {                                   // task q -> (rb, cb), rb <= cb, column cb first: q = cb (cb + 1) / 2 + rb
         int cb = (int)((sqrt(8.0 * (double)q + 1.0) - 1.0) * 0.5);
@@ -2253,6 +2260,9 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g, Th
         T* base = tj_ < g.nprev ? const_cast<T*>(g.Aprev) : As;        // (nprev = 0 outside the sharded schedule)
         if constexpr (TBX == 128) return base + tile_index(gi, gj, g.R128) * TS;
         else return base + tile_index(gi >> 1, gj >> 1, g.R128) * TS + (long)(gj & 1) * 64 * TB + (gi & 1) * 64;
+    };
+    auto tptrT = [&](int ti_, int tj_) -> const T* {        // block (ti, tj) of the transposed-blocks copy (backward launch; 64-tiles)
+        return g.LT + tile_index(ti_ >> 1, tj_ >> 1, g.R128) * TS + (long)(tj_ & 1) * 64 * TB + (ti_ & 1) * 64;
     };
     constexpr long LDA = TB;
     T* Ct = tptr(i, (inverse && j > i) ? i : j);           // tile (i,j)  (a forward launch's row block index is not a tile column)
@@ -2366,7 +2376,8 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g, Th
     // this loop makes the register allocator spill accumulators around it.
     // mi >= 0: both operands walk the finished tile columns 0, 1, .. of tile rows mi / mj (one TBX-wide slab = SPB
     // stages per column; the columns are separate tiles of the packed workspace); otherwise Ig / Jg are contiguous in k.
-    // multi_c = 2 (inverse launch): I contiguous in k (a row block of U), J walks the tiles (mj, mi), (mj, mi + 1), ..
+    // multi_c = 2 (inverse / forward launch): I contiguous in k (a row block of U), J walks the tiles (mj, mi), (mj, mi + 1), ..;
+    // multi_c = 3 (backward launch): J walks the transposed blocks (mi, mj), (mi + 1, mj), .. of DfArgs::LT
     auto run_k_impl = [&](auto multi_c, acc_t (&A)[FJ][FI], const T* Ig0, long ldi, const T* Jg0, long ldj, int nk, bool negate,
                           int mi, int mj) {
         constexpr int MULTI = (int)decltype(multi_c)::value;
@@ -2382,6 +2393,9 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g, Th
             } else if constexpr (MULTI == 2) {
                 Ig = Ig0 + (long)kb * GK * ldi;
                 Jg = tptr(mj, mi + kb / SPB) + (long)(kb % SPB) * GK * LDA;
+            } else if constexpr (MULTI == 3) {               // backward launch: J walks the transposed blocks (mi, mj), (mi + 1, mj), ..
+                Ig = Ig0 + (long)kb * GK * ldi;
+                Jg = tptrT(mi + kb / SPB, mj) + (long)(kb % SPB) * GK * LDA;
             } else {
                 Ig = Ig0 + (long)kb * GK * ldi;
                 Jg = Jg0 + (long)kb * GK * ldj;
@@ -2525,8 +2539,10 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g, Th
         // task before this one in the row -- a chain of nd - rb hops per row, nd rows side by side.
         // Forward launch (u_rows > 0): the same recurrence on a dense block of right-hand-side rows, from column 0, starting
         // from the tile's own content instead of the identity.
-        const bool fwd = g.u_rows > 0;
-        const int cb = i, rb = j, kf = fwd ? 0 : rb, nsl = cb - kf;          // slabs k = kf .. cb - 1
+        // Backward launch (u_back): the recurrence read from the other end -- slabs k = nd-1 .. cb+1, blocks of the transposed copy.
+        const bool fwd = g.u_rows > 0, back = fwd && g.u_back != 0;
+        const int cb = i, rb = j, kf = fwd ? 0 : rb, nsl = back ? g.nd - 1 - cb : cb - kf;      // slabs k = kf .. cb - 1 (back: nd-1 .. cb+1)
+        auto kblk = [&](int b) { return back ? g.nd - 1 - b : kf + b; };                        // block column of slab b, in the order they finish
         T* Ut = g.U + (long)cb * TBX * g.ldu + (long)rb * TBX;
         const T* Urow = g.U + (long)rb * TBX;               // U(rb rows, column c) at Urow[r + c * ldu]
         // two-per-CU builds (76 KiB of LDS): W_cb is prefetched behind the stage area now -- the factor is final -- and the
@@ -2563,31 +2579,35 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g, Th
                 for (int c0 = 0; c0 < nsl; c0 += 64) {
                     const int c = c0 + lane;
                     const bool ready = c < nsl &&
-                        __hip_atomic_load(F + rb * R + kf + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == g.epoch;
+                        __hip_atomic_load(F + rb * R + kblk(c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == g.epoch;
                     const unsigned long long miss = ~__ballot(ready);
                     const int lead = miss ? __builtin_ctzll(miss) : 64;
                     run += lead;
                     if (lead < 64) break;
                 }
-                if (lane == 0) s_task = run < nsl ? run : nsl;
+                if (lane == 0) s_known = run < nsl ? run : nsl;
             }
             __syncthreads();
-            known = __builtin_amdgcn_readfirstlane(s_task);
+            known = __builtin_amdgcn_readfirstlane(s_known);
             if (known > 0 && GP_DF_ACQUIRE) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
         int b0 = 0;
         if constexpr (TBX == 64) {
             if (known > 0) {
-                run_k_impl(std::integral_constant<int, 2>{}, acc, Urow + (long)kf * TBX * g.ldu, g.ldu, nullptr, LDA, known * SPB, true, kf, cb);
+                if (back)               // the finished run = the LAST `known` block columns: one ascending pass over [nd - known, nd)
+                    run_k_impl(std::integral_constant<int, 3>{}, acc, Urow + (long)(g.nd - known) * TBX * g.ldu, g.ldu, nullptr, LDA, known * SPB,
+                               true, g.nd - known, cb);
+                else
+                    run_k_impl(std::integral_constant<int, 2>{}, acc, Urow + (long)kf * TBX * g.ldu, g.ldu, nullptr, LDA, known * SPB, true, kf, cb);
                 b0 = known;
             }
         }
         for (int b = b0; b < nsl; ++b) {
             if (b >= known) {
-                if (wave == 0) df_wait(F + rb * R + kf + b, g.epoch, g.abort_flag);
+                if (wave == 0) df_wait(F + rb * R + kblk(b), g.epoch, g.abort_flag);
                 __syncthreads();
             }
-            run_k(acc, Urow + (long)(kf + b) * TBX * g.ldu, g.ldu, tptr(cb, kf + b), LDA, SPB, true);
+            run_k(acc, Urow + (long)kblk(b) * TBX * g.ldu, g.ldu, back ? tptrT(kblk(b), cb) : tptr(cb, kblk(b)), LDA, SPB, true);
         }
         if constexpr (XXF) {
             static_assert(IMG16 == X64_IMG, "operand image of 16 k-columns");
@@ -2688,10 +2708,10 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g, Th
                 run += lead;
                 if (lead < 64) break;
             }
-            if (lane == 0) s_task = run < jacc ? run : jacc;
+            if (lane == 0) s_known = run < jacc ? run : jacc;
         }
         __syncthreads();
-        known = __builtin_amdgcn_readfirstlane(s_task);
+        known = __builtin_amdgcn_readfirstlane(s_known);
         if (known > 0 && GP_DF_ACQUIRE) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     int b0 = 0;
@@ -3071,6 +3091,23 @@ __global__ void utri_gemv_finish_kernel(const double* __restrict__ part, int nch
     double s = 0.0;
     for (int y = 0; y < nchunks; ++y) s += part[(long)y * npad + r];
     out[r] = (T)s;
+}
+
+// out = in with every 64 x 64 block transposed IN PLACE POSITION (block (a, b) of a tile stays block (a, b), its content turns):
+// the copy of the factor (grid.x = lower tiles of the packed workspace, 4 blocks each) or of the 64-block inverses
+// (tile_elems = 64 * 64, ld = 64, one block per workgroup) that the backward launch of chol_dataflow_kernel reads.
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_blocks64_kernel(const T* __restrict__ in, T* __restrict__ out, long tile_elems, int ld, int nblk) {
+    __shared__ T t[64][65];
+    const long base = (long)blockIdx.x * tile_elems;
+    for (int q = 0; q < nblk; ++q) {
+        const int a = q & 1, b = q >> 1;
+        const long o = base + (long)b * 64 * ld + a * 64;
+        for (int e = threadIdx.x; e < 4096; e += 256) t[e >> 6][e & 63] = in[o + (long)(e >> 6) * ld + (e & 63)];       // t[col][row]
+        __syncthreads();
+        for (int e = threadIdx.x; e < 4096; e += 256) out[o + (long)(e >> 6) * ld + (e & 63)] = t[e & 63][e >> 6];      // (row, col) <- (col, row)
+        __syncthreads();
+    }
 }
 
 template <typename T>

@@ -119,6 +119,8 @@ struct gphip_ctx {
     void* dW64 = nullptr;                                   // typed [2 Nt][64 x 64]: the 64-block inverses of a single-launch factorisation
                                                             // whose caller substitutes afterwards (fit, gradient); dW then takes the 128-blocks
     unsigned long w64_gen = ~0ul;                           // ws_gen of the factor dW64 belongs to
+    void *dLT = nullptr, *dW64T = nullptr;                  // typed: the factor / the 64-block inverses with every 64 x 64 block transposed in place
+    unsigned long lt_gen = ~0ul;                            // (gphip_solve's backward launch, DfArgs::LT); ws_gen of the factor they were made from
     double *dInvEll = nullptr, *dSlotp = nullptr, *dPartial = nullptr, *dRes = nullptr;
     int* dInfo = nullptr;
     double *hInvEll = nullptr, *hSlotp = nullptr, *hRes = nullptr;
@@ -305,8 +307,8 @@ void harvest(gphip_ctx* h) {   // call after stream sync
 void free_slots(gphip_ctx* h) {
     (void)hipFree(h->dA); (void)hipFree(h->dXs); (void)hipFree(h->dInvEll); (void)hipFree(h->dSlotp);
     (void)hipFree(h->dW); (void)hipFree(h->dPartial); (void)hipFree(h->dRes); (void)hipFree(h->dInfo);
-    (void)hipFree(h->dFlags); (void)hipFree(h->dTicket); (void)hipFree(h->dW64); (void)hipFree(h->dDinv);
-    h->dW64 = h->dDinv = nullptr; h->w64_gen = ~0ul;
+    (void)hipFree(h->dFlags); (void)hipFree(h->dTicket); (void)hipFree(h->dW64); (void)hipFree(h->dDinv); (void)hipFree(h->dLT); (void)hipFree(h->dW64T);
+    h->dW64 = h->dDinv = h->dLT = h->dW64T = nullptr; h->w64_gen = h->lt_gen = ~0ul;
     (void)hipFree(h->dPwMean); (void)hipFree(h->dPwNug);
     h->dPwMean = h->dPwNug = nullptr; h->pw_cap = 0;
     (void)hipFree(h->dXs2); (void)hipFree(h->dInvEll2); (void)hipHostFree(h->hInvEll2);
@@ -840,7 +842,7 @@ constexpr int64_t GRAD_LD_PAD = 16;
 // task turns one tile of them into the same tile of V L^-T (DfArgs::u_rows): the forward substitution of a prediction with
 // few test points as ONE launch whose chain is a handful of microseconds per 64 columns, not two launches per tile column.
 template <typename T, int TBX, int OCC = 2, int NST = 2>
-void launch_dataflow_inverse(gphip_ctx* h, int64_t fwd_rows = 0) {
+void launch_dataflow_inverse(gphip_ctx* h, int64_t fwd_rows = 0, bool back = false) {
     const int nd = (int)(h->Npad / TBX);
     const long tasks = fwd_rows > 0 ? (long)(fwd_rows / TBX) * nd : (long)nd * (nd + 1) / 2;
     if (fwd_rows == 0)
@@ -856,6 +858,7 @@ void launch_dataflow_inverse(gphip_ctx* h, int64_t fwd_rows = 0) {
     g.nd = nd; g.nslots = 1; g.epoch = ++h->epoch;
     g.U = (T*)h->dKinv; g.ldu = (long)(h->Npad + GRAD_LD_PAD);
     if (fwd_rows > 0) { g.U = (T*)h->dV; g.ldu = (long)fwd_rows; g.u_rows = (int)(fwd_rows / TBX); }
+    if (back) { g.u_back = 1; g.LT = (const T*)h->dLT; g.W = (T*)h->dW64T; }        // (the caller made them for this factor: df_backward_ready)
     h->ticket_base += (unsigned long long)tasks;
     ProfScope ps(h, 2, fwd_rows > 0 ? (double)fwd_rows * h->Npad * h->Npad : ((double)h->Npad * h->Npad * h->Npad) / 3.0, 0.0);
     size_t lds = df_lds_bytes<T, TBX, NST>();
@@ -869,6 +872,20 @@ void launch_dataflow_inverse(gphip_ctx* h, int64_t fwd_rows = 0) {
 // there): the forward substitution as one dataflow launch.  Measured against the multi-kernel substitution
 // (scripts/gpu_predict_df_sweep.py, profiles/r05_predict_df_sweep.txt): 100 test points 3.1x faster at N = 2048-12288, 2048
 // points 1.3-2x, 4096 points 1.1-1.3x up to N = 8192 and a tie at 12288, 8192 points 15-20 % slower
+// The backward half of a solve as a dataflow launch needs the factor's 64 x 64 blocks transposed (DfArgs::LT) and the transposed
+// 64-block inverses: made once per fit, on the first solve (one pass over the factor, N^2 / 2 elements).  false: no memory.
+template <typename T>
+bool df_backward_ready(gphip_ctx* h) {
+    if (h->dLT && h->dW64T && h->lt_gen == h->ws_gen) return true;
+    if (!h->dLT && hipMalloc(&h->dLT, (size_t)h->slot_elems * sizeof(T)) != hipSuccess) { (void)hipGetLastError(); h->dLT = nullptr; return false; }
+    if (!h->dW64T && hipMalloc(&h->dW64T, (size_t)h->Nt * TB * TB * sizeof(T)) != hipSuccess) { (void)hipGetLastError(); h->dW64T = nullptr; return false; }
+    const long ntiles = (long)h->R * (h->R + 1) / 2;
+    hipLaunchKernelGGL(transpose_blocks64_kernel<T>, dim3((unsigned)ntiles), dim3(256), 0, h->stream, (const T*)h->dA, (T*)h->dLT, (long)TS, (int)TB, 4);
+    hipLaunchKernelGGL(transpose_blocks64_kernel<T>, dim3((unsigned)(2 * h->Nt)), dim3(256), 0, h->stream, (const T*)h->dW64, (T*)h->dW64T, 4096l, 64, 1);
+    h->lt_gen = h->ws_gen;
+    return true;
+}
+
 bool df_forward_ok(const gphip_ctx* h, int64_t mpad) {
     return h->dataflow && h->predict_df > 0 && h->dtype == 64 && h->dist_world == 0 && h->dW64 && h->w64_gen == h->ws_gen &&
            h->w64_gen == h->fit_gen && mpad <= (h->Npad <= 8192 ? 2 : 1) * (int64_t)h->predict_df && mpad / 64 <= h->Npad / 64;
@@ -3015,9 +3032,13 @@ int gphip_solve(gphip_handle h, const double* rhs, int64_t nrhs, double* out) {
             for (int64_t j = 0; j < N; ++j) v[(size_t)j * mpad + t] = rhs[(m0 + t) * N + j];
         rc = DISPATCH(h, upload, h, h->dV, v, h->stream);
         if (rc) return rc;
-        if (df_forward_ok(h, mpad)) launch_dataflow_inverse<double, 64>(h, mpad);      // (the forward half as one dataflow launch, as in gphip_predict)
+        // after a single-launch fit both halves are ONE dataflow launch each (forward as in gphip_predict; backward over a copy of
+        // the factor with its 64 x 64 blocks transposed, made on the first solve of a fit)
+        const bool dfs = df_forward_ok(h, mpad);
+        if (dfs) launch_dataflow_inverse<double, 64>(h, mpad);
         else DISPATCH(h, queue_forward_rows, h, mpad, 1);
-        DISPATCH(h, queue_backward_rows, h, mpad);
+        if (dfs && df_backward_ready<double>(h)) launch_dataflow_inverse<double, 64>(h, mpad, true);
+        else DISPATCH(h, queue_backward_rows, h, mpad);
         rc = DISPATCH(h, download, h, v, h->dV, (size_t)mpad * Npad, h->stream);
         if (rc) return rc;
         HIPCHK(hipGetLastError());

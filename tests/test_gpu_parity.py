@@ -705,6 +705,40 @@ def test_prediction_forward_launch_equals_multi_kernel_substitution(n, d, m):
     h.close()
 
 
+@pytest.mark.parametrize("n,d,nrhs", [(1500, 3, 1), (2100, 2, 70), (6300, 4, 3), (300, 2, 2)])
+def test_solve_dataflow_launches_equal_multi_kernel_substitution(n, d, nrhs):
+    """a3 "Inverse" (BGP:131-141 applied to a vector or an N x M matrix): after a single-launch fit both halves of the solve are
+    one dataflow launch each -- forward as in the prediction, backward over a copy of the factor with its 64 x 64 blocks
+    transposed (DfArgs::LT, made once per fit) -- against the multi-kernel substitutions and against K itself."""
+    X, y = syn.make_dataset(n, d)
+    kernel = "se_ard"
+    th = syn.default_theta(kernel, d)
+    rng = np.random.default_rng(n)
+    b = rng.standard_normal(n) if nrhs == 1 else rng.standard_normal((n, nrhs))       # N, or N x M: columns are right-hand sides
+    h = _lib.Handle(X, y, kernel)
+    out = {}
+    for mode in (2048, 0):
+        h.set_option("predict_df", mode)
+        assert h.fit(th) == 0
+        out[mode] = (h.solve(b), h.solve(b))              # (the second call reuses the transposed copy)
+        h.set_option("profile", 2); h.reset_profile(); h.solve(b)
+        out[("launches", mode)] = sum(int(v["launches"]) for k, v in h.profile().items() if k in ("trsm", "gemm_panel"))
+        h.set_option("profile", 0)
+    np.testing.assert_array_equal(out[2048][0], out[2048][1])
+    scale = np.abs(out[0][0]).max()
+    np.testing.assert_allclose(out[2048][0], out[0][0], rtol=0, atol=1e-10 * scale)
+    assert out[("launches", 2048)] == 2 < out[("launches", 0)], out
+    if n <= 2100:
+        K = h.covariance(th)
+        np.testing.assert_allclose(K @ out[2048][0], b, rtol=0, atol=1e-8 * np.abs(b).max() * max(1.0, scale))
+    assert h.fit(th * 1.05) == 0                          # a new fit: the copy is made again, for the new factor
+    x2 = h.solve(b)
+    h.set_option("predict_df", 0)
+    assert h.fit(th * 1.05) == 0
+    np.testing.assert_allclose(x2, h.solve(b), rtol=0, atol=1e-10 * np.abs(x2).max())
+    h.close()
+
+
 def test_gradient_null_kernel_and_fp32():
     X, y = syn.make_dataset(50, 2)
     h = _lib.Handle(X, y, "null", "const")
