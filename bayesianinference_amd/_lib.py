@@ -74,6 +74,7 @@ _SIGNATURES = {
                                            C.c_int, C.c_int, C.c_void_p, C.POINTER(_h)]),
     "gphip_create_error": (C.c_char_p, []),
     "gphip_custom_compile": (C.c_int, [C.c_char_p, C.c_int, C.c_char_p, C.c_int, _ip]),
+    "gphip_custom_compile_d": (C.c_int, [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_int, _ip]),
     "gphip_kernel_parse": (C.c_int, [C.c_char_p, C.c_int64, _ip]),
     "gphip_cform_to_body": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int64]),
     "gphip_tab_prior_sample": (C.c_int, [_dp, _dp, C.c_int, C.c_int64, C.c_int, C.c_uint64, _dp]),

@@ -130,11 +130,14 @@ template <typename S, int NP>
 GP_HD Dual<S, NP> pow(const Dual<S, NP>& a, const Dual<S, NP>& b) {
     Dual<S, NP> r;
     r.v = ::pow(a.v, b.v);
-    const S da = b.v == (S)0 ? (S)0 : b.v * ::pow(a.v, b.v - (S)1);
+    const S da = (b.v == (S)0 || (a.v == (S)0 && b.v < (S)1)) ? (S)0 : b.v * ::pow(a.v, b.v - (S)1);   // (a = 0, b < 1: as sqrt at 0)
     bool bdep = false;
     for (int k = 0; k < NP; ++k) bdep = bdep || b.g[k] != (S)0;
     const S db = bdep ? r.v * ::log(a.v) : (S)0;
-    for (int k = 0; k < NP; ++k) r.g[k] = da * a.g[k] + (b.g[k] != (S)0 ? db * b.g[k] : (S)0);
+    // (a.g[k] == 0 skips the base's term: Power(r2, 0.5) on the diagonal has da = inf and a.g = 0 -- inf * 0 would
+    //  turn every partial derivative into NaN; sqrt() above guards the same point)
+    for (int k = 0; k < NP; ++k)
+        r.g[k] = (a.g[k] != (S)0 ? da * a.g[k] : (S)0) + (b.g[k] != (S)0 ? db * b.g[k] : (S)0);
     return r;
 }
 template <typename S, int NP, GP_NUM_ARG(A)> GP_HD Dual<S, NP> pow(const Dual<S, NP>& a, A b) { return pow(a, Dual<S, NP>(b)); }

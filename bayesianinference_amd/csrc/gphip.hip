@@ -108,9 +108,18 @@ struct gphip_ctx {
     // training inputs per dimension.  A theta's slot goes to that kernel while sum_k (half_k / l_k)^2 <= kbuild_mfma_bound
     // (fp32: / 8) -- the rounding error of its squared distances grows with that sum (gp_kernels.h); above it, and for every
     // other covariance form, kbuild_kernel builds the slot.  Option kbuild_mfma: 0 never, 1 by the bound, 2 always (tests).
+    // The bound B limits the error of an ENTRY (eps B k_ij); what the likelihood sees of it is amplified by the
+    // conditioning of K: with dK_ij = k_ij eta_ij, |eta| <= eps B, the quadratic form moves by a' dK a <= eps B sf^2 |a|^2
+    // <= eps B (sf^2 / sn_min^2) r'K^-1 r and log det by tr(K^-1 dK) <= eps B sf^2 sqrt(N) / sn_min^2 against ~N.  So the
+    // second half of the verdict is eps max(B, 64) (1 + k(x,x) / min nugget) <= 10^-kbuild_mfma_digits (fp64).  Calibrated on
+    // clustered inputs (scripts/gpu_clustered_margin.py -> profiles/r06_clustered_margin.txt: N = 1500-6000, d = 1-3, B = 8-500,
+    // sn = 1e-3 .. 3e-2, 360 cases): the two forms' likelihoods differ by at most 0.15 x this bound (the floor of 64: below
+    // it the difference no longer shrinks with B -- table exponential, other summation order), so at the default 1e-9
+    // a theta routed to the MFMA form stays within 1.5e-10 of the direct form.  The ill-conditioned theta (near-duplicate
+    // points, small nugget) go to the direct form, whose error is eps r^2 k_ij.
     double* dCentre = nullptr;                              // [d]
     std::vector<double> x_centre, x_half;
-    int kbuild_mfma = 1, kbuild_mfma_bound = 512;
+    int kbuild_mfma = 1, kbuild_mfma_bound = 512, kbuild_mfma_digits = 9;
     double test_ratio = 0.0;                                // current test points: largest |x* - centre| / half range over the dimensions
     // batch workspace
     int slots = 0;
@@ -385,7 +394,7 @@ int ensure_slots(gphip_ctx* h, int want, bool workspace = true) {
         host((void**)&h->hCustomP, S * (size_t)std::max(h->ncp, 1) * 8, "pinned covariance-function parameters");
     }
     host((void**)&h->hRes, S * 2 * 8, "pinned results");
-    host((void**)&h->hInfo, (S + 1) * 4, "pinned info words");            // + the dataflow abort flag
+    host((void**)&h->hInfo, (S + 2) * 4, "pinned info words");            // + the dataflow abort flag (factorisations: [nb]; later launches: [S + 1])
     // ON THE HANDLE'S STREAM: the handle's streams are non-blocking, so a null-stream hipMemset is not ordered before
     // the kernels queued next -- a dataflow task could read a recycled allocation's stale flags (another handle's epoch
     // numbers) or tickets before the clear landed.  Found by scripts/gpu_api_fuzz.py (wrong likelihood / memory fault
@@ -891,6 +900,22 @@ bool df_forward_ok(const gphip_ctx* h, int64_t mpad) {
            h->w64_gen == h->fit_gen && mpad <= (h->Npad <= 8192 ? 2 : 1) * (int64_t)h->predict_df && mpad / 64 <= h->Npad / 64;
 }
 
+// The forward / backward / inverse launches above have no finalize kernel behind them to export the abort word (a dependency
+// wait that hit its spin limit makes every later wait of the launch fall through: the results are void).  The caller queues
+// this copy behind them and asks for the verdict after its stream synchronisation.
+int queue_abort_probe(gphip_ctx* h) {
+    HIPCHK(hipMemcpyAsync(h->hInfo + h->slots + 1, reinterpret_cast<int*>(h->dTicket + 1), 4, hipMemcpyDeviceToHost, h->stream));
+    return GPHIP_OK;
+}
+int abort_probe_verdict(gphip_ctx* h, const char* what) {
+    if (h->hInfo[h->slots + 1] == 0) return GPHIP_OK;
+    h->hInfo[h->slots + 1] = 0;
+    HIPCHK(hipMemsetAsync(h->dTicket + 1, 0, 8 + DF_PARK_SLOTS * 4, h->stream));
+    h->fitted = false;                         // the factor itself may be intact, but nothing derived from it in this call is
+    h->u_ready = false;
+    return fail(h, GPHIP_ERR_HIP, what);
+}
+
 template <typename T>
 void launch_finalize(gphip_ctx* h, int nslots, int nparts, int pstride = 0, const double* part2 = nullptr, int n2 = 0) {
     hipLaunchKernelGGL(finalize_kernel<T>, dim3(nslots), dim3(64), 0, h->stream, (const T*)h->dA, (long)h->slot_elems,
@@ -1136,12 +1161,14 @@ bool stage_theta(gphip_ctx* h, int slot, const double* th, const double* nug_row
     const double kxx = (h->ks.op == 1 ? k1 + k2 : (h->ks.op == 2 ? k1 * k2 : k1)) + c;      // k(x, x): every family is 1 at r = 0
     sp[0] = k1; sp[1] = sn * sn; sp[2] = mu;
     sp[SP_SF2B] = k2; sp[SP_ALPHA1] = a1; sp[SP_ALPHA2] = a2; sp[SP_OFFSET] = c; sp[SP_KXX] = kxx;
-    double nug_scale = sn * sn;
+    double nug_scale = sn * sn, nug_min = sn * sn;
     if (nug_row) {                             // point-dependent nugget: the pivot tolerance scales with its largest value
         nug_scale = 0.0;
+        nug_min = HUGE_VAL;
         for (int64_t i = 0; i < h->N; ++i) {
             if (!std::isfinite(nug_row[i])) ok = false;
             nug_scale = std::max(nug_scale, std::fabs(nug_row[i]));
+            nug_min = std::min(nug_min, std::fabs(nug_row[i]));
         }
     }
     if (mean_row)
@@ -1160,7 +1187,12 @@ bool stage_theta(gphip_ctx* h, int slot, const double* th, const double* nug_row
         double bound = 0.0;
         for (int j = 0; j < h->d; ++j) bound += (h->x_half[(size_t)j] * ie[j]) * (h->x_half[(size_t)j] * ie[j]);
         const double lim = h->dtype == 64 ? (double)h->kbuild_mfma_bound : (double)h->kbuild_mfma_bound / 8.0;
-        if (h->kbuild_mfma >= 2 || bound <= lim) sp[SP_MFMA] = 1.0;
+        // entry accuracy (bound <= lim) AND what the conditioning of K makes of it (see gphip_ctx::kbuild_mfma_digits);
+        // fp32 results carry eps32 cond(K) whichever kernel builds K: the same rule 6 digits up
+        const double eps = h->dtype == 64 ? 2.220446049250313e-16 : 5.9604644775390625e-8;
+        const double amp = eps * std::max(bound, 64.0) * (1.0 + std::fabs(kxx) / nug_min);      // (nug_min = 0: inf, the direct form)
+        const double amp_lim = std::pow(10.0, -(double)h->kbuild_mfma_digits + (h->dtype == 64 ? 0.0 : 6.0));
+        if (h->kbuild_mfma >= 2 || (bound <= lim && amp <= amp_lim)) sp[SP_MFMA] = 1.0;
     }
     return ok;
 }
@@ -2071,19 +2103,25 @@ const char* gphip_create_error(void) { return g_create_error.c_str(); }
 /* Compiles a covariance function exactly as gphip_create_custom would, without a handle and without a device (hiprtc
  * cross-compiles): a caller can validate user input early, a deployment can check that the library found hiprtc and carries
  * its kernel text, and the code object lands in the per-process cache the next gphip_create_custom of the same function hits. */
-int gphip_custom_compile(const char* body, int dtype, const char* arch, int grad_nparams, int* cache_hit) {
+int gphip_custom_compile_d(const char* body, int dtype, const char* arch, int grad_nparams, int d, int* cache_hit) {
     g_create_error.clear();
+    if (d < 0) { g_create_error = "negative input dimension"; return GPHIP_ERR_ARG; }
     if (!body || !*body || (dtype != 64 && dtype != 32)) { g_create_error = "null / empty function body or bad dtype"; return GPHIP_ERR_ARG; }
     bool hit = false;
     std::string msg;
     if (grad_nparams == 0 || grad_nparams > 64) { g_create_error = "the gradient program takes 1 .. 64 hyper-parameters"; return GPHIP_ERR_ARG; }
-    const std::shared_ptr<const RtcResult> r = rtc_compile_custom(body, dtype, (arch && *arch) ? arch : "gfx950", msg, &hit, grad_nparams < 0 ? -1 : grad_nparams);
+    const std::shared_ptr<const RtcResult> r = rtc_compile_custom(body, dtype, (arch && *arch) ? arch : "gfx950", msg, &hit, grad_nparams < 0 ? -1 : grad_nparams, d);
     if (cache_hit) *cache_hit = hit ? 1 : 0;
     if (!r) {
         g_create_error = msg;
         return rtc().ok() ? GPHIP_ERR_ARG : GPHIP_ERR_UNSUPPORTED;
     }
     return GPHIP_OK;
+}
+
+/* the dimension-generic program (d = 0): what a handle with d > 32 inputs runs */
+int gphip_custom_compile(const char* body, int dtype, const char* arch, int grad_nparams, int* cache_hit) {
+    return gphip_custom_compile_d(body, dtype, arch, grad_nparams, 0, cache_hit);
 }
 
 static int group_create(const void* X, const void* y, int64_t N, int64_t d, int kernel_id, int mean_id, int dtype,
@@ -2332,10 +2370,13 @@ int gphip_loglik_grad(gphip_handle h, const double* theta, int p, double* out, d
     }
     std::vector<double> gacc(ngacc), alpha;
     HIPCHK(hipMemcpyAsync(gacc.data(), h->dGacc, gacc.size() * 8, hipMemcpyDeviceToHost, h->stream));
+    const bool u_df = potri && h->u_ready;     // U = L^-T came from an inverse launch of the dataflow kernel
+    if (u_df) { rc = queue_abort_probe(h); if (rc) return rc; }
     rc = DISPATCH(h, download, h, alpha, h->dAlpha, (size_t)N, h->stream);
     if (rc) return rc;
     HIPCHK(hipGetLastError());
     harvest(h);
+    if (u_df) { rc = abort_probe_verdict(h, "dataflow inverse launch timed out (set option grad_potri=2 and report)"); if (rc) return rc; }
     h->grad_analytic = 1;
     if (h->custom) {
         // theta = [p_0 .. p_{ncp-1}] sn [mu]  (accumulators: custom_grad_kernel)
@@ -2634,14 +2675,17 @@ static int predict_local(gphip_handle h, const void* Xs, int64_t M, double* mean
         rc = upload_pw_test(h, 0, 1, m0, mc, mpad);
         if (rc) return rc;
         DISPATCH(h, queue_cross, h, mc, mpad, 1);
-        if (df_forward_ok(h, mpad)) launch_dataflow_inverse<double, 64>(h, mpad);
+        const bool dfp = df_forward_ok(h, mpad);
+        if (dfp) launch_dataflow_inverse<double, 64>(h, mpad);
         else DISPATCH(h, queue_forward_rows, h, mpad, 1);
         DISPATCH(h, queue_predict_reduce, h, mc, mpad, 1);
         HIPCHK(hipMemcpyAsync(mean + m0, h->dMean, (size_t)mc * 8, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipMemcpyAsync(var + m0, h->dVar, (size_t)mc * 8, hipMemcpyDeviceToHost, h->stream));
+        if (dfp) { rc = queue_abort_probe(h); if (rc) return rc; }
         HIPCHK(hipStreamSynchronize(h->stream));
         HIPCHK(hipGetLastError());
         harvest(h);
+        if (dfp) { rc = abort_probe_verdict(h, "dataflow forward substitution timed out (set option predict_df=0 and report)"); if (rc) return rc; }
     }
     return GPHIP_OK;
 }
@@ -3039,10 +3083,12 @@ int gphip_solve(gphip_handle h, const double* rhs, int64_t nrhs, double* out) {
         else DISPATCH(h, queue_forward_rows, h, mpad, 1);
         if (dfs && df_backward_ready<double>(h)) launch_dataflow_inverse<double, 64>(h, mpad, true);
         else DISPATCH(h, queue_backward_rows, h, mpad);
+        if (dfs) { rc = queue_abort_probe(h); if (rc) return rc; }
         rc = DISPATCH(h, download, h, v, h->dV, (size_t)mpad * Npad, h->stream);
         if (rc) return rc;
         HIPCHK(hipGetLastError());
         harvest(h);
+        if (dfs) { rc = abort_probe_verdict(h, "dataflow substitution timed out (set option predict_df=0 and report)"); if (rc) return rc; }
         for (int64_t t = 0; t < mc; ++t)
             for (int64_t j = 0; j < N; ++j) out[(m0 + t) * N + j] = v[(size_t)j * mpad + t];
     }
@@ -3271,12 +3317,17 @@ int* option_slot(gphip_ctx* h, const char* name) {
         {"dataflow_occ3", &gphip_ctx::dataflow_occ3},
         {"fused_eval", &gphip_ctx::fuse_option}, {"panel_df", &gphip_ctx::panel_df}, {"grad_potri", &gphip_ctx::grad_potri}, {"predict_df", &gphip_ctx::predict_df},
         {"kbuild_mfma", &gphip_ctx::kbuild_mfma}, {"kbuild_mfma_bound", &gphip_ctx::kbuild_mfma_bound},
+        {"kbuild_mfma_digits", &gphip_ctx::kbuild_mfma_digits},
         {"custom_grad", &gphip_ctx::custom_grad}, {"grad_analytic", &gphip_ctx::grad_analytic},
         {"max_slots", &gphip_ctx::max_slots}, {"shard_min_n", &gphip_ctx::shard_min_n},
         {"replicate_factor", &gphip_ctx::replicate_factor}, {"share_local_panels", &gphip_ctx::share_local_panels},
         {"bcast_chunks", &gphip_ctx::bcast_chunks}, {"bcast_two_hop", &gphip_ctx::bcast_two_hop}, {"dist_panel_df", &gphip_ctx::dist_panel_df},
         {"debug_fail_alloc", &gphip_ctx::debug_fail_alloc}, {"debug_fail_hip", &gphip_ctx::debug_fail_hip},
     };
+    // fault injection ("debug_*") exists for the test-suite only: the names resolve in a process that was started with
+    // GPHIP_TEST_HOOKS=1 and nowhere else (not through GPHIP_OPTIONS either: apply_env_options skips them)
+    static const bool test_hooks = [] { const char* e = getenv("GPHIP_TEST_HOOKS"); return e && !strcmp(e, "1"); }();
+    if (!strncmp(name, "debug_", 6) && !test_hooks) return nullptr;
     for (const Entry& e : table)
         if (!strcmp(name, e.name)) return &(h->*(e.field));
     return nullptr;
@@ -3300,7 +3351,7 @@ void apply_env_options(gphip_ctx* h) {
             key.erase(key.find_last_not_of(" \t") + 1);
             char* stop = nullptr;
             const double v = strtod(item.c_str() + eq + 1, &stop);
-            if (stop != item.c_str() + eq + 1) (void)gphip_set_option(h, key.c_str(), v);
+            if (stop != item.c_str() + eq + 1 && key.compare(0, 6, "debug_") != 0) (void)gphip_set_option(h, key.c_str(), v);
         }
         pos = end + 1;
     }

@@ -87,3 +87,20 @@ def theta_batch(b: int, kernel: str, d: int, seed: int = SEED) -> np.ndarray:
     lo = np.concatenate([np.full(nl, 0.1), [0.1, 0.01]])
     hi = np.concatenate([np.full(nl, 10.0), [10.0, 1.0]])
     return np.exp(np.log(lo) + u * (np.log(hi) - np.log(lo)))
+
+
+def make_clustered(n: int, d: int, clusters: int = 100, spread: float = 1e-4, noise: float = 0.1, seed: int = SEED):
+    """Near-duplicate inputs: ``clusters`` centres uniform in [-0.99, 0.99]^d, every point within ``spread`` of one of
+    them, plus the two corners (-1,..,-1), (1,..,1) so that the half range is exactly 1.  The adversarial case for a
+    kernel build that forms r^2 = |a|^2 + |b|^2 - 2 a.b: short length scales make the norms large while the
+    near-duplicates make K as ill-conditioned as the nugget allows.
+    y = sin(2 sum_j x_j / (1 + j)) + noise * g."""
+    cen = 0.99 * (2.0 * uniform(STREAM_X, 0, clusters * d, seed + 17).reshape(clusters, d) - 1.0)
+    which = (uniform(STREAM_X, 0, n, seed + 18) * clusters).astype(np.int64) % clusters
+    off = spread * (2.0 * uniform(STREAM_X, 0, n * d, seed + 19).reshape(n, d) - 1.0)
+    X = cen[which] + off
+    X[0] = -1.0
+    X[1] = 1.0
+    w = 1.0 / (1.0 + np.arange(d))
+    y = np.sin(2.0 * (X @ w)) + noise * normal(STREAM_NOISE, 0, n, seed + 20)
+    return X, y

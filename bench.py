@@ -755,6 +755,9 @@ def main() -> None:
                                                   "the headline above was measured before this series started"}
                         rec["strong_speedup"] = rec["strong_ms_per_eval"] = rec["rccl_ranks"] = None
                     print(json.dumps(rec), flush=True)
+                # (the failure must not be visible in the JSON line only)
+                print(f"bench: rank {rank}: the optional strong-scaling series did not return within {args.strong_timeout:.0f} s; "
+                      "leaving the process (the weak-scaling headline above was measured before it started)", file=sys.stderr, flush=True)
                 os._exit(3 if args.strict_strong else 0)
         dog = threading.Timer(args.strong_timeout + (0.0 if rank == 0 else 5.0), give_up)
         dog.daemon = True

@@ -102,14 +102,17 @@ int gphip_create_custom_devices(const void* X, const void* y, int64_t N, int64_t
 int gphip_create_custom_rank(const void* X, const void* y, int64_t N, int64_t d, const char* body, int nparams, int mean_id,
                              int dtype, int device, int rank, int world, const void* id128, gphip_handle* out);
 const char* gphip_create_error(void);
-/* Compile `body` exactly as gphip_create_custom would -- no handle, no device needed (hiprtc cross-compiles for `arch`, null =
- * "gfx950").  Validates user input early; proves that a deployed libgphip.so finds hiprtc and carries its own kernel text (the
+/* gphip_custom_compile_d: compile `body` exactly as gphip_create_custom of a d-dimensional problem would (the program is
+ * specialised on the input dimension for 1 <= d <= 32; d = 0 or d > 32: the dimension-generic program) -- no handle, no device
+ * needed (hiprtc cross-compiles for `arch`, null = "gfx950").  Validates user input early; proves that a deployed libgphip.so finds hiprtc and carries its own kernel text (the
  * text of csrc/gp_kernels.h is embedded in the library at build time; $GPHIP_SRC_DIR overrides it for development); and warms
- * the per-process code-object cache (key: body, dtype, arch) that later gphip_create_custom* calls hit.  *cache_hit = 1 when
+ * the per-process code-object cache (key: body, dtype, arch, d) that later gphip_create_custom* calls OF THE SAME d hit.  *cache_hit = 1 when
  * the code object was already there.  grad_nparams < 0: the value program (kernel build + prior variance kernels);
  * 1 .. 64: the GRADIENT program instead -- the same text instantiated with forward-mode dual numbers in its grad_nparams
  * hyper-parameters (csrc/gp_dual.h), what the first gphip_loglik_grad of such a handle compiles.
  * Errors as gphip_create_custom (gphip_create_error() = the compiler's log). */
+int gphip_custom_compile_d(const char* body, int dtype, const char* arch, int grad_nparams, int d, int* cache_hit);
+/* the same with d = 0: validates the function and warms the cache of handles with d > 32 only */
 int gphip_custom_compile(const char* body, int dtype, const char* arch, int grad_nparams, int* cache_hit);
 
 /* ---- host logic shared by the two hosts (pure C++, no device; csrc/gphip_hostlogic.inc) ------------------------------------
@@ -319,13 +322,17 @@ int gphip_ns_crude_weights(const double* points, const double* loglik, int64_t m
  *                  wins depends on the link bandwidth: bench.py --gpus N times both).  Rank-local: need not agree across ranks.
  *   "kbuild_mfma"  0 / 1 (default) / 2: the kernel-matrix build of the SE / Matern-5/2 kernels with the cross term of the squared
  *                  distances on the matrix pipe (kbuild_mfma_kernel): never / for every theta whose accuracy bound
- *                  sum_k (halfrange_k / l_k)^2 <= "kbuild_mfma_bound" (default 512; fp32: / 8) holds / always (tests).  Slots above
- *                  the bound are built by the direct-difference kernel, per theta of a batch.
+ *                  B = sum_k (halfrange_k / l_k)^2 <= "kbuild_mfma_bound" (default 512; fp32: / 8) holds AND whose
+ *                  conditioning keeps that entry error out of the likelihood: eps max(B, 64) (1 + k(x,x) / min nugget) <=
+ *                  10^-"kbuild_mfma_digits" (default 9; fp32: 6 digits up) / always (tests).  Every other theta is built by the
+ *                  direct-difference kernel, per theta of a batch.
  *   "custom_grad"  0/1 (default 1): gphip_loglik_grad of a run-time compiled covariance function through forward-mode dual
  *                  numbers (one factorisation); 0 = central differences.  "grad_analytic" (read-only) = 1 after a gradient call
  *                  that took the one-factorisation route.
  *   "debug_fail_alloc" / "debug_fail_hip" n: tests only -- the n-th device allocation of the next slot allocation / the n-th checked
- *                  HIP call of the next collective sequence fails (fault injection of the multi-process tests).
+ *                  HIP call of the next collective sequence fails (fault injection of the multi-process tests).  The names exist
+ *                  only in a process started with GPHIP_TEST_HOOKS=1 in its environment ("unknown option" otherwise) and are
+ *                  never taken from GPHIP_OPTIONS.
  *   "panel", "shard_min_n", "replicate_factor", "bcast_chunks", "bcast_two_hop" must have the same value on every rank of a
  *   multi-process job (checked by one small all-reduce at the start of every sharded evaluation: a mismatch fails the call on ALL
  *   ranks). */

@@ -3,6 +3,8 @@ checked against numpy on the covariance matrix the LIBRARY itself returns (so no
 script): likelihood parts, batch, fit -> predict / solve / logdet, gradient vs finite differences of the likelihood,
 cross covariance, option flips in between.  Finds state-machine bugs (stale fitted flags, scratch buffers reused at a
 different size, slots re-allocated under a resident factor)."""
+import os
+os.environ["GPHIP_TEST_HOOKS"] = "1"      # (the fault-injection option names exist only with this)
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -9,6 +9,10 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# the library's fault-injection options ("debug_fail_alloc", "debug_fail_hip") resolve only in a process started with this
+# (read once, at the first option call; worker subprocesses inherit it)
+os.environ["GPHIP_TEST_HOOKS"] = "1"
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

@@ -64,5 +64,12 @@ int main() {
     // sqrt at 0 and fabs at 0 stay finite
     const D3 z = sqrt(D3::param(0.0, 0)) + fabs(D3::param(0.0, 1));
     std::printf("at_zero %.3e %.3e\n", std::fabs(z.v), (std::isfinite(z.g[0]) && std::isfinite(z.g[1])) ? 0.0 : 1.0);
+    // Power(r2, 0.5) on the diagonal: r2 = (x - x)^2 / l^2 is a CONSTANT zero (no parameter dependence), the exponent a constant:
+    // b a^(b-1) = inf must not meet the zero partials (inf * 0 = NaN in every derivative); with a parameter-dependent zero
+    // base the derivative follows sqrt's convention (0)
+    const D3 r2 = D3(0.0) / (D3::param(0.7, 0) * D3::param(0.7, 0));
+    const D3 pz = D3::param(1.3, 1) * pow(r2, 0.5) + pow(D3::param(0.0, 2), 0.5) + pow(r2, D3(0.25));
+    std::printf("pow_at_zero %.3e %.3e\n", std::fabs(pz.v), (std::isfinite(pz.g[0]) && std::isfinite(pz.g[1]) && std::isfinite(pz.g[2]) &&
+                                                            pz.g[0] == 0.0 && pz.g[1] == 0.0 && pz.g[2] == 0.0) ? 0.0 : 1.0);
     return 0;
 }

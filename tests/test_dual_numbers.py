@@ -23,7 +23,7 @@ def test_dual_numbers_match_central_differences(tmp_path):
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
     assert out.returncode == 0, out.stderr
     rows = [ln.split() for ln in out.stdout.strip().splitlines()]
-    assert len(rows) == 12, out.stdout
+    assert len(rows) == 13, out.stdout
     for name, verr, gerr in rows:
         assert float(verr) <= 1e-14, (name, verr)
         assert float(gerr) <= 2e-8, (name, gerr)          # (central differences with h = 1e-6 |theta|: ~1e-10 .. 1e-9)

@@ -346,3 +346,36 @@ def test_gradient_fp32_and_fallback_for_a_body_that_cannot_be_differentiated():
     assert info == 0 and h.get_option("grad_analytic") == 0
     np.testing.assert_allclose(g, orc.log_likelihood_grad("se_ard", th64, X, y), rtol=2e-5, atol=2e-5 * n)
     h.close()
+
+
+def test_compile_call_and_create_share_the_code_object_cache():
+    """gphip_custom_compile_d(.., d, ..) compiles THE program a d-dimensional handle runs (specialised on d), so a
+    create after it -- or it after a create -- is a cache hit; the d-generic gphip_custom_compile is another code object.  Also
+    the diagonal of a kernel written with Power(r2, 0.5) must not poison the dual-number gradient (pow at a zero base)."""
+    import ctypes as C
+    lib = _lib.load()
+    d = 3
+    body = SE_ARD_BODY + " /* cache test " + str(np.random.default_rng().integers(1 << 60)) + " */"
+    hit = C.c_int(-1)
+    assert lib.gphip_custom_compile_d(body.encode(), 64, None, -1, d, C.byref(hit)) == 0 and hit.value == 0
+    X, y = syn.make_dataset(300, d)
+    h = _lib.Handle(X, y, _lib.CustomKernel(body, d + 1, fn=se_ard_fn))
+    assert lib.gphip_custom_compile_d(body.encode(), 64, None, -1, d, C.byref(hit)) == 0 and hit.value == 1
+    assert lib.gphip_custom_compile(body.encode(), 64, None, -1, C.byref(hit)) == 0 and hit.value == 0     # d-generic: its own entry
+    body2 = body + " /* second */"
+    h2 = _lib.Handle(X, y, _lib.CustomKernel(body2, d + 1, fn=se_ard_fn))
+    assert lib.gphip_custom_compile_d(body2.encode(), 64, None, -1, d, C.byref(hit)) == 0 and hit.value == 1   # the create compiled it
+    h.close(); h2.close()
+    # Matern-1/2 through Power(r2, 0.5): value and gradient finite and equal to central differences
+    mbody = "T s = 0; for (int k = 0; k < D; ++k) { const T u = (X(k) - Y(k)) / P(0); s += u * u; } return Power(P(1),2) * Exp(-Power(s, 0.5));"
+    ck = _lib.CustomKernel(mbody, 2, fn=lambda A, B, p: p[1] ** 2 * np.exp(-np.sqrt((((A - B) / p[0]) ** 2).sum(-1))))
+    h = _lib.Handle(X, y, ck)
+    th = np.array([0.8, 1.1, 0.2])
+    ll, g, info = h.loglik_grad(th)
+    assert info == 0 and np.all(np.isfinite(g)), g
+    for k in range(3):
+        e = np.zeros(3); e[k] = 1e-5 * th[k]
+        num = (h.loglik(th + e)[0] - h.loglik(th - e)[0]) / (2 * e[k])
+        assert abs(g[k] - num) <= 1e-5 * max(1.0, abs(num)), (k, g[k], num)
+    assert h.get_option("grad_analytic") == 1                                     # (dual numbers, not the central-difference fallback)
+    h.close()

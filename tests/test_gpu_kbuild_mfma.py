@@ -157,3 +157,70 @@ def test_loglik_multi_tile_sizes(n, opts):
         ll, info = h.loglik(th)
         assert info == 0 and abs(ll - want) <= 1e-9 * abs(want), (mode, ll, want)
     h.close()
+
+
+def _clustered_case(n, d, b_target, sn, noise, seed):
+    X, y = syn.make_clustered(n, d, 100, 1e-4, noise, seed=syn.SEED + seed)
+    ell = np.sqrt(d / b_target)                                 # half range is exactly 1 per dimension: B = d / l^2
+    th = np.concatenate([np.full(d, ell), [1.0, sn]])
+    bound = float(np.sum((np.ptp(X, axis=0) / 2 / ell) ** 2))
+    return X, y, th, bound
+
+
+@pytest.mark.parametrize("d", [1, 2, 3])
+@pytest.mark.parametrize("sn", [1e-3, 3e-3])
+@pytest.mark.parametrize("b_target,seed", [(256.0, 1), (400.0, 2), (500.0, 3)])
+def test_clustered_inputs_hold_the_likelihood_bar(d, sn, b_target, seed):
+    """The corner where entry accuracy and conditioning decouple: ~100 clusters
+    of spread 1e-4 (near-duplicate points: cond(K) ~ N_cluster sf^2 / sn^2 ~ 1e7-1e8) with length scales SHORT enough
+    that the MFMA form's norms are large (B in [256, 512], inside its entry bound).  The routing (mode 1) must hand
+    these theta to the direct form -- eps max(B, 64) (1 + sf^2 / sn^2) = 6e-9 .. 1.1e-7 > 1e-9 -- and hold the 1e-8 bar on the
+    likelihood, log det and quadratic form against the oracle (BGP:181-199) with the direct form's margin; the forced
+    MFMA form (mode 2) is only held to 1e-7 here: that is the error the rule keeps out."""
+    n = 3000
+    for noise in (0.1, sn):                    # (y off the model: the quadratic form dominates; y on the model: log det does)
+        X, y, th, bound = _clustered_case(n, d, b_target, sn, noise, seed)
+        assert 250 <= bound <= 512
+        want, ld_o, quad_o, info_o = orc.log_likelihood("se_ard", th, X, y, parts=True)
+        assert info_o == 0
+        h = _lib.Handle(X, y, "se_ard")
+        h.set_option("fused_eval", 0)          # (one theta at this N would build its tiles inside the dataflow launch: direct form)
+        got = {}
+        for mode in (0, 1, 2):
+            h.set_option("kbuild_mfma", mode)
+            ll, ld, quad, info = h.loglik_parts(th)
+            assert info == 0
+            got[mode] = (ll, ld, quad)
+            tol = 1e-8 if mode < 2 else 1e-7
+            assert abs(ll - want) <= tol * abs(want), (mode, noise, ll, want)
+            assert abs(ld - ld_o) <= tol * max(abs(ld_o), n), (mode, noise, ld, ld_o)
+            assert abs(quad - quad_o) <= tol * max(abs(quad_o), n), (mode, noise, quad, quad_o)
+        K0 = None
+        h.set_option("kbuild_mfma", 0)
+        K0 = h.covariance(th)
+        h.set_option("kbuild_mfma", 1)
+        K1 = h.covariance(th)
+        h.close()
+        assert np.array_equal(K0, K1)                                           # mode 1 took the direct form
+        assert abs(got[1][0] - got[0][0]) <= 1e-9 * abs(got[0][0])
+
+
+@pytest.mark.parametrize("d,sn", [(1, 0.011), (2, 0.02), (3, 0.1)])
+def test_clustered_inputs_on_the_mfma_side_of_the_rule(d, sn):
+    """The same inputs with a nugget just large enough that the rule keeps the MFMA form (B = 500: eps B (1 + 1 / sn^2)
+    = 9e-10 at sn = 0.011): mode 1 takes it and stays within 1e-9 of the direct form, 1e-8 of the oracle."""
+    n = 3000
+    X, y, th, bound = _clustered_case(n, d, 500.0, sn, 0.1, 4)
+    assert EPS * bound * (1 + 1 / sn ** 2) <= 1e-9
+    want = orc.log_likelihood("se_ard", th, X, y)
+    h = _lib.Handle(X, y, "se_ard")
+    h.set_option("fused_eval", 0)
+    ll = {}
+    for mode in (0, 1, 2):
+        h.set_option("kbuild_mfma", mode)
+        ll[mode], info = h.loglik(th)
+        assert info == 0
+    h.close()
+    assert ll[1] == ll[2] and ll[1] != ll[0]
+    assert abs(ll[1] - ll[0]) <= 1e-9 * abs(ll[0]), (ll, want)
+    assert abs(ll[1] - want) <= 1e-8 * abs(want)

@@ -946,6 +946,35 @@ def test_failed_slot_allocation_rolls_back_and_the_handle_stays_usable():
     h.close()
 
 
+def test_fault_injection_options_do_not_exist_in_a_product_process():
+    """The "debug_fail_*" options resolve only under GPHIP_TEST_HOOKS=1 (tests/conftest.py sets it): a process without it --
+    any user of the library, the LibraryLink shim -- gets "unknown option", from gphip_set_option and from GPHIP_OPTIONS."""
+    import os
+    import subprocess
+    import sys
+    code = ("import numpy as np\n"
+            "from bayesianinference_amd import _lib, synthetic as syn\n"
+            "X, y = syn.make_dataset(200, 2)\n"
+            "h = _lib.Handle(X, y, 'se_ard')\n"
+            "assert h.get_option('panel') == 6, h.get_option('panel')\n"          # (GPHIP_OPTIONS is read ...)
+            "for name in ('debug_fail_alloc', 'debug_fail_hip'):\n"
+            "    try:\n"
+            "        h.set_option(name, 1)\n"
+            "    except _lib.GphipError as e:\n"
+            "        assert 'unknown option' in str(e), e\n"
+            "    else:\n"
+            "        raise SystemExit('option %s exists' % name)\n"
+            "ll, info = h.loglik_batch(syn.theta_batch(12, 'se_ard', 2))\n"        # (... but did not arm the fault)
+            "assert np.all(np.isfinite(ll))\n"
+            "print('ok')\n")
+    env = {k: v for k, v in os.environ.items() if k != "GPHIP_TEST_HOOKS"}
+    env["GPHIP_OPTIONS"] = "panel=6,debug_fail_alloc=1"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
+    res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0 and "ok" in res.stdout, res.stdout + res.stderr
+
+
 def test_fit_predict_solve_on_the_lookahead_schedule_against_oracle():
     """Fit -> predict / solve / logdet where the factor comes from the look-ahead schedule (N > 12288, ragged): diagonal
     blocks factored by the updates that complete them, 64-tile dataflow tail, 128-block inverses rebuilt for the
