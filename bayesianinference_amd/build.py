@@ -12,7 +12,7 @@ import sys
 
 PKG = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(PKG, "csrc", "gphip.hip")
-DEPS = [SRC, os.path.join(PKG, "csrc", "gp_kernels.h"), os.path.join(PKG, "csrc", "gphip_multi.inc"),
+DEPS = [SRC, os.path.join(PKG, "csrc", "gp_kernels.h"), os.path.join(PKG, "csrc", "gp_trsv.h"), os.path.join(PKG, "csrc", "gphip_multi.inc"),
         os.path.join(PKG, "csrc", "gphip_sampler.inc"), os.path.join(PKG, "csrc", "rtc_dyn.h"), os.path.join(PKG, "csrc", "gp_dual.h"),
         os.path.join(PKG, "csrc", "gphip_hostlogic.inc"),
         os.path.join(PKG, "csrc", "rccl_dyn.h"), os.path.join(os.path.dirname(PKG), "include", "gphip.h")]

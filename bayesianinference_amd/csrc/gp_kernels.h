@@ -712,8 +712,9 @@ __global__ __launch_bounds__(256) void custom_grad_kernel(GradArgs<T> a, const d
 namespace gphip {
 
 // ---------------------------------------------------------------------------------------------
-// kbuild_mfma_kernel: the tiles of kbuild_kernel (K1 / K7, BGP:29-43 and BGP:100-109) for the two named stationary
-// kernels, with the distance loop moved from the vector ALU to the matrix pipe.
+// kbuild_mfma_kernel: the tiles of kbuild_kernel (K1 / K7, BGP:29-43 and BGP:100-109) for the four named stationary
+// families (KT = 0 SE, 1 Matern-5/2, 2 Matern-3/2, 3 rational quadratic; one term, no offset), with the distance loop moved
+// from the vector ALU to the matrix pipe.
 //
 // kbuild_kernel spends 2 fp64 VALU instructions per input dimension and entry on sum ((p_k - q_k) / l_k)^2 and ~12 more
 // on the exponential: at d = 8 the kernel is fp64-VALU bound (0.73 - 0.84 busy, MFMA pipe idle) and its time follows the
@@ -753,8 +754,12 @@ template <typename T, int KS> __host__ __device__ constexpr size_t kbuild_mfma_l
 template <typename T, int KT> struct KmScale;
 template <> struct KmScale<double, 0> { static constexpr double v = EXP_COORD_SCALE_SE; };       // u = table units of exp(-r2 / 2)
 template <> struct KmScale<double, 1> { static constexpr double v = 2.2360679774997896 * EXP_U_PER_ARG; };   // u = (sqrt(5) r 512 / ln2)^2: sqrt(u) in table units
+template <> struct KmScale<double, 2> { static constexpr double v = 1.7320508075688772 * EXP_U_PER_ARG; };   // Matern-3/2: u = (sqrt(3) r 512 / ln2)^2
+template <> struct KmScale<double, 3> { static constexpr double v = 0.70710678118654752; };      // rational quadratic: u = r2 / 2 (q = u / alpha)
 template <> struct KmScale<float, 0> { static constexpr double v = 0.84932180028801904; };        // u = r2 log2(e) / 2
 template <> struct KmScale<float, 1> { static constexpr double v = 2.2360679774997896; };
+template <> struct KmScale<float, 2> { static constexpr double v = 1.7320508075688772; };         // u = 3 r2
+template <> struct KmScale<float, 3> { static constexpr double v = 0.70710678118654752; };
 
 // the entry from its accumulator u >= 0 (cancellation may leave u a few ulp of the norms below zero: clamped)
 // sf2 2^(-w / 512) for w >= 0 in table units (exp_tab_u without its upper clamp: the host's bound on the norms keeps w far
@@ -775,10 +780,29 @@ __device__ __forceinline__ double km_exp_u(double w, const double* __restrict__ 
     const int ki = __double2loint(t);
     return __builtin_ldexp(tab[ki & (EXP_TAB - 1)] * p, ki >> 9);
 }
+// alpha, inv_sf2: the rational quadratic's shape parameter and 1 / sf2 (the LDS table carries sf2)
 template <int KT>
-__device__ __forceinline__ double km_value(double u, double, const double* __restrict__ tab) {
+__device__ __forceinline__ double km_value(double u, double, const double* __restrict__ tab, double alpha = 1.0, double inv_sf2 = 1.0) {
     if (KT == 0) {
         return km_exp_u(u, tab);                                  // (no clamp of u: two fp64 instructions per entry saved)
+    } else if (KT == 2) {
+        // Matern-3/2, (1 + s3) exp(-s3) with s3 = sqrt(3) r = (ln2 / 512) w, w = sqrt(u): the Matern-5/2 recipe without the square term
+        asm("v_max_f64 %0, %1, %2" : "=v"(u) : "v"(u), "v"(1.0e-200));
+        const double y = __builtin_amdgcn_rsq(u);
+        const double e = __builtin_fma(-u * y, y, 1.0);
+        const double w = u * __builtin_fma(0.5 * y, e, y);
+        constexpr double A1 = 1.3538030870311431e-03;
+        return __builtin_fma(A1, w, 1.0) * km_exp_u(w, tab);
+    } else if (KT == 3) {
+        // rational quadratic (1 + q)^-alpha = exp(-alpha log1p(q)), q = r2 / (2 alpha) = u / alpha >= 0.  No fp64 logarithm in
+        // hardware: x0 = ln(1 + q) from v_log_f32 (relative error ~1e-7), one Newton step on exp(x) = 1 + q with the table
+        // exponential, x1 = x0 + ln(1 + dl), dl = (1 + q) exp(-x0) - 1.  Tiny q: the seed is 0 and x1 = q - q^2 / 2.
+        const double q = fmax(u, 0.0) / alpha, yq = 1.0 + q;
+        const double x0 = (double)(__builtin_amdgcn_logf((float)yq) * 0.69314718f);
+        const double ex = km_exp_u(x0 * EXP_U_PER_ARG, tab) * inv_sf2;           // exp(-x0)
+        const double dl = __builtin_fma(yq, ex, -1.0);                          // (1 + q) exp(-x0) - 1, |dl| ~ 1e-7 x0
+        const double x1 = x0 + __builtin_fma(-0.5 * dl, dl, dl);                // ln(1 + dl) to second order: error ~ dl^3 / 3
+        return km_exp_u(alpha * x1 * EXP_U_PER_ARG, tab);
     } else {
         // Matern-5/2 with s5 = sqrt(5) r in table units: w = sqrt(u) by the hardware's reciprocal square root seed and one
         // Newton step (relative error ~4e-15; the IEEE sqrt expansion was 15 instructions), s5 = w ln2 / 512
@@ -792,9 +816,17 @@ __device__ __forceinline__ double km_value(double u, double, const double* __res
     }
 }
 template <int KT>
-__device__ __forceinline__ float km_value(float u, float sf2, const double*) {
+__device__ __forceinline__ float km_value(float u, float sf2, const double*, float alpha = 1.f, float = 1.f) {
     if (KT == 0) {
         return sf2 * __builtin_amdgcn_exp2f(-fmaxf(u, 0.f));
+    } else if (KT == 2) {
+        const float q = fmaxf(u, 1e-30f);
+        const float s3 = q * __builtin_amdgcn_rsqf(q);
+        return sf2 * (1.0f + s3) * __builtin_amdgcn_exp2f(s3 * -1.4426950408889634f);
+    } else if (KT == 3) {
+        // (1 + q)^-alpha = 2^(-alpha log2(1 + q)); log1pf keeps the small-q end at fp32 accuracy
+        const float q = fmaxf(u, 0.f) / alpha;
+        return sf2 * __builtin_amdgcn_exp2f(-alpha * 1.4426950408889634f * log1pf(q));
     } else {
         const float q = fmaxf(u, 1e-30f);
         const float s5 = q * __builtin_amdgcn_rsqf(q);
@@ -828,6 +860,7 @@ __global__ __launch_bounds__(256, 2) void kbuild_mfma_kernel(KBuildMArgs<T> m) {
     const double* sp = a.slotp + (long)slot * SLOTP;
     if (sp[SP_MFMA] == 0.0) return;                 // (kbuild_kernel's slot)
     const T sf2 = (T)sp[0], sn2 = (T)sp[1], mu = (T)sp[2];
+    const T alpha = (T)sp[SP_ALPHA1], inv_sf2 = (T)(1.0 / sp[0]);           // (rational quadratic only)
     const long ldo = (a.mode == 0) ? (long)TB : a.ld;
     T* out = a.out + (long)slot * a.bstride +
              ((a.mode == 0) ? (tile_index(ti, tj, a.nt_i) + (a.adj ? a.adj[panel_slot(tj, a.nt_j, a.own_panel)] : 0l)) * TS
@@ -906,7 +939,7 @@ __global__ __launch_bounds__(256, 2) void kbuild_mfma_kernel(KBuildMArgs<T> m) {
             const int jc = j0 + Num<T>::drow(g, r);
             vec_t v;
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) v[q] = km_value<KT>(acc[q][r], sf2, etab);
+            for (int q = 0; q < NQ; ++q) v[q] = km_value<KT>(acc[q][r], sf2, etab, alpha, inv_sf2);
             if (edge) {
                 const int gj = tj * TB + jc;
 #pragma unroll

@@ -1,0 +1,369 @@
+// gp_trsv.h -- triangular solves with ONE .. FOUR right-hand sides against the blocked factor, streaming L once per solve.
+//
+// The reference's "Inverse"[vector] (BGP:194, 407-412) and alpha = K^-1 r are two substitutions with a matrix that is read
+// exactly once each: HBM-bound, 2 x 268 MB at N = 8192.  The GEMM-shaped substitution of gphip_solve
+// (128 right-hand-side rows at a time, one launch or one dataflow hop per tile column) is latency bound for a single vector.
+// Here ONE launch per triangle:
+//
+//   forward   x_k = W_k (b_k - sum_{c<k} L(k,c) x_c)              W_k = L_kk^-1 (explicit 128 x 128 inverses, resident)
+//   backward  x_k = W_k^T (b_k - sum_{c>k} L(c,k)^T x_c)          the same schedule on mirrored block indices, tiles read transposed
+//
+// * a task = one 128 x 128 tile: s(I,K) = s(I,K-1) - L(I,K) x_K for K <= I-2, held in REGISTERS (64 values per lane, loaded
+//   before the task's inputs exist -- L is static) by the persistent "tile" workgroups, which take tasks from a ticket in
+//   column-major order (a topological order: every dependency belongs to an earlier ticket or to the chain) and prefetch the
+//   next task's tile while they wait for the current one's inputs;
+// * the chain: TRSV_CHAIN "chain" workgroups take the diagonal steps round-robin; step K holds W_K AND the sub-diagonal tile
+//   L(K,K-1) in registers, so x_K = W_K (s(K,K-2) - L(K,K-1) x_{K-1}) is one hand-off per 128 columns;
+// * hand-offs carry NO flags: every 128-vector a task produces goes to its own slot of a scratch buffer that was filled with a
+//   sentinel (all-ones bit pattern, a NaN no finite arithmetic produces) before the launch, written with write-through (sc1)
+//   8-byte stores and polled by the consumer with sc1 loads until no word is the sentinel -- one fabric latency per hop
+//   instead of payload + drain + flag + payload read.  The running sums are a chain per row block (deterministic summation
+//   order, bit-identical results run to run; no atomics).
+// Scratch: nrhs * 128 * Nt (Nt - 1) / 2 values for the row sums (33.5 MB per right-hand side at N = 32768) + the solution.
+#pragma once
+#include "gp_kernels.h"
+
+namespace gphip {
+
+constexpr int TRSV_MAXR = 4;        // right-hand sides per launch
+constexpr int TRSV_CHAIN = 8;       // chain workgroups (each loads 2 tiles per step it owns: 256 KiB every 8 hops)
+constexpr int TRSV_SPIN_LIMIT = 1 << 24;
+#ifndef TRSV_TILE_BACKOFF
+#define TRSV_TILE_BACKOFF 16         // s_sleep units (64 clocks) between a waiting tile task's polls: they have a hop of slack, the chain has none
+#endif
+
+template <typename T>
+struct TrsvArgs {
+    const T* A; int R128;           // packed tile-major factor (slot 0), tile rows of the workspace (Nt + 1)
+    const T* W;                     // [Nt][128 x 128] W_b = L_bb^-1, column-major, explicit zero upper triangle
+    const T* B;                     // [nrhs][ldx] right-hand sides
+    T* X;                           // [nrhs][ldx] solutions; sentinel-filled before the launch
+    T* Xc;                          // [nrhs][ldx] a second copy of the solution that ONLY the next chain step polls (the tile role's
+                                    // hundreds of pollers queue on X's lines at one memory channel); sentinel-filled
+    T* S;                           // [I (I - 1) / 2 + K][nrhs][128] running sums s(I,K), K <= I - 2; sentinel-filled
+    long ldx;
+    int nt, nrhs, back;
+    int dbg;                        // developer timing: 1 = the chain ignores the row sums (wrong results)
+    unsigned int* ticket;           // 0xFFFFFFFF before the launch (part of the sentinel fill)
+    long long* trace;               // developer timing (scripts/micro/trsv_trace.hip): 8 stamps per chain step, or null
+    int* abort_flag;                // shared with the dataflow kernels (set on a spin-limit hit, never cleared here)
+};
+
+template <typename T> struct TrsvBits;
+template <> struct TrsvBits<double> {
+    typedef unsigned long long u;
+    static __device__ __forceinline__ bool pending(double v) { return __double_as_longlong(v) == -1ll; }
+};
+template <> struct TrsvBits<float> {
+    typedef unsigned int u;
+    static __device__ __forceinline__ bool pending(float v) { return __float_as_int(v) == -1; }
+};
+
+// One wave reads nrhs x 128 values that another workgroup is about to write (or wrote long ago) into `dst` (LDS, [r][128]).
+// src(r) = the global address of right-hand side r's 128 values.
+// MODE 0: plain loads (the caller's right-hand side).
+// MODE 1 (tile role): poll ONE word first -- hundreds of waiting workgroups watch the same block -- then the payload.
+// MODE 2 (chain role): poll the payload itself: the hop is one fabric round trip, not two.
+// The word poll of MODE 1 is pipelined (two loads in flight, the older one examined: loads return in order).  The producer's
+// 8-byte stores land within nanoseconds of each other in no particular order: the payload is accepted when no word of it is
+// the sentinel.
+template <typename T, int MODE, typename Src>
+__device__ __forceinline__ void trsv_fetch(Src src, int nrhs, T* dst, int lane, int* abort_flag) {
+    T va[2 * TRSV_MAXR];
+    int spins = 0;
+    auto give_up = [&]() -> bool {
+        if ((++spins & 255) != 0) return false;
+        if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return true;
+        if (spins > TRSV_SPIN_LIMIT) { __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return true; }
+        return false;
+    };
+    auto load_set = [&](T (&v)[2 * TRSV_MAXR]) {
+#pragma unroll
+        for (int r = 0; r < TRSV_MAXR; ++r)
+            if (r < nrhs) {
+                const T* p = src(r);
+                if (MODE == 0) {
+                    v[2 * r] = p[lane];
+                    v[2 * r + 1] = p[64 + lane];
+                } else {
+                    v[2 * r] = __hip_atomic_load(p + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    v[2 * r + 1] = __hip_atomic_load(p + 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+    };
+    auto complete = [&](const T (&v)[2 * TRSV_MAXR]) -> bool {
+        bool bad = false;
+#pragma unroll
+        for (int r = 0; r < TRSV_MAXR; ++r)
+            if (r < nrhs) bad = bad || TrsvBits<T>::pending(v[2 * r]) || TrsvBits<T>::pending(v[2 * r + 1]);
+        return __all(!bad);
+    };
+    if (MODE == 1) {
+        const T* p0 = src(0);
+        T a = __hip_atomic_load(p0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        T b = __hip_atomic_load(p0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        while (__builtin_expect(TrsvBits<T>::pending(a), 0)) {
+            a = b;
+            __builtin_amdgcn_s_sleep(TRSV_TILE_BACKOFF);
+            b = __hip_atomic_load(p0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (give_up()) break;
+        }
+    }
+    load_set(va);
+    if (MODE != 0) {
+        // (the payload poll is NOT pipelined: a load left in flight behind the accepted one would be waited for by the next
+        //  s_waitcnt vmcnt(0) -- half a round trip on the chain -- which is what pipelining would have saved)
+        while (__builtin_expect(!complete(va), 0)) {
+            load_set(va);
+            if (give_up()) break;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < TRSV_MAXR; ++r)
+        if (r < nrhs) {
+            dst[r * TB + lane] = va[2 * r];
+            dst[r * TB + 64 + lane] = va[2 * r + 1];
+        }
+}
+
+// 512 lanes share a column-major 128 x 128 tile: a lane holds the block of 8 entries along the CONTRACTED dimension --
+// columns for y = M x (forward), rows for y = M^T x (backward) -- by 4 along the output dimension.  The 16 lanes of a DPP row
+// (lo = tid & 15) walk the contraction, so the sum over it is a butterfly inside the row (no LDS, no bank conflicts, no
+// barrier); the 32 rows of the workgroup (ob = tid >> 4) are the 32 output blocks of 4.  a[cc][rr] = M(r0 + rr, c0 + cc):
+//   forward   NC = 8, NR = 4, c0 = 8 lo, r0 = 4 ob          backward   NC = 4, NR = 8, c0 = 4 ob, r0 = 8 lo
+template <typename T, bool BACK> struct TrsvBlk {
+    static constexpr int NC = BACK ? 4 : 8, NR = BACK ? 8 : 4;
+    T a[BACK ? 4 : 8][BACK ? 8 : 4];
+};
+template <typename T, bool BACK>
+__device__ __forceinline__ void trsv_load_tile(TrsvBlk<T, BACK>& m, const T* __restrict__ tile, int lo, int ob) {
+    constexpr int NC = TrsvBlk<T, BACK>::NC, NR = TrsvBlk<T, BACK>::NR;
+    const int c0 = BACK ? 4 * ob : 8 * lo, r0 = BACK ? 8 * lo : 4 * ob;
+#pragma unroll
+    for (int cc = 0; cc < NC; ++cc) {
+        const T* p = tile + (long)(c0 + cc) * TB + r0;
+#pragma unroll
+        for (int rr = 0; rr < NR; ++rr) m.a[cc][rr] = p[rr];
+    }
+}
+
+// Wait for every outstanding load of this wave, then tell the compiler that the tile's registers are plain values from here
+// on.  Without this it protects every later use of the tile with a conservative s_waitcnt vmcnt(0) -- loads return in order,
+// and inside these loops it cannot count the younger ones -- which also waits for whatever was issued AFTER the tile: the
+// polls still in flight (a fabric round trip on the chain) or the next task's prefetch.
+template <typename T, bool BACK>
+__device__ __forceinline__ void trsv_settle(TrsvBlk<T, BACK>& m) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int cc = 0; cc < TrsvBlk<T, BACK>::NC; ++cc)
+#pragma unroll
+        for (int rr = 0; rr < TrsvBlk<T, BACK>::NR; ++rr) asm volatile("" : "+v"(m.a[cc][rr]));
+}
+
+template <int CTRL> __device__ __forceinline__ double trsv_dpp(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+template <int CTRL> __device__ __forceinline__ float trsv_dpp(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+// sum over the 16 lanes of a DPP row, the same bits in every lane: xor 1, xor 2 (quad_perm), row_half_mirror, row_mirror --
+// each step pairs lanes that hold the sums of disjoint groups, and a + b = b + a
+template <typename T> __device__ __forceinline__ T trsv_row16_sum(T v) {
+    v += trsv_dpp<0xB1>(v);
+    v += trsv_dpp<0x4E>(v);
+    v += trsv_dpp<0x141>(v);
+    v += trsv_dpp<0x140>(v);
+    return v;
+}
+
+// y[k] = the 4 outputs of this lane's output block for ONE right-hand side (x in LDS, 128 values)
+template <typename T, bool BACK>
+__device__ __forceinline__ void trsv_matvec(const TrsvBlk<T, BACK>& m, const T* x, int lo, T (&y)[4]) {
+    T xv[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) xv[k] = x[lo * 8 + k];
+    if constexpr (!BACK) {
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            T acc = (T)0;
+#pragma unroll
+            for (int cc = 0; cc < 8; ++cc) acc = __builtin_fma(m.a[cc][rr], xv[cc], acc);
+            y[rr] = acc;
+        }
+    } else {
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+            T acc = (T)0;
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr) acc = __builtin_fma(m.a[cc][rr], xv[rr], acc);
+            y[cc] = acc;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) y[k] = trsv_row16_sum(y[k]);
+}
+
+constexpr int TRSV_THREADS = 512;
+
+template <typename T, bool BACK>
+__global__ __launch_bounds__(TRSV_THREADS, 1) void trsv_dataflow_kernel(TrsvArgs<T> g) {
+    constexpr int NC = TrsvBlk<T, BACK>::NC, NR = TrsvBlk<T, BACK>::NR;
+    extern __shared__ double trsv_lds_raw[];
+    __shared__ unsigned int s_q;
+    T* xs = reinterpret_cast<T*>(trsv_lds_raw);            // [4][128] x of the source block
+    T* ss = xs + TRSV_MAXR * TB;                           // [4][128] running sum coming in
+    T* ts = ss + TRSV_MAXR * TB;                           // [4][128] chain step: s - L x, the operand of the W product
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lo = tid & 15, ob = tid >> 4;                // block along the contraction / output block (see trsv_load_tile)
+    const int nt = g.nt, nrhs = g.nrhs;
+    auto blk = [&](int K) { return BACK ? nt - 1 - K : K; };                        // mirrored -> real block index
+    auto sslot = [&](int I, int K) { return g.S + ((long)I * (I - 1) / 2 + K) * nrhs * TB; };
+    auto ltile = [&](int I, int K) {                                                // the tile that couples mirrored blocks I > K
+        const int bi = blk(I), bk = blk(K);
+        return g.A + tile_index(bi > bk ? bi : bk, bi > bk ? bk : bi, g.R128) * TS;
+    };
+
+    if ((int)blockIdx.x < TRSV_CHAIN) {
+        // ---------------- chain role: diagonal steps K = blockIdx.x, + TRSV_CHAIN, ..
+        // (measured and dropped: a row layout for the chain -- 32 contraction entries x 1 output per lane, 41 VALU operations
+        //  per product instead of 80 -- is TWICE as slow, 1.7 vs 0.85 us per product: its 16 LDS reads of x per lane expose the
+        //  LDS latency sixteen times; scripts/micro/trsv_trace.hip, profiles/r06_trsv_chain.txt)
+        TrsvBlk<T, BACK> w, l;
+        for (int K = (int)blockIdx.x; K < nt; K += TRSV_CHAIN) {
+            const int b = blk(K);
+            long long* tr = g.trace ? g.trace + (long)K * 8 : nullptr;
+            long long st[8];                                // (kept in registers until the step is over: a store per stamp would put its own
+            auto stamp = [&](int k) { if (tr) st[k] = wall_clock64(); };     //  completion into the next s_waitcnt vmcnt(0))
+            stamp(0);
+            if (tr) st[6] = clock64();
+            trsv_load_tile<T, BACK>(w, g.W + (long)b * TS, lo, ob);
+            if (K > 0) trsv_load_tile<T, BACK>(l, ltile(K, K - 1), lo, ob);
+            trsv_settle(w);                                 // (this step's inputs are TRSV_CHAIN hops away: the wait is free)
+            trsv_settle(l);
+            // inputs: the row sum so far (or the right-hand side itself), and x of the previous step
+            if (wave == 1) {
+                if (K >= 2 && !(g.dbg & 1)) trsv_fetch<T, 2>([&](int r) { return sslot(K, K - 2) + (long)r * TB; }, nrhs, ss, lane, g.abort_flag);
+                else trsv_fetch<T, 0>([&](int r) { return g.B + (long)r * g.ldx + (long)b * TB; }, nrhs, ss, lane, g.abort_flag);
+            }
+            if (wave == 0 && K > 0)
+                trsv_fetch<T, 2>([&](int r) { return g.Xc + (long)r * g.ldx + (long)blk(K - 1) * TB; }, nrhs, xs, lane, g.abort_flag);
+            stamp(1);
+            __syncthreads();
+            stamp(2);
+            const T* opnd = ss;
+            if (K > 0) {
+                for (int r = 0; r < nrhs; ++r) {
+                    T y[4];
+                    trsv_matvec<T, BACK>(l, xs + r * TB, lo, y);
+                    if (g.dbg & 4) {                        // developer timing: 8 more products (marginal cost of one)
+                        for (int it = 0; it < 8; ++it) {
+                            T y2[4];
+                            asm volatile("" ::: "memory");
+                            trsv_matvec<T, BACK>(l, xs + r * TB, lo, y2);
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) y[k] += (T)1e-300 * y2[k];
+                        }
+                    }
+                    if (lo == 0) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) ts[r * TB + ob * 4 + k] = ss[r * TB + ob * 4 + k] - y[k];
+                    }
+                }
+                stamp(4);
+                __syncthreads();
+                opnd = ts;
+            }
+            stamp(3);
+            for (int r = 0; r < nrhs; ++r) {
+                T y[4];
+                trsv_matvec<T, BACK>(w, opnd + r * TB, lo, y);
+                if (lo == 0) {
+                    T* oc = g.Xc + (long)r * g.ldx + (long)b * TB + ob * 4;                                   // the chain first
+                    T* ox = g.X + (long)r * g.ldx + (long)b * TB + ob * 4;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) __hip_atomic_store(oc + k, y[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) __hip_atomic_store(ox + k, y[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            stamp(5);
+            if (tr) {
+                st[7] = clock64();
+                if (tid == 0)
+                    for (int k = 0; k < 8; ++k) tr[k] = st[k];
+            }
+            __syncthreads();                                // (ts / ss / xs are rewritten by the next step)
+        }
+        return;
+    }
+
+    // ---------------- tile role: tasks (I, K), K <= I - 2, column-major: column K holds I = K + 2 .. nt - 1
+    if (nt < 3) return;
+    const long ntasks = (long)(nt - 2) * (nt - 1) / 2;
+    auto take = [&]() -> long {
+        __syncthreads();                                    // (s_q of the previous take has been read by everybody)
+        if (tid == 0) s_q = atomicAdd(g.ticket, 1u) + 1u;       // (the ticket starts at the sentinel: 0xFFFFFFFF + 1 = task 0)
+        __syncthreads();
+        return (long)s_q;
+    };
+    auto decode = [&](long q, int& I, int& K) {             // off(K) = K (nt - 2) - K (K - 1) / 2
+        const double bq = (double)(2 * nt - 3);
+        int k = (int)((bq - sqrt(bq * bq - 8.0 * (double)q)) * 0.5);
+        if (k < 0) k = 0;
+        if (k > nt - 3) k = nt - 3;
+        while (k + 1 <= nt - 3 && (long)(k + 1) * (nt - 2) - (long)(k + 1) * k / 2 <= q) ++k;
+        while (k > 0 && (long)k * (nt - 2) - (long)k * (k - 1) / 2 > q) --k;
+        K = __builtin_amdgcn_readfirstlane(k);
+        I = __builtin_amdgcn_readfirstlane(k + 2 + (int)(q - ((long)k * (nt - 2) - (long)k * (k - 1) / 2)));
+    };
+    TrsvBlk<T, BACK> ta, tb;
+    long q = take();
+    if (q >= ntasks) return;
+    int I, K;
+    decode(q, I, K);
+    trsv_load_tile<T, BACK>(ta, ltile(I, K), lo, ob);
+    // one task: poll its inputs (behind its own tile's loads, which it needs anyway), settle the tile, THEN take the next ticket and
+    // start that tile's loads -- they fly under this task's arithmetic, its stores and the next task's wait
+    auto process = [&](TrsvBlk<T, BACK>& cur, TrsvBlk<T, BACK>& nxt) -> bool {
+        const long qn = take();
+        int In = 0, Kn = 0;
+        if (qn < ntasks) {
+            decode(qn, In, Kn);
+            trsv_load_tile<T, BACK>(nxt, ltile(In, Kn), lo, ob);   // in flight while this task waits for its inputs
+        }
+        // (the first task of a column, I = K + 2, is the one the chain waits for one hop later: it polls the payload directly)
+        if (wave == 0) {
+            if (I == K + 2) trsv_fetch<T, 2>([&](int r) { return g.X + (long)r * g.ldx + (long)blk(K) * TB; }, nrhs, xs, lane, g.abort_flag);
+            else trsv_fetch<T, 1>([&](int r) { return g.X + (long)r * g.ldx + (long)blk(K) * TB; }, nrhs, xs, lane, g.abort_flag);
+        }
+        if (wave == 1) {
+            if (K > 0) trsv_fetch<T, 1>([&](int r) { return sslot(I, K - 1) + (long)r * TB; }, nrhs, ss, lane, g.abort_flag);
+            else trsv_fetch<T, 0>([&](int r) { return g.B + (long)r * g.ldx + (long)blk(I) * TB; }, nrhs, ss, lane, g.abort_flag);
+        }
+        trsv_settle(cur);                                   // (loads return in order: whoever saw its poll answered has both tiles)
+        trsv_settle(nxt);
+        __syncthreads();
+        T* out = sslot(I, K);
+        for (int r = 0; r < nrhs; ++r) {
+            T y[4];
+            trsv_matvec<T, BACK>(cur, xs + r * TB, lo, y);
+            if (lo == 0) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    __hip_atomic_store(out + (long)r * TB + ob * 4 + k, ss[r * TB + ob * 4 + k] - y[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        I = In; K = Kn;
+        return qn < ntasks;                                 // (the next take()'s barrier frees xs / ss)
+    };
+    for (;;) {
+        if (!process(ta, tb)) return;
+        if (!process(tb, ta)) return;
+    }
+}
+
+constexpr size_t trsv_lds_bytes(size_t es) { return (size_t)(3 * TRSV_MAXR * TB) * es; }
+
+}  // namespace gphip

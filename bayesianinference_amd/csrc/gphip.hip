@@ -13,12 +13,14 @@
 // Work is queued on two handle-owned HIP streams (main + panel/look-ahead); X, y stay resident.
 // Device arithmetic is fp64 (dtype 64) or fp32 (dtype 32); the ABI is fp64 either way.
 #include "gp_kernels.h"
+#include "gp_trsv.h"
 #include "rccl_dyn.h"
 #include "rtc_dyn.h"
 
 #include <hip/hip_ext.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cctype>
 #include <cmath>
 #include <cstdio>
@@ -74,12 +76,15 @@ struct gphip_ctx {
     double *dCustomP = nullptr, *hCustomP = nullptr;   // [slot][ncp]
     double* dKss = nullptr; size_t kss_cap = 0;  // k(x*, x*) of the current test points, [slot][mpad]
     int panel_df = -1;                           // one-GPU look-ahead schedule, one theta, fp64: every outer panel as ONE fused dataflow launch
-    int dist_panel_df = 0;                       // sharded evaluation, fp64: the owner factors its outer panel as ONE 64-tile dataflow launch
-                                                 // (1), which also applies the look-ahead update (2); -1 = 2 when world > 1, else 0
-                                                 // (latency-shaped owner path: flags instead of 3 launches per tile column)
+    int dist_panel_df = -1;                      // sharded evaluation, fp64: the owner factors its outer panel as ONE 64-tile dataflow launch
+                                                 // (1), which also applies the look-ahead update (2); -1 (default) = 2 at world 2, else 0:
+                                                 // a dataflow panel is final only when its launch ends, so its WHOLE transfer sits on the
+                                                 // owner chain, where the per-tile-column schedule keeps only the last column's there -- from
+                                                 // 4 ranks on that outweighs the shorter kernel chain (profiles/r06_scale_model.txt)
     bool dist_df_active = false;                 // the current sharded evaluation runs with dataflow panels (64-block partials / inverses)
     int dist_df_mode = 0;                        // .. and which form (dist_panel_df resolved: 0, 1, 2)
-    int bcast_two_hop = 0;                       // sharded evaluation over RCCL, world > 2: every broadcast as scatter (send / recv) + in-place all-gather
+    int bcast_two_hop = -1;                      // sharded evaluation over RCCL, world > 2: every broadcast as scatter (send / recv) + in-place all-gather;
+                                                 // -1 (default) = on from 4 ranks when the loaded RCCL has send / recv / group calls (two_hop_ok)
     std::vector<hipEvent_t>* col_events = nullptr;   // queue_panel: record "tile column final" events here (owner of a sharded panel)
     int fuse_potrf = 1;                          // option: panel-stream updates factor the diagonal tile they have just updated
     int fuse_b = -1;                             // launch_gemm: request (tile to factor) ...
@@ -178,6 +183,10 @@ struct gphip_ctx {
     size_t part_cap = 0;
     int64_t vcap = 0;
     void* dAlpha = nullptr;                                  // typed [Npad] (gradient)
+    // single-vector substitutions (gp_trsv.h): input block + two passes of {solution, chain copy, row sums, ticket} (trsv_pass_elems)
+    void* dTrsvX = nullptr;
+    int trsv = 1;                                            // option: gphip_solve with <= 4 right-hand sides and alpha through trsv_dataflow_kernel
+    int ncu = 0;                                             // compute units of the device
     void* dKinv = nullptr;                                   // typed [(Npad + GRAD_LD_PAD) x Npad] lower tiles of K^-1 (gradient, potri route)
     double* dGacc = nullptr;                                 // [d + 2] gradient accumulators
     // profiling
@@ -196,6 +205,7 @@ struct gphip_ctx {
     double* dScal8 = nullptr;                    // 8 doubles for the scalar all-reduces (multi-process groups)
     void* drain_buf = nullptr;                   // scratch a draining member broadcasts through (group_drain_buf)
     size_t drain_bytes = 0;
+    int last_issue_us = 0;                       // read-only: host microseconds the last sharded evaluation spent issuing its schedule
     int debug_fail_hip = 0;                      // tests: make the n-th checked HIP call of the next collective sequence fail
     int fit_rank = 0, fit_world = 0;             // the layout a distributed fit was made in
     bool in_group_call = false;                  // set on a member while the group handle runs a sharded call on it
@@ -448,24 +458,37 @@ void launch_kbuild_mfma_kt(gphip_ctx* h, const KBuildMArgs<T>& m, dim3 grid) {
 #undef KM_CASE
 }
 
+// Which family of kbuild_mfma_kernel serves this handle: the two fast paths (kt 0 / 1), and the general form when it is ONE
+// term without offset -- Matern-3/2 (2), rational quadratic (3); -1: composed kernels, run-time compiled functions.
+int mfma_family(const gphip_ctx* h) {
+    if (h->custom) return -1;
+    if (h->kt <= 1) return h->kt;
+    if (h->ks.op == 0 && !h->ks.offset && h->nl2 == 0 && h->ks.fam1 >= 0 && h->ks.fam1 <= 3) return h->ks.fam1;
+    return -1;
+}
+
 // xri / xrj: the RAW (unscaled) row / column points kbuild_mfma_kernel scales itself; null = this build has no such form
 // (the direct kernel builds every slot)
 template <typename T>
 void launch_kbuild(gphip_ctx* h, const KBuildArgs<T>& a0, dim3 grid, const T* xri = nullptr, const T* xrj = nullptr) {
-    if (!h->custom && h->kt <= 1 && xri && xrj) {
+    const int mk = mfma_family(h);                 // family the matrix-pipe build serves this handle with (-1: none)
+    if (!h->custom && mk >= 0 && xri && xrj) {
         int nm = 0;                                // slots of this launch the staged thetas hand to the matrix-pipe build
         for (unsigned s2 = 0; s2 < grid.y; ++s2) nm += h->hSlotp[(size_t)s2 * SLOTP + SP_MFMA] != 0.0;
         if (nm > 0) {
             KBuildMArgs<T> m{};
             m.b = a0; m.xri = xri; m.xrj = xrj; m.inv_ell = h->dInvEll; m.centre = h->dCentre;
-            if (h->kt == 0) launch_kbuild_mfma_kt<T, 0>(h, m, grid);
-            else launch_kbuild_mfma_kt<T, 1>(h, m, grid);
+            if (mk == 0) launch_kbuild_mfma_kt<T, 0>(h, m, grid);
+            else if (mk == 1) launch_kbuild_mfma_kt<T, 1>(h, m, grid);
+            else if (mk == 2) launch_kbuild_mfma_kt<T, 2>(h, m, grid);
+            else launch_kbuild_mfma_kt<T, 3>(h, m, grid);
             if (nm == (int)grid.y) return;
         }
         KBuildArgs<T> a = a0;
         a.mfma_skip = nm > 0;
         if (h->kt == 0) launch_kbuild_kt<T, 0>(h, a, grid);
-        else launch_kbuild_kt<T, 1>(h, a, grid);
+        else if (h->kt == 1) launch_kbuild_kt<T, 1>(h, a, grid);
+        else hipLaunchKernelGGL((kbuild_kernel<T, 0, 2>), grid, dim3(256), a.d > KB_LDS_MAXD ? 64 : (size_t)4 * a.d * TB * sizeof(T), h->cs, a);
         return;
     }
     if (h->custom) {                               // the run-time compiled instantiation kbuild_kernel<T, 0, 3>
@@ -1183,7 +1206,7 @@ bool stage_theta(gphip_ctx* h, int slot, const double* th, const double* nug_row
     sp[4] = ok ? 0.0 : 1.0;
     // which kernel builds this slot's K (see gphip_ctx::kbuild_mfma)
     sp[SP_MFMA] = 0.0;
-    if (h->kbuild_mfma && h->kt <= 1 && h->nl2 == 0 && h->d <= KB_LDS_MAXD && h->dCentre && ok) {
+    if (h->kbuild_mfma && mfma_family(h) >= 0 && h->d <= KB_LDS_MAXD && h->dCentre && ok) {
         double bound = 0.0;
         for (int j = 0; j < h->d; ++j) bound += (h->x_half[(size_t)j] * ie[j]) * (h->x_half[(size_t)j] * ie[j]);
         const double lim = h->dtype == 64 ? (double)h->kbuild_mfma_bound : (double)h->kbuild_mfma_bound / 8.0;
@@ -1752,11 +1775,67 @@ void launch_grad(gphip_ctx* h, GradArgs<T>& a, dim3 grid) {
     }
 }
 
+// ---- substitutions with 1 .. TRSV_MAXR right-hand sides: one launch per triangle, L streamed once (gp_trsv.h) ----
+// The factor of slot 0 and its 128-block inverses (dW) must be resident.  false: not applicable / no memory (the caller keeps
+// the GEMM-shaped substitution).
+// Scratch (one allocation, dTrsvX):  [input block: TRSV_MAXR x Npad] [pass 0] [pass 1],  a pass = {X, Xc: nrhs x Npad each,
+// S: nrhs x 128 x (Nt (Nt - 1) / 2 + 1), ticket: 64 bytes} laid out for the call's nrhs -- everything a launch polls or counts
+// with is ONE contiguous range per call, filled with the sentinel (0xFF bytes) by ONE memset for both passes: the ticket too,
+// the kernel counts from 0xFFFFFFFF + 1.
+size_t trsv_pass_elems(const gphip_ctx* h, int nrhs) {
+    return (size_t)nrhs * ((size_t)2 * h->Npad + (size_t)TB * (size_t)(h->Nt * (h->Nt - 1) / 2 + 1)) + 64 / h->es;
+}
+bool trsv_ok(gphip_ctx* h, int nrhs) {
+    if (!h->trsv || nrhs < 1 || nrhs > TRSV_MAXR || h->Nt > 512 || h->dist_world > 0 || h->ws_override) return false;
+    const size_t bytes = ((size_t)TRSV_MAXR * h->Npad + 2 * trsv_pass_elems(h, TRSV_MAXR)) * h->es;
+    if (!h->dTrsvX && hipMalloc(&h->dTrsvX, bytes) != hipSuccess) { (void)hipGetLastError(); h->dTrsvX = nullptr; return false; }
+    return true;
+}
+template <typename T> T* trsv_input(gphip_ctx* h) { return (T*)h->dTrsvX; }
+template <typename T> T* trsv_pass(gphip_ctx* h, int nrhs, int pass) { return (T*)h->dTrsvX + (size_t)TRSV_MAXR * h->Npad + (size_t)pass * trsv_pass_elems(h, nrhs); }
+
+// the sentinel for `npasses` launches of a call with nrhs right-hand sides
+template <typename T>
+int queue_trsv_fill(gphip_ctx* h, int nrhs, int npasses) {
+    HIPCHK(hipMemsetAsync(trsv_pass<T>(h, nrhs, 0), 0xFF, (size_t)npasses * trsv_pass_elems(h, nrhs) * sizeof(T), h->stream));
+    return GPHIP_OK;
+}
+
+// pass `pass` of the call: X <- L^-1 B (back = false) or L^-T B (back = true); B: [nrhs][Npad]; returns X ([nrhs][Npad]) in *Xout
+template <typename T>
+int queue_trsv(gphip_ctx* h, const T* B, int pass, int nrhs, bool back, T** Xout) {
+    const int nt = (int)h->Nt;
+    T* base = trsv_pass<T>(h, nrhs, pass);
+    TrsvArgs<T> g{};
+    g.A = (const T*)h->dA; g.R128 = (int)h->R; g.W = (const T*)h->dW; g.B = B; g.ldx = (long)h->Npad;
+    g.X = base; g.Xc = base + (size_t)nrhs * h->Npad; g.S = base + (size_t)2 * nrhs * h->Npad;
+    g.ticket = reinterpret_cast<unsigned int*>(g.S + (size_t)nrhs * TB * (size_t)(nt * (nt - 1) / 2 + 1));
+    g.nt = nt; g.nrhs = nrhs; g.back = back ? 1 : 0; g.dbg = h->trsv >> 1;
+    g.abort_flag = reinterpret_cast<int*>(h->dTicket + 1);
+    const long ntasks = nt >= 3 ? (long)(nt - 2) * (nt - 1) / 2 : 0;
+    const long grid = std::min<long>((long)h->ncu, TRSV_CHAIN + ntasks);             // one workgroup per CU: all resident at once
+    ProfScope ps(h, 2, 0.0, (double)h->slot_elems * sizeof(T));
+    if (back) hipLaunchKernelGGL((trsv_dataflow_kernel<T, true>), dim3((unsigned)grid), dim3(TRSV_THREADS), trsv_lds_bytes(sizeof(T)), h->stream, g);
+    else hipLaunchKernelGGL((trsv_dataflow_kernel<T, false>), dim3((unsigned)grid), dim3(TRSV_THREADS), trsv_lds_bytes(sizeof(T)), h->stream, g);
+    *Xout = g.X;
+    return GPHIP_OK;
+}
+
 // alpha = K^-1 r from the fitted factor (z = L^-1 r sits in the rhs row): one backward pass on a
 // 128-row scratch block whose row 0 is z
 template <typename T>
 int queue_alpha(gphip_ctx* h) {
     const int64_t mpad = TB, Npad = h->Npad;
+    if (trsv_ok(h, 1)) {                       // one backward launch that streams L once
+        T *z = trsv_input<T>(h), *x = nullptr;
+        hipLaunchKernelGGL(gather_rhs_row_kernel<T>, dim3((unsigned)((Npad + 255) / 256)), dim3(256), 0, h->stream, (const T*)h->dA,
+                           (int)h->R, 0, (int)Npad, z, 1l);
+        int rc = queue_trsv_fill<T>(h, 1, 1);
+        if (!rc) rc = queue_trsv<T>(h, z, 0, 1, true, &x);
+        if (rc) return rc;
+        HIPCHK(hipMemcpyAsync(h->dAlpha, x, (size_t)Npad * sizeof(T), hipMemcpyDeviceToDevice, h->stream));
+        return GPHIP_OK;
+    }
     HIPCHK(hipMemsetAsync(h->dV, 0, (size_t)mpad * Npad * sizeof(T), h->stream));
     hipLaunchKernelGGL(gather_rhs_row_kernel<T>, dim3((unsigned)((Npad + 255) / 256)), dim3(256), 0, h->stream, (const T*)h->dA,
                        (int)h->R, 0, (int)Npad, (T*)h->dV, (long)mpad);
@@ -1995,6 +2074,10 @@ static int create_ctx(const void* X, const void* y, int64_t N, int64_t d, int ke
     if (device >= 0) h->device = device;
     else (void)hipGetDevice(&h->device);
     if (h->device < 0 || h->device >= ndevs) { delete h; return GPHIP_ERR_NODEVICE; }
+    if (hipDeviceGetAttribute(&h->ncu, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess || h->ncu < 1) {
+        (void)hipGetLastError();
+        h->ncu = 256;
+    }
     h->dtype = dtype;
     h->es = dtype == 64 ? 8 : 4;
     h->N = N; h->d = d;
@@ -2049,7 +2132,7 @@ static int create_ctx(const void* X, const void* y, int64_t N, int64_t d, int ke
     }
     if (DISPATCH(h, upload, h, h->dXt, xt, h->stream) != GPHIP_OK) return bail(GPHIP_ERR_HIP);
     if (DISPATCH(h, upload, h, h->dY, yp, h->stream) != GPHIP_OK) return bail(GPHIP_ERR_HIP);
-    if (kernel_id != GPHIP_KERNEL_NULL && !custom_body && h->kt <= 1) {
+    if (kernel_id != GPHIP_KERNEL_NULL && !custom_body && mfma_family(h) >= 0) {
         // mid-range / half range of the inputs AS THE DEVICE HOLDS THEM (fp32 handles: rounded to float)
         h->x_centre.assign((size_t)d, 0.0); h->x_half.assign((size_t)d, 0.0);
         bool finite = true;
@@ -2218,6 +2301,7 @@ int gphip_destroy(gphip_handle h) {
     if (h->cgmod) (void)hipModuleUnload(h->cgmod);
     (void)hipFree(h->dV); (void)hipFree(h->dXsT); (void)hipFree(h->dXsS); (void)hipFree(h->dMean);
     (void)hipFree(h->dVar); (void)hipFree(h->dAlpha); (void)hipFree(h->dGacc); (void)hipFree(h->dKinv);
+    (void)hipFree(h->dTrsvX);
     (void)hipFree(h->dXsS2); (void)hipFree(h->dPwMeanT); (void)hipFree(h->dPwNugT);
     (void)hipFree(h->dNullMu); (void)hipFree(h->dNullOut); (void)hipFree(h->dPart);
     for (auto e : h->pool) (void)hipEventDestroy(e);
@@ -3064,6 +3148,50 @@ int gphip_solve(gphip_handle h, const double* rhs, int64_t nrhs, double* out) {
     }
     HIPCHK(hipSetDevice(h->device));
     const int64_t N = h->N, Npad = h->Npad, MC = 2048;
+    if (trsv_ok(h, (int)std::min<int64_t>(nrhs, TRSV_MAXR + 1))) {
+        // 1 .. 4 right-hand sides: two launches that stream the factor once each (gp_trsv.h) instead of a 128-row GEMM substitution
+        const int nr = (int)nrhs;
+        h->cs = h->stream;
+        std::vector<double> b((size_t)nr * Npad, 0.0);
+        for (int t = 0; t < nr; ++t)
+            for (int64_t j = 0; j < N; ++j) b[(size_t)t * Npad + j] = rhs[(size_t)t * N + j];
+        // (no synchronisation after the upload: `b` lives until the download below has synchronised the stream)
+        std::vector<float> b32;
+        if (h->dtype == 64) {
+            HIPCHK(hipMemcpyAsync(h->dTrsvX, b.data(), b.size() * 8, hipMemcpyHostToDevice, h->stream));
+        } else {
+            b32.assign(b.begin(), b.end());
+            HIPCHK(hipMemcpyAsync(h->dTrsvX, b32.data(), b32.size() * 4, hipMemcpyHostToDevice, h->stream));
+        }
+        // forward: input -> pass 0; backward: pass 0 -> pass 1
+        int rc;
+        void* xres = nullptr;
+        if (h->dtype == 64) {
+            double *x0 = nullptr, *x1 = nullptr;
+            rc = queue_trsv_fill<double>(h, nr, 2);
+            if (!rc) rc = queue_trsv<double>(h, trsv_input<double>(h), 0, nr, false, &x0);
+            if (!rc) rc = queue_trsv<double>(h, x0, 1, nr, true, &x1);
+            xres = x1;
+        } else {
+            float *x0 = nullptr, *x1 = nullptr;
+            rc = queue_trsv_fill<float>(h, nr, 2);
+            if (!rc) rc = queue_trsv<float>(h, trsv_input<float>(h), 0, nr, false, &x0);
+            if (!rc) rc = queue_trsv<float>(h, x0, 1, nr, true, &x1);
+            xres = x1;
+        }
+        if (rc) return rc;
+        rc = queue_abort_probe(h);
+        if (rc) return rc;
+        rc = DISPATCH(h, download, h, b, xres, (size_t)nr * Npad, h->stream);
+        if (rc) return rc;
+        HIPCHK(hipGetLastError());
+        harvest(h);
+        rc = abort_probe_verdict(h, "single-vector substitution timed out (set option trsv=0 and report)");
+        if (rc) return rc;
+        for (int t = 0; t < nr; ++t)
+            for (int64_t j = 0; j < N; ++j) out[(size_t)t * N + j] = b[(size_t)t * Npad + j];
+        return GPHIP_OK;
+    }
     int rc = ensure_vbuf(h, nrhs < MC ? (nrhs + TB - 1) / TB * TB : MC);
     if (rc) return rc;
     h->cs = h->stream;
@@ -3158,7 +3286,7 @@ int gphip_dist_begin(gphip_handle h, const double* theta, int p, int rank, int w
     rc = copy_theta(h, 1);
     if (rc) return rc;
     HIPCHK(hipMemsetAsync(h->dInfo, 0, 4, h->stream));
-    h->dist_df_mode = (h->dtype == 64 && h->dataflow != 0) ? (h->dist_panel_df < 0 ? (world > 1 ? 2 : 0) : h->dist_panel_df) : 0;
+    h->dist_df_mode = (h->dtype == 64 && h->dataflow != 0) ? (h->dist_panel_df < 0 ? (world == 2 ? 2 : 0) : h->dist_panel_df) : 0;
     h->dist_df_active = h->dist_df_mode != 0;
     h->df_prev_ptr = nullptr; h->df_prev_k = -2;
     HIPCHK(hipMemsetAsync(h->dPartial, 0, (size_t)2 * h->Nt * 8, h->stream));
@@ -3317,7 +3445,7 @@ int* option_slot(gphip_ctx* h, const char* name) {
         {"dataflow_occ3", &gphip_ctx::dataflow_occ3},
         {"fused_eval", &gphip_ctx::fuse_option}, {"panel_df", &gphip_ctx::panel_df}, {"grad_potri", &gphip_ctx::grad_potri}, {"predict_df", &gphip_ctx::predict_df},
         {"kbuild_mfma", &gphip_ctx::kbuild_mfma}, {"kbuild_mfma_bound", &gphip_ctx::kbuild_mfma_bound},
-        {"kbuild_mfma_digits", &gphip_ctx::kbuild_mfma_digits},
+        {"kbuild_mfma_digits", &gphip_ctx::kbuild_mfma_digits}, {"trsv", &gphip_ctx::trsv}, {"last_issue_us", &gphip_ctx::last_issue_us},
         {"custom_grad", &gphip_ctx::custom_grad}, {"grad_analytic", &gphip_ctx::grad_analytic},
         {"max_slots", &gphip_ctx::max_slots}, {"shard_min_n", &gphip_ctx::shard_min_n},
         {"replicate_factor", &gphip_ctx::replicate_factor}, {"share_local_panels", &gphip_ctx::share_local_panels},

@@ -308,14 +308,15 @@ int gphip_ns_crude_weights(const double* points, const double* loglik, int64_t m
  *   "share_local_panels"  0/1 (default 1): ranks that share the owner's GPU (virtual ranks of a 1-GPU box, device-copy
  *                  communicator) read a factored panel where the owner keeps it instead of copying it; 0 forces the copies
  *                  through the rotating receive buffers (what distinct GPUs do)
- *   "bcast_two_hop"  0/1 (default 0): sharded evaluation over RCCL with more than two ranks -- every panel message goes out as
+ *   "bcast_two_hop"  -1 by size (default: on from 4 ranks when the loaded RCCL has send / recv / group calls) / 0 / 1: sharded
+ *                  evaluation over RCCL with more than two ranks -- every panel message goes out as
  *                  scatter (the owner sends piece r to rank r: grouped ncclSend / ncclRecv) + in-place ncclAllGather instead of one
  *                  ncclBroadcast, so that all links of the xGMI mesh carry 1 / world of the message at once (never measured on
  *                  real multi-GPU hardware; results are bit-identical; must agree on all ranks: checked)
  *   "panel_df"     -1 by size (default) / 0 / 1: one theta, fp64, look-ahead schedule -- every outer panel (the look-ahead update by
  *                  the panel before it + its own factorisation) is ONE 64-tile dataflow launch whose tasks read the finished panel as
  *                  extra slabs; by size = 92 <= Nt <= 120 (N = 11k-15k: -2..-8 %, with an 80-column dataflow tail behind the panels)
- *   "dist_panel_df" 0 (default) / 1 / 2: sharded evaluation, fp64 -- the owner factors its outer panel as ONE 64-tile dataflow launch
+ *   "dist_panel_df" -1 (default: 2 at world 2, else 0) / 0 / 1 / 2: sharded evaluation, fp64 -- the owner factors its outer panel as ONE 64-tile dataflow launch
  *                  (1), which also applies the look-ahead update, reading the previous panel from the receive buffer (2): the owner's
  *                  chain of kernels 31.8 -> 22.6 ms per N = 32768 evaluation with the chip to itself, but a panel is then final only
  *                  when its launch ends, so "bcast_chunks" cannot overlap its columns with the factorisation any more (which side

@@ -14,12 +14,18 @@ Model = the dependency graph of group_eval_run replayed with those durations, th
     main stream    REST(k) on every rank: its share of the trailing panels (by tile count), owner(k+2) does panel k+2 first
 A rank's REST share shrinks with the world, but a launch never runs faster than `floor_us` (tail of a grid that no longer
 fills 256 CUs).  Panel-stream work and REST share one GPU: the makespan is at least each rank's total work.
-   python scripts/scale_model.py gpurun_out/owner_path_32768.json [alpha_us beta_GBs]"""
+Host term (round 6): nothing of step k starts before the host thread has issued it -- `issue_us` per rank and outer panel
+(measured: option "last_issue_us" of an 8-virtual-rank evaluation / 8 ranks / panels, scripts/gpu_multi_overhead.py), times
+the number of local ranks when ONE thread drives all of them (a one-process multi-device handle).
+Speed-ups are printed against the model's own one-rank sharded time AND against the plain one-GPU evaluation (`--plain-ms`,
+what bench.py's `strong_speedup` divides by).
+   python scripts/scale_model.py owner_path_32768.json [more.json ..] [--links a_us:b_GBs,..] [--plain-ms 177.1] [--issue-us 35]"""
 import json
 import sys
 
 
-def simulate(data, mode, W, alpha_us, beta_gbs, chunks=True, two_hop=False, split_rest=True, floor_us=25.0, launch_us=6.0):
+def simulate(data, mode, W, alpha_us, beta_gbs, chunks=True, two_hop=False, split_rest=True, floor_us=25.0, launch_us=6.0, issue_us=0.0,
+             one_thread=False, final_at_end=False):
     N, P = data["N"], data["panel_tiles"]
     m = data["modes"][mode]
     f, la, rest = m["factor_us"], m["la_us"], m["rest_us"]
@@ -38,6 +44,9 @@ def simulate(data, mode, W, alpha_us, beta_gbs, chunks=True, two_hop=False, spli
     def own(j):
         return j % W
 
+    def issued(k):                                         # host time at which step k's operations exist on the streams
+        return (k + 1) * issue_us * (W if one_thread else 1)
+
     p = [0.0] * W
     c = [0.0] * W
     mn = [0.0] * W
@@ -48,6 +57,7 @@ def simulate(data, mode, W, alpha_us, beta_gbs, chunks=True, two_hop=False, spli
 
     def factor_and_broadcast(k):
         o = own(k)
+        p[o] = max(p[o], issued(k - 1))
         start = p[o]
         p[o] += f[k]
         work[o] += f[k]
@@ -57,12 +67,13 @@ def simulate(data, mode, W, alpha_us, beta_gbs, chunks=True, two_hop=False, spli
             return
         nin = width[k]
         for i in range(W):
-            t = c[i]
+            t = max(c[i], issued(k - 1))
             if k >= 3:
                 t = max(t, rest_done[k - 3][i])
             if chunks:
                 for s2 in range(nin):
-                    ready = start + (s2 + 1) * (F - start) / nin
+                    # (a dataflow panel launch -- dist_panel_df -- has no 'tile column final' events: every column is ready when it ends)
+                    ready = F if final_at_end else start + (s2 + 1) * (F - start) / nin
                     t = max(t, ready) + alpha + col_tiles[k][s2] * tile_bytes / beta * 1e6
             else:
                 t = max(t, F) + alpha + sum(col_tiles[k]) * tile_bytes / beta * 1e6
@@ -73,7 +84,7 @@ def simulate(data, mode, W, alpha_us, beta_gbs, chunks=True, two_hop=False, spli
     for k in range(nouter):
         if k + 1 < nouter:
             o = own(k + 1)
-            t = max(p[o], B[k][o])
+            t = max(p[o], B[k][o], issued(k))
             if k >= 1:
                 t = max(t, first_done[k - 1][o] if split_rest else rest_done[k - 1][o])
             p[o] = t + la[k]
@@ -82,7 +93,7 @@ def simulate(data, mode, W, alpha_us, beta_gbs, chunks=True, two_hop=False, spli
         lo = k + 2 if k + 1 < nouter else k + 1
         tot = sum(wj[j] for j in range(lo, nouter)) or 1
         for i in range(W):
-            t = max(mn[i], B[k][i])
+            t = max(mn[i], B[k][i], issued(k))
             mine = [j for j in range(lo, nouter) if own(j) == i]
             share = sum(wj[j] for j in mine) / tot
             dur_all = 0.0
@@ -105,37 +116,56 @@ def simulate(data, mode, W, alpha_us, beta_gbs, chunks=True, two_hop=False, spli
 
 
 def main():
-    path = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/owner_path_32768.json"
-    data = json.load(open(path))
-    a0 = float(sys.argv[2]) if len(sys.argv) > 2 else None
-    b0 = float(sys.argv[3]) if len(sys.argv) > 3 else None
-    links = [(a0, b0)] if a0 is not None and b0 is not None else [(10.0, 120.0), (20.0, 60.0), (40.0, 30.0)]
-    variants = [("default (per-tile-column broadcast)", "df0_fuse1", dict(chunks=True)),
-                ("dist_panel_df=2 (one launch per panel)", "df2_fuse0", dict(chunks=True)),
-                ("dist_panel_df=2 + two-hop broadcast", "df2_fuse0", dict(chunks=True, two_hop=True)),
-                ("default, REST(k-1) not split (round 4)", "df0_fuse1", dict(chunks=True, split_rest=False))]
-    print(f"# N = {data['N']}, outer panel = {data['panel_tiles']} tiles; times in ms; speed-up against the model's own one-rank time")
-    for alpha, beta in links:
-        print(f"## alpha = {alpha:.0f} us per collective, beta = {beta:.0f} GB/s per receiver")
-        print("| schedule | 1 GPU | 2 GPUs | 4 GPUs | 8 GPUs | speed-up at 8 | bound at 8 |")
-        print("|---|---|---|---|---|---|---|")
-        for name, mode, kw in variants:
-            if mode not in data["modes"]:
-                continue
-            t = {}
-            why = ""
-            for W in (1, 2, 4, 8):
-                tot, cp, wk = simulate(data, mode, W, alpha, beta, **kw)
-                t[W] = tot
-                if W == 8:
-                    why = "owner chain + links" if cp >= wk else "work per rank"
-            print(f"| {name} | {t[1] / 1e3:.1f} | {t[2] / 1e3:.1f} | {t[4] / 1e3:.1f} | {t[8] / 1e3:.1f} | {t[1] / t[8]:.2f}x | {why} |")
-        # what the chain alone costs at 8 ranks: the floor no link can beat
-        for name, mode, kw in variants[:2]:
+    args = sys.argv[1:]
+    paths, links, plain_ms, issue_us = [], None, 177.07, 0.0
+    i = 0
+    while i < len(args):
+        if args[i] == "--links":
+            links = [tuple(float(x) for x in it.split(":")) for it in args[i + 1].split(",")]
+            i += 2
+        elif args[i] == "--plain-ms":
+            plain_ms = float(args[i + 1])
+            i += 2
+        elif args[i] == "--issue-us":
+            issue_us = float(args[i + 1])
+            i += 2
+        else:
+            paths.append(args[i])
+            i += 1
+    paths = paths or ["gpurun_out/owner_path_32768.json"]
+    links = links or [(10.0, 120.0), (20.0, 60.0), (40.0, 30.0)]
+    # (name, step-time set, simulate() options): "two_hop_from" = world size from which the all-links broadcast is used
+    variants = [("DEFAULT round 6: dist_panel_df=2, two-hop from 4 ranks", "df2_fuse0", dict(chunks=True, final_at_end=True), 4),
+                ("round-5 default: per-tile-column broadcast, 3 launches per tile column", "df0_fuse1", dict(chunks=True), 99),
+                ("dist_panel_df=2, plain broadcast", "df2_fuse0", dict(chunks=True, final_at_end=True), 99),
+                ("round-5 default + two-hop from 4 ranks", "df0_fuse1", dict(chunks=True), 4)]
+    for path in paths:
+        data = json.load(open(path))
+        print(f"# N = {data['N']}, outer panel = {data['panel_tiles']} tiles ({path}); times in ms; host issue {issue_us:.0f} us per rank and panel; "
+              f"plain one-GPU evaluation {plain_ms:.1f} ms")
+        for alpha, beta in links:
+            print(f"## alpha = {alpha:.0f} us per collective, beta = {beta:.0f} GB/s per receiver")
+            print("| schedule | 1 GPU | 2 GPUs | 4 GPUs | 8 GPUs | at 8: vs own 1-rank time | at 8: vs plain one-GPU | one host thread for all 8 ranks | bound at 8 |")
+            print("|---|---|---|---|---|---|---|---|---|")
+            for name, mode, kw, th_from in variants:
+                if mode not in data["modes"]:
+                    continue
+                t = {}
+                why = ""
+                for W in (1, 2, 4, 8):
+                    tot, cp, wk = simulate(data, mode, W, alpha, beta, two_hop=W >= th_from, issue_us=issue_us, **kw)
+                    t[W] = tot
+                    if W == 8:
+                        why = "owner chain + links" if cp >= wk else "work per rank"
+                one, _, _ = simulate(data, mode, 8, alpha, beta, two_hop=8 >= th_from, issue_us=issue_us, one_thread=True, **kw)
+                print(f"| {name} | {t[1] / 1e3:.1f} | {t[2] / 1e3:.1f} | {t[4] / 1e3:.1f} | {t[8] / 1e3:.1f} | {t[1] / t[8]:.2f}x | "
+                      f"{plain_ms * 1e3 / t[8]:.2f}x | {one / 1e3:.1f} ms = {plain_ms * 1e3 / one:.2f}x | {why} |")
+        for name, mode, kw, _ in variants[:2]:
             if mode in data["modes"]:
                 m = data["modes"][mode]
                 print(f"   chain of '{name}': factor {sum(m['factor_us']) / 1e3:.1f} ms + look-ahead {sum(m['la_us']) / 1e3:.1f} ms; "
-                      f"trailing work {sum(m['rest_us']) / 1e3:.1f} ms / 8 = {sum(m['rest_us']) / 8e3:.1f} ms per rank")
+                      f"trailing work {sum(m['rest_us']) / 1e3:.1f} ms / 8 = {sum(m['rest_us']) / 8e3:.1f} ms per rank; "
+                      f"factor bytes per receiver {data['N'] ** 2 * 4 / 1e9:.2f} GB")
 
 
 if __name__ == "__main__":

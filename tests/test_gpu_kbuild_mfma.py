@@ -224,3 +224,70 @@ def test_clustered_inputs_on_the_mfma_side_of_the_rule(d, sn):
     assert ll[1] == ll[2] and ll[1] != ll[0]
     assert abs(ll[1] - ll[0]) <= 1e-9 * abs(ll[0]), (ll, want)
     assert abs(ll[1] - want) <= 1e-8 * abs(want)
+
+
+@pytest.mark.parametrize("kernel,d,n", [("matern32_ard", 5, 300), ("matern32", 2, 257), ("rq_ard", 4, 300), ("rq", 1, 200), ("rq_ard", 13, 150),
+                                        ("matern32_ard", 20, 140)])
+@pytest.mark.parametrize("scale", [1.0, 0.25])
+def test_matern32_and_rational_quadratic_on_the_matrix_pipe(kernel, d, n, scale):
+    """Round 6: the two remaining named families (one term, no offset) take the MFMA form too -- Matern-3/2 with the Matern-5/2
+    recipe, the rational quadratic (1 + r^2 / (2 alpha))^-alpha = exp(-alpha log1p(q)) with a v_log_f32 seed + one Newton step
+    on the table exponential.  Entries of K (BGP:29-43) and k* (BGP:100-109) against the oracle at the 1e-12 bar of the direct
+    form in mode 1 (inside the bound), the likelihood in all three modes, composed kernels stay on the direct form."""
+    X, y = syn.make_dataset(n, d)
+    X = X + 2.0
+    nl = d if kernel.endswith("_ard") else 1
+    ell = (0.3 if d == 1 else 1.0) * scale
+    th = np.array([ell] * nl + ([1.7] if kernel.startswith("rq") else []) + [1.3, 0.2])
+    Ko = orc.covariance_matrix(kernel, th, X)
+    Xs = syn.make_test_points(100, d) + 2.0
+    ko = orc.k_and_kappa(kernel, th, X, Xs)[0]
+    want = orc.log_likelihood(kernel, th, X, y)
+    h = _lib.Handle(X, y, kernel)
+    h.set_option("fused_eval", 0)
+    got = {}
+    bound = float(np.sum((np.ptp(X, axis=0) / 2 / ell) ** 2))
+    for mode in (0, 1, 2):
+        h.set_option("kbuild_mfma", mode)
+        K = h.covariance(th)
+        k, kappa = h.cross_covariance(th, Xs)
+        ll, info = h.loglik(th)
+        got[mode] = K
+        tol = 1e-12 if mode < 2 else max(1e-12, 8 * EPS * bound)
+        np.testing.assert_allclose(K, Ko, rtol=tol, atol=1e-300, err_msg=f"mode {mode}")
+        np.testing.assert_allclose(k, ko, rtol=tol, atol=1e-300, err_msg=f"cross, mode {mode}")
+        assert np.array_equal(K, K.T) and info == 0 and abs(ll - want) <= 1e-9 * abs(want), (mode, ll, want)
+    assert not np.array_equal(got[0], got[2])                      # (the forced mode really took the other kernel)
+    if bound <= 512:
+        assert np.array_equal(got[1], got[2])
+    h.close()
+
+
+def test_composed_kernels_stay_on_the_direct_form():
+    X, y = syn.make_dataset(300, 3)
+    th = np.array([1.0, 1.0, 1.0, 1.2, 0.7, 0.7, 0.7, 0.5, 0.1])
+    h = _lib.Handle(X, y, "se_ard + matern32_ard")
+    K = {}
+    for mode in (0, 2):
+        h.set_option("kbuild_mfma", mode)
+        K[mode] = h.covariance(th)
+    h.close()
+    assert np.array_equal(K[0], K[2])
+
+
+@pytest.mark.parametrize("kernel", ["matern32_ard", "rq_ard"])
+def test_fp32_matern32_and_rq(kernel):
+    d = 6
+    X, y = syn.make_dataset(400, d)
+    th = np.array([1.0] * d + ([2.5] if kernel.startswith("rq") else []) + [1.0, 0.3])
+    Ko = orc.covariance_matrix(kernel, th, X.astype(np.float32).astype(np.float64))
+    h = _lib.Handle(X, y, kernel, dtype=32)
+    lls = {}
+    for mode in (0, 1):
+        h.set_option("kbuild_mfma", mode)
+        K = h.covariance(th)
+        assert np.abs(K - Ko).max() <= (2e-6 if mode == 0 else 6e-6), (mode, np.abs(K - Ko).max())
+        lls[mode], info = h.loglik(th)
+        assert info == 0
+    h.close()
+    assert abs(lls[1] - lls[0]) <= 1e-4 * abs(lls[0])

@@ -716,6 +716,7 @@ def test_solve_dataflow_launches_equal_multi_kernel_substitution(n, d, nrhs):
     rng = np.random.default_rng(n)
     b = rng.standard_normal(n) if nrhs == 1 else rng.standard_normal((n, nrhs))       # N, or N x M: columns are right-hand sides
     h = _lib.Handle(X, y, kernel)
+    h.set_option("trsv", 0)                               # (1 .. 4 vectors would take the single-vector launches, tests/test_gpu_trsv.py)
     out = {}
     for mode in (2048, 0):
         h.set_option("predict_df", mode)
