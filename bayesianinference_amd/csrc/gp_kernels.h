@@ -499,34 +499,8 @@ __global__ __launch_bounds__(256) void kbuild_kernel(KBuildArgs<T> a) {
     const int gi = ti * TB + r0;
     // columns of the tile dealt round-robin to the four waves: at any moment the workgroup writes four ADJACENT 1 KiB
     // column segments (one contiguous 4 KiB of the tile)
-    for (int jj = wave; jj < TB; jj += 4) {
-        T ra = (T)0, rb = (T)0;
-        if constexpr (KT == 3) {
-            // (the caller's function sees the points themselves, not a distance)
-        } else if (D > 0) {
-#pragma unroll
-            for (int dd = 0; dd < D; ++dd) {
-                const T xjv = xjs[dd * TB + jj];
-                const T da = xa[dd] - xjv, db = xb[dd] - xjv;
-                ra = Num<T>::fma_(da, da, ra);
-                rb = Num<T>::fma_(db, db, rb);
-            }
-        } else if (!glb) {
-            for (int dd = 0; dd < d; ++dd) {
-                const T xjv = xjs[dd * TB + jj];
-                const T da = xis[dd * TB + r0] - xjv, db = xis[dd * TB + r0 + 1] - xjv;
-                ra = Num<T>::fma_(da, da, ra);
-                rb = Num<T>::fma_(db, db, rb);
-            }
-        } else {
-            for (int dd = 0; dd < d; ++dd) {
-                const T xjv = xjg[(long)dd * a.npad_j + jj];
-                const pair_t xi = *reinterpret_cast<const pair_t*>(xig + (long)dd * a.npad_i + r0);
-                const T da = xi.x - xjv, db = xi.y - xjv;
-                ra = Num<T>::fma_(da, da, ra);
-                rb = Num<T>::fma_(db, db, rb);
-            }
-        }
+    // everything after the first term's squared distances of column jj: the kernel function, nugget / padding, the store
+    auto finish = [&](int jj, T ra, T rb) {
         T va, vb;
         if constexpr (KT == 3) {
             const double* cp = cpl;
@@ -589,6 +563,59 @@ __global__ __launch_bounds__(256) void kbuild_kernel(KBuildArgs<T> a) {
         v.x = va;
         v.y = vb;
         *reinterpret_cast<pair_t*>(out + (long)jj * ldo + r0) = v;
+    };
+    if constexpr (D == 0 && KT != 3) {
+        if (!glb) {
+            // generic d, points in LDS (round 6): FOUR columns per pass, so that the I-side pair of a dimension is read from LDS
+            // once per four columns instead of once per column -- 1.25 LDS reads per dimension and column instead of 2 (the
+            // loop is LDS-issue bound from d ~ 12 on: SE-ARD d = 24 ran at 0.15 of the HBM rate)
+            for (int j0 = wave; j0 < TB; j0 += 16) {
+                T ra4[4] = {(T)0, (T)0, (T)0, (T)0}, rb4[4] = {(T)0, (T)0, (T)0, (T)0};
+                for (int dd = 0; dd < d; ++dd) {
+                    const pair_t xi = *reinterpret_cast<const pair_t*>(xis + dd * TB + r0);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const T xjv = xjs[dd * TB + j0 + 4 * c];
+                        const T da = xi.x - xjv, db = xi.y - xjv;
+                        ra4[c] = Num<T>::fma_(da, da, ra4[c]);
+                        rb4[c] = Num<T>::fma_(db, db, rb4[c]);
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) finish(j0 + 4 * c, ra4[c], rb4[c]);
+            }
+            return;
+        }
+    }
+    for (int jj = wave; jj < TB; jj += 4) {
+        T ra = (T)0, rb = (T)0;
+        if constexpr (KT == 3) {
+            // (the caller's function sees the points themselves, not a distance)
+        } else if (D > 0) {
+#pragma unroll
+            for (int dd = 0; dd < D; ++dd) {
+                const T xjv = xjs[dd * TB + jj];
+                const T da = xa[dd] - xjv, db = xb[dd] - xjv;
+                ra = Num<T>::fma_(da, da, ra);
+                rb = Num<T>::fma_(db, db, rb);
+            }
+        } else if (!glb) {
+            for (int dd = 0; dd < d; ++dd) {
+                const T xjv = xjs[dd * TB + jj];
+                const T da = xis[dd * TB + r0] - xjv, db = xis[dd * TB + r0 + 1] - xjv;
+                ra = Num<T>::fma_(da, da, ra);
+                rb = Num<T>::fma_(db, db, rb);
+            }
+        } else {
+            for (int dd = 0; dd < d; ++dd) {
+                const T xjv = xjg[(long)dd * a.npad_j + jj];
+                const pair_t xi = *reinterpret_cast<const pair_t*>(xig + (long)dd * a.npad_i + r0);
+                const T da = xi.x - xjv, db = xi.y - xjv;
+                ra = Num<T>::fma_(da, da, ra);
+                rb = Num<T>::fma_(db, db, rb);
+            }
+        }
+        finish(jj, ra, rb);
     }
 }
 
@@ -749,7 +776,8 @@ constexpr int KM_LDP = 144;   // LDS row stride (elements) of the operand tiles:
                               // on disjoint banks (144 * 8 B = 288 dwords = 32 mod 64; 144 * 4 B = 16 mod 32)
 template <typename T, int KS> __host__ __device__ constexpr size_t kbuild_mfma_lds(int d) {
     const int kr = KS > 0 ? 4 * KS : 4 * ((d + 3) / 4);
-    return ((size_t)2 * kr * KM_LDP + 2 * TB) * sizeof(T) + (sizeof(T) == 8 ? (size_t)EXP_TAB * 8 : 0);
+    // (fp64: the I-side tile only, the J-side operand lives in registers -- see the kernel)
+    return ((size_t)(sizeof(T) == 8 ? 1 : 2) * kr * KM_LDP + 2 * TB) * sizeof(T) + (sizeof(T) == 8 ? (size_t)EXP_TAB * 8 : 0);
 }
 template <typename T, int KT> struct KmScale;
 template <> struct KmScale<double, 0> { static constexpr double v = EXP_COORD_SCALE_SE; };       // u = table units of exp(-r2 / 2)
@@ -782,7 +810,7 @@ __device__ __forceinline__ double km_exp_u(double w, const double* __restrict__ 
 }
 // alpha, inv_sf2: the rational quadratic's shape parameter and 1 / sf2 (the LDS table carries sf2)
 template <int KT>
-__device__ __forceinline__ double km_value(double u, double, const double* __restrict__ tab, double alpha = 1.0, double inv_sf2 = 1.0) {
+__device__ __forceinline__ double km_value(double u, double, const double* __restrict__ tab, double alpha = 1.0, double inv_sf2 = 1.0, double inv_alpha = 1.0) {
     if (KT == 0) {
         return km_exp_u(u, tab);                                  // (no clamp of u: two fp64 instructions per entry saved)
     } else if (KT == 2) {
@@ -797,7 +825,7 @@ __device__ __forceinline__ double km_value(double u, double, const double* __res
         // rational quadratic (1 + q)^-alpha = exp(-alpha log1p(q)), q = r2 / (2 alpha) = u / alpha >= 0.  No fp64 logarithm in
         // hardware: x0 = ln(1 + q) from v_log_f32 (relative error ~1e-7), one Newton step on exp(x) = 1 + q with the table
         // exponential, x1 = x0 + ln(1 + dl), dl = (1 + q) exp(-x0) - 1.  Tiny q: the seed is 0 and x1 = q - q^2 / 2.
-        const double q = fmax(u, 0.0) / alpha, yq = 1.0 + q;
+        const double q = fmax(u, 0.0) * inv_alpha, yq = 1.0 + q;              // (a product: an fp64 division is ~20 instructions per entry)
         const double x0 = (double)(__builtin_amdgcn_logf((float)yq) * 0.69314718f);
         const double ex = km_exp_u(x0 * EXP_U_PER_ARG, tab) * inv_sf2;           // exp(-x0)
         const double dl = __builtin_fma(yq, ex, -1.0);                          // (1 + q) exp(-x0) - 1, |dl| ~ 1e-7 x0
@@ -816,7 +844,7 @@ __device__ __forceinline__ double km_value(double u, double, const double* __res
     }
 }
 template <int KT>
-__device__ __forceinline__ float km_value(float u, float sf2, const double*, float alpha = 1.f, float = 1.f) {
+__device__ __forceinline__ float km_value(float u, float sf2, const double*, float alpha = 1.f, float = 1.f, float inv_alpha = 1.f) {
     if (KT == 0) {
         return sf2 * __builtin_amdgcn_exp2f(-fmaxf(u, 0.f));
     } else if (KT == 2) {
@@ -824,9 +852,10 @@ __device__ __forceinline__ float km_value(float u, float sf2, const double*, flo
         const float s3 = q * __builtin_amdgcn_rsqf(q);
         return sf2 * (1.0f + s3) * __builtin_amdgcn_exp2f(s3 * -1.4426950408889634f);
     } else if (KT == 3) {
-        // (1 + q)^-alpha = 2^(-alpha log2(1 + q)); log1pf keeps the small-q end at fp32 accuracy
-        const float q = fmaxf(u, 0.f) / alpha;
-        return sf2 * __builtin_amdgcn_exp2f(-alpha * 1.4426950408889634f * log1pf(q));
+        // (1 + q)^-alpha = 2^(-alpha log2(1 + q)) on v_log_f32 / v_exp_f32 (the library's log1pf made this entry 5x slower than the
+        // other families'; rounding 1 + q costs 6e-8 alpha of relative error in the entry, below the fp32 build's own 1e-6)
+        const float q = fmaxf(u, 0.f) * inv_alpha;
+        return sf2 * __builtin_amdgcn_exp2f(-alpha * __builtin_amdgcn_logf(1.0f + q));
     } else {
         const float q = fmaxf(u, 1e-30f);
         const float s5 = q * __builtin_amdgcn_rsqf(q);
@@ -860,7 +889,7 @@ __global__ __launch_bounds__(256, 2) void kbuild_mfma_kernel(KBuildMArgs<T> m) {
     const double* sp = a.slotp + (long)slot * SLOTP;
     if (sp[SP_MFMA] == 0.0) return;                 // (kbuild_kernel's slot)
     const T sf2 = (T)sp[0], sn2 = (T)sp[1], mu = (T)sp[2];
-    const T alpha = (T)sp[SP_ALPHA1], inv_sf2 = (T)(1.0 / sp[0]);           // (rational quadratic only)
+    const T alpha = (T)sp[SP_ALPHA1], inv_sf2 = (T)(1.0 / sp[0]), inv_alpha = (T)(1.0 / sp[SP_ALPHA1]);   // (rational quadratic only)
     const long ldo = (a.mode == 0) ? (long)TB : a.ld;
     T* out = a.out + (long)slot * a.bstride +
              ((a.mode == 0) ? (tile_index(ti, tj, a.nt_i) + (a.adj ? a.adj[panel_slot(tj, a.nt_j, a.own_panel)] : 0l)) * TS
@@ -880,43 +909,67 @@ __global__ __launch_bounds__(256, 2) void kbuild_mfma_kernel(KBuildMArgs<T> m) {
     }
     const int d = a.d;
     const int ks = KS > 0 ? KS : (d + 3) / 4, kr = 4 * ks;
-    T* xjs = reinterpret_cast<T*>(lds_raw);         // [kr][KM_LDP]  -2 b
-    T* xis = xjs + kr * KM_LDP;                     // [kr][KM_LDP]  a
+    constexpr int KSR = KS > 0 ? KS : KB_LDS_MAXD / 4;    // k-steps a lane keeps J-side operands for (generic build: d <= 32)
+    constexpr bool JREG = sizeof(T) == 8;           // J-side operand in registers (fp64) or in LDS (fp32), see below
+    T* xjs = reinterpret_cast<T*>(lds_raw);         // [kr][KM_LDP]  -2 b  (fp32 only)
+    T* xis = xjs + (JREG ? 0 : kr * KM_LDP);        // [kr][KM_LDP]  a
     T* nrm = xis + kr * KM_LDP;                     // [2][TB]  |b|^2, |a|^2
     const double* etab = reinterpret_cast<const double*>(nrm + 2 * TB);
     if (sizeof(T) == 8) {
         double* et = const_cast<double*>(etab);
         for (int idx = tid; idx < EXP_TAB; idx += 256) et[idx] = sp[0] * a.exp2tab[idx];
     }
+    const double* ie = m.inv_ell + (long)slot * d;
+    const double cs = KmScale<T, KT>::v;
     {   // one thread per point of the two tiles: centre, scale, round to T, norm of the ROUNDED coordinates
         const int side = tid >> 7, p = tid & 127;
         const T* src = side ? m.xri + (long)ti * TB + p : m.xrj + (long)tj * TB + p;
         const long np = side ? a.npad_i : a.npad_j;
         T* dst = (side ? xis : xjs) + p;
-        const double* ie = m.inv_ell + (long)slot * d;
-        const double cs = KmScale<T, KT>::v;
         double n2 = 0.0;
         for (int dd = 0; dd < d; ++dd) {
             const T v = (T)(((double)src[(long)dd * np] - m.centre[dd]) * (ie[dd] * cs));
             n2 = __builtin_fma((double)v, (double)v, n2);
-            dst[dd * KM_LDP] = side ? v : (T)-2 * v;
+            if (side) dst[dd * KM_LDP] = v;
+            else if (!JREG) dst[dd * KM_LDP] = (T)-2 * v;
         }
-        for (int dd = d; dd < kr; ++dd) dst[dd * KM_LDP] = (T)0;
+        if (side || !JREG)
+            for (int dd = d; dd < kr; ++dd) dst[dd * KM_LDP] = (T)0;
         nrm[side * TB + p] = (T)n2;
+    }
+    const int c = lane & 15, g = lane >> 4;
+    // fp64 (round 6): the J-side operand -2 b of this wave's two 16-column blocks lives in REGISTERS: lane (c, g) feeds MFMA step s
+    // with the coordinate k = 4 s + g of column j0 + c -- 2 ks values, the same rounded numbers the norms were formed from.  LDS
+    // then holds the I-side tile only: half the footprint, i.e. more workgroups per CU where it set the occupancy (d = 32: 80 ->
+    // 43 KiB, one -> three workgroups per CU; d = 16: 43 -> 25 KiB): d = 16 0.61 -> 0.67, d = 24 0.45 -> 0.53 of 8 TB/s.  Not fp32:
+    // its tiles are half the size already and the extra registers cost more than the LDS gave (d = 16 0.66 -> 0.60).
+    T avr[2][JREG ? KSR : 1];
+    if constexpr (JREG) {
+#pragma unroll
+        for (int jbi = 0; jbi < 2; ++jbi)
+#pragma unroll
+            for (int s = 0; s < KSR; ++s) {
+                const int k = 4 * s + g;
+                T v = (T)0;
+                if (k < d)
+                    v = (T)-2 * (T)(((double)m.xrj[(long)k * a.npad_j + (long)tj * TB + (wave + 4 * jbi) * 16 + c] - m.centre[k]) * (ie[k] * cs));
+                avr[jbi][s] = v;
+            }
     }
     __syncthreads();
 
-    const int c = lane & 15, g = lane >> 4;
     const bool edge = (a.mode == 0) ? (ti == tj || (ti + 1) * TB > a.n_i)
                                     : ((ti + 1) * TB > a.n_i || (tj + 1) * TB > a.n_j);
-    // 2 column blocks x NIB row blocks per wave, one rolled loop: the operands of a step are re-read from LDS (a handful
-    // of ds_read per ~100 VALU instructions), which keeps the kernel at ~64 registers -- several workgroups per CU, whose
-    // MFMA and VALU phases overlap -- and the code small
+    // 2 column blocks x NIB row blocks per wave; the I-side operands of a step are re-read from LDS (a handful of ds_read per
+    // ~100 VALU instructions), which keeps the kernel small in registers -- several workgroups per CU, whose MFMA and VALU
+    // phases overlap -- and the code small
+#pragma unroll
+    for (int jbi = 0; jbi < 2; ++jbi)
 #pragma unroll 1
-    for (int step = 0; step < 2 * NIB; ++step) {
+    for (int ib = 0; ib < NIB; ++ib) {
         // the four waves take ADJACENT 16-column blocks (w, w + 4): the workgroup's stores of a moment fall into one contiguous
         // 64 KiB of its tile (measured against a wave owning 32 columns: 0.69 -> 0.72 of 8 TB/s; profiles/r05_kbuild_store_order.txt)
-        const int jb = wave + 4 * (step / NIB), ib = step % NIB;
+        const int jb = wave + 4 * jbi;
         const int j0 = jb * 16, i0 = ib * IBR + NQ * c;
         const vec_t nai = *reinterpret_cast<const vec_t*>(nrm + TB + i0);
         acc_t acc[NQ];
@@ -927,11 +980,13 @@ __global__ __launch_bounds__(256, 2) void kbuild_mfma_kernel(KBuildMArgs<T> m) {
             for (int q = 0; q < NQ; ++q) acc[q][r] = nai[q] + nbj;
         }
 #pragma unroll
-        for (int s = 0; s < (KS > 0 ? KS : ks); ++s) {
-            const T av = xjs[(4 * s + g) * KM_LDP + j0 + c];
-            const vec_t bv = *reinterpret_cast<const vec_t*>(xis + (4 * s + g) * KM_LDP + i0);
+        for (int s = 0; s < KSR; ++s) {
+            if (KS > 0 || s < ks) {
+                const T av = JREG ? avr[jbi][JREG ? s : 0] : xjs[(4 * s + g) * KM_LDP + j0 + c];
+                const vec_t bv = *reinterpret_cast<const vec_t*>(xis + (4 * s + g) * KM_LDP + i0);
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) acc[q] = Num<T>::mfma(av, bv[q], acc[q]);
+                for (int q = 0; q < NQ; ++q) acc[q] = Num<T>::mfma(av, bv[q], acc[q]);
+            }
         }
         const int gi0 = ti * TB + i0;
 #pragma unroll
@@ -939,7 +994,7 @@ __global__ __launch_bounds__(256, 2) void kbuild_mfma_kernel(KBuildMArgs<T> m) {
             const int jc = j0 + Num<T>::drow(g, r);
             vec_t v;
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) v[q] = km_value<KT>(acc[q][r], sf2, etab, alpha, inv_sf2);
+            for (int q = 0; q < NQ; ++q) v[q] = km_value<KT>(acc[q][r], sf2, etab, alpha, inv_sf2, inv_alpha);
             if (edge) {
                 const int gj = tj * TB + jc;
 #pragma unroll

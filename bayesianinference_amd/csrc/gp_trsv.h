@@ -12,8 +12,12 @@
 //   before the task's inputs exist -- L is static) by the persistent "tile" workgroups, which take tasks from a ticket in
 //   column-major order (a topological order: every dependency belongs to an earlier ticket or to the chain) and prefetch the
 //   next task's tile while they wait for the current one's inputs;
-// * the chain: TRSV_CHAIN "chain" workgroups take the diagonal steps round-robin; step K holds W_K AND the sub-diagonal tile
-//   L(K,K-1) in registers, so x_K = W_K (s(K,K-2) - L(K,K-1) x_{K-1}) is one hand-off per 128 columns;
+// * the chain: TRSV_CHAIN PAIRS of "chain" workgroups take the diagonal steps round-robin.  x_K = W_K (s(K,K-2) - L(K,K-1) x_{K-1})
+//   is evaluated as W_K s - P_K x_{K-1} with P_K = W_K L(K,K-1) formed once per factor (trsv_prep_kernel): both products start
+//   from the step's INPUTS, so each workgroup of the pair computes 64 of the 128 outputs from its halves of W_K and P_K (in
+//   registers, loaded hops ahead) as ONE sum with ONE reduction -- the arithmetic on the chain is that of a single 128 x 128
+//   product instead of two dependent ones with an LDS round trip between them (hop 3.1 -> 2.x us; an fp64 VALU operation
+//   with fresh operands costs 8-22 clocks per wave here, scripts/micro/valu_rate.hip, profiles/r06_trsv_chain.txt);
 // * hand-offs carry NO flags: every 128-vector a task produces goes to its own slot of a scratch buffer that was filled with a
 //   sentinel (all-ones bit pattern, a NaN no finite arithmetic produces) before the launch, written with write-through (sc1)
 //   8-byte stores and polled by the consumer with sc1 loads until no word is the sentinel -- one fabric latency per hop
@@ -36,6 +40,8 @@ template <typename T>
 struct TrsvArgs {
     const T* A; int R128;           // packed tile-major factor (slot 0), tile rows of the workspace (Nt + 1)
     const T* W;                     // [Nt][128 x 128] W_b = L_bb^-1, column-major, explicit zero upper triangle
+    const T* P;                     // [Nt][128 x 128] the chain's products (trsv_prep_kernel): forward P_b = W_b L(b,b-1), b >= 1;
+                                    // backward P_b = L(b+1,b) W_b, b <= Nt - 2 (applied transposed)
     const T* B;                     // [nrhs][ldx] right-hand sides
     T* X;                           // [nrhs][ldx] solutions; sentinel-filled before the launch
     T* Xc;                          // [nrhs][ldx] a second copy of the solution that ONLY the next chain step polls (the tile role's
@@ -205,6 +211,95 @@ __device__ __forceinline__ void trsv_matvec(const TrsvBlk<T, BACK>& m, const T* 
     for (int k = 0; k < 4; ++k) y[k] = trsv_row16_sum(y[k]);
 }
 
+// ---- the chain's half tiles: 64 outputs x 128 contraction entries over 512 lanes = 8 along the contraction (DPP row) x 2 outputs
+//   forward   a[cc][rr] = M(64 hf + 2 ob + rr, 8 lo + cc)        backward   a[cc][rr] = M(8 lo + rr, 64 hf + 2 ob + cc)
+template <typename T, bool BACK> struct TrsvHalf {
+    static constexpr int NC = BACK ? 2 : 8, NR = BACK ? 8 : 2;
+    T a[BACK ? 2 : 8][BACK ? 8 : 2];
+};
+template <typename T, bool BACK>
+__device__ __forceinline__ void trsv_load_half(TrsvHalf<T, BACK>& m, const T* __restrict__ tile, int lo, int ob, int hf) {
+    constexpr int NC = TrsvHalf<T, BACK>::NC, NR = TrsvHalf<T, BACK>::NR;
+    const int c0 = BACK ? 64 * hf + 2 * ob : 8 * lo, r0 = BACK ? 8 * lo : 64 * hf + 2 * ob;
+#pragma unroll
+    for (int cc = 0; cc < NC; ++cc) {
+        const T* p = tile + (long)(c0 + cc) * TB + r0;
+#pragma unroll
+        for (int rr = 0; rr < NR; ++rr) m.a[cc][rr] = p[rr];
+    }
+}
+template <typename T, bool BACK>
+__device__ __forceinline__ void trsv_settle_half(TrsvHalf<T, BACK>& m) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int cc = 0; cc < TrsvHalf<T, BACK>::NC; ++cc)
+#pragma unroll
+        for (int rr = 0; rr < TrsvHalf<T, BACK>::NR; ++rr) asm volatile("" : "+v"(m.a[cc][rr]));
+}
+// y[k] += sign * (M x) for this lane's two outputs, before the reduction over the DPP row
+template <typename T, bool BACK>
+__device__ __forceinline__ void trsv_half_fma(const TrsvHalf<T, BACK>& m, const T* x, int lo, bool negate, T (&y)[2]) {
+    T xv[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) xv[k] = negate ? -x[lo * 8 + k] : x[lo * 8 + k];
+    if constexpr (!BACK) {
+#pragma unroll
+        for (int cc = 0; cc < 8; ++cc)
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) y[rr] = __builtin_fma(m.a[cc][rr], xv[cc], y[rr]);
+    } else {
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr)
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc) y[cc] = __builtin_fma(m.a[cc][rr], xv[rr], y[cc]);
+    }
+}
+
+// P tiles of one direction (grid = (Nt, 1), 256 threads): forward P_b = W_b L(b,b-1) for b >= 1, backward P_b = L(b+1,b) W_b for
+// b <= Nt - 2; plain LDS-tiled fp64 / fp32 product, once per factor (a few tens of microseconds).
+template <typename T>
+__global__ __launch_bounds__(256) void trsv_prep_kernel(const T* __restrict__ A, int R128, const T* __restrict__ W, T* __restrict__ P, int nt, int back) {
+    __shared__ T As[16][TB + 4], Bs[16][TB + 4];
+    const int b = blockIdx.x, tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    if (back ? b > nt - 2 : b < 1) return;
+    const T* Lt = A + tile_index(back ? b + 1 : b, back ? b : b - 1, R128) * TS;
+    const T* Wb = W + (long)b * TS;
+    const T* Am = back ? Lt : Wb;                           // C = Am Bm
+    const T* Bm = back ? Wb : Lt;
+    T c[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) c[i][j] = (T)0;
+    for (int k0 = 0; k0 < TB; k0 += 16) {
+        for (int idx = tid; idx < 16 * TB; idx += 256) {
+            const int kk = idx >> 7, r = idx & 127;
+            As[kk][r] = Am[(long)(k0 + kk) * TB + r];                      // A(r, k0 + kk)
+        }
+        for (int idx = tid; idx < 16 * TB; idx += 256) {
+            const int cc = idx >> 4, kk = idx & 15;
+            Bs[kk][cc] = Bm[(long)cc * TB + k0 + kk];                      // B(k0 + kk, cc)
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int kk = 0; kk < 16; ++kk) {
+            T av[8], bv[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { av[i] = As[kk][8 * ty + i]; bv[i] = Bs[kk][8 * tx + i]; }
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) c[i][j] = __builtin_fma(av[i], bv[j], c[i][j]);
+        }
+        __syncthreads();
+    }
+    T* Pb = P + (long)b * TS;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) Pb[(long)(8 * tx + j) * TB + 8 * ty + i] = c[i][j];
+}
+
 constexpr int TRSV_THREADS = 512;
 
 template <typename T, bool BACK>
@@ -214,7 +309,6 @@ __global__ __launch_bounds__(TRSV_THREADS, 1) void trsv_dataflow_kernel(TrsvArgs
     __shared__ unsigned int s_q;
     T* xs = reinterpret_cast<T*>(trsv_lds_raw);            // [4][128] x of the source block
     T* ss = xs + TRSV_MAXR * TB;                           // [4][128] running sum coming in
-    T* ts = ss + TRSV_MAXR * TB;                           // [4][128] chain step: s - L x, the operand of the W product
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lo = tid & 15, ob = tid >> 4;                // block along the contraction / output block (see trsv_load_tile)
     const int nt = g.nt, nrhs = g.nrhs;
@@ -225,23 +319,24 @@ __global__ __launch_bounds__(TRSV_THREADS, 1) void trsv_dataflow_kernel(TrsvArgs
         return g.A + tile_index(bi > bk ? bi : bk, bi > bk ? bk : bi, g.R128) * TS;
     };
 
-    if ((int)blockIdx.x < TRSV_CHAIN) {
-        // ---------------- chain role: diagonal steps K = blockIdx.x, + TRSV_CHAIN, ..
-        // (measured and dropped: a row layout for the chain -- 32 contraction entries x 1 output per lane, 41 VALU operations
-        //  per product instead of 80 -- is TWICE as slow, 1.7 vs 0.85 us per product: its 16 LDS reads of x per lane expose the
-        //  LDS latency sixteen times; scripts/micro/trsv_trace.hip, profiles/r06_trsv_chain.txt)
-        TrsvBlk<T, BACK> w, l;
-        for (int K = (int)blockIdx.x; K < nt; K += TRSV_CHAIN) {
+    if ((int)blockIdx.x < 2 * TRSV_CHAIN) {
+        // ---------------- chain role: pair c = blockIdx.x >> 1 takes the diagonal steps K = c, c + TRSV_CHAIN, ..; workgroup hf of the
+        // pair computes outputs 64 hf .. 64 hf + 63 of x_K = W_K s(K,K-2) - P_K x_{K-1}
+        // (measured and dropped: a row layout -- 32 contraction entries x 1 output per lane, half the VALU operations -- is TWICE
+        //  as slow: its 16 LDS reads of x per lane expose the LDS latency sixteen times; profiles/r06_trsv_chain.txt)
+        TrsvHalf<T, BACK> w, pm;
+        const int hf = (int)blockIdx.x & 1;
+        for (int K = (int)blockIdx.x >> 1; K < nt; K += TRSV_CHAIN) {
             const int b = blk(K);
-            long long* tr = g.trace ? g.trace + (long)K * 8 : nullptr;
+            long long* tr = (g.trace && hf == 0) ? g.trace + (long)K * 8 : nullptr;
             long long st[8];                                // (kept in registers until the step is over: a store per stamp would put its own
             auto stamp = [&](int k) { if (tr) st[k] = wall_clock64(); };     //  completion into the next s_waitcnt vmcnt(0))
             stamp(0);
             if (tr) st[6] = clock64();
-            trsv_load_tile<T, BACK>(w, g.W + (long)b * TS, lo, ob);
-            if (K > 0) trsv_load_tile<T, BACK>(l, ltile(K, K - 1), lo, ob);
-            trsv_settle(w);                                 // (this step's inputs are TRSV_CHAIN hops away: the wait is free)
-            trsv_settle(l);
+            trsv_load_half<T, BACK>(w, g.W + (long)b * TS, lo, ob, hf);
+            if (K > 0) trsv_load_half<T, BACK>(pm, g.P + (long)b * TS, lo, ob, hf);
+            trsv_settle_half(w);                            // (this step's inputs are TRSV_CHAIN hops away: the wait is free)
+            trsv_settle_half(pm);
             // inputs: the row sum so far (or the right-hand side itself), and x of the previous step
             if (wave == 1) {
                 if (K >= 2 && !(g.dbg & 1)) trsv_fetch<T, 2>([&](int r) { return sslot(K, K - 2) + (long)r * TB; }, nrhs, ss, lane, g.abort_flag);
@@ -252,49 +347,30 @@ __global__ __launch_bounds__(TRSV_THREADS, 1) void trsv_dataflow_kernel(TrsvArgs
             stamp(1);
             __syncthreads();
             stamp(2);
-            const T* opnd = ss;
-            if (K > 0) {
-                for (int r = 0; r < nrhs; ++r) {
-                    T y[4];
-                    trsv_matvec<T, BACK>(l, xs + r * TB, lo, y);
-                    if (g.dbg & 4) {                        // developer timing: 8 more products (marginal cost of one)
-                        for (int it = 0; it < 8; ++it) {
-                            T y2[4];
-                            asm volatile("" ::: "memory");
-                            trsv_matvec<T, BACK>(l, xs + r * TB, lo, y2);
-#pragma unroll
-                            for (int k = 0; k < 4; ++k) y[k] += (T)1e-300 * y2[k];
-                        }
-                    }
-                    if (lo == 0) {
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) ts[r * TB + ob * 4 + k] = ss[r * TB + ob * 4 + k] - y[k];
-                    }
-                }
-                stamp(4);
-                __syncthreads();
-                opnd = ts;
-            }
             stamp(3);
             for (int r = 0; r < nrhs; ++r) {
-                T y[4];
-                trsv_matvec<T, BACK>(w, opnd + r * TB, lo, y);
+                T y[2] = {(T)0, (T)0};
+                trsv_half_fma<T, BACK>(w, ss + r * TB, lo, false, y);
+                if (K > 0) trsv_half_fma<T, BACK>(pm, xs + r * TB, lo, true, y);
+                y[0] = trsv_row16_sum(y[0]);
+                y[1] = trsv_row16_sum(y[1]);
                 if (lo == 0) {
-                    T* oc = g.Xc + (long)r * g.ldx + (long)b * TB + ob * 4;                                   // the chain first
-                    T* ox = g.X + (long)r * g.ldx + (long)b * TB + ob * 4;
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) __hip_atomic_store(oc + k, y[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) __hip_atomic_store(ox + k, y[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    T* oc = g.Xc + (long)r * g.ldx + (long)b * TB + 64 * hf + 2 * ob;                         // the chain first
+                    T* ox = g.X + (long)r * g.ldx + (long)b * TB + 64 * hf + 2 * ob;
+                    __hip_atomic_store(oc, y[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(oc + 1, y[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(ox, y[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(ox + 1, y[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
+            stamp(4);
             stamp(5);
             if (tr) {
                 st[7] = clock64();
                 if (tid == 0)
                     for (int k = 0; k < 8; ++k) tr[k] = st[k];
             }
-            __syncthreads();                                // (ts / ss / xs are rewritten by the next step)
+            __syncthreads();                                // (ss / xs are rewritten by the next step)
         }
         return;
     }
@@ -364,6 +440,6 @@ __global__ __launch_bounds__(TRSV_THREADS, 1) void trsv_dataflow_kernel(TrsvArgs
     }
 }
 
-constexpr size_t trsv_lds_bytes(size_t es) { return (size_t)(3 * TRSV_MAXR * TB) * es; }
+constexpr size_t trsv_lds_bytes(size_t es) { return (size_t)(2 * TRSV_MAXR * TB) * es; }
 
 }  // namespace gphip

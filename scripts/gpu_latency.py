@@ -3,7 +3,8 @@ import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from bayesianinference_amd import _lib, synthetic as syn
-for n, d, kernel in ((512, 1, "se"), (4096, 8, "se_ard")):
+sizes = [int(a) for a in sys.argv[1:]]
+for n, d, kernel in ([(n_, 8, "se_ard") for n_ in sizes] or [(512, 1, "se"), (4096, 8, "se_ard")]):
     X, y = syn.make_dataset(n, d)
     th = syn.default_theta(kernel, d)
     h = _lib.Handle(X, y, kernel)

@@ -20,9 +20,10 @@ int main(int argc, char** argv) {
     for (auto& v : A) { s = s * 1664525u + 1013904223u; v = ((s >> 8) & 0xffff) / 65536.0 * 1e-4; }
     for (int b = 0; b < Nt; ++b)
         for (int i = 0; i < TB; ++i) W[(size_t)b * TS + (size_t)i * TB + i] = 1.0;
-    double *dA, *dW, *dB, *dX, *dXc, *dS; unsigned int* dT; int* dAb; long long* dTr;
+    double *dA, *dW, *dB, *dX, *dXc, *dS, *dP; unsigned int* dT; int* dAb; long long* dTr;
     const size_t sbytes = (size_t)nrhs * TB * ((size_t)Nt * (Nt - 1) / 2 + 1) * 8;
     hipMalloc(&dA, A.size() * 8); hipMalloc(&dW, W.size() * 8); hipMalloc(&dB, B.size() * 8); hipMalloc(&dX, B.size() * 8);
+    hipMalloc(&dP, W.size() * 8); hipMemcpy(dP, A.data(), W.size() * 8, hipMemcpyHostToDevice);      // (any small numbers)
     hipMalloc(&dXc, B.size() * 8); hipMalloc(&dS, sbytes); hipMalloc(&dT, 256); hipMalloc(&dAb, 256); hipMalloc(&dTr, (size_t)Nt * 64);
     hipMemcpy(dA, A.data(), A.size() * 8, hipMemcpyHostToDevice); hipMemcpy(dW, W.data(), W.size() * 8, hipMemcpyHostToDevice);
     hipMemcpy(dB, B.data(), B.size() * 8, hipMemcpyHostToDevice); hipMemset(dAb, 0, 256);
@@ -34,10 +35,10 @@ int main(int argc, char** argv) {
             hipMemset(dX, 0xFF, B.size() * 8); hipMemset(dXc, 0xFF, B.size() * 8); hipMemset(dS, 0xFF, sbytes); hipMemset(dT, 0xFF, 256);
             hipMemset(dTr, 0, (size_t)Nt * 64);
             TrsvArgs<double> g{};
-            g.A = dA; g.R128 = R128; g.W = dW; g.B = dB; g.X = dX; g.Xc = dXc; g.S = dS; g.ldx = npad; g.nt = Nt; g.nrhs = nrhs; g.back = back;
+            g.A = dA; g.R128 = R128; g.W = dW; g.P = dP; g.B = dB; g.X = dX; g.Xc = dXc; g.S = dS; g.ldx = npad; g.nt = Nt; g.nrhs = nrhs; g.back = back;
             g.dbg = dbg; g.ticket = dT; g.abort_flag = dAb; g.trace = dTr;
             const long ntasks = Nt >= 3 ? (long)(Nt - 2) * (Nt - 1) / 2 : 0;
-            const long grid = std::min<long>(nwg, TRSV_CHAIN + ntasks);
+            const long grid = std::min<long>(nwg, 2 * TRSV_CHAIN + ntasks);
             hipEventRecord(e0, 0);
             if (back) hipLaunchKernelGGL((trsv_dataflow_kernel<double, true>), dim3((unsigned)grid), dim3(TRSV_THREADS), trsv_lds_bytes(8), 0, g);
             else hipLaunchKernelGGL((trsv_dataflow_kernel<double, false>), dim3((unsigned)grid), dim3(TRSV_THREADS), trsv_lds_bytes(8), 0, g);
@@ -55,14 +56,14 @@ int main(int argc, char** argv) {
         for (int K = 2; K < Nt; ++K) {
             const long long* t = &tr[(size_t)K * 8]; const long long* p = &tr[(size_t)(K - 1) * 8];
             if (K % (Nt / 8 > 0 ? Nt / 8 : 1) == 3)
-                printf("  step %3d: prev stored -> x seen %5.2f | barrier %5.2f | s - L x %5.2f | W t + store %5.2f | step start was %7.2f before x seen\n",
+                printf("  step %3d: prev stored -> x seen %5.2f | barrier %5.2f | (unused) %5.2f | W s - P x + store %5.2f | step start was %7.2f before x seen\n",
                        K, us(t[1], p[5]), us(t[2], t[1]), us(t[3], t[2]), us(t[5], t[3]), us(t[1], t[0]));
             acc[0] += us(t[1], p[5]); acc[1] += us(t[2], t[1]); acc[2] += us(t[3], t[2]); acc[3] += us(t[5], t[3]);
             acc[5] += us(t[5], p[5]); mv += us(t[4], t[2]);
             acc[4] += (double)(t[7] - t[6]) / (double)(t[5] - t[0]) * 100.0;          // shader clocks per 10 ns tick -> MHz
             ++cnt;
         }
-        printf("  mean over %d steps: hand-off %.2f | barrier %.2f | s - L x %.2f | W t + store %.2f || store-to-store %.2f us | shader clock %.0f MHz | L x alone (wave 0, before the barrier) %.2f\n", cnt,
+        printf("  mean over %d steps: hand-off %.2f | barrier %.2f | (unused) %.2f | W s - P x + reduction + store %.2f || store-to-store %.2f us | shader clock %.0f MHz | (unused %.2f)\n", cnt,
                acc[0] / cnt, acc[1] / cnt, acc[2] / cnt, acc[3] / cnt, acc[5] / cnt, acc[4] / cnt, mv / cnt);
     }
     return 0;

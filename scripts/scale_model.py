@@ -135,10 +135,15 @@ def main():
     paths = paths or ["gpurun_out/owner_path_32768.json"]
     links = links or [(10.0, 120.0), (20.0, 60.0), (40.0, 30.0)]
     # (name, step-time set, simulate() options): "two_hop_from" = world size from which the all-links broadcast is used
-    variants = [("DEFAULT round 6: dist_panel_df=2, two-hop from 4 ranks", "df2_fuse0", dict(chunks=True, final_at_end=True), 4),
-                ("round-5 default: per-tile-column broadcast, 3 launches per tile column", "df0_fuse1", dict(chunks=True), 99),
-                ("dist_panel_df=2, plain broadcast", "df2_fuse0", dict(chunks=True, final_at_end=True), 99),
-                ("round-5 default + two-hop from 4 ranks", "df0_fuse1", dict(chunks=True), 4)]
+    # (name, W -> (step-time set, simulate() options)).  The library's default since round 6 (gphip_multi.inc group_eval_run,
+    # gphip_dist_begin): 2 ranks = dataflow panels (final at launch end), plain broadcast; 3+ ranks = per-tile-column panels,
+    # from 4 ranks every message as scatter + in-place all-gather over all links.
+    df0 = lambda two_hop: ("df0_fuse1", dict(chunks=True, two_hop=two_hop))
+    df2 = lambda two_hop: ("df2_fuse0", dict(chunks=True, final_at_end=True, two_hop=two_hop))
+    variants = [("DEFAULT round 6: dataflow panels at 2 ranks; per-tile-column panels + two-hop from 4 ranks", lambda W: df2(False) if W == 2 else df0(W >= 4)),
+                ("round-5 default: per-tile-column panels, plain ncclBroadcast", lambda W: df0(False)),
+                ("dataflow panels (dist_panel_df=2), plain broadcast", lambda W: df2(False)),
+                ("dataflow panels + two-hop from 4 ranks", lambda W: df2(W >= 4))]
     for path in paths:
         data = json.load(open(path))
         print(f"# N = {data['N']}, outer panel = {data['panel_tiles']} tiles ({path}); times in ms; host issue {issue_us:.0f} us per rank and panel; "
@@ -147,25 +152,29 @@ def main():
             print(f"## alpha = {alpha:.0f} us per collective, beta = {beta:.0f} GB/s per receiver")
             print("| schedule | 1 GPU | 2 GPUs | 4 GPUs | 8 GPUs | at 8: vs own 1-rank time | at 8: vs plain one-GPU | one host thread for all 8 ranks | bound at 8 |")
             print("|---|---|---|---|---|---|---|---|---|")
-            for name, mode, kw, th_from in variants:
-                if mode not in data["modes"]:
-                    continue
+            for name, pick in variants:
                 t = {}
                 why = ""
                 for W in (1, 2, 4, 8):
-                    tot, cp, wk = simulate(data, mode, W, alpha, beta, two_hop=W >= th_from, issue_us=issue_us, **kw)
+                    mode, kw = pick(W)
+                    tot, cp, wk = simulate(data, mode, W, alpha, beta, issue_us=issue_us, **kw)
                     t[W] = tot
                     if W == 8:
                         why = "owner chain + links" if cp >= wk else "work per rank"
-                one, _, _ = simulate(data, mode, 8, alpha, beta, two_hop=8 >= th_from, issue_us=issue_us, one_thread=True, **kw)
+                mode, kw = pick(8)
+                one, _, _ = simulate(data, mode, 8, alpha, beta, issue_us=issue_us, one_thread=True, **kw)
                 print(f"| {name} | {t[1] / 1e3:.1f} | {t[2] / 1e3:.1f} | {t[4] / 1e3:.1f} | {t[8] / 1e3:.1f} | {t[1] / t[8]:.2f}x | "
                       f"{plain_ms * 1e3 / t[8]:.2f}x | {one / 1e3:.1f} ms = {plain_ms * 1e3 / one:.2f}x | {why} |")
-        for name, mode, kw, _ in variants[:2]:
+        for label, mode in (("per-tile-column panels", "df0_fuse1"), ("dataflow panels", "df2_fuse0")):
             if mode in data["modes"]:
                 m = data["modes"][mode]
-                print(f"   chain of '{name}': factor {sum(m['factor_us']) / 1e3:.1f} ms + look-ahead {sum(m['la_us']) / 1e3:.1f} ms; "
+                print(f"   owner chain, {label}: factor {sum(m['factor_us']) / 1e3:.1f} ms + look-ahead {sum(m['la_us']) / 1e3:.1f} ms; "
                       f"trailing work {sum(m['rest_us']) / 1e3:.1f} ms / 8 = {sum(m['rest_us']) / 8e3:.1f} ms per rank; "
-                      f"factor bytes per receiver {data['N'] ** 2 * 4 / 1e9:.2f} GB")
+                      f"factor bytes per receiver {data['N'] ** 2 * 4 / 1e9:.2f} GB "
+                      f"(= {data['N'] ** 2 * 4 / 1e9 / 0.06:.0f} ms over ONE 60 GB/s link, {data['N'] ** 2 * 4 / 1e9 / 0.24:.0f} ms two-hop at 8 ranks)")
+        print("   term that forbids 6x (= %.1f ms at 8 GPUs): the owner chain (factor + look-ahead, 33.6 ms per-tile-column / 23.5 ms dataflow) is SERIAL across\n"
+              "   panels and each hop of it also waits for the last tile column's (per-tile-column) or the whole panel's (dataflow) transfer; a rank's\n"
+              "   trailing share (21 ms) hides under it, not the other way round." % (plain_ms / 6.0))
 
 
 if __name__ == "__main__":

@@ -49,6 +49,41 @@ for k in sorted(agg):
     iv, im = agg[k].get("SQ_INSTS_VALU"), agg[k].get("SQ_INSTS_MFMA")
     if iv and "kbuild" in k:
         lines.append(f"# {k}: SQ_INSTS_VALU/launch {sum(iv)/len(iv):.4g}" + (f", SQ_INSTS_MFMA/launch {sum(im)/len(im):.4g}" if im else ""))
+# shader clock per kernel: SQ_BUSY_CYCLES is summed over the 32 shader engines -> clock = value / 32 / duration; taken from every
+# PMC pass that carries the counter together with the dispatch's timestamps (the file's launches run one at a time)
+clk = collections.defaultdict(list)
+for sub in subs:
+    path = os.path.join(src, sub, "bench_counter_collection.csv")
+    if not os.path.exists(path):
+        continue
+    with open(path) as f:
+        for row in csv.DictReader(f):
+            if row["Counter_Name"] == "SQ_BUSY_CYCLES" and "Start_Timestamp" in row and "End_Timestamp" in row:
+                dur = float(row["End_Timestamp"]) - float(row["Start_Timestamp"])
+                if dur > 0:
+                    name = row["Kernel_Name"].split("(")[0].replace("void ", "")
+                    clk[name].append((float(row["Counter_Value"]) / 32.0 / dur, dur))
+for k in sorted(clk):
+    if "rocclr" in k or not clk[k]:
+        continue
+    ghz = sum(c for c, _ in clk[k]) / len(clk[k])
+    ms = sum(d_ for _, d_ in clk[k]) / len(clk[k]) / 1e6
+    lines.append(f"# shader clock {k}: {ghz:.3f} GHz over {len(clk[k])} launches (SQ_BUSY_CYCLES / 32 / duration; average duration in that PMC pass {ms:.4f} ms)")
+# what the bench printed in the SAME traced run (HIP-event averages on the library's own streams), for the recomputation of its fractions
+import json
+log = os.path.join(src, trace + ".log")
+if os.path.exists(log):
+    for ln in open(log):
+        ln = ln.strip()
+        if ln.startswith("{") and '"roofline"' in ln:
+            try:
+                rec = json.loads(ln)
+            except Exception:
+                continue
+            r, kb = rec.get("roofline", {}), rec.get("roofline_kbuild", {})
+            lines.append(f"# bench line of the traced run ({trace}.log): ms_per_step {rec.get('ms_per_step'):.3f}; trailing SYRK HIP-event average "
+                         f"{r.get('avg_launch_ms'):.4f} ms over {r.get('launches')} launches = {r.get('achieved'):.2f} TFLOP/s = {r.get('frac'):.3f} of {r.get('peak')}; "
+                         f"kernel build {kb.get('avg_launch_ms', float('nan')):.4f} ms = {kb.get('achieved', float('nan')):.0f} GB/s = {kb.get('frac', float('nan')):.3f}")
 with open(os.path.join(dst, f"{tag}_pmc_summary.csv"), "w") as f:
     f.write("\n".join(lines) + "\n")
 print("\n".join(lines[-12:]))
