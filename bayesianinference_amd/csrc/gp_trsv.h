@@ -403,15 +403,22 @@ __global__ __launch_bounds__(TRSV_THREADS, 1) void trsv_dataflow_kernel(TrsvArgs
     // one task: poll its inputs (behind its own tile's loads, which it needs anyway), settle the tile, THEN take the next ticket and
     // start that tile's loads -- they fly under this task's arithmetic, its stores and the next task's wait
     auto process = [&](TrsvBlk<T, BACK>& cur, TrsvBlk<T, BACK>& nxt) -> bool {
-        const long qn = take();
+        // The first task of a column, I = K + 2, is the one the chain waits for one hop later: it polls the payload directly and
+        // takes its next ticket only AFTER it has stored its result -- a prefetch issued before the polls would put 128 KiB of
+        // loads in front of them (loads return in order: +1.3 us on the chain at N = 32768, where HBM is busy).
+        const bool crit = I == K + 2;
+        long qn = 0;
         int In = 0, Kn = 0;
-        if (qn < ntasks) {
-            decode(qn, In, Kn);
-            trsv_load_tile<T, BACK>(nxt, ltile(In, Kn), lo, ob);   // in flight while this task waits for its inputs
-        }
-        // (the first task of a column, I = K + 2, is the one the chain waits for one hop later: it polls the payload directly)
+        auto prefetch = [&]() {
+            qn = take();
+            if (qn < ntasks) {
+                decode(qn, In, Kn);
+                trsv_load_tile<T, BACK>(nxt, ltile(In, Kn), lo, ob);   // in flight while a task waits for its inputs
+            }
+        };
+        if (!crit) prefetch();
         if (wave == 0) {
-            if (I == K + 2) trsv_fetch<T, 2>([&](int r) { return g.X + (long)r * g.ldx + (long)blk(K) * TB; }, nrhs, xs, lane, g.abort_flag);
+            if (crit) trsv_fetch<T, 2>([&](int r) { return g.X + (long)r * g.ldx + (long)blk(K) * TB; }, nrhs, xs, lane, g.abort_flag);
             else trsv_fetch<T, 1>([&](int r) { return g.X + (long)r * g.ldx + (long)blk(K) * TB; }, nrhs, xs, lane, g.abort_flag);
         }
         if (wave == 1) {
@@ -419,7 +426,7 @@ __global__ __launch_bounds__(TRSV_THREADS, 1) void trsv_dataflow_kernel(TrsvArgs
             else trsv_fetch<T, 0>([&](int r) { return g.B + (long)r * g.ldx + (long)blk(I) * TB; }, nrhs, ss, lane, g.abort_flag);
         }
         trsv_settle(cur);                                   // (loads return in order: whoever saw its poll answered has both tiles)
-        trsv_settle(nxt);
+        if (!crit) trsv_settle(nxt);
         __syncthreads();
         T* out = sslot(I, K);
         for (int r = 0; r < nrhs; ++r) {
@@ -431,6 +438,7 @@ __global__ __launch_bounds__(TRSV_THREADS, 1) void trsv_dataflow_kernel(TrsvArgs
                     __hip_atomic_store(out + (long)r * TB + ob * 4 + k, ss[r * TB + ob * 4 + k] - y[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
+        if (crit) prefetch();                               // (settled as `cur` of the next call)
         I = In; K = Kn;
         return qn < ntasks;                                 // (the next take()'s barrier frees xs / ss)
     };

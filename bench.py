@@ -441,6 +441,17 @@ def other_configs(local_rank: int) -> dict:
                 Xs = syn.make_test_points(100, d)
                 out[name]["next_rows"] = {"fit_ms": med_ms(lambda: h.fit(th)), "predict_100_points_ms": med_ms(lambda: h.predict(Xs)),
                                           "loglik_and_gradient_ms": med_ms(lambda: h.loglik_grad(th))}
+                # "Inverse"[vector] (BGP:194, 407-412): one right-hand side through the single-vector substitution launches
+                # (csrc/gp_trsv.h; the factor streamed once per triangle: 2 x s N^2 / 2 bytes) and through the GEMM-shaped one
+                h.fit(th)
+                bvec = syn.normal(syn.STREAM_NOISE, 0, n)
+                one = med_ms(lambda: h.solve(bvec), 20)
+                h.set_option("trsv", 0)
+                old = med_ms(lambda: h.solve(bvec), 5)
+                h.set_option("trsv", 1)
+                out[name]["next_rows"]["solve_one_vector_ms"] = one
+                out[name]["next_rows"]["solve_one_vector_gemm_path_ms"] = old
+                out[name]["next_rows"]["solve_one_vector_frac_of_hbm_time"] = (8.0 * n * n / HBM_PEAK_GBS / 1e9 * 1e3) / one
             h.close()
     except Exception as exc:                                    # never let an extra break the headline
         out["cfg1_cfg2_error"] = repr(exc)
