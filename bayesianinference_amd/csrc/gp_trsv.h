@@ -104,18 +104,23 @@ __device__ __forceinline__ void trsv_fetch(Src src, int nrhs, T* dst, int lane, 
             if (r < nrhs) bad = bad || TrsvBits<T>::pending(v[2 * r]) || TrsvBits<T>::pending(v[2 * r + 1]);
         return __all(!bad);
     };
+    load_set(va);
     if (MODE == 1) {
-        const T* p0 = src(0);
-        T a = __hip_atomic_load(p0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        T b = __hip_atomic_load(p0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        while (__builtin_expect(TrsvBits<T>::pending(a), 0)) {
-            a = b;
-            __builtin_amdgcn_s_sleep(TRSV_TILE_BACKOFF);
-            b = __hip_atomic_load(p0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (give_up()) break;
+        // (in the throughput-bound regime -- N = 32768: 250 tasks per column for 230 workgroups -- the inputs are usually there
+        //  already: the payload is tried first, one round trip, and only a miss falls back to watching one word)
+        if (__builtin_expect(!complete(va), 0)) {
+            const T* p0 = src(0);
+            T a = __hip_atomic_load(p0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            T b = __hip_atomic_load(p0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            while (__builtin_expect(TrsvBits<T>::pending(a), 0)) {
+                a = b;
+                __builtin_amdgcn_s_sleep(TRSV_TILE_BACKOFF);
+                b = __hip_atomic_load(p0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (give_up()) break;
+            }
+            load_set(va);
         }
     }
-    load_set(va);
     if (MODE != 0) {
         // (the payload poll is NOT pipelined: a load left in flight behind the accepted one would be waited for by the next
         //  s_waitcnt vmcnt(0) -- half a round trip on the chain -- which is what pipelining would have saved)
@@ -375,59 +380,8 @@ __global__ __launch_bounds__(TRSV_THREADS, 1) void trsv_dataflow_kernel(TrsvArgs
         return;
     }
 
-    // ---------------- tile role: tasks (I, K), K <= I - 2, column-major: column K holds I = K + 2 .. nt - 1
-    if (nt < 3) return;
-    const long ntasks = (long)(nt - 2) * (nt - 1) / 2;
-    auto take = [&]() -> long {
-        __syncthreads();                                    // (s_q of the previous take has been read by everybody)
-        if (tid == 0) s_q = atomicAdd(g.ticket, 1u) + 1u;       // (the ticket starts at the sentinel: 0xFFFFFFFF + 1 = task 0)
-        __syncthreads();
-        return (long)s_q;
-    };
-    auto decode = [&](long q, int& I, int& K) {             // off(K) = K (nt - 2) - K (K - 1) / 2
-        const double bq = (double)(2 * nt - 3);
-        int k = (int)((bq - sqrt(bq * bq - 8.0 * (double)q)) * 0.5);
-        if (k < 0) k = 0;
-        if (k > nt - 3) k = nt - 3;
-        while (k + 1 <= nt - 3 && (long)(k + 1) * (nt - 2) - (long)(k + 1) * k / 2 <= q) ++k;
-        while (k > 0 && (long)k * (nt - 2) - (long)k * (k - 1) / 2 > q) --k;
-        K = __builtin_amdgcn_readfirstlane(k);
-        I = __builtin_amdgcn_readfirstlane(k + 2 + (int)(q - ((long)k * (nt - 2) - (long)k * (k - 1) / 2)));
-    };
-    TrsvBlk<T, BACK> ta, tb;
-    long q = take();
-    if (q >= ntasks) return;
-    int I, K;
-    decode(q, I, K);
-    trsv_load_tile<T, BACK>(ta, ltile(I, K), lo, ob);
-    // one task: poll its inputs (behind its own tile's loads, which it needs anyway), settle the tile, THEN take the next ticket and
-    // start that tile's loads -- they fly under this task's arithmetic, its stores and the next task's wait
-    auto process = [&](TrsvBlk<T, BACK>& cur, TrsvBlk<T, BACK>& nxt) -> bool {
-        // The first task of a column, I = K + 2, is the one the chain waits for one hop later: it polls the payload directly and
-        // takes its next ticket only AFTER it has stored its result -- a prefetch issued before the polls would put 128 KiB of
-        // loads in front of them (loads return in order: +1.3 us on the chain at N = 32768, where HBM is busy).
-        const bool crit = I == K + 2;
-        long qn = 0;
-        int In = 0, Kn = 0;
-        auto prefetch = [&]() {
-            qn = take();
-            if (qn < ntasks) {
-                decode(qn, In, Kn);
-                trsv_load_tile<T, BACK>(nxt, ltile(In, Kn), lo, ob);   // in flight while a task waits for its inputs
-            }
-        };
-        if (!crit) prefetch();
-        if (wave == 0) {
-            if (crit) trsv_fetch<T, 2>([&](int r) { return g.X + (long)r * g.ldx + (long)blk(K) * TB; }, nrhs, xs, lane, g.abort_flag);
-            else trsv_fetch<T, 1>([&](int r) { return g.X + (long)r * g.ldx + (long)blk(K) * TB; }, nrhs, xs, lane, g.abort_flag);
-        }
-        if (wave == 1) {
-            if (K > 0) trsv_fetch<T, 1>([&](int r) { return sslot(I, K - 1) + (long)r * TB; }, nrhs, ss, lane, g.abort_flag);
-            else trsv_fetch<T, 0>([&](int r) { return g.B + (long)r * g.ldx + (long)blk(I) * TB; }, nrhs, ss, lane, g.abort_flag);
-        }
-        trsv_settle(cur);                                   // (loads return in order: whoever saw its poll answered has both tiles)
-        if (!crit) trsv_settle(nxt);
-        __syncthreads();
+    // the arithmetic of one tile task: s(I,K) = (incoming sum in ss) - L(I,K) x (in xs), stored to its slot
+    auto tile_out = [&](const TrsvBlk<T, BACK>& cur, int I, int K) {
         T* out = sslot(I, K);
         for (int r = 0; r < nrhs; ++r) {
             T y[4];
@@ -438,7 +392,70 @@ __global__ __launch_bounds__(TRSV_THREADS, 1) void trsv_dataflow_kernel(TrsvArgs
                     __hip_atomic_store(out + (long)r * TB + ob * 4 + k, ss[r * TB + ob * 4 + k] - y[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
-        if (crit) prefetch();                               // (settled as `cur` of the next call)
+    };
+    if ((int)blockIdx.x < 3 * TRSV_CHAIN) {
+        // ---------------- feeder role: workgroup c takes the tasks (K + 2, K), K = c, c + TRSV_CHAIN, .. -- the row sum the chain
+        // needs two hops after x_K.  In the common ticket list that task is picked up only after the previous column's tasks have
+        // been handed out (240 workgroups, up to 255 tasks per column at N = 32768): the chain then waits ~1.3 us per hop for
+        // it.  Here its tile is resident hops ahead and its inputs are polled directly.
+        TrsvBlk<T, BACK> cur;
+        for (int K = (int)blockIdx.x - 2 * TRSV_CHAIN; K + 2 < nt; K += TRSV_CHAIN) {
+            const int I = K + 2;
+            trsv_load_tile<T, BACK>(cur, ltile(I, K), lo, ob);
+            trsv_settle(cur);
+            if (wave == 0) trsv_fetch<T, 2>([&](int r) { return g.Xc + (long)r * g.ldx + (long)blk(K) * TB; }, nrhs, xs, lane, g.abort_flag);
+            if (wave == 1) {
+                if (K > 0) trsv_fetch<T, 2>([&](int r) { return sslot(I, K - 1) + (long)r * TB; }, nrhs, ss, lane, g.abort_flag);
+                else trsv_fetch<T, 0>([&](int r) { return g.B + (long)r * g.ldx + (long)blk(I) * TB; }, nrhs, ss, lane, g.abort_flag);
+            }
+            __syncthreads();
+            tile_out(cur, I, K);
+            __syncthreads();                                // (xs / ss are rewritten by the next step)
+        }
+        return;
+    }
+
+    // ---------------- tile role: tasks (I, K), K <= I - 3, column-major: column K holds I = K + 3 .. nt - 1
+    if (nt < 4) return;
+    const long ntasks = (long)(nt - 3) * (nt - 2) / 2;
+    auto take = [&]() -> long {
+        __syncthreads();                                    // (s_q of the previous take has been read by everybody)
+        if (tid == 0) s_q = atomicAdd(g.ticket, 1u) + 1u;       // (the ticket starts at the sentinel: 0xFFFFFFFF + 1 = task 0)
+        __syncthreads();
+        return (long)s_q;
+    };
+    auto decode = [&](long q, int& I, int& K) {             // off(K) = K (nt - 3) - K (K - 1) / 2
+        const double bq = (double)(2 * nt - 5);
+        int k = (int)((bq - sqrt(bq * bq - 8.0 * (double)q)) * 0.5);
+        if (k < 0) k = 0;
+        if (k > nt - 4) k = nt - 4;
+        while (k + 1 <= nt - 4 && (long)(k + 1) * (nt - 3) - (long)(k + 1) * k / 2 <= q) ++k;
+        while (k > 0 && (long)k * (nt - 3) - (long)k * (k - 1) / 2 > q) --k;
+        K = __builtin_amdgcn_readfirstlane(k);
+        I = __builtin_amdgcn_readfirstlane(k + 3 + (int)(q - ((long)k * (nt - 3) - (long)k * (k - 1) / 2)));
+    };
+    TrsvBlk<T, BACK> ta, tb;
+    long q = take();
+    if (q >= ntasks) return;
+    int I, K;
+    decode(q, I, K);
+    trsv_load_tile<T, BACK>(ta, ltile(I, K), lo, ob);
+    auto process = [&](TrsvBlk<T, BACK>& cur, TrsvBlk<T, BACK>& nxt) -> bool {
+        const long qn = take();
+        int In = 0, Kn = 0;
+        if (qn < ntasks) {
+            decode(qn, In, Kn);
+            trsv_load_tile<T, BACK>(nxt, ltile(In, Kn), lo, ob);   // in flight while this task waits for its inputs
+        }
+        if (wave == 0) trsv_fetch<T, 1>([&](int r) { return g.X + (long)r * g.ldx + (long)blk(K) * TB; }, nrhs, xs, lane, g.abort_flag);
+        if (wave == 1) {
+            if (K > 0) trsv_fetch<T, 1>([&](int r) { return sslot(I, K - 1) + (long)r * TB; }, nrhs, ss, lane, g.abort_flag);
+            else trsv_fetch<T, 0>([&](int r) { return g.B + (long)r * g.ldx + (long)blk(I) * TB; }, nrhs, ss, lane, g.abort_flag);
+        }
+        trsv_settle(cur);                                   // (loads return in order: whoever saw its poll answered has both tiles)
+        trsv_settle(nxt);
+        __syncthreads();
+        tile_out(cur, I, K);
         I = In; K = Kn;
         return qn < ntasks;                                 // (the next take()'s barrier frees xs / ss)
     };

@@ -1822,8 +1822,8 @@ int queue_trsv(gphip_ctx* h, const T* B, int pass, int nrhs, bool back, T** Xout
     g.ticket = reinterpret_cast<unsigned int*>(g.S + (size_t)nrhs * TB * (size_t)(nt * (nt - 1) / 2 + 1));
     g.nt = nt; g.nrhs = nrhs; g.back = back ? 1 : 0; g.dbg = h->trsv >> 1;
     g.abort_flag = reinterpret_cast<int*>(h->dTicket + 1);
-    const long ntasks = nt >= 3 ? (long)(nt - 2) * (nt - 1) / 2 : 0;
-    const long grid = std::min<long>((long)h->ncu, 2 * TRSV_CHAIN + ntasks);         // one workgroup per CU: all resident at once
+    const long ntasks = nt >= 4 ? (long)(nt - 3) * (nt - 2) / 2 : 0;                 // common ticket list: I >= K + 3
+    const long grid = std::min<long>((long)h->ncu, 3 * TRSV_CHAIN + ntasks);         // chain pairs + feeders + tile role; one per CU: all resident
     ProfScope ps(h, 2, 0.0, (double)h->slot_elems * sizeof(T));
     if (back) hipLaunchKernelGGL((trsv_dataflow_kernel<T, true>), dim3((unsigned)grid), dim3(TRSV_THREADS), trsv_lds_bytes(sizeof(T)), h->stream, g);
     else hipLaunchKernelGGL((trsv_dataflow_kernel<T, false>), dim3((unsigned)grid), dim3(TRSV_THREADS), trsv_lds_bytes(sizeof(T)), h->stream, g);
@@ -3158,7 +3158,11 @@ int gphip_solve(gphip_handle h, const double* rhs, int64_t nrhs, double* out) {
     }
     HIPCHK(hipSetDevice(h->device));
     const int64_t N = h->N, Npad = h->Npad, MC = 2048;
-    if (trsv_ok(h, (int)std::min<int64_t>(nrhs, TRSV_MAXR + 1))) {
+    // (a non-finite right-hand side keeps the GEMM-shaped substitution: the single-vector launches recognise "not written yet" by
+    //  an all-ones NaN pattern, which arithmetic on a NaN with that payload could reproduce -- a seconds-long wait, then an error)
+    bool rhs_finite = nrhs <= TRSV_MAXR;
+    for (int64_t i = 0; rhs_finite && i < nrhs * N; ++i) rhs_finite = std::isfinite(rhs[i]);
+    if (rhs_finite && trsv_ok(h, (int)std::min<int64_t>(nrhs, TRSV_MAXR + 1))) {
         // 1 .. 4 right-hand sides: two launches that stream the factor once each (gp_trsv.h) instead of a 128-row GEMM substitution
         const int nr = (int)nrhs;
         h->cs = h->stream;

@@ -37,8 +37,8 @@ int main(int argc, char** argv) {
             TrsvArgs<double> g{};
             g.A = dA; g.R128 = R128; g.W = dW; g.P = dP; g.B = dB; g.X = dX; g.Xc = dXc; g.S = dS; g.ldx = npad; g.nt = Nt; g.nrhs = nrhs; g.back = back;
             g.dbg = dbg; g.ticket = dT; g.abort_flag = dAb; g.trace = dTr;
-            const long ntasks = Nt >= 3 ? (long)(Nt - 2) * (Nt - 1) / 2 : 0;
-            const long grid = std::min<long>(nwg, 2 * TRSV_CHAIN + ntasks);
+            const long ntasks = Nt >= 4 ? (long)(Nt - 3) * (Nt - 2) / 2 : 0;
+            const long grid = std::min<long>(nwg, 3 * TRSV_CHAIN + ntasks);
             hipEventRecord(e0, 0);
             if (back) hipLaunchKernelGGL((trsv_dataflow_kernel<double, true>), dim3((unsigned)grid), dim3(TRSV_THREADS), trsv_lds_bytes(8), 0, g);
             else hipLaunchKernelGGL((trsv_dataflow_kernel<double, false>), dim3((unsigned)grid), dim3(TRSV_THREADS), trsv_lds_bytes(8), 0, g);
