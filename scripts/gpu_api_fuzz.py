@@ -33,7 +33,7 @@ while time.time() < t_end:
     dtype = int(rng.choice([64, 64, 64, 32]))
     RT = 1e-8 if dtype == 64 else 2e-3                    # fp32 device arithmetic: 1e-3-class agreement
     d = int(rng.choice([1, 2, 3, 8]))
-    kernel = str(rng.choice(["se", "se_ard", "matern52", "matern52_ard"]))
+    kernel = str(rng.choice(["se", "se_ard", "matern52", "matern52_ard"]))     # (default_theta knows these four)
     mean = str(rng.choice(["zero", "const"]))
     world = int(rng.choice([1, 1, 2, 3, 4]))
     X, y = syn.make_dataset(n, d, seed=int(rng.integers(1 << 30)))
@@ -57,7 +57,7 @@ while time.time() < t_end:
         print(f'  op {op}', file=log, flush=True)
         if op == "option":
             name = str(rng.choice(["panel", "dataflow", "lookahead", "thin_tiles", "fused_eval", "dataflow_fine_nt", "panel_wide",
-                                   "dataflow_tail", "grad_potri", "max_slots", "latency_gemm", "shard_min_n", "panel_left",
+                                   "dataflow_tail", "grad_potri", "max_slots", "trsv", "kbuild_mfma", "latency_gemm", "shard_min_n", "panel_left",
                                    "replicate_factor", "share_local_panels", "debug_fail_alloc", "supertile", "dataflow_lds_kib", "fuse_potrf", "bcast_chunks",
                                    "dist_panel_df", "bcast_two_hop", "panel_df", "kbuild_mfma", "kbuild_mfma_bound", "custom_grad"]))
             if name == "debug_fail_alloc" and rng.random() < 0.7:

@@ -128,3 +128,20 @@ def test_library_alone_compiles_custom_functions_and_caches_them(tmp_path):
     env = {k: v for k, v in os.environ.items() if k != "GPHIP_SRC_DIR"}
     res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=str(tmp_path), env=env, timeout=300)
     assert res.returncode == 0, res.stdout + res.stderr
+
+
+def test_compile_for_a_dimension_is_its_own_cache_entry():
+    """the code-object cache is keyed by the input dimension the program is specialised on.  gphip_custom_compile_d(.., d)
+    is the program a d-dimensional gphip_create_custom compiles (1 <= d <= 32); gphip_custom_compile the dimension-generic one
+    (d > 32).  (That a create after a compile_d is a hit: tests/test_gpu_custom_kernel.py, it needs a device.)"""
+    if _hiprtc() is None:
+        pytest.skip("no libhiprtc.so on this machine")
+    lib = _lib.load()
+    body = (SE_ARD_BODY + " /* dim cache test */").encode()
+    hit = C.c_int(-1)
+    assert lib.gphip_custom_compile_d(body, 64, None, -1, 5, C.byref(hit)) == 0 and hit.value == 0
+    assert lib.gphip_custom_compile_d(body, 64, None, -1, 5, C.byref(hit)) == 0 and hit.value == 1
+    assert lib.gphip_custom_compile_d(body, 64, None, -1, 6, C.byref(hit)) == 0 and hit.value == 0      # another d: another program
+    assert lib.gphip_custom_compile(body, 64, None, -1, C.byref(hit)) == 0 and hit.value == 0           # generic: another one
+    assert lib.gphip_custom_compile_d(body, 64, None, -1, 40, C.byref(hit)) == 0 and hit.value == 1     # d > 32 IS the generic program
+    assert lib.gphip_custom_compile_d(body, 64, None, -1, -1, C.byref(hit)) == 1                        # bad argument
