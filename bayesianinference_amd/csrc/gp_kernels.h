@@ -223,15 +223,42 @@ __device__ __forceinline__ void kfamily(int fam, T r2, T alpha, T& g, T& m2dg, T
     }
 }
 
+// g_fam(r2) alone, for the kernel BUILD of the general form (round 6): what kfamily computes, minus what only the gradient needs and
+// minus the slow library routes -- square roots by v_rsq + one Newton step (5 instructions instead of the IEEE expansion's 15;
+// relative error ~4e-15), the rational quadratic's logarithm from a v_log_f32 seed corrected to second order on exp_nonpos
+// (two exp_nonpos + ~10 instructions instead of the library's log1p + exp: ~150).  Direct-form rational quadratic d = 8 0.16 ->
+// see profiles/r06_kbuild_family_table.txt.
+__device__ __forceinline__ double kvalue(int fam, double r2, double alpha, double inv_alpha) {
+    if (fam == 0) return exp_nonpos(-0.5 * r2);
+    if (fam == 3) {
+        const double q = r2 * (0.5 * inv_alpha), yq = 1.0 + q;
+        const double x0 = (double)(__builtin_amdgcn_logf((float)yq) * 0.69314718f);
+        const double dl = __builtin_fma(yq, exp_nonpos(-x0), -1.0);
+        const double x1 = x0 + __builtin_fma(-0.5 * dl, dl, dl);
+        return exp_nonpos(-alpha * x1);
+    }
+    const double u = fmax((fam == 1 ? 5.0 : 3.0) * r2, 1.0e-280);
+    const double y = __builtin_amdgcn_rsq(u);
+    const double e = __builtin_fma(-u * y, y, 1.0);
+    const double s = u * __builtin_fma(0.5 * y, e, y);            // sqrt(u)
+    const double ex = exp_nonpos(-s);
+    return fam == 1 ? (1.0 + s + (1.0 / 3.0) * u) * ex : (1.0 + s) * ex;
+}
+__device__ __forceinline__ float kvalue(int fam, float r2, float alpha, float inv_alpha) {
+    if (fam == 0) return __builtin_amdgcn_exp2f(-0.72134752f * r2);
+    if (fam == 3) return __builtin_amdgcn_exp2f(-alpha * __builtin_amdgcn_logf(1.0f + r2 * (0.5f * inv_alpha)));
+    const float u = fmaxf((fam == 1 ? 5.0f : 3.0f) * r2, 1e-30f);
+    const float s = u * __builtin_amdgcn_rsqf(u);
+    const float ex = __builtin_amdgcn_exp2f(s * -1.4426950408889634f);
+    return fam == 1 ? (1.0f + s + (1.0f / 3.0f) * u) * ex : (1.0f + s) * ex;
+}
+
 // k(p, q) of the general form from the two squared scaled distances; sp = the slot's scalars
 template <typename T>
-__device__ __forceinline__ T kgeneral(const KSpec& ks, T r2a, T r2b, const double* __restrict__ sp) {
-    T g, m2, da;
-    kfamily<T>(ks.fam1, r2a, (T)sp[SP_ALPHA1], g, m2, da);
-    T k = (T)sp[0] * g;
+__device__ __forceinline__ T kgeneral(const KSpec& ks, T r2a, T r2b, const double* __restrict__ sp, T inv_a1, T inv_a2) {
+    T k = (T)sp[0] * kvalue(ks.fam1, r2a, (T)sp[SP_ALPHA1], inv_a1);
     if (ks.op != 0) {
-        kfamily<T>(ks.fam2, r2b, (T)sp[SP_ALPHA2], g, m2, da);
-        const T k2 = (T)sp[SP_SF2B] * g;
+        const T k2 = (T)sp[SP_SF2B] * kvalue(ks.fam2, r2b, (T)sp[SP_ALPHA2], inv_a2);
         k = (ks.op == 1) ? k + k2 : k * k2;
     }
     return ks.offset ? k + (T)sp[SP_OFFSET] : k;
@@ -364,6 +391,7 @@ __global__ __launch_bounds__(256) void kbuild_kernel(KBuildArgs<T> a) {
     const double* sp = a.slotp + (long)slot * SLOTP;
     if (a.mfma_skip && sp[SP_MFMA] != 0.0) return;
     const T sf2 = (T)sp[0], sn2 = (T)sp[1], mu = (T)sp[2];
+    const T inv_a1 = (T)(1.0 / sp[SP_ALPHA1]), inv_a2 = (T)(1.0 / sp[SP_ALPHA2]);      // (general form, rational quadratic terms)
     // mode 0 writes one whole tile of the packed workspace (128 KiB contiguous in fp64); mode 1 a tile of a
     // column-major block
     const long ldo = (a.mode == 0) ? (long)TB : a.ld;
@@ -529,8 +557,8 @@ __global__ __launch_bounds__(256) void kbuild_kernel(KBuildArgs<T> a) {
                     rb2 = Num<T>::fma_(db, db, rb2);
                 }
             }
-            va = kgeneral<T>(a.ks, ra, ra2, sp);
-            vb = kgeneral<T>(a.ks, rb, rb2, sp);
+            va = kgeneral<T>(a.ks, ra, ra2, sp, inv_a1, inv_a2);
+            vb = kgeneral<T>(a.ks, rb, rb2, sp, inv_a1, inv_a2);
         } else if constexpr (sizeof(T) == 8) {
             if (KT == 0) {
                 va = exp_tab<true>(ra, etab);
@@ -890,6 +918,7 @@ __global__ __launch_bounds__(256, 2) void kbuild_mfma_kernel(KBuildMArgs<T> m) {
     if (sp[SP_MFMA] == 0.0) return;                 // (kbuild_kernel's slot)
     const T sf2 = (T)sp[0], sn2 = (T)sp[1], mu = (T)sp[2];
     const T alpha = (T)sp[SP_ALPHA1], inv_sf2 = (T)(1.0 / sp[0]), inv_alpha = (T)(1.0 / sp[SP_ALPHA1]);   // (rational quadratic only)
+    const T coff = (T)sp[SP_OFFSET];                // constant offset of c + k1 (0 without one)
     const long ldo = (a.mode == 0) ? (long)TB : a.ld;
     T* out = a.out + (long)slot * a.bstride +
              ((a.mode == 0) ? (tile_index(ti, tj, a.nt_i) + (a.adj ? a.adj[panel_slot(tj, a.nt_j, a.own_panel)] : 0l)) * TS
@@ -994,7 +1023,7 @@ __global__ __launch_bounds__(256, 2) void kbuild_mfma_kernel(KBuildMArgs<T> m) {
             const int jc = j0 + Num<T>::drow(g, r);
             vec_t v;
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) v[q] = km_value<KT>(acc[q][r], sf2, etab, alpha, inv_sf2, inv_alpha);
+            for (int q = 0; q < NQ; ++q) v[q] = km_value<KT>(acc[q][r], sf2, etab, alpha, inv_sf2, inv_alpha) + coff;
             if (edge) {
                 const int gj = tj * TB + jc;
 #pragma unroll

@@ -461,11 +461,14 @@ void launch_kbuild_mfma_kt(gphip_ctx* h, const KBuildMArgs<T>& m, dim3 grid) {
 }
 
 // Which family of kbuild_mfma_kernel serves this handle: the two fast paths (kt 0 / 1), and the general form when it is ONE
-// term without offset -- Matern-3/2 (2), rational quadratic (3); -1: composed kernels, run-time compiled functions.
+// term, with or without a constant offset -- SE (0), Matern-5/2 (1), Matern-3/2 (2), rational quadratic (3); -1: two-term kernels,
+// run-time compiled functions.
 int mfma_family(const gphip_ctx* h) {
     if (h->custom) return -1;
     if (h->kt <= 1) return h->kt;
-    if (h->ks.op == 0 && !h->ks.offset && h->nl2 == 0 && h->ks.fam1 >= 0 && h->ks.fam1 <= 3) return h->ks.fam1;
+    // (a constant offset c + k1 -- the reference's own example kernel, #2 + Exp[-(pt1 - pt2)^2 / #1^2], BGP:16 -- rides along: the
+    //  kernel adds slot scalar SP_OFFSET, which is 0 without one)
+    if (h->ks.op == 0 && h->nl2 == 0 && h->ks.fam1 >= 0 && h->ks.fam1 <= 3) return h->ks.fam1;
     return -1;
 }
 

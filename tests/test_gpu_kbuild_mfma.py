@@ -227,7 +227,7 @@ def test_clustered_inputs_on_the_mfma_side_of_the_rule(d, sn):
 
 
 @pytest.mark.parametrize("kernel,d,n", [("matern32_ard", 5, 300), ("matern32", 2, 257), ("rq_ard", 4, 300), ("rq", 1, 200), ("rq_ard", 13, 150),
-                                        ("matern32_ard", 20, 140)])
+                                        ("matern32_ard", 20, 140), ("se + const", 1, 300), ("matern52_ard + const", 6, 200), ("rq_ard + const", 3, 257)])
 @pytest.mark.parametrize("scale", [1.0, 0.25])
 def test_matern32_and_rational_quadratic_on_the_matrix_pipe(kernel, d, n, scale):
     """Round 6: the two remaining named families (one term, no offset) take the MFMA form too -- Matern-3/2 with the Matern-5/2
@@ -236,9 +236,10 @@ def test_matern32_and_rational_quadratic_on_the_matrix_pipe(kernel, d, n, scale)
     form in mode 1 (inside the bound), the likelihood in all three modes, composed kernels stay on the direct form."""
     X, y = syn.make_dataset(n, d)
     X = X + 2.0
-    nl = d if kernel.endswith("_ard") else 1
+    nl = d if "_ard" in kernel else 1
     ell = (0.3 if d == 1 else 1.0) * scale
-    th = np.array([ell] * nl + ([1.7] if kernel.startswith("rq") else []) + [1.3, 0.2])
+    # (c + k1: the reference's own example kernel, #2 + Exp[-(pt1 - pt2)^2 / #1^2], BGP:16 -- the offset rides along on the matrix pipe)
+    th = np.array([ell] * nl + ([1.7] if kernel.startswith("rq") else []) + [1.3] + ([0.6] if kernel.endswith("const") else []) + [0.2])
     Ko = orc.covariance_matrix(kernel, th, X)
     Xs = syn.make_test_points(100, d) + 2.0
     ko = orc.k_and_kappa(kernel, th, X, Xs)[0]
