@@ -8,16 +8,17 @@
 //   forward   x_k = W_k (b_k - sum_{c<k} L(k,c) x_c)              W_k = L_kk^-1 (explicit 128 x 128 inverses, resident)
 //   backward  x_k = W_k^T (b_k - sum_{c>k} L(c,k)^T x_c)          the same schedule on mirrored block indices, tiles read transposed
 //
-// * a task = one 128 x 128 tile: s(I,K) = s(I,K-1) - L(I,K) x_K for K <= I-2, held in REGISTERS (64 values per lane, loaded
+// * a task = one 128 x 128 tile: s(I,K) = s(I,K-1) - L(I,K) x_K for K <= I-3, held in REGISTERS (64 values per lane, loaded
 //   before the task's inputs exist -- L is static) by the persistent "tile" workgroups, which take tasks from a ticket in
 //   column-major order (a topological order: every dependency belongs to an earlier ticket or to the chain) and prefetch the
 //   next task's tile while they wait for the current one's inputs;
-// * the chain: TRSV_CHAIN PAIRS of "chain" workgroups take the diagonal steps round-robin.  x_K = W_K (s(K,K-2) - L(K,K-1) x_{K-1})
-//   is evaluated as W_K s - P_K x_{K-1} with P_K = W_K L(K,K-1) formed once per factor (trsv_prep_kernel): both products start
-//   from the step's INPUTS, so each workgroup of the pair computes 64 of the 128 outputs from its halves of W_K and P_K (in
-//   registers, loaded hops ahead) as ONE sum with ONE reduction -- the arithmetic on the chain is that of a single 128 x 128
-//   product instead of two dependent ones with an LDS round trip between them (hop 3.1 -> 2.x us; an fp64 VALU operation
-//   with fresh operands costs 8-22 clocks per wave here, scripts/micro/valu_rate.hip, profiles/r06_trsv_chain.txt);
+// * the chain: TRSV_CHAIN PAIRS of "chain" workgroups take the diagonal steps round-robin.  With P1_K = W_K L(K,K-1) and
+//   P2_K = W_K L(K,K-2) formed once per factor (trsv_prep_kernel),
+//       x_K = [ W_K s(K,K-3) - P2_K x_{K-2} ]  -  P1_K x_{K-1} :
+//   the bracket needs nothing younger than two hops and is accumulated per lane BEFORE x_{K-1} arrives; what follows the
+//   arrival is one half-tile product (each workgroup of a pair owns 64 of the 128 outputs), ONE 16-lane reduction and the
+//   store.  The row sum the chain needs, s(K,K-3), is three hops old when it is used: the tile role is never on the critical
+//   cycle (with s(K,K-2) it was: x_K -> feeder task -> chain step K+2 measured 2.0-2.7 us per hop, the arithmetic itself 0.2);
 // * hand-offs carry NO flags: every 128-vector a task produces goes to its own slot of a scratch buffer that was filled with a
 //   sentinel (all-ones bit pattern, a NaN no finite arithmetic produces) before the launch, written with write-through (sc1)
 //   8-byte stores and polled by the consumer with sc1 loads until no word is the sentinel -- one fabric latency per hop
@@ -33,20 +34,20 @@ constexpr int TRSV_MAXR = 4;        // right-hand sides per launch
 constexpr int TRSV_CHAIN = 8;       // chain workgroups (each loads 2 tiles per step it owns: 256 KiB every 8 hops)
 constexpr int TRSV_SPIN_LIMIT = 1 << 24;
 #ifndef TRSV_TILE_BACKOFF
-#define TRSV_TILE_BACKOFF 16         // s_sleep units (64 clocks) between a waiting tile task's polls: they have a hop of slack, the chain has none
+#define TRSV_TILE_BACKOFF 6          // s_sleep units (64 clocks: ~0.16 us) between a waiting tile task's polls of its 1-4 KiB of inputs
 #endif
 
 template <typename T>
 struct TrsvArgs {
     const T* A; int R128;           // packed tile-major factor (slot 0), tile rows of the workspace (Nt + 1)
     const T* W;                     // [Nt][128 x 128] W_b = L_bb^-1, column-major, explicit zero upper triangle
-    const T* P;                     // [Nt][128 x 128] the chain's products (trsv_prep_kernel): forward P_b = W_b L(b,b-1), b >= 1;
-                                    // backward P_b = L(b+1,b) W_b, b <= Nt - 2 (applied transposed)
+    const T* P;                     // [2][Nt][128 x 128] the chain's products (trsv_prep_kernel), P[g - 1] for the block g = 1, 2 steps back:
+                                    // forward P_b = W_b L(b,b-g), b >= g; backward P_b = L(b+g,b) W_b, b <= Nt - 1 - g (applied transposed)
     const T* B;                     // [nrhs][ldx] right-hand sides
     T* X;                           // [nrhs][ldx] solutions; sentinel-filled before the launch
     T* Xc;                          // [nrhs][ldx] a second copy of the solution that ONLY the next chain step polls (the tile role's
                                     // hundreds of pollers queue on X's lines at one memory channel); sentinel-filled
-    T* S;                           // [I (I - 1) / 2 + K][nrhs][128] running sums s(I,K), K <= I - 2; sentinel-filled
+    T* S;                           // [I (I - 1) / 2 + K][nrhs][128] running sums s(I,K), K <= I - 3; sentinel-filled
     long ldx;
     int nt, nrhs, back;
     int dbg;                        // developer timing: 1 = the chain ignores the row sums (wrong results)
@@ -68,11 +69,10 @@ template <> struct TrsvBits<float> {
 // One wave reads nrhs x 128 values that another workgroup is about to write (or wrote long ago) into `dst` (LDS, [r][128]).
 // src(r) = the global address of right-hand side r's 128 values.
 // MODE 0: plain loads (the caller's right-hand side).
-// MODE 1 (tile role): poll ONE word first -- hundreds of waiting workgroups watch the same block -- then the payload.
-// MODE 2 (chain role): poll the payload itself: the hop is one fabric round trip, not two.
-// The word poll of MODE 1 is pipelined (two loads in flight, the older one examined: loads return in order).  The producer's
-// 8-byte stores land within nanoseconds of each other in no particular order: the payload is accepted when no word of it is
-// the sentinel.
+// MODE 1 (tile role): poll the payload with a short sleep between polls.
+// MODE 2 (chain role): poll the payload back to back.
+// The producer's 8-byte stores land within nanoseconds of each other in no particular order: the payload is accepted when no word
+// of it is the sentinel.
 template <typename T, int MODE, typename Src>
 __device__ __forceinline__ void trsv_fetch(Src src, int nrhs, T* dst, int lane, int* abort_flag) {
     T va[2 * TRSV_MAXR];
@@ -105,26 +105,14 @@ __device__ __forceinline__ void trsv_fetch(Src src, int nrhs, T* dst, int lane, 
         return __all(!bad);
     };
     load_set(va);
-    if (MODE == 1) {
-        // (in the throughput-bound regime -- N = 32768: 250 tasks per column for 230 workgroups -- the inputs are usually there
-        //  already: the payload is tried first, one round trip, and only a miss falls back to watching one word)
-        if (__builtin_expect(!complete(va), 0)) {
-            const T* p0 = src(0);
-            T a = __hip_atomic_load(p0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            T b = __hip_atomic_load(p0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            while (__builtin_expect(TrsvBits<T>::pending(a), 0)) {
-                a = b;
-                __builtin_amdgcn_s_sleep(TRSV_TILE_BACKOFF);
-                b = __hip_atomic_load(p0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (give_up()) break;
-            }
-            load_set(va);
-        }
-    }
     if (MODE != 0) {
-        // (the payload poll is NOT pipelined: a load left in flight behind the accepted one would be waited for by the next
-        //  s_waitcnt vmcnt(0) -- half a round trip on the chain -- which is what pipelining would have saved)
+        // The payload itself is polled (not pipelined: a load left in flight behind the accepted one would be waited for by the next
+        // s_waitcnt vmcnt(0), which is what pipelining would have saved).  MODE 1 sleeps between polls -- hundreds of workgroups
+        // watch the same kilobyte -- but does NOT watch a single word first any more: a row sum is a chain of tasks, each of
+        // which must see its predecessor's output within a hop (2.6 us) of the chain or the rows fall behind the chain; word +
+        // payload was two fabric round trips per link (3.75 us), the payload alone is one (2.3 us with the product).
         while (__builtin_expect(!complete(va), 0)) {
+            if (MODE == 1) __builtin_amdgcn_s_sleep(TRSV_TILE_BACKOFF);
             load_set(va);
             if (give_up()) break;
         }
@@ -260,14 +248,15 @@ __device__ __forceinline__ void trsv_half_fma(const TrsvHalf<T, BACK>& m, const 
     }
 }
 
-// P tiles of one direction (grid = (Nt, 1), 256 threads): forward P_b = W_b L(b,b-1) for b >= 1, backward P_b = L(b+1,b) W_b for
-// b <= Nt - 2; plain LDS-tiled fp64 / fp32 product, once per factor (a few tens of microseconds).
+// P tiles of one direction and gap (grid = (Nt, 2): blockIdx.y = gap - 1, 256 threads): forward P_b = W_b L(b,b-gap) for b >= gap,
+// backward P_b = L(b+gap,b) W_b for b <= Nt - 1 - gap; plain LDS-tiled fp64 / fp32 product, once per factor (tens of microseconds).
 template <typename T>
 __global__ __launch_bounds__(256) void trsv_prep_kernel(const T* __restrict__ A, int R128, const T* __restrict__ W, T* __restrict__ P, int nt, int back) {
     __shared__ T As[16][TB + 4], Bs[16][TB + 4];
-    const int b = blockIdx.x, tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
-    if (back ? b > nt - 2 : b < 1) return;
-    const T* Lt = A + tile_index(back ? b + 1 : b, back ? b : b - 1, R128) * TS;
+    const int b = blockIdx.x, gap = (int)blockIdx.y + 1, tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    if (back ? b > nt - 1 - gap : b < gap) return;
+    P += (long)blockIdx.y * nt * TS;
+    const T* Lt = A + tile_index(back ? b + gap : b, back ? b : b - gap, R128) * TS;
     const T* Wb = W + (long)b * TS;
     const T* Am = back ? Lt : Wb;                           // C = Am Bm
     const T* Bm = back ? Wb : Lt;
@@ -318,6 +307,7 @@ __global__ __launch_bounds__(TRSV_THREADS, 1) void trsv_dataflow_kernel(TrsvArgs
     const int lo = tid & 15, ob = tid >> 4;                // block along the contraction / output block (see trsv_load_tile)
     const int nt = g.nt, nrhs = g.nrhs;
     auto blk = [&](int K) { return BACK ? nt - 1 - K : K; };                        // mirrored -> real block index
+    const T* Xpoll = (g.dbg & 64) ? g.Xc : g.X;                                     // (developer timing: everybody polls the chain's copy)
     auto sslot = [&](int I, int K) { return g.S + ((long)I * (I - 1) / 2 + K) * nrhs * TB; };
     auto ltile = [&](int I, int K) {                                                // the tile that couples mirrored blocks I > K
         const int bi = blk(I), bk = blk(K);
@@ -326,11 +316,12 @@ __global__ __launch_bounds__(TRSV_THREADS, 1) void trsv_dataflow_kernel(TrsvArgs
 
     if ((int)blockIdx.x < 2 * TRSV_CHAIN) {
         // ---------------- chain role: pair c = blockIdx.x >> 1 takes the diagonal steps K = c, c + TRSV_CHAIN, ..; workgroup hf of the
-        // pair computes outputs 64 hf .. 64 hf + 63 of x_K = W_K s(K,K-2) - P_K x_{K-1}
+        // pair computes outputs 64 hf .. 64 hf + 63 of x_K = W_K s(K,K-3) - P2_K x_{K-2} - P1_K x_{K-1}
         // (measured and dropped: a row layout -- 32 contraction entries x 1 output per lane, half the VALU operations -- is TWICE
         //  as slow: its 16 LDS reads of x per lane expose the LDS latency sixteen times; profiles/r06_trsv_chain.txt)
-        TrsvHalf<T, BACK> w, pm;
+        TrsvHalf<T, BACK> w, p1, p2;
         const int hf = (int)blockIdx.x & 1;
+        T* xs2 = ss + TRSV_MAXR * TB;                       // [4][128] x of the step before the previous one
         for (int K = (int)blockIdx.x >> 1; K < nt; K += TRSV_CHAIN) {
             const int b = blk(K);
             long long* tr = (g.trace && hf == 0) ? g.trace + (long)K * 8 : nullptr;
@@ -339,43 +330,60 @@ __global__ __launch_bounds__(TRSV_THREADS, 1) void trsv_dataflow_kernel(TrsvArgs
             stamp(0);
             if (tr) st[6] = clock64();
             trsv_load_half<T, BACK>(w, g.W + (long)b * TS, lo, ob, hf);
-            if (K > 0) trsv_load_half<T, BACK>(pm, g.P + (long)b * TS, lo, ob, hf);
+            if (K > 0) trsv_load_half<T, BACK>(p1, g.P + (long)b * TS, lo, ob, hf);
+            if (K > 1) trsv_load_half<T, BACK>(p2, g.P + ((long)nt + b) * TS, lo, ob, hf);
             trsv_settle_half(w);                            // (this step's inputs are TRSV_CHAIN hops away: the wait is free)
-            trsv_settle_half(pm);
-            // inputs: the row sum so far (or the right-hand side itself), and x of the previous step
+            trsv_settle_half(p1);
+            trsv_settle_half(p2);
+            // early inputs: the row sum up to column K - 3 (or the right-hand side itself) and x of two steps back
             if (wave == 1) {
-                if (K >= 2 && !(g.dbg & 1)) trsv_fetch<T, 2>([&](int r) { return sslot(K, K - 2) + (long)r * TB; }, nrhs, ss, lane, g.abort_flag);
+                if (K >= 3 && !(g.dbg & 1)) trsv_fetch<T, 2>([&](int r) { return sslot(K, K - 3) + (long)r * TB; }, nrhs, ss, lane, g.abort_flag);
                 else trsv_fetch<T, 0>([&](int r) { return g.B + (long)r * g.ldx + (long)b * TB; }, nrhs, ss, lane, g.abort_flag);
             }
+            // (with back-off, from the tile role's copy: only the step that is NEXT polls the chain's copy hard -- five workgroups
+            //  hammering the lines of Xc stretched the hand-off from 1.25 to 1.9 us)
+            if (wave == 2 && K > 1)
+                trsv_fetch<T, 1>([&](int r) { return g.X + (long)r * g.ldx + (long)blk(K - 2) * TB; }, nrhs, xs2, lane, g.abort_flag);
+            __syncthreads();
+            stamp(2);
+            T y[TRSV_MAXR][2];
+#pragma unroll
+            for (int r = 0; r < TRSV_MAXR; ++r) {
+                y[r][0] = y[r][1] = (T)0;
+                if (r < nrhs) {
+                    trsv_half_fma<T, BACK>(w, ss + r * TB, lo, false, y[r]);
+                    if (K > 1) trsv_half_fma<T, BACK>(p2, xs2 + r * TB, lo, true, y[r]);
+                }
+            }
+            stamp(3);
+            // the late input: x of the previous step
             if (wave == 0 && K > 0)
                 trsv_fetch<T, 2>([&](int r) { return g.Xc + (long)r * g.ldx + (long)blk(K - 1) * TB; }, nrhs, xs, lane, g.abort_flag);
             stamp(1);
             __syncthreads();
-            stamp(2);
-            stamp(3);
-            for (int r = 0; r < nrhs; ++r) {
-                T y[2] = {(T)0, (T)0};
-                trsv_half_fma<T, BACK>(w, ss + r * TB, lo, false, y);
-                if (K > 0) trsv_half_fma<T, BACK>(pm, xs + r * TB, lo, true, y);
-                y[0] = trsv_row16_sum(y[0]);
-                y[1] = trsv_row16_sum(y[1]);
-                if (lo == 0) {
-                    T* oc = g.Xc + (long)r * g.ldx + (long)b * TB + 64 * hf + 2 * ob;                         // the chain first
-                    T* ox = g.X + (long)r * g.ldx + (long)b * TB + 64 * hf + 2 * ob;
-                    __hip_atomic_store(oc, y[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(oc + 1, y[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(ox, y[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(ox + 1, y[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
             stamp(4);
+#pragma unroll
+            for (int r = 0; r < TRSV_MAXR; ++r)
+                if (r < nrhs) {
+                    if (K > 0) trsv_half_fma<T, BACK>(p1, xs + r * TB, lo, true, y[r]);
+                    y[r][0] = trsv_row16_sum(y[r][0]);
+                    y[r][1] = trsv_row16_sum(y[r][1]);
+                    if (lo == 0) {
+                        T* oc = g.Xc + (long)r * g.ldx + (long)b * TB + 64 * hf + 2 * ob;                     // the chain first
+                        T* ox = g.X + (long)r * g.ldx + (long)b * TB + 64 * hf + 2 * ob;
+                        __hip_atomic_store(oc, y[r][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(oc + 1, y[r][1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(ox, y[r][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(ox + 1, y[r][1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
             stamp(5);
             if (tr) {
                 st[7] = clock64();
                 if (tid == 0)
                     for (int k = 0; k < 8; ++k) tr[k] = st[k];
             }
-            __syncthreads();                                // (ss / xs are rewritten by the next step)
+            __syncthreads();                                // (ss / xs / xs2 are rewritten by the next step)
         }
         return;
     }
@@ -394,18 +402,19 @@ __global__ __launch_bounds__(TRSV_THREADS, 1) void trsv_dataflow_kernel(TrsvArgs
         }
     };
     if ((int)blockIdx.x < 3 * TRSV_CHAIN) {
-        // ---------------- feeder role: workgroup c takes the tasks (K + 2, K), K = c, c + TRSV_CHAIN, .. -- the row sum the chain
-        // needs two hops after x_K.  In the common ticket list that task is picked up only after the previous column's tasks have
-        // been handed out (240 workgroups, up to 255 tasks per column at N = 32768): the chain then waits ~1.3 us per hop for
-        // it.  Here its tile is resident hops ahead and its inputs are polled directly.
+        // ---------------- feeder role: workgroup c takes the tasks (K + 3, K), K = c, c + TRSV_CHAIN, .. -- the last link of the row sum
+        // s(K+3, K) the chain consumes three hops after x_K.  In the common ticket list that task would be picked up only after the
+        // previous column's tasks have been handed out (230 workgroups, up to 250 tasks per column at N = 32768); here its tile
+        // is resident hops ahead and its inputs are polled directly.
         TrsvBlk<T, BACK> cur;
-        for (int K = (int)blockIdx.x - 2 * TRSV_CHAIN; K + 2 < nt; K += TRSV_CHAIN) {
-            const int I = K + 2;
+        for (int K = (int)blockIdx.x - 2 * TRSV_CHAIN; K + 3 < nt; K += TRSV_CHAIN) {
+            const int I = K + 3;
             trsv_load_tile<T, BACK>(cur, ltile(I, K), lo, ob);
             trsv_settle(cur);
-            if (wave == 0) trsv_fetch<T, 2>([&](int r) { return g.Xc + (long)r * g.ldx + (long)blk(K) * TB; }, nrhs, xs, lane, g.abort_flag);
+            // (three hops of slack: polite polls, off the chain's copy)
+            if (wave == 0) trsv_fetch<T, 1>([&](int r) { return g.X + (long)r * g.ldx + (long)blk(K) * TB; }, nrhs, xs, lane, g.abort_flag);
             if (wave == 1) {
-                if (K > 0) trsv_fetch<T, 2>([&](int r) { return sslot(I, K - 1) + (long)r * TB; }, nrhs, ss, lane, g.abort_flag);
+                if (K > 0) trsv_fetch<T, 1>([&](int r) { return sslot(I, K - 1) + (long)r * TB; }, nrhs, ss, lane, g.abort_flag);
                 else trsv_fetch<T, 0>([&](int r) { return g.B + (long)r * g.ldx + (long)blk(I) * TB; }, nrhs, ss, lane, g.abort_flag);
             }
             __syncthreads();
@@ -415,24 +424,24 @@ __global__ __launch_bounds__(TRSV_THREADS, 1) void trsv_dataflow_kernel(TrsvArgs
         return;
     }
 
-    // ---------------- tile role: tasks (I, K), K <= I - 3, column-major: column K holds I = K + 3 .. nt - 1
-    if (nt < 4) return;
-    const long ntasks = (long)(nt - 3) * (nt - 2) / 2;
+    // ---------------- tile role: tasks (I, K), K <= I - 4, column-major: column K holds I = K + 4 .. nt - 1
+    if (nt < 5) return;
+    const long ntasks = (long)(nt - 4) * (nt - 3) / 2;
     auto take = [&]() -> long {
         __syncthreads();                                    // (s_q of the previous take has been read by everybody)
         if (tid == 0) s_q = atomicAdd(g.ticket, 1u) + 1u;       // (the ticket starts at the sentinel: 0xFFFFFFFF + 1 = task 0)
         __syncthreads();
         return (long)s_q;
     };
-    auto decode = [&](long q, int& I, int& K) {             // off(K) = K (nt - 3) - K (K - 1) / 2
-        const double bq = (double)(2 * nt - 5);
+    auto decode = [&](long q, int& I, int& K) {             // off(K) = K (nt - 4) - K (K - 1) / 2
+        const double bq = (double)(2 * nt - 7);
         int k = (int)((bq - sqrt(bq * bq - 8.0 * (double)q)) * 0.5);
         if (k < 0) k = 0;
-        if (k > nt - 4) k = nt - 4;
-        while (k + 1 <= nt - 4 && (long)(k + 1) * (nt - 3) - (long)(k + 1) * k / 2 <= q) ++k;
-        while (k > 0 && (long)k * (nt - 3) - (long)k * (k - 1) / 2 > q) --k;
+        if (k > nt - 5) k = nt - 5;
+        while (k + 1 <= nt - 5 && (long)(k + 1) * (nt - 4) - (long)(k + 1) * k / 2 <= q) ++k;
+        while (k > 0 && (long)k * (nt - 4) - (long)k * (k - 1) / 2 > q) --k;
         K = __builtin_amdgcn_readfirstlane(k);
-        I = __builtin_amdgcn_readfirstlane(k + 3 + (int)(q - ((long)k * (nt - 3) - (long)k * (k - 1) / 2)));
+        I = __builtin_amdgcn_readfirstlane(k + 4 + (int)(q - ((long)k * (nt - 4) - (long)k * (k - 1) / 2)));
     };
     TrsvBlk<T, BACK> ta, tb;
     long q = take();
@@ -447,7 +456,7 @@ __global__ __launch_bounds__(TRSV_THREADS, 1) void trsv_dataflow_kernel(TrsvArgs
             decode(qn, In, Kn);
             trsv_load_tile<T, BACK>(nxt, ltile(In, Kn), lo, ob);   // in flight while this task waits for its inputs
         }
-        if (wave == 0) trsv_fetch<T, 1>([&](int r) { return g.X + (long)r * g.ldx + (long)blk(K) * TB; }, nrhs, xs, lane, g.abort_flag);
+        if (wave == 0) trsv_fetch<T, 1>([&](int r) { return Xpoll + (long)r * g.ldx + (long)blk(K) * TB; }, nrhs, xs, lane, g.abort_flag);
         if (wave == 1) {
             if (K > 0) trsv_fetch<T, 1>([&](int r) { return sslot(I, K - 1) + (long)r * TB; }, nrhs, ss, lane, g.abort_flag);
             else trsv_fetch<T, 0>([&](int r) { return g.B + (long)r * g.ldx + (long)blk(I) * TB; }, nrhs, ss, lane, g.abort_flag);
@@ -465,6 +474,6 @@ __global__ __launch_bounds__(TRSV_THREADS, 1) void trsv_dataflow_kernel(TrsvArgs
     }
 }
 
-constexpr size_t trsv_lds_bytes(size_t es) { return (size_t)(2 * TRSV_MAXR * TB) * es; }
+constexpr size_t trsv_lds_bytes(size_t es) { return (size_t)(3 * TRSV_MAXR * TB) * es; }
 
 }  // namespace gphip

@@ -185,7 +185,7 @@ struct gphip_ctx {
     void* dAlpha = nullptr;                                  // typed [Npad] (gradient)
     // single-vector substitutions (gp_trsv.h): input block + two passes of {solution, chain copy, row sums, ticket} (trsv_pass_elems)
     void* dTrsvX = nullptr;
-    void* dTrsvP = nullptr;                                  // typed [2][Nt][128 x 128]: the chain's products P_b of both directions (trsv_prep_kernel)
+    void* dTrsvP = nullptr;                                  // typed [2 directions][2 gaps][Nt][128 x 128]: the chain's products (trsv_prep_kernel)
     unsigned long trsvp_gen = ~0ul;                          // ws_gen of the factor they were made from
     int trsv = 1;                                            // option: gphip_solve with <= 4 right-hand sides and alpha through trsv_dataflow_kernel
     int ncu = 0;                                             // compute units of the device
@@ -1794,7 +1794,7 @@ bool trsv_ok(gphip_ctx* h, int nrhs) {
     if (!h->trsv || nrhs < 1 || nrhs > TRSV_MAXR || h->Nt > 512 || h->dist_world > 0 || h->ws_override) return false;
     const size_t bytes = ((size_t)TRSV_MAXR * h->Npad + 2 * trsv_pass_elems(h, TRSV_MAXR)) * h->es;
     if (!h->dTrsvX && hipMalloc(&h->dTrsvX, bytes) != hipSuccess) { (void)hipGetLastError(); h->dTrsvX = nullptr; return false; }
-    if (!h->dTrsvP && hipMalloc(&h->dTrsvP, (size_t)2 * h->Nt * TS * h->es) != hipSuccess) { (void)hipGetLastError(); h->dTrsvP = nullptr; return false; }
+    if (!h->dTrsvP && hipMalloc(&h->dTrsvP, (size_t)4 * h->Nt * TS * h->es) != hipSuccess) { (void)hipGetLastError(); h->dTrsvP = nullptr; return false; }
     return true;
 }
 template <typename T> T* trsv_input(gphip_ctx* h) { return (T*)h->dTrsvX; }
@@ -1813,19 +1813,19 @@ int queue_trsv(gphip_ctx* h, const T* B, int pass, int nrhs, bool back, T** Xout
     const int nt = (int)h->Nt;
     if (h->trsvp_gen != h->ws_gen) {             // first substitution with this factor: the chain's products, both directions
         for (int dir = 0; dir < 2; ++dir)
-            hipLaunchKernelGGL(trsv_prep_kernel<T>, dim3((unsigned)nt), dim3(256), 0, h->stream, (const T*)h->dA, (int)h->R, (const T*)h->dW,
-                               (T*)h->dTrsvP + (size_t)dir * nt * TS, nt, dir);
+            hipLaunchKernelGGL(trsv_prep_kernel<T>, dim3((unsigned)nt, 2), dim3(256), 0, h->stream, (const T*)h->dA, (int)h->R, (const T*)h->dW,
+                               (T*)h->dTrsvP + (size_t)dir * 2 * nt * TS, nt, dir);
         h->trsvp_gen = h->ws_gen;
     }
     T* base = trsv_pass<T>(h, nrhs, pass);
     TrsvArgs<T> g{};
     g.A = (const T*)h->dA; g.R128 = (int)h->R; g.W = (const T*)h->dW; g.B = B; g.ldx = (long)h->Npad;
-    g.P = (const T*)h->dTrsvP + (size_t)(back ? 1 : 0) * nt * TS;
+    g.P = (const T*)h->dTrsvP + (size_t)(back ? 1 : 0) * 2 * nt * TS;
     g.X = base; g.Xc = base + (size_t)nrhs * h->Npad; g.S = base + (size_t)2 * nrhs * h->Npad;
     g.ticket = reinterpret_cast<unsigned int*>(g.S + (size_t)nrhs * TB * (size_t)(nt * (nt - 1) / 2 + 1));
     g.nt = nt; g.nrhs = nrhs; g.back = back ? 1 : 0; g.dbg = h->trsv >> 1;
     g.abort_flag = reinterpret_cast<int*>(h->dTicket + 1);
-    const long ntasks = nt >= 4 ? (long)(nt - 3) * (nt - 2) / 2 : 0;                 // common ticket list: I >= K + 3
+    const long ntasks = nt >= 5 ? (long)(nt - 4) * (nt - 3) / 2 : 0;                 // common ticket list: I >= K + 4
     const long grid = std::min<long>((long)h->ncu, 3 * TRSV_CHAIN + ntasks);         // chain pairs + feeders + tile role; one per CU: all resident
     ProfScope ps(h, 2, 0.0, (double)h->slot_elems * sizeof(T));
     if (back) hipLaunchKernelGGL((trsv_dataflow_kernel<T, true>), dim3((unsigned)grid), dim3(TRSV_THREADS), trsv_lds_bytes(sizeof(T)), h->stream, g);

@@ -23,7 +23,7 @@ int main(int argc, char** argv) {
     double *dA, *dW, *dB, *dX, *dXc, *dS, *dP; unsigned int* dT; int* dAb; long long* dTr;
     const size_t sbytes = (size_t)nrhs * TB * ((size_t)Nt * (Nt - 1) / 2 + 1) * 8;
     hipMalloc(&dA, A.size() * 8); hipMalloc(&dW, W.size() * 8); hipMalloc(&dB, B.size() * 8); hipMalloc(&dX, B.size() * 8);
-    hipMalloc(&dP, W.size() * 8); hipMemcpy(dP, A.data(), W.size() * 8, hipMemcpyHostToDevice);      // (any small numbers)
+    hipMalloc(&dP, 2 * W.size() * 8); hipMemcpy(dP, A.data(), 2 * W.size() * 8, hipMemcpyHostToDevice);      // (any small numbers)
     hipMalloc(&dXc, B.size() * 8); hipMalloc(&dS, sbytes); hipMalloc(&dT, 256); hipMalloc(&dAb, 256); hipMalloc(&dTr, (size_t)Nt * 64);
     hipMemcpy(dA, A.data(), A.size() * 8, hipMemcpyHostToDevice); hipMemcpy(dW, W.data(), W.size() * 8, hipMemcpyHostToDevice);
     hipMemcpy(dB, B.data(), B.size() * 8, hipMemcpyHostToDevice); hipMemset(dAb, 0, 256);
@@ -37,7 +37,7 @@ int main(int argc, char** argv) {
             TrsvArgs<double> g{};
             g.A = dA; g.R128 = R128; g.W = dW; g.P = dP; g.B = dB; g.X = dX; g.Xc = dXc; g.S = dS; g.ldx = npad; g.nt = Nt; g.nrhs = nrhs; g.back = back;
             g.dbg = dbg; g.ticket = dT; g.abort_flag = dAb; g.trace = dTr;
-            const long ntasks = Nt >= 4 ? (long)(Nt - 3) * (Nt - 2) / 2 : 0;
+            const long ntasks = Nt >= 5 ? (long)(Nt - 4) * (Nt - 3) / 2 : 0;
             const long grid = std::min<long>(nwg, 3 * TRSV_CHAIN + ntasks);
             hipEventRecord(e0, 0);
             if (back) hipLaunchKernelGGL((trsv_dataflow_kernel<double, true>), dim3((unsigned)grid), dim3(TRSV_THREADS), trsv_lds_bytes(8), 0, g);
@@ -51,20 +51,22 @@ int main(int argc, char** argv) {
         printf("%s: Nt=%d nrhs=%d dbg=%d wgs=%d: %.3f ms = %.2f us per step (abort %d)\n", back ? "backward" : "forward", Nt, nrhs, dbg, nwg, best,
                best * 1e3 / Nt, ab);
         auto us = [&](long long a, long long b) { return (a - b) / 100.0; };
-        double acc[6] = {0}, mv = 0;
+        double acc[8] = {0};
         int cnt = 0;
-        for (int K = 2; K < Nt; ++K) {
+        for (int K = 3; K < Nt; ++K) {
             const long long* t = &tr[(size_t)K * 8]; const long long* p = &tr[(size_t)(K - 1) * 8];
+            // stamps: 0 step start, 2 early inputs in LDS, 3 early sums done, 1 x of the previous step fetched, 4 barrier passed, 5 stored
+            const double v[6] = {us(t[2], p[5]), us(t[3], t[2]), us(t[1], p[5]), us(t[4], t[1]), us(t[5], t[4]), us(t[5], p[5])};
             if (K % (Nt / 8 > 0 ? Nt / 8 : 1) == 3)
-                printf("  step %3d: prev stored -> x seen %5.2f | barrier %5.2f | (unused) %5.2f | W s - P x + store %5.2f | step start was %7.2f before x seen\n",
-                       K, us(t[1], p[5]), us(t[2], t[1]), us(t[3], t[2]), us(t[5], t[3]), us(t[1], t[0]));
-            acc[0] += us(t[1], p[5]); acc[1] += us(t[2], t[1]); acc[2] += us(t[3], t[2]); acc[3] += us(t[5], t[3]);
-            acc[5] += us(t[5], p[5]); mv += us(t[4], t[2]);
-            acc[4] += (double)(t[7] - t[6]) / (double)(t[5] - t[0]) * 100.0;          // shader clocks per 10 ns tick -> MHz
+                printf("  step %3d: early inputs in %+6.2f (rel. prev store) | early sums %5.2f | x seen %+6.2f (rel. prev store) | barrier %5.2f | P1 x + reduction + store %5.2f | step start was %7.2f before x seen\n",
+                       K, v[0], v[1], v[2], v[3], v[4], us(t[1], t[0]));
+            for (int i = 0; i < 6; ++i) acc[i] += v[i];
+            acc[6] += (double)(t[7] - t[6]) / (double)(t[5] - t[0]) * 100.0;          // shader clocks per 10 ns tick -> MHz
             ++cnt;
         }
-        printf("  mean over %d steps: hand-off %.2f | barrier %.2f | (unused) %.2f | W s - P x + reduction + store %.2f || store-to-store %.2f us | shader clock %.0f MHz | (unused %.2f)\n", cnt,
-               acc[0] / cnt, acc[1] / cnt, acc[2] / cnt, acc[3] / cnt, acc[5] / cnt, acc[4] / cnt, mv / cnt);
+        printf("  mean over %d steps: early inputs in %+.2f (rel. prev store) | early sums %.2f | hand-off (prev stored -> x seen) %.2f | barrier %.2f | "
+               "P1 x + reduction + store %.2f || store-to-store %.2f us | shader clock %.0f MHz\n", cnt, acc[0] / cnt, acc[1] / cnt, acc[2] / cnt,
+               acc[3] / cnt, acc[4] / cnt, acc[5] / cnt, acc[6] / cnt);
     }
     return 0;
 }
