@@ -474,6 +474,23 @@ __global__ __launch_bounds__(TRSV_THREADS, 1) void trsv_dataflow_kernel(TrsvArgs
     }
 }
 
+// A few right-hand sides for the GEMM-shaped substitution (5 .. ~100 vectors): they ride as ROWS of the 128-row scratch block V
+// (column-major, leading dimension mpad).  The host used to build and move the whole zero-padded block -- 16 MB each way at
+// N = 16384 for five vectors, 17 ms of a 20 ms call; now it moves the vectors themselves ([mc][npad], contiguous) and these two
+// kernels scatter / gather them on the device.
+template <typename T>
+__global__ void rows_to_vblock_kernel(const T* __restrict__ rows, int mc, long npad, T* __restrict__ V, long mpad) {
+    const long j = (long)blockIdx.x * blockDim.x + threadIdx.x;           // point index; one thread fills column j of V
+    if (j >= npad) return;
+    for (long t = 0; t < mpad; ++t) V[j * mpad + t] = t < mc ? rows[t * npad + j] : (T)0;
+}
+template <typename T>
+__global__ void vblock_to_rows_kernel(const T* __restrict__ V, long mpad, int mc, long npad, T* __restrict__ rows) {
+    const long j = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= npad) return;
+    for (int t = 0; t < mc; ++t) rows[(long)t * npad + j] = V[j * mpad + t];
+}
+
 constexpr size_t trsv_lds_bytes(size_t es) { return (size_t)(3 * TRSV_MAXR * TB) * es; }
 
 }  // namespace gphip

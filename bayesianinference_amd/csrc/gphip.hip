@@ -185,6 +185,7 @@ struct gphip_ctx {
     void* dAlpha = nullptr;                                  // typed [Npad] (gradient)
     // single-vector substitutions (gp_trsv.h): input block + two passes of {solution, chain copy, row sums, ticket} (trsv_pass_elems)
     void* dTrsvX = nullptr;
+    void* dRows = nullptr; size_t rows_cap = 0;              // gphip_solve, few vectors on the GEMM path: [mc][Npad] staging block (rows_to_vblock_kernel)
     void* dTrsvP = nullptr;                                  // typed [2 directions][2 gaps][Nt][128 x 128]: the chain's products (trsv_prep_kernel)
     unsigned long trsvp_gen = ~0ul;                          // ws_gen of the factor they were made from
     int trsv = 1;                                            // option: gphip_solve with <= 4 right-hand sides and alpha through trsv_dataflow_kernel
@@ -2314,7 +2315,7 @@ int gphip_destroy(gphip_handle h) {
     if (h->cgmod) (void)hipModuleUnload(h->cgmod);
     (void)hipFree(h->dV); (void)hipFree(h->dXsT); (void)hipFree(h->dXsS); (void)hipFree(h->dMean);
     (void)hipFree(h->dVar); (void)hipFree(h->dAlpha); (void)hipFree(h->dGacc); (void)hipFree(h->dKinv);
-    (void)hipFree(h->dTrsvX); (void)hipFree(h->dTrsvP);
+    (void)hipFree(h->dTrsvX); (void)hipFree(h->dTrsvP); (void)hipFree(h->dRows);
     (void)hipFree(h->dXsS2); (void)hipFree(h->dPwMeanT); (void)hipFree(h->dPwNugT);
     (void)hipFree(h->dNullMu); (void)hipFree(h->dNullOut); (void)hipFree(h->dPart);
     for (auto e : h->pool) (void)hipEventDestroy(e);
@@ -3163,50 +3164,53 @@ int gphip_solve(gphip_handle h, const double* rhs, int64_t nrhs, double* out) {
     const int64_t N = h->N, Npad = h->Npad, MC = 2048;
     // (a non-finite right-hand side keeps the GEMM-shaped substitution: the single-vector launches recognise "not written yet" by
     //  an all-ones NaN pattern, which arithmetic on a NaN with that payload could reproduce -- a seconds-long wait, then an error)
-    bool rhs_finite = nrhs <= TRSV_MAXR;
+    // 1 .. 4 vectors always, up to 16 from N = 12288 on (there the GEMM-shaped substitution is hundreds of launches at ~17 us of
+    // host time each: five vectors at N = 16384 14.6 ms against two batches of the single-vector launches, ~2.5 ms)
+    bool rhs_finite = nrhs <= TRSV_MAXR || (nrhs <= 4 * TRSV_MAXR && h->Nt >= 96);
     for (int64_t i = 0; rhs_finite && i < nrhs * N; ++i) rhs_finite = std::isfinite(rhs[i]);
-    if (rhs_finite && trsv_ok(h, (int)std::min<int64_t>(nrhs, TRSV_MAXR + 1))) {
-        // 1 .. 4 right-hand sides: two launches that stream the factor once each (gp_trsv.h) instead of a 128-row GEMM substitution
-        const int nr = (int)nrhs;
+    if (rhs_finite && trsv_ok(h, (int)std::min<int64_t>(nrhs, TRSV_MAXR))) {
+        // two launches per batch of <= 4 right-hand sides that stream the factor once each (gp_trsv.h) instead of a 128-row GEMM substitution
         h->cs = h->stream;
-        std::vector<double> b((size_t)nr * Npad, 0.0);
-        for (int t = 0; t < nr; ++t)
-            for (int64_t j = 0; j < N; ++j) b[(size_t)t * Npad + j] = rhs[(size_t)t * N + j];
-        // (no synchronisation after the upload: `b` lives until the download below has synchronised the stream)
+        std::vector<double> b;
         std::vector<float> b32;
-        if (h->dtype == 64) {
-            HIPCHK(hipMemcpyAsync(h->dTrsvX, b.data(), b.size() * 8, hipMemcpyHostToDevice, h->stream));
-        } else {
-            b32.assign(b.begin(), b.end());
-            HIPCHK(hipMemcpyAsync(h->dTrsvX, b32.data(), b32.size() * 4, hipMemcpyHostToDevice, h->stream));
+        for (int64_t m0 = 0; m0 < nrhs; m0 += TRSV_MAXR) {
+            const int nr = (int)std::min<int64_t>(TRSV_MAXR, nrhs - m0);
+            b.assign((size_t)nr * Npad, 0.0);
+            for (int t = 0; t < nr; ++t) memcpy(&b[(size_t)t * Npad], rhs + (m0 + t) * N, (size_t)N * 8);
+            // (no synchronisation after the upload: `b` lives until the download below has synchronised the stream)
+            if (h->dtype == 64) {
+                HIPCHK(hipMemcpyAsync(h->dTrsvX, b.data(), b.size() * 8, hipMemcpyHostToDevice, h->stream));
+            } else {
+                b32.assign(b.begin(), b.end());
+                HIPCHK(hipMemcpyAsync(h->dTrsvX, b32.data(), b32.size() * 4, hipMemcpyHostToDevice, h->stream));
+            }
+            // forward: input -> pass 0; backward: pass 0 -> pass 1
+            int rc;
+            void* xres = nullptr;
+            if (h->dtype == 64) {
+                double *x0 = nullptr, *x1 = nullptr;
+                rc = queue_trsv_fill<double>(h, nr, 2);
+                if (!rc) rc = queue_trsv<double>(h, trsv_input<double>(h), 0, nr, false, &x0);
+                if (!rc) rc = queue_trsv<double>(h, x0, 1, nr, true, &x1);
+                xres = x1;
+            } else {
+                float *x0 = nullptr, *x1 = nullptr;
+                rc = queue_trsv_fill<float>(h, nr, 2);
+                if (!rc) rc = queue_trsv<float>(h, trsv_input<float>(h), 0, nr, false, &x0);
+                if (!rc) rc = queue_trsv<float>(h, x0, 1, nr, true, &x1);
+                xres = x1;
+            }
+            if (rc) return rc;
+            rc = queue_abort_probe(h);
+            if (rc) return rc;
+            rc = DISPATCH(h, download, h, b, xres, (size_t)nr * Npad, h->stream);
+            if (rc) return rc;
+            HIPCHK(hipGetLastError());
+            harvest(h);
+            rc = abort_probe_verdict(h, "single-vector substitution timed out (set option trsv=0 and report)");
+            if (rc) return rc;
+            for (int t = 0; t < nr; ++t) memcpy(out + (m0 + t) * N, &b[(size_t)t * Npad], (size_t)N * 8);
         }
-        // forward: input -> pass 0; backward: pass 0 -> pass 1
-        int rc;
-        void* xres = nullptr;
-        if (h->dtype == 64) {
-            double *x0 = nullptr, *x1 = nullptr;
-            rc = queue_trsv_fill<double>(h, nr, 2);
-            if (!rc) rc = queue_trsv<double>(h, trsv_input<double>(h), 0, nr, false, &x0);
-            if (!rc) rc = queue_trsv<double>(h, x0, 1, nr, true, &x1);
-            xres = x1;
-        } else {
-            float *x0 = nullptr, *x1 = nullptr;
-            rc = queue_trsv_fill<float>(h, nr, 2);
-            if (!rc) rc = queue_trsv<float>(h, trsv_input<float>(h), 0, nr, false, &x0);
-            if (!rc) rc = queue_trsv<float>(h, x0, 1, nr, true, &x1);
-            xres = x1;
-        }
-        if (rc) return rc;
-        rc = queue_abort_probe(h);
-        if (rc) return rc;
-        rc = DISPATCH(h, download, h, b, xres, (size_t)nr * Npad, h->stream);
-        if (rc) return rc;
-        HIPCHK(hipGetLastError());
-        harvest(h);
-        rc = abort_probe_verdict(h, "single-vector substitution timed out (set option trsv=0 and report)");
-        if (rc) return rc;
-        for (int t = 0; t < nr; ++t)
-            for (int64_t j = 0; j < N; ++j) out[(size_t)t * N + j] = b[(size_t)t * Npad + j];
         return GPHIP_OK;
     }
     int rc = ensure_vbuf(h, nrhs < MC ? (nrhs + TB - 1) / TB * TB : MC);
@@ -3216,11 +3220,35 @@ int gphip_solve(gphip_handle h, const double* rhs, int64_t nrhs, double* out) {
     for (int64_t m0 = 0; m0 < nrhs; m0 += MC) {
         const int64_t mc = (nrhs - m0 < MC) ? (nrhs - m0) : MC;
         const int64_t mpad = (mc + TB - 1) / TB * TB;
-        v.assign((size_t)mpad * Npad, 0.0);
-        for (int64_t t = 0; t < mc; ++t)
-            for (int64_t j = 0; j < N; ++j) v[(size_t)j * mpad + t] = rhs[(m0 + t) * N + j];
-        rc = DISPATCH(h, upload, h, h->dV, v, h->stream);
-        if (rc) return rc;
+        // few vectors in a 128-row block: move the vectors, not the zero padding (rows_to_vblock_kernel); the staging block is the
+        // single-vector path's scratch when it exists and is large enough, else a buffer of its own
+        const bool compact = mc * 4 <= mpad * 3;
+        void* dRows = nullptr;
+        if (compact) {
+            const size_t need = (size_t)mc * Npad * h->es;
+            if (need > h->rows_cap) {
+                (void)hipFree(h->dRows);
+                h->dRows = nullptr; h->rows_cap = 0;
+                if (hipMalloc(&h->dRows, need) == hipSuccess) h->rows_cap = need;
+                else (void)hipGetLastError();
+            }
+            dRows = h->rows_cap >= need ? h->dRows : nullptr;
+        }
+        if (dRows) {
+            v.assign((size_t)mc * Npad, 0.0);
+            for (int64_t t = 0; t < mc; ++t) memcpy(&v[(size_t)t * Npad], rhs + (m0 + t) * N, (size_t)N * 8);
+            rc = DISPATCH(h, upload, h, dRows, v, h->stream);
+            if (rc) return rc;
+            const unsigned gx = (unsigned)((Npad + 255) / 256);
+            if (h->dtype == 64) hipLaunchKernelGGL(rows_to_vblock_kernel<double>, dim3(gx), dim3(256), 0, h->stream, (const double*)dRows, (int)mc, (long)Npad, (double*)h->dV, (long)mpad);
+            else hipLaunchKernelGGL(rows_to_vblock_kernel<float>, dim3(gx), dim3(256), 0, h->stream, (const float*)dRows, (int)mc, (long)Npad, (float*)h->dV, (long)mpad);
+        } else {
+            v.assign((size_t)mpad * Npad, 0.0);
+            for (int64_t t = 0; t < mc; ++t)
+                for (int64_t j = 0; j < N; ++j) v[(size_t)j * mpad + t] = rhs[(m0 + t) * N + j];
+            rc = DISPATCH(h, upload, h, h->dV, v, h->stream);
+            if (rc) return rc;
+        }
         // after a single-launch fit both halves are ONE dataflow launch each (forward as in gphip_predict; backward over a copy of
         // the factor with its 64 x 64 blocks transposed, made on the first solve of a fit)
         const bool dfs = df_forward_ok(h, mpad);
@@ -3229,13 +3257,24 @@ int gphip_solve(gphip_handle h, const double* rhs, int64_t nrhs, double* out) {
         if (dfs && df_backward_ready<double>(h)) launch_dataflow_inverse<double, 64>(h, mpad, true);
         else DISPATCH(h, queue_backward_rows, h, mpad);
         if (dfs) { rc = queue_abort_probe(h); if (rc) return rc; }
-        rc = DISPATCH(h, download, h, v, h->dV, (size_t)mpad * Npad, h->stream);
+        if (dRows) {
+            const unsigned gx = (unsigned)((Npad + 255) / 256);
+            if (h->dtype == 64) hipLaunchKernelGGL(vblock_to_rows_kernel<double>, dim3(gx), dim3(256), 0, h->stream, (const double*)h->dV, (long)mpad, (int)mc, (long)Npad, (double*)dRows);
+            else hipLaunchKernelGGL(vblock_to_rows_kernel<float>, dim3(gx), dim3(256), 0, h->stream, (const float*)h->dV, (long)mpad, (int)mc, (long)Npad, (float*)dRows);
+            rc = DISPATCH(h, download, h, v, dRows, (size_t)mc * Npad, h->stream);
+        } else {
+            rc = DISPATCH(h, download, h, v, h->dV, (size_t)mpad * Npad, h->stream);
+        }
         if (rc) return rc;
         HIPCHK(hipGetLastError());
         harvest(h);
         if (dfs) { rc = abort_probe_verdict(h, "dataflow substitution timed out (set option predict_df=0 and report)"); if (rc) return rc; }
-        for (int64_t t = 0; t < mc; ++t)
-            for (int64_t j = 0; j < N; ++j) out[(m0 + t) * N + j] = v[(size_t)j * mpad + t];
+        if (dRows) {
+            for (int64_t t = 0; t < mc; ++t) memcpy(out + (m0 + t) * N, &v[(size_t)t * Npad], (size_t)N * 8);
+        } else {
+            for (int64_t t = 0; t < mc; ++t)
+                for (int64_t j = 0; j < N; ++j) out[(m0 + t) * N + j] = v[(size_t)j * mpad + t];
+        }
     }
     return GPHIP_OK;
 }

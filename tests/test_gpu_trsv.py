@@ -88,3 +88,26 @@ def test_gradient_alpha_through_the_backward_launch():
         np.testing.assert_allclose(g, want, rtol=1e-7, atol=1e-7 * np.abs(want).max())
         res[trsv] = g
     np.testing.assert_allclose(res[1], res[0], rtol=1e-9, atol=1e-9 * np.abs(want).max())
+
+
+def test_up_to_sixteen_vectors_in_batches_at_large_n():
+    """From N = 12288 on, 5 .. 16 right-hand sides go through the single-vector launches in batches of four (there the
+    GEMM-shaped substitution is hundreds of launches: five vectors at N = 16384 14.6 -> 2.9 ms): the same solutions as the
+    GEMM-shaped path (itself held to the oracle elsewhere), ragged N, and K x = b on sampled rows (BGP:29-43 for the rows)."""
+    n, d, nrhs = 12400, 4, 6
+    X, y = syn.make_dataset(n, d)
+    th = syn.default_theta("se_ard", d)
+    th[-1] = 0.3
+    B = np.random.default_rng(5).standard_normal((n, nrhs))
+    h = _lib.Handle(X, y, "se_ard")
+    assert h.fit(th) == 0
+    got = h.solve(B)
+    h.set_option("trsv", 0)
+    old = h.solve(B)
+    h.close()
+    scale = np.abs(old).max()
+    np.testing.assert_allclose(got, old, rtol=1e-9, atol=1e-10 * scale)
+    rows = np.array([0, 1, 127, 128, 5000, 12287, 12288, n - 1])
+    Krows = orc.kernel_matrix("se_ard", th[:d], th[d], X[rows], X)
+    Krows[np.arange(len(rows)), rows] += th[-1] ** 2
+    assert np.abs(Krows @ got - B[rows]).max() <= 1e-8 * n
