@@ -491,6 +491,20 @@ __global__ void vblock_to_rows_kernel(const T* __restrict__ V, long mpad, int mc
     for (int t = 0; t < mc; ++t) rows[(long)t * npad + j] = V[j * mpad + t];
 }
 
+// The two 64 x 64 diagonal blocks of a 128-block inverse W_b = L_bb^-1 ARE the inverses of L_bb's 64 x 64 diagonal blocks: the
+// 64-block inverses the forward / backward dataflow launches substitute with (DfArgs::W, [2 Nt][64 x 64], column-major) can
+// be cut out of dW after ANY fit -- also one that came from the look-ahead schedule, which only produces 128-block inverses.
+template <typename T>
+__global__ __launch_bounds__(256) void w128_to_w64_kernel(const T* __restrict__ W128, T* __restrict__ W64) {
+    const int j = blockIdx.x, b = j >> 1, q = j & 1;       // 64-block j = half q of 128-block b
+    const T* src = W128 + (long)b * TS + (long)(q * 64) * TB + q * 64;
+    T* dst = W64 + (long)j * 4096;
+    for (int idx = threadIdx.x; idx < 4096; idx += 256) {
+        const int c = idx >> 6, r = idx & 63;
+        dst[idx] = src[(long)c * TB + r];
+    }
+}
+
 constexpr size_t trsv_lds_bytes(size_t es) { return (size_t)(3 * TRSV_MAXR * TB) * es; }
 
 }  // namespace gphip

@@ -152,6 +152,7 @@ struct gphip_ctx {
     int fuse_option = 1;                         // allow the single-launch evaluation (option "fused_eval")
     int grad_potri = 1;                          // gradient: K^-1 = U U^T in one go when the memory is there (1: U = L^-T from the dataflow kernel's
                                                  // inverse launch where the factor came from one launch; 2: always from the multi-kernel forward pass)
+    int predict_df_max_nt = 256;                 // .. and, after a look-ahead-schedule fit, up to this many tile columns (N = 32768)
     int predict_df = 2048;                       // prediction after a single-launch fit: forward substitution as ONE dataflow launch up to this many (padded) test points
                                                  // (twice that up to N = 8192); 0 = never
     int panel_wide = 1;                          // wider outer panels while the trailing matrix is large (queue_factor)
@@ -922,6 +923,18 @@ bool df_backward_ready(gphip_ctx* h) {
     hipLaunchKernelGGL(transpose_blocks64_kernel<T>, dim3((unsigned)(2 * h->Nt)), dim3(256), 0, h->stream, (const T*)h->dW64, (T*)h->dW64T, 4096l, 64, 1);
     h->lt_gen = h->ws_gen;
     return true;
+}
+
+// After a fit that did not come from the 64-tile single launch (N > 12288: the look-ahead schedule leaves 128-block inverses in
+// dW): cut the 64-block inverses out of them, so that a prediction of few test points is ONE forward dataflow launch there too
+// instead of two launches per tile column (N = 16384, 100 test points: 256 launches, 9.1 ms per call).
+void ensure_w64(gphip_ctx* h) {
+    if (!h->dataflow || h->predict_df <= 0 || h->dtype != 64 || h->dist_world != 0 || h->dist_fit || !has_fit(h) || !h->dW) return;
+    if (h->dW64 && h->w64_gen == h->ws_gen) return;
+    if (h->Nt > h->predict_df_max_nt) return;
+    if (!h->dW64 && hipMalloc(&h->dW64, (size_t)h->Nt * TB * TB * sizeof(double)) != hipSuccess) { (void)hipGetLastError(); h->dW64 = nullptr; return; }
+    hipLaunchKernelGGL(w128_to_w64_kernel<double>, dim3((unsigned)(2 * h->Nt)), dim3(256), 0, h->stream, (const double*)h->dW, (double*)h->dW64);
+    h->w64_gen = h->ws_gen;
 }
 
 bool df_forward_ok(const gphip_ctx* h, int64_t mpad) {
@@ -2773,6 +2786,7 @@ static int predict_local(gphip_handle h, const void* Xs, int64_t M, double* mean
         rc = upload_pw_test(h, 0, 1, m0, mc, mpad);
         if (rc) return rc;
         DISPATCH(h, queue_cross, h, mc, mpad, 1);
+        ensure_w64(h);
         const bool dfp = df_forward_ok(h, mpad);
         if (dfp) launch_dataflow_inverse<double, 64>(h, mpad);
         else DISPATCH(h, queue_forward_rows, h, mpad, 1);
@@ -3501,7 +3515,7 @@ int* option_slot(gphip_ctx* h, const char* name) {
         {"dataflow_occ3", &gphip_ctx::dataflow_occ3},
         {"fused_eval", &gphip_ctx::fuse_option}, {"panel_df", &gphip_ctx::panel_df}, {"grad_potri", &gphip_ctx::grad_potri}, {"predict_df", &gphip_ctx::predict_df},
         {"kbuild_mfma", &gphip_ctx::kbuild_mfma}, {"kbuild_mfma_bound", &gphip_ctx::kbuild_mfma_bound},
-        {"kbuild_mfma_digits", &gphip_ctx::kbuild_mfma_digits}, {"trsv", &gphip_ctx::trsv}, {"last_issue_us", &gphip_ctx::last_issue_us},
+        {"kbuild_mfma_digits", &gphip_ctx::kbuild_mfma_digits}, {"trsv", &gphip_ctx::trsv}, {"predict_df_max_nt", &gphip_ctx::predict_df_max_nt}, {"last_issue_us", &gphip_ctx::last_issue_us},
         {"custom_grad", &gphip_ctx::custom_grad}, {"grad_analytic", &gphip_ctx::grad_analytic},
         {"max_slots", &gphip_ctx::max_slots}, {"shard_min_n", &gphip_ctx::shard_min_n},
         {"replicate_factor", &gphip_ctx::replicate_factor}, {"share_local_panels", &gphip_ctx::share_local_panels},

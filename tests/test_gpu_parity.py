@@ -665,9 +665,10 @@ def test_gradient_inverse_launch_equals_forward_pass(n, d, dtype):
     h.close()
 
 
-@pytest.mark.parametrize("n,d,m", [(1900, 3, 70), (3000, 2, 1), (700, 5, 640), (9000, 4, 200), (300, 2, 500)])
+@pytest.mark.parametrize("n,d,m", [(1900, 3, 70), (3000, 2, 1), (700, 5, 640), (9000, 4, 200), (300, 2, 500), (13100, 3, 90)])
 def test_prediction_forward_launch_equals_multi_kernel_substitution(n, d, m):
-    """a7: after a fit that came from the 64-tile single launch, a prediction of few test points runs its forward substitution
+    """a7: after a fit that came from the 64-tile single launch -- or (round 6) from the look-ahead schedule, N = 13100: the 64-block
+    inverses are then cut out of the 128-block ones, w128_to_w64_kernel -- a prediction of few test points runs its forward substitution
     v = L^-1 k* as ONE dataflow launch (tasks = 64 x 64 tiles of the right-hand-side rows, DfArgs::u_rows) -- against the
     multi-kernel substitution (option predict_df = 0) and, where the oracle is quick, against predictFromGaussianProcessInternal
     (BGP:396-422).  m = 500 at n = 300 has more row blocks than the factor has columns: stays on the multi-kernel path."""
