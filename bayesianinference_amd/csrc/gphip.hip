@@ -3265,6 +3265,7 @@ int gphip_solve(gphip_handle h, const double* rhs, int64_t nrhs, double* out) {
         }
         // after a single-launch fit both halves are ONE dataflow launch each (forward as in gphip_predict; backward over a copy of
         // the factor with its 64 x 64 blocks transposed, made on the first solve of a fit)
+        ensure_w64(h);                         // (also after a look-ahead-schedule fit: 64-block inverses cut out of the 128-block ones)
         const bool dfs = df_forward_ok(h, mpad);
         if (dfs) launch_dataflow_inverse<double, 64>(h, mpad);
         else DISPATCH(h, queue_forward_rows, h, mpad, 1);
