@@ -456,6 +456,33 @@ def other_configs(local_rank: int) -> dict:
     except Exception as exc:                                    # never let an extra break the headline
         out["cfg1_cfg2_error"] = repr(exc)
     try:
+        # the rows either side of the likelihood at the HEADLINE size (a3 / a7 after gphip_fit at N = 32768, d = 8): the factor is
+        # 4.3 GB, so K^-1 b of one vector has 2 x 4.3 GB to stream (gp_trsv.h) and a prediction of 100 test points is one forward
+        # dataflow launch over it -- medians of blocking calls
+        n, d = 32768, 8
+        X, y = syn.make_dataset(n, d)
+        th = syn.default_theta("se_ard", d)
+        h = _lib.Handle(X, y, "se_ard", device=local_rank)
+
+        def med_ms(f, k):
+            f()
+            tt = np.empty(k)
+            for i in range(k):
+                t0 = time.perf_counter()
+                f()
+                tt[i] = time.perf_counter() - t0
+            return float(np.median(tt)) * 1e3
+        fit = med_ms(lambda: h.fit(th), 3)
+        Xs = syn.make_test_points(100, d)
+        bvec = syn.normal(syn.STREAM_NOISE, 0, n)
+        one = med_ms(lambda: h.solve(bvec), 8)
+        out["cfg3_rows_n32768_d8_f64"] = {"fit_ms": fit, "predict_100_points_ms": med_ms(lambda: h.predict(Xs), 5), "solve_one_vector_ms": one,
+                                          "solve_one_vector_tb_per_s_of_factor": 8.0 * n * n / (one * 1e-3) / 1e12,
+                                          "what": "gphip_fit / gphip_predict (100 test points) / gphip_solve (one vector) at the headline size"}
+        h.close()
+    except Exception as exc:
+        out["cfg3_rows_error"] = repr(exc)
+    try:
         X, y = syn.make_dataset(4096, 8)
         Th = syn.theta_batch(200, "se_ard", 8)
         Th[:, -1] = np.maximum(Th[:, -1], 0.05)
