@@ -8,10 +8,11 @@
 //   forward   x_k = W_k (b_k - sum_{c<k} L(k,c) x_c)              W_k = L_kk^-1 (explicit 128 x 128 inverses, resident)
 //   backward  x_k = W_k^T (b_k - sum_{c>k} L(c,k)^T x_c)          the same schedule on mirrored block indices, tiles read transposed
 //
-// * a task = one 128 x 128 tile: s(I,K) = s(I,K-1) - L(I,K) x_K for K <= I-3, held in REGISTERS (64 values per lane, loaded
+// * a task = one 128 x 128 tile: s(I,K) = s(I,K-1) - L(I,K) x_K for K <= I-3, held in REGISTERS (32 values per lane, loaded
 //   before the task's inputs exist -- L is static) by the persistent "tile" workgroups, which take tasks from a ticket in
 //   column-major order (a topological order: every dependency belongs to an earlier ticket or to the chain) and prefetch the
-//   next task's tile while they wait for the current one's inputs;
+//   next task's tile while they wait for the current one's inputs; the last link of every row sum, task (K+3, K), belongs to
+//   one of TRSV_CHAIN "feeder" workgroups whose tile is resident hops ahead;
 // * the chain: TRSV_CHAIN PAIRS of "chain" workgroups take the diagonal steps round-robin.  With P1_K = W_K L(K,K-1) and
 //   P2_K = W_K L(K,K-2) formed once per factor (trsv_prep_kernel),
 //       x_K = [ W_K s(K,K-3) - P2_K x_{K-2} ]  -  P1_K x_{K-1} :
@@ -31,7 +32,7 @@
 namespace gphip {
 
 constexpr int TRSV_MAXR = 4;        // right-hand sides per launch
-constexpr int TRSV_CHAIN = 8;       // chain workgroups (each loads 2 tiles per step it owns: 256 KiB every 8 hops)
+constexpr int TRSV_CHAIN = 8;       // chain PAIRS (a workgroup loads 3 half tiles per step it owns: 192 KiB every 8 hops), and as many feeders
 constexpr int TRSV_SPIN_LIMIT = 1 << 24;
 #ifndef TRSV_TILE_BACKOFF
 #define TRSV_TILE_BACKOFF 6          // s_sleep units (64 clocks: ~0.16 us) between a waiting tile task's polls of its 1-4 KiB of inputs
