@@ -24,6 +24,47 @@ def _kernel(kernel, ell, sf, a, b):
     raise ValueError(kernel)
 
 
+def general_log_likelihood(family, ell, sf, sn, X, y, alpha=None, offset=0.0):
+    """The same 50-digit likelihood for ONE term of the general kernel grammar of oracle/gp_oracle.py (round 6: the families that
+    got a matrix-pipe build on the device) -- `family` in se / matern52 / matern32 / rq, `ell` one length scale per dimension,
+    `alpha` the rational quadratic's shape, `offset` the additive constant c of "term + const" (BGP:16 is c + SE).  Pins
+    gp_oracle.general_kernel_matrix / log_likelihood for those forms."""
+    n, d = len(X), len(X[0])
+    ell = [mp.mpf(float(v)) for v in ell]
+    sf, sn, c = mp.mpf(float(sf)), mp.mpf(float(sn)), mp.mpf(float(offset))
+
+    def k(a, b):
+        r2 = mp.mpf(0)
+        for j in range(d):
+            t = (mp.mpf(float(a[j])) - mp.mpf(float(b[j]))) / ell[j]
+            r2 += t * t
+        if family == "se":
+            g = mp.exp(-r2 / 2)
+        elif family == "matern52":
+            s5 = mp.sqrt(5 * r2)
+            g = (1 + s5 + mp.mpf(5) / 3 * r2) * mp.exp(-s5)
+        elif family == "matern32":
+            s3 = mp.sqrt(3 * r2)
+            g = (1 + s3) * mp.exp(-s3)
+        elif family == "rq":
+            a_ = mp.mpf(float(alpha))
+            g = (1 + r2 / (2 * a_)) ** (-a_)
+        else:
+            raise ValueError(family)
+        return sf * sf * g + c
+
+    K = mp.matrix(n, n)
+    for i in range(n):
+        for j in range(i + 1):
+            K[i, j] = K[j, i] = k(X[i], X[j])
+        K[i, i] += sn * sn
+    L = mp.cholesky(K)
+    z = mp.lu_solve(L, mp.matrix([mp.mpf(float(v)) for v in y]))
+    logdet = 2 * sum(mp.log(L[i, i]) for i in range(n))
+    quad = sum(z[i] * z[i] for i in range(n))
+    return float(-(n * mp.log(2 * mp.pi) + logdet + quad) / 2), float(logdet), float(quad)
+
+
 def _split(kernel, d, theta, mean):
     th = [mp.mpf(float(t)) for t in theta]
     nl = 1 if kernel in ("se", "matern52") else d

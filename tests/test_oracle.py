@@ -105,6 +105,24 @@ def test_mpmath_live_small():
     assert orc.log_likelihood("se_ard", th, X, y) == pytest.approx(ll, rel=1e-13)
 
 
+@pytest.mark.parametrize("kernel,family,theta", [("matern32_ard", "matern32", [0.7, 1.3, 0.9, 0.2]), ("rq_ard", "rq", [0.7, 1.3, 1.8, 0.9, 0.2]),
+                                                 ("matern32", "matern32", [0.8, 1.1, 0.25]), ("rq", "rq", [0.8, 0.6, 1.1, 0.25]),
+                                                 ("se + const", "se", [0.8, 1.1, 0.5, 0.25]), ("rq_ard + const", "rq", [0.7, 1.3, 2.5, 0.9, 0.4, 0.2])])
+def test_general_kernel_forms_against_mpmath(kernel, family, theta):
+    """Round 6: the families that got a matrix-pipe build on the device (Matern-3/2, rational quadratic, `term + const` -- the
+    reference's own example kernel is c + SE, BGP:16) pinned by an independent 50-digit evaluation of the same formulas:
+    gp_oracle's general grammar (parse_kernel / split_general / general_kernel_matrix) against oracle/hp_oracle.py."""
+    from oracle import hp_oracle as hp
+    d = 2
+    X, y = syn.make_dataset(14, d)
+    terms, op, c, sn, mu = orc.split_general(kernel, d, theta)
+    (_, ell, alpha, sf), = terms
+    ll, ld, qd = hp.general_log_likelihood(family, ell, sf, sn, X.tolist(), y.tolist(), alpha=alpha, offset=c)
+    got, ld_o, qd_o, info = orc.log_likelihood(kernel, theta, X, y, parts=True)
+    assert info == 0
+    assert got == pytest.approx(ll, rel=1e-12) and ld_o == pytest.approx(ld, rel=1e-12, abs=1e-12) and qd_o == pytest.approx(qd, rel=1e-11)
+
+
 @pytest.mark.parametrize("name", ["f1_se_n512_d1", "f2_se_ard_n256_d8", "f2_matern52_ard_n256_d8",
                                   "f2_matern52_const_n333_d3"])
 def test_oracle_reproduces_golden(golden_dir, name):
