@@ -2181,6 +2181,11 @@ struct DfArgs {
                                               // FINISHED outer panel (operands only, read through Aprev -- the owner's receive buffer,
                                               // addressed with the same global tile indices); task numbering starts at task0 = the
                                               // first task of column nprev.  The launch applies that panel to its own columns itself.
+    unsigned int* colsig;                     // sharded schedule, panel launch (ncols > 0), or null: per 128-tile column of the panel a counter of
+                                              // FINISHED 64 x 64 tiles -- every task adds one for each tile it has made final (its own; the
+                                              // diagonal task also the sub-diagonal tile it solves) AFTER that tile's write-through stores
+                                              // have drained.  The owner's communication stream waits for the column's tile count
+                                              // (hipStreamWaitValue32) and sends the column while the launch is still factoring the next ones.
     int* park;                                // 64-tiles, two workgroups per CU: [DF_PARK_SLOTS] counters "a chain task is in its critical
                                               // section on this CU" (index = XCC / SE / SH / CU id); the neighbour sleeps meanwhile; or null
     T* D; long d_bstride;                     // 64-tiles: the 16x16 diagonal inverses of every 64-block, [slot][nd][4][col * 16 + row] -- with L_jj what the
@@ -2650,6 +2655,11 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g, Th
         if (tid == 0) __hip_atomic_store(F + fi_ * R + fj_, g.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
 
+    // "one more tile of 64-column jc is final" (call with this workgroup's stores of that tile drained and a barrier behind them)
+    auto col_done = [&](int jc) {
+        if (TBX == 64 && g.colsig && tid == 0 && jc >= g.nprev && jc < g.ncols)
+            __hip_atomic_fetch_add(g.colsig + ((jc - g.nprev) >> 1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    };
     constexpr bool XXF = TBX == 64 && OCC <= 2;           // builds whose LDS holds the stage area AND a second 36 KiB region (DF_XXF_LDS)
     if (inverse) {
         // ---- a tile of U = L^-T.  Row block rb of U advances one column block per task: the k-th slab needs U(rb,k), i.e. the
@@ -2970,6 +2980,7 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g, Th
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // X(j,j-1) is at the coherent level (sc1 stores) ..
                 __syncthreads();                                // .. for every wave; block column 0 of the image is complete
                 if (tid == 0) __hip_atomic_store(F + j * R + jm, g.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                col_done(jm);                                   // tile (j, j-1) is final
                 stamp(6);
             } else {
 #pragma unroll
@@ -2991,6 +3002,7 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g, Th
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // X(j,j-1) is at the coherent level (sc1 stores) ..
                 __syncthreads();                                // .. for every wave; and the images make way for the potrf image
                 if (tid == 0) __hip_atomic_store(F + j * R + jm, g.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                col_done(jm);                                   // tile (j, j-1) is final
                 stamp(6);
             }
         }
@@ -3038,6 +3050,11 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g, Th
         else if (GP_DF_WT_POTRF) publish_wt(j, j);
         else publish(j, j);
         leave_critical();
+        if (TBX == 64 && g.colsig) {                        // the L tile went out AFTER ready(j,j): drain it before the column count
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            col_done(j);
+        }
         stamp(4);
         return;
     }
@@ -3057,6 +3074,7 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g, Th
     stamp(3);
     store_c(acc, Ct, LDA);
     publish_wt(i, j);
+    col_done(j);
     stamp(4);
 }
 

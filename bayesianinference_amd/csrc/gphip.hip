@@ -82,10 +82,16 @@ struct gphip_ctx {
                                                  // owner chain, where the per-tile-column schedule keeps only the last column's there -- from
                                                  // 4 ranks on that outweighs the shorter kernel chain (profiles/r06_scale_model.txt)
     bool dist_df_active = false;                 // the current sharded evaluation runs with dataflow panels (64-block partials / inverses)
-    int dist_df_mode = 0;                        // .. and which form (dist_panel_df resolved: 0, 1, 2)
+    int dist_df_mode = 0;                        // .. and which form (dist_panel_df resolved: 0, 1, 2, 3; readable as option last_dist_panel_df)
     int bcast_two_hop = -1;                      // sharded evaluation over RCCL, world > 2: every broadcast as scatter (send / recv) + in-place all-gather;
                                                  // -1 (default) = on from 4 ranks when the loaded RCCL has send / recv / group calls (two_hop_ok)
     std::vector<hipEvent_t>* col_events = nullptr;   // queue_panel: record "tile column final" events here (owner of a sharded panel)
+    // dist_panel_df = 3: a dataflow panel launch counts finished tiles per tile column (DfArgs::colsig); the owner's communication
+    // stream waits for a column's count with hipStreamWaitValue32.  Counters are cumulative over the panels of one evaluation
+    // (zeroed in gphip_dist_begin): the target of a wait = everything counted before + the column's own tiles.
+    unsigned int* dColSig = nullptr;                 // [64] counters (the first `panel` are used)
+    unsigned int colsig_target[64] = {0};
+    std::vector<std::pair<unsigned int*, unsigned int>>* col_waits = nullptr;   // where gphip_dist_factor_panel reports (address, target) per tile column
     int fuse_potrf = 1;                          // option: panel-stream updates factor the diagonal tile they have just updated
     int fuse_b = -1;                             // launch_gemm: request (tile to factor) ...
     bool fuse_done = false;                      // ... and answer (the launch took it)
@@ -809,7 +815,7 @@ bool use_dataflow(const gphip_ctx* h, int nslots) {
 // look-ahead schedule, already updated by every earlier panel.  No finalize here.
 template <typename T, int TBX, int OCC = 2, int NST = 2, bool BUILD = false>
 void launch_dataflow(gphip_ctx* h, int nslots, int c0 = 0, double* part = nullptr, long pstride = 0, int ncols = 0, int nprev = 0,
-                     const void* aprev = nullptr) {
+                     const void* aprev = nullptr, unsigned int* colsig = nullptr) {
     const int nd = (int)(h->Npad / TBX) - c0, R = nd + 1;
     // ncols > 0: only the first ncols tile columns (an outer panel of the sharded schedule) -- a prefix of the column-major task list
     // nprev > 0: .. of which the first nprev are a finished panel read through aprev (no tasks of their own)
@@ -817,6 +823,7 @@ void launch_dataflow(gphip_ctx* h, int nslots, int c0 = 0, double* part = nullpt
     const long tasks = ((ncols > 0 && ncols < R ? (long)ncols * R - (long)ncols * (ncols - 1) / 2 : (long)R * (R + 1) / 2) - task0) * nslots;
     DfArgs<T> g{};
     g.nprev = nprev; g.task0 = task0; g.Aprev = (const T*)aprev;
+    g.colsig = (TBX == 64 && ncols > 0 && ncols < R) ? colsig : nullptr;
     g.A = (T*)(h->ws_override ? h->ws_override : h->dA); g.bstride = h->slot_elems; g.R128 = (int)h->R; g.c0 = c0;
     g.ncols = (ncols > 0 && ncols < R) ? ncols : 0;
     g.W = (T*)h->dW + (long)c0 * TBX * TBX; g.w_bstride = (long)h->Nt * TB * TB;
@@ -2328,7 +2335,7 @@ int gphip_destroy(gphip_handle h) {
     if (h->cgmod) (void)hipModuleUnload(h->cgmod);
     (void)hipFree(h->dV); (void)hipFree(h->dXsT); (void)hipFree(h->dXsS); (void)hipFree(h->dMean);
     (void)hipFree(h->dVar); (void)hipFree(h->dAlpha); (void)hipFree(h->dGacc); (void)hipFree(h->dKinv);
-    (void)hipFree(h->dTrsvX); (void)hipFree(h->dTrsvP); (void)hipFree(h->dRows);
+    (void)hipFree(h->dTrsvX); (void)hipFree(h->dTrsvP); (void)hipFree(h->dRows); (void)hipFree(h->dColSig);
     (void)hipFree(h->dXsS2); (void)hipFree(h->dPwMeanT); (void)hipFree(h->dPwNugT);
     (void)hipFree(h->dNullMu); (void)hipFree(h->dNullOut); (void)hipFree(h->dPart);
     for (auto e : h->pool) (void)hipEventDestroy(e);
@@ -3357,7 +3364,21 @@ int gphip_dist_begin(gphip_handle h, const double* theta, int p, int rank, int w
     rc = copy_theta(h, 1);
     if (rc) return rc;
     HIPCHK(hipMemsetAsync(h->dInfo, 0, 4, h->stream));
-    h->dist_df_mode = (h->dtype == 64 && h->dataflow != 0) ? (h->dist_panel_df < 0 ? (world == 2 ? 2 : 0) : h->dist_panel_df) : 0;
+    // panel schedule of the owner (dist_panel_df; -1 = the library's choice).  Round 6, by scripts/scale_model.py on measured step
+    // times: 3 (ONE dataflow launch per panel incl. the look-ahead update, every tile column handed to the broadcast stream by a
+    // counter the launch bumps) from 2 ranks on; where the device has no stream-ordered wait on memory: 2 at two ranks, else 0.
+    const bool df_able = h->dtype == 64 && h->dataflow != 0;
+    h->dist_df_mode = !df_able ? 0 : h->dist_panel_df < 0 ? (world >= 2 ? 3 : 0) : h->dist_panel_df;
+    if (h->dist_df_mode >= 3) {                // column signals: needs stream-ordered waits on device memory
+        int can = 0;
+        if (hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, h->device) != hipSuccess) { (void)hipGetLastError(); can = 0; }
+        if (can && !h->dColSig && hipMalloc((void**)&h->dColSig, 64 * sizeof(unsigned int)) != hipSuccess) { (void)hipGetLastError(); h->dColSig = nullptr; }
+        if (!can || !h->dColSig || h->panel > 64) h->dist_df_mode = (h->dist_panel_df < 0 && world != 2) ? 0 : 2;
+        else {
+            HIPCHK(hipMemsetAsync(h->dColSig, 0, 64 * sizeof(unsigned int), h->pstream));
+            for (unsigned int& t : h->colsig_target) t = 0;
+        }
+    }
     h->dist_df_active = h->dist_df_mode != 0;
     h->df_prev_ptr = nullptr; h->df_prev_k = -2;
     HIPCHK(hipMemsetAsync(h->dPartial, 0, (size_t)2 * h->Nt * 8, h->stream));
@@ -3397,15 +3418,39 @@ int gphip_dist_factor_panel(gphip_handle h, int k, void* packed) {
             const int64_t Kp = K0 - h->panel;
             const char* pbase = static_cast<const char*>(h->df_prev_ptr) - dist_panel_first(h, k - 1) * TS * (long)h->es;
             // (three workgroups per CU once the launch is throughput bound: the early, tall panels)
+            unsigned int* sig = h->dist_df_mode >= 3 ? h->dColSig : nullptr;
             if (h->dataflow_occ3 > 0)
-                launch_dataflow<double, 64, 3>(h, 1, 2 * (int)Kp, nullptr, 0, 2 * (int)(K1 - Kp), 2 * (int)(K0 - Kp), pbase);
+                launch_dataflow<double, 64, 3>(h, 1, 2 * (int)Kp, nullptr, 0, 2 * (int)(K1 - Kp), 2 * (int)(K0 - Kp), pbase, sig);
             else
-                launch_dataflow<double, 64>(h, 1, 2 * (int)Kp, nullptr, 0, 2 * (int)(K1 - Kp), 2 * (int)(K0 - Kp), pbase);
+                launch_dataflow<double, 64>(h, 1, 2 * (int)Kp, nullptr, 0, 2 * (int)(K1 - Kp), 2 * (int)(K0 - Kp), pbase, sig);
+            if (sig) {
+                // tiles the launch makes final per tile column: 64-columns j0, j0 + 1 of a submatrix with R64 tile rows (rhs row included)
+                const int nprev = 2 * (int)(K0 - Kp), R64 = 2 * (int)(h->Nt - Kp) + 1;
+                for (int c = 0; c < (int)(K1 - K0); ++c) {
+                    const int j0 = nprev + 2 * c;
+                    h->colsig_target[c] += (unsigned int)((R64 - j0) + (R64 - j0 - 1));
+                    if (h->col_waits) h->col_waits->push_back({h->dColSig + c, h->colsig_target[c]});
+                }
+            }
         } else {
-            launch_dataflow<double, 64>(h, 1, 2 * (int)K0, nullptr, 0, 2 * (int)(K1 - K0));
+            unsigned int* sig = h->dist_df_mode >= 3 ? h->dColSig : nullptr;
+            launch_dataflow<double, 64>(h, 1, 2 * (int)K0, nullptr, 0, 2 * (int)(K1 - K0), 0, nullptr, sig);
+            if (sig) {
+                const int R64 = 2 * (int)(h->Nt - K0) + 1;
+                for (int c = 0; c < (int)(K1 - K0); ++c) {
+                    h->colsig_target[c] += (unsigned int)((R64 - 2 * c) + (R64 - 2 * c - 1));
+                    if (h->col_waits) h->col_waits->push_back({h->dColSig + c, h->colsig_target[c]});
+                }
+            }
         }
         h->df_prev_ptr = nullptr; h->df_prev_k = -2;
         h->stream = keep;
+        if (h->dist_df_mode >= 3) {
+            // a launch that never ran would leave the column counters short of their targets and the waits on them pending for
+            // ever: report it NOW (the caller then skips the waits: drain mode)
+            const hipError_t le = hipGetLastError();
+            if (le != hipSuccess) { h->ws_override = nullptr; h->cs = h->stream; if (h->col_waits) h->col_waits->clear(); return fail(h, GPHIP_ERR_HIP, hipGetErrorString(le)); }
+        }
     } else {
         DISPATCH(h, queue_panel, h, (int)K0, (int)(K1 - K0), 1, first_factored);
     }
@@ -3516,7 +3561,7 @@ int* option_slot(gphip_ctx* h, const char* name) {
         {"dataflow_occ3", &gphip_ctx::dataflow_occ3},
         {"fused_eval", &gphip_ctx::fuse_option}, {"panel_df", &gphip_ctx::panel_df}, {"grad_potri", &gphip_ctx::grad_potri}, {"predict_df", &gphip_ctx::predict_df},
         {"kbuild_mfma", &gphip_ctx::kbuild_mfma}, {"kbuild_mfma_bound", &gphip_ctx::kbuild_mfma_bound},
-        {"kbuild_mfma_digits", &gphip_ctx::kbuild_mfma_digits}, {"trsv", &gphip_ctx::trsv}, {"predict_df_max_nt", &gphip_ctx::predict_df_max_nt}, {"last_issue_us", &gphip_ctx::last_issue_us},
+        {"kbuild_mfma_digits", &gphip_ctx::kbuild_mfma_digits}, {"trsv", &gphip_ctx::trsv}, {"predict_df_max_nt", &gphip_ctx::predict_df_max_nt}, {"last_issue_us", &gphip_ctx::last_issue_us}, {"last_dist_panel_df", &gphip_ctx::dist_df_mode},
         {"custom_grad", &gphip_ctx::custom_grad}, {"grad_analytic", &gphip_ctx::grad_analytic},
         {"max_slots", &gphip_ctx::max_slots}, {"shard_min_n", &gphip_ctx::shard_min_n},
         {"replicate_factor", &gphip_ctx::replicate_factor}, {"share_local_panels", &gphip_ctx::share_local_panels},

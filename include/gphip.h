@@ -316,11 +316,24 @@ int gphip_ns_crude_weights(const double* points, const double* loglik, int64_t m
  *   "panel_df"     -1 by size (default) / 0 / 1: one theta, fp64, look-ahead schedule -- every outer panel (the look-ahead update by
  *                  the panel before it + its own factorisation) is ONE 64-tile dataflow launch whose tasks read the finished panel as
  *                  extra slabs; by size = 92 <= Nt <= 120 (N = 11k-15k: -2..-8 %, with an 80-column dataflow tail behind the panels)
- *   "dist_panel_df" -1 (default: 2 at world 2, else 0) / 0 / 1 / 2: sharded evaluation, fp64 -- the owner factors its outer panel as ONE 64-tile dataflow launch
+ *   "dist_panel_df" -1 (default: 3 from 2 ranks on; where the device has no stream-ordered wait on memory, 2 at world 2, else 0)
+ *                  / 0 / 1 / 2 / 3: sharded evaluation, fp64 -- the owner factors its outer panel as ONE 64-tile dataflow launch
  *                  (1), which also applies the look-ahead update, reading the previous panel from the receive buffer (2): the owner's
  *                  chain of kernels 31.8 -> 22.6 ms per N = 32768 evaluation with the chip to itself, but a panel is then final only
- *                  when its launch ends, so "bcast_chunks" cannot overlap its columns with the factorisation any more (which side
- *                  wins depends on the link bandwidth: bench.py --gpus N times both).  Rank-local: need not agree across ranks.
+ *                  when its launch ends, so "bcast_chunks" cannot overlap its columns with the factorisation any more; (3) = (2)
+ *                  with a counter per 128-wide tile column that the launch's tasks bump when they finish a tile of it: the
+ *                  communication stream waits on the counter (hipStreamWaitValue32, value = the column's tile count) and sends
+ *                  the column while the launch still works on the later ones.  Same arithmetic as 2 (bit-identical results).
+ *                  bench.py --gpus N times every form.  Rank-local: need not agree across ranks.  "last_dist_panel_df"
+ *                  (read-only): the form the last sharded evaluation used.
+ *   "last_issue_us" (read-only): host microseconds the last sharded evaluation spent issuing its schedule (all members of a
+ *                  one-process group together).
+ *   "trsv"         0 / 1 (default): gphip_solve of up to 4 right-hand sides (up to 16 from Nt >= 96, in batches of 4) and the
+ *                  alpha = K^-1 (y - m) of gphip_fit run each triangle as ONE persistent launch that streams the factor once
+ *                  (csrc/gp_trsv.h: tiles in registers, a band-2 chain of workgroup pairs, sentinel hand-offs); 0 = the
+ *                  GEMM-shaped substitution for every count.  fp64 and fp32.
+ *   "predict_df_max_nt" (default 256): gphip_predict / gphip_solve after a look-ahead fit (Nt above "dataflow_max_nt") still run
+ *                  their forward / backward substitutions as single dataflow launches up to this many 128-tiles.
  *   "kbuild_mfma"  0 / 1 (default) / 2: the kernel-matrix build of the SE / Matern-5/2 kernels with the cross term of the squared
  *                  distances on the matrix pipe (kbuild_mfma_kernel): never / for every theta whose accuracy bound
  *                  B = sum_k (halfrange_k / l_k)^2 <= "kbuild_mfma_bound" (default 512; fp32: / 8) holds AND whose

@@ -66,7 +66,7 @@ while time.time() < t_end:
                    "debug_fail_alloc": int(rng.choice([1, 3, 7, 10])),
                    "dataflow_tail": int(rng.choice([0, 7, 64])), "max_slots": int(rng.choice([1, 3, 256])),
                    "shard_min_n": int(rng.choice([0, 1 << 30])), "panel_left": int(rng.choice([-1, 0, 1])), "supertile": int(rng.choice([0, 2, 3])), "dataflow_lds_kib": int(rng.choice([-1, 0, 84])),
-                   "dist_panel_df": int(rng.choice([0, 1, 2])), "panel_df": int(rng.choice([-1, 0, 1])),
+                   "dist_panel_df": int(rng.choice([-1, 0, 1, 2, 3])), "panel_df": int(rng.choice([-1, 0, 1])),
                    "kbuild_mfma": int(rng.choice([0, 1, 2])), "kbuild_mfma_bound": int(rng.choice([1, 64, 512]))}.get(name, int(rng.integers(0, 2)))
             print(f'    {name}={val}', file=log, flush=True)
             if name == "debug_fail_alloc":

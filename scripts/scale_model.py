@@ -25,7 +25,7 @@ import sys
 
 
 def simulate(data, mode, W, alpha_us, beta_gbs, chunks=True, two_hop=False, split_rest=True, floor_us=25.0, launch_us=6.0, issue_us=0.0,
-             one_thread=False, final_at_end=False):
+             one_thread=False, final_at_end=False, first_ready=None):
     N, P = data["N"], data["panel_tiles"]
     m = data["modes"][mode]
     f, la, rest = m["factor_us"], m["la_us"], m["rest_us"]
@@ -73,7 +73,13 @@ def simulate(data, mode, W, alpha_us, beta_gbs, chunks=True, two_hop=False, spli
             if chunks:
                 for s2 in range(nin):
                     # (a dataflow panel launch -- dist_panel_df -- has no 'tile column final' events: every column is ready when it ends)
-                    ready = F if final_at_end else start + (s2 + 1) * (F - start) / nin
+                    # dist_panel_df = 3 counts finished tiles per column inside the launch and the broadcast stream waits on the
+                    # counter: column 0 is final `first_ready` of the way through the launch (measured, profiles/r06_colsig_overlap.txt:
+                    # the look-ahead update of the whole panel comes first), the last one at its end
+                    if first_ready is not None:
+                        ready = start + (first_ready + (1.0 - first_ready) * s2 / max(nin - 1, 1)) * (F - start)
+                    else:
+                        ready = F if final_at_end else start + (s2 + 1) * (F - start) / nin
                     t = max(t, ready) + alpha + col_tiles[k][s2] * tile_bytes / beta * 1e6
             else:
                 t = max(t, F) + alpha + sum(col_tiles[k]) * tile_bytes / beta * 1e6
@@ -134,16 +140,18 @@ def main():
             i += 1
     paths = paths or ["gpurun_out/owner_path_32768.json"]
     links = links or [(10.0, 120.0), (20.0, 60.0), (40.0, 30.0)]
-    # (name, step-time set, simulate() options): "two_hop_from" = world size from which the all-links broadcast is used
-    # (name, W -> (step-time set, simulate() options)).  The library's default since round 6 (gphip_multi.inc group_eval_run,
-    # gphip_dist_begin): 2 ranks = dataflow panels (final at launch end), plain broadcast; 3+ ranks = per-tile-column panels,
-    # from 4 ranks every message as scatter + in-place all-gather over all links.
+    # (name, W -> (step-time set, simulate() options)).  The library's default since round 6 (gphip_dist_begin, gphip_multi.inc
+    # group_eval_run): dataflow panels whose tile columns are handed over by counters (dist_panel_df = 3); from 4 ranks every
+    # message as scatter + in-place all-gather over all links.
     df0 = lambda two_hop: ("df0_fuse1", dict(chunks=True, two_hop=two_hop))
     df2 = lambda two_hop: ("df2_fuse0", dict(chunks=True, final_at_end=True, two_hop=two_hop))
-    variants = [("DEFAULT round 6: dataflow panels at 2 ranks; per-tile-column panels + two-hop from 4 ranks", lambda W: df2(False) if W == 2 else df0(W >= 4)),
+    df3 = lambda two_hop: ("df2_fuse0", dict(chunks=True, first_ready=0.36, two_hop=two_hop))
+    variants = [("DEFAULT round 6: dataflow panels with column signals (dist_panel_df=3), two-hop from 4 ranks", lambda W: df3(W >= 4)),
+                ("fallback default (no stream-ordered wait on the device): dataflow panels at 2 ranks; per-tile-column panels + two-hop from 4 ranks", lambda W: df2(False) if W == 2 else df0(W >= 4)),
                 ("round-5 default: per-tile-column panels, plain ncclBroadcast", lambda W: df0(False)),
                 ("dataflow panels (dist_panel_df=2), plain broadcast", lambda W: df2(False)),
-                ("dataflow panels + two-hop from 4 ranks", lambda W: df2(W >= 4))]
+                ("dataflow panels + two-hop from 4 ranks", lambda W: df2(W >= 4)),
+                ("dataflow panels with column signals (dist_panel_df=3), plain broadcast", lambda W: df3(False))]
     for path in paths:
         data = json.load(open(path))
         print(f"# N = {data['N']}, outer panel = {data['panel_tiles']} tiles ({path}); times in ms; host issue {issue_us:.0f} us per rank and panel; "
@@ -172,10 +180,9 @@ def main():
                       f"trailing work {sum(m['rest_us']) / 1e3:.1f} ms / 8 = {sum(m['rest_us']) / 8e3:.1f} ms per rank; "
                       f"factor bytes per receiver {data['N'] ** 2 * 4 / 1e9:.2f} GB "
                       f"(= {data['N'] ** 2 * 4 / 1e9 / 0.06:.0f} ms over ONE 60 GB/s link, {data['N'] ** 2 * 4 / 1e9 / 0.24:.0f} ms two-hop at 8 ranks)")
-        print("   term that forbids 6x (= %.1f ms at 8 GPUs): the owner chain (factor + look-ahead, 33.6 ms per-tile-column / 23.5 ms dataflow) is SERIAL across\n"
-              "   panels and each hop of it also waits for the last tile column's (per-tile-column) or the whole panel's (dataflow) transfer; a rank's\n"
-              "   trailing share (21 ms) hides under it, not the other way round." % (plain_ms / 6.0))
-
+        print("   term that decides 6x (= %.1f ms at 8 GPUs): the owner chain (factor + look-ahead, 33.6 ms per-tile-column / 23.5 ms dataflow) is SERIAL across\n"
+              "   panels and each hop of it also waits for the last tile column's transfer (per-tile-column panels, dataflow panels with column signals)\n"
+              "   or the whole panel's (dataflow panels without signals); a rank's trailing share (21 ms) hides under it, not the other way round." % (plain_ms / 6.0))
 
 if __name__ == "__main__":
     main()

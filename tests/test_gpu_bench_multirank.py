@@ -49,10 +49,11 @@ def test_two_ranks_weak_headline_and_strong_series():
     # the split north_star names is also readable at the top level, next to the weak headline
     assert rec["rccl_ranks"] == 2 and rec["strong_ms_per_eval"] == st["ms_per_eval"] and rec["strong_speedup"] > 0
     # the schedule variants only a multi-GPU node can rank are timed beside the default and must agree with it
-    assert set(st["variants"]) == {"per_column_broadcast", "dist_panel_df"} and st["default_options"] == {"dist_panel_df": 2, "bcast_two_hop": 0}
+    assert set(st["variants"]) == {"per_column_broadcast", "dist_panel_df"} and st["default_options"] == {"dist_panel_df": 3, "bcast_two_hop": 0}
     for v in st["variants"].values():
         assert v["same_results"] and v["ms_per_eval"] > 0
     assert st["best_variant"] in ("default", "per_column_broadcast", "dist_panel_df")
+    assert st["variants"]["dist_panel_df"]["same_results"]          # (2 and 3 share the arithmetic: compared bit for bit)
     assert "cpu_baseline" not in rec                                # rank 0 at N = 1 only
 
 
@@ -70,17 +71,18 @@ def test_strong_series_watchdog_keeps_the_headline():
 
 def test_eight_ranks_every_schedule_variant_at_sharding_size():
     """The job the driver launches on an 8-GPU node -- 8 ranks, N large enough that the library shards by itself (16384 =
-    shard_min_n) -- with every schedule variant of the strong series: the default (from 4 ranks on: per-tile-column panels, every
-    message as grouped send / recv + in-place all-gather over all links), plain per-tile-column broadcasts (REST split so that the
-    look-ahead update waits for its own panel's piece only), one-launch dataflow panels, and those with the two-hop broadcast.  Eight processes share GPU 0 and the tests-only collective
+    shard_min_n) -- with every schedule variant of the strong series: the default (one dataflow launch per panel whose tile
+    columns are handed to the broadcast stream by counters, from 4 ranks on every message as grouped send / recv + in-place
+    all-gather over all links), the same with plain broadcasts, per-tile-column panels with either broadcast form, and dataflow
+    panels without the counters with either form.  Eight processes share GPU 0 and the tests-only collective
     library; what is checked is the control flow and that all variants return the same likelihoods."""
     rec = _run("c", ["--strong-timeout", "600"], world=8, timeout=1500, npoints=16384)
     assert rec["n_gpus"] == 8 and rec["value"] > 0 and rec["config"]["parallelism"] == "theta-sharded x8"
     st = rec["strong"]
     assert "error" not in st and "variants_error" not in st, st
     assert st["rccl_ranks"] == 8 and st["all_ok"]
-    assert set(st["variants"]) == {"per_column_broadcast", "two_hop", "dist_panel_df", "two_hop_dist_panel_df"}
-    assert st["default_options"] == {"dist_panel_df": 0, "bcast_two_hop": 1}
+    assert set(st["variants"]) == {"per_column_broadcast", "two_hop", "dist_panel_df", "two_hop_dist_panel_df", "column_signals"}
+    assert st["default_options"] == {"dist_panel_df": 3, "bcast_two_hop": 1}
     for name, v in st["variants"].items():
         assert v["same_results"] and v["ms_per_eval"] > 0, (name, v)
     assert st["two_hop_identical_results"] and st["best_variant"] in {"default", *st["variants"]}

@@ -69,7 +69,7 @@ def test_sharded_loglik_matches_oracle_and_single_device(n, d, kernel, world, pa
     gd.close(); g.close(); h.close()
 
 
-@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("mode", [1, 2, 3])
 @pytest.mark.parametrize("n,d,kernel,world,panel", [(1500, 3, "se_ard", 2, 2), (1500, 3, "matern52_ard", 3, 1), (8192, 8, "se_ard", 8, 4),
                                                     (100, 2, "se_ard", 3, 4), (1300, 4, "matern52", 5, 3), (2100, 2, "se_ard", 2, 4)])
 def test_sharded_loglik_with_dataflow_panels(n, d, kernel, world, panel, mode):
@@ -77,7 +77,9 @@ def test_sharded_loglik_with_dataflow_panels(n, d, kernel, world, panel, mode):
     launch restricted to the panel's columns instead of three launches per tile column.  Same factorisation up to the summation
     order inside 64-blocks: oracle / single-device values at the usual bars, bit-repeatable, verdicts through the reduction, a
     sharded fit (block inverses rebuilt) and the streamed prediction.  mode 2: the look-ahead update of the panel rides in the
-    same launch (the previous panel, read from the receive buffer, is 2 P more slabs of every task)."""
+    same launch (the previous panel, read from the receive buffer, is 2 P more slabs of every task).  mode 3 (round 6): mode 2 +
+    the launch counts finished tiles per tile column and the owner's communication stream waits for a column's count
+    (hipStreamWaitValue32) instead of the launch's end -- the columns of a panel leave while the launch still factors the rest."""
     X, y = syn.make_dataset(n, d)
     th = syn.default_theta(kernel, d)
     g = _lib.Handle(X, y, kernel, device=[0] * world)

@@ -31,14 +31,16 @@ def close(a, b, n, rtol=1e-8):
     (900, 2, "matern52_ard", 1, 3, 1),           # every panel broadcast as scatter (send / recv) + in-place all-gather
     (1300, 3, "se_ard", 2, 4, 1),
     (1500, 3, "se_ard", 2, 3, "dist_panel_df=2"),      # the owner's panel + look-ahead update as ONE dataflow launch reading the
-    (2100, 2, "se_ard", 4, 2, "dist_panel_df=2,bcast_two_hop=0")])   # previous panel from the RECEIVE buffer of a real other process
+    (2100, 2, "se_ard", 4, 2, "dist_panel_df=2,bcast_two_hop=0"),    # previous panel from the RECEIVE buffer of a real other process
+    (2100, 2, "se_ard", 4, 3, "dist_panel_df=3,bcast_two_hop=0"),    # + each column broadcast when the launch's counter says it is final
+    (1700, 3, "matern52_ard", 3, 4, "dist_panel_df=3,bcast_two_hop=1")])
 def test_rank_handles_in_separate_processes(tmp_path, n, d, kernel, panel, world, two_hop):
     fake = build.build_fake_rccl()
     env = dict(os.environ, GPHIP_NO_TORCH="1", GPHIP_RCCL_PATH=fake, FAKE_RCCL_SHM=f"/gphip_fake_{os.getpid()}_{n}_{two_hop}",
                LD_LIBRARY_PATH="/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
     if isinstance(two_hop, str):
         env["GPHIP_OPTIONS"] = two_hop
-        env["FAKE_RCCL_SHM"] = f"/gphip_fake_{os.getpid()}_{n}_df"
+        env["FAKE_RCCL_SHM"] = f"/gphip_fake_{os.getpid()}_{n}_{world}_df"
     elif two_hop:
         env["GPHIP_OPTIONS"] = "bcast_two_hop=1"     # (every rank of the job: the setting is part of the agreement check)
     outs = [str(tmp_path / f"rank{r}.json") for r in range(world)]

@@ -28,6 +28,11 @@ def test_scale_model_properties():
         end = m.simulate(data, "df2_fuse0", 8, alpha, beta, two_hop=True, final_at_end=True)[0]
         cols = m.simulate(data, "df2_fuse0", 8, alpha, beta, two_hop=True, final_at_end=False)[0]
         assert end >= cols
+        # the round-6 default (column counters inside the launch): between "all at the end" and "evenly spread", and a later first
+        # column can only cost time
+        sig = m.simulate(data, "df2_fuse0", 8, alpha, beta, two_hop=True, first_ready=0.36)[0]
+        late = m.simulate(data, "df2_fuse0", 8, alpha, beta, two_hop=True, first_ready=0.9)[0]
+        assert cols * 0.999 <= sig <= late <= end * 1.001 and sig <= t[8]
         slow_host = m.simulate(data, "df0_fuse1", 8, alpha, beta, two_hop=True, issue_us=2000.0, one_thread=True)[0]
         assert slow_host >= t[8] and slow_host >= 64 * 2000.0 * 8 * 0.99        # 64 panels x 8 ranks x 2 ms on one thread
     # the one-rank replay is the sum of its steps: no collective, no link
