@@ -1844,7 +1844,7 @@ int queue_trsv(gphip_ctx* h, const T* B, int pass, int nrhs, bool back, T** Xout
     g.P = (const T*)h->dTrsvP + (size_t)(back ? 1 : 0) * 2 * nt * TS;
     g.X = base; g.Xc = base + (size_t)nrhs * h->Npad; g.S = base + (size_t)2 * nrhs * h->Npad;
     g.ticket = reinterpret_cast<unsigned int*>(g.S + (size_t)nrhs * TB * (size_t)(nt * (nt - 1) / 2 + 1));
-    g.nt = nt; g.nrhs = nrhs; g.back = back ? 1 : 0; g.dbg = h->trsv >> 1;
+    g.nt = nt; g.nrhs = nrhs; g.back = back ? 1 : 0; g.dbg = 0;              // (dbg: developer timing bits, scripts/micro/trsv_trace.hip only)
     g.abort_flag = reinterpret_cast<int*>(h->dTicket + 1);
     const long ntasks = nt >= 5 ? (long)(nt - 4) * (nt - 3) / 2 : 0;                 // common ticket list: I >= K + 4
     const long grid = std::min<long>((long)h->ncu, 3 * TRSV_CHAIN + ntasks);         // chain pairs + feeders + tile role; one per CU: all resident

@@ -87,10 +87,16 @@ def test_sharded_loglik_with_dataflow_panels(n, d, kernel, world, panel, mode):
     g.set_option("shard_min_n", 0)
     g.set_option("dist_panel_df", mode)
     ll, ld, qd, inf = g.loglik_parts(th)
-    assert inf == 0
+    assert inf == 0 and g.get_option("last_dist_panel_df") == mode
     h = _lib.Handle(X, y, kernel)
     l1, ld1, qd1, _ = h.loglik_parts(th)
     assert close(ll, l1, n, 1e-10) and close(ld, ld1, n, 1e-10) and close(qd, qd1, n, 1e-9)
+    if mode == 3:                                        # the library's own choice on this device, and the same arithmetic as 2
+        g.set_option("dist_panel_df", -1)
+        assert g.loglik_parts(th)[0] == ll and g.get_option("last_dist_panel_df") == 3
+        g.set_option("dist_panel_df", 2)
+        assert g.loglik_parts(th)[:3] == (ll, ld, qd) and g.get_option("last_dist_panel_df") == 2
+        g.set_option("dist_panel_df", 3)
     if n <= 2000:
         want = orc.log_likelihood(kernel, th, X, y, parts=True)
         assert close(ll, want[0], n) and close(ld, want[1], n) and close(qd, want[2], n)
