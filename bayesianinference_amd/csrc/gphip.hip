@@ -76,11 +76,11 @@ struct gphip_ctx {
     double *dCustomP = nullptr, *hCustomP = nullptr;   // [slot][ncp]
     double* dKss = nullptr; size_t kss_cap = 0;  // k(x*, x*) of the current test points, [slot][mpad]
     int panel_df = -1;                           // one-GPU look-ahead schedule, one theta, fp64: every outer panel as ONE fused dataflow launch
+    int dist_owner_yield = -1;                   // sharded schedule: the owner's trailing updates wait for its panel launch (-1 = from 4 ranks)
     int dist_panel_df = -1;                      // sharded evaluation, fp64: the owner factors its outer panel as ONE 64-tile dataflow launch
-                                                 // (1), which also applies the look-ahead update (2); -1 (default) = 2 at world 2, else 0:
-                                                 // a dataflow panel is final only when its launch ends, so its WHOLE transfer sits on the
-                                                 // owner chain, where the per-tile-column schedule keeps only the last column's there -- from
-                                                 // 4 ranks on that outweighs the shorter kernel chain (profiles/r06_scale_model.txt)
+                                                 // (1), which also applies the look-ahead update (2), and hands its tile columns to the
+                                                 // broadcast stream by counters while it runs (3); -1 (default) = 3 from 2 ranks on where
+                                                 // the device has stream-ordered waits on memory (gphip_dist_begin)
     bool dist_df_active = false;                 // the current sharded evaluation runs with dataflow panels (64-block partials / inverses)
     int dist_df_mode = 0;                        // .. and which form (dist_panel_df resolved: 0, 1, 2, 3; readable as option last_dist_panel_df)
     int bcast_two_hop = -1;                      // sharded evaluation over RCCL, world > 2: every broadcast as scatter (send / recv) + in-place all-gather;
@@ -2016,6 +2016,29 @@ char* dist_panel_range(const gphip_ctx* h, int q) {
 
 }  // namespace
 
+// Developer experiment, never set in production: a context whose streams may only use a SLICE of the chip's CUs, so that virtual
+// ranks sharing ONE GPU run side by side instead of time-slicing the whole chip -- the closest thing to several GPUs a one-GPU
+// box offers (scripts/gpu_cu_partition.py).  A slice is 1 / W of the CUs of EVERY XCD: bit b of a
+// hipExtStreamCreateWithCUMask mask is CU b / 8 of XCD b % 8 (profiles/r04_cumask_map.txt), slice r of W = bits
+// [256 r / W, 256 (r + 1) / W) -- whole shader-engine rounds, so the dispatcher's even split over engines stays balanced.
+// (Masks that empty a whole XCD are ignored by this stack: scripts/micro/cumask.hip.)  GPHIP_CU_SLICE="r/W": every context of
+// the process on that slice; GPHIP_CU_PARTITION=1: member i of a W-member one-device group on slice i (set by group_create).
+static thread_local int g_slice_r = 0, g_slice_w = 0;
+static bool cu_slice(int* r, int* w) {
+    if (g_slice_w) { *r = g_slice_r; *w = g_slice_w; return true; }
+    const char* e = getenv("GPHIP_CU_SLICE");
+    return e && sscanf(e, "%d/%d", r, w) == 2 && (*w == 2 || *w == 4 || *w == 8) && *r >= 0 && *r < *w;
+}
+static hipError_t make_slice_stream(hipStream_t* st, int r, int w) {
+    uint32_t words[8] = {0};
+    for (int b = 256 * r / w; b < 256 * (r + 1) / w; ++b) words[b / 32] |= 1u << (b % 32);
+    const hipError_t e = hipExtStreamCreateWithCUMask(st, 8, words);
+    static bool told = false;
+    if (!told) fprintf(stderr, "gphip: DEVELOPER CU partition active (slice %d of %d on a new stream: %s)\n", r, w, hipGetErrorString(e));
+    told = true;
+    return e;
+}
+
 static int create_ctx(const void* X, const void* y, int64_t N, int64_t d, int kernel_id, int mean_id, int dtype, int device,
                       gphip_handle* out, const char* custom_body = nullptr, int ncp = 0, std::string* why = nullptr);
 namespace {
@@ -2144,7 +2167,11 @@ static int create_ctx(const void* X, const void* y, int64_t N, int64_t d, int ke
     const double* yd = static_cast<const double*>(y);
     auto bail = [&](int code) { gphip_destroy(h); return code; };
     if (hipSetDevice(h->device) != hipSuccess) return bail(GPHIP_ERR_HIP);
-    {
+    if (int sr = 0, sw = 0; cu_slice(&sr, &sw)) {
+        // developer experiment (scripts/gpu_cu_partition.py): this context runs on a slice of the chip's CUs
+        if (make_slice_stream(&h->stream, sr, sw) != hipSuccess || make_slice_stream(&h->pstream, sr, sw) != hipSuccess) return bail(GPHIP_ERR_HIP);
+        h->cs = h->stream;
+    } else {
         int least = 0, greatest = 0;                // numerically lower = higher priority
         (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
         if (hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, least) != hipSuccess) return bail(GPHIP_ERR_HIP);
@@ -3565,7 +3592,7 @@ int* option_slot(gphip_ctx* h, const char* name) {
         {"custom_grad", &gphip_ctx::custom_grad}, {"grad_analytic", &gphip_ctx::grad_analytic},
         {"max_slots", &gphip_ctx::max_slots}, {"shard_min_n", &gphip_ctx::shard_min_n},
         {"replicate_factor", &gphip_ctx::replicate_factor}, {"share_local_panels", &gphip_ctx::share_local_panels},
-        {"bcast_chunks", &gphip_ctx::bcast_chunks}, {"bcast_two_hop", &gphip_ctx::bcast_two_hop}, {"dist_panel_df", &gphip_ctx::dist_panel_df},
+        {"bcast_chunks", &gphip_ctx::bcast_chunks}, {"bcast_two_hop", &gphip_ctx::bcast_two_hop}, {"dist_panel_df", &gphip_ctx::dist_panel_df}, {"dist_owner_yield", &gphip_ctx::dist_owner_yield},
         {"debug_fail_alloc", &gphip_ctx::debug_fail_alloc}, {"debug_fail_hip", &gphip_ctx::debug_fail_hip},
     };
     // fault injection ("debug_*") exists for the test-suite only: the names resolve in a process that was started with

@@ -842,12 +842,18 @@ def main() -> None:
                 variants += [("two_hop", {"dist_panel_df": 0, "bcast_two_hop": 1}), ("two_hop_dist_panel_df", {"dist_panel_df": 2, "bcast_two_hop": 1}),
                              ("two_hop_column_signals", {"dist_panel_df": 3, "bcast_two_hop": 1})]
             variants = [v for v in variants if v[1] != {"dist_panel_df": default_df, "bcast_two_hop": default_hop}]    # (= the default itself)
-            strong["default_options"] = {"dist_panel_df": default_df, "bcast_two_hop": default_hop}
+            # .. and the default with "dist_owner_yield" flipped: on (the library's choice from 4 ranks) the owner's trailing updates
+            # are queued behind its panel launch's end event instead of sharing the GPU with it
+            default_yield = int(world >= 4)
+            variants.append(("owner_yield_off" if default_yield else "owner_yield_on",
+                             {"dist_panel_df": default_df, "bcast_two_hop": default_hop, "dist_owner_yield": 1 - default_yield}))
+            strong["default_options"] = {"dist_panel_df": default_df, "bcast_two_hop": default_hop, "dist_owner_yield": default_yield}
             strong["variants"] = {}
             partial[0] = dict(strong)
             best = ("default", strong["ms_per_eval"])
             try:
                 for vname, opts in variants:
+                    hs.set_option("dist_owner_yield", -1)
                     for k_, v_ in opts.items():
                         hs.set_option(k_, v_)
                     hs.loglik(ths[0])

@@ -326,6 +326,13 @@ int gphip_ns_crude_weights(const double* points, const double* loglik, int64_t m
  *                  the column while the launch still works on the later ones.  Same arithmetic as 2 (bit-identical results).
  *                  bench.py --gpus N times every form.  Rank-local: need not agree across ranks.  "last_dist_panel_df"
  *                  (read-only): the form the last sharded evaluation used.
+ *   "dist_owner_yield" -1 (default: on from 4 ranks) / 0 / 1: sharded evaluation -- on the rank that factors outer panel k + 1 the
+ *                  remainder of its trailing update REST(k - 1) and its REST(k) are queued behind the END event of that panel
+ *                  launch instead of sharing the GPU with it (only the piece of REST(k - 1) on panel k + 1 itself runs before):
+ *                  a CU hands a freed slot to the next workgroup of the launch it is already dispatching whatever the stream
+ *                  priorities, so a panel launch that becomes ready under a trailing GEMM of the same GPU otherwise runs at
+ *                  that GEMM's pace (scripts/gpu_cu_partition.py: 8-10 ms instead of 1.2).  Results are bit-identical either way.
+ *                  Rank-local.
  *   "last_issue_us" (read-only): host microseconds the last sharded evaluation spent issuing its schedule (all members of a
  *                  one-process group together).
  *   "trsv"         0 / 1 (default): gphip_solve of up to 4 right-hand sides (up to 16 from Nt >= 96, in batches of 4) and the

@@ -34,12 +34,12 @@ for w in (2, 4, 8):
     dt, r = timeit(g); print(f"N={n} {w} virtual ranks, panels read in place: {dt*1e3:8.2f} ms  ll={r[0]:.10g}   "
                              f"[host thread issued the whole schedule of all {w} ranks in {g.get_option('last_issue_us') / 1e3:.2f} ms = "
                              f"{g.get_option('last_issue_us') / w / 1e3:.2f} ms per rank]", flush=True)
-    for opts in ({"dist_panel_df": 0}, {"dist_panel_df": 2}, {"dist_panel_df": 3}):
+    for opts in ({"dist_panel_df": 0}, {"dist_panel_df": 2}, {"dist_panel_df": 3}, {"dist_panel_df": 3, "dist_owner_yield": 1 - int(w >= 4)}):
         for k_, v_ in opts.items():
             g.set_option(k_, v_)
         dt2, r2 = timeit(g)
         print(f"N={n}   ... {opts}: {dt2*1e3:8.2f} ms, issue {g.get_option('last_issue_us') / 1e3:.2f} ms", flush=True)
-    g.set_option("dist_panel_df", -1)
+    g.set_option("dist_panel_df", -1); g.set_option("dist_owner_yield", -1)
     dt, r = timeit(g, fit=True); print(f"N={n}   ... fit (factor stays distributed):  {dt*1e3:8.2f} ms", flush=True)
     g.set_option("share_local_panels", 0)
     dt, r = timeit(g); print(f"N={n} {w} virtual ranks, device copies into receive buffers: {dt*1e3:8.2f} ms", flush=True)

@@ -30,6 +30,20 @@ int main() {
             float ms; hipEventElapsedTime(&ms, a, b);
             printf("%s stream: 4096 x 100 us one-per-CU workgroups in %.3f ms (%.1f rounds)\n", st == full ? "full  " : "masked", ms, ms / 0.1);
         }
+    // whole-XCD masks (round 6, scripts/gpu_xcd_partition.py): every byte of the mask = the set of XCDs
+    for (uint32_t xcds : {0x01u, 0x0fu, 0xf0u, 0x80u}) {
+        std::vector<uint32_t> m2(8, xcds * 0x01010101u);
+        hipStream_t st;
+        if (hipExtStreamCreateWithCUMask(&st, 8, m2.data()) != hipSuccess) { printf("xcd mask %02x: create failed\n", xcds); continue; }
+        for (int rep = 0; rep < 2; ++rep) {
+            hipEventRecord(a, st);
+            hipLaunchKernelGGL(spin, dim3(4096), dim3(256), 100 * 1024, st, 10000ll);
+            hipEventRecord(b, st);
+            hipEventSynchronize(b);
+            float ms; hipEventElapsedTime(&ms, a, b);
+            printf("XCD mask 0x%02x: 4096 x 100 us one-per-CU workgroups in %.3f ms (%.1f rounds)\n", xcds, ms, ms / 0.1);
+        }
+    }
     // small-kernel latency under a long big kernel
     for (hipStream_t st : {full, masked}) {
         hipLaunchKernelGGL(spin, dim3(40960), dim3(256), 100 * 1024, st, 10000ll);         // ~16 ms of back-to-back workgroups

@@ -25,7 +25,7 @@ import sys
 
 
 def simulate(data, mode, W, alpha_us, beta_gbs, chunks=True, two_hop=False, split_rest=True, floor_us=25.0, launch_us=6.0, issue_us=0.0,
-             one_thread=False, final_at_end=False, first_ready=None):
+             one_thread=False, final_at_end=False, first_ready=None, owner_yield=False):
     N, P = data["N"], data["panel_tiles"]
     m = data["modes"][mode]
     f, la, rest = m["factor_us"], m["la_us"], m["rest_us"]
@@ -87,6 +87,7 @@ def simulate(data, mode, W, alpha_us, beta_gbs, chunks=True, two_hop=False, spli
             B[k][i] = F if i == o else t            # (the owner reads its own storage: ready when factored)
 
     factor_and_broadcast(0)
+    deferred = [0.0] * W                                   # owner_yield: remainder of REST(k-1) still to run on that rank (duration)
     for k in range(nouter):
         if k + 1 < nouter:
             o = own(k + 1)
@@ -99,6 +100,13 @@ def simulate(data, mode, W, alpha_us, beta_gbs, chunks=True, two_hop=False, spli
         lo = k + 2 if k + 1 < nouter else k + 1
         tot = sum(wj[j] for j in range(lo, nouter)) or 1
         for i in range(W):
+            if owner_yield and W > 1 and k + 1 < nouter and own(k + 1) == i:
+                # option dist_owner_yield: this rank's trailing work stands back until its panel launch factor(k+1) has ended,
+                # then the deferred remainder of REST(k-1) runs, then REST(k)
+                mn[i] = max(mn[i], p[i]) + deferred[i]
+                if k >= 1:
+                    rest_done[k - 1][i] = mn[i]
+                deferred[i] = 0.0
             t = max(mn[i], B[k][i], issued(k))
             mine = [j for j in range(lo, nouter) if own(j) == i]
             share = sum(wj[j] for j in mine) / tot
@@ -109,7 +117,11 @@ def simulate(data, mode, W, alpha_us, beta_gbs, chunks=True, two_hop=False, spli
                 d1 = max(rest[k] * wj[k + 2] / tot, floor_us) + launch_us
                 t += d1
                 first_done[k][i] = t
-                t += max(dur_all - d1, 0.0) + (launch_us if len(mine) > 1 else 0.0)
+                rem = max(dur_all - d1, 0.0) + (launch_us if len(mine) > 1 else 0.0)
+                if owner_yield:
+                    deferred[i] = rem                      # goes out behind factor(k + 2), next step
+                else:
+                    t += rem
                 work[i] += max(dur_all, d1)
             else:
                 t += dur_all
@@ -145,8 +157,9 @@ def main():
     # message as scatter + in-place all-gather over all links.
     df0 = lambda two_hop: ("df0_fuse1", dict(chunks=True, two_hop=two_hop))
     df2 = lambda two_hop: ("df2_fuse0", dict(chunks=True, final_at_end=True, two_hop=two_hop))
-    df3 = lambda two_hop: ("df2_fuse0", dict(chunks=True, first_ready=0.36, two_hop=two_hop))
-    variants = [("DEFAULT round 6: dataflow panels with column signals (dist_panel_df=3), two-hop from 4 ranks", lambda W: df3(W >= 4)),
+    df3 = lambda two_hop, yld=False: ("df2_fuse0", dict(chunks=True, first_ready=0.36, two_hop=two_hop, owner_yield=yld))
+    variants = [("DEFAULT round 6: dataflow panels with column signals (dist_panel_df=3); from 4 ranks two-hop + the owner's trailing work yields to its panel launch", lambda W: df3(W >= 4, W >= 4)),
+                ("the same without the owner yielding (the model lets a panel launch and a trailing update of one GPU overlap at no cost: optimistic)", lambda W: df3(W >= 4)),
                 ("fallback default (no stream-ordered wait on the device): dataflow panels at 2 ranks; per-tile-column panels + two-hop from 4 ranks", lambda W: df2(False) if W == 2 else df0(W >= 4)),
                 ("round-5 default: per-tile-column panels, plain ncclBroadcast", lambda W: df0(False)),
                 ("dataflow panels (dist_panel_df=2), plain broadcast", lambda W: df2(False)),

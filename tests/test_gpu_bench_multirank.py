@@ -49,10 +49,11 @@ def test_two_ranks_weak_headline_and_strong_series():
     # the split north_star names is also readable at the top level, next to the weak headline
     assert rec["rccl_ranks"] == 2 and rec["strong_ms_per_eval"] == st["ms_per_eval"] and rec["strong_speedup"] > 0
     # the schedule variants only a multi-GPU node can rank are timed beside the default and must agree with it
-    assert set(st["variants"]) == {"per_column_broadcast", "dist_panel_df"} and st["default_options"] == {"dist_panel_df": 3, "bcast_two_hop": 0}
+    assert set(st["variants"]) == {"per_column_broadcast", "dist_panel_df", "owner_yield_on"}
+    assert st["default_options"] == {"dist_panel_df": 3, "bcast_two_hop": 0, "dist_owner_yield": 0}
     for v in st["variants"].values():
         assert v["same_results"] and v["ms_per_eval"] > 0
-    assert st["best_variant"] in ("default", "per_column_broadcast", "dist_panel_df")
+    assert st["best_variant"] in ("default", "per_column_broadcast", "dist_panel_df", "owner_yield_on")
     assert st["variants"]["dist_panel_df"]["same_results"]          # (2 and 3 share the arithmetic: compared bit for bit)
     assert "cpu_baseline" not in rec                                # rank 0 at N = 1 only
 
@@ -81,8 +82,8 @@ def test_eight_ranks_every_schedule_variant_at_sharding_size():
     st = rec["strong"]
     assert "error" not in st and "variants_error" not in st, st
     assert st["rccl_ranks"] == 8 and st["all_ok"]
-    assert set(st["variants"]) == {"per_column_broadcast", "two_hop", "dist_panel_df", "two_hop_dist_panel_df", "column_signals"}
-    assert st["default_options"] == {"dist_panel_df": 3, "bcast_two_hop": 1}
+    assert set(st["variants"]) == {"per_column_broadcast", "two_hop", "dist_panel_df", "two_hop_dist_panel_df", "column_signals", "owner_yield_off"}
+    assert st["default_options"] == {"dist_panel_df": 3, "bcast_two_hop": 1, "dist_owner_yield": 1}
     for name, v in st["variants"].items():
         assert v["same_results"] and v["ms_per_eval"] > 0, (name, v)
     assert st["two_hop_identical_results"] and st["best_variant"] in {"default", *st["variants"]}

@@ -330,3 +330,31 @@ def test_fit_epoch_members_never_serve_an_older_fit():
     np.testing.assert_allclose(mu_b, rb[0], rtol=1e-9, atol=1e-11)     # (wrong on the second half of Xs without the epoch)
     np.testing.assert_allclose(var_b, rb[1], rtol=1e-8, atol=1e-11)
     assert np.abs(ra[0] - rb[0]).max() > 1e-4                          # the two fits do differ
+
+
+@pytest.mark.parametrize("world,panel,mode", [(2, 2, 3), (4, 1, 3), (5, 3, 0), (8, 2, 2)])
+def test_owner_yield_only_reorders_independent_updates(world, panel, mode):
+    """Option dist_owner_yield (round 6; on from 4 ranks): on the rank that factors panel k + 1 the remainder of REST(k - 1) and
+    REST(k) are queued behind the panel launch's end event instead of running beside it.  Every tile still receives its updates
+    in the same order, so the results are bit-identical with the option on and off, for every panel form."""
+    n, d = 2900, 3
+    X, y = syn.make_dataset(n, d)
+    th = syn.default_theta("se_ard", d)
+    g = _lib.Handle(X, y, "se_ard", device=[0] * world)
+    g.set_option("panel", panel); g.set_option("shard_min_n", 0); g.set_option("dist_panel_df", mode)
+    g.set_option("share_local_panels", 0)
+    out = {}
+    for yld in (0, 1, -1):
+        g.set_option("dist_owner_yield", yld)
+        out[yld] = g.loglik_parts(th)
+        assert out[yld][3] == 0
+    assert out[0] == out[1] == out[-1]
+    want = orc.log_likelihood("se_ard", th, X, y, parts=True)
+    assert close(out[1][0], want[0], n) and close(out[1][1], want[1], n) and close(out[1][2], want[2], n)
+    assert g.fit(th) == 0                                  # a sharded fit keeps the factor where the schedule left it
+    Xs = syn.make_test_points(200, d)
+    mo, so = orc.predict_internal("se_ard", th, X, y, Xs)
+    mu, var = g.predict(Xs)
+    np.testing.assert_allclose(mu, mo, rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(np.sqrt(var), so, rtol=1e-7)
+    g.close()
