@@ -42,8 +42,45 @@ def analyze(d):
     for name, ms in sorted(busy.items(), key=lambda kv: -kv[1])[:6]:
         print(f"  summed kernel time since the first panel launch: {name[:70]:70s} {ms:9.1f} ms")
 
-if __name__ == "__main__":
+if __name__ == "__main__" and sys.argv[1] != "queues":
     if sys.argv[1] == "run":
         run(int(sys.argv[2]), int(sys.argv[3]) if len(sys.argv) > 3 else 32768)
     else:
         analyze(sys.argv[2])
+
+
+def queues(d):
+    """per hardware queue (= stream of a rank): busy time inside the last evaluation, kernel mix, and for each panel launch what the
+    same rank's other queues were doing in the 50 us before it started"""
+    rows = []
+    for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            rows.append((int(row["Start_Timestamp"]), int(row["End_Timestamp"]), row["Kernel_Name"].split("(")[0].replace("void gphip::", "").split("<")[0],
+                         row.get("Queue_Id", "?")))
+    rows.sort()
+    df = [r for r in rows if r[2].startswith("chol_dataflow_kernel")]
+    half = df[len(df) // 2:]
+    t0, t1 = half[0][0], max(r[1] for r in rows)
+    per = {}
+    for s, e, name, q in rows:
+        if s >= t0 and not name.startswith("__amd_rocclr_streamOpsWait"):
+            per.setdefault(q, {}).setdefault(name, [0, 0.0])
+            per[q][name][0] += 1
+            per[q][name][1] += (e - s) / 1e6
+    print(f"window {(t1 - t0) / 1e6:.1f} ms; per queue: busy ms (launches) by kernel")
+    for q, mix in sorted(per.items(), key=lambda kv: -sum(v[1] for v in kv[1].values())):
+        tot = sum(v[1] for v in mix.values())
+        print(f"  queue {q:>4s}: {tot:7.1f} ms busy = {100 * tot / ((t1 - t0) / 1e6):3.0f} %   " + ", ".join(f"{n} {v[1]:.1f} ({v[0]})" for n, v in sorted(mix.items(), key=lambda kv: -kv[1][1])[:3]))
+    # what delayed each panel launch: the latest kernel (any queue) that ENDED within 30 us before the launch started
+    print("panel launch i: start (ms since first) | gap since previous panel launch's end | the kernel whose end released it")
+    for i, (s, e, name, q) in enumerate(half):
+        prev_end = half[i - 1][1] if i else s
+        cands = [r for r in rows if s - 30000 <= r[1] <= s and r[0] < s and not r[2].startswith("__amd")]
+        last = max(cands, key=lambda r: r[1]) if cands else None
+        if i < 24 or i % 8 == 0:
+            print(f"  {i:2d} q{q}: {(s - t0) / 1e6:7.2f} | {(s - prev_end) / 1e3:8.0f} us | " +
+                  (f"{last[2]} on q{last[3]}, ran {(last[1] - last[0]) / 1e3:.0f} us, ended {(s - last[1]) / 1e3:.0f} us before" if last else "nothing ended in the 30 us before"))
+
+
+if __name__ == "__main__" and sys.argv[1] == "queues":
+    queues(sys.argv[2])
