@@ -71,6 +71,11 @@ def queues(d):
     for q, mix in sorted(per.items(), key=lambda kv: -sum(v[1] for v in kv[1].values())):
         tot = sum(v[1] for v in mix.values())
         print(f"  queue {q:>4s}: {tot:7.1f} ms busy = {100 * tot / ((t1 - t0) / 1e6):3.0f} %   " + ", ".join(f"{n} {v[1]:.1f} ({v[0]})" for n, v in sorted(mix.items(), key=lambda kv: -kv[1][1])[:3]))
+    # the trailing GEMMs of each main-stream queue, step by step: (start ms, duration ms) of the 14 longest-running early ones
+    for q, mix in sorted(per.items()):
+        if "gemm_nt_kernel" in mix and mix["gemm_nt_kernel"][1] > 50:
+            gl = [(s, e) for s, e, name, qq in rows if qq == q and s >= t0 and name == "gemm_nt_kernel" and e - s > 1e6][:14]
+            print(f"  queue {q} GEMMs > 1 ms: " + " ".join(f"{(s - t0) / 1e6:.0f}+{(e - s) / 1e6:.1f}" for s, e in gl))
     # what delayed each panel launch: the latest kernel (any queue) that ENDED within 30 us before the launch started
     print("panel launch i: start (ms since first) | gap since previous panel launch's end | the kernel whose end released it")
     for i, (s, e, name, q) in enumerate(half):
