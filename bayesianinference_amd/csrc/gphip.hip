@@ -2023,8 +2023,14 @@ char* dist_panel_range(const gphip_ctx* h, int q) {
 // [256 r / W, 256 (r + 1) / W) -- whole shader-engine rounds, so the dispatcher's even split over engines stays balanced.
 // (Masks that empty a whole XCD are ignored by this stack: scripts/micro/cumask.hip.)  GPHIP_CU_SLICE="r/W": every context of
 // the process on that slice; GPHIP_CU_PARTITION=1: member i of a W-member one-device group on slice i (set by group_create).
+// Both are read only in a process started with GPHIP_TEST_HOOKS=1.
 static thread_local int g_slice_r = 0, g_slice_w = 0;
+static bool dev_hooks() {                   // like the fault-injection options: only in a process started with GPHIP_TEST_HOOKS=1
+    static const bool on = [] { const char* e = getenv("GPHIP_TEST_HOOKS"); return e && !strcmp(e, "1"); }();
+    return on;
+}
 static bool cu_slice(int* r, int* w) {
+    if (!dev_hooks()) return false;
     if (g_slice_w) { *r = g_slice_r; *w = g_slice_w; return true; }
     const char* e = getenv("GPHIP_CU_SLICE");
     return e && sscanf(e, "%d/%d", r, w) == 2 && (*w == 2 || *w == 4 || *w == 8) && *r >= 0 && *r < *w;

@@ -59,7 +59,7 @@ while time.time() < t_end:
             name = str(rng.choice(["panel", "dataflow", "lookahead", "thin_tiles", "fused_eval", "dataflow_fine_nt", "panel_wide",
                                    "dataflow_tail", "grad_potri", "max_slots", "trsv", "kbuild_mfma", "latency_gemm", "shard_min_n", "panel_left",
                                    "replicate_factor", "share_local_panels", "debug_fail_alloc", "supertile", "dataflow_lds_kib", "fuse_potrf", "bcast_chunks",
-                                   "dist_panel_df", "bcast_two_hop", "panel_df", "kbuild_mfma", "kbuild_mfma_bound", "custom_grad"]))
+                                   "dist_panel_df", "dist_owner_yield", "bcast_two_hop", "panel_df", "kbuild_mfma", "kbuild_mfma_bound", "custom_grad"]))
             if name == "debug_fail_alloc" and rng.random() < 0.7:
                 name = "panel"
             val = {"panel": int(rng.choice([1, 2, 3, 4, 6])), "dataflow_fine_nt": int(rng.choice([0, 96])),

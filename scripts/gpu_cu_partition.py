@@ -8,6 +8,7 @@ HBM by blit kernels on the masked streams; HBM, the L2s and the Infinity Cache a
 GPUs (a slice sees MORE bandwidth per CU than a whole chip does).
 What it cannot measure: xGMI.   python3 scripts/gpu_xcd_partition.py [N]"""
 import os, sys, time
+os.environ["GPHIP_TEST_HOOKS"] = "1"          # (the CU-partition hooks are read only with this)
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

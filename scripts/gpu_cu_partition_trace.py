@@ -3,6 +3,7 @@
    python3 scripts/gpu_cu_partition_trace.py analyze DIR          owner chain = the dataflow panel launches of the LAST evaluation:
                                                                   their durations, the gaps between them, what else ran meanwhile"""
 import csv, glob, os, sys
+os.environ["GPHIP_TEST_HOOKS"] = "1"          # (the CU-partition hooks are read only with this)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 

@@ -358,3 +358,28 @@ def test_owner_yield_only_reorders_independent_updates(world, panel, mode):
     np.testing.assert_allclose(mu, mo, rtol=1e-7, atol=1e-9)
     np.testing.assert_allclose(np.sqrt(var), so, rtol=1e-7)
     g.close()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_virtual_ranks_side_by_side_on_cu_slices(world, monkeypatch):
+    """Developer hook of scripts/gpu_cu_partition.py (read only with GPHIP_TEST_HOOKS=1, which conftest sets): the virtual ranks of
+    a one-device group get CU-masked streams on disjoint slices of the chip, so their launches really run at the same time --
+    column counters, stream-ordered waits and the owner's yield events under true concurrency.  Same results as the ranks that
+    time-slice the whole chip, bit for bit, evaluation after evaluation."""
+    n, d = 4200, 3
+    X, y = syn.make_dataset(n, d)
+    th = syn.default_theta("se_ard", d)
+    ref = _lib.Handle(X, y, "se_ard", device=[0] * world)
+    ref.set_option("shard_min_n", 0); ref.set_option("panel", 2); ref.set_option("share_local_panels", 0)
+    want = ref.loglik_parts(th)
+    ref.close()
+    monkeypatch.setenv("GPHIP_CU_PARTITION", "1")
+    g = _lib.Handle(X, y, "se_ard", device=[0] * world)
+    monkeypatch.delenv("GPHIP_CU_PARTITION")
+    g.set_option("shard_min_n", 0); g.set_option("panel", 2); g.set_option("share_local_panels", 0)
+    for yld in (1, 0, -1):
+        g.set_option("dist_owner_yield", yld)
+        for _ in range(3):
+            assert g.loglik_parts(th) == want
+    assert want[3] == 0 and close(want[0], orc.log_likelihood("se_ard", th, X, y), n)
+    g.close()
