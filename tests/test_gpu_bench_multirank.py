@@ -51,6 +51,7 @@ def test_two_ranks_weak_headline_and_strong_series():
     # the schedule variants only a multi-GPU node can rank are timed beside the default and must agree with it
     assert set(st["variants"]) == {"per_column_broadcast", "dist_panel_df", "owner_yield_on"}
     assert st["default_options"] == {"dist_panel_df": 3, "bcast_two_hop": 0, "dist_owner_yield": 0}
+    assert st["oldest_schedule"]["all_ok"] and st["oldest_schedule"]["agrees_with_default"] and st["oldest_schedule"]["ms_per_eval"] > 0
     for v in st["variants"].values():
         assert v["same_results"] and v["ms_per_eval"] > 0
     assert st["best_variant"] in ("default", "per_column_broadcast", "dist_panel_df", "owner_yield_on")
