@@ -847,6 +847,25 @@ def main() -> None:
                       "rccl_ranks": ci["world"], "comm": ci["comm"], "factor_bytes_per_rank": hs.factor_bytes(),
                       "all_ok": bool(all(v[1] == 0 and np.isfinite(v[0]) for v in sv))}
             strong["oldest_schedule"] = early[0]
+            try:
+                # what scripts/scale_model.py predicts for THIS world size and the default schedule from single-GPU step times
+                # (profiles/r06_owner_path_32768.json) -- printed so that the first multi-GPU run falsifies or
+                # confirms it in the same line
+                import importlib.util
+                here = os.path.dirname(os.path.abspath(__file__))
+                spec = importlib.util.spec_from_file_location("scale_model", os.path.join(here, "scripts", "scale_model.py"))
+                sm = importlib.util.module_from_spec(spec)
+                spec.loader.exec_module(sm)
+                with open(os.path.join(here, "profiles", "r06_owner_path_32768.json")) as f:
+                    steps_data = json.load(f)
+                if steps_data["N"] == n and world in (2, 4, 8):
+                    kw = dict(chunks=True, first_ready=0.36, two_hop=world >= 4, owner_yield=world >= 4, issue_us=24.0)
+                    strong["model_ms_per_eval"] = {f"alpha_{a:.0f}us_beta_{b:.0f}GBs": sm.simulate(steps_data, "df2_fuse0", world, a, b, **kw)[0] / 1e3
+                                                   for a, b in ((10.0, 120.0), (20.0, 60.0), (40.0, 30.0))}
+                    strong["model_note"] = ("scripts/scale_model.py on single-GPU step times of an MI355X build box; alpha = latency per "
+                                            "collective, beta = bandwidth per receiver; made before any multi-GPU run existed")
+            except Exception as exc:
+                strong["model_error"] = repr(exc)
             strong["oldest_schedule"]["agrees_with_default"] = bool(all(a[1] == b[1] and abs(a[0] - b[0]) <= 1e-10 * abs(a[0]) for a, b in zip(sv, sv0)))
             strong_failed = not strong["all_ok"]
             # The same five evaluations under every explicit schedule, which only a real multi-GPU node can rank (none is measurable

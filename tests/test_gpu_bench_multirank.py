@@ -85,6 +85,7 @@ def test_eight_ranks_every_schedule_variant_at_sharding_size():
     assert st["rccl_ranks"] == 8 and st["all_ok"]
     assert set(st["variants"]) == {"per_column_broadcast", "two_hop", "dist_panel_df", "two_hop_dist_panel_df", "column_signals", "owner_yield_off"}
     assert st["default_options"] == {"dist_panel_df": 3, "bcast_two_hop": 1, "dist_owner_yield": 1}
+    assert "model_error" not in st
     for name, v in st["variants"].items():
         assert v["same_results"] and v["ms_per_eval"] > 0, (name, v)
     assert st["two_hop_identical_results"] and st["best_variant"] in {"default", *st["variants"]}
