@@ -708,6 +708,31 @@ struct GradArgs {
     KSpec ks;
     int d0;                         // general form, more than KB_LDS_MAXD dimensions: this launch accumulates the length-scale
                                     // derivatives of dimensions [d0, d0 + 32) only (and the scalar ones when d0 == 0)
+    double* gpart;                  // [workgroups][np] per-workgroup sums (grad_finish_kernel adds them into gacc), or null: atomics on gacc
+    int np, ws_off;                 // accumulator slots per workgroup; where the [4 waves][np] staging area starts in LDS (doubles)
+};
+
+// How gradient accumulators leave a workgroup (round 6).  Every wave used to add its wave-reduced sums to gacc with atomics:
+// thousands of waves queued on a dozen addresses (N = 8192: 1 ms of a 12.5 ms gradient call) and the sums were not bit-repeatable.
+// Now every wave parks its sums in LDS, the workgroup adds the four in a fixed order and stores row `wg` of gpart; grad_finish_kernel
+// adds the rows in a fixed order.  gpart == null (more slots than the staging area takes): the atomics.
+struct GradEmit {
+    double* ws; double* row; double* gacc; int np, tid;
+    template <typename A>
+    __device__ GradEmit(const A& a, double* lds_raw, int tid_) : ws(a.gpart ? lds_raw + a.ws_off : nullptr),
+        row(a.gpart ? a.gpart + ((long)blockIdx.y * gridDim.x + blockIdx.x) * a.np : nullptr), gacc(a.gacc), np(a.np), tid(tid_) {
+        if (ws) for (int p = tid; p < 4 * np; p += 256) ws[p] = 0.0;           // (the kernel's own barrier after its LDS loads covers this)
+    }
+    __device__ void skip() const { if (row) for (int p = tid; p < np; p += 256) row[p] = 0.0; }      // a workgroup with no tile
+    __device__ void put(double v, int p) const {                                                      // all lanes of all waves
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+        if ((tid & 63) == 0) { if (ws) ws[(tid >> 6) * np + p] = v; else atomicAdd(gacc + p, v); }
+    }
+    __device__ void finish() const {
+        if (!ws) return;
+        __syncthreads();
+        for (int p = tid; p < np; p += 256) row[p] = (ws[p] + ws[np + p]) + (ws[2 * np + p] + ws[3 * np + p]);
+    }
 };
 
 #if defined(GP_CUSTOM_KERNEL) && defined(GP_CUSTOM_GRAD)
@@ -727,7 +752,8 @@ __global__ __launch_bounds__(256) void custom_grad_kernel(GradArgs<T> a, const d
     T* aj = xjs + (glb ? 0 : d * TB);
     const int tid = threadIdx.x, row = tid & 127, half = tid >> 7;
     const int ti = blockIdx.x, tj = blockIdx.y;
-    if (a.tri && tj > ti) return;
+    const GradEmit out(a, lds_raw, tid);
+    if (a.tri && tj > ti) { out.skip(); return; }
     const double wt = (a.tri && tj < ti) ? 2.0 : 1.0;
     const int t = ti * TB + row, g = a.c0 + t;
     for (int idx = tid; idx < (glb ? 0 : d * TB); idx += 256) xjs[idx] = a.xs[(long)(idx >> 7) * a.npad + tj * TB + (idx & 127)];
@@ -751,15 +777,11 @@ __global__ __launch_bounds__(256) void custom_grad_kernel(GradArgs<T> a, const d
             if (j == g) acc_dg += w;
         }
     }
-    const int lane = tid & 63;
 #pragma unroll
-    for (int m = 0; m < GP_NCP; ++m) {
-        double v = acc[m];
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
-        if (lane == 0 && m < ncp) atomicAdd(a.gacc + m, v);
-    }
-    for (int off = 32; off > 0; off >>= 1) acc_dg += __shfl_down(acc_dg, off);
-    if (lane == 0) atomicAdd(a.gacc + ncp, acc_dg);
+    for (int m = 0; m < GP_NCP; ++m)
+        if (m < ncp) out.put(acc[m], m);
+    out.put(acc_dg, ncp);
+    out.finish();
 }
 #endif
 }  // namespace gphip
@@ -3264,7 +3286,8 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(GradArgs<T> a) {
     T* aj = xjs + d * TB;
     const int tid = threadIdx.x, row = tid & 127, half = tid >> 7;
     const int ti = blockIdx.x, tj = blockIdx.y;
-    if (a.tri && tj > ti) return;
+    const GradEmit out(a, lds_raw, tid);
+    if (a.tri && tj > ti) { out.skip(); return; }
     const double wt = (a.tri && tj < ti) ? 2.0 : 1.0;
     const int t = ti * TB + row, g = a.c0 + t;
     for (int idx = tid; idx < d * TB; idx += 256) xjs[idx] = a.xs[(long)(idx >> 7) * a.npad + tj * TB + (idx & 127)];
@@ -3314,24 +3337,13 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(GradArgs<T> a) {
             if (j == g) acc_dg += w;
         }
     }
-    // wave reduction, one atomic per wave and parameter
-    const int lane = tid & 63;
+    // out of the workgroup: wave sums -> LDS -> one row of per-workgroup sums (GradEmit)
 #pragma unroll
-    for (int dd = 0; dd < DM; ++dd) {
-        if (dd < d) {
-            double v = acc[dd];
-            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
-            if (lane == 0) atomicAdd(a.gacc + dd, v);
-        }
-    }
-    for (int off = 32; off > 0; off >>= 1) {
-        acc_sf += __shfl_down(acc_sf, off);
-        acc_dg += __shfl_down(acc_dg, off);
-    }
-    if (lane == 0) {
-        atomicAdd(a.gacc + d, acc_sf);
-        atomicAdd(a.gacc + d + 1, acc_dg);
-    }
+    for (int dd = 0; dd < DM; ++dd)
+        if (dd < d) out.put(acc[dd], dd);
+    out.put(acc_sf, d);
+    out.put(acc_dg, d + 1);
+    out.finish();
 }
 
 // The same reduction for the general covariance form (KSpec): w = wt (alpha_g alpha_j - Kinv_gj) contracted with every
@@ -3360,7 +3372,8 @@ __global__ __launch_bounds__(256) void grad_reduce_general_kernel(GradArgs<T> a)
     const bool two = a.ks.op != 0;
     const int tid = threadIdx.x, row = tid & 127, half = tid >> 7;
     const int ti = blockIdx.x, tj = blockIdx.y;
-    if (a.tri && tj > ti) return;
+    const GradEmit out(a, lds_raw, tid);
+    if (a.tri && tj > ti) { out.skip(); return; }
     const double wt = (a.tri && tj < ti) ? 2.0 : 1.0;
     const int t = ti * TB + row, g = a.c0 + t;
     const int g0 = a.c0 + ti * TB;               // first row point of this tile
@@ -3430,25 +3443,36 @@ __global__ __launch_bounds__(256) void grad_reduce_general_kernel(GradArgs<T> a)
             if (j == g) acc_dg += w;
         }
     }
-    const int lane = tid & 63;
-    auto wave_add = [&](double v, double* dst) {
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
-        if (lane == 0) atomicAdd(dst, v);
-    };
 #pragma unroll
     for (int q = 0; q < 32; ++q)
         if (d0 + q < d) {
-            wave_add(acc1[q], a.gacc + d0 + q);
-            if (two) wave_add(acc2[q], a.gacc + d + 2 + d0 + q);
+            out.put(acc1[q], d0 + q);
+            if (two) out.put(acc2[q], d + 2 + d0 + q);
         }
     if (d0 == 0) {                                 // the scalar derivatives once, whatever the number of windows
-        wave_add(acc_sf1, a.gacc + d);
-        wave_add(acc_dg, a.gacc + d + 1);
-        if (two) wave_add(acc_sf2, a.gacc + 2 * d + 2);
-        wave_add(acc_a1, a.gacc + 2 * d + 3);
-        if (two) wave_add(acc_a2, a.gacc + 2 * d + 4);
-        wave_add(acc_c, a.gacc + 2 * d + 5);
+        out.put(acc_sf1, d);
+        out.put(acc_dg, d + 1);
+        if (two) out.put(acc_sf2, 2 * d + 2);
+        out.put(acc_a1, 2 * d + 3);
+        if (two) out.put(acc_a2, 2 * d + 4);
+        out.put(acc_c, 2 * d + 5);
     }
+    out.finish();
+}
+
+// adds the per-workgroup rows of a gradient reduction into gacc: block p = accumulator slot p, fixed summation order
+__global__ __launch_bounds__(256) void grad_finish_kernel(const double* __restrict__ part, long nwg, int np, double* __restrict__ gacc) {
+    __shared__ double s[256];
+    const int p = blockIdx.x, tid = threadIdx.x;
+    double v = 0.0;
+    for (long w = tid; w < nwg; w += 256) v += part[w * np + p];
+    s[tid] = v;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (tid < off) s[tid] += s[tid + off];
+        __syncthreads();
+    }
+    if (tid == 0) gacc[p] += s[0];
 }
 
 // Null kernel Function[0] (BGP:25-27, 156-159): K = diag(sn^2), so the quadratic form is

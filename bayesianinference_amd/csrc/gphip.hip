@@ -76,6 +76,7 @@ struct gphip_ctx {
     double *dCustomP = nullptr, *hCustomP = nullptr;   // [slot][ncp]
     double* dKss = nullptr; size_t kss_cap = 0;  // k(x*, x*) of the current test points, [slot][mpad]
     int panel_df = -1;                           // one-GPU look-ahead schedule, one theta, fp64: every outer panel as ONE fused dataflow launch
+    double* dGpart = nullptr; size_t gpart_bytes = 0, ngacc = 0;   // gradient reduction: per-workgroup accumulator rows (grad_rows)
     int dist_owner_yield = -1;                   // sharded schedule: the owner's trailing updates wait for its panel launch (-1 = from 4 ranks)
     int dist_panel_df = -1;                      // sharded evaluation, fp64: the owner factors its outer panel as ONE 64-tile dataflow launch
                                                  // (1), which also applies the look-ahead update (2), and hands its tile columns to the
@@ -1487,7 +1488,8 @@ int set_func_attrs(gphip_ctx* h) {
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>((kbuild_kernel<T, 0, 2>)),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * h->d * TB * sizeof(T))));
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(grad_reduce_general_kernel<T>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)((4 * h->d + 1) * TB * sizeof(T))));
+                                   hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)((4 * h->d + 1) * TB * sizeof(T) + 8 + 4 * (2 * h->d + 6) * 8)));     // (+ GradEmit's staging area)
     }
 #define GEMM_ATTR(ROLE)                                                                                   \
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<T, ROLE, 2, 2, 2>),             \
@@ -1761,17 +1763,40 @@ int queue_finalize(gphip_ctx* h) {         // sharded evaluation: the corner til
 }
 
 template <typename T, int KT>
-void launch_grad_kt(gphip_ctx* h, const GradArgs<T>& a, dim3 grid) {
+void launch_grad_kt(gphip_ctx* h, const GradArgs<T>& a, dim3 grid, size_t lds) {
 #define GR_CASE(DD)                                                                                   \
     case DD:                                                                                          \
-        hipLaunchKernelGGL((grad_reduce_kernel<T, DD, KT>), grid, dim3(256), (size_t)(DD + 1) * TB * sizeof(T), h->cs, a); \
+        hipLaunchKernelGGL((grad_reduce_kernel<T, DD, KT>), grid, dim3(256), lds, h->cs, a);          \
         break;
     switch (a.d) {
         GR_CASE(1) GR_CASE(2) GR_CASE(3) GR_CASE(4) GR_CASE(5) GR_CASE(6) GR_CASE(7) GR_CASE(8) GR_CASE(16)
         default:
-            hipLaunchKernelGGL((grad_reduce_kernel<T, 0, KT>), grid, dim3(256), (size_t)(a.d + 1) * TB * sizeof(T), h->cs, a);
+            hipLaunchKernelGGL((grad_reduce_kernel<T, 0, KT>), grid, dim3(256), lds, h->cs, a);
     }
 #undef GR_CASE
+}
+
+// where the accumulators of a gradient reduction go (GradEmit, gp_kernels.h): per-workgroup rows in dGpart + a [4][np] staging
+// area behind the kernel's own LDS -- or, when that area would be larger than 8 KiB or the rows cannot be allocated, the atomics
+// on gacc.  Returns the LDS bytes to launch with.
+template <typename T>
+size_t grad_rows(gphip_ctx* h, GradArgs<T>& a, dim3 grid, size_t lds) {
+    const size_t np = h->ngacc, nwg = (size_t)grid.x * grid.y, need = nwg * np * 8;
+    a.gpart = nullptr; a.np = (int)np; a.ws_off = (int)((lds + 7) / 8);
+    if (np == 0 || 4 * np * 8 > 8192) return lds;
+    if (need > h->gpart_bytes) {
+        (void)hipFree(h->dGpart);
+        h->dGpart = nullptr; h->gpart_bytes = 0;
+        if (hipMalloc((void**)&h->dGpart, need) != hipSuccess) { (void)hipGetLastError(); h->dGpart = nullptr; return lds; }
+        h->gpart_bytes = need;
+    }
+    a.gpart = h->dGpart;
+    return (size_t)a.ws_off * 8 + 4 * np * 8;
+}
+template <typename T>
+void grad_rows_finish(gphip_ctx* h, const GradArgs<T>& a, dim3 grid) {
+    if (a.gpart)
+        hipLaunchKernelGGL(grad_finish_kernel, dim3((unsigned)a.np), dim3(256), 0, h->cs, (const double*)a.gpart, (long)grid.x * grid.y, a.np, a.gacc);
 }
 
 template <typename T>
@@ -1779,26 +1804,34 @@ void launch_grad(gphip_ctx* h, GradArgs<T>& a, dim3 grid) {
     if (h->custom) {                               // the run-time compiled custom_grad_kernel<T> (dual-number instantiation)
         const double* cp = h->dCustomP;
         int ncp = h->ncp;
+        const size_t lds = grad_rows<T>(h, a, grid, (size_t)((a.d > KB_LDS_MAXD ? 0 : a.d) + 1) * TB * sizeof(T));
         void* params[] = {&a, &cp, &ncp};
-        const size_t lds = (size_t)((a.d > KB_LDS_MAXD ? 0 : a.d) + 1) * TB * sizeof(T);
         (void)hipModuleLaunchKernel(h->f_cgrad, grid.x, grid.y, grid.z, 256, 1, 1, (unsigned)lds, h->cs, params, nullptr);
+        grad_rows_finish<T>(h, a, grid);
         return;
     }
     if (a.d > KB_LDS_MAXD) {
         // any form, more dimensions than the specialised kernels hold in LDS / registers: the general kernel reading the points
         // from global memory, one launch per window of 32 length-scale derivatives
         a.ks = h->ks; a.xs2 = (const T*)h->dXs2;
-        for (a.d0 = 0; a.d0 < a.d; a.d0 += 32)
-            hipLaunchKernelGGL(grad_reduce_general_kernel<T>, grid, dim3(256), (size_t)TB * sizeof(T), h->cs, a);
+        const size_t lds = grad_rows<T>(h, a, grid, (size_t)TB * sizeof(T));
+        for (a.d0 = 0; a.d0 < a.d; a.d0 += 32) {
+            hipLaunchKernelGGL(grad_reduce_general_kernel<T>, grid, dim3(256), lds, h->cs, a);
+            grad_rows_finish<T>(h, a, grid);
+        }
         a.d0 = 0;
         return;
     }
-    if (h->kt == 0) launch_grad_kt<T, 0>(h, a, grid);
-    else if (h->kt == 1) launch_grad_kt<T, 1>(h, a, grid);
-    else {
+    if (h->kt == 0 || h->kt == 1) {
+        const size_t lds = grad_rows<T>(h, a, grid, (size_t)(a.d + 1) * TB * sizeof(T));
+        if (h->kt == 0) launch_grad_kt<T, 0>(h, a, grid, lds);
+        else launch_grad_kt<T, 1>(h, a, grid, lds);
+    } else {
         a.ks = h->ks; a.xs2 = (const T*)h->dXs2;
-        hipLaunchKernelGGL(grad_reduce_general_kernel<T>, grid, dim3(256), (size_t)(4 * a.d + 1) * TB * sizeof(T), h->cs, a);
+        const size_t lds = grad_rows<T>(h, a, grid, (size_t)(4 * a.d + 1) * TB * sizeof(T));
+        hipLaunchKernelGGL(grad_reduce_general_kernel<T>, grid, dim3(256), lds, h->cs, a);
     }
+    grad_rows_finish<T>(h, a, grid);
 }
 
 // ---- substitutions with 1 .. TRSV_MAXR right-hand sides: one launch per triangle, L streamed once (gp_trsv.h) ----
@@ -2368,7 +2401,7 @@ int gphip_destroy(gphip_handle h) {
     if (h->cgmod) (void)hipModuleUnload(h->cgmod);
     (void)hipFree(h->dV); (void)hipFree(h->dXsT); (void)hipFree(h->dXsS); (void)hipFree(h->dMean);
     (void)hipFree(h->dVar); (void)hipFree(h->dAlpha); (void)hipFree(h->dGacc); (void)hipFree(h->dKinv);
-    (void)hipFree(h->dTrsvX); (void)hipFree(h->dTrsvP); (void)hipFree(h->dRows); (void)hipFree(h->dColSig);
+    (void)hipFree(h->dTrsvX); (void)hipFree(h->dTrsvP); (void)hipFree(h->dRows); (void)hipFree(h->dColSig); (void)hipFree(h->dGpart);
     (void)hipFree(h->dXsS2); (void)hipFree(h->dPwMeanT); (void)hipFree(h->dPwNugT);
     (void)hipFree(h->dNullMu); (void)hipFree(h->dNullOut); (void)hipFree(h->dPart);
     for (auto e : h->pool) (void)hipEventDestroy(e);
@@ -2489,6 +2522,7 @@ int gphip_loglik_grad(gphip_handle h, const double* theta, int p, double* out, d
     // general form: both terms' length scales, sf, alpha, c, sn; run-time compiled function: its ncp parameters, sn
     const size_t ngacc = std::max((size_t)2 * d + 6, (size_t)h->ncp + 1);
     if (!h->dGacc) HIPCHK(hipMalloc(&h->dGacc, ngacc * 8));
+    h->ngacc = ngacc;
     int64_t MC = 0;
     if (!potri) {
         // rows of K^-1 per pass: as many as keep the scratch block within ~8 GiB (each pass runs a forward and a

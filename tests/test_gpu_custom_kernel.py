@@ -289,7 +289,9 @@ def test_gradient_by_dual_numbers_matches_the_named_kernel_and_the_oracle(n, d):
         ref = _lib.Handle(X, y, "se_ard")
         l0, g0, _ = ref.loglik_grad(th)
         np.testing.assert_allclose(g, g0, rtol=1e-9, atol=1e-9 * n)
+        assert np.array_equal(ref.loglik_grad(th)[1], g0)   # (fixed summation order: windowed general reduction at d = 40)
         ref.close()
+    assert np.array_equal(h.loglik_grad(th)[1], g)          # .. and the run-time compiled dual-number reduction
     # the factor of theta stays resident, as after the named kernels' gradient
     mu, var = h.predict(syn.make_test_points(20, d))
     mo, so = orc.predict_internal(ck, th, X, y, syn.make_test_points(20, d))

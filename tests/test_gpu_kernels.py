@@ -70,6 +70,7 @@ def test_kernel_family_gradient(kernel, d, mean, theta):
         assert info == 0 and close(ll, orc.log_likelihood(kernel, th, X, y, mean), n)
         want = orc.log_likelihood_grad(kernel, th, X, y, mean)           # central differences of the oracle
         np.testing.assert_allclose(grad, want, rtol=2e-6, atol=2e-6 * np.abs(want).max())
+        assert np.array_equal(h.loglik_grad(th)[1], grad)                # (general-form reduction: fixed summation order too)
     h.close()
 
 

@@ -632,6 +632,10 @@ def test_loglik_gradient_matches_oracle(kernel, d, n, mean):
         ll, grad, info = h.loglik_grad(th)
         assert info == 0 and close(ll, orc.log_likelihood(kernel, th, X, y, mean), n)
         np.testing.assert_allclose(grad, want, rtol=1e-7, atol=1e-7 * np.abs(want).max())
+        # bit-repeatable since round 6: the accumulators leave their workgroups as rows summed in a fixed order, no atomics
+        for _ in range(3):
+            ll2, grad2, _ = h.loglik_grad(th)
+            assert ll2 == ll and np.array_equal(grad2, grad)
     mu, var = h.predict(X[:3])                            # the factor stays resident after the gradient
     mo, so = orc.predict_internal(kernel, th, X, y, X[:3], mean)
     np.testing.assert_allclose(mu, mo, rtol=1e-7, atol=1e-9)
