@@ -153,7 +153,10 @@ struct gphip_ctx {
     int latency_gemm = 1;                        // launches of <= latency_tiles tiles use the latency GEMM shape
     static constexpr int latency_tiles = 256;
     int latency_max_nt = 48;                     // ... for problems of at most this many tile columns (beyond: its 147 KB of LDS evicts trailing-SYRK workgroups)
-    int dataflow = 1, dataflow_max_nt = 96, dataflow_max_slots = 8;   // single-launch dataflow Cholesky: latency regime only
+    int dataflow = 1, dataflow_max_nt = 96;      // single-launch dataflow Cholesky: latency regime only
+    int dataflow_max_slots = -1;                 // -1 (default): fp64 batches go through ONE dataflow launch by TASK COUNT (dataflow_max_tasks);
+                                                 // n >= 1: the pre-round-6 rule -- up to n thetas (a few more of a small problem)
+    int dataflow_max_tasks = 34000;              // 64-tile tasks of all slots together up to which one dataflow launch beats the multi-kernel batch
     int dataflow_fine_nt = 96;                   // ... with 64x64 tiles up to this many 128-tiles (fp64; measured best up to N = 12288)
     int panel_left = -1;                         // in-panel updates left-looking: -1 auto (batches), 0 never, 1 always
     int fuse_option = 1;                         // allow the single-launch evaluation (option "fused_eval")
@@ -536,6 +539,7 @@ std::vector<int> panel_bounds(const gphip_ctx* h) {
     return bnd;
 }
 bool use_dataflow(const gphip_ctx* h, int nslots);
+inline int few_slots(const gphip_ctx* h) { return h->dataflow_max_slots < 0 ? 8 : h->dataflow_max_slots; }   // "a few thetas": schedule choices made for latency
 hipEvent_t sync_event(gphip_ctx* h);
 
 // queue k_scale + kbuild for nslots slots (theta already staged in dInvEll / dSlotp)
@@ -740,7 +744,7 @@ int queue_panel(gphip_ctx* h, int K0, int nin, int nslots, bool first_factored =
     // better throughput once a batch of thetas fills the chip anyway).
     // auto: batches, and the wide (>= 8-tile) early panels of a large single factorisation (N = 32768: -0.7 %, N = 49152:
     // -0.8 %; with 4-6-tile panels right-looking is 1 % faster)
-    const bool left = h->panel_left > 0 || (h->panel_left < 0 && (nslots > h->dataflow_max_slots || nin >= 8));
+    const bool left = h->panel_left > 0 || (h->panel_left < 0 && (nslots > few_slots(h) || nin >= 8));
     // "fuse_potrf": an update launch that completes diagonal tile (b, b) also factors it (GemmArgs::fuse_b) -- then there is
     // no potrf128 launch for column b.  first_factored: the caller's look-ahead update already did that for column K0.
     // One theta (or a few): the diagonal block is latency-critical.  Batches are throughput bound and the fused kernel's 272
@@ -801,11 +805,20 @@ bool use_dataflow(const gphip_ctx* h, int nslots) {
     // measured: wins 1.05-2.3x for one theta up to N = 12288, ties at 8-16 slots, loses 2x at 200 slots
     // (there the multi-kernel schedule's big launches are throughput bound, not latency bound)
     if (!h->dataflow || h->dist_world > 0 || h->Nt > h->dataflow_max_nt) return false;
-    if (nslots > h->dataflow_max_slots) {
+    // Round 6, re-measured with the round-5 kernel (scripts/gpu_batch_crossover.py, profiles/r06_batch_crossover.txt): for every
+    // N = 512 .. 12288 the two schedules cross where ALL slots together have ~34-36 thousand 64-tile tasks -- 750 thetas at
+    // N = 512, 128 at N = 1024, 16 at N = 4096, 4 at N = 8192, 2 at N = 12288.  The old rule (<= 8 thetas at any size, a few
+    // more of a small problem) left up to 2.6x on the table for 9-100 thetas of N <= 2048 and lost 9-16 % for 6-8 thetas at
+    // N >= 8192.
+    if (h->dataflow_max_slots < 0 && h->dtype == 64 && h->Nt <= h->dataflow_fine_nt) {
+        const long t64 = (long)(2 * h->Nt + 1) * (2 * h->Nt + 2) / 2 * nslots;
+        return nslots == 1 || t64 <= h->dataflow_max_tasks;
+    }
+    if (nslots > few_slots(h)) {
         // a few more thetas of a SMALL problem still win (fp64 64-tiles): measured crossover at ~2500 tile tasks
         // (N=512: 16 thetas +42 %, 32 +15 %, 64 -16 %; N=1024: 16 +34 %, 32 -9 %)
         const long t64 = (long)(2 * h->Nt + 1) * (2 * h->Nt + 2) / 2 * nslots;
-        if (h->dtype != 64 || nslots > 4 * h->dataflow_max_slots || t64 > 2500 || h->Nt > h->dataflow_fine_nt) return false;
+        if (h->dtype != 64 || nslots > 4 * few_slots(h) || t64 > 2500 || h->Nt > h->dataflow_fine_nt) return false;
     }
     if (h->dtype == 32 && h->Nt > 64) return false;        // fp32 has 128-tiles only: measured range ends at N = 8192
     const long tasks = (long)(2 * h->Nt + 1) * (2 * h->Nt + 2) / 2 * nslots;
@@ -1075,7 +1088,7 @@ int queue_factor(gphip_ctx* h, int nslots) {
         // (round-4 re-tune: just above the single-launch range a 48-column tail wins -- N=14336: 18.9 vs 19.9 ms with 64 --, from
         //  N=16384 on 64 does: 26.0 vs 26.8)
         const int tail_cols = h->dataflow_tail != 64 ? h->dataflow_tail : (pdf ? 80 : (Nt < 124 ? 48 : 64));
-        if (h->dataflow && h->dataflow_tail > 0 && nslots <= h->dataflow_max_slots && h->dist_world == 0)
+        if (h->dataflow && h->dataflow_tail > 0 && nslots <= few_slots(h) && h->dist_world == 0)
             for (int k = 1; k < nouter; ++k)
                 if (Nt - k0(k) <= tail_cols && Nt - k0(k) <= h->dataflow_max_nt) { kc = k; break; }
         for (int k = 0; k < nouter; ++k) {
@@ -3623,7 +3636,7 @@ int* option_slot(gphip_ctx* h, const char* name) {
         {"panel_left", &gphip_ctx::panel_left}, {"thin_tiles", &gphip_ctx::thin_tiles}, {"fuse_potrf", &gphip_ctx::fuse_potrf},
         {"latency_gemm", &gphip_ctx::latency_gemm}, {"latency_max_nt", &gphip_ctx::latency_max_nt},
         {"dataflow", &gphip_ctx::dataflow}, {"dataflow_max_nt", &gphip_ctx::dataflow_max_nt},
-        {"dataflow_max_slots", &gphip_ctx::dataflow_max_slots}, {"dataflow_fine_nt", &gphip_ctx::dataflow_fine_nt},
+        {"dataflow_max_slots", &gphip_ctx::dataflow_max_slots}, {"dataflow_max_tasks", &gphip_ctx::dataflow_max_tasks}, {"dataflow_fine_nt", &gphip_ctx::dataflow_fine_nt},
         {"dataflow_tail", &gphip_ctx::dataflow_tail}, {"dataflow_lds_kib", &gphip_ctx::dataflow_lds_kib},
         {"dataflow_occ3", &gphip_ctx::dataflow_occ3},
         {"fused_eval", &gphip_ctx::fuse_option}, {"panel_df", &gphip_ctx::panel_df}, {"grad_potri", &gphip_ctx::grad_potri}, {"predict_df", &gphip_ctx::predict_df},

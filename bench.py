@@ -456,6 +456,27 @@ def other_configs(local_rank: int) -> dict:
     except Exception as exc:                                    # never let an extra break the headline
         out["cfg1_cfg2_error"] = repr(exc)
     try:
+        # batches of thetas at the small sizes (the initial sweep of the reference's sampler, BS:902-916, is such a batch): all
+        # slots of a call share ONE dataflow launch while they have <= 34 000 tile tasks together (round 6, option
+        # dataflow_max_tasks; profiles/r06_batch_crossover.txt)
+        for name, n, d, kernel, B in (("cfg1_batch_400x512_d1_f64", 512, 1, "se", 400), ("batch_32x1024_d8_f64", 1024, 8, "se_ard", 32)):
+            X, y = syn.make_dataset(n, d)
+            Th = syn.theta_batch(B, kernel, d)
+            Th[:, -1] = np.maximum(Th[:, -1], 0.05)
+            h = _lib.Handle(X, y, kernel, device=local_rank)
+            h.loglik_batch(Th); h.loglik_batch(Th)
+            ts = np.empty(9)
+            for i in range(9):
+                t0 = time.perf_counter()
+                _, info = h.loglik_batch(Th)
+                ts[i] = time.perf_counter() - t0
+            med = float(np.median(ts))
+            out[name] = {"evals_per_s": B / med, "ms_per_batch_median": med * 1e3, "tflops": B * n ** 3 / 3.0 / med / 1e12,
+                         "failed": int((info != 0).sum())}
+            h.close()
+    except Exception as exc:
+        out["small_batch_error"] = repr(exc)
+    try:
         # the rows either side of the likelihood at the HEADLINE size (a3 / a7 after gphip_fit at N = 32768, d = 8): the factor is
         # 4.3 GB, so K^-1 b of one vector has 2 x 4.3 GB to stream (gp_trsv.h) and a prediction of 100 test points is one forward
         # dataflow launch over it -- medians of blocking calls

@@ -268,13 +268,16 @@ int gphip_ns_crude_weights(const double* points, const double* loglik, int64_t m
  *   "lookahead"    0/1 factor panel k+1 on a second stream under the trailing update of panel k (default 1)
  *   "latency_gemm" 0/1 4x4-wave GEMM shape for launches of <= 256 tiles of problems up to "latency_max_nt" tile columns
  *   "dataflow"     0/1 single-launch dataflow Cholesky (one workgroup per tile, flags instead of launches)
- *                  for problems of <= "dataflow_max_nt" 128-tiles (default 96, N <= 12288) and
- *                  <= "dataflow_max_slots" thetas per call (default 8), with 64x64 tiles up to
- *                  "dataflow_fine_nt" 128-tiles (default 96, fp64); larger problems hand their last
+ *                  for problems of <= "dataflow_max_nt" 128-tiles (default 96, N <= 12288), with 64x64 tiles up to
+ *                  "dataflow_fine_nt" 128-tiles (default 96, fp64).  How many thetas of a call share ONE such launch:
+ *                  "dataflow_max_slots" -1 (default) = fp64: as many as keep the launch within "dataflow_max_tasks" 64-tile
+ *                  tasks (default 34 000, the measured crossover with the multi-kernel batch at every N = 512 .. 12288: 750
+ *                  thetas at N = 512, 128 at 1024, 16 at 4096, 4 at 8192), fp32: 8; n >= 1 = at most n thetas (and up to 4 n
+ *                  of a problem with <= 2 500 tasks in all: the rule before round 6).  Larger problems hand their last
  *                  "dataflow_tail" tile columns (default 64, 0 = off) to the same kernel
  *   "panel_left"   -1 auto / 0 / 1: left-looking in-panel updates (one K = 128 s update per column instead of
- *                  K = 128 updates after every column); auto = for batches of more than "dataflow_max_slots" and
- *                  for panels of >= 8 tiles (the wide early panels of a large factorisation)
+ *                  K = 128 updates after every column); auto = for batches of more than 8 thetas ("dataflow_max_slots" if set)
+ *                  and for panels of >= 8 tiles (the wide early panels of a large factorisation)
  *   "dataflow_lds_kib" -1 auto (default) / 0 / KiB: LDS request of the 64-tile dataflow kernel; > 80 puts ONE workgroup on a
  *                  CU, which keeps the chain's latency-bound waves off SIMDs busy with another workgroup's MFMAs: auto
  *                  asks for 84 KiB while the launch has <= 2 700 tile tasks (one theta up to N ~ 4 600: -2..-7 %)

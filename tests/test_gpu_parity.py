@@ -1006,3 +1006,40 @@ def test_fit_predict_solve_on_the_lookahead_schedule_against_oracle():
         ll, g, info = h.loglik_grad(th)
         assert info == 0 and close(ll, want[0], n)
         h.close()
+
+
+@pytest.mark.parametrize("n,d,B", [(1024, 8, 24), (512, 1, 150), (2048, 3, 12), (4096, 4, 20)])
+def test_batches_share_one_dataflow_launch_by_task_count(n, d, B):
+    """Round 6: all thetas of a call go through ONE dataflow launch while they have <= dataflow_max_tasks (34 000) 64-tile tasks
+    together -- the crossover with the multi-kernel batch schedule measured at every size (profiles/r06_batch_crossover.txt);
+    before, the limit was 8 thetas.  Both schedules against the oracle and each other; which one ran is read off the per-class
+    launch profile (the multi-kernel schedule factors diagonal blocks with potrf128_kernel, the dataflow launch has none)."""
+    kernel = "se_ard" if d > 1 else "se"
+    X, y = syn.make_dataset(n, d)
+    Th = syn.theta_batch(B, kernel, d)
+    Th[:, -1] = np.maximum(Th[:, -1], 0.05)
+    h = _lib.Handle(X, y, kernel)
+    tasks = (2 * (n // 128) + 1) * (2 * (n // 128) + 2) // 2 * B
+    def run():
+        h.set_option("profile", 2); h.reset_profile()
+        ll, info = h.loglik_batch(Th)
+        pr = h.profile(); h.set_option("profile", 0)
+        return ll, info, pr["potrf"]["launches"]
+    ll, info, potrf = run()
+    assert (potrf == 0) == (tasks <= 34000)                       # the library's choice follows the task count
+    h.set_option("dataflow_max_slots", 1)                         # the pre-round-6 style cap: multi-kernel schedule for the batch
+    ll_mk, info_mk, potrf_mk = run()
+    assert potrf_mk > 0
+    h.set_option("dataflow_max_slots", -1)
+    h.set_option("dataflow_max_tasks", 10 ** 9)                   # .. and everything in one launch
+    ll_df, info_df, potrf_df = run()
+    assert potrf_df == 0
+    assert np.array_equal(info, info_mk) and np.array_equal(info, info_df) and (info == 0).all()
+    # (two schedules = two summation orders; theta_batch draws badly conditioned thetas too: the 1e-8 bar with a decade to spare)
+    np.testing.assert_allclose(ll_mk, ll_df, rtol=1e-9, atol=1e-9 * n)
+    np.testing.assert_allclose(ll, ll_df, rtol=1e-9, atol=1e-9 * n)
+    for i in (0, B // 2, B - 1):
+        assert close(ll[i], orc.log_likelihood(kernel, Th[i], X, y), n)
+    one = [h.loglik(Th[i])[0] for i in (0, B - 1)]               # a theta alone = the same theta in the batch
+    np.testing.assert_allclose([ll_df[0], ll_df[B - 1]], one, rtol=1e-12)
+    h.close()
