@@ -814,6 +814,12 @@ bool use_dataflow(const gphip_ctx* h, int nslots) {
         const long t64 = (long)(2 * h->Nt + 1) * (2 * h->Nt + 2) / 2 * nslots;
         return nslots == 1 || t64 <= h->dataflow_max_tasks;
     }
+    // fp32 runs 128-tiles: the same sweep (profiles/r06_batch_crossover_f32.txt) puts its crossover at 13-15 thousand 128-tile tasks
+    // (N <= 8192, the measured range of the fp32 single launch): 2 / 5 of the fp64 figure
+    if (h->dataflow_max_slots < 0 && h->dtype == 32 && h->Nt <= 64) {
+        const long t128 = (long)(h->Nt + 1) * (h->Nt + 2) / 2 * nslots;
+        return nslots == 1 || t128 <= (long)h->dataflow_max_tasks * 2 / 5;
+    }
     if (nslots > few_slots(h)) {
         // a few more thetas of a SMALL problem still win (fp64 64-tiles): measured crossover at ~2500 tile tasks
         // (N=512: 16 thetas +42 %, 32 +15 %, 64 -16 %; N=1024: 16 +34 %, 32 -9 %)

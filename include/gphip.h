@@ -272,7 +272,7 @@ int gphip_ns_crude_weights(const double* points, const double* loglik, int64_t m
  *                  "dataflow_fine_nt" 128-tiles (default 96, fp64).  How many thetas of a call share ONE such launch:
  *                  "dataflow_max_slots" -1 (default) = fp64: as many as keep the launch within "dataflow_max_tasks" 64-tile
  *                  tasks (default 34 000, the measured crossover with the multi-kernel batch at every N = 512 .. 12288: 750
- *                  thetas at N = 512, 128 at 1024, 16 at 4096, 4 at 8192), fp32: 8; n >= 1 = at most n thetas (and up to 4 n
+ *                  thetas at N = 512, 128 at 1024, 16 at 4096, 4 at 8192), fp32 (128-tiles): 2 / 5 of that many 128-tile tasks; n >= 1 = at most n thetas (and up to 4 n
  *                  of a problem with <= 2 500 tasks in all: the rule before round 6).  Larger problems hand their last
  *                  "dataflow_tail" tile columns (default 64, 0 = off) to the same kernel
  *   "panel_left"   -1 auto / 0 / 1: left-looking in-panel updates (one K = 128 s update per column instead of

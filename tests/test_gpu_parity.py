@@ -1008,8 +1008,8 @@ def test_fit_predict_solve_on_the_lookahead_schedule_against_oracle():
         h.close()
 
 
-@pytest.mark.parametrize("n,d,B", [(1024, 8, 24), (512, 1, 150), (2048, 3, 12), (4096, 4, 20)])
-def test_batches_share_one_dataflow_launch_by_task_count(n, d, B):
+@pytest.mark.parametrize("n,d,B,dtype", [(1024, 8, 24, 64), (512, 1, 150, 64), (2048, 3, 12, 64), (4096, 4, 20, 64), (2048, 3, 20, 32), (3072, 2, 60, 32)])
+def test_batches_share_one_dataflow_launch_by_task_count(n, d, B, dtype):
     """Round 6: all thetas of a call go through ONE dataflow launch while they have <= dataflow_max_tasks (34 000) 64-tile tasks
     together -- the crossover with the multi-kernel batch schedule measured at every size (profiles/r06_batch_crossover.txt);
     before, the limit was 8 thetas.  Both schedules against the oracle and each other; which one ran is read off the per-class
@@ -1018,8 +1018,9 @@ def test_batches_share_one_dataflow_launch_by_task_count(n, d, B):
     X, y = syn.make_dataset(n, d)
     Th = syn.theta_batch(B, kernel, d)
     Th[:, -1] = np.maximum(Th[:, -1], 0.05)
-    h = _lib.Handle(X, y, kernel)
-    tasks = (2 * (n // 128) + 1) * (2 * (n // 128) + 2) // 2 * B
+    h = _lib.Handle(X, y, kernel, dtype=dtype)
+    nt = n // 128 * (2 if dtype == 64 else 1)                     # (fp32 runs 128-tiles and crosses at 2/5 of the task count)
+    tasks = (nt + 1) * (nt + 2) // 2 * B * (1.0 if dtype == 64 else 2.5)
     def run():
         h.set_option("profile", 2); h.reset_profile()
         ll, info = h.loglik_batch(Th)
@@ -1034,6 +1035,15 @@ def test_batches_share_one_dataflow_launch_by_task_count(n, d, B):
     h.set_option("dataflow_max_tasks", 10 ** 9)                   # .. and everything in one launch
     ll_df, info_df, potrf_df = run()
     assert potrf_df == 0
+    if dtype == 32:                                               # fp32: the well-conditioned half of the draw, at the fp32 bar
+        ok = (info == 0) & (info_mk == 0) & (info_df == 0) & (Th[:, -1] >= 0.2)
+        assert ok.sum() >= B // 4
+        np.testing.assert_allclose(ll_mk[ok], ll_df[ok], rtol=2e-3, atol=2e-3 * n)
+        np.testing.assert_allclose(ll[ok], ll_df[ok], rtol=2e-3, atol=2e-3 * n)
+        i = int(np.flatnonzero(ok)[0])
+        assert abs(ll[i] - orc.log_likelihood(kernel, Th[i], X, y)) <= 2e-3 * max(abs(ll[i]), n)
+        h.close()
+        return
     assert np.array_equal(info, info_mk) and np.array_equal(info, info_df) and (info == 0).all()
     # (two schedules = two summation orders; theta_batch draws badly conditioned thetas too: the 1e-8 bar with a decade to spare)
     np.testing.assert_allclose(ll_mk, ll_df, rtol=1e-9, atol=1e-9 * n)
