@@ -1954,7 +1954,7 @@ int queue_grad_chunk(gphip_ctx* h, int64_t c0, int64_t mc, int64_t mpad) {
 // scratch: the head of dV (z, then the per-chunk partial sums), free until K^-1 is contracted into it
 template <typename T>
 int queue_alpha_from_u(gphip_ctx* h) {
-    const int npad = (int)h->Npad, chunk = 512, nch = (npad + chunk - 1) / chunk;
+    const int npad = (int)h->Npad, chunk = 128, nch = (npad + chunk - 1) / chunk;     // (128-column chunks: Nt x Nt / 2 workgroups with work)
     T* z = (T*)h->dV;
     double* part = reinterpret_cast<double*>(static_cast<char*>(h->dV) + (((size_t)npad * sizeof(T) + 255) / 256) * 256);
     hipLaunchKernelGGL(gather_rhs_row_kernel<T>, dim3((unsigned)((npad + 255) / 256)), dim3(256), 0, h->stream, (const T*)h->dA,
