@@ -12,7 +12,8 @@ X, y = syn.make_dataset(n, d)
 th = syn.default_theta("se_ard", d)
 h = _lib.Handle(X, y, "se_ard", dtype=dtype)
 Xs = syn.make_test_points(1000 if what == "predict1000" else 100, d)
-S = np.tile(th, (4, 1)) * (1 + 0.05 * np.random.default_rng(0).random((4, len(th))))
+NS = int(os.environ.get("KSO_SAMPLES", "4"))
+S = np.tile(th, (NS, 1)) * (1 + 0.05 * np.random.default_rng(0).random((NS, len(th))))
 h.fit(th)
 f = {"grad": lambda: h.loglik_grad(th), "predict100": lambda: h.predict(Xs), "predict1000": lambda: h.predict(Xs),
      "solve1": lambda: h.solve(y), "solve24": lambda: h.solve(np.tile(y[:, None], (1, 24))),
