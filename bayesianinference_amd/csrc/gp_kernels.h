@@ -2223,6 +2223,7 @@ struct DfArgs {
                                               // right-hand sides as ROWS (test-point covariances k*^T); every task turns one tile into
                                               // the same tile of U L^-T: U(rb,cb) = (U(rb,cb) - sum_{k<cb} U(rb,k) L(cb,k)^T) W_cb^T,
                                               // in place.  Tasks in column order, u_rows * nd of them; needs u_rows <= nd + 1
+    long u_bstride;                           // forward launch over several slots (gphip_predict_samples): elements between the slots' U blocks
     const T* LT; int u_back;                  // BACKWARD launch (u_rows > 0, u_back = 1): the rows of U become U L^-1 -- the second half of a solve with K.
                                               // LT = a copy of the factor whose 64x64 blocks are stored TRANSPOSED in place (tile (k, cb) holds L(k,cb)^T),
                                               // W = the transposed 64-block inverses: with them U(rb,cb) = (U(rb,cb) - sum_{k>cb} U(rb,k) L(k,cb)) W_cb is
@@ -2692,8 +2693,8 @@ __global__ __launch_bounds__(256, OCC) void chol_dataflow_kernel(DfArgs<T> g, Th
         const bool fwd = g.u_rows > 0, back = fwd && g.u_back != 0;
         const int cb = i, rb = j, kf = fwd ? 0 : rb, nsl = back ? g.nd - 1 - cb : cb - kf;      // slabs k = kf .. cb - 1 (back: nd-1 .. cb+1)
         auto kblk = [&](int b) { return back ? g.nd - 1 - b : kf + b; };                        // block column of slab b, in the order they finish
-        T* Ut = g.U + (long)cb * TBX * g.ldu + (long)rb * TBX;
-        const T* Urow = g.U + (long)rb * TBX;               // U(rb rows, column c) at Urow[r + c * ldu]
+        T* Ut = g.U + (long)slot * g.u_bstride + (long)cb * TBX * g.ldu + (long)rb * TBX;
+        const T* Urow = g.U + (long)slot * g.u_bstride + (long)rb * TBX;      // U(rb rows, column c) at Urow[r + c * ldu]
         // two-per-CU builds (76 KiB of LDS): W_cb is prefetched behind the stage area now -- the factor is final -- and the
         // tile's solve at the end takes both operands from LDS (the accumulators written out as the I image) instead of
         // storing the pre-solve tile, draining the store and loading it back: ~2 of the ~8 us of a hop on the row's chain

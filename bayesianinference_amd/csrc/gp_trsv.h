@@ -496,10 +496,10 @@ __global__ void vblock_to_rows_kernel(const T* __restrict__ V, long mpad, int mc
 // 64-block inverses the forward / backward dataflow launches substitute with (DfArgs::W, [2 Nt][64 x 64], column-major) can
 // be cut out of dW after ANY fit -- also one that came from the look-ahead schedule, which only produces 128-block inverses.
 template <typename T>
-__global__ __launch_bounds__(256) void w128_to_w64_kernel(const T* __restrict__ W128, T* __restrict__ W64) {
-    const int j = blockIdx.x, b = j >> 1, q = j & 1;       // 64-block j = half q of 128-block b
-    const T* src = W128 + (long)b * TS + (long)(q * 64) * TB + q * 64;
-    T* dst = W64 + (long)j * 4096;
+__global__ __launch_bounds__(256) void w128_to_w64_kernel(const T* __restrict__ W128, T* __restrict__ W64, long slot_stride = 0) {
+    const int j = blockIdx.x, b = j >> 1, q = j & 1;       // 64-block j = half q of 128-block b  (blockIdx.y = batch slot)
+    const T* src = W128 + (long)blockIdx.y * slot_stride + (long)b * TS + (long)(q * 64) * TB + q * 64;
+    T* dst = W64 + (long)blockIdx.y * slot_stride + (long)j * 4096;
     for (int idx = threadIdx.x; idx < 4096; idx += 256) {
         const int c = idx >> 6, r = idx & 63;
         dst[idx] = src[(long)c * TB + r];

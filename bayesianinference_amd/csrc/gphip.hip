@@ -76,6 +76,7 @@ struct gphip_ctx {
     double *dCustomP = nullptr, *hCustomP = nullptr;   // [slot][ncp]
     double* dKss = nullptr; size_t kss_cap = 0;  // k(x*, x*) of the current test points, [slot][mpad]
     int panel_df = -1;                           // one-GPU look-ahead schedule, one theta, fp64: every outer panel as ONE fused dataflow launch
+    void* dW64s = nullptr; size_t w64s_bytes = 0;                  // gphip_predict_samples: 64-block inverses of every slot (samples_forward_df)
     double* dGpart = nullptr; size_t gpart_bytes = 0, ngacc = 0;   // gradient reduction: per-workgroup accumulator rows (grad_rows)
     int dist_owner_yield = -1;                   // sharded schedule: the owner's trailing updates wait for its panel launch (-1 = from 4 ranks)
     int dist_panel_df = -1;                      // sharded evaluation, fp64: the owner factors its outer panel as ONE 64-tile dataflow launch
@@ -907,10 +908,12 @@ constexpr int64_t GRAD_LD_PAD = 16;
 // fwd_rows > 0: the FORWARD launch instead -- dV holds fwd_rows right-hand sides as rows (leading dimension fwd_rows), every
 // task turns one tile of them into the same tile of V L^-T (DfArgs::u_rows): the forward substitution of a prediction with
 // few test points as ONE launch whose chain is a handful of microseconds per 64 columns, not two launches per tile column.
+// nslots > 1 (forward only): the same rows against the factors of slots 0 .. nslots-1, slot s's block of right-hand sides at
+// dV + s fwd_rows Npad and its 64-block inverses at w64s + s Nt 128^2 (gphip_predict_samples).
 template <typename T, int TBX, int OCC = 2, int NST = 2>
-void launch_dataflow_inverse(gphip_ctx* h, int64_t fwd_rows = 0, bool back = false) {
+void launch_dataflow_inverse(gphip_ctx* h, int64_t fwd_rows = 0, bool back = false, int nslots = 1, const void* w64s = nullptr) {
     const int nd = (int)(h->Npad / TBX);
-    const long tasks = fwd_rows > 0 ? (long)(fwd_rows / TBX) * nd : (long)nd * (nd + 1) / 2;
+    const long tasks = (fwd_rows > 0 ? (long)(fwd_rows / TBX) * nd : (long)nd * (nd + 1) / 2) * nslots;
     if (fwd_rows == 0)
         (void)hipMemsetAsync(h->dKinv, 0, (size_t)(h->Npad + GRAD_LD_PAD) * h->Npad * sizeof(T), h->stream);      // (dV stays free for the alpha solve)
     DfArgs<T> g{};
@@ -921,9 +924,10 @@ void launch_dataflow_inverse(gphip_ctx* h, int64_t fwd_rows = 0, bool back = fal
     g.flags = h->dFlags; g.f_bstride = (long)(2 * h->Nt + 1) * (2 * h->Nt + 1);
     g.ticket = h->dTicket; g.ticket_base = h->ticket_base;
     g.abort_flag = reinterpret_cast<int*>(h->dTicket + 1);
-    g.nd = nd; g.nslots = 1; g.epoch = ++h->epoch;
+    g.nd = nd; g.nslots = nslots; g.epoch = ++h->epoch;
     g.U = (T*)h->dKinv; g.ldu = (long)(h->Npad + GRAD_LD_PAD);
-    if (fwd_rows > 0) { g.U = (T*)h->dV; g.ldu = (long)fwd_rows; g.u_rows = (int)(fwd_rows / TBX); }
+    if (fwd_rows > 0) { g.U = (T*)h->dV; g.ldu = (long)fwd_rows; g.u_rows = (int)(fwd_rows / TBX); g.u_bstride = (long)fwd_rows * h->Npad; }
+    if (w64s) g.W = (T*)w64s;
     if (back) { g.u_back = 1; g.LT = (const T*)h->dLT; g.W = (T*)h->dW64T; }        // (the caller made them for this factor: df_backward_ready)
     h->ticket_base += (unsigned long long)tasks;
     ProfScope ps(h, 2, fwd_rows > 0 ? (double)fwd_rows * h->Npad * h->Npad : ((double)h->Npad * h->Npad * h->Npad) / 3.0, 0.0);
@@ -967,6 +971,27 @@ void ensure_w64(gphip_ctx* h) {
 bool df_forward_ok(const gphip_ctx* h, int64_t mpad) {
     return h->dataflow && h->predict_df > 0 && h->dtype == 64 && h->dist_world == 0 && h->dW64 && h->w64_gen == h->ws_gen &&
            h->w64_gen == h->fit_gen && mpad <= (h->Npad <= 8192 ? 2 : 1) * (int64_t)h->predict_df && mpad / 64 <= h->Npad / 64;
+}
+
+// gphip_predict_samples: nb freshly factored slots (their 128-block inverses are in dW), mpad padded test points each.  true: the
+// 64-block inverses of all slots have been cut out of dW into dW64s and ONE forward dataflow launch may serve all slots.
+// (fp64, sizes the 64-tile kernel covers; the launch is chain bound per slot, so it pays while it is small: up to 2 048 padded
+// rows per slot and 12 000 tasks in all -- beyond that the batched GEMM substitution, whose launches are shared by all slots.
+// 8 samples x 100 points: N = 1024 0.75 -> 0.51 ms, N = 2048 1.64 -> 1.11 ms, N = 4096 6.4 -> 5.1 ms per call; 32 x 100: -12 .. -22 %.)
+bool samples_forward_df(gphip_ctx* h, int nb, int64_t mpad) {
+    if (!h->dataflow || h->predict_df <= 0 || h->dtype != 64 || h->dist_world != 0 || !h->dW || h->Nt > h->dataflow_fine_nt) return false;
+    const long nd = h->Npad / 64, tasks = (long)nb * (mpad / 64) * nd;
+    if (mpad > h->predict_df || mpad / 64 > nd || tasks > 12000) return false;      // (measured: wins up to ~8 000 tasks, loses from ~16 000)
+    const size_t need = (size_t)nb * h->Nt * TB * TB * sizeof(double);
+    if (need > h->w64s_bytes) {
+        (void)hipFree(h->dW64s);
+        h->dW64s = nullptr; h->w64s_bytes = 0;
+        if (hipMalloc(&h->dW64s, need) != hipSuccess) { (void)hipGetLastError(); h->dW64s = nullptr; return false; }
+        h->w64s_bytes = need;
+    }
+    hipLaunchKernelGGL(w128_to_w64_kernel<double>, dim3((unsigned)(2 * h->Nt), (unsigned)nb), dim3(256), 0, h->stream, (const double*)h->dW,
+                       (double*)h->dW64s, (long)h->Nt * TB * TB);
+    return true;
 }
 
 // The forward / backward / inverse launches above have no finalize kernel behind them to export the abort word (a dependency
@@ -2420,7 +2445,7 @@ int gphip_destroy(gphip_handle h) {
     if (h->cgmod) (void)hipModuleUnload(h->cgmod);
     (void)hipFree(h->dV); (void)hipFree(h->dXsT); (void)hipFree(h->dXsS); (void)hipFree(h->dMean);
     (void)hipFree(h->dVar); (void)hipFree(h->dAlpha); (void)hipFree(h->dGacc); (void)hipFree(h->dKinv);
-    (void)hipFree(h->dTrsvX); (void)hipFree(h->dTrsvP); (void)hipFree(h->dRows); (void)hipFree(h->dColSig); (void)hipFree(h->dGpart);
+    (void)hipFree(h->dTrsvX); (void)hipFree(h->dTrsvP); (void)hipFree(h->dRows); (void)hipFree(h->dColSig); (void)hipFree(h->dGpart); (void)hipFree(h->dW64s);
     (void)hipFree(h->dXsS2); (void)hipFree(h->dPwMeanT); (void)hipFree(h->dPwNugT);
     (void)hipFree(h->dNullMu); (void)hipFree(h->dNullOut); (void)hipFree(h->dPart);
     for (auto e : h->pool) (void)hipEventDestroy(e);
@@ -3168,7 +3193,12 @@ int gphip_predict_samples(gphip_handle h, const double* Thetas, int S, int p, co
             rc = upload_pw_test(h, s0, nb, m0, mc, mpad);
             if (rc) return rc;
             DISPATCH(h, queue_cross, h, mc, mpad, nb);
-            DISPATCH(h, queue_forward_rows, h, mpad, nb);
+            // few test points per sample: the forward substitutions of ALL samples as ONE dataflow launch (slot = sample) instead
+            // of two launches per tile column (samples_forward_df)
+            const bool dff = samples_forward_df(h, nb, mpad);
+            if (dff) launch_dataflow_inverse<double, 64>(h, mpad, false, nb, h->dW64s);
+            else DISPATCH(h, queue_forward_rows, h, mpad, nb);
+            if (dff) { rc = queue_abort_probe(h); if (rc) return rc; }
             DISPATCH(h, queue_predict_reduce, h, mc, mpad, nb);
             hm.resize((size_t)nb * mpad);
             hv.resize((size_t)nb * mpad);
@@ -3177,6 +3207,7 @@ int gphip_predict_samples(gphip_handle h, const double* Thetas, int S, int p, co
             HIPCHK(hipStreamSynchronize(h->stream));
             HIPCHK(hipGetLastError());
             harvest(h);
+            if (dff) { rc = abort_probe_verdict(h, "dataflow forward substitution timed out (set option predict_df=0 and report)"); if (rc) return rc; }
             for (int s = 0; s < nb; ++s)
                 for (int64_t t = 0; t < mc; ++t) {
                     mean[(size_t)(s0 + s) * M + m0 + t] = hm[(size_t)s * mpad + t];

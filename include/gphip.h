@@ -297,7 +297,9 @@ int gphip_ns_crude_weights(const double* points, const double* loglik, int64_t m
  *                  over U, instead of ~5 dependent launches per tile column; 2: U always from the multi-kernel forward pass)
  *   "predict_df"   (default 2048; 0 = off): gphip_predict after a fit that was ONE dataflow launch runs the forward substitution
  *                  L^-1 k* of up to this many test points (twice that up to N = 8192) as one launch of the same kernel
- *                  (tasks = 64 x 64 tiles of the right-hand-side rows) instead of two launches per tile column
+ *                  (tasks = 64 x 64 tiles of the right-hand-side rows) instead of two launches per tile column; also after a
+ *                  look-ahead-schedule fit up to "predict_df_max_nt" tile columns, and for gphip_predict_samples (all posterior
+ *                  samples of a pass in ONE such launch, slot = sample, while the launch has <= 12 000 tasks)
  *   "thin_tiles"   0/1 (default 1): the GEMM kernel skips work whose result is known or never read -- all but the first
  *                  of the 128 bordered right-hand-side rows (zero), and the strictly-upper quadrant of diagonal tiles
  *   "max_slots"    cap on concurrently resident batch matrices

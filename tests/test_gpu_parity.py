@@ -511,6 +511,41 @@ def test_predict_samples_batched_equals_per_sample():
     h.close()
 
 
+@pytest.mark.parametrize("n,d,S,M", [(1024, 3, 12, 100), (700, 2, 5, 64), (2048, 4, 20, 300), (1300, 3, 7, 1)])
+def test_predict_samples_forward_substitutions_as_one_dataflow_launch(n, d, S, M):
+    """Round 6: with few test points per posterior sample the forward substitutions of ALL samples are one dataflow launch
+    (slot = sample; the 64-block inverses of every slot cut out of its 128-block ones) instead of two launches per tile column
+    shared by the slots.  Against the GEMM-shaped substitution (predict_df = 0), the oracle, an unusable sample in the middle,
+    and chunking over samples."""
+    X, y = syn.make_dataset(n, d)
+    Xs = syn.make_test_points(M, d)
+    thetas = syn.theta_batch(S, "se_ard", d)
+    thetas[:, -1] = np.maximum(thetas[:, -1], 0.05)
+    thetas[S // 2, -2] = np.nan                          # unusable sample: verdict only, the others unaffected
+    h = _lib.Handle(X, y, "se_ard")
+    h.set_option("profile", 2); h.reset_profile()
+    mean, var, info = h.predict_samples(thetas, Xs)
+    launches_df = h.profile()["trsm"]["launches"]
+    h.set_option("predict_df", 0); h.reset_profile()
+    mean0, var0, info0 = h.predict_samples(thetas, Xs)
+    launches_mk = h.profile()["trsm"]["launches"]
+    h.set_option("profile", 0); h.set_option("predict_df", 2048)
+    assert launches_df < launches_mk                     # (the panel solves of the multi-kernel substitution are gone)
+    assert np.array_equal(info, info0) and info[S // 2] != 0 and np.all(np.delete(info, S // 2) == 0)
+    keep = info == 0
+    np.testing.assert_allclose(mean[keep], mean0[keep], rtol=1e-8, atol=1e-9)
+    np.testing.assert_allclose(var[keep], var0[keep], rtol=1e-7, atol=1e-12)
+    for s in (0, S - 1):
+        mo, so = orc.predict_internal("se_ard", thetas[s], X, y, Xs)
+        np.testing.assert_allclose(mean[s], mo, rtol=1e-7, atol=1e-9)
+        np.testing.assert_allclose(np.sqrt(var[s]), so, rtol=1e-7)
+    assert np.array_equal(h.predict_samples(thetas, Xs)[0][keep], mean[keep])      # bit-repeatable
+    h.set_option("max_slots", 3)                         # chunks of 3 samples: the launch per chunk
+    mean2, var2, info2 = h.predict_samples(thetas, Xs)
+    np.testing.assert_allclose(mean2[keep], mean[keep], rtol=1e-8, atol=1e-10)
+    h.close()
+
+
 def test_edge_shapes_and_chunking():
     """Ragged / extreme shapes: M = 1 test point, more right-hand sides than one 2048-row chunk,
     d = 32 (largest LDS-staged dimension of the generic-d kernel), d > 32 (global-memory point tiles), batch larger than the slot cap."""
